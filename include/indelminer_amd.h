@@ -1,0 +1,233 @@
+/*
+ * indelminer_amd.h -- C ABI of the MI355X (gfx950) split-read hot path.
+ *
+ * This is the drop-in boundary: plain pointers and sizes, no C++/torch types.
+ * Each entry point names the reference interface it replaces (file:line under
+ * ratan-lab/indelMINER).  The library is libindelminer_amd.so, built from
+ * indelminer_amd/csrc/ with hipcc --offload-arch=gfx950.  There is NO CPU
+ * fallback: every compute entry point needs a GPU and returns IM_E_NOGPU /
+ * IM_E_HIP loudly without one.
+ *
+ * Two levels:
+ *   im_realign_batch / im_cluster_sr      host buffers in, host buffers out
+ *                                         (what the C host driver calls);
+ *   im_dev_*                              same kernels on caller-owned device
+ *                                         buffers and a caller-owned stream
+ *                                         (bench.py, multi-GPU plumbing).
+ */
+#ifndef INDELMINER_AMD_H
+#define INDELMINER_AMD_H
+
+#include <stdint.h>
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define IM_ABI_VERSION 1
+
+/* ---- return codes ------------------------------------------------------ */
+#define IM_OK             0
+#define IM_E_ARG         -1     /* bad argument                                      */
+#define IM_E_NOGPU       -2     /* no HIP device / wrong architecture                */
+#define IM_E_HIP         -3     /* a HIP runtime call failed (see im_last_error)     */
+#define IM_E_UNSUPPORTED -4     /* parameters outside what the kernels implement     */
+#define IM_E_ABORT       -5     /* a read hit a condition on which the reference
+                                   exits (forceassert, src/asserts.h:9-19)           */
+#define IM_E_OVERFLOW    -6     /* a fixed bound (IM_MAX_OPS / IM_MAX_EV) exceeded   */
+
+/* ---- per-read status (im_read_result.status) --------------------------- */
+#define IM_ST_NONE        0     /* attempt_pe_alignment returned NULL                */
+#define IM_ST_EVIDENCE    1     /* segment list + n_ev >= 1 evidence records valid   */
+#define IM_ST_ABORT      -1     /* the reference would have exited on this read      */
+#define IM_ST_OVERFLOW   -2
+#define IM_ST_UNSUPPORTED -3    /* e.g. read longer than IM_MAX_READ                 */
+
+/* CIGAR op codes in packed words (len<<4|op): samtools bam.h + src/readaln.h:10-11 */
+#define IM_OP_M  0
+#define IM_OP_I  1
+#define IM_OP_D  2
+#define IM_OP_S  4
+#define IM_OP_EQ 7
+#define IM_OP_X  8
+
+#define IM_MAX_READ  255        /* longest read the kernels take                     */
+#define IM_MAX_OPS   64         /* packed segment words per realigned read           */
+#define IM_MAX_EV    4          /* indel segments (= evidence) per realigned read    */
+
+#define IM_CLS_INSERTION 0      /* varianttype, src/evidence.h:13-17                 */
+#define IM_CLS_DELETION  1
+
+typedef struct im_ctx im_ctx;
+
+/* The globals the reference path reads (src/alignment.c:3-9), set from the CLI
+ * (src/indelminer.c:930-944): -k, -g, -s, -n. */
+typedef struct im_params {
+    uint32_t klength;           /* 2..15, default 6    */
+    uint32_t numgaps;           /* default 0           */
+    uint32_t maxdelsize;        /* default 1000        */
+    uint32_t ethreshold;        /* default 10          */
+} im_params;
+
+/* One evidence record = one D/I segment of a realigned read
+ * (new_evidence, src/evidence.c:4-34) plus the per-evidence reductions
+ * print_variants / print_vcf_output take over aln1/aln3 (src/variant.c:217-290,704-775). */
+typedef struct im_evidence {
+    int32_t cls;                /* IM_CLS_*                                          */
+    int32_t b1, b2;             /* segment [start,end) on the contig, 0-based        */
+    int32_t seg;                /* index of the segment in ops[]                     */
+    int32_t read_off;           /* read offset of the segment's first base           */
+    int32_t lflank, rflank;     /* M/=/X/I bases left / right of the segment         */
+    int32_t nd_print;           /* X+I+D bases in aln1+aln3 (DF=)                    */
+    int32_t nd_filter;          /* nd_print + soft-clipped bases (-f filter)         */
+} im_evidence;
+
+/* One raw band alignment (attempt_band_alignment, src/alignment.c:343-391). */
+typedef struct im_band_aln {
+    int32_t r1, r2, q1, q2;     /* 0-based half-open contig / read coordinates       */
+    int32_t low;                /* diagonal chosen by find_best_band                 */
+    int32_t votes;              /* k-mer votes on that band                          */
+    int32_t win_bytes;          /* reference window bytes scanned (roofline book-keeping) */
+    int32_t piece_bytes;        /* read piece bytes                                  */
+} im_band_aln;
+
+/* What attempt_pe_alignment (src/alignment.c:764-799) leaves behind for one read. */
+typedef struct im_read_result {
+    int32_t status;             /* IM_ST_*                                           */
+    int32_t ref_start;          /* contig coordinate of the first segment            */
+    int32_t n_ops;              /* words valid in ops[]                              */
+    int32_t n_ev;               /* records valid in ev[]                             */
+    int32_t n_band;             /* band searches done (0, 1 or 2)                    */
+    int32_t reserved[7];        /* pads the record to 512 bytes */
+    im_band_aln band[2];
+    im_evidence ev[IM_MAX_EV];  /* in segment order, left to right                   */
+    uint32_t ops[IM_MAX_OPS];   /* final segment list, update_readsegs (src/readaln.c:348-458) */
+} im_read_result;
+
+/* A batch of candidate reads, struct-of-arrays.  Replaces the per-read
+ * arguments of attempt_pe_alignment(sequences, tid, position, range, rln)
+ * (src/alignment.h:21-25, call sites src/indelminer.c:411,486). */
+typedef struct im_read_batch {
+    int32_t        n;           /* reads                                             */
+    const uint8_t* bases;       /* ASCII read bases, concatenated; already reverse-
+                                   complemented where the caller decided so
+                                   (src/indelminer.c:404-409,479-484)                */
+    const int64_t* base_off;    /* n+1 offsets into bases                            */
+    const int32_t* tid;         /* mate contig  (core.mtid)                          */
+    const int32_t* anchor;      /* mate position (core.mpos)                         */
+    const int32_t* range_max;   /* range[1] of the read group                        */
+} im_read_batch;
+
+/* ---- context ----------------------------------------------------------- */
+
+/* Open HIP device `device` (must be gfx950).  One context per GPU. */
+int  im_ctx_create(int device, im_ctx** out);
+void im_ctx_destroy(im_ctx* ctx);
+/* Last error text of this context (or of im_ctx_create when ctx == NULL). */
+const char* im_last_error(const im_ctx* ctx);
+int  im_abi_version(void);
+
+/* Make the reference contigs resident in HBM.  seqs[i] is contig i exactly as
+ * read_reference keeps it (upper-cased ASCII, src/shared.c:46-82); lens[i] its
+ * length.  Replaces the `char** sequences` argument of attempt_pe_alignment. */
+int im_set_reference(im_ctx* ctx, int32_t n_contigs,
+                     const char* const* seqs, const int64_t* lens);
+
+/* ---- seam 1: split-read realignment ------------------------------------ */
+
+/* Realign every read of the batch: per read, the exact result of
+ * attempt_pe_alignment (src/alignment.c:764-799).  out[] has batch->n entries.
+ * Returns IM_OK, or IM_E_ABORT / IM_E_OVERFLOW / IM_E_UNSUPPORTED if any read
+ * ended in the corresponding status (all results are still written). */
+int im_realign_batch(im_ctx* ctx, const im_params* params,
+                     const im_read_batch* batch, im_read_result* out);
+
+/* ---- seam 2: split-read clustering -------------------------------------- */
+
+/* The split-read part of process_evidence (src/indelminer.c:117-209 with the
+ * SR rule of add_node, src/graph.c:122-127): evidence arrives as parallel
+ * arrays in ARRIVAL order; it is sorted by (b1,b2), cut at the first
+ * b2 >= marker, and grouped by identical (cls,b1,b2).
+ *   order[n]     evidence indices, cluster after cluster, clusters ascending
+ *                in (b1,b2); members ascending in arrival (tie_desc = 0, what
+ *                glibc's stable qsort yields) or descending (tie_desc = 1, the
+ *                order test_data/indelminer.expected.vcf was made with)
+ *   cl_first/cl_count[n]  slice of order[] per cluster
+ *   used[n]      1 for every evidence that became a graph node
+ *   n_clusters   number of clusters
+ */
+int im_cluster_sr(im_ctx* ctx, int32_t n,
+                  const int32_t* cls, const int32_t* b1, const int32_t* b2,
+                  int32_t marker, int32_t tie_desc,
+                  int32_t* order, int32_t* cl_first, int32_t* cl_count,
+                  uint8_t* used, int32_t* n_clusters);
+
+/* ---- device-resident level --------------------------------------------- */
+
+/* Device buffers of one realign batch.  All pointers are device pointers owned
+ * by the caller (hipMalloc or a torch tensor's data_ptr).  bases must hold
+ * each read at a 4-byte aligned offset (base_off[i] % 4 == 0) and 8 spare
+ * bytes after the last read. */
+typedef struct im_dev_batch {
+    int32_t        n;
+    const uint8_t* bases;
+    const int64_t* base_off;    /* n   start of read i in bases, multiple of 4 */
+    const int32_t* read_len;    /* n   */
+    const int32_t* tid;
+    const int32_t* anchor;
+    const int32_t* range_max;
+    im_read_result* out;        /* n   */
+} im_dev_batch;
+
+/* Launch the realign kernel on `stream` (a hipStream_t, NULL = default stream).
+ * Asynchronous: returns after the launch. */
+int im_dev_realign(im_ctx* ctx, const im_params* params,
+                   const im_dev_batch* batch, void* stream);
+
+/* Bytes of device scratch im_dev_cluster_sr needs for n evidence records. */
+size_t im_dev_cluster_scratch_bytes(int32_t n);
+
+/* Device form of im_cluster_sr.  n_clusters is a device int32.  Asynchronous. */
+int im_dev_cluster_sr(im_ctx* ctx, int32_t n,
+                      const int32_t* cls, const int32_t* b1, const int32_t* b2,
+                      int32_t marker, int32_t tie_desc,
+                      int32_t* order, int32_t* cl_first, int32_t* cl_count,
+                      uint8_t* used, int32_t* n_clusters,
+                      void* scratch, size_t scratch_bytes, void* stream);
+
+/* Gather the evidence records of a realigned batch into dense SoA arrays
+ * (arrival order = read order, then segment order), the input format of
+ * im_dev_cluster_sr.  n_out is a device int32 (number of records written);
+ * src[] receives read_index*IM_MAX_EV + k for each record.  cap = capacity of
+ * the output arrays.  Asynchronous. */
+int im_dev_gather_evidence(im_ctx* ctx, const im_read_result* res, int32_t n,
+                           int32_t* cls, int32_t* b1, int32_t* b2, int32_t* src,
+                           int32_t cap, int32_t* n_out, void* scratch, size_t scratch_bytes,
+                           void* stream);
+size_t im_dev_gather_scratch_bytes(int32_t n);
+
+/* ---- device memory / timing plumbing for callers without a HIP binding --- */
+
+/* hipMalloc / hipFree / hipMemcpy on the context's device.  im_dev_upload and
+ * im_dev_download are synchronous. */
+int  im_dev_alloc(im_ctx* ctx, size_t bytes, void** out);
+int  im_dev_free(im_ctx* ctx, void* p);
+int  im_dev_upload(im_ctx* ctx, void* dst_dev, const void* src_host, size_t bytes);
+int  im_dev_download(im_ctx* ctx, void* dst_host, const void* src_dev, size_t bytes);
+/* The context's own stream (a hipStream_t) and a wait for it. */
+void* im_ctx_stream(im_ctx* ctx);
+int  im_stream_sync(im_ctx* ctx, void* stream);
+/* HIP-event stopwatch on a stream: create, record start / stop on the stream the
+ * kernels are launched on, read the elapsed milliseconds (synchronises on stop). */
+typedef struct im_timer im_timer;
+int  im_timer_create(im_ctx* ctx, im_timer** out);
+void im_timer_destroy(im_timer* t);
+int  im_timer_start(im_timer* t, void* stream);
+int  im_timer_stop(im_timer* t, void* stream);
+int  im_timer_elapsed_ms(im_timer* t, float* ms);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

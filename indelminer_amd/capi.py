@@ -1,0 +1,246 @@
+"""ctypes mirror of include/indelminer_amd.h.
+
+Thin plumbing for the tests and bench.py: the product is the HIP library
+(indelminer_amd/libindelminer_amd.so) and the C host driver above it.  There is
+no CPU fallback here: if the library is missing or no gfx950 device is present,
+everything raises.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+from . import build as _build
+
+MAX_OPS = 64
+MAX_EV = 4
+MAX_READ = 255
+
+IM_OK = 0
+E_ARG, E_NOGPU, E_HIP, E_UNSUPPORTED, E_ABORT, E_OVERFLOW = -1, -2, -3, -4, -5, -6
+ST_NONE, ST_EVIDENCE, ST_ABORT, ST_OVERFLOW, ST_UNSUPPORTED = 0, 1, -1, -2, -3
+
+
+class Params(C.Structure):
+    _fields_ = [("klength", C.c_uint32), ("numgaps", C.c_uint32),
+                ("maxdelsize", C.c_uint32), ("ethreshold", C.c_uint32)]
+
+
+class Evidence(C.Structure):
+    _fields_ = [("cls", C.c_int32), ("b1", C.c_int32), ("b2", C.c_int32), ("seg", C.c_int32),
+                ("read_off", C.c_int32), ("lflank", C.c_int32), ("rflank", C.c_int32),
+                ("nd_print", C.c_int32), ("nd_filter", C.c_int32)]
+
+
+class BandAln(C.Structure):
+    _fields_ = [("r1", C.c_int32), ("r2", C.c_int32), ("q1", C.c_int32), ("q2", C.c_int32),
+                ("low", C.c_int32), ("votes", C.c_int32), ("win_bytes", C.c_int32), ("piece_bytes", C.c_int32)]
+
+
+class ReadResult(C.Structure):
+    _fields_ = [("status", C.c_int32), ("ref_start", C.c_int32), ("n_ops", C.c_int32), ("n_ev", C.c_int32),
+                ("n_band", C.c_int32), ("reserved", C.c_int32 * 7),
+                ("band", BandAln * 2), ("ev", Evidence * MAX_EV), ("ops", C.c_uint32 * MAX_OPS)]
+
+
+assert C.sizeof(ReadResult) == 512
+
+# numpy view of the same record
+RESULT_DTYPE = np.dtype([
+    ("status", "<i4"), ("ref_start", "<i4"), ("n_ops", "<i4"), ("n_ev", "<i4"), ("n_band", "<i4"),
+    ("reserved", "<i4", (7,)),
+    ("band", [("r1", "<i4"), ("r2", "<i4"), ("q1", "<i4"), ("q2", "<i4"), ("low", "<i4"),
+              ("votes", "<i4"), ("win_bytes", "<i4"), ("piece_bytes", "<i4")], (2,)),
+    ("ev", [("cls", "<i4"), ("b1", "<i4"), ("b2", "<i4"), ("seg", "<i4"), ("read_off", "<i4"),
+            ("lflank", "<i4"), ("rflank", "<i4"), ("nd_print", "<i4"), ("nd_filter", "<i4")], (MAX_EV,)),
+    ("ops", "<u4", (MAX_OPS,)),
+])
+assert RESULT_DTYPE.itemsize == 512
+
+
+class ReadBatch(C.Structure):
+    _fields_ = [("n", C.c_int32), ("bases", C.c_void_p), ("base_off", C.c_void_p),
+                ("tid", C.c_void_p), ("anchor", C.c_void_p), ("range_max", C.c_void_p)]
+
+
+class DevBatch(C.Structure):
+    _fields_ = [("n", C.c_int32), ("bases", C.c_void_p), ("base_off", C.c_void_p), ("read_len", C.c_void_p),
+                ("tid", C.c_void_p), ("anchor", C.c_void_p), ("range_max", C.c_void_p), ("out", C.c_void_p)]
+
+
+class IMError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__("indelminer_amd error %d: %s" % (code, msg))
+        self.code = code
+
+
+_lib = None
+
+
+def library_path():
+    return _build.LIB
+
+
+def lib():
+    """Load the HIP library; raises if it has not been built (no fallback)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(_build.LIB):
+            raise IMError(E_NOGPU, "libindelminer_amd.so is not built; run __graft_entry__.build()")
+        L = C.CDLL(_build.LIB)
+        L.im_last_error.restype = C.c_char_p
+        L.im_last_error.argtypes = [C.c_void_p]
+        L.im_ctx_create.argtypes = [C.c_int, C.POINTER(C.c_void_p)]
+        L.im_ctx_destroy.argtypes = [C.c_void_p]
+        L.im_ctx_destroy.restype = None
+        L.im_set_reference.argtypes = [C.c_void_p, C.c_int32, C.POINTER(C.c_char_p), C.POINTER(C.c_int64)]
+        L.im_realign_batch.argtypes = [C.c_void_p, C.POINTER(Params), C.POINTER(ReadBatch), C.c_void_p]
+        L.im_cluster_sr.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32,
+                                    C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_int32)]
+        L.im_dev_realign.argtypes = [C.c_void_p, C.POINTER(Params), C.POINTER(DevBatch), C.c_void_p]
+        L.im_dev_cluster_scratch_bytes.restype = C.c_size_t
+        L.im_dev_cluster_scratch_bytes.argtypes = [C.c_int32]
+        L.im_dev_gather_scratch_bytes.restype = C.c_size_t
+        L.im_dev_gather_scratch_bytes.argtypes = [C.c_int32]
+        L.im_dev_cluster_sr.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32,
+                                        C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                        C.c_void_p, C.c_size_t, C.c_void_p]
+        L.im_dev_gather_evidence.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p,
+                                             C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
+        L.im_dev_alloc.argtypes = [C.c_void_p, C.c_size_t, C.POINTER(C.c_void_p)]
+        L.im_dev_free.argtypes = [C.c_void_p, C.c_void_p]
+        L.im_dev_upload.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]
+        L.im_dev_download.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]
+        L.im_ctx_stream.restype = C.c_void_p
+        L.im_ctx_stream.argtypes = [C.c_void_p]
+        L.im_stream_sync.argtypes = [C.c_void_p, C.c_void_p]
+        L.im_timer_create.argtypes = [C.c_void_p, C.POINTER(C.c_void_p)]
+        L.im_timer_destroy.argtypes = [C.c_void_p]
+        L.im_timer_destroy.restype = None
+        L.im_timer_start.argtypes = [C.c_void_p, C.c_void_p]
+        L.im_timer_stop.argtypes = [C.c_void_p, C.c_void_p]
+        L.im_timer_elapsed_ms.argtypes = [C.c_void_p, C.POINTER(C.c_float)]
+        _lib = L
+    return _lib
+
+
+def _ptr(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+class DevBuf:
+    """A device allocation owned through the C ABI."""
+
+    def __init__(self, ctx, nbytes):
+        self.ctx = ctx
+        self.nbytes = int(nbytes)
+        p = C.c_void_p()
+        ctx._check(lib().im_dev_alloc(ctx.h, self.nbytes, C.byref(p)))
+        self.ptr = p.value
+
+    def upload(self, arr):
+        arr = np.ascontiguousarray(arr)
+        assert arr.nbytes <= self.nbytes
+        self.ctx._check(lib().im_dev_upload(self.ctx.h, self.ptr, _ptr(arr), arr.nbytes))
+        return self
+
+    def download(self, dtype, count):
+        out = np.empty(count, dtype=dtype)
+        assert out.nbytes <= self.nbytes
+        self.ctx._check(lib().im_dev_download(self.ctx.h, _ptr(out), self.ptr, out.nbytes))
+        return out
+
+    def free(self):
+        if self.ptr:
+            lib().im_dev_free(self.ctx.h, self.ptr)
+            self.ptr = None
+
+
+class Timer:
+    def __init__(self, ctx):
+        self.ctx = ctx
+        p = C.c_void_p()
+        ctx._check(lib().im_timer_create(ctx.h, C.byref(p)))
+        self.h = p.value
+
+    def start(self, stream):
+        self.ctx._check(lib().im_timer_start(self.h, stream))
+
+    def stop(self, stream):
+        self.ctx._check(lib().im_timer_stop(self.h, stream))
+
+    def elapsed_ms(self):
+        ms = C.c_float()
+        self.ctx._check(lib().im_timer_elapsed_ms(self.h, C.byref(ms)))
+        return float(ms.value)
+
+    def close(self):
+        if self.h:
+            lib().im_timer_destroy(self.h)
+            self.h = None
+
+
+class Context:
+    """One GPU.  Mirrors im_ctx_* / im_set_reference / im_realign_batch / im_cluster_sr."""
+
+    def __init__(self, device=0):
+        L = lib()
+        h = C.c_void_p()
+        rc = L.im_ctx_create(device, C.byref(h))
+        if rc != IM_OK:
+            raise IMError(rc, L.im_last_error(None).decode())
+        self.h = h.value
+        self.stream = L.im_ctx_stream(self.h)
+        self._keep = None
+
+    def _check(self, rc, allow=()):
+        if rc != IM_OK and rc not in allow:
+            raise IMError(rc, lib().im_last_error(self.h).decode())
+        return rc
+
+    def close(self):
+        if self.h:
+            lib().im_ctx_destroy(self.h)
+            self.h = None
+
+    def set_reference(self, contigs):
+        """contigs: list of bytes (upper-cased ASCII, as read_reference keeps them)."""
+        n = len(contigs)
+        arr = (C.c_char_p * n)(*contigs)
+        lens = (C.c_int64 * n)(*[len(c) for c in contigs])
+        self._check(lib().im_set_reference(self.h, n, arr, lens))
+        self.contig_len = [len(c) for c in contigs]
+
+    def realign_batch(self, params, reads, tid, anchor, range_max, allow=()):
+        """reads: list of bytes.  Returns (rc, numpy structured array of RESULT_DTYPE)."""
+        n = len(reads)
+        bases = np.frombuffer(b"".join(reads) + b"\0" * 8, dtype=np.uint8).copy()
+        off = np.zeros(n + 1, dtype=np.int64)
+        np.cumsum([len(r) for r in reads], out=off[1:])
+        tid = np.ascontiguousarray(tid, dtype=np.int32)
+        anchor = np.ascontiguousarray(anchor, dtype=np.int32)
+        range_max = np.ascontiguousarray(range_max, dtype=np.int32)
+        out = np.zeros(n, dtype=RESULT_DTYPE)
+        b = ReadBatch(n, _ptr(bases), _ptr(off), _ptr(tid), _ptr(anchor), _ptr(range_max))
+        rc = lib().im_realign_batch(self.h, C.byref(params), C.byref(b), _ptr(out))
+        self._check(rc, allow=allow)
+        return rc, out
+
+    def cluster_sr(self, cls, b1, b2, marker=2**31 - 1, tie_desc=0):
+        n = len(cls)
+        cls = np.ascontiguousarray(cls, dtype=np.int32)
+        b1 = np.ascontiguousarray(b1, dtype=np.int32)
+        b2 = np.ascontiguousarray(b2, dtype=np.int32)
+        order = np.zeros(max(n, 1), dtype=np.int32)
+        first = np.zeros(max(n, 1), dtype=np.int32)
+        count = np.zeros(max(n, 1), dtype=np.int32)
+        used = np.zeros(max(n, 1), dtype=np.uint8)
+        ncl = C.c_int32(0)
+        self._check(lib().im_cluster_sr(self.h, n, _ptr(cls), _ptr(b1), _ptr(b2), marker, tie_desc,
+                                        _ptr(order), _ptr(first), _ptr(count), _ptr(used), C.byref(ncl)))
+        k = ncl.value
+        return order[:n], first[:k], count[:k], used[:n], k
+
+
+def params(klength=6, numgaps=0, maxdelsize=1000, ethreshold=10):
+    return Params(klength, numgaps, maxdelsize, ethreshold)

@@ -1,0 +1,399 @@
+// im_capi.hip -- the C ABI of include/indelminer_amd.h over the HIP kernels.
+// No CPU fallback anywhere: without a gfx950 device every entry point fails.
+
+#include "im_device.hpp"
+
+#include <stdarg.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <vector>
+
+struct im_ctx {
+    int device = -1;
+    int n_cu = 0;
+    hipStream_t stream = nullptr;
+    char err[512] = {0};
+    // reference
+    int32_t n_contigs = 0;
+    uint8_t* ref_ascii = nullptr;
+    uint64_t* ref_pk = nullptr;
+    int64_t* d_asc_off = nullptr;
+    int64_t* d_pk_off = nullptr;
+    int32_t* d_len = nullptr;
+    // reusable device workspace for the host-buffer entry points
+    void* ws = nullptr;
+    size_t ws_bytes = 0;
+};
+
+namespace {
+
+char g_err[512] = "";
+
+void set_err(im_ctx* ctx, const char* fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    char* dst = ctx ? ctx->err : g_err;
+    vsnprintf(dst, 512, fmt, ap);
+    va_end(ap);
+}
+
+#define HIP_TRY(ctx, expr)                                                              \
+    do {                                                                                \
+        hipError_t e_ = (expr);                                                         \
+        if (e_ != hipSuccess) {                                                         \
+            set_err(ctx, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
+            return IM_E_HIP;                                                            \
+        }                                                                               \
+    } while (0)
+
+int check_params(im_ctx* ctx, const im_params* p)
+{
+    if (!p) { set_err(ctx, "params is NULL"); return IM_E_ARG; }
+    // forceassert((klength > 1) && (klength < 16)), src/indelminer.c:1028
+    if (p->klength < 2 || p->klength > 15) { set_err(ctx, "klength %u outside 2..15", p->klength); return IM_E_ARG; }
+    if (p->maxdelsize == 0) { set_err(ctx, "maxdelsize must be > 0"); return IM_E_ARG; }
+    if (p->numgaps != 0) {
+        set_err(ctx, "numgaps=%u: the gfx950 realign kernel implements the -g 0 path only "
+                     "(banded affine DP for -g > 0 is not built yet); refusing rather than falling back", p->numgaps);
+        return IM_E_UNSUPPORTED;
+    }
+    return IM_OK;
+}
+
+int ensure_ws(im_ctx* ctx, size_t bytes)
+{
+    if (bytes <= ctx->ws_bytes) return IM_OK;
+    if (ctx->ws) { HIP_TRY(ctx, hipFree(ctx->ws)); ctx->ws = nullptr; ctx->ws_bytes = 0; }
+    bytes = (bytes + (1u << 20) - 1) / (1u << 20) * (1u << 20);
+    HIP_TRY(ctx, hipMalloc(&ctx->ws, bytes));
+    ctx->ws_bytes = bytes;
+    return IM_OK;
+}
+
+inline size_t up256(size_t x) { return (x + 255) / 256 * 256; }
+
+void free_reference(im_ctx* ctx)
+{
+    if (ctx->ref_ascii) (void)hipFree(ctx->ref_ascii);
+    if (ctx->ref_pk) (void)hipFree(ctx->ref_pk);
+    if (ctx->d_asc_off) (void)hipFree(ctx->d_asc_off);
+    if (ctx->d_pk_off) (void)hipFree(ctx->d_pk_off);
+    if (ctx->d_len) (void)hipFree(ctx->d_len);
+    ctx->ref_ascii = nullptr; ctx->ref_pk = nullptr; ctx->d_asc_off = nullptr; ctx->d_pk_off = nullptr; ctx->d_len = nullptr;
+    ctx->n_contigs = 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+int im_abi_version(void) { return IM_ABI_VERSION; }
+
+const char* im_last_error(const im_ctx* ctx) { return ctx ? ctx->err : g_err; }
+
+int im_ctx_create(int device, im_ctx** out)
+{
+    if (!out) { set_err(nullptr, "out is NULL"); return IM_E_ARG; }
+    *out = nullptr;
+    int count = 0;
+    hipError_t e = hipGetDeviceCount(&count);
+    if (e != hipSuccess || count <= 0) {
+        set_err(nullptr, "no HIP device available (%s); this library has no CPU path", e == hipSuccess ? "count = 0" : hipGetErrorString(e));
+        return IM_E_NOGPU;
+    }
+    if (device < 0 || device >= count) { set_err(nullptr, "device %d out of range (0..%d)", device, count - 1); return IM_E_ARG; }
+    hipDeviceProp_t prop;
+    e = hipGetDeviceProperties(&prop, device);
+    if (e != hipSuccess) { set_err(nullptr, "hipGetDeviceProperties: %s", hipGetErrorString(e)); return IM_E_HIP; }
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
+        set_err(nullptr, "device %d is %s; the kernels are built for gfx950 only", device, prop.gcnArchName);
+        return IM_E_NOGPU;
+    }
+    im_ctx* ctx = new im_ctx();
+    ctx->device = device;
+    ctx->n_cu = prop.multiProcessorCount;
+    e = hipSetDevice(device);
+    if (e == hipSuccess) e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
+    if (e != hipSuccess) { set_err(nullptr, "stream create: %s", hipGetErrorString(e)); delete ctx; return IM_E_HIP; }
+    *out = ctx;
+    return IM_OK;
+}
+
+void im_ctx_destroy(im_ctx* ctx)
+{
+    if (!ctx) return;
+    (void)hipSetDevice(ctx->device);
+    free_reference(ctx);
+    if (ctx->ws) (void)hipFree(ctx->ws);
+    if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
+    delete ctx;
+}
+
+int im_set_reference(im_ctx* ctx, int32_t n_contigs, const char* const* seqs, const int64_t* lens)
+{
+    if (!ctx) return IM_E_ARG;
+    if (n_contigs <= 0 || !seqs || !lens) { set_err(ctx, "bad reference arguments"); return IM_E_ARG; }
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    free_reference(ctx);
+    // layout: [256 B zero pad][contig 0][>= 64 B zero pad, next start 256-aligned][contig 1]...
+    std::vector<int64_t> asc_off(n_contigs), pk_off(n_contigs);
+    std::vector<int32_t> len32(n_contigs);
+    int64_t pos = 256;
+    for (int32_t i = 0; i < n_contigs; i++) {
+        if (lens[i] < 0 || lens[i] > 0x7fffff00LL) { set_err(ctx, "contig %d length %lld unsupported", i, (long long)lens[i]); return IM_E_ARG; }
+        asc_off[i] = pos;
+        pk_off[i] = pos / 32;
+        len32[i] = (int32_t)lens[i];
+        pos = (int64_t)up256((size_t)(pos + lens[i] + 64));
+    }
+    const int64_t total = pos + 256;                 // multiple of 256, hence of 32
+    HIP_TRY(ctx, hipMalloc((void**)&ctx->ref_ascii, (size_t)total));
+    HIP_TRY(ctx, hipMalloc((void**)&ctx->ref_pk, (size_t)(total / 32 + 4) * sizeof(uint64_t)));
+    HIP_TRY(ctx, hipMalloc((void**)&ctx->d_asc_off, sizeof(int64_t) * n_contigs));
+    HIP_TRY(ctx, hipMalloc((void**)&ctx->d_pk_off, sizeof(int64_t) * n_contigs));
+    HIP_TRY(ctx, hipMalloc((void**)&ctx->d_len, sizeof(int32_t) * n_contigs));
+    HIP_TRY(ctx, hipMemsetAsync(ctx->ref_ascii, 0, (size_t)total, ctx->stream));
+    HIP_TRY(ctx, hipMemsetAsync(ctx->ref_pk, 0, (size_t)(total / 32 + 4) * sizeof(uint64_t), ctx->stream));
+    for (int32_t i = 0; i < n_contigs; i++)
+        if (lens[i] > 0)
+            HIP_TRY(ctx, hipMemcpyAsync(ctx->ref_ascii + asc_off[i], seqs[i], (size_t)lens[i], hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->d_asc_off, asc_off.data(), sizeof(int64_t) * n_contigs, hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->d_pk_off, pk_off.data(), sizeof(int64_t) * n_contigs, hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->d_len, len32.data(), sizeof(int32_t) * n_contigs, hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(ctx, im::launch_pack_reference(ctx->ref_ascii, ctx->ref_pk, total, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    ctx->n_contigs = n_contigs;
+    return IM_OK;
+}
+
+int im_dev_realign(im_ctx* ctx, const im_params* params, const im_dev_batch* batch, void* stream)
+{
+    if (!ctx || !batch) return IM_E_ARG;
+    int rc = check_params(ctx, params);
+    if (rc) return rc;
+    if (!ctx->ref_ascii) { set_err(ctx, "im_set_reference has not been called"); return IM_E_ARG; }
+    if (batch->n < 0) { set_err(ctx, "negative batch size"); return IM_E_ARG; }
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    im::RealignArgs a;
+    a.ref.ascii = ctx->ref_ascii; a.ref.pk = ctx->ref_pk;
+    a.ref.asc_off = ctx->d_asc_off; a.ref.pk_off = ctx->d_pk_off; a.ref.len = ctx->d_len;
+    a.ref.n_contigs = ctx->n_contigs;
+    a.batch = *batch;
+    a.P = *params;
+    HIP_TRY(ctx, im::launch_realign(a, ctx->n_cu, (hipStream_t)stream));
+    return IM_OK;
+}
+
+int im_realign_batch(im_ctx* ctx, const im_params* params, const im_read_batch* batch, im_read_result* out)
+{
+    if (!ctx || !batch || !out) return IM_E_ARG;
+    int rc = check_params(ctx, params);
+    if (rc) return rc;
+    const int32_t n = batch->n;
+    if (n < 0) { set_err(ctx, "negative batch size"); return IM_E_ARG; }
+    if (n == 0) return IM_OK;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+
+    // re-pack the reads at 4-byte aligned offsets (device layout requirement)
+    std::vector<int64_t> off((size_t)n);
+    std::vector<int32_t> len((size_t)n);
+    int64_t pos = 0;
+    for (int32_t i = 0; i < n; i++) {
+        const int64_t l = batch->base_off[i + 1] - batch->base_off[i];
+        if (l < 0 || l > 0x7fffffff) { set_err(ctx, "read %d has a bad length", i); return IM_E_ARG; }
+        off[i] = pos;
+        len[i] = (int32_t)l;
+        pos += (l + 3) & ~(int64_t)3;
+    }
+    std::vector<uint8_t> packed((size_t)pos + 16, 0);
+    for (int32_t i = 0; i < n; i++)
+        memcpy(packed.data() + off[i], batch->bases + batch->base_off[i], (size_t)len[i]);
+
+    const size_t bases_bytes = up256(packed.size());
+    const size_t off_bytes = up256(sizeof(int64_t) * (size_t)n);
+    const size_t i32_bytes = up256(sizeof(int32_t) * (size_t)n);
+    const size_t res_bytes = up256(sizeof(im_read_result) * (size_t)n);
+    rc = ensure_ws(ctx, bases_bytes + off_bytes + 4 * i32_bytes + res_bytes);
+    if (rc) return rc;
+    char* w = static_cast<char*>(ctx->ws);
+    uint8_t* d_bases = (uint8_t*)w; w += bases_bytes;
+    int64_t* d_off = (int64_t*)w; w += off_bytes;
+    int32_t* d_len = (int32_t*)w; w += i32_bytes;
+    int32_t* d_tid = (int32_t*)w; w += i32_bytes;
+    int32_t* d_anchor = (int32_t*)w; w += i32_bytes;
+    int32_t* d_range = (int32_t*)w; w += i32_bytes;
+    im_read_result* d_res = (im_read_result*)w;
+
+    HIP_TRY(ctx, hipMemcpyAsync(d_bases, packed.data(), packed.size(), hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(ctx, hipMemcpyAsync(d_off, off.data(), sizeof(int64_t) * (size_t)n, hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(ctx, hipMemcpyAsync(d_len, len.data(), sizeof(int32_t) * (size_t)n, hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(ctx, hipMemcpyAsync(d_tid, batch->tid, sizeof(int32_t) * (size_t)n, hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(ctx, hipMemcpyAsync(d_anchor, batch->anchor, sizeof(int32_t) * (size_t)n, hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(ctx, hipMemcpyAsync(d_range, batch->range_max, sizeof(int32_t) * (size_t)n, hipMemcpyHostToDevice, ctx->stream));
+
+    im_dev_batch db;
+    db.n = n; db.bases = d_bases; db.base_off = d_off; db.read_len = d_len; db.tid = d_tid; db.anchor = d_anchor; db.range_max = d_range;
+    db.out = d_res;
+    rc = im_dev_realign(ctx, params, &db, ctx->stream);
+    if (rc) return rc;
+    HIP_TRY(ctx, hipMemcpyAsync(out, d_res, sizeof(im_read_result) * (size_t)n, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+
+    int worst = IM_OK;
+    for (int32_t i = 0; i < n; i++) {
+        const int st = out[i].status;
+        if (st == IM_ST_ABORT && worst == IM_OK) { worst = IM_E_ABORT; set_err(ctx, "read %d: the reference would abort on this input", i); }
+        else if (st == IM_ST_OVERFLOW && worst == IM_OK) { worst = IM_E_OVERFLOW; set_err(ctx, "read %d: segment list longer than IM_MAX_OPS", i); }
+        else if (st == IM_ST_UNSUPPORTED && worst == IM_OK) { worst = IM_E_UNSUPPORTED; set_err(ctx, "read %d: longer than IM_MAX_READ=%d", i, IM_MAX_READ); }
+    }
+    return worst;
+}
+
+size_t im_dev_cluster_scratch_bytes(int32_t n) { return im::cluster_scratch_bytes(n); }
+size_t im_dev_gather_scratch_bytes(int32_t n) { return im::gather_scratch_bytes(n); }
+
+int im_dev_cluster_sr(im_ctx* ctx, int32_t n, const int32_t* cls, const int32_t* b1, const int32_t* b2,
+                      int32_t marker, int32_t tie_desc,
+                      int32_t* order, int32_t* cl_first, int32_t* cl_count, uint8_t* used, int32_t* n_clusters,
+                      void* scratch, size_t scratch_bytes, void* stream)
+{
+    if (!ctx) return IM_E_ARG;
+    if (n < 0) { set_err(ctx, "negative evidence count"); return IM_E_ARG; }
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, im::launch_cluster_sr(n, cls, b1, b2, marker, tie_desc, order, cl_first, cl_count, used, n_clusters,
+                                       scratch, scratch_bytes, (hipStream_t)stream));
+    return IM_OK;
+}
+
+int im_dev_gather_evidence(im_ctx* ctx, const im_read_result* res, int32_t n,
+                           int32_t* cls, int32_t* b1, int32_t* b2, int32_t* src,
+                           int32_t cap, int32_t* n_out, void* scratch, size_t scratch_bytes, void* stream)
+{
+    if (!ctx) return IM_E_ARG;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, im::launch_gather_evidence(res, n, cls, b1, b2, src, cap, n_out, scratch, scratch_bytes, (hipStream_t)stream));
+    return IM_OK;
+}
+
+int im_cluster_sr(im_ctx* ctx, int32_t n, const int32_t* cls, const int32_t* b1, const int32_t* b2,
+                  int32_t marker, int32_t tie_desc,
+                  int32_t* order, int32_t* cl_first, int32_t* cl_count, uint8_t* used, int32_t* n_clusters)
+{
+    if (!ctx || !n_clusters) return IM_E_ARG;
+    if (n < 0) { set_err(ctx, "negative evidence count"); return IM_E_ARG; }
+    *n_clusters = 0;
+    if (n == 0) return IM_OK;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const size_t a32 = up256(sizeof(int32_t) * (size_t)n);
+    const size_t scratch = im::cluster_scratch_bytes(n);
+    int rc = ensure_ws(ctx, 6 * a32 + up256((size_t)n) + 256 + scratch);
+    if (rc) return rc;
+    char* w = static_cast<char*>(ctx->ws);
+    int32_t* d_cls = (int32_t*)w; w += a32;
+    int32_t* d_b1 = (int32_t*)w; w += a32;
+    int32_t* d_b2 = (int32_t*)w; w += a32;
+    int32_t* d_order = (int32_t*)w; w += a32;
+    int32_t* d_first = (int32_t*)w; w += a32;
+    int32_t* d_count = (int32_t*)w; w += a32;
+    uint8_t* d_used = (uint8_t*)w; w += up256((size_t)n);
+    int32_t* d_ncl = (int32_t*)w; w += 256;
+    void* d_scratch = w;
+    HIP_TRY(ctx, hipMemcpyAsync(d_cls, cls, sizeof(int32_t) * (size_t)n, hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(ctx, hipMemcpyAsync(d_b1, b1, sizeof(int32_t) * (size_t)n, hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(ctx, hipMemcpyAsync(d_b2, b2, sizeof(int32_t) * (size_t)n, hipMemcpyHostToDevice, ctx->stream));
+    rc = im_dev_cluster_sr(ctx, n, d_cls, d_b1, d_b2, marker, tie_desc, d_order, d_first, d_count, d_used, d_ncl,
+                           d_scratch, scratch, ctx->stream);
+    if (rc) return rc;
+    HIP_TRY(ctx, hipMemcpyAsync(n_clusters, d_ncl, sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    const int32_t ncl = *n_clusters;
+    HIP_TRY(ctx, hipMemcpyAsync(order, d_order, sizeof(int32_t) * (size_t)n, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipMemcpyAsync(used, d_used, (size_t)n, hipMemcpyDeviceToHost, ctx->stream));
+    if (ncl > 0) {
+        HIP_TRY(ctx, hipMemcpyAsync(cl_first, d_first, sizeof(int32_t) * (size_t)ncl, hipMemcpyDeviceToHost, ctx->stream));
+        HIP_TRY(ctx, hipMemcpyAsync(cl_count, d_count, sizeof(int32_t) * (size_t)ncl, hipMemcpyDeviceToHost, ctx->stream));
+    }
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return IM_OK;
+}
+
+struct im_timer { im_ctx* ctx; hipEvent_t a, b; };
+
+int im_dev_alloc(im_ctx* ctx, size_t bytes, void** out)
+{
+    if (!ctx || !out) return IM_E_ARG;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, hipMalloc(out, bytes ? bytes : 1));
+    return IM_OK;
+}
+int im_dev_free(im_ctx* ctx, void* p)
+{
+    if (!ctx) return IM_E_ARG;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, hipFree(p));
+    return IM_OK;
+}
+int im_dev_upload(im_ctx* ctx, void* dst_dev, const void* src_host, size_t bytes)
+{
+    if (!ctx) return IM_E_ARG;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, hipMemcpy(dst_dev, src_host, bytes, hipMemcpyHostToDevice));
+    return IM_OK;
+}
+int im_dev_download(im_ctx* ctx, void* dst_host, const void* src_dev, size_t bytes)
+{
+    if (!ctx) return IM_E_ARG;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, hipMemcpy(dst_host, src_dev, bytes, hipMemcpyDeviceToHost));
+    return IM_OK;
+}
+void* im_ctx_stream(im_ctx* ctx) { return ctx ? (void*)ctx->stream : nullptr; }
+int im_stream_sync(im_ctx* ctx, void* stream)
+{
+    if (!ctx) return IM_E_ARG;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, hipStreamSynchronize((hipStream_t)stream));
+    return IM_OK;
+}
+int im_timer_create(im_ctx* ctx, im_timer** out)
+{
+    if (!ctx || !out) return IM_E_ARG;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    im_timer* t = new im_timer();
+    t->ctx = ctx;
+    hipError_t e = hipEventCreate(&t->a);
+    if (e == hipSuccess) e = hipEventCreate(&t->b);
+    if (e != hipSuccess) { set_err(ctx, "hipEventCreate: %s", hipGetErrorString(e)); delete t; return IM_E_HIP; }
+    *out = t;
+    return IM_OK;
+}
+void im_timer_destroy(im_timer* t)
+{
+    if (!t) return;
+    (void)hipEventDestroy(t->a); (void)hipEventDestroy(t->b);
+    delete t;
+}
+int im_timer_start(im_timer* t, void* stream)
+{
+    if (!t) return IM_E_ARG;
+    HIP_TRY(t->ctx, hipEventRecord(t->a, (hipStream_t)stream));
+    return IM_OK;
+}
+int im_timer_stop(im_timer* t, void* stream)
+{
+    if (!t) return IM_E_ARG;
+    HIP_TRY(t->ctx, hipEventRecord(t->b, (hipStream_t)stream));
+    return IM_OK;
+}
+int im_timer_elapsed_ms(im_timer* t, float* ms)
+{
+    if (!t || !ms) return IM_E_ARG;
+    HIP_TRY(t->ctx, hipEventSynchronize(t->b));
+    HIP_TRY(t->ctx, hipEventElapsedTime(ms, t->a, t->b));
+    return IM_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,315 @@
+// im_cluster.hip -- split-read evidence clustering on gfx950.
+//
+// Replaces the split-read part of process_evidence (src/indelminer.c:117-209):
+//   slsort(allevidence, sort_evidence)      src/indelminer.c:123, src/evidence.c:50-58
+//   nodes for the sorted prefix b2 < marker src/indelminer.c:137-146
+//   SR edges: same class, b1, b2            src/graph.c:122-127
+//   components -> variants                  src/indelminer.c:159-204
+// The reference builds the graph with an O(N^2) list scan; the SR rule only
+// joins identical keys, so the same partition is a stable sort by (b1,b2)
+// followed by a run-length pass.  Evidence arrives in ARRIVAL order; the
+// reference's prepend list + glibc's stable merge sort leave the members of a
+// cluster in ascending arrival order, which is exactly what a
+// stable LSD radix sort of the arrival-ordered input gives.
+//
+// For identical (b1,b2) every record has the same class by construction
+// (insertions have b1 == b2, deletions b2 > b1), so class is checked between
+// sorted neighbours instead of being a sort key.
+//
+// Kernels: key build, 8 x (tile histogram, offset scan, stable scatter),
+// marker cut (min-reduction), run heads, head scan, cluster table, order.
+// All memory-streaming; the radix passes move 12 B per record per pass.
+
+#include "im_device.hpp"
+
+namespace im {
+namespace {
+
+constexpr int kSortThreads = 256;
+constexpr int kSortItems = 8;
+constexpr int kSortTile = kSortThreads * kSortItems;     // 2048 records per workgroup
+constexpr int kScanThreads = 1024;
+
+__device__ __forceinline__ uint64_t make_key(int32_t b1, int32_t b2)
+{
+    // order-preserving for signed values
+    return ((uint64_t)((uint32_t)b1 ^ 0x80000000u) << 32) | (uint64_t)((uint32_t)b2 ^ 0x80000000u);
+}
+__device__ __forceinline__ int32_t key_b2(uint64_t k) { return (int32_t)((uint32_t)k ^ 0x80000000u); }
+
+__global__ __launch_bounds__(256) void build_keys_kernel(int32_t n, const int32_t* __restrict__ b1, const int32_t* __restrict__ b2,
+                                                        uint64_t* __restrict__ keys, uint32_t* __restrict__ vals)
+{
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        keys[i] = make_key(b1[i], b2[i]);
+        vals[i] = (uint32_t)i;
+    }
+}
+
+// per-tile digit histogram, stored digit-major: hist[d * nblocks + tile]
+__global__ __launch_bounds__(kSortThreads) void radix_hist_kernel(const uint64_t* __restrict__ keys, int32_t n, int shift,
+                                                                 uint32_t* __restrict__ hist, int nblocks)
+{
+    __shared__ uint32_t h[256];
+    h[threadIdx.x] = 0;
+    __syncthreads();
+    const int64_t base = (int64_t)blockIdx.x * kSortTile;
+#pragma unroll
+    for (int r = 0; r < kSortItems; r++) {
+        const int64_t e = base + r * kSortThreads + threadIdx.x;
+        if (e < n) atomicAdd(&h[(uint32_t)(keys[e] >> shift) & 255u], 1u);
+    }
+    __syncthreads();
+    hist[(int64_t)threadIdx.x * nblocks + blockIdx.x] = h[threadIdx.x];
+}
+
+// exclusive scan of a u32 array by ONE workgroup (arrays here are small: 256 x tiles,
+// or one flag per evidence record).  total (optional) receives the sum.
+__global__ __launch_bounds__(kScanThreads) void scan_excl_kernel(const uint32_t* in, uint32_t* out,
+                                                                int64_t n, uint32_t* __restrict__ total)
+{
+    __shared__ uint32_t wsum[kScanThreads / 64];
+    __shared__ uint32_t carry_s;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (tid == 0) carry_s = 0;
+    __syncthreads();
+    for (int64_t base = 0; base < n; base += kScanThreads) {
+        const int64_t i = base + tid;
+        const uint32_t v = (i < n) ? in[i] : 0u;
+        uint32_t x = v;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) { uint32_t t = __shfl_up(x, o); if (lane >= o) x += t; }
+        if (lane == 63) wsum[wave] = x;
+        __syncthreads();
+        uint32_t woff = 0;
+        for (int w = 0; w < wave; w++) woff += wsum[w];
+        const uint32_t carry = carry_s;
+        if (i < n) out[i] = carry + woff + x - v;
+        __syncthreads();
+        if (tid == kScanThreads - 1) carry_s = carry + woff + x;
+        __syncthreads();
+    }
+    if (tid == 0 && total) *total = carry_s;
+}
+
+// stable scatter of one radix pass
+__global__ __launch_bounds__(kSortThreads) void radix_scatter_kernel(const uint64_t* __restrict__ kin, const uint32_t* __restrict__ vin,
+                                                                    uint64_t* __restrict__ kout, uint32_t* __restrict__ vout,
+                                                                    int32_t n, int shift, const uint32_t* __restrict__ offs, int nblocks)
+{
+    __shared__ uint32_t running[256];
+    __shared__ uint32_t wcnt[kSortThreads / 64][256];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    running[tid] = offs[(int64_t)tid * nblocks + blockIdx.x];
+    const int64_t base = (int64_t)blockIdx.x * kSortTile;
+    const uint64_t lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+    for (int r = 0; r < kSortItems; r++) {
+        const int64_t e = base + r * kSortThreads + tid;
+        const bool valid = e < n;
+        uint64_t key = 0; uint32_t val = 0;
+        if (valid) { key = kin[e]; val = vin[e]; }
+        const uint32_t d = (uint32_t)(key >> shift) & 255u;
+#pragma unroll
+        for (int w = 0; w < kSortThreads / 64; w++) wcnt[w][tid] = 0;
+        // lanes of this wave holding the same digit
+        uint64_t peers = __ballot(valid);
+#pragma unroll
+        for (int b = 0; b < 8; b++) {
+            const uint64_t m = __ballot(valid && ((d >> b) & 1u));
+            peers &= ((d >> b) & 1u) ? m : ~m;
+        }
+        const uint32_t rank = (uint32_t)__popcll(peers & lt_mask);
+        const uint32_t cnt = (uint32_t)__popcll(peers);
+        __syncthreads();
+        if (valid && rank == 0) wcnt[wave][d] = cnt;
+        __syncthreads();
+        {
+            // digit `tid`: turn the per-wave counts into per-wave output offsets
+            uint32_t run = running[tid];
+#pragma unroll
+            for (int w = 0; w < kSortThreads / 64; w++) { const uint32_t c = wcnt[w][tid]; wcnt[w][tid] = run; run += c; }
+            running[tid] = run;
+        }
+        __syncthreads();
+        if (valid) {
+            const uint32_t dst = wcnt[wave][d] + rank;
+            kout[dst] = key; vout[dst] = val;
+        }
+        __syncthreads();
+    }
+}
+
+// first sorted position whose b2 >= marker (the reference stops making nodes there,
+// src/indelminer.c:140-142); *cut starts at n
+__global__ __launch_bounds__(256) void cut_kernel(const uint64_t* __restrict__ keys, int32_t n, int32_t marker, uint32_t* __restrict__ cut)
+{
+    uint32_t best = 0xFFFFFFFFu;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+        if (key_b2(keys[i]) >= marker) { best = (uint32_t)i; break; }     // positions ascend per thread
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) best = min(best, (uint32_t)__shfl_xor((int)best, o));
+    if ((threadIdx.x & 63) == 0 && best != 0xFFFFFFFFu) atomicMin(cut, best);
+}
+
+__global__ __launch_bounds__(256) void heads_kernel(const uint64_t* __restrict__ keys, const uint32_t* __restrict__ vals,
+                                                   const int32_t* __restrict__ cls, int32_t n, const uint32_t* __restrict__ cut,
+                                                   uint32_t* __restrict__ head, uint8_t* __restrict__ used)
+{
+    const uint32_t m = min(*cut, (uint32_t)n);
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        uint32_t h = 0;
+        if (i < m) h = (i == 0) || keys[i] != keys[i - 1] || cls[vals[i]] != cls[vals[i - 1]];
+        head[i] = h;
+        used[vals[i]] = (i < m) ? 1 : 0;
+    }
+}
+
+// cl_first[c] for every head; cl_first[n_clusters] = cut as a sentinel (array has n+1 slots in scratch)
+__global__ __launch_bounds__(256) void cluster_first_kernel(const uint32_t* __restrict__ head, const uint32_t* __restrict__ cid,
+                                                           int32_t n, const uint32_t* __restrict__ cut, const uint32_t* __restrict__ ncl,
+                                                           int32_t* __restrict__ first_tmp, int32_t* __restrict__ n_clusters)
+{
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+        if (head[i]) first_tmp[cid[i]] = (int32_t)i;
+    if (blockIdx.x == 0 && threadIdx.x == 0) { first_tmp[*ncl] = (int32_t)min(*cut, (uint32_t)n); *n_clusters = (int32_t)*ncl; }
+}
+
+__global__ __launch_bounds__(256) void cluster_finish_kernel(const uint32_t* __restrict__ vals, const uint32_t* __restrict__ head,
+                                                            const uint32_t* __restrict__ cid, int32_t n,
+                                                            const uint32_t* __restrict__ cut, const int32_t* __restrict__ first_tmp,
+                                                            int32_t tie_desc,
+                                                            int32_t* __restrict__ order, int32_t* __restrict__ cl_first, int32_t* __restrict__ cl_count)
+{
+    const uint32_t m = min(*cut, (uint32_t)n);
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        if (i >= m) { order[i] = (int32_t)vals[i]; continue; }
+        // cid[] is the exclusive scan of head[], so a head's own id is cid, a member's is cid - 1
+        const uint32_t c = head[i] ? cid[i] : cid[i] - 1;
+        const int32_t f = first_tmp[c], cnt = first_tmp[c + 1] - f;
+        if (head[i]) { cl_first[c] = f; cl_count[c] = cnt; }
+        const int32_t pos = tie_desc ? (f + (cnt - 1 - ((int32_t)i - f))) : (int32_t)i;
+        order[pos] = (int32_t)vals[i];
+    }
+}
+
+// ---- evidence gather ----------------------------------------------------------
+
+__global__ __launch_bounds__(256) void count_ev_kernel(const im_read_result* __restrict__ res, int32_t n, uint32_t* __restrict__ cnt)
+{
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+        cnt[i] = (res[i].status == IM_ST_EVIDENCE) ? (uint32_t)res[i].n_ev : 0u;
+}
+
+__global__ __launch_bounds__(256) void write_ev_kernel(const im_read_result* __restrict__ res, int32_t n, const uint32_t* __restrict__ offs,
+                                                      const uint32_t* __restrict__ total, int32_t cap,
+                                                      int32_t* __restrict__ cls, int32_t* __restrict__ b1, int32_t* __restrict__ b2,
+                                                      int32_t* __restrict__ src, int32_t* __restrict__ n_out)
+{
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        if (res[i].status != IM_ST_EVIDENCE) continue;
+        const int ne = res[i].n_ev;
+        for (int k = 0; k < ne && k < IM_MAX_EV; k++) {
+            const int64_t o = (int64_t)offs[i] + k;
+            if (o >= cap) break;
+            cls[o] = res[i].ev[k].cls; b1[o] = res[i].ev[k].b1; b2[o] = res[i].ev[k].b2;
+            src[o] = (int32_t)(i * IM_MAX_EV + k);
+        }
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) *n_out = (int32_t)min(*total, (uint32_t)cap);
+}
+
+inline int grid_for(int64_t n, int threads)
+{
+    int64_t b = (n + threads - 1) / threads;
+    if (b < 1) b = 1;
+    if (b > 256 * 8) b = 256 * 8;
+    return (int)b;
+}
+
+inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
+
+struct ClusterScratch {
+    uint64_t *keysA, *keysB;
+    uint32_t *valsA, *valsB, *hist, *head, *cid, *misc;      // misc[0] = cut, misc[1] = n heads
+    int32_t* first_tmp;
+    int nblocks;
+};
+
+inline size_t carve(ClusterScratch* cs, void* base, int32_t n)
+{
+    const size_t nn = (size_t)(n > 0 ? n : 1);
+    const int nblocks = (int)((nn + kSortTile - 1) / kSortTile);
+    size_t off = 0;
+    auto take = [&](size_t bytes) { size_t o = off; off = align_up(off + bytes, 256); return o; };
+    const size_t oKA = take(nn * 8), oKB = take(nn * 8), oVA = take(nn * 4), oVB = take(nn * 4);
+    const size_t oH = take((size_t)nblocks * 256 * 4), oHead = take(nn * 4), oCid = take(nn * 4);
+    const size_t oMisc = take(64), oFirst = take((nn + 1) * 4);
+    if (cs) {
+        char* b = static_cast<char*>(base);
+        cs->keysA = (uint64_t*)(b + oKA); cs->keysB = (uint64_t*)(b + oKB);
+        cs->valsA = (uint32_t*)(b + oVA); cs->valsB = (uint32_t*)(b + oVB);
+        cs->hist = (uint32_t*)(b + oH); cs->head = (uint32_t*)(b + oHead); cs->cid = (uint32_t*)(b + oCid);
+        cs->misc = (uint32_t*)(b + oMisc); cs->first_tmp = (int32_t*)(b + oFirst);
+        cs->nblocks = nblocks;
+    }
+    return off;
+}
+
+}  // namespace
+
+size_t cluster_scratch_bytes(int32_t n) { return carve(nullptr, nullptr, n); }
+
+hipError_t launch_cluster_sr(int32_t n, const int32_t* cls, const int32_t* b1, const int32_t* b2,
+                             int32_t marker, int32_t tie_desc,
+                             int32_t* order, int32_t* cl_first, int32_t* cl_count,
+                             uint8_t* used, int32_t* n_clusters,
+                             void* scratch, size_t scratch_bytes, hipStream_t stream)
+{
+    if (n <= 0) return hipMemsetAsync(n_clusters, 0, sizeof(int32_t), stream);
+    ClusterScratch cs;
+    if (carve(&cs, scratch, n) > scratch_bytes) return hipErrorInvalidValue;
+    const int g256 = grid_for(n, 256);
+    hipLaunchKernelGGL(build_keys_kernel, dim3(g256), dim3(256), 0, stream, n, b1, b2, cs.keysA, cs.valsA);
+    uint64_t *kin = cs.keysA, *kout = cs.keysB;
+    uint32_t *vin = cs.valsA, *vout = cs.valsB;
+    const int64_t nh = (int64_t)cs.nblocks * 256;
+    for (int pass = 0; pass < 8; pass++) {
+        const int shift = pass * 8;
+        hipLaunchKernelGGL(radix_hist_kernel, dim3(cs.nblocks), dim3(kSortThreads), 0, stream, kin, n, shift, cs.hist, cs.nblocks);
+        hipLaunchKernelGGL(scan_excl_kernel, dim3(1), dim3(kScanThreads), 0, stream, cs.hist, cs.hist, nh, (uint32_t*)nullptr);
+        hipLaunchKernelGGL(radix_scatter_kernel, dim3(cs.nblocks), dim3(kSortThreads), 0, stream, kin, vin, kout, vout, n, shift, cs.hist, cs.nblocks);
+        uint64_t* tk = kin; kin = kout; kout = tk;
+        uint32_t* tv = vin; vin = vout; vout = tv;
+    }
+    // 8 passes: the sorted data is back in keysA / valsA (kin / vin)
+    hipError_t e = hipMemsetAsync(cs.misc, 0xFF, sizeof(uint32_t), stream);      // cut = "none"
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(cut_kernel, dim3(g256), dim3(256), 0, stream, kin, n, marker, cs.misc);
+    hipLaunchKernelGGL(heads_kernel, dim3(g256), dim3(256), 0, stream, kin, vin, cls, n, cs.misc, cs.head, used);
+    hipLaunchKernelGGL(scan_excl_kernel, dim3(1), dim3(kScanThreads), 0, stream, cs.head, cs.cid, (int64_t)n, cs.misc + 1);
+    hipLaunchKernelGGL(cluster_first_kernel, dim3(g256), dim3(256), 0, stream, cs.head, cs.cid, n, cs.misc, cs.misc + 1, cs.first_tmp, n_clusters);
+    hipLaunchKernelGGL(cluster_finish_kernel, dim3(g256), dim3(256), 0, stream, vin, cs.head, cs.cid, n, cs.misc, cs.first_tmp, tie_desc, order, cl_first, cl_count);
+    return hipGetLastError();
+}
+
+size_t gather_scratch_bytes(int32_t n) { return align_up((size_t)(n > 0 ? n : 1) * 4, 256) * 2 + 256; }
+
+hipError_t launch_gather_evidence(const im_read_result* res, int32_t n,
+                                  int32_t* cls, int32_t* b1, int32_t* b2, int32_t* src,
+                                  int32_t cap, int32_t* n_out, void* scratch, size_t scratch_bytes,
+                                  hipStream_t stream)
+{
+    if (n <= 0) return hipMemsetAsync(n_out, 0, sizeof(int32_t), stream);
+    if (gather_scratch_bytes(n) > scratch_bytes) return hipErrorInvalidValue;
+    const size_t stride = align_up((size_t)n * 4, 256);
+    uint32_t* cnt = (uint32_t*)scratch;
+    uint32_t* offs = (uint32_t*)((char*)scratch + stride);
+    uint32_t* total = (uint32_t*)((char*)scratch + 2 * stride);
+    const int g256 = grid_for(n, 256);
+    hipLaunchKernelGGL(count_ev_kernel, dim3(g256), dim3(256), 0, stream, res, n, cnt);
+    hipLaunchKernelGGL(scan_excl_kernel, dim3(1), dim3(kScanThreads), 0, stream, cnt, offs, (int64_t)n, total);
+    hipLaunchKernelGGL(write_ev_kernel, dim3(g256), dim3(256), 0, stream, res, n, offs, total, cap, cls, b1, b2, src, n_out);
+    return hipGetLastError();
+}
+
+}  // namespace im

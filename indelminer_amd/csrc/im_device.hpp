@@ -1,0 +1,53 @@
+// im_device.hpp -- shared declarations of the HIP side (gfx950 only).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "indelminer_amd.h"
+
+namespace im {
+
+// Reference contigs resident in HBM, two forms:
+//   ascii : the bytes as the reference keeps them (src/shared.c:46-82); each
+//           contig starts 256-byte aligned with >= 64 zero bytes before and
+//           after, so unaligned 4/16-byte reads at a window edge stay in bounds.
+//           Needed by the diagonal scan, which compares raw bytes
+//           (W[i][j] = MATCH iff i == j, src/localalign.c:61-67).
+//   pk    : 2-bit codes (base2bits, src/alignment.c:11-24: A,a=0 C,c=1 G,g=2
+//           T,t=3, anything else 0), 32 bases per 64-bit word, first base in
+//           the most significant bits.  Needed by the k-mer band vote only.
+struct RefDev {
+    const uint8_t*  ascii;
+    const uint64_t* pk;
+    const int64_t*  asc_off;    // [n_contigs] byte offset of contig start in ascii
+    const int64_t*  pk_off;     // [n_contigs] word offset of contig start in pk
+    const int32_t*  len;        // [n_contigs]
+    int32_t         n_contigs;
+};
+
+struct RealignArgs {
+    RefDev      ref;
+    im_dev_batch batch;
+    im_params   P;
+};
+
+// launchers (im_realign.hip / im_cluster.hip)
+hipError_t launch_pack_reference(const uint8_t* ascii, uint64_t* pk, int64_t n_bases_padded,
+                                 hipStream_t stream);
+hipError_t launch_realign(const RealignArgs& a, int n_cu, hipStream_t stream);
+
+size_t cluster_scratch_bytes(int32_t n);
+hipError_t launch_cluster_sr(int32_t n, const int32_t* cls, const int32_t* b1, const int32_t* b2,
+                             int32_t marker, int32_t tie_desc,
+                             int32_t* order, int32_t* cl_first, int32_t* cl_count,
+                             uint8_t* used, int32_t* n_clusters,
+                             void* scratch, size_t scratch_bytes, hipStream_t stream);
+
+size_t gather_scratch_bytes(int32_t n);
+hipError_t launch_gather_evidence(const im_read_result* res, int32_t n,
+                                  int32_t* cls, int32_t* b1, int32_t* b2, int32_t* src,
+                                  int32_t cap, int32_t* n_out, void* scratch, size_t scratch_bytes,
+                                  hipStream_t stream);
+
+}  // namespace im

@@ -1,0 +1,137 @@
+"""Parity of the HIP realign kernel (through the C ABI) with the CPU oracle and the
+reference's golden vectors.  Bit-exact: integer / index work."""
+import os
+import random
+
+import numpy as np
+import pytest
+
+from tests.support import bamlite, golden, gpucmp, oraclebind as ob
+
+pytestmark = pytest.mark.gpu
+
+
+def _run_cases(ctx, capi, P_hip, P_or, contig, cases, dump=None):
+    reads = [c["read"].encode() for c in cases]
+    n = len(cases)
+    rc, out = ctx.realign_batch(P_hip, reads, np.zeros(n, np.int32),
+                                np.array([c["anchor"] for c in cases], np.int32),
+                                np.array([c["range_max"] for c in cases], np.int32),
+                                allow=(capi.E_ABORT,))
+    bad = []
+    for i, c in enumerate(cases):
+        st, res = ob.realign(P_or, contig, len(contig), c["anchor"], c["range_max"], c["read"])
+        msg = gpucmp.hip_vs_oracle(out[i], st, res)
+        if msg:
+            bad.append((i, msg, c["anchor"], c["range_max"], c["read"]))
+    if bad and dump:
+        os.makedirs(os.path.dirname(dump), exist_ok=True)
+        with open(dump, "w") as fh:
+            for b in bad:
+                fh.write(repr(b) + "\n")
+    return out, bad
+
+
+def test_hip_matches_oracle_and_golden_on_test_data(gpu_ctx, golden_dir):
+    from indelminer_amd import capi
+    g = golden.load("realign_testdata.json")
+    _, seqs = bamlite.read_fasta(os.path.join(golden_dir, "test_data", "reference.fa"))
+    contig = seqs[0].encode()
+    gpu_ctx.set_reference([contig])
+    out, bad = _run_cases(gpu_ctx, capi, capi.params(**g["params"]), ob.params(**g["params"]), contig, g["cases"],
+                          dump="gpurun_out/mismatch_testdata.txt")
+    assert not bad, "%d of %d differ, first: %r" % (len(bad), len(g["cases"]), bad[0][:2])
+    # and straight against what the reference itself returned
+    n_ev = 0
+    for rec, c in zip(out, g["cases"]):
+        ops = [int(x) for x in rec["ops"][:int(rec["n_ops"])]] if rec["status"] == 1 else []
+        evs = [(int(e["cls"]), int(e["b1"]), int(e["b2"]), int(e["seg"])) for e in rec["ev"][:int(rec["n_ev"])]] if rec["status"] == 1 else []
+        msg = golden.golden_vs_segments(c["ref"], int(rec["status"]), int(rec["ref_start"]), ops, evs)
+        assert msg is None, (c["qname"], msg)
+        n_ev += len(evs)
+    assert n_ev == 443
+
+
+def test_hip_matches_oracle_on_synthetic_golden_groups(gpu_ctx):
+    from indelminer_amd import capi
+    groups = [g for g in golden.load("realign_synth.json") if g["params"]["numgaps"] == 0]
+    assert len(groups) >= 5
+    for gi, grp in enumerate(groups):
+        contig = grp["contig"].encode()
+        gpu_ctx.set_reference([contig])
+        cases = [c for c in grp["cases"] if len(c["read"]) <= capi.MAX_READ]
+        out, bad = _run_cases(gpu_ctx, capi, capi.params(**grp["params"]), ob.params(**grp["params"]), contig, cases,
+                              dump="gpurun_out/mismatch_synth_%d.txt" % gi)
+        assert not bad, "%r: %d of %d differ, first: %r" % (grp["params"], len(bad), len(cases), bad[0][:2])
+        for rec, c in zip(out, cases):
+            ops = [int(x) for x in rec["ops"][:int(rec["n_ops"])]] if rec["status"] == 1 else []
+            evs = [(int(e["cls"]), int(e["b1"]), int(e["b2"]), int(e["seg"])) for e in rec["ev"][:int(rec["n_ev"])]] if rec["status"] == 1 else []
+            msg = golden.golden_vs_segments(c["ref"], int(rec["status"]), int(rec["ref_start"]), ops, evs)
+            assert msg is None, (grp["params"], msg)
+
+
+def _synthetic_batch(seed, n, clen=200000, L=100, Rm=700):
+    rng = random.Random(seed)
+    contig = "".join(rng.choice("ACGT") for _ in range(clen))
+    cases = []
+    for _ in range(n):
+        anchor = rng.randint(0, clen - 1)
+        p = max(0, min(clen - L - 80, anchor + rng.randint(-Rm + 50, Rm - 150)))
+        typ = rng.random()
+        cut = rng.randint(12, L - 12)
+        if typ < 0.5:
+            d = rng.randint(1, 50)
+            read = contig[p:p + cut] + contig[p + cut + d:p + cut + d + (L - cut)]
+        elif typ < 0.9:
+            d = rng.randint(1, 30)
+            ins = "".join(rng.choice("ACGT") for _ in range(d))
+            read = (contig[p:p + cut] + ins + contig[p + cut:p + L])[:L]
+        else:
+            read = contig[p:p + L]
+        read = "".join((rng.choice("ACGT") if rng.random() < 0.005 else ch) for ch in read)
+        cases.append(dict(anchor=anchor, range_max=Rm, read=read))
+    return contig.encode(), cases
+
+
+@pytest.mark.parametrize("k", [6, 8])
+def test_hip_matches_oracle_on_seeded_batch(gpu_ctx, k):
+    """5000 seeded reads with planted 1-50 bp indels (BASELINE config-2 shape, smaller)."""
+    from indelminer_amd import capi
+    contig, cases = _synthetic_batch(100 + k, 5000)
+    gpu_ctx.set_reference([contig])
+    out, bad = _run_cases(gpu_ctx, capi, capi.params(klength=k), ob.params(klength=k), contig, cases,
+                          dump="gpurun_out/mismatch_seeded_k%d.txt" % k)
+    assert not bad, "%d of %d differ, first: %r" % (len(bad), len(cases), bad[0][:2])
+    assert int((out["status"] == 1).sum()) > 2000
+
+
+def test_edge_cases(gpu_ctx):
+    """Windows clipped at both contig ends, reads shorter than k, all-N reads, empty batch."""
+    from indelminer_amd import capi
+    rng = random.Random(7)
+    contig = "".join(rng.choice("ACGT") for _ in range(1500))
+    cb = contig.encode()
+    gpu_ctx.set_reference([cb])
+    cases = []
+    for anchor in (0, 1, 5, 700, 1400, 1499, 1500):
+        for p in (0, 3, 600, 1380, 1400):
+            cases.append(dict(anchor=anchor, range_max=705, read=contig[p:p + 40] + contig[p + 60:p + 120]))
+            cases.append(dict(anchor=anchor, range_max=50, read=contig[p:p + 100][:max(4, 100 - p % 7)]))
+    cases.append(dict(anchor=700, range_max=705, read="ACG"))
+    cases.append(dict(anchor=700, range_max=705, read="N" * 100))
+    cases.append(dict(anchor=700, range_max=705, read="A" * 100))
+    cases = [c for c in cases if len(c["read"]) > 0]
+    out, bad = _run_cases(gpu_ctx, capi, capi.params(), ob.params(), cb, cases, dump="gpurun_out/mismatch_edge.txt")
+    assert not bad, bad[0][:2]
+    rc, out = gpu_ctx.realign_batch(capi.params(), [], [], [], [])
+    assert rc == 0 and len(out) == 0
+
+
+def test_unsupported_is_loud(gpu_ctx):
+    from indelminer_amd import capi
+    gpu_ctx.set_reference([b"ACGT" * 500])
+    with pytest.raises(capi.IMError) as ei:
+        gpu_ctx.realign_batch(capi.params(numgaps=2), [b"ACGTACGTACGTACGTACGT"], [0], [100], [300])
+    assert ei.value.code == capi.E_UNSUPPORTED
+    rc, out = gpu_ctx.realign_batch(capi.params(), [b"A" * 300], [0], [100], [300], allow=(capi.E_UNSUPPORTED,))
+    assert rc == capi.E_UNSUPPORTED and out[0]["status"] == capi.ST_UNSUPPORTED

@@ -1,0 +1,46 @@
+"""Live check of the CPU oracle against the real reference compiled in place
+(oracle/_ref/libimref.so).  Only runs where that library exists (the build
+container, or a GPU box that received the prebuilt file); the committed golden
+vectors cover the same ground everywhere else."""
+import ctypes as C
+import random
+
+import pytest
+
+from tests.support import compare, oraclebind as ob, refbind
+
+pytestmark = pytest.mark.skipif(not refbind.available(), reason="oracle/_ref not built (make -C oracle ref)")
+
+
+@pytest.mark.parametrize("k,g,seed", [(6, 0, 11), (6, 1, 12), (8, 2, 13), (5, 0, 14)])
+def test_fuzz_against_reference(k, g, seed):
+    rng = random.Random(seed)
+    R = refbind.Ref()
+    maxdel = rng.choice([1000, 200])
+    eth = max(k, 10)
+    R.set_params(k, g, maxdel, eth)
+    P = ob.params(k, g, maxdel, eth)
+    contig = "".join(rng.choice("ACGT") for _ in range(6000))
+    cb = contig.encode()
+    buf = C.create_string_buffer(cb)
+    n_ev = 0
+    for _ in range(150):
+        L = rng.choice([100, 100, 76, 150])
+        anchor = rng.randint(0, len(contig) - 1)
+        p = max(0, min(len(contig) - L - 60, anchor + rng.randint(-700, 700)))
+        d = rng.choice([1, 3, 10, 50, 300])
+        cut = rng.randint(5, L - 5)
+        if rng.random() < 0.6:
+            read = contig[p:p + cut] + contig[p + cut + d:p + cut + d + (L - cut)]
+        else:
+            ins = "".join(rng.choice("ACGT") for _ in range(min(d, 30)))
+            read = (contig[p:p + cut] + ins + contig[p + cut:p + L])[:L]
+        if rng.random() < 0.3:
+            i = rng.randrange(len(read))
+            read = read[:i] + rng.choice("ACGT") + read[i + 1:]
+        ro = R.realign(buf, anchor, 500, read)
+        st, res = ob.realign(P, cb, len(cb), anchor, 500, read)
+        msg = compare.ref_vs_oracle(ro, st, res, read)
+        assert msg is None, msg
+        n_ev += 0 if ro is None else len(ro)
+    assert n_ev > 5
