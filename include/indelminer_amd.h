@@ -178,6 +178,12 @@ typedef struct im_dev_batch {
     const int32_t* anchor;
     const int32_t* range_max;
     im_read_result* out;        /* n   */
+    /* optional evidence SLOT arrays, n * IM_MAX_EV entries each (NULL = not wanted):
+     * slot i*IM_MAX_EV+k carries evidence k of read i, cls = -1 marks an empty slot.
+     * Slot order is arrival order, so the arrays feed im_dev_cluster_slots directly. */
+    int32_t* ev_cls;
+    int32_t* ev_b1;
+    int32_t* ev_b2;
 } im_dev_batch;
 
 /* Launch the realign kernel on `stream` (a hipStream_t, NULL = default stream).
@@ -188,13 +194,30 @@ int im_dev_realign(im_ctx* ctx, const im_params* params,
 /* Bytes of device scratch im_dev_cluster_sr needs for n evidence records. */
 size_t im_dev_cluster_scratch_bytes(int32_t n);
 
-/* Device form of im_cluster_sr.  n_clusters is a device int32.  Asynchronous. */
-int im_dev_cluster_sr(im_ctx* ctx, int32_t n,
+/* Device form of im_cluster_sr.  The record count is read from device memory
+ * (*n_dev, e.g. the n_out of im_dev_gather_evidence) so that no host round trip
+ * sits between the stages; n_cap is the capacity the arrays and the scratch
+ * were sized for.  n_clusters is a device int32.  Asynchronous. */
+int im_dev_cluster_sr(im_ctx* ctx, int32_t n_cap, const int32_t* n_dev,
                       const int32_t* cls, const int32_t* b1, const int32_t* b2,
                       int32_t marker, int32_t tie_desc,
                       int32_t* order, int32_t* cl_first, int32_t* cl_count,
                       uint8_t* used, int32_t* n_clusters,
                       void* scratch, size_t scratch_bytes, void* stream);
+
+/* Single-launch form for evidence SLOT arrays (see im_dev_batch): compacts the live
+ * slots (cls >= 0) in arrival order and clusters them in one workgroup.  Holds up
+ * to im_dev_cluster_slots_max() live records (a READCHUNK flush of the reference is
+ * a few thousand); with more, counts[0] is set to -1 and the caller takes the
+ * im_dev_gather_evidence + im_dev_cluster_sr path instead.  order[] lists slot
+ * indices; used[] (n_slots, may be NULL) marks slots that became graph nodes;
+ * counts (device int32[2]) = {clusters, live records}.  Asynchronous. */
+int im_dev_cluster_slots(im_ctx* ctx, int32_t n_slots,
+                         const int32_t* cls, const int32_t* b1, const int32_t* b2,
+                         int32_t marker, int32_t tie_desc,
+                         int32_t* order, int32_t* cl_first, int32_t* cl_count,
+                         uint8_t* used, int32_t* counts, void* stream);
+int im_dev_cluster_slots_max(void);
 
 /* Gather the evidence records of a realigned batch into dense SoA arrays
  * (arrival order = read order, then segment order), the input format of

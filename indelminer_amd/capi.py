@@ -65,7 +65,8 @@ class ReadBatch(C.Structure):
 
 class DevBatch(C.Structure):
     _fields_ = [("n", C.c_int32), ("bases", C.c_void_p), ("base_off", C.c_void_p), ("read_len", C.c_void_p),
-                ("tid", C.c_void_p), ("anchor", C.c_void_p), ("range_max", C.c_void_p), ("out", C.c_void_p)]
+                ("tid", C.c_void_p), ("anchor", C.c_void_p), ("range_max", C.c_void_p), ("out", C.c_void_p),
+                ("ev_cls", C.c_void_p), ("ev_b1", C.c_void_p), ("ev_b2", C.c_void_p)]
 
 
 class IMError(RuntimeError):
@@ -102,11 +103,13 @@ def lib():
         L.im_dev_cluster_scratch_bytes.argtypes = [C.c_int32]
         L.im_dev_gather_scratch_bytes.restype = C.c_size_t
         L.im_dev_gather_scratch_bytes.argtypes = [C.c_int32]
-        L.im_dev_cluster_sr.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32,
+        L.im_dev_cluster_sr.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32,
                                         C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                         C.c_void_p, C.c_size_t, C.c_void_p]
         L.im_dev_gather_evidence.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p,
                                              C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
+        L.im_dev_cluster_slots.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32,
+                                           C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         L.im_dev_alloc.argtypes = [C.c_void_p, C.c_size_t, C.POINTER(C.c_void_p)]
         L.im_dev_free.argtypes = [C.c_void_p, C.c_void_p]
         L.im_dev_upload.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]

@@ -237,6 +237,7 @@ int im_realign_batch(im_ctx* ctx, const im_params* params, const im_read_batch* 
     im_dev_batch db;
     db.n = n; db.bases = d_bases; db.base_off = d_off; db.read_len = d_len; db.tid = d_tid; db.anchor = d_anchor; db.range_max = d_range;
     db.out = d_res;
+    db.ev_cls = nullptr; db.ev_b1 = nullptr; db.ev_b2 = nullptr;
     rc = im_dev_realign(ctx, params, &db, ctx->stream);
     if (rc) return rc;
     HIP_TRY(ctx, hipMemcpyAsync(out, d_res, sizeof(im_read_result) * (size_t)n, hipMemcpyDeviceToHost, ctx->stream));
@@ -255,16 +256,31 @@ int im_realign_batch(im_ctx* ctx, const im_params* params, const im_read_batch* 
 size_t im_dev_cluster_scratch_bytes(int32_t n) { return im::cluster_scratch_bytes(n); }
 size_t im_dev_gather_scratch_bytes(int32_t n) { return im::gather_scratch_bytes(n); }
 
-int im_dev_cluster_sr(im_ctx* ctx, int32_t n, const int32_t* cls, const int32_t* b1, const int32_t* b2,
+int im_dev_cluster_sr(im_ctx* ctx, int32_t n_cap, const int32_t* n_dev,
+                      const int32_t* cls, const int32_t* b1, const int32_t* b2,
                       int32_t marker, int32_t tie_desc,
                       int32_t* order, int32_t* cl_first, int32_t* cl_count, uint8_t* used, int32_t* n_clusters,
                       void* scratch, size_t scratch_bytes, void* stream)
 {
     if (!ctx) return IM_E_ARG;
-    if (n < 0) { set_err(ctx, "negative evidence count"); return IM_E_ARG; }
+    if (n_cap < 0 || !n_dev) { set_err(ctx, "bad evidence count arguments"); return IM_E_ARG; }
     HIP_TRY(ctx, hipSetDevice(ctx->device));
-    HIP_TRY(ctx, im::launch_cluster_sr(n, cls, b1, b2, marker, tie_desc, order, cl_first, cl_count, used, n_clusters,
+    HIP_TRY(ctx, im::launch_cluster_sr(n_cap, n_dev, cls, b1, b2, marker, tie_desc, order, cl_first, cl_count, used, n_clusters,
                                        scratch, scratch_bytes, (hipStream_t)stream));
+    return IM_OK;
+}
+
+int im_dev_cluster_slots_max(void) { return im::cluster_small_max(); }
+
+int im_dev_cluster_slots(im_ctx* ctx, int32_t n_slots, const int32_t* cls, const int32_t* b1, const int32_t* b2,
+                         int32_t marker, int32_t tie_desc,
+                         int32_t* order, int32_t* cl_first, int32_t* cl_count, uint8_t* used, int32_t* counts, void* stream)
+{
+    if (!ctx) return IM_E_ARG;
+    if (n_slots < 0 || !counts) { set_err(ctx, "bad slot arguments"); return IM_E_ARG; }
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, im::launch_cluster_small(n_slots, nullptr, cls, b1, b2, marker, tie_desc, order, cl_first, cl_count,
+                                          used, counts, (hipStream_t)stream));
     return IM_OK;
 }
 
@@ -299,14 +315,22 @@ int im_cluster_sr(im_ctx* ctx, int32_t n, const int32_t* cls, const int32_t* b1,
     int32_t* d_first = (int32_t*)w; w += a32;
     int32_t* d_count = (int32_t*)w; w += a32;
     uint8_t* d_used = (uint8_t*)w; w += up256((size_t)n);
-    int32_t* d_ncl = (int32_t*)w; w += 256;
+    int32_t* d_ncl = (int32_t*)w; w += 128;
+    int32_t* d_n = (int32_t*)w; w += 128;
     void* d_scratch = w;
     HIP_TRY(ctx, hipMemcpyAsync(d_cls, cls, sizeof(int32_t) * (size_t)n, hipMemcpyHostToDevice, ctx->stream));
     HIP_TRY(ctx, hipMemcpyAsync(d_b1, b1, sizeof(int32_t) * (size_t)n, hipMemcpyHostToDevice, ctx->stream));
     HIP_TRY(ctx, hipMemcpyAsync(d_b2, b2, sizeof(int32_t) * (size_t)n, hipMemcpyHostToDevice, ctx->stream));
-    rc = im_dev_cluster_sr(ctx, n, d_cls, d_b1, d_b2, marker, tie_desc, d_order, d_first, d_count, d_used, d_ncl,
-                           d_scratch, scratch, ctx->stream);
-    if (rc) return rc;
+    HIP_TRY(ctx, hipMemcpyAsync(d_n, &n, sizeof(int32_t), hipMemcpyHostToDevice, ctx->stream));
+    if (n <= im::cluster_small_max()) {
+        // every record is live: the slot form with n slots is the same computation in one launch
+        HIP_TRY(ctx, im::launch_cluster_small(n, nullptr, d_cls, d_b1, d_b2, marker, tie_desc, d_order, d_first, d_count,
+                                              d_used, d_ncl, ctx->stream));
+    } else {
+        rc = im_dev_cluster_sr(ctx, n, d_n, d_cls, d_b1, d_b2, marker, tie_desc, d_order, d_first, d_count, d_used, d_ncl,
+                               d_scratch, scratch, ctx->stream);
+        if (rc) return rc;
+    }
     HIP_TRY(ctx, hipMemcpyAsync(n_clusters, d_ncl, sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     const int32_t ncl = *n_clusters;

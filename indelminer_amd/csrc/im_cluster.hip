@@ -37,9 +37,10 @@ __device__ __forceinline__ uint64_t make_key(int32_t b1, int32_t b2)
 }
 __device__ __forceinline__ int32_t key_b2(uint64_t k) { return (int32_t)((uint32_t)k ^ 0x80000000u); }
 
-__global__ __launch_bounds__(256) void build_keys_kernel(int32_t n, const int32_t* __restrict__ b1, const int32_t* __restrict__ b2,
+__global__ __launch_bounds__(256) void build_keys_kernel(const int32_t* __restrict__ n_dev, int32_t n_cap, const int32_t* __restrict__ b1, const int32_t* __restrict__ b2,
                                                         uint64_t* __restrict__ keys, uint32_t* __restrict__ vals)
 {
+    const int32_t n = min(*n_dev, n_cap);
     for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
         keys[i] = make_key(b1[i], b2[i]);
         vals[i] = (uint32_t)i;
@@ -47,9 +48,10 @@ __global__ __launch_bounds__(256) void build_keys_kernel(int32_t n, const int32_
 }
 
 // per-tile digit histogram, stored digit-major: hist[d * nblocks + tile]
-__global__ __launch_bounds__(kSortThreads) void radix_hist_kernel(const uint64_t* __restrict__ keys, int32_t n, int shift,
+__global__ __launch_bounds__(kSortThreads) void radix_hist_kernel(const uint64_t* __restrict__ keys, const int32_t* __restrict__ n_dev, int32_t n_cap, int shift,
                                                                  uint32_t* __restrict__ hist, int nblocks)
 {
+    const int32_t n = min(*n_dev, n_cap);
     __shared__ uint32_t h[256];
     h[threadIdx.x] = 0;
     __syncthreads();
@@ -66,8 +68,11 @@ __global__ __launch_bounds__(kSortThreads) void radix_hist_kernel(const uint64_t
 // exclusive scan of a u32 array by ONE workgroup (arrays here are small: 256 x tiles,
 // or one flag per evidence record).  total (optional) receives the sum.
 __global__ __launch_bounds__(kScanThreads) void scan_excl_kernel(const uint32_t* in, uint32_t* out,
-                                                                int64_t n, uint32_t* __restrict__ total)
+                                                                int64_t n_host, const int32_t* __restrict__ n_dev,
+                                                                uint32_t* __restrict__ total)
 {
+    // n_dev (if given) bounds the scan from device memory; n_host is then the capacity
+    const int64_t n = n_dev ? min((int64_t)*n_dev, n_host) : n_host;
     __shared__ uint32_t wsum[kScanThreads / 64];
     __shared__ uint32_t carry_s;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -95,8 +100,10 @@ __global__ __launch_bounds__(kScanThreads) void scan_excl_kernel(const uint32_t*
 // stable scatter of one radix pass
 __global__ __launch_bounds__(kSortThreads) void radix_scatter_kernel(const uint64_t* __restrict__ kin, const uint32_t* __restrict__ vin,
                                                                     uint64_t* __restrict__ kout, uint32_t* __restrict__ vout,
-                                                                    int32_t n, int shift, const uint32_t* __restrict__ offs, int nblocks)
+                                                                    const int32_t* __restrict__ n_dev, int32_t n_cap, int shift,
+                                                                    const uint32_t* __restrict__ offs, int nblocks)
 {
+    const int32_t n = min(*n_dev, n_cap);
     __shared__ uint32_t running[256];
     __shared__ uint32_t wcnt[kSortThreads / 64][256];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -141,8 +148,9 @@ __global__ __launch_bounds__(kSortThreads) void radix_scatter_kernel(const uint6
 
 // first sorted position whose b2 >= marker (the reference stops making nodes there,
 // src/indelminer.c:140-142); *cut starts at n
-__global__ __launch_bounds__(256) void cut_kernel(const uint64_t* __restrict__ keys, int32_t n, int32_t marker, uint32_t* __restrict__ cut)
+__global__ __launch_bounds__(256) void cut_kernel(const uint64_t* __restrict__ keys, const int32_t* __restrict__ n_dev, int32_t n_cap, int32_t marker, uint32_t* __restrict__ cut)
 {
+    const int32_t n = min(*n_dev, n_cap);
     uint32_t best = 0xFFFFFFFFu;
     for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
         if (key_b2(keys[i]) >= marker) { best = (uint32_t)i; break; }     // positions ascend per thread
@@ -152,9 +160,11 @@ __global__ __launch_bounds__(256) void cut_kernel(const uint64_t* __restrict__ k
 }
 
 __global__ __launch_bounds__(256) void heads_kernel(const uint64_t* __restrict__ keys, const uint32_t* __restrict__ vals,
-                                                   const int32_t* __restrict__ cls, int32_t n, const uint32_t* __restrict__ cut,
+                                                   const int32_t* __restrict__ cls, const int32_t* __restrict__ n_dev, int32_t n_cap,
+                                                   const uint32_t* __restrict__ cut,
                                                    uint32_t* __restrict__ head, uint8_t* __restrict__ used)
 {
+    const int32_t n = min(*n_dev, n_cap);
     const uint32_t m = min(*cut, (uint32_t)n);
     for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
         uint32_t h = 0;
@@ -166,20 +176,23 @@ __global__ __launch_bounds__(256) void heads_kernel(const uint64_t* __restrict__
 
 // cl_first[c] for every head; cl_first[n_clusters] = cut as a sentinel (array has n+1 slots in scratch)
 __global__ __launch_bounds__(256) void cluster_first_kernel(const uint32_t* __restrict__ head, const uint32_t* __restrict__ cid,
-                                                           int32_t n, const uint32_t* __restrict__ cut, const uint32_t* __restrict__ ncl,
+                                                           const int32_t* __restrict__ n_dev, int32_t n_cap,
+                                                           const uint32_t* __restrict__ cut, const uint32_t* __restrict__ ncl,
                                                            int32_t* __restrict__ first_tmp, int32_t* __restrict__ n_clusters)
 {
+    const int32_t n = min(*n_dev, n_cap);
     for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
         if (head[i]) first_tmp[cid[i]] = (int32_t)i;
     if (blockIdx.x == 0 && threadIdx.x == 0) { first_tmp[*ncl] = (int32_t)min(*cut, (uint32_t)n); *n_clusters = (int32_t)*ncl; }
 }
 
 __global__ __launch_bounds__(256) void cluster_finish_kernel(const uint32_t* __restrict__ vals, const uint32_t* __restrict__ head,
-                                                            const uint32_t* __restrict__ cid, int32_t n,
+                                                            const uint32_t* __restrict__ cid, const int32_t* __restrict__ n_dev, int32_t n_cap,
                                                             const uint32_t* __restrict__ cut, const int32_t* __restrict__ first_tmp,
                                                             int32_t tie_desc,
                                                             int32_t* __restrict__ order, int32_t* __restrict__ cl_first, int32_t* __restrict__ cl_count)
 {
+    const int32_t n = min(*n_dev, n_cap);
     const uint32_t m = min(*cut, (uint32_t)n);
     for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
         if (i >= m) { order[i] = (int32_t)vals[i]; continue; }
@@ -190,6 +203,163 @@ __global__ __launch_bounds__(256) void cluster_finish_kernel(const uint32_t* __r
         const int32_t pos = tie_desc ? (f + (cnt - 1 - ((int32_t)i - f))) : (int32_t)i;
         order[pos] = (int32_t)vals[i];
     }
+}
+
+// ---- single-workgroup path ----------------------------------------------------
+//
+// One launch for the whole of process_evidence's split-read work when at most
+// kSmallMax evidence records are live (a READCHUNK flush of the reference holds a
+// few thousand): compaction of the evidence slots in arrival order, bitonic sort
+// of (b1, b2, slot) in LDS, marker cut, run heads, head scan, cluster table.
+// Input is a SLOT array: slot i is live iff cls[i] >= 0 (the realign kernel writes
+// IM_MAX_EV slots per read, empty ones with cls = -1); slot order = arrival order.
+
+constexpr int kSmallThreads = 1024;
+constexpr int kSmallMax = 8192;
+
+struct SmallLds {
+    int32_t  b1[kSmallMax];
+    int32_t  b2[kSmallMax];
+    uint32_t slot[kSmallMax];
+    int32_t  first[kSmallMax + 1];
+    uint32_t wsum[kSmallThreads / 64];
+    uint32_t carry;
+    uint32_t cut;
+};
+
+// exclusive scan of one value per thread across the workgroup; returns the exclusive
+// prefix and leaves the block total in *total_out (read by every thread)
+__device__ __forceinline__ uint32_t block_scan_excl(uint32_t v, uint32_t* wsum, uint32_t* total_out)
+{
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    uint32_t x = v;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { uint32_t t = __shfl_up(x, o); if (lane >= o) x += t; }
+    __syncthreads();
+    if (lane == 63) wsum[wave] = x;
+    __syncthreads();
+    uint32_t woff = 0, tot = 0;
+#pragma unroll
+    for (int w = 0; w < kSmallThreads / 64; w++) { const uint32_t c = wsum[w]; if (w < wave) woff += c; tot += c; }
+    *total_out = tot;
+    return woff + x - v;
+}
+
+__device__ __forceinline__ bool tuple_less(int32_t a1, int32_t a2, uint32_t as, int32_t b1, int32_t b2, uint32_t bs)
+{
+    if (a1 != b1) return a1 < b1;
+    if (a2 != b2) return a2 < b2;
+    return as < bs;
+}
+
+// out_counts[0] = clusters (or -1 on overflow), out_counts[1] = live evidence records
+__global__ __launch_bounds__(kSmallThreads) void cluster_small_kernel(
+    int32_t n_slots_host, const int32_t* __restrict__ n_slots_dev,
+    const int32_t* __restrict__ cls, const int32_t* __restrict__ b1, const int32_t* __restrict__ b2,
+    int32_t marker, int32_t tie_desc,
+    int32_t* __restrict__ order, int32_t* __restrict__ cl_first, int32_t* __restrict__ cl_count,
+    uint8_t* __restrict__ used, int32_t* __restrict__ out_counts)
+{
+    extern __shared__ __align__(16) unsigned char smem_raw[];
+    SmallLds& s = *reinterpret_cast<SmallLds*>(smem_raw);
+    const int tid = threadIdx.x;
+    const int32_t n_slots = n_slots_dev ? min(*n_slots_dev, n_slots_host) : n_slots_host;
+
+    // 1. compaction in arrival order
+    uint32_t carry = 0;
+    for (int32_t base = 0; base < n_slots; base += kSmallThreads) {
+        const int32_t i = base + tid;
+        const bool live = (i < n_slots) && (cls[i] >= 0);
+        uint32_t tot;
+        const uint32_t r = carry + block_scan_excl(live ? 1u : 0u, s.wsum, &tot);
+        if (live && r < (uint32_t)kSmallMax) { s.b1[r] = b1[i]; s.b2[r] = b2[i]; s.slot[r] = (uint32_t)i; }
+        if (i < n_slots && used) used[i] = 0;
+        carry += tot;
+    }
+    const uint32_t nv = carry;
+    if (nv > (uint32_t)kSmallMax) {                  // caller must take the multi-kernel path
+        if (tid == 0) { out_counts[0] = -1; out_counts[1] = (int32_t)nv; }
+        return;
+    }
+    uint32_t P = 2;
+    while (P < nv) P <<= 1;
+    for (uint32_t i = nv + tid; i < P; i += kSmallThreads) { s.b1[i] = INT_MAX; s.b2[i] = INT_MAX; s.slot[i] = 0xFFFFFFFFu; }
+    __syncthreads();
+
+    // 2. bitonic sort, ascending in (b1, b2, slot); slot order = arrival order, so equal
+    //    keys stay in arrival order like the reference's stable sort
+    for (uint32_t k = 2; k <= P; k <<= 1) {
+        for (uint32_t j = k >> 1; j > 0; j >>= 1) {
+            for (uint32_t t = tid; t < (P >> 1); t += kSmallThreads) {
+                const uint32_t lo = ((t & ~(j - 1)) << 1) | (t & (j - 1));   // index with bit j clear
+                const uint32_t hi = lo | j;
+                const bool asc = (lo & k) == 0;
+                const int32_t a1 = s.b1[lo], a2 = s.b2[lo], c1 = s.b1[hi], c2 = s.b2[hi];
+                const uint32_t as = s.slot[lo], cs = s.slot[hi];
+                const bool hi_lt_lo = tuple_less(c1, c2, cs, a1, a2, as);
+                if (hi_lt_lo == asc) {
+                    s.b1[lo] = c1; s.b2[lo] = c2; s.slot[lo] = cs;
+                    s.b1[hi] = a1; s.b2[hi] = a2; s.slot[hi] = as;
+                }
+            }
+            __syncthreads();
+        }
+    }
+
+    // 3. marker cut: nodes are made only for the sorted prefix before the first b2 >= marker
+    if (tid == 0) s.cut = nv;
+    __syncthreads();
+    {
+        uint32_t best = 0xFFFFFFFFu;
+        for (uint32_t p = tid; p < nv; p += kSmallThreads) if (s.b2[p] >= marker) { best = p; break; }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) best = min(best, (uint32_t)__shfl_xor((int)best, o));
+        if ((tid & 63) == 0 && best != 0xFFFFFFFFu) atomicMin(&s.cut, best);
+    }
+    __syncthreads();
+    const uint32_t m = s.cut;
+
+    // 4. run heads + cluster ids (8 consecutive positions per thread)
+    constexpr int kPer = kSmallMax / kSmallThreads;
+    uint32_t head[kPer];
+    uint32_t nh = 0;
+#pragma unroll
+    for (int e = 0; e < kPer; e++) {
+        const uint32_t p = (uint32_t)tid * kPer + e;
+        uint32_t h = 0;
+        if (p < m) {
+            h = (p == 0) || s.b1[p] != s.b1[p - 1] || s.b2[p] != s.b2[p - 1] ||
+                cls[s.slot[p]] != cls[s.slot[p - 1]];
+        }
+        head[e] = h; nh += h;
+    }
+    uint32_t ncl;
+    uint32_t cid = block_scan_excl(nh, s.wsum, &ncl);
+    uint32_t mycid[kPer];
+#pragma unroll
+    for (int e = 0; e < kPer; e++) {
+        const uint32_t p = (uint32_t)tid * kPer + e;
+        if (head[e]) { s.first[cid] = (int32_t)p; mycid[e] = cid; cid++; }
+        else mycid[e] = cid - 1;
+    }
+    if (tid == 0) s.first[ncl] = (int32_t)m;
+    __syncthreads();
+
+    // 5. outputs
+#pragma unroll
+    for (int e = 0; e < kPer; e++) {
+        const uint32_t p = (uint32_t)tid * kPer + e;
+        if (p >= nv) continue;
+        const uint32_t sl = s.slot[p];
+        if (p >= m) { order[p] = (int32_t)sl; continue; }
+        const uint32_t c = mycid[e];
+        const int32_t f = s.first[c], cnt = s.first[c + 1] - f;
+        if (head[e]) { cl_first[c] = f; cl_count[c] = cnt; }
+        const int32_t pos = tie_desc ? (f + (cnt - 1 - ((int32_t)p - f))) : (int32_t)p;
+        order[pos] = (int32_t)sl;
+        if (used) used[sl] = 1;
+    }
+    if (tid == 0) { out_counts[0] = (int32_t)ncl; out_counts[1] = (int32_t)nv; }
 }
 
 // ---- evidence gather ----------------------------------------------------------
@@ -259,36 +429,57 @@ inline size_t carve(ClusterScratch* cs, void* base, int32_t n)
 
 size_t cluster_scratch_bytes(int32_t n) { return carve(nullptr, nullptr, n); }
 
-hipError_t launch_cluster_sr(int32_t n, const int32_t* cls, const int32_t* b1, const int32_t* b2,
+hipError_t launch_cluster_sr(int32_t n_cap, const int32_t* n_dev,
+                             const int32_t* cls, const int32_t* b1, const int32_t* b2,
                              int32_t marker, int32_t tie_desc,
                              int32_t* order, int32_t* cl_first, int32_t* cl_count,
                              uint8_t* used, int32_t* n_clusters,
                              void* scratch, size_t scratch_bytes, hipStream_t stream)
 {
-    if (n <= 0) return hipMemsetAsync(n_clusters, 0, sizeof(int32_t), stream);
+    if (n_cap <= 0) return hipMemsetAsync(n_clusters, 0, sizeof(int32_t), stream);
     ClusterScratch cs;
-    if (carve(&cs, scratch, n) > scratch_bytes) return hipErrorInvalidValue;
-    const int g256 = grid_for(n, 256);
-    hipLaunchKernelGGL(build_keys_kernel, dim3(g256), dim3(256), 0, stream, n, b1, b2, cs.keysA, cs.valsA);
+    if (carve(&cs, scratch, n_cap) > scratch_bytes) return hipErrorInvalidValue;
+    const int g256 = grid_for(n_cap, 256);
+    hipLaunchKernelGGL(build_keys_kernel, dim3(g256), dim3(256), 0, stream, n_dev, n_cap, b1, b2, cs.keysA, cs.valsA);
     uint64_t *kin = cs.keysA, *kout = cs.keysB;
     uint32_t *vin = cs.valsA, *vout = cs.valsB;
     const int64_t nh = (int64_t)cs.nblocks * 256;
     for (int pass = 0; pass < 8; pass++) {
         const int shift = pass * 8;
-        hipLaunchKernelGGL(radix_hist_kernel, dim3(cs.nblocks), dim3(kSortThreads), 0, stream, kin, n, shift, cs.hist, cs.nblocks);
-        hipLaunchKernelGGL(scan_excl_kernel, dim3(1), dim3(kScanThreads), 0, stream, cs.hist, cs.hist, nh, (uint32_t*)nullptr);
-        hipLaunchKernelGGL(radix_scatter_kernel, dim3(cs.nblocks), dim3(kSortThreads), 0, stream, kin, vin, kout, vout, n, shift, cs.hist, cs.nblocks);
+        hipLaunchKernelGGL(radix_hist_kernel, dim3(cs.nblocks), dim3(kSortThreads), 0, stream, kin, n_dev, n_cap, shift, cs.hist, cs.nblocks);
+        hipLaunchKernelGGL(scan_excl_kernel, dim3(1), dim3(kScanThreads), 0, stream, cs.hist, cs.hist, nh, (const int32_t*)nullptr, (uint32_t*)nullptr);
+        hipLaunchKernelGGL(radix_scatter_kernel, dim3(cs.nblocks), dim3(kSortThreads), 0, stream, kin, vin, kout, vout, n_dev, n_cap, shift, cs.hist, cs.nblocks);
         uint64_t* tk = kin; kin = kout; kout = tk;
         uint32_t* tv = vin; vin = vout; vout = tv;
     }
     // 8 passes: the sorted data is back in keysA / valsA (kin / vin)
     hipError_t e = hipMemsetAsync(cs.misc, 0xFF, sizeof(uint32_t), stream);      // cut = "none"
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(cut_kernel, dim3(g256), dim3(256), 0, stream, kin, n, marker, cs.misc);
-    hipLaunchKernelGGL(heads_kernel, dim3(g256), dim3(256), 0, stream, kin, vin, cls, n, cs.misc, cs.head, used);
-    hipLaunchKernelGGL(scan_excl_kernel, dim3(1), dim3(kScanThreads), 0, stream, cs.head, cs.cid, (int64_t)n, cs.misc + 1);
-    hipLaunchKernelGGL(cluster_first_kernel, dim3(g256), dim3(256), 0, stream, cs.head, cs.cid, n, cs.misc, cs.misc + 1, cs.first_tmp, n_clusters);
-    hipLaunchKernelGGL(cluster_finish_kernel, dim3(g256), dim3(256), 0, stream, vin, cs.head, cs.cid, n, cs.misc, cs.first_tmp, tie_desc, order, cl_first, cl_count);
+    hipLaunchKernelGGL(cut_kernel, dim3(g256), dim3(256), 0, stream, kin, n_dev, n_cap, marker, cs.misc);
+    hipLaunchKernelGGL(heads_kernel, dim3(g256), dim3(256), 0, stream, kin, vin, cls, n_dev, n_cap, cs.misc, cs.head, used);
+    hipLaunchKernelGGL(scan_excl_kernel, dim3(1), dim3(kScanThreads), 0, stream, cs.head, cs.cid, (int64_t)n_cap, n_dev, cs.misc + 1);
+    hipLaunchKernelGGL(cluster_first_kernel, dim3(g256), dim3(256), 0, stream, cs.head, cs.cid, n_dev, n_cap, cs.misc, cs.misc + 1, cs.first_tmp, n_clusters);
+    hipLaunchKernelGGL(cluster_finish_kernel, dim3(g256), dim3(256), 0, stream, vin, cs.head, cs.cid, n_dev, n_cap, cs.misc, cs.first_tmp, tie_desc, order, cl_first, cl_count);
+    return hipGetLastError();
+}
+
+int cluster_small_max() { return kSmallMax; }
+
+hipError_t launch_cluster_small(int32_t n_slots, const int32_t* n_slots_dev,
+                                const int32_t* cls, const int32_t* b1, const int32_t* b2,
+                                int32_t marker, int32_t tie_desc,
+                                int32_t* order, int32_t* cl_first, int32_t* cl_count,
+                                uint8_t* used, int32_t* out_counts, hipStream_t stream)
+{
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(cluster_small_kernel),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(SmallLds));
+        if (e != hipSuccess) return e;
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(cluster_small_kernel, dim3(1), dim3(kSmallThreads), sizeof(SmallLds), stream,
+                       n_slots, n_slots_dev, cls, b1, b2, marker, tie_desc, order, cl_first, cl_count, used, out_counts);
     return hipGetLastError();
 }
 
@@ -307,7 +498,7 @@ hipError_t launch_gather_evidence(const im_read_result* res, int32_t n,
     uint32_t* total = (uint32_t*)((char*)scratch + 2 * stride);
     const int g256 = grid_for(n, 256);
     hipLaunchKernelGGL(count_ev_kernel, dim3(g256), dim3(256), 0, stream, res, n, cnt);
-    hipLaunchKernelGGL(scan_excl_kernel, dim3(1), dim3(kScanThreads), 0, stream, cnt, offs, (int64_t)n, total);
+    hipLaunchKernelGGL(scan_excl_kernel, dim3(1), dim3(kScanThreads), 0, stream, cnt, offs, (int64_t)n, (const int32_t*)nullptr, total);
     hipLaunchKernelGGL(write_ev_kernel, dim3(g256), dim3(256), 0, stream, res, n, offs, total, cap, cls, b1, b2, src, n_out);
     return hipGetLastError();
 }

@@ -38,11 +38,19 @@ hipError_t launch_pack_reference(const uint8_t* ascii, uint64_t* pk, int64_t n_b
 hipError_t launch_realign(const RealignArgs& a, int n_cu, hipStream_t stream);
 
 size_t cluster_scratch_bytes(int32_t n);
-hipError_t launch_cluster_sr(int32_t n, const int32_t* cls, const int32_t* b1, const int32_t* b2,
+hipError_t launch_cluster_sr(int32_t n_cap, const int32_t* n_dev,
+                             const int32_t* cls, const int32_t* b1, const int32_t* b2,
                              int32_t marker, int32_t tie_desc,
                              int32_t* order, int32_t* cl_first, int32_t* cl_count,
                              uint8_t* used, int32_t* n_clusters,
                              void* scratch, size_t scratch_bytes, hipStream_t stream);
+
+int cluster_small_max();
+hipError_t launch_cluster_small(int32_t n_slots, const int32_t* n_slots_dev,
+                                const int32_t* cls, const int32_t* b1, const int32_t* b2,
+                                int32_t marker, int32_t tie_desc,
+                                int32_t* order, int32_t* cl_first, int32_t* cl_count,
+                                uint8_t* used, int32_t* out_counts, hipStream_t stream);
 
 size_t gather_scratch_bytes(int32_t n);
 hipError_t launch_gather_evidence(const im_read_result* res, int32_t n,

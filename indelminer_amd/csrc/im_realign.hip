@@ -402,6 +402,18 @@ __device__ __forceinline__ void finish(im_read_result* out, int status, int n_ba
     if (lane == 0) { out->status = status; out->n_band = n_band; if (status != IM_ST_EVIDENCE) { out->n_ev = 0; out->n_ops = 0; out->ref_start = 0; } }
 }
 
+// evidence slots of read c (see im_dev_batch): slot k < n_ev live, the rest empty
+__device__ __forceinline__ void write_slots(const RealignArgs& A, int c, int n_ev, int cls0, int b1, int b2, int lane)
+{
+    if (A.batch.ev_cls && lane < IM_MAX_EV) {
+        const int64_t sl = (int64_t)c * IM_MAX_EV + lane;
+        const bool live = lane < n_ev;
+        A.batch.ev_cls[sl] = live ? cls0 : -1;
+        A.batch.ev_b1[sl] = live ? b1 : 0;
+        A.batch.ev_b2[sl] = live ? b2 : 0;
+    }
+}
+
 // attempt_pe_alignment -> attempt_diagonal_alignments (src/alignment.c:539-799)
 template <bool DIRECT>
 __device__ void realign_one(WaveLds& s, const RealignArgs& A, int c, int lane)
@@ -415,6 +427,8 @@ __device__ void realign_one(WaveLds& s, const RealignArgs& A, int c, int lane)
     const uint32_t k = A.P.klength, g = A.P.numgaps, eth = A.P.ethreshold;
 
     if (lane < 16) reinterpret_cast<uint32_t*>(&out->band[0])[lane] = 0u;
+    if (lane < 7) out->reserved[lane] = 0;
+    write_slots(A, c, 0, -1, 0, 0, lane);
     if (Lraw <= 0 || Lraw > IM_MAX_READ || tid < 0 || tid >= A.ref.n_contigs || (off & 3)) {
         finish(out, (Lraw > IM_MAX_READ || (off & 3)) ? IM_ST_UNSUPPORTED : IM_ST_ABORT, 0, lane);
         return;
@@ -622,6 +636,7 @@ __device__ void realign_one(WaveLds& s, const RealignArgs& A, int c, int lane)
         out->status = IM_ST_EVIDENCE;
         out->n_band = 2;
     }
+    write_slots(A, c, 1, hasD ? IM_CLS_DELETION : IM_CLS_INSERTION, refindx, hasD ? rindex : refindx, lane);
 }
 
 template <bool DIRECT>

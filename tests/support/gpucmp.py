@@ -8,6 +8,8 @@ def hip_vs_oracle(rec, st, res, check_bands=True):
     """rec: one element of capi.RESULT_DTYPE; st/res: oracle status and Result."""
     if int(rec["status"]) != _ST.get(st, st):
         return "status hip %d oracle %d" % (rec["status"], st)
+    if st < 0:
+        return None
     if check_bands:
         nb = res.n_band
         if int(rec["n_band"]) != nb:

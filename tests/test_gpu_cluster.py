@@ -58,3 +58,39 @@ def test_cluster_sortedness_and_grouping_large(gpu_ctx):
     assert (np.diff(order)[same] > 0).all()
     heads = np.zeros(n, bool); heads[first] = True
     assert np.array_equal(heads[1:], ~same)
+
+
+def test_cluster_slots_matches_oracle(gpu_ctx):
+    """Slot form (empty slots = cls -1) through im_dev_cluster_slots: same clusters as the oracle
+    on the compacted records, order[] in slot indices."""
+    import ctypes as C
+    from indelminer_amd import capi
+    L = capi.lib()
+    for seed, n_slots, live_frac, marker, tie in [(1, 4000, 0.5, 2**31 - 1, 0), (2, 30000, 0.25, 2**31 - 1, 1),
+                                                  (3, 9000, 0.9, 40000, 0), (4, 50, 0.5, 2**31 - 1, 0)]:
+        rng = np.random.default_rng(seed)
+        cls, b1, b2 = _random_evidence(seed, n_slots, 80000)
+        live = rng.random(n_slots) < live_frac
+        cls_s = np.where(live, cls, -1).astype(np.int32)
+        idx = np.nonzero(live)[0]
+        o_order, o_first, o_count, o_used, o_k = _cluster_oracle(cls[idx], b1[idx], b2[idx], marker, tie)
+        bufs = {}
+        for name, arr in (("cls", cls_s), ("b1", b1), ("b2", b2)):
+            bufs[name] = capi.DevBuf(gpu_ctx, 4 * n_slots).upload(arr)
+        d_order = capi.DevBuf(gpu_ctx, 4 * n_slots); d_first = capi.DevBuf(gpu_ctx, 4 * n_slots)
+        d_count = capi.DevBuf(gpu_ctx, 4 * n_slots); d_used = capi.DevBuf(gpu_ctx, n_slots); d_counts = capi.DevBuf(gpu_ctx, 64)
+        gpu_ctx._check(L.im_dev_cluster_slots(gpu_ctx.h, n_slots, bufs["cls"].ptr, bufs["b1"].ptr, bufs["b2"].ptr, marker, tie,
+                                              d_order.ptr, d_first.ptr, d_count.ptr, d_used.ptr, d_counts.ptr, gpu_ctx.stream))
+        gpu_ctx._check(L.im_stream_sync(gpu_ctx.h, gpu_ctx.stream))
+        counts = d_counts.download(np.int32, 2)
+        if len(idx) > L.im_dev_cluster_slots_max():
+            assert counts[0] == -1 and counts[1] == len(idx)
+            continue
+        assert counts[1] == len(idx) and counts[0] == o_k
+        m = int(o_used.sum())
+        assert np.array_equal(d_order.download(np.int32, n_slots)[:m], idx[o_order[:m]])
+        assert np.array_equal(d_first.download(np.int32, n_slots)[:o_k], o_first)
+        assert np.array_equal(d_count.download(np.int32, n_slots)[:o_k], o_count)
+        used = d_used.download(np.uint8, n_slots)
+        want = np.zeros(n_slots, np.uint8); want[idx[o_used.astype(bool)]] = 1
+        assert np.array_equal(used, want)
