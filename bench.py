@@ -28,7 +28,7 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-from indelminer_amd import capi, synth  # noqa: E402
+from indelminer_amd import capi, shard as shardlib, synth  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0           # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 
@@ -90,6 +90,16 @@ class Shard:
                                    self.d_cls.ptr, self.d_b1.ptr, self.d_b2.ptr)
         self.P = capi.params()
         self.small = True                        # single-launch cluster path; cleared if it overflows
+        # multi-GPU: per-shard cluster list (16 B records) and the gathered lists of all ranks
+        self.tid = 0
+        self.rec_cap = 16384
+        self.comm = None
+        self.d_recs = capi.DevBuf(ctx, 16 * self.rec_cap)
+        self.d_gather = None
+
+    def attach_comm(self, comm):
+        self.comm = comm
+        self.d_gather = capi.DevBuf(self.ctx, 16 * self.rec_cap * comm.world)
 
     def step(self, timer=None):
         L_ = capi.lib()
@@ -111,6 +121,13 @@ class Shard:
             ctx._check(L_.im_dev_cluster_sr(ctx.h, self.cap, self.d_nout.ptr, self.d_dcls.ptr, self.d_db1.ptr, self.d_db2.ptr,
                                             2**31 - 1, 0, self.d_order.ptr, self.d_first.ptr, self.d_count.ptr,
                                             self.d_used.ptr, self.d_counts.ptr, self.d_cs.ptr, self.cs_bytes, st))
+        if self.comm is not None:
+            # the one collective of the path: all-gather of the per-shard cluster lists (RCCL over xGMI)
+            src = (self.d_cls, self.d_b1, self.d_b2) if self.small else (self.d_dcls, self.d_db1, self.d_db2)
+            ctx._check(L_.im_dev_cluster_records(ctx.h, self.tid, self.d_counts.ptr, self.d_order.ptr, self.d_first.ptr,
+                                                 self.d_count.ptr, src[0].ptr, src[1].ptr, src[2].ptr,
+                                                 self.d_recs.ptr, self.rec_cap, st))
+            self.comm.allgather(self.d_recs.ptr, self.d_gather.ptr, 16 * self.rec_cap, st)
 
     def sync(self):
         self.ctx._check(capi.lib().im_stream_sync(self.ctx.h, self.ctx.stream))
@@ -190,6 +207,17 @@ def main():
     ctx = capi.Context(local_rank)
     ctx.set_reference([refs[0].tobytes()])
     shard = Shard(ctx, refs[0], cand, L)
+    shard.tid = rank                          # contig id = rank: every rank owns one contig
+    collective = None
+    if world > 1 or os.environ.get("IM_BENCH_FORCE_COMM") == "1":
+        try:
+            ids = [capi.comm_unique_id() if rank == 0 else None]
+            if dist is not None:
+                dist.broadcast_object_list(ids, src=0)
+            shard.attach_comm(capi.Comm(ctx, ids[0], rank, world))
+            collective = "rccl all-gather of per-shard cluster lists, %d B per rank per step" % (16 * shard.rec_cap)
+        except Exception as e:                # plumbing failure must not hide the compute numbers
+            collective = "NONE (RCCL unavailable: %s); shards ran independently" % e
 
     def barrier():
         shard.sync()
@@ -231,6 +259,11 @@ def main():
     kern_s = float(kern_ms.mean()) * 1e-3
     achieved = alg_bytes / kern_s / 1e9
 
+    gathered_clusters = None
+    if shard.comm is not None and rank == 0:
+        g = shard.d_gather.download(np.int32, 4 * shard.rec_cap * world)
+        recs, trunc = shardlib.merge_gathered(g, shard.rec_cap)
+        gathered_clusters = int(len(recs))
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
         value = total_reads * args.steps / elapsed
@@ -259,6 +292,8 @@ def main():
                        "evidence_per_step_rank0": nev, "clusters_per_step_rank0": ncl,
                        "candidates_per_s": total_cand * args.steps / elapsed,
                        "cluster_path": "single-workgroup" if shard.small else "radix multi-kernel",
+                       "parallelism": "contig-sharded x%d" % world, "collective": collective,
+                       "gathered_clusters": gathered_clusters,
                        "timed_region": "realign kernel + SR cluster kernel(s) on the resident candidate batch; "
                                        "host BAM decode / candidate filter not included",
                        "parity": parity},

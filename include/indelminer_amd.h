@@ -230,6 +230,31 @@ int im_dev_gather_evidence(im_ctx* ctx, const im_read_result* res, int32_t n,
                            void* stream);
 size_t im_dev_gather_scratch_bytes(int32_t n);
 
+/* ---- multi-GPU: one collective ------------------------------------------------ */
+
+/* Contigs are independent (the reference's own parallel mode is one process per -c
+ * region, src/indelminer.c:536-542), so ranks own disjoint contigs and exchange
+ * nothing until each holds its cluster list; then ONE all-gather (RCCL over xGMI).
+ * Rendezvous: rank 0 calls im_comm_unique_id and ships the IM_COMM_ID_BYTES to the
+ * other ranks by any side channel (bench.py: torch.distributed/gloo broadcast). */
+#define IM_COMM_ID_BYTES 128
+typedef struct im_comm im_comm;
+int  im_comm_unique_id(void* id_bytes);
+int  im_comm_init(im_ctx* ctx, const void* id_bytes, int rank, int world, im_comm** out);
+/* every rank contributes bytes_per_rank bytes; recv_dev holds world * bytes_per_rank.  Asynchronous. */
+int  im_comm_allgather(im_comm* comm, const void* send_dev, void* recv_dev, size_t bytes_per_rank, void* stream);
+void im_comm_destroy(im_comm* comm);
+const char* im_comm_last_error(void);
+
+/* One 16-byte record per cluster, the unit that is gathered: {tid, b1, b2, cls<<24 | support}.
+ * recs[0] = {n_clusters, n_live_evidence, tid, 0}; cluster c at recs[1 + c]; cap = records the
+ * buffer holds (clusters beyond cap-1 are dropped and recs[0].w is set to 1).  counts = the
+ * device int32[2] written by im_dev_cluster_slots / n_clusters of im_dev_cluster_sr. */
+int im_dev_cluster_records(im_ctx* ctx, int32_t tid, const int32_t* counts,
+                           const int32_t* order, const int32_t* cl_first, const int32_t* cl_count,
+                           const int32_t* cls, const int32_t* b1, const int32_t* b2,
+                           int32_t* recs, int32_t cap, void* stream);
+
 /* ---- device memory / timing plumbing for callers without a HIP binding --- */
 
 /* hipMalloc / hipFree / hipMemcpy on the context's device.  im_dev_upload and

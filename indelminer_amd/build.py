@@ -7,7 +7,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libindelminer_amd.so")
-SOURCES = ["im_realign.hip", "im_cluster.hip", "im_capi.hip"]
+SOURCES = ["im_realign.hip", "im_cluster.hip", "im_capi.hip", "im_comm.hip"]
 HEADERS = [os.path.join(ROOT, "include", "indelminer_amd.h"), os.path.join(CSRC, "im_device.hpp")]
 
 
@@ -32,7 +32,7 @@ def build(force=False, verbose=False):
     cmd = [hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
            "-I" + os.path.join(ROOT, "include"), "-I" + CSRC]
     cmd += [os.path.join(CSRC, s) for s in SOURCES]
-    cmd += ["-o", LIB]
+    cmd += ["-ldl", "-o", LIB]
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)

@@ -110,6 +110,13 @@ def lib():
                                              C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
         L.im_dev_cluster_slots.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32,
                                            C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.im_dev_cluster_records.argtypes = [C.c_void_p, C.c_int32] + [C.c_void_p] * 8 + [C.c_int32, C.c_void_p]
+        L.im_comm_unique_id.argtypes = [C.c_void_p]
+        L.im_comm_init.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_void_p)]
+        L.im_comm_allgather.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
+        L.im_comm_destroy.argtypes = [C.c_void_p]
+        L.im_comm_destroy.restype = None
+        L.im_comm_last_error.restype = C.c_char_p
         L.im_dev_alloc.argtypes = [C.c_void_p, C.c_size_t, C.POINTER(C.c_void_p)]
         L.im_dev_free.argtypes = [C.c_void_p, C.c_void_p]
         L.im_dev_upload.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]
@@ -243,6 +250,39 @@ class Context:
                                         _ptr(order), _ptr(first), _ptr(count), _ptr(used), C.byref(ncl)))
         k = ncl.value
         return order[:n], first[:k], count[:k], used[:n], k
+
+
+COMM_ID_BYTES = 128
+
+
+def comm_unique_id():
+    buf = C.create_string_buffer(COMM_ID_BYTES)
+    rc = lib().im_comm_unique_id(buf)
+    if rc != IM_OK:
+        raise IMError(rc, lib().im_comm_last_error().decode())
+    return buf.raw
+
+
+class Comm:
+    """RCCL communicator over the C ABI (one all-gather of cluster lists per step)."""
+
+    def __init__(self, ctx, id_bytes, rank, world):
+        self.ctx, self.rank, self.world = ctx, rank, world
+        h = C.c_void_p()
+        rc = lib().im_comm_init(ctx.h, id_bytes, rank, world, C.byref(h))
+        if rc != IM_OK:
+            raise IMError(rc, lib().im_comm_last_error().decode())
+        self.h = h.value
+
+    def allgather(self, send_ptr, recv_ptr, bytes_per_rank, stream):
+        rc = lib().im_comm_allgather(self.h, send_ptr, recv_ptr, bytes_per_rank, stream)
+        if rc != IM_OK:
+            raise IMError(rc, lib().im_comm_last_error().decode())
+
+    def close(self):
+        if self.h:
+            lib().im_comm_destroy(self.h)
+            self.h = None
 
 
 def params(klength=6, numgaps=0, maxdelsize=1000, ethreshold=10):

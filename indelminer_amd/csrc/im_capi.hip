@@ -272,6 +272,17 @@ int im_dev_cluster_sr(im_ctx* ctx, int32_t n_cap, const int32_t* n_dev,
 
 int im_dev_cluster_slots_max(void) { return im::cluster_small_max(); }
 
+int im_dev_cluster_records(im_ctx* ctx, int32_t tid, const int32_t* counts,
+                           const int32_t* order, const int32_t* cl_first, const int32_t* cl_count,
+                           const int32_t* cls, const int32_t* b1, const int32_t* b2,
+                           int32_t* recs, int32_t cap, void* stream)
+{
+    if (!ctx || cap < 1) return IM_E_ARG;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, im::launch_cluster_records(tid, counts, order, cl_first, cl_count, cls, b1, b2, recs, cap, (hipStream_t)stream));
+    return IM_OK;
+}
+
 int im_dev_cluster_slots(im_ctx* ctx, int32_t n_slots, const int32_t* cls, const int32_t* b1, const int32_t* b2,
                          int32_t marker, int32_t tie_desc,
                          int32_t* order, int32_t* cl_first, int32_t* cl_count, uint8_t* used, int32_t* counts, void* stream)

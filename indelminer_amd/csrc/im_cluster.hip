@@ -463,6 +463,30 @@ hipError_t launch_cluster_sr(int32_t n_cap, const int32_t* n_dev,
     return hipGetLastError();
 }
 
+__global__ __launch_bounds__(256) void cluster_records_kernel(int32_t tid, const int32_t* __restrict__ counts,
+                                                             const int32_t* __restrict__ order, const int32_t* __restrict__ cl_first,
+                                                             const int32_t* __restrict__ cl_count,
+                                                             const int32_t* __restrict__ cls, const int32_t* __restrict__ b1,
+                                                             const int32_t* __restrict__ b2, int4* __restrict__ recs, int32_t cap)
+{
+    const int32_t ncl = max(counts[0], 0);
+    const int32_t lim = min(ncl, cap - 1);
+    for (int64_t c = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; c < lim; c += (int64_t)gridDim.x * blockDim.x) {
+        const int32_t e = order[cl_first[c]];
+        recs[1 + c] = make_int4(tid, b1[e], b2[e], (cls[e] << 24) | (cl_count[c] & 0xFFFFFF));
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) recs[0] = make_int4(counts[0], counts[1], tid, ncl > cap - 1 ? 1 : 0);
+}
+
+hipError_t launch_cluster_records(int32_t tid, const int32_t* counts, const int32_t* order, const int32_t* cl_first,
+                                  const int32_t* cl_count, const int32_t* cls, const int32_t* b1, const int32_t* b2,
+                                  int32_t* recs, int32_t cap, hipStream_t stream)
+{
+    hipLaunchKernelGGL(cluster_records_kernel, dim3(grid_for(cap, 256)), dim3(256), 0, stream,
+                       tid, counts, order, cl_first, cl_count, cls, b1, b2, reinterpret_cast<int4*>(recs), cap);
+    return hipGetLastError();
+}
+
 int cluster_small_max() { return kSmallMax; }
 
 hipError_t launch_cluster_small(int32_t n_slots, const int32_t* n_slots_dev,

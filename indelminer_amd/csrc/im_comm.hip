@@ -1,0 +1,105 @@
+// im_comm.hip -- the one data-path collective of the multi-GPU design: an RCCL
+// all-gather of per-shard cluster lists over xGMI.
+//
+// The reference has no communication at all (its only parallel mode is running
+// several processes with -c regions, src/indelminer.c:536-542,711-713); contigs are
+// independent, so the shards exchange nothing until each holds its cluster list.
+// librccl is loaded lazily (dlopen) so that single-GPU users never touch it.
+
+#include "im_device.hpp"
+
+#include <dlfcn.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <rccl/rccl.h>
+
+struct im_comm {
+    im_ctx* ctx;
+    ncclComm_t comm;
+    int rank, world;
+};
+
+namespace {
+
+struct RcclApi {
+    void* handle = nullptr;
+    ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
+    ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
+    ncclResult_t (*AllGather)(const void*, void*, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    const char* (*GetErrorString)(ncclResult_t) = nullptr;
+    char err[256] = {0};
+} g_rccl;
+
+bool load_rccl()
+{
+    if (g_rccl.handle) return true;
+    const char* names[] = { "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1" };
+    for (const char* n : names) { g_rccl.handle = dlopen(n, RTLD_NOW | RTLD_GLOBAL); if (g_rccl.handle) break; }
+    if (!g_rccl.handle) { snprintf(g_rccl.err, sizeof g_rccl.err, "cannot load librccl: %s", dlerror()); return false; }
+#define LOAD(field, sym) \
+    *(void**)(&g_rccl.field) = dlsym(g_rccl.handle, sym); \
+    if (!g_rccl.field) { snprintf(g_rccl.err, sizeof g_rccl.err, "librccl lacks %s", sym); return false; }
+    LOAD(GetUniqueId, "ncclGetUniqueId")
+    LOAD(CommInitRank, "ncclCommInitRank")
+    LOAD(AllGather, "ncclAllGather")
+    LOAD(CommDestroy, "ncclCommDestroy")
+    LOAD(GetErrorString, "ncclGetErrorString")
+#undef LOAD
+    return true;
+}
+
+}  // namespace
+
+extern "C" {
+
+int im_comm_unique_id(void* id_bytes)
+{
+    if (!id_bytes) return IM_E_ARG;
+    if (!load_rccl()) return IM_E_HIP;
+    ncclUniqueId id;
+    if (g_rccl.GetUniqueId(&id) != ncclSuccess) return IM_E_HIP;
+    memcpy(id_bytes, &id, IM_COMM_ID_BYTES);
+    return IM_OK;
+}
+
+const char* im_comm_last_error(void) { return g_rccl.err; }
+
+int im_comm_init(im_ctx* ctx, const void* id_bytes, int rank, int world, im_comm** out)
+{
+    if (!ctx || !id_bytes || !out || world < 1 || rank < 0 || rank >= world) return IM_E_ARG;
+    if (!load_rccl()) return IM_E_HIP;
+    ncclUniqueId id;
+    memcpy(&id, id_bytes, IM_COMM_ID_BYTES);
+    im_comm* c = new im_comm();
+    c->ctx = ctx; c->rank = rank; c->world = world;
+    ncclResult_t r = g_rccl.CommInitRank(&c->comm, world, id, rank);
+    if (r != ncclSuccess) {
+        snprintf(g_rccl.err, sizeof g_rccl.err, "ncclCommInitRank: %s", g_rccl.GetErrorString(r));
+        delete c;
+        return IM_E_HIP;
+    }
+    *out = c;
+    return IM_OK;
+}
+
+int im_comm_allgather(im_comm* c, const void* send_dev, void* recv_dev, size_t bytes_per_rank, void* stream)
+{
+    if (!c) return IM_E_ARG;
+    ncclResult_t r = g_rccl.AllGather(send_dev, recv_dev, bytes_per_rank, ncclInt8, c->comm, (hipStream_t)stream);
+    if (r != ncclSuccess) {
+        snprintf(g_rccl.err, sizeof g_rccl.err, "ncclAllGather: %s", g_rccl.GetErrorString(r));
+        return IM_E_HIP;
+    }
+    return IM_OK;
+}
+
+void im_comm_destroy(im_comm* c)
+{
+    if (!c) return;
+    if (g_rccl.CommDestroy) (void)g_rccl.CommDestroy(c->comm);
+    delete c;
+}
+
+}  // extern "C"

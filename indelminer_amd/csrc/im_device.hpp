@@ -45,6 +45,9 @@ hipError_t launch_cluster_sr(int32_t n_cap, const int32_t* n_dev,
                              uint8_t* used, int32_t* n_clusters,
                              void* scratch, size_t scratch_bytes, hipStream_t stream);
 
+hipError_t launch_cluster_records(int32_t tid, const int32_t* counts, const int32_t* order, const int32_t* cl_first,
+                                  const int32_t* cl_count, const int32_t* cls, const int32_t* b1, const int32_t* b2,
+                                  int32_t* recs, int32_t cap, hipStream_t stream);
 int cluster_small_max();
 hipError_t launch_cluster_small(int32_t n_slots, const int32_t* n_slots_dev,
                                 const int32_t* cls, const int32_t* b1, const int32_t* b2,

@@ -94,3 +94,32 @@ def test_cluster_slots_matches_oracle(gpu_ctx):
         used = d_used.download(np.uint8, n_slots)
         want = np.zeros(n_slots, np.uint8); want[idx[o_used.astype(bool)]] = 1
         assert np.array_equal(used, want)
+
+
+def test_cluster_records_and_rccl_allgather_world1(gpu_ctx):
+    """The gathered unit (16 B cluster records) and the RCCL all-gather entry point with one rank."""
+    import ctypes as C
+    from indelminer_amd import capi, shard
+    L = capi.lib()
+    n = 3000
+    cls, b1, b2 = _random_evidence(77, n, 40000)
+    o_order, o_first, o_count, o_used, o_k = _cluster_oracle(cls, b1, b2, 2**31 - 1, 0)
+    d = {k: capi.DevBuf(gpu_ctx, 4 * n).upload(v) for k, v in (("cls", cls), ("b1", b1), ("b2", b2))}
+    d_order = capi.DevBuf(gpu_ctx, 4 * n); d_first = capi.DevBuf(gpu_ctx, 4 * n); d_count = capi.DevBuf(gpu_ctx, 4 * n)
+    d_counts = capi.DevBuf(gpu_ctx, 64)
+    cap = 4096
+    d_recs = capi.DevBuf(gpu_ctx, 16 * cap); d_all = capi.DevBuf(gpu_ctx, 16 * cap)
+    st = gpu_ctx.stream
+    gpu_ctx._check(L.im_dev_cluster_slots(gpu_ctx.h, n, d["cls"].ptr, d["b1"].ptr, d["b2"].ptr, 2**31 - 1, 0,
+                                          d_order.ptr, d_first.ptr, d_count.ptr, None, d_counts.ptr, st))
+    gpu_ctx._check(L.im_dev_cluster_records(gpu_ctx.h, 3, d_counts.ptr, d_order.ptr, d_first.ptr, d_count.ptr,
+                                            d["cls"].ptr, d["b1"].ptr, d["b2"].ptr, d_recs.ptr, cap, st))
+    comm = capi.Comm(gpu_ctx, capi.comm_unique_id(), 0, 1)
+    comm.allgather(d_recs.ptr, d_all.ptr, 16 * cap, st)
+    gpu_ctx._check(L.im_stream_sync(gpu_ctx.h, st))
+    got, trunc = shard.merge_gathered(d_all.download(np.int32, 4 * cap), cap)
+    heads = o_order[o_first]
+    want = shard.pack_records(3, b1[heads], b2[heads], cls[heads], o_count, n, cap)
+    want, _ = shard.merge_gathered(want.reshape(-1), cap)
+    assert not trunc and np.array_equal(got, want)
+    comm.close()
