@@ -1,0 +1,467 @@
+/*
+ * hostio.c -- BGZF / BAM / BAI / FASTA readers of the indelminer host driver.
+ * Own code over zlib.  Formats: SAM/BAM specification sections 4.1-4.2, 5.
+ * Behaviour the reference observes through libbam is cited as SURVEY.md A.12 items.
+ */
+#define _POSIX_C_SOURCE 200809L
+#include "hostio.h"
+
+#include <ctype.h>
+#include <stdlib.h>
+#include <string.h>
+#include <zlib.h>
+
+/* ------------------------------------------------------------------ BGZF -- */
+
+#define BGZF_MAX_BLOCK 65536
+
+struct bgzf_reader {
+    FILE*    fp;
+    uint8_t  cbuf[BGZF_MAX_BLOCK + 64];
+    uint8_t  ubuf[BGZF_MAX_BLOCK];
+    int32_t  ulen, upos;
+    int64_t  block_coff;        /* file offset of the block in ubuf */
+    int64_t  next_coff;         /* file offset of the next block */
+    int      eof;
+};
+
+bgzf_reader* bgzf_open(const char* path)
+{
+    FILE* fp = fopen(path, "rb");
+    if (!fp) return NULL;
+    bgzf_reader* r = calloc(1, sizeof *r);
+    r->fp = fp;
+    return r;
+}
+
+void bgzf_close(bgzf_reader* r)
+{
+    if (!r) return;
+    fclose(r->fp);
+    free(r);
+}
+
+/* loads the block at r->next_coff; returns 1, 0 at EOF, -1 on error */
+static int bgzf_load_block(bgzf_reader* r)
+{
+    uint8_t* h = r->cbuf;
+    if (fseeko(r->fp, r->next_coff, SEEK_SET) != 0) return -1;
+    size_t got = fread(h, 1, 18, r->fp);
+    if (got == 0) { r->eof = 1; r->ulen = r->upos = 0; return 0; }
+    if (got < 18 || h[0] != 31 || h[1] != 139 || h[2] != 8 || !(h[3] & 4)) return -1;
+    const int xlen = h[10] | (h[11] << 8);
+    /* find the BC subfield */
+    int bsize = -1;
+    if (xlen == 6 && h[12] == 'B' && h[13] == 'C') bsize = h[16] | (h[17] << 8);
+    else {
+        uint8_t* x = malloc((size_t)xlen);
+        memcpy(x, h + 12, 6);
+        if (xlen > 6 && fread(x + 6, 1, (size_t)xlen - 6, r->fp) != (size_t)xlen - 6) { free(x); return -1; }
+        for (int i = 0; i + 4 <= xlen;) {
+            const int slen = x[i + 2] | (x[i + 3] << 8);
+            if (x[i] == 'B' && x[i + 1] == 'C' && slen == 2) bsize = x[i + 4] | (x[i + 5] << 8);
+            i += 4 + slen;
+        }
+        free(x);
+        if (fseeko(r->fp, r->next_coff + 18, SEEK_SET) != 0) return -1;
+    }
+    if (bsize < 0) return -1;
+    const int total = bsize + 1;
+    const int hdr = 12 + xlen;
+    const int remain = total - 18;
+    if (remain < 0 || total > BGZF_MAX_BLOCK + 64) return -1;
+    if (fread(h + 18, 1, (size_t)remain, r->fp) != (size_t)remain) return -1;
+    const int clen = total - hdr - 8;
+    z_stream zs;
+    memset(&zs, 0, sizeof zs);
+    if (inflateInit2(&zs, -15) != Z_OK) return -1;
+    zs.next_in = h + hdr; zs.avail_in = (uInt)clen;
+    zs.next_out = r->ubuf; zs.avail_out = BGZF_MAX_BLOCK;
+    const int zr = inflate(&zs, Z_FINISH);
+    const int ulen = (int)zs.total_out;
+    inflateEnd(&zs);
+    if (zr != Z_STREAM_END) return -1;
+    r->block_coff = r->next_coff;
+    r->next_coff += total;
+    r->ulen = ulen; r->upos = 0;
+    return 1;
+}
+
+int64_t bgzf_read(bgzf_reader* r, void* buf, int64_t n)
+{
+    uint8_t* out = buf;
+    int64_t done = 0;
+    while (done < n) {
+        if (r->upos >= r->ulen) {
+            if (r->eof) break;
+            int rc = bgzf_load_block(r);
+            if (rc < 0) return -1;
+            if (rc == 0) break;
+            if (r->ulen == 0) continue;     /* empty block (EOF marker) */
+        }
+        int64_t take = r->ulen - r->upos;
+        if (take > n - done) take = n - done;
+        memcpy(out + done, r->ubuf + r->upos, (size_t)take);
+        r->upos += (int32_t)take;
+        done += take;
+    }
+    return done;
+}
+
+int64_t bgzf_tell(const bgzf_reader* r)
+{
+    if (r->upos >= r->ulen) return r->next_coff << 16;      /* at a block boundary */
+    return (r->block_coff << 16) | (int64_t)r->upos;
+}
+
+int bgzf_seek(bgzf_reader* r, int64_t voffset)
+{
+    r->eof = 0;
+    r->next_coff = voffset >> 16;
+    r->ulen = r->upos = 0;
+    const int within = (int)(voffset & 0xffff);
+    if (within > 0) {
+        int rc = bgzf_load_block(r);
+        if (rc <= 0) return -1;
+        if (within > r->ulen) return -1;
+        r->upos = within;
+    }
+    return 0;
+}
+
+/* ------------------------------------------------------------------- BAM -- */
+
+static int rd_i32(bgzf_reader* r, int32_t* v)
+{
+    uint8_t b[4];
+    if (bgzf_read(r, b, 4) != 4) return -1;
+    *v = (int32_t)((uint32_t)b[0] | ((uint32_t)b[1] << 8) | ((uint32_t)b[2] << 16) | ((uint32_t)b[3] << 24));
+    return 0;
+}
+
+bam_header* bam_header_load(bgzf_reader* r)
+{
+    char magic[4];
+    if (bgzf_read(r, magic, 4) != 4 || memcmp(magic, "BAM\1", 4) != 0) return NULL;
+    int32_t l_text, n_ref;
+    if (rd_i32(r, &l_text)) return NULL;
+    char* text = malloc((size_t)l_text + 1);
+    if (bgzf_read(r, text, l_text) != l_text) { free(text); return NULL; }
+    free(text);
+    if (rd_i32(r, &n_ref)) return NULL;
+    bam_header* h = calloc(1, sizeof *h);
+    h->n_targets = n_ref;
+    h->target_name = calloc((size_t)(n_ref > 0 ? n_ref : 1), sizeof(char*));
+    h->target_len = calloc((size_t)(n_ref > 0 ? n_ref : 1), sizeof(int32_t));
+    for (int32_t i = 0; i < n_ref; i++) {
+        int32_t l_name;
+        if (rd_i32(r, &l_name)) { bam_header_free(h); return NULL; }
+        h->target_name[i] = calloc((size_t)l_name + 1, 1);
+        if (bgzf_read(r, h->target_name[i], l_name) != l_name) { bam_header_free(h); return NULL; }
+        if (rd_i32(r, &h->target_len[i])) { bam_header_free(h); return NULL; }
+    }
+    return h;
+}
+
+void bam_header_free(bam_header* h)
+{
+    if (!h) return;
+    for (int32_t i = 0; i < h->n_targets; i++) free(h->target_name[i]);
+    free(h->target_name); free(h->target_len); free(h);
+}
+
+int bam_read_record(bgzf_reader* r, bam_record* b)
+{
+    uint8_t c[36];
+    int64_t got = bgzf_read(r, c, 4);
+    if (got == 0) return 0;
+    if (got != 4) return -1;
+    const int32_t block_size = (int32_t)((uint32_t)c[0] | ((uint32_t)c[1] << 8) | ((uint32_t)c[2] << 16) | ((uint32_t)c[3] << 24));
+    if (block_size < 32) return -1;
+    if (bgzf_read(r, c, 32) != 32) return -1;
+#define U32(o) ((uint32_t)c[o] | ((uint32_t)c[(o) + 1] << 8) | ((uint32_t)c[(o) + 2] << 16) | ((uint32_t)c[(o) + 3] << 24))
+    b->tid = (int32_t)U32(0); b->pos = (int32_t)U32(4);
+    b->l_qname = c[8]; b->mapq = c[9]; b->bin = (uint16_t)(c[10] | (c[11] << 8));
+    b->n_cigar = (uint16_t)(c[12] | (c[13] << 8)); b->flag = (uint16_t)(c[14] | (c[15] << 8));
+    b->l_seq = (int32_t)U32(16); b->mtid = (int32_t)U32(20); b->mpos = (int32_t)U32(24); b->isize = (int32_t)U32(28);
+#undef U32
+    b->l_data = block_size - 32;
+    if (b->l_data + 8 > b->m_data) { b->m_data = b->l_data + 64; b->data = realloc(b->data, (size_t)b->m_data); }
+    if (bgzf_read(r, b->data, b->l_data) != b->l_data) return -1;
+    return 1;
+}
+
+int32_t bam_record_end(const bam_record* b)
+{
+    /* bam_calend (bam.c:17-39): M, D, N, =, X consume the reference */
+    const uint32_t* cig = BAMR_CIGAR(b);
+    int32_t end = b->pos;
+    for (int k = 0; k < b->n_cigar; k++) {
+        const int op = (int)(cig[k] & 15u);
+        if (op == 0 || op == 2 || op == 3 || op == 7 || op == 8) end += (int32_t)(cig[k] >> 4);
+    }
+    return end;
+}
+
+static int aux_size(int type)
+{
+    switch (type) {
+    case 'A': case 'c': case 'C': return 1;
+    case 's': case 'S': return 2;
+    case 'i': case 'I': case 'f': return 4;
+    case 'd': return 8;
+    default: return 0;
+    }
+}
+
+const uint8_t* bam_aux_find(const bam_record* b, const char tag[2])
+{
+    const uint8_t* s = BAMR_AUX(b);
+    const uint8_t* end = b->data + b->l_data;
+    while (s + 3 <= end) {
+        const int hit = (s[0] == (uint8_t)tag[0] && s[1] == (uint8_t)tag[1]);
+        const int type = s[2];
+        const uint8_t* v = s + 2;
+        s += 3;
+        if (hit) return v;
+        if (type == 'Z' || type == 'H') { while (s < end && *s) s++; s++; }
+        else if (type == 'B') {
+            if (s + 5 > end) return NULL;
+            const int sz = aux_size(s[0]);
+            const uint32_t cnt = (uint32_t)s[1] | ((uint32_t)s[2] << 8) | ((uint32_t)s[3] << 16) | ((uint32_t)s[4] << 24);
+            s += 5 + (size_t)sz * cnt;
+        } else {
+            const int sz = aux_size(type);
+            if (sz == 0) return NULL;
+            s += sz;
+        }
+    }
+    return NULL;
+}
+
+int32_t bam_aux_int(const uint8_t* s)
+{
+    if (!s) return 0;
+    const int type = *s++;
+    switch (type) {
+    case 'c': return (int32_t)(int8_t)s[0];
+    case 'C': return (int32_t)s[0];
+    case 's': return (int32_t)(int16_t)(s[0] | (s[1] << 8));
+    case 'S': return (int32_t)(uint16_t)(s[0] | (s[1] << 8));
+    case 'i': case 'I': return (int32_t)((uint32_t)s[0] | ((uint32_t)s[1] << 8) | ((uint32_t)s[2] << 16) | ((uint32_t)s[3] << 24));
+    default: return 0;
+    }
+}
+
+const char* bam_aux_str(const uint8_t* s) { return (const char*)(s + 1); }
+
+/* ------------------------------------------------------------------- BAI -- */
+
+typedef struct {
+    int32_t   n_intv;
+    uint64_t* ioffset;
+    uint64_t  first_chunk;      /* smallest chunk start of any real bin, 0 if none */
+} bai_ref;
+
+struct bai_index {
+    int32_t  n_ref;
+    bai_ref* ref;
+};
+
+static int frd(FILE* fp, void* p, size_t n) { return fread(p, 1, n, fp) == n ? 0 : -1; }
+
+bai_index* bai_load(const char* bam_path)
+{
+    size_t l = strlen(bam_path);
+    char* path = malloc(l + 8);
+    sprintf(path, "%s.bai", bam_path);
+    FILE* fp = fopen(path, "rb");
+    if (!fp && l > 4 && strcmp(bam_path + l - 4, ".bam") == 0) {   /* x.bam -> x.bai */
+        strcpy(path, bam_path);
+        strcpy(path + l - 3, "bai");
+        fp = fopen(path, "rb");
+    }
+    free(path);
+    if (!fp) return NULL;
+    char magic[4];
+    int32_t n_ref;
+    if (frd(fp, magic, 4) || memcmp(magic, "BAI\1", 4) != 0 || frd(fp, &n_ref, 4)) { fclose(fp); return NULL; }
+    bai_index* idx = calloc(1, sizeof *idx);
+    idx->n_ref = n_ref;
+    idx->ref = calloc((size_t)(n_ref > 0 ? n_ref : 1), sizeof(bai_ref));
+    for (int32_t i = 0; i < n_ref; i++) {
+        int32_t n_bin;
+        if (frd(fp, &n_bin, 4)) goto fail;
+        uint64_t first = 0;
+        for (int32_t j = 0; j < n_bin; j++) {
+            uint32_t bin; int32_t n_chunk;
+            if (frd(fp, &bin, 4) || frd(fp, &n_chunk, 4)) goto fail;
+            for (int32_t c = 0; c < n_chunk; c++) {
+                uint64_t uv[2];
+                if (frd(fp, uv, 16)) goto fail;
+                if (bin != 37450 && (first == 0 || uv[0] < first)) first = uv[0];
+            }
+        }
+        idx->ref[i].first_chunk = first;
+        if (frd(fp, &idx->ref[i].n_intv, 4)) goto fail;
+        idx->ref[i].ioffset = calloc((size_t)(idx->ref[i].n_intv > 0 ? idx->ref[i].n_intv : 1), 8);
+        if (idx->ref[i].n_intv > 0 && frd(fp, idx->ref[i].ioffset, 8 * (size_t)idx->ref[i].n_intv)) goto fail;
+    }
+    fclose(fp);
+    return idx;
+fail:
+    fclose(fp);
+    bai_free(idx);
+    return NULL;
+}
+
+void bai_free(bai_index* idx)
+{
+    if (!idx) return;
+    for (int32_t i = 0; i < idx->n_ref; i++) free(idx->ref[i].ioffset);
+    free(idx->ref); free(idx);
+}
+
+int bam_region_begin(bam_region_iter* it, bgzf_reader* r, const bai_index* idx, int32_t tid, int32_t beg, int32_t end)
+{
+    memset(it, 0, sizeof *it);
+    it->r = r; it->tid = tid; it->beg = beg < 0 ? 0 : beg; it->end = end;
+    if (!idx || tid < 0 || tid >= idx->n_ref || end < it->beg) { it->done = 1; return 0; }
+    const bai_ref* br = &idx->ref[tid];
+    if (br->first_chunk == 0) { it->done = 1; return 0; }        /* no record on this contig */
+    /* smallest offset of any record overlapping the 16 kb window of beg (bam_index.c:605-615);
+     * every record that overlaps [beg,end) starts at or after it, the file is coordinate sorted */
+    uint64_t min_off = 0;
+    if (br->n_intv > 0) {
+        int32_t w = it->beg >> 14;
+        min_off = (w >= br->n_intv) ? br->ioffset[br->n_intv - 1] : br->ioffset[w];
+        if (min_off == 0) {
+            int32_t n = w > br->n_intv ? br->n_intv : w;
+            for (int32_t i = n - 1; i >= 0; i--) if (br->ioffset[i] != 0) { min_off = br->ioffset[i]; break; }
+        }
+    }
+    if (min_off < br->first_chunk) min_off = br->first_chunk;
+    if (bgzf_seek(r, (int64_t)min_off) != 0) return -1;
+    return 0;
+}
+
+int bam_region_next(bam_region_iter* it, bam_record* b)
+{
+    while (!it->done) {
+        int rc = bam_read_record(it->r, b);
+        if (rc <= 0) { it->done = 1; return rc; }
+        if (b->tid != it->tid || b->pos >= it->end) { it->done = 1; return 0; }   /* bam_index.c:704-707 */
+        const uint32_t rbeg = (uint32_t)b->pos;
+        const uint32_t rend = b->n_cigar ? (uint32_t)bam_record_end(b) : (uint32_t)b->pos + 1u;   /* bam_index.c:571-576 */
+        if (rend > (uint32_t)it->beg && rbeg < (uint32_t)it->end) return 1;
+    }
+    return 0;
+}
+
+int bam_parse_region_str(const bam_header* h, const char* str, int* tid, int* beg, int* end)
+{
+    /* bam_parse_region (bam_aux.c:107-161): spaces dropped, last ':' splits the name, commas
+     * ignored, 1-based begin -> 0-based, missing end = 2^29 */
+    *tid = *beg = *end = -1;
+    size_t l = strlen(str);
+    char* s = malloc(l + 1);
+    size_t k = 0;
+    for (size_t i = 0; i < l; i++) if (!isspace((unsigned char)str[i])) s[k++] = str[i];
+    s[k] = 0; l = k;
+    long name_end = (long)l;
+    for (long i = (long)l - 1; i >= 0; i--) if (s[i] == ':') { name_end = i; break; }
+    int found = -1;
+    if (name_end < (long)l) {
+        int n_hyphen = 0; long i;
+        for (i = name_end + 1; i < (long)l; i++) {
+            if (s[i] == '-') n_hyphen++;
+            else if (!isdigit((unsigned char)s[i]) && s[i] != ',') break;
+        }
+        if (i < (long)l || n_hyphen > 1) name_end = (long)l;
+        char save = s[name_end]; s[name_end] = 0;
+        for (int32_t t = 0; t < h->n_targets; t++) if (strcmp(h->target_name[t], s) == 0) { found = t; break; }
+        if (found < 0) {
+            for (int32_t t = 0; t < h->n_targets; t++) if (strcmp(h->target_name[t], str) == 0) { found = t; break; }
+            if (found < 0) { free(s); return -1; }
+            s[name_end] = save; name_end = (long)l;
+        }
+    } else {
+        for (int32_t t = 0; t < h->n_targets; t++) if (strcmp(h->target_name[t], str) == 0) { found = t; break; }
+    }
+    if (found < 0) { free(s); return -1; }
+    *tid = found;
+    if (name_end < (long)l) {
+        long i, kk;
+        for (i = kk = name_end + 1; i < (long)l; i++) if (s[i] != ',') s[kk++] = s[i];
+        s[kk] = 0;
+        *beg = atoi(s + name_end + 1);
+        for (i = name_end + 1; i != kk; i++) if (s[i] == '-') break;
+        *end = i < kk ? atoi(s + i + 1) : 1 << 29;
+        if (*beg > 0) --*beg;
+    } else { *beg = 0; *end = 1 << 29; }
+    free(s);
+    return *beg <= *end ? 0 : -1;
+}
+
+/* ----------------------------------------------------------------- FASTA -- */
+
+static int fasta_keep(int ch)
+{
+    /* bases[] of src/sequences.c:6-20: A B C D G H K M N R S T V W Y in either case */
+    switch (ch) {
+    case 'A': case 'B': case 'C': case 'D': case 'G': case 'H': case 'K': case 'M': case 'N': case 'R':
+    case 'S': case 'T': case 'V': case 'W': case 'Y':
+    case 'a': case 'b': case 'c': case 'd': case 'g': case 'h': case 'k': case 'm': case 'n': case 'r':
+    case 's': case 't': case 'v': case 'w': case 'y':
+        return 1;
+    default:
+        return 0;
+    }
+}
+
+int fasta_load(const char* path, int32_t n_expected, char*** seqs_out, int64_t** lens_out, int only_index)
+{
+    FILE* fp = fopen(path, "rb");
+    if (!fp) return -1;
+    char** seqs = calloc((size_t)(n_expected > 0 ? n_expected : 1), sizeof(char*));
+    int64_t* lens = calloc((size_t)(n_expected > 0 ? n_expected : 1), sizeof(int64_t));
+    int32_t indx = 0;
+    int ch = fgetc(fp);
+    while (ch == ' ' || ch == '\t') ch = fgetc(fp);
+    while (ch == '>') {
+        /* header: everything up to the newline (src/sequences.c:73-80) */
+        do { ch = fgetc(fp); } while (ch != '\n' && ch != EOF);
+        size_t cap = 1 << 16, len = 0;
+        const int keep = (only_index < 0 || only_index == indx) && indx < n_expected;
+        char* buf = keep ? malloc(cap) : NULL;
+        for (;;) {
+            ch = fgetc(fp);
+            if (ch == '>' || ch == EOF) break;
+            if (keep && fasta_keep(ch)) {
+                if (len + 2 > cap) { cap *= 2; buf = realloc(buf, cap); }
+                buf[len++] = (char)toupper(ch);                      /* src/shared.c:66-69 */
+            }
+        }
+        if (keep) { buf[len] = 0; seqs[indx] = buf; lens[indx] = (int64_t)len; }
+        indx++;
+    }
+    fclose(fp);
+    *seqs_out = seqs; *lens_out = lens;
+    return indx;        /* caller checks indx == n_targets (forceassert, src/shared.c:77) */
+}
+
+/* ------------------------------------------------------------- getline -- */
+
+long im_getline(char** lineptr, size_t* cap, FILE* fp)
+{
+    int ch = EOF;
+    size_t size = 0;
+    while ((ch = fgetc(fp)) != EOF) {
+        if (size + 2 > *cap) { *cap = size + (size >> 5) + 16; *lineptr = realloc(*lineptr, *cap); }
+        (*lineptr)[size++] = (char)ch;
+        if (ch == '\n') break;
+    }
+    if (size != 0) (*lineptr)[size] = 0;
+    if (size == 0 || ch == EOF) return -1;       /* a final line without '\n' is dropped (src/files.c:50-52) */
+    return (long)size;
+}

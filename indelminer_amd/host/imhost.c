@@ -1,0 +1,1382 @@
+/*
+ * imhost.c -- the indelminer host driver: same CLI, config file and VCF output as the
+ * reference (src/indelminer.c), with the split-read realignment and the split-read
+ * clustering done on the GPU through the C ABI of include/indelminer_amd.h.
+ *
+ * Host side = what BASELINE.json's north_star keeps on the host: BAM decode, the
+ * fetch_func dispatch rules, insert-length estimation, paired-read evidence, variant
+ * merge / filter / emit.  There is no CPU implementation of the two GPU seams in this
+ * program: without the device it stops with the library's error.
+ *
+ * Two passes per contig:
+ *   pass A  walk the BAM records, apply fetch_func's rules (src/indelminer.c:339-615),
+ *           collect candidate reads, CIGAR-derived and paired-read evidence in arrival
+ *           order, and record every READCHUNK flush point with its marker (617-623)
+ *   GPU     one im_realign_batch over the contig's candidates
+ *   pass B  replay: evidence enters the pending list in arrival order; at every flush
+ *           point process_evidence -> sort -> merge -> print exactly as the reference
+ */
+#define _POSIX_C_SOURCE 200809L
+#include "imhost.h"
+
+#include <ctype.h>
+#include <getopt.h>
+#include <limits.h>
+#include <math.h>
+#include <stdarg.h>
+#include <stdlib.h>
+#include <string.h>
+#include <time.h>
+
+#define INDELMINER_VERSION 0.2          /* src/indelminer.c:26 */
+
+#define OP_M 0
+#define OP_I 1
+#define OP_D 2
+#define OP_N 3
+#define OP_S 4
+#define OP_H 5
+#define OP_P 6
+#define OP_EQ 7
+#define OP_X 8
+#define CIG_OP(c)  ((int)((c) & 15u))
+#define CIG_LEN(c) ((int)((c) >> 4))
+
+static im_options O;
+static time_t t0;
+
+static void fatalf(const char* fmt, ...)
+{
+    /* src/errors.c:15-27: message on stderr, exit(1) */
+    va_list ap;
+    va_start(ap, fmt);
+    fflush(stdout);
+    fprintf(stderr, "indelminer: ");
+    vfprintf(stderr, fmt, ap);
+    fprintf(stderr, "\n");
+    va_end(ap);
+    exit(EXIT_FAILURE);
+}
+#define forceassert(e) do { if (!(e)) { fprintf(stderr, "Assertion failed: %s file %s line %d\n", #e, __FILE__, __LINE__); exit(EXIT_FAILURE); } } while (0)
+
+static void timestamp(const char* fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vfprintf(stderr, fmt, ap);
+    fprintf(stderr, " : %ld sec. elapsed\n", (long)(time(0) - t0));
+    va_end(ap);
+}
+
+static void* xmalloc(size_t n) { void* p = malloc(n ? n : 1); if (!p) { fprintf(stderr, "out of memory\n"); exit(2); } return p; }
+static void* xcalloc(size_t n, size_t s) { void* p = calloc(n ? n : 1, s ? s : 1); if (!p) { fprintf(stderr, "out of memory\n"); exit(2); } return p; }
+static void* xrealloc(void* p, size_t n) { p = realloc(p, n ? n : 1); if (!p) { fprintf(stderr, "out of memory\n"); exit(2); } return p; }
+static char* xstrdup(const char* s) { size_t l = strlen(s); char* d = xmalloc(l + 1); memcpy(d, s, l + 1); return d; }
+
+/* ------------------------------------------------------------------ qhash -- */
+
+static uint32_t djb2_rev(const char* data, int len)
+{
+    uint32_t result = 5381;
+    for (int i = len - 1; i >= 0; i--) result += (result << 5) + (uint32_t)(int)data[i];
+    return result;
+}
+
+qhash* qhash_new(int po2size)
+{
+    qhash* h = xcalloc(1, sizeof *h);
+    h->po2 = po2size > 24 ? 24 : po2size;
+    h->mask = (1u << h->po2) - 1u;
+    h->bins = xcalloc((size_t)1 << h->po2, sizeof(qbin*));
+    return h;
+}
+
+void qhash_add(qhash* h, const char* name, int len, void* val)
+{
+    const uint32_t idx = djb2_rev(name, len) & h->mask;
+    qbin* b = xcalloc(1, sizeof *b);
+    b->name = xmalloc((size_t)len + 1);
+    memcpy(b->name, name, (size_t)len);
+    b->name[len] = 0;
+    b->val = val;
+    b->next = h->bins[idx];
+    h->bins[idx] = b;
+}
+
+qbin* qhash_lookup(qhash* h, const char* name, int len)
+{
+    const uint32_t idx = djb2_rev(name, len) & h->mask;
+    qbin* hit = NULL;
+    for (qbin* it = h->bins[idx]; it; it = it->next)
+        if (strncmp(it->name, name, (size_t)len) == 0) hit = it;      /* LAST match (src/hashtable.c:73-79) */
+    return hit;
+}
+
+void* qhash_remove(qhash* h, const char* name, int len)
+{
+    const uint32_t idx = djb2_rev(name, len) & h->mask;
+    qbin** pp = &h->bins[idx];
+    for (; *pp; pp = &(*pp)->next) {
+        if (strncmp((*pp)->name, name, (size_t)len) == 0) {           /* FIRST match (src/hashtable.c:133-141) */
+            qbin* b = *pp;
+            void* v = b->val;
+            *pp = b->next;
+            free(b->name); free(b);
+            return v;
+        }
+    }
+    return NULL;
+}
+
+void qhash_free(qhash* h, void (*free_val)(void*))
+{
+    if (!h) return;
+    for (uint32_t i = 0; i <= h->mask; i++) {
+        qbin* it = h->bins[i];
+        while (it) { qbin* n = it->next; if (free_val) free_val(it->val); free(it->name); free(it); it = n; }
+    }
+    free(h->bins); free(h);
+}
+
+/* --------------------------------------------------------------- seglists -- */
+
+static const char kRevcomp[256] = {
+    ['A'] = 'T', ['C'] = 'G', ['G'] = 'C', ['T'] = 'A', ['N'] = 'N',
+    ['a'] = 't', ['c'] = 'g', ['g'] = 'c', ['t'] = 'a', ['n'] = 'n',
+};
+
+static char bit2char(int enc)
+{
+    /* src/readaln.c:4-17 */
+    switch (enc & 0xF) {
+    case 1: return 'A';
+    case 2: return 'C';
+    case 4: return 'G';
+    case 8: return 'T';
+    case 15: return 'N';
+    default: fatalf("Unhandled base encoding : %d:%d", enc, enc & 0xF);
+    }
+    return 'X';
+}
+
+static char* decode_bases(const bam_record* b)
+{
+    char* s = xmalloc((size_t)b->l_seq + 1);
+    const uint8_t* q = BAMR_SEQ(b);
+    for (int i = 0; i < b->l_seq; i++) s[i] = bit2char(BAMR_SEQI(q, i));
+    s[b->l_seq] = 0;
+    return s;
+}
+
+static void revcomp_inplace(char* s)
+{
+    /* reverse_complement_string, src/sequences.c:204-220 with the table at 22-26 */
+    const size_t n = strlen(s);
+    for (size_t i = 0; i < n / 2; i++) { const char t = s[i]; s[i] = s[n - 1 - i]; s[n - 1 - i] = t; }
+    for (size_t i = 0; i < n; i++) { const char c = kRevcomp[(unsigned char)s[i]]; s[i] = c ? c : ' '; }
+}
+
+/* new_readaln for an aligned record (src/readaln.c:192-239): CIGAR ops verbatim; N/H/P are
+ * "Implement" fatals there (new_readseg_bam 163-180) */
+static seglist seglist_from_record(const bam_record* b)
+{
+    seglist s;
+    s.ref_start = b->pos;
+    s.n = b->n_cigar;
+    s.ops = xmalloc(sizeof(uint32_t) * (size_t)(b->n_cigar ? b->n_cigar : 1));
+    const uint32_t* cig = BAMR_CIGAR(b);
+    for (int i = 0; i < b->n_cigar; i++) {
+        const int op = CIG_OP(cig[i]);
+        if (op == OP_N || op == OP_H || op == OP_P) fatalf("Implement new_readseg_bam: CIGAR op %d", op);
+        if (op > OP_X) fatalf("Unhandled cigar operation");
+        s.ops[i] = cig[i];
+    }
+    s.bases = decode_bases(b);
+    return s;
+}
+
+static seglist seglist_copy(const seglist* a)
+{
+    seglist s = *a;
+    s.ops = xmalloc(sizeof(uint32_t) * (size_t)(a->n ? a->n : 1));
+    memcpy(s.ops, a->ops, sizeof(uint32_t) * (size_t)a->n);
+    s.bases = xstrdup(a->bases);
+    return s;
+}
+
+static void seglist_free(seglist* s) { free(s->ops); free(s->bases); s->ops = NULL; s->bases = NULL; s->n = 0; }
+
+static int seglist_first_start(const seglist* s) { return s->ref_start; }
+
+static int seglist_last_end(const seglist* s)
+{
+    int r = s->ref_start;
+    for (int i = 0; i < s->n; i++) {
+        const int op = CIG_OP(s->ops[i]);
+        if (op == OP_M || op == OP_EQ || op == OP_X || op == OP_D) r += CIG_LEN(s->ops[i]);
+    }
+    return r;   /* end of the last segment: segments that consume no reference end where they start */
+}
+
+/* flank / difference reductions of print_variants and print_vcf_output over the segments
+ * [from,to) of a list (src/variant.c:217-274 and 704-767) */
+static void seg_reduce(const seglist* a, int from, int to, const char* ref,
+                       int32_t* flank, int32_t* nd_print, int32_t* nd_filter)
+{
+    int refpos = a->ref_start, readpos = 0;
+    for (int i = 0; i < a->n; i++) {
+        const int op = CIG_OP(a->ops[i]), len = CIG_LEN(a->ops[i]);
+        if (i >= from && i < to) {
+            switch (op) {
+            case OP_M:
+                *flank += len;
+                for (int j = 0; j < len; j++)
+                    if (a->bases[readpos + j] != ref[refpos + j]) { *nd_print += 1; *nd_filter += 1; }
+                break;
+            case OP_EQ: *flank += len; break;
+            case OP_X: *flank += len; *nd_print += len; *nd_filter += len; break;
+            case OP_I: *flank += len; *nd_print += len; *nd_filter += len; break;
+            case OP_D: *nd_print += len; *nd_filter += len; break;
+            case OP_S: *nd_filter += len; break;
+            default: fatalf("unhandled BAM operation");
+            }
+        }
+        if (op == OP_M || op == OP_EQ || op == OP_X || op == OP_D) refpos += len;
+        if (op != OP_D) readpos += len;
+    }
+}
+
+/* ---------------------------------------------------------------- evidence -- */
+
+static evidence_t* evidence_new_sr(const seglist* whole, int seg, int cls, char strand, uint8_t qual,
+                                   const char* qname, const char* ref)
+{
+    /* new_evidence for SPLIT_READ (src/evidence.c:4-34): aln1 = segments before, aln2 = the
+     * indel segment, aln3 = the rest; b1/b2 = the segment's start/end */
+    evidence_t* e = xcalloc(1, sizeof *e);
+    e->type = EV_SPLIT_READ; e->cls = cls; e->strand = strand; e->qual = qual;
+    e->qname = xstrdup(qname);
+    e->aln = seglist_copy(whole);
+    e->seg = seg;
+    int refpos = whole->ref_start;
+    for (int i = 0; i < seg; i++) {
+        const int op = CIG_OP(whole->ops[i]);
+        if (op == OP_M || op == OP_EQ || op == OP_X || op == OP_D) refpos += CIG_LEN(whole->ops[i]);
+    }
+    e->b1 = refpos;
+    e->b2 = (CIG_OP(whole->ops[seg]) == OP_D) ? refpos + CIG_LEN(whole->ops[seg]) : refpos;
+    seg_reduce(whole, 0, seg, ref, &e->lflank, &e->nd_print, &e->nd_filter);
+    seg_reduce(whole, seg + 1, whole->n, ref, &e->rflank, &e->nd_print, &e->nd_filter);
+    return e;
+}
+
+static void evidence_free(evidence_t* e)
+{
+    if (!e) return;
+    free(e->qname);
+    seglist_free(&e->aln);
+    if (e->aln3.ops || e->aln3.bases) seglist_free(&e->aln3);
+    free(e);
+}
+
+/* check_variants (src/indelminer.c:285-337): evidence from the aligner's own CIGAR.
+ * Returned in segment order (left to right); out[] must hold rln->n entries. */
+static int check_variants(const seglist* rln, char strand, uint8_t qual, const char* qname, const char* ref,
+                          evidence_t** out)
+{
+    uint32_t rpos = 0, tpos = 0;
+    for (int i = 0; i < rln->n; i++) {
+        const int op = CIG_OP(rln->ops[i]);
+        if (op == OP_EQ || op == OP_X || op == OP_M || op == OP_I) tpos += (uint32_t)CIG_LEN(rln->ops[i]);
+    }
+    int n = 0;
+    for (int i = 0; i < rln->n; i++) {
+        const int op = CIG_OP(rln->ops[i]);
+        if (op == OP_D || op == OP_I) {
+            if (rpos > O.ethreshold_vcfcheck && (tpos - rpos) > O.ethreshold_vcfcheck)
+                out[n++] = evidence_new_sr(rln, i, op == OP_D ? CLS_DELETION : CLS_INSERTION, strand, qual, qname, ref);
+        } else if (op == OP_M || op == OP_EQ || op == OP_X) {
+            rpos += (uint32_t)CIG_LEN(rln->ops[i]);
+        } else if (op == OP_S) {
+            forceassert(i == 0 || i == rln->n - 1);
+        } else fatalf("unknown cigar op");
+    }
+    return n;
+}
+
+/* ------------------------------------------------------------------ pass A -- */
+
+enum { ITEM_CAND = 1, ITEM_PE = 2 };
+
+typedef struct {
+    int kind;
+    int cand;                   /* ITEM_CAND: index into the candidate batch */
+    evidence_t** bwa; int nbwa; /* ITEM_CAND: CIGAR-derived fallback (src/indelminer.c:504-510) */
+    evidence_t* pe;             /* ITEM_PE */
+} item_t;
+
+typedef struct { int64_t n_items; int marker; int32_t tid; } flush_t;
+
+typedef struct {
+    /* candidate batch of the contig, struct of arrays for im_realign_batch */
+    int32_t n, cap;
+    uint8_t* bases; int64_t bases_len, bases_cap;
+    int64_t* base_off;
+    int32_t *tid, *anchor, *range_max;
+    char** qname; char* strand; uint8_t* qual;
+} cand_batch;
+
+typedef struct {
+    im_ctx* gpu;
+    bam_header* hdr;
+    char** sequences; int64_t* seqlen;
+    qhash* insertlengths;
+    qhash* readpairs;
+    const char* bam_name;
+    bai_index* idx;
+    int64_t numread;
+    item_t* items; int64_t n_items, cap_items;
+    flush_t* flushes; int n_flushes, cap_flushes;
+    cand_batch cb;
+    evidence_t** pending; int64_t n_pending, cap_pending;
+    int64_t arrival;
+} driver;
+
+static void cb_push(cand_batch* cb, const char* bases, int32_t tid, int32_t anchor, int32_t range_max,
+                    const char* qname, char strand, uint8_t qual)
+{
+    if (cb->n == cb->cap) {
+        cb->cap = cb->cap ? cb->cap * 2 : 4096;
+        cb->base_off = xrealloc(cb->base_off, sizeof(int64_t) * ((size_t)cb->cap + 1));
+        cb->tid = xrealloc(cb->tid, sizeof(int32_t) * (size_t)cb->cap);
+        cb->anchor = xrealloc(cb->anchor, sizeof(int32_t) * (size_t)cb->cap);
+        cb->range_max = xrealloc(cb->range_max, sizeof(int32_t) * (size_t)cb->cap);
+        cb->qname = xrealloc(cb->qname, sizeof(char*) * (size_t)cb->cap);
+        cb->strand = xrealloc(cb->strand, (size_t)cb->cap);
+        cb->qual = xrealloc(cb->qual, (size_t)cb->cap);
+    }
+    const size_t l = strlen(bases);
+    if (cb->bases_len + (int64_t)l + 16 > cb->bases_cap) {
+        cb->bases_cap = (cb->bases_cap ? cb->bases_cap * 2 : (1 << 20)) + (int64_t)l;
+        cb->bases = xrealloc(cb->bases, (size_t)cb->bases_cap);
+    }
+    memcpy(cb->bases + cb->bases_len, bases, l);
+    cb->base_off[cb->n] = cb->bases_len;
+    cb->bases_len += (int64_t)l;
+    cb->base_off[cb->n + 1] = cb->bases_len;
+    cb->tid[cb->n] = tid; cb->anchor[cb->n] = anchor; cb->range_max[cb->n] = range_max;
+    cb->qname[cb->n] = xstrdup(qname); cb->strand[cb->n] = strand; cb->qual[cb->n] = qual;
+    cb->n++;
+}
+
+static void cb_reset(cand_batch* cb)
+{
+    for (int32_t i = 0; i < cb->n; i++) free(cb->qname[i]);
+    cb->n = 0; cb->bases_len = 0;
+}
+
+static item_t* push_item(driver* d)
+{
+    if (d->n_items == d->cap_items) {
+        d->cap_items = d->cap_items ? d->cap_items * 2 : 4096;
+        d->items = xrealloc(d->items, sizeof(item_t) * (size_t)d->cap_items);
+    }
+    item_t* it = &d->items[d->n_items++];
+    memset(it, 0, sizeof *it);
+    return it;
+}
+
+static int find_marker(const qhash* readpairs)
+{
+    /* src/indelminer.c:211-233: smallest aln1->start among the pairs still waiting for a mate */
+    int m = INT_MAX;
+    for (uint32_t i = 0; i <= readpairs->mask; i++)
+        for (const qbin* it = readpairs->bins[i]; it; it = it->next) {
+            const evidence_t* e = it->val;
+            if (seglist_first_start(&e->aln) < m) m = seglist_first_start(&e->aln);
+        }
+    return m;
+}
+
+/* find_mate_rln (src/indelminer.c:256-280): look the mate up in the BAM when it is not in the
+ * pair table (region runs).  Returns 1 and fills *out when found. */
+static int find_mate(driver* d, int32_t tid, int32_t pos, char want_index, const char* qname, seglist* out, char* strand)
+{
+    bgzf_reader* r = bgzf_open(d->bam_name);
+    if (!r) return 0;
+    bam_header* h = bam_header_load(r);
+    bam_region_iter it;
+    bam_record b; memset(&b, 0, sizeof b);
+    int found = 0;
+    if (h && bam_region_begin(&it, r, d->idx, tid, pos, pos + 1) == 0) {
+        while (bam_region_next(&it, &b) == 1) {
+            if (strcmp(BAMR_QNAME(&b), qname) != 0) continue;
+            const char index = (b.flag & 0x40) ? '1' : '2';
+            if (index != want_index) continue;
+            if (b.flag & 0x4) continue;     /* check_for_mate goes through new_readaln: unaligned mates leave segments NULL-start; treated as not found */
+            if (found) seglist_free(out);   /* a later hit overwrites (src/indelminer.c:243-251) */
+            *out = seglist_from_record(&b);
+            *strand = (b.flag & 0x10) ? '-' : '+';
+            found = 1;
+        }
+    }
+    free(b.data);
+    bam_header_free(h);
+    bgzf_close(r);
+    return found;
+}
+
+static int mate_mapq(const bam_record* b, int strict)
+{
+    /* MQ tag if present, else the read's own MAPQ (src/indelminer.c:388-400,463-472,592-601) */
+    const uint8_t* p = bam_aux_find(b, "MQ");
+    if (!p) return b->mapq;
+    if (strict) forceassert(p[0] == 'I' || p[0] == 'i' || p[0] == 'C' || p[0] == 'c' || p[0] == 'S' || p[0] == 's');
+    return bam_aux_int(p);
+}
+
+/* fetch_func (src/indelminer.c:339-673) for one record, pass A part */
+static void dispatch_record(driver* d, const bam_record* b)
+{
+    const int flag = b->flag;
+    if (flag & 0x100) return;
+    if (flag & 0x200) return;
+    if (flag & 0x400) return;
+    if (flag & 0x800) return;
+    const int is_aligned = (flag & 0x4) == 0, is_mate_aligned = (flag & 0x8) == 0;
+    const int is_se = (flag & 0x1) == 0, is_proper_pair = (flag & 0x2) == 0x2;
+    const int is_rc = (flag & 0x10) == 0x10, is_mate_rc = (flag & 0x20) == 0x20;
+    if (is_se) return;
+    if (is_aligned && is_mate_aligned && b->tid != b->mtid) return;
+
+    const uint8_t* rg = bam_aux_find(b, "RG");
+    const char* rgname = "generic";
+    if (rg) rgname = bam_aux_str(rg);
+    qbin* rb = qhash_lookup(d->insertlengths, rgname, (int)strlen(rgname));
+    if (!rb) fatalf("did not find %s in the hash", rgname);
+    const int32_t* range = rb->val;
+    const char* qname = BAMR_QNAME(b);
+
+    if (is_aligned && !is_mate_aligned) {
+        /* dealt with at the mate */
+    } else if (!is_aligned && is_mate_aligned) {
+        const int mmq = mate_mapq(b, 1);
+        if (mmq >= O.qthreshold) {
+            char* bases = decode_bases(b);
+            char strand = is_rc ? '-' : '+';
+            if (!is_mate_rc) { revcomp_inplace(bases); strand = (strand == '+') ? '-' : '+'; }
+            item_t* it = push_item(d);
+            it->kind = ITEM_CAND; it->cand = d->cb.n;
+            cb_push(&d->cb, bases, b->mtid, b->mpos, range[1], qname, strand, (uint8_t)mmq);
+            free(bases);
+        }
+    } else if (is_aligned && is_mate_aligned && is_proper_pair) {
+        seglist rln = seglist_from_record(b);
+        const char strand0 = is_rc ? '-' : '+';
+        uint32_t numcdels = 0, numcins = 0, numcsclip = 0;
+        int is_threeprime_clip = 0;
+        for (int i = 0; i < rln.n; i++) {
+            const int op = CIG_OP(rln.ops[i]);
+            if (op == OP_D) numcdels++;
+            if (op == OP_I) numcins++;
+            if (op == OP_S) numcsclip++;
+            if (((strand0 == '+' && i == rln.n - 1) || (strand0 == '-' && i == 0)) && op == OP_S) is_threeprime_clip = 1;
+        }
+        const uint32_t numinteresting = numcdels + numcins + numcsclip;
+        if (numinteresting > 0) {
+            if (((numcsclip == 0) || (numcsclip == 1 && is_threeprime_clip)) && numcdels == 0 && numcins == 0) {
+                /* nothing to do (src/indelminer.c:457-460) */
+            } else {
+                const int mmq = mate_mapq(b, 0);
+                if (mmq >= O.qthreshold) {
+                    const char* own_ref = d->sequences[b->tid];
+                    evidence_t** bwa = xmalloc(sizeof(evidence_t*) * (size_t)(rln.n ? rln.n : 1));
+                    const int nbwa = check_variants(&rln, strand0, b->mapq, qname, own_ref, bwa);
+                    char* bases = decode_bases(b);
+                    char strand = strand0;
+                    if ((is_rc && is_mate_rc) || (!is_rc && !is_mate_rc)) { revcomp_inplace(bases); strand = (strand == '+') ? '-' : '+'; }
+                    item_t* it = push_item(d);
+                    it->kind = ITEM_CAND; it->cand = d->cb.n; it->bwa = bwa; it->nbwa = nbwa;
+                    cb_push(&d->cb, bases, b->mtid, b->mpos, range[1], qname, strand, b->mapq);
+                    free(bases);
+                }
+            }
+        }
+        seglist_free(&rln);
+    } else if (is_aligned && is_mate_aligned && !is_proper_pair) {
+        if (abs(b->isize) > range[1] && (uint32_t)abs(b->isize) < O.maxpedelsize && is_rc != is_mate_rc) {
+            if (b->pos < b->mpos) {
+                evidence_t* e = xcalloc(1, sizeof *e);
+                e->type = EV_PAIRED_READ; e->cls = CLS_DELETION;
+                e->qual = b->mapq; e->strand = is_rc ? '-' : '+';
+                e->qname = xstrdup(qname);
+                e->aln = seglist_from_record(b);
+                qhash_add(d->readpairs, qname, b->l_qname, e);
+            } else {
+                qbin* hb = qhash_lookup(d->readpairs, qname, b->l_qname);
+                evidence_t* e = hb ? hb->val : NULL;
+                int skip = 0;
+                if (!e) {
+                    seglist m; char mstrand = '+';
+                    const char want = (flag & 0x40) ? '2' : '1';
+                    if (!find_mate(d, b->mtid, b->mpos, want, qname, &m, &mstrand)) skip = 1;
+                    else {
+                        e = xcalloc(1, sizeof *e);
+                        e->type = EV_PAIRED_READ; e->cls = CLS_DELETION;
+                        e->qual = 0;            /* find_mate_rln never copies the mate's MAPQ (src/indelminer.c:243-251) */
+                        e->strand = mstrand;
+                        e->qname = xstrdup(qname);
+                        e->aln = m;
+                        if (b->mapq < e->qual) e->qual = b->mapq;
+                        qhash_add(d->readpairs, qname, b->l_qname, e);
+                    }
+                }
+                if (!skip) {
+                    e->aln3 = seglist_from_record(b);
+                    e->b1 = seglist_last_end(&e->aln);
+                    e->b2 = seglist_first_start(&e->aln3);
+                    e->mindelsize = abs(b->isize) - range[1];
+                    e->max = range[1];
+                    const int smq = b->mapq, mmq = mate_mapq(b, 0);
+                    if (smq >= O.qthreshold || mmq >= O.qthreshold) {
+                        const char* r = d->sequences[b->tid];
+                        seg_reduce(&e->aln, 0, e->aln.n, r, &e->lflank, &e->nd_print, &e->nd_filter);
+                        seg_reduce(&e->aln3, 0, e->aln3.n, r, &e->rflank, &e->nd_print, &e->nd_filter);
+                        item_t* it = push_item(d);
+                        it->kind = ITEM_PE; it->pe = e;
+                    } else evidence_free(e);
+                }
+                qhash_remove(d->readpairs, qname, b->l_qname);
+            }
+        }
+    }
+
+    if ((++d->numread % READCHUNK) == 0) {
+        timestamp("Read %ld reads", (long)d->numread);
+        int marker = find_marker(d->readpairs);
+        if (b->pos < marker) marker = b->pos;
+        if (d->n_flushes == d->cap_flushes) {
+            d->cap_flushes = d->cap_flushes ? d->cap_flushes * 2 : 64;
+            d->flushes = xrealloc(d->flushes, sizeof(flush_t) * (size_t)d->cap_flushes);
+        }
+        d->flushes[d->n_flushes].n_items = d->n_items;
+        d->flushes[d->n_flushes].marker = marker;
+        d->flushes[d->n_flushes].tid = b->tid;
+        d->n_flushes++;
+    }
+}
+
+/* ------------------------------------------------------- variants (host) -- */
+
+static void vl_push(variant_list* l, variant_t* v)
+{
+    if (l->n == l->cap) { l->cap = l->cap ? l->cap * 2 : 64; l->v = xrealloc(l->v, sizeof(variant_t*) * (size_t)l->cap); }
+    l->v[l->n++] = v;
+}
+
+static void variant_free(variant_t* v) { if (v) { free(v->evidence); free(v); } }
+
+/* stable insertion of sort_by_position (src/variant.c:15-25,40-44): glibc qsort is a stable
+ * merge sort for these sizes, so equal (start,stop) keep their list order */
+static int cmp_variant_pos(const variant_t* a, const variant_t* b)
+{
+    if (a->start == b->start) return (int)a->stop - (int)b->stop;
+    return (int)a->start - (int)b->start;
+}
+static void sort_variants(variant_list* l)
+{
+    /* merge sort on pointers, stable */
+    if (l->n < 2) return;
+    variant_t** tmp = xmalloc(sizeof(variant_t*) * (size_t)l->n);
+    for (int w = 1; w < l->n; w *= 2) {
+        for (int lo = 0; lo < l->n; lo += 2 * w) {
+            int mid = lo + w < l->n ? lo + w : l->n, hi = lo + 2 * w < l->n ? lo + 2 * w : l->n;
+            int i = lo, j = mid, k = lo;
+            while (i < mid && j < hi) tmp[k++] = (cmp_variant_pos(l->v[j], l->v[i]) < 0) ? l->v[j++] : l->v[i++];
+            while (i < mid) tmp[k++] = l->v[i++];
+            while (j < hi) tmp[k++] = l->v[j++];
+        }
+        memcpy(l->v, tmp, sizeof(variant_t*) * (size_t)l->n);
+    }
+    free(tmp);
+}
+
+/* voted_consensus (src/variant.c:52-113) with its 16-bin table walk */
+static char* voted_consensus(evidence_t** ev, uint32_t nsupport, int* maxsize)
+{
+    qhash* counts = qhash_new(4);
+    uint32_t* intcounts = xcalloc(nsupport, sizeof(uint32_t));
+    uint32_t indx = 0;
+    int size = 0;
+    char** keep = xcalloc(nsupport, sizeof(char*));
+    for (uint32_t i = 0; i < nsupport; i++) {
+        forceassert(ev[i]->type == EV_SPLIT_READ);
+        const seglist* a = &ev[i]->aln;
+        /* aln2->sequence: the segment's read bases, '-' for a deletion (src/readaln.c:58-73) */
+        int readpos = 0;
+        for (int s = 0; s < ev[i]->seg; s++) if (CIG_OP(a->ops[s]) != OP_D) readpos += CIG_LEN(a->ops[s]);
+        const int op = CIG_OP(a->ops[ev[i]->seg]), len = CIG_LEN(a->ops[ev[i]->seg]);
+        char* seq = xmalloc((size_t)len + 1);
+        if (op == OP_D) memset(seq, '-', (size_t)len); else memcpy(seq, a->bases + readpos, (size_t)len);
+        seq[len] = 0;
+        keep[i] = seq;
+        const int inslen = (int)strlen(seq);
+        if (inslen > size) size = inslen;
+        if (qhash_lookup(counts, seq, inslen) == NULL) { qhash_add(counts, seq, inslen, intcounts + indx); indx++; }
+        qbin* b = qhash_lookup(counts, seq, inslen);
+        *(uint32_t*)b->val += 1;
+    }
+    *maxsize = size;
+    uint32_t maximumcount = 0;
+    const char* consensus = NULL;
+    for (uint32_t j = 0; j <= counts->mask; j++)
+        for (qbin* it = counts->bins[j]; it; it = it->next)
+            if (*(uint32_t*)it->val > maximumcount) { maximumcount = *(uint32_t*)it->val; consensus = it->name; }
+    forceassert(consensus != NULL);
+    char* rt = xstrdup(consensus);
+    for (uint32_t i = 0; i < nsupport; i++) free(keep[i]);
+    free(keep); free(intcounts);
+    qhash_free(counts, NULL);
+    return rt;
+}
+
+/* move_boundaries (src/variant.c:923-991).  The reference indexes the contig without bounds
+ * checks; reads past either end are stopped here (they are out-of-bounds reads there). */
+static void move_boundaries(variant_t* vs, const char* reference, int64_t reflen)
+{
+    uint32_t lw = 0, rw = 0;
+    if (vs->type == CLS_INSERTION) {
+        int maxinsertsize;
+        char* consensus = voted_consensus(vs->evidence, vs->support, &maxinsertsize);
+        const size_t cl = strlen(consensus);
+        while ((int64_t)vs->start - (int64_t)cl - (int64_t)lw >= 0 && cl > 0 &&
+               strncmp(consensus, reference + vs->start - cl - lw, cl) == 0) lw += (uint32_t)cl;
+        uint32_t shift = 0;
+        while (shift < cl && (int64_t)vs->start - 1 - (int64_t)lw >= 0 &&
+               consensus[cl - shift - 1] == reference[vs->start - 1 - lw]) { lw++; shift++; }
+        while (cl > 0 && (int64_t)vs->stop + rw < reflen && strncmp(consensus, reference + vs->stop + rw, cl) == 0) rw += (uint32_t)cl;
+        shift = 0;
+        while (shift < cl && (int64_t)vs->stop + rw < reflen && consensus[shift] == reference[vs->stop + rw]) { rw++; shift++; }
+        free(consensus);
+    } else if (vs->type == CLS_DELETION) {
+        while ((int64_t)vs->start - 1 - (int64_t)lw >= 0 && reference[vs->start - 1 - lw] == reference[vs->stop - 1 - lw]) lw++;
+        while ((int64_t)vs->stop + rw < reflen && reference[vs->start + rw] == reference[vs->stop + rw]) rw++;
+    }
+    vs->lw = lw; vs->rw = rw;
+}
+
+/* merge_variants (src/variant.c:1029-1225) over arrays.  in: sorted list; out: sorted list. */
+static void merge_variants(variant_list* pvs, const char* reference, int64_t reflen, int join_sr_pe)
+{
+    if (pvs->n == 0) return;
+    for (int i = 0; i < pvs->n; i++)
+        if (pvs->v[i]->evdnctype == EV_SPLIT_READ) move_boundaries(pvs->v[i], reference, reflen);
+
+    variant_list vs = {0}, pe = {0};
+    for (int i = 0; i < pvs->n; i++) vl_push(pvs->v[i]->evdnctype == EV_PAIRED_READ ? &pe : &vs, pvs->v[i]);
+    sort_variants(&vs);
+
+    /* SR variants with the same type and the same shifted boundaries collapse into the first
+     * (1079-1123).  Each iter1 scans forward while start <= iter1.stop + iter1.rw. */
+    for (int i = 0; i < vs.n; i++) {
+        variant_t* a = vs.v[i];
+        int j = i + 1;
+        while (j < vs.n && vs.v[j]->start <= a->stop + a->rw) {
+            variant_t* b = vs.v[j];
+            forceassert(a->evdnctype == EV_SPLIT_READ);
+            forceassert(b->evdnctype == EV_SPLIT_READ);
+            if (b->type == a->type && (a->start - a->lw) == (b->start - b->lw) && (a->stop + a->rw) == (b->stop + b->rw)) {
+                /* mergeSRvariants (993-1023): a's coordinates, evidence of a then of b */
+                a->evidence = xrealloc(a->evidence, sizeof(evidence_t*) * (size_t)(a->support + b->support));
+                memcpy(a->evidence + a->support, b->evidence, sizeof(evidence_t*) * (size_t)b->support);
+                a->support += b->support;
+                variant_free(b);
+                memmove(&vs.v[j], &vs.v[j + 1], sizeof(variant_t*) * (size_t)(vs.n - j - 1));
+                vs.n--;
+                j = i + 1;          /* the reference restarts its scan behind the merged node (1113-1118) */
+                continue;
+            }
+            j++;
+        }
+    }
+
+    if (!join_sr_pe) {
+        for (int i = 0; i < pe.n; i++) vl_push(&vs, pe.v[i]);
+        sort_variants(&vs);
+        free(pvs->v); free(pe.v);
+        *pvs = vs;
+        return;
+    }
+
+    /* paired-read variants join the best-overlapping split-read variant (1143-1217).  vs is a
+     * list whose HEAD receives every PE variant that did not merge; the candidate scan walks
+     * that list from the head and stops at the first start > stop, prepended PE variants
+     * included -- kept as is. */
+    variant_t** lst = xmalloc(sizeof(variant_t*) * (size_t)(vs.n + pe.n + 1));
+    int nl = vs.n;
+    memcpy(lst, vs.v, sizeof(variant_t*) * (size_t)vs.n);
+    for (int p = 0; p < pe.n; p++) {
+        variant_t* it1 = pe.v[p];
+        uint32_t overlap = 0;
+        variant_t* cand = NULL;
+        for (int q = 0; q < nl; q++) {
+            variant_t* it2 = lst[q];
+            if (it2->start > it1->stop) break;
+            if (it2->evdnctype == EV_PAIRED_READ) continue;
+            uint32_t olap = 0;
+            if (it1->start >= it2->start && it1->start < it2->stop)
+                olap = (it1->stop < it2->stop ? it1->stop : it2->stop) - it1->start;
+            else if (it2->start >= it1->start && it2->start < it1->stop)
+                olap = (it1->stop < it2->stop ? it1->stop : it2->stop) - it2->start;
+            const double f = (olap * 100.0 / (double)(it1->stop - it1->start)) + (olap * 100.0 / (double)(it2->stop - it2->start));
+            const uint32_t olapf = isfinite(f) ? (uint32_t)f : 0u;     /* NaN/inf convert to 0 on x86-64 */
+            if (olapf > overlap) { overlap = olapf; cand = it2; }
+        }
+        int tomerge = 1;
+        if (cand) {
+            const int size = (int)cand->stop - (int)cand->start;
+            for (uint32_t i = 0; i < it1->support; i++) if (size < it1->evidence[i]->mindelsize) { tomerge = 0; break; }
+        }
+        if (cand && tomerge) {
+            cand->evidence = xrealloc(cand->evidence, sizeof(evidence_t*) * (size_t)(cand->support + it1->support));
+            memcpy(cand->evidence + cand->support, it1->evidence, sizeof(evidence_t*) * (size_t)it1->support);
+            cand->support += it1->support;
+            if ((cand->evdnctype == EV_PAIRED_READ && it1->evdnctype == EV_SPLIT_READ) ||
+                (cand->evdnctype == EV_SPLIT_READ && it1->evdnctype == EV_PAIRED_READ)) cand->evdnctype = EV_COMPOSITE;
+            variant_free(it1);
+        } else {
+            memmove(lst + 1, lst, sizeof(variant_t*) * (size_t)nl);
+            lst[0] = it1;
+            nl++;
+        }
+    }
+    free(pvs->v); free(vs.v); free(pe.v);
+    pvs->v = lst; pvs->n = nl; pvs->cap = nl;
+    sort_variants(pvs);
+}
+
+/* ---- region depth, calculate_cov_params (src/shared.c:178-212) ---- */
+static uint32_t region_depth(driver* d, int32_t tid, int32_t start, int32_t stop)
+{
+    /* pileup semantics (bam_pileup.c:67-143,238-265): records with flag & (0x4|0x100|0x200|0x400)
+     * or tid < 0 are skipped; a position counts a read iff its covering op is M/=/X */
+    if (stop <= start) return 0;
+    uint32_t* cov = xcalloc((size_t)(stop - start), sizeof(uint32_t));
+    bgzf_reader* r = bgzf_open(d->bam_name);
+    if (!r) fatalf("error in opening the file %s", d->bam_name);
+    bam_header* h = bam_header_load(r);
+    bam_region_iter it;
+    bam_record b; memset(&b, 0, sizeof b);
+    if (h && bam_region_begin(&it, r, d->idx, tid, start, stop) == 0) {
+        while (bam_region_next(&it, &b) == 1) {
+            if (b.tid < 0 || (b.flag & (0x4 | 0x100 | 0x200 | 0x400))) continue;
+            const uint32_t* cig = BAMR_CIGAR(&b);
+            int32_t x = b.pos;
+            for (int k = 0; k < b.n_cigar; k++) {
+                const int op = CIG_OP(cig[k]), len = CIG_LEN(cig[k]);
+                if (op == OP_M || op == OP_EQ || op == OP_X) {
+                    int32_t lo = x < start ? start : x, hi = x + len > stop ? stop : x + len;
+                    for (int32_t p = lo; p < hi; p++) cov[p - start]++;
+                    x += len;
+                } else if (op == OP_D || op == OP_N) x += len;
+            }
+        }
+    }
+    free(b.data);
+    bam_header_free(h);
+    bgzf_close(r);
+    uint64_t covsum = 0;
+    for (int32_t i = 0; i < stop - start; i++) covsum += cov[i];
+    free(cov);
+    return (uint32_t)floor((uint32_t)covsum * 1.0 / (uint32_t)(stop - start));
+}
+
+/* print_vcf_output (src/variant.c:115-311) */
+static void print_vcf_output(driver* d, const variant_t* v)
+{
+    const char* seq = d->sequences[v->tid];
+    printf("%s\t%d\t.\t", d->hdr->target_name[v->tid], (int)(v->start - v->lw));
+    int endpos = -1;
+    if (v->type == CLS_DELETION) {
+        const int reflength = (int)(v->stop + v->rw) - (int)(v->start - v->lw - 1);
+        forceassert(reflength >= 1);
+        const int altlength = (int)(v->start + v->rw) - (int)(v->start - v->lw - 1);
+        forceassert(altlength >= 1);
+        endpos = (int)(v->start - v->lw) + reflength - altlength + 1;
+        for (int i = 0; i < (reflength - altlength + 1); i++) printf("%c", seq[v->start - v->lw - 1 + (uint32_t)i]);
+        printf("\t");
+        printf("%c\t", seq[v->start - v->lw - 1]);
+    } else if (v->type == CLS_INSERTION) {
+        const int reflength = (int)(v->stop + v->rw) - (int)(v->start - v->lw - 1);
+        forceassert(reflength >= 1);
+        int maxinsertsize = 0;
+        char* consensus = voted_consensus(v->evidence, v->support, &maxinsertsize);
+        const int altlength = reflength + (int)strlen(consensus) + (int)(v->stop + v->rw) - (int)v->start;
+        forceassert(altlength >= 1);
+        endpos = (int)(v->start - v->lw) + 1;
+        printf("%c\t", seq[v->start - v->lw - 1]);
+        printf("%c", seq[v->start - v->lw - 1]);
+        printf("%s\t", consensus);
+        free(consensus);
+    } else fatalf("unhandled variant type");
+
+    printf(".\t.\t%s;", v->type == CLS_DELETION ? "DELETION" : "INSERTION");
+    if (v->evdnctype == EV_SPLIT_READ) printf("SPLIT_READ;");
+    else if (v->evdnctype == EV_PAIRED_READ) printf("PAIRED_READ;");
+    else if (v->evdnctype == EV_COMPOSITE) printf("COMPOSITE;");
+    else fatalf("unknown evidence type for this variant");
+    forceassert(endpos != -1);
+    printf("NS=%u;END=%d;BP_END=%d", v->support, endpos, (int)(v->stop + v->rw + 1));
+
+    uint32_t nf = 0, nr = 0;
+    for (uint32_t i = 0; i < v->support; i++) {
+        if (v->evidence[i]->strand == '+') nf++;
+        else if (v->evidence[i]->strand == '-') nr++;
+        else fatalf("unknown strand");
+    }
+    printf(";NFS=%u;NRS=%u", nf, nr);
+
+    uint32_t maxtaild = 100;
+    char* taildistances = xcalloc(maxtaild + 1, 1);
+    uint32_t nut = 0, num_pe = 0, mq = 0, mq30 = 0, numdiffs = 0;
+    int balance = INT_MAX, lflank = -1, rflank = -1;
+    for (uint32_t i = 0; i < v->support; i++) {
+        const evidence_t* e = v->evidence[i];
+        mq += e->qual;
+        if (e->qual >= 30) mq30++;
+        const uint32_t ltmp = (uint32_t)e->lflank, rtmp = (uint32_t)e->rflank;
+        numdiffs += (uint32_t)e->nd_print;
+        const uint32_t taild = rtmp < ltmp ? rtmp : ltmp;
+        if (taild > maxtaild) {
+            taildistances = xrealloc(taildistances, taild + 1);
+            memset(taildistances + maxtaild + 1, 0, taild - maxtaild);
+            maxtaild = taild;
+        }
+        taildistances[taild] = '1';
+        if (e->type == EV_PAIRED_READ) num_pe++;
+        if (abs((int)(rtmp - ltmp)) < balance) { balance = abs((int)(rtmp - ltmp)); lflank = (int)ltmp; rflank = (int)rtmp; }
+    }
+    for (uint32_t i = 0; i < maxtaild; i++) if (taildistances[i] == '1') nut++;     /* i < maxtaild: src/variant.c:293-295 */
+    nut += num_pe;
+    printf(";UTAILS=%d;MQ=%d;MQ30=%d;DF=%d;DP=%d", (int)nut, (int)(mq * 1.0 / v->support), (int)mq30,
+           (int)((numdiffs * 1.0 / v->support) + 0.5),
+           (int)region_depth(d, v->tid, (int32_t)(v->start - v->lw - 1), (int32_t)(v->stop + v->rw + 1)));
+    printf(";BF=%d,%d", lflank, rflank);
+    printf("\n");
+    free(taildistances);
+}
+
+/* print_variants (src/variant.c:678-838) */
+static void print_variants(driver* d, variant_list* vs)
+{
+    variant_list sel = {0};
+    for (int x = 0; x < vs->n; x++) {
+        variant_t* it = vs->v[x];
+        int left = 0, right = 0, balance = INT_MAX, lflank = -1, rflank = -1;
+        uint32_t numdiffs = 0;
+        for (uint32_t i = 0; i < it->support; i++) {
+            const evidence_t* e = it->evidence[i];
+            const uint32_t ltmp = (uint32_t)e->lflank, rtmp = (uint32_t)e->rflank;
+            numdiffs += (uint32_t)e->nd_filter;
+            if (ltmp >= O.minbalance) left = 1;
+            if (rtmp >= O.minbalance) right = 1;
+            if (abs((int)(rtmp - ltmp)) < balance) { balance = abs((int)(rtmp - ltmp)); lflank = (int)ltmp; rflank = (int)rtmp; }
+        }
+        const uint32_t xnumdiffs = (uint32_t)((int)(numdiffs * 1.0 / it->support) + 0.5);
+        const int ok_flanks = (it->type == CLS_DELETION && (uint32_t)lflank >= O.minbalance && (uint32_t)rflank >= O.minbalance) ||
+                              (it->type == CLS_INSERTION && ((uint32_t)lflank >= O.minbalance || (uint32_t)rflank >= O.minbalance));
+        if (ok_flanks && it->support >= O.minsupport && xnumdiffs <= O.maxdiffsallowed && left && right) vl_push(&sel, it);
+    }
+    if (O.call_all_indels) {
+        for (int i = 0; i < sel.n; i++) print_vcf_output(d, sel.v[i]);
+    } else {
+        int i = 0;
+        while (i < sel.n) {
+            const variant_t* it = sel.v[i];
+            int j = i + 1;
+            while (j < sel.n && (sel.v[j]->start - sel.v[j]->lw) <= (it->stop + it->rw)) j++;
+            uint32_t maxsupport = 0;
+            const variant_t* chosen = it;
+            for (int t = i; t < j; t++) if (sel.v[t]->support > maxsupport) { maxsupport = sel.v[t]->support; chosen = sel.v[t]; }
+            print_vcf_output(d, chosen);
+            i = j;
+        }
+    }
+    free(sel.v);
+}
+
+/* --------------------------------------------------------- process_evidence -- */
+
+typedef struct { int32_t b1, b2; int64_t arrival; int64_t idx; } skey;
+static int g_tie_desc;
+static int cmp_skey(const void* x, const void* y)
+{
+    const skey* a = x; const skey* b = y;
+    if (a->b1 != b->b1) return a->b1 < b->b1 ? -1 : 1;
+    if (a->b2 != b->b2) return a->b2 < b->b2 ? -1 : 1;
+    /* prepend list + stable merge sort: ties newest first; the expected.vcf
+     * order is the opposite */
+    if (a->arrival == b->arrival) return 0;
+    if (g_tie_desc) return a->arrival < b->arrival ? -1 : 1;
+    return a->arrival > b->arrival ? -1 : 1;
+}
+
+static int uf_find(int* p, int x) { while (p[x] != x) { p[x] = p[p[x]]; x = p[x]; } return x; }
+
+/* process_evidence (src/indelminer.c:117-209): consumes the pending evidence list, returns the
+ * variants sorted by position (sort_variants applied). */
+static void process_evidence(driver* d, int32_t tid, int marker, variant_list* out)
+{
+    const int64_t n = d->n_pending;
+    out->n = 0;
+    if (n == 0) return;
+    skey* keys = xmalloc(sizeof(skey) * (size_t)n);
+    for (int64_t i = 0; i < n; i++) { keys[i].b1 = d->pending[i]->b1; keys[i].b2 = d->pending[i]->b2; keys[i].arrival = d->pending[i]->arrival; keys[i].idx = i; }
+    g_tie_desc = O.tie_desc;
+    qsort(keys, (size_t)n, sizeof(skey), cmp_skey);
+    int64_t m = 0;
+    while (m < n && keys[m].b2 < marker) m++;           /* nodes for the sorted prefix (137-146) */
+
+    /* split-read nodes: the GPU groups them (identical class,b1,b2; src/graph.c:122-127) */
+    int32_t nsr = 0, npe = 0;
+    int64_t* sr_idx = xmalloc(sizeof(int64_t) * (size_t)(m ? m : 1));
+    int64_t* pe_pos = xmalloc(sizeof(int64_t) * (size_t)(m ? m : 1));    /* sorted positions of PE nodes */
+    uint8_t* is_node = xcalloc((size_t)n, 1);
+    int64_t* sorted_pos = xmalloc(sizeof(int64_t) * (size_t)n);
+    for (int64_t s = 0; s < m; s++) { is_node[keys[s].idx] = 1; sorted_pos[keys[s].idx] = s; if (d->pending[keys[s].idx]->type == EV_PAIRED_READ) pe_pos[npe++] = s; }
+    for (int64_t i = 0; i < n; i++) if (is_node[i] && d->pending[i]->type == EV_SPLIT_READ) sr_idx[nsr++] = i;   /* arrival order */
+
+    variant_list vars = {0};
+    if (nsr > 0) {
+        int32_t *cls = xmalloc(4 * (size_t)nsr), *b1 = xmalloc(4 * (size_t)nsr), *b2 = xmalloc(4 * (size_t)nsr);
+        int32_t *order = xmalloc(4 * (size_t)nsr), *first = xmalloc(4 * (size_t)nsr), *count = xmalloc(4 * (size_t)nsr);
+        uint8_t* used = xmalloc((size_t)nsr);
+        for (int32_t i = 0; i < nsr; i++) { const evidence_t* e = d->pending[sr_idx[i]]; cls[i] = e->cls; b1[i] = e->b1; b2[i] = e->b2; }
+        int32_t ncl = 0;
+        const int rc = im_cluster_sr(d->gpu, nsr, cls, b1, b2, INT_MAX, O.tie_desc, order, first, count, used, &ncl);
+        if (rc != IM_OK) fatalf("im_cluster_sr: %s", im_last_error(d->gpu));
+        for (int32_t c = 0; c < ncl; c++) {
+            variant_t* v = xcalloc(1, sizeof *v);
+            const evidence_t* e0 = d->pending[sr_idx[order[first[c]]]];
+            v->type = e0->cls; v->evdnctype = EV_SPLIT_READ; v->tid = tid;
+            v->start = (uint32_t)e0->b1; v->stop = (uint32_t)e0->b2; v->support = (uint32_t)count[c];
+            v->evidence = xmalloc(sizeof(evidence_t*) * (size_t)count[c]);
+            int64_t rep = -1;
+            for (int32_t k = 0; k < count[c]; k++) {
+                const int64_t pi = sr_idx[order[first[c] + k]];
+                v->evidence[k] = d->pending[pi];
+                if (sorted_pos[pi] > rep) rep = sorted_pos[pi];
+            }
+            v->rep_arrival = rep;       /* largest sorted position of a member: decides the component id order */
+            if (v->start <= v->stop) vl_push(&vars, v); else variant_free(v);
+        }
+        free(cls); free(b1); free(b2); free(order); free(first); free(count); free(used);
+    }
+    if (npe > 0) {
+        /* paired-read nodes: add_node's O(N^2) rule (src/graph.c:100-121), union-find for the components */
+        int* parent = xmalloc(sizeof(int) * (size_t)npe);
+        for (int i = 0; i < npe; i++) parent[i] = i;
+        for (int j = 0; j < npe; j++) {
+            const evidence_t* e1 = d->pending[keys[pe_pos[j]].idx];
+            for (int i = 0; i < j; i++) {
+                const evidence_t* e2 = d->pending[keys[pe_pos[i]].idx];
+                forceassert(e2->b1 <= e1->b1);
+                if (e2->b1 < e1->b2 && e1->cls == e2->cls) {
+                    const int32_t bb1 = e1->b1 > e2->b1 ? e1->b1 : e2->b1;
+                    const int32_t bb2 = e1->b2 < e2->b2 ? e1->b2 : e2->b2;
+                    const int32_t d1 = bb1 - seglist_first_start(&e1->aln) + seglist_last_end(&e1->aln3) - bb2;
+                    const int32_t d2 = bb1 - seglist_first_start(&e2->aln) + seglist_last_end(&e2->aln3) - bb2;
+                    if (d1 < e1->max && d2 < e2->max) { int a = uf_find(parent, i), c = uf_find(parent, j); if (a != c) parent[a] = c; }
+                }
+            }
+        }
+        /* components; members in descending sorted position (node list is prepend order) */
+        uint8_t* done = xcalloc((size_t)npe, 1);
+        for (int j = npe - 1; j >= 0; j--) {
+            if (done[j]) continue;
+            const int root = uf_find(parent, j);
+            variant_t* v = xcalloc(1, sizeof *v);
+            v->evidence = xmalloc(sizeof(evidence_t*) * (size_t)npe);
+            int left = -1, right = -1;
+            for (int t = j; t >= 0; t--) {
+                if (done[t] || uf_find(parent, t) != root) continue;
+                done[t] = 1;
+                evidence_t* e = d->pending[keys[pe_pos[t]].idx];
+                v->evidence[v->support++] = e;
+                if (left == -1 || e->b1 > left) left = e->b1;
+                if (right == -1 || e->b2 < right) right = e->b2;
+            }
+            const evidence_t* e0 = v->evidence[0];
+            v->type = e0->cls; v->evdnctype = e0->type; v->tid = tid;
+            v->start = (uint32_t)left; v->stop = (uint32_t)right;
+            v->rep_arrival = pe_pos[j];
+            if (v->start <= v->stop) vl_push(&vars, v); else variant_free(v);
+        }
+        free(parent); free(done);
+    }
+    /* components are numbered from the largest sorted position down, the variant list is built by
+     * prepending, and sort_variants is stable: equal (start,stop) come out in ascending order of
+     * the component's largest sorted position */
+    for (int i = 1; i < vars.n; i++) {
+        variant_t* v = vars.v[i]; int j = i - 1;
+        while (j >= 0 && vars.v[j]->rep_arrival > v->rep_arrival) { vars.v[j + 1] = vars.v[j]; j--; }
+        vars.v[j + 1] = v;
+    }
+    sort_variants(&vars);
+
+    /* every node is used up, whether or not its component made a variant (189,199) */
+    for (int64_t i = 0; i < n; i++) if (is_node[i]) d->pending[i]->used = 1;
+    free(keys); free(sr_idx); free(pe_pos); free(is_node); free(sorted_pos);
+    *out = vars;
+}
+
+static void free_used_evidence(driver* d)
+{
+    int64_t k = 0;
+    for (int64_t i = 0; i < d->n_pending; i++) {
+        if (d->pending[i]->used) evidence_free(d->pending[i]);
+        else d->pending[k++] = d->pending[i];
+    }
+    d->n_pending = k;
+}
+
+static void pending_push(driver* d, evidence_t* e)
+{
+    if (d->n_pending == d->cap_pending) {
+        d->cap_pending = d->cap_pending ? d->cap_pending * 2 : 4096;
+        d->pending = xrealloc(d->pending, sizeof(evidence_t*) * (size_t)d->cap_pending);
+    }
+    e->arrival = d->arrival++;
+    d->pending[d->n_pending++] = e;
+}
+
+static void flush_variants(driver* d, int32_t tid, int marker)
+{
+    variant_list vs = {0};
+    process_evidence(d, tid, marker, &vs);
+    merge_variants(&vs, d->sequences[tid], d->seqlen[tid], 1);
+    print_variants(d, &vs);
+    fflush(stdout);
+    free_used_evidence(d);
+    for (int i = 0; i < vs.n; i++) variant_free(vs.v[i]);
+    free(vs.v);
+}
+
+/* ------------------------------------------------------ config / estimates -- */
+
+static void read_configuration(const char* filename, qhash* insertlengths)
+{
+    /* src/shared.c:5-44 */
+    size_t cap = 2;
+    char* line = xmalloc(cap);
+    FILE* fp = fopen(filename, "r");
+    if (!fp) fatalf("error in opening the file %s", filename);
+    while (im_getline(&line, &cap, fp) != -1) {
+        char name[128]; unsigned a, b;
+        if (strncmp(line, "IL", 2) == 0) {
+            if (sscanf(line, "IL %127s %u %u\n", name, &a, &b) != 3) fatalf("error in reading the insert length range: %s", line);
+            int32_t* range = xmalloc(2 * sizeof(int32_t));
+            range[0] = (int32_t)a; range[1] = (int32_t)b;
+            qhash_add(insertlengths, name, (int)strlen(name), range);
+        } else if (strncmp(line, "RC", 2) == 0) {
+            if (sscanf(line, "RC %127s %u\n", name, &a) != 2) fatalf("error in reading the mean coverage: %s", line);
+        } else fatalf("unknown tag in configuration: %s", line);
+    }
+    free(line);
+    fclose(fp);
+}
+
+static void estimate_insertlengths(driver* d, int chromid)
+{
+    /* src/bamoperations.c:15-86: min / max proper-pair isize per read group */
+    bgzf_reader* r = bgzf_open(d->bam_name);
+    if (!r) fatalf("error in opening the file %s", d->bam_name);
+    bam_header* h = bam_header_load(r);
+    bam_record b; memset(&b, 0, sizeof b);
+    for (int32_t t = 0; t < h->n_targets; t++) {
+        if (chromid != -1 && t != chromid) continue;
+        bam_region_iter it;
+        if (bam_region_begin(&it, r, d->idx, t, 0, h->target_len[t]) != 0) continue;
+        while (bam_region_next(&it, &b) == 1) {
+            if ((b.flag & 0x1) == 0 || (b.flag & 0x4) || (b.flag & 0x2) == 0) continue;
+            if (b.flag & (0x100 | 0x200 | 0x400)) continue;
+            if (b.isize < 0) continue;
+            const uint8_t* rg = bam_aux_find(&b, "RG");
+            const char* rgname = "generic";
+            if (rg) { forceassert(rg[0] == 'Z'); rgname = bam_aux_str(rg); }
+            const int32_t isize = b.isize;
+            if (b.mpos - b.pos < 0) continue;
+            if (isize < b.mpos - b.pos) continue;
+            qbin* q = qhash_lookup(d->insertlengths, rgname, (int)strlen(rgname));
+            if (!q) {
+                int32_t* range = xmalloc(2 * sizeof(int32_t));
+                range[0] = range[1] = isize;
+                qhash_add(d->insertlengths, rgname, (int)strlen(rgname), range);
+            } else {
+                int32_t* range = q->val;
+                if (range[0] > isize) range[0] = isize;
+                if (range[1] < isize) range[1] = isize;
+            }
+        }
+    }
+    free(b.data);
+    bam_header_free(h);
+    bgzf_close(r);
+}
+
+/* --------------------------------------------------------------- preamble -- */
+
+static void print_vcf_preamble(void)
+{
+    /* src/shared.c:84-109, byte for byte */
+    printf("##fileformat=VCFv4.1\n");
+    printf("##%sVersion=%2.2f\n", "indelminer", INDELMINER_VERSION);
+    printf("##INFO=<ID=INSERTION,Number=0,Type=Flag,Description=\"Indicates that the variant is an insertion.\">\n");
+    printf("##INFO=<ID=DELETION,Number=0,Type=Flag,Description=\"Indicates that the variant is a deletion.\">\n");
+    printf("##INFO=<ID=SPLIT_READ,Number=0,Type=Flag,Description=\"Indicates that at least one split read supports this variant.\">\n");
+    printf("##INFO=<ID=PAIRED_READ,Number=0,Type=Flag,Description=\"Indicates that at least one PE read supports this variant.\">\n");
+    printf("##INFO=<ID=COMPOSITE,Number=0,Type=Flag,Description=\"Indicates that at least one split read and at least one PE read supports this variant.\">\n");
+    printf("##INFO=<ID=NS,Number=1,Type=Integer,Description=\"Number of reads supporting the variant\">\n");
+    printf("##INFO=<ID=END,Number=1,Type=Integer,Description=\"end position of the variant described in this record\">\n");
+    printf("##INFO=<ID=BP_END,Number=1,Type=Integer,Description=\"possible 3' end of the breakpoint described in this record\">\n");
+    printf("##INFO=<ID=NFS,Number=1,Type=Integer,Description=\"Number of reads supporting the variant on the forward strand\">\n");
+    printf("##INFO=<ID=NRS,Number=1,Type=Integer,Description=\"Number of reads supporting the variant on the forward strand\">\n");
+    printf("##INFO=<ID=UTAILS,Number=1,Type=Integer,Description=\"The number of unique tail distances in supporting reads for this variant\">\n");
+    printf("##INFO=<ID=MQ,Number=1,Type=Integer,Description=\"RMS mapping quality of the reads covering the breakpoints\">\n");
+    printf("##INFO=<ID=MQ30,Number=1,Type=Integer,Description=\"Number of reads with mapping quality greater than or equal to 30, covering the breakpoints\">\n");
+    printf("##INFO=<ID=DF,Number=1,Type=Integer,Description=\"Average number of other differences on reads supporting the reported variant\">\n");
+    printf("##INFO=<ID=DP,Number=1,Type=Integer,Description=\"Average read depth across the breakpoints\">\n");
+    printf("##INFO=<ID=BF,Number=2,Type=Integer,Description=\"Flanks from the split read or pair best sorrounding the variant\">\n");
+}
+
+/* ----------------------------------------------------------------- pass B -- */
+
+/* the evidence one candidate read contributes: the realigned segments when the GPU found any
+ * (they replace the CIGAR-derived ones, src/indelminer.c:494-502), else the CIGAR-derived */
+static void resolve_candidate(driver* d, const item_t* it, const im_read_result* r, int32_t tid)
+{
+    const cand_batch* cb = &d->cb;
+    const int c = it->cand;
+    if (r->status == IM_ST_EVIDENCE && r->n_ev > 0) {
+        seglist whole;
+        whole.ref_start = r->ref_start; whole.n = r->n_ops;
+        whole.ops = (uint32_t*)r->ops;
+        const int64_t len = cb->base_off[c + 1] - cb->base_off[c];
+        char* bases = xmalloc((size_t)len + 1);
+        memcpy(bases, cb->bases + cb->base_off[c], (size_t)len); bases[len] = 0;
+        whole.bases = bases;
+        for (int k = 0; k < r->n_ev; k++) {
+            const im_evidence* ge = &r->ev[k];
+            evidence_t* e = xcalloc(1, sizeof *e);
+            e->type = EV_SPLIT_READ; e->cls = ge->cls; e->strand = cb->strand[c]; e->qual = cb->qual[c];
+            e->qname = xstrdup(cb->qname[c]);
+            e->aln = seglist_copy(&whole);
+            e->seg = ge->seg; e->b1 = ge->b1; e->b2 = ge->b2;
+            e->lflank = ge->lflank; e->rflank = ge->rflank; e->nd_print = ge->nd_print; e->nd_filter = ge->nd_filter;
+            pending_push(d, e);
+        }
+        free(bases);
+        for (int k = 0; k < it->nbwa; k++) evidence_free(it->bwa[k]);
+    } else {
+        for (int k = 0; k < it->nbwa; k++) pending_push(d, it->bwa[k]);
+    }
+    (void)tid;
+}
+
+static void run_contig(driver* d, int32_t tid, int32_t beg, int32_t end, bgzf_reader* r)
+{
+    d->n_items = 0; d->n_flushes = 0;
+    cb_reset(&d->cb);
+    bam_region_iter it;
+    bam_record b; memset(&b, 0, sizeof b);
+    if (bam_region_begin(&it, r, d->idx, tid, beg, end) != 0) fatalf("cannot seek in %s", d->bam_name);
+    while (bam_region_next(&it, &b) == 1) dispatch_record(d, &b);
+    free(b.data);
+
+    im_read_result* res = NULL;
+    if (d->cb.n > 0) {
+        im_params P = { O.klength, O.numgaps, O.maxdelsize, O.ethreshold };
+        im_read_batch batch = { d->cb.n, d->cb.bases, d->cb.base_off, d->cb.tid, d->cb.anchor, d->cb.range_max };
+        res = xmalloc(sizeof(im_read_result) * (size_t)d->cb.n);
+        const int rc = im_realign_batch(d->gpu, &P, &batch, res);
+        if (rc != IM_OK) fatalf("im_realign_batch: %s", im_last_error(d->gpu));
+    }
+    int f = 0;
+    for (int64_t i = 0; i <= d->n_items; i++) {
+        while (f < d->n_flushes && d->flushes[f].n_items == i) {
+            flush_variants(d, d->flushes[f].tid, d->flushes[f].marker);
+            f++;
+        }
+        if (i == d->n_items) break;
+        const item_t* itm = &d->items[i];
+        if (itm->kind == ITEM_CAND) { resolve_candidate(d, itm, &res[itm->cand], tid); free(itm->bwa); }
+        else pending_push(d, itm->pe);
+    }
+    free(res);
+    flush_variants(d, tid, INT_MAX);        /* end of contig (src/indelminer.c:806-823) */
+}
+
+/* -------------------------------------------------------------------- main -- */
+
+static void print_help(FILE* file)
+{
+    /* src/indelminer.c:883-923 */
+    fprintf(file, "\n");
+    fprintf(file, "Program: indelminer (Call/Tag indels from a clean BAM file)\n");
+    fprintf(file, "Version: %2.2f\n\n", INDELMINER_VERSION);
+    fprintf(file, "Usage:\n");
+    fprintf(file, "\tindelminer [options] ref.fa [indels.vcf] sample=aln.bam\n");
+    fprintf(file, "where the options are\n");
+    fprintf(file, "\t-h   print help and return\n");
+    fprintf(file, "\n");
+    fprintf(file, "\t-i, read the configuration from this file\n");
+    fprintf(file, " \t-c, only analyze this chromosomal region [ALL]\n");
+    fprintf(file, " \t-t, do not call indels on 3' regions of the read\n");
+    fprintf(file, " \t-q, do not call indels from reads with MQ < INT [10]\n");
+    fprintf(file, " \t-n, disallow indel within INT bp towards the ends [10]\n");
+    fprintf(file, " \t    We ignore the 3' soft-clipping, since that is where\n");
+    fprintf(file, " \t    we expect the low quality region on the reads\n");
+    fprintf(file, "\t-a, in case of overlapping indels, call all of them\n");
+    fprintf(file, "\t    Default is to call the indels with most support\n");
+    fprintf(file, "\t-e, minimum support for an indel [2]\n");
+    fprintf(file, "\t-o, output format. vcf/detailed [vcf]\n");
+    fprintf(file, "\t-s, maximum size of deletion reported using split reads [1 kbp]\n");
+    fprintf(file, "\t-p, maximum size of deletion reported using PE reads [1 Mbp]\n");
+    fprintf(file, "\n");
+    fprintf(file, "\t-k, length of the kmers to be used in alignments[6]\n");
+    fprintf(file, "\t-g, number of gaps allowed in the alignments[0]\n");
+    fprintf(file, "\t-f, number of differences allowed in an alignment[6]\n");
+    fprintf(file, "\t-b, require at least one read with these bases on \n");
+    fprintf(file, "\t    either side of the indel[30]\n");
+    fprintf(file, "\n");
+    fprintf(file, "Assumptions:\n");
+    fprintf(file, "\tThe BAM file is coordinate sorted\n");
+    fprintf(file, "\tUnless specified in a config file, insertlengths for\n");
+    fprintf(file, "\treadgroups, as well as average coverage per chromosome\n");
+    fprintf(file, "\tare estimated from the BAM file (which can be slow!!!),\n");
+    fprintf(file, "\tas well as lead to false negatives as some of the PE\n");
+    fprintf(file, "\tevidence which is accounted for in one sample,might not\n");
+    fprintf(file, "\tbe accounted for in the other\n");
+}
+
+static void free_range(void* p) { free(p); }
+
+int main(int argc, char** argv)
+{
+    O.maxdelsize = 1000; O.maxpedelsize = 1000000; O.minsupport = 2; O.klength = 6; O.numgaps = 0;
+    O.outputformat = "vcf"; O.qthreshold = 10; O.ethreshold = 10; O.ethreshold_vcfcheck = 10;
+    O.call_all_indels = 0; O.maxdiffsallowed = 6; O.minbalance = 30;
+    const char* tie_env = getenv("INDELMINER_TIE_ORDER");       /* "expected": SURVEY.md 0.2 */
+    O.tie_desc = (tie_env && strcmp(tie_env, "expected") == 0) ? 1 : 0;
+
+    int c;
+    while ((c = getopt(argc, argv, "dl:hc:e:o:k:g:x:i:s:p:tn:q:af:b:")) != -1) {
+        switch (c) {
+        case 'd': O.debug = 1; break;
+        case 'l': break;
+        case 'h': print_help(stdout); return EXIT_SUCCESS;
+        case 'c': O.region = optarg; break;
+        case 'e': if (sscanf(optarg, "%u", &O.minsupport) != 1) fatalf("incorrect option for -e: %s\n", optarg); break;
+        case 'o': O.outputformat = optarg; break;
+        case 'k': if (sscanf(optarg, "%u", &O.klength) != 1) fatalf("incorrect option for -k: %s\n", optarg); break;
+        case 'f': if (sscanf(optarg, "%u", &O.maxdiffsallowed) != 1) fatalf("incorrect option for -f: %s\n", optarg); break;
+        case 'g': if (sscanf(optarg, "%u", &O.numgaps) != 1) fatalf("incorrect option for -g: %s\n", optarg); break;
+        case 'x': break;                                            /* accepted, unused (src/indelminer.c:793-794) */
+        case 'i': O.configfile = optarg; break;
+        case 's': if (sscanf(optarg, "%u", &O.maxdelsize) != 1) fatalf("incorrect option for -s: %s\n", optarg); break;
+        case 'p': if (sscanf(optarg, "%u", &O.maxpedelsize) != 1) fatalf("incorrect option for -p: %s\n", optarg); break;
+        case 't': break;                                            /* stored, never read (src/indelminer.c:775) */
+        case 'n':
+            if (sscanf(optarg, "%u", &O.ethreshold) != 1) fatalf("incorrect option for -n: %s\n", optarg);
+            if (O.ethreshold < O.klength) O.ethreshold = O.klength;
+            O.ethreshold_vcfcheck = O.ethreshold;
+            break;
+        case 'q': if (sscanf(optarg, "%d", &O.qthreshold) != 1) fatalf("incorrect option for -q: %s\n", optarg); break;
+        case 'a': O.call_all_indels = 1; break;
+        case 'b': if (sscanf(optarg, "%u", &O.minbalance) != 1) fatalf("incorrect option for -b: %s\n", optarg); break;
+        case '?': break;
+        default: print_help(stderr); return EXIT_FAILURE;
+        }
+    }
+    forceassert(O.maxdelsize > 0);
+    forceassert(O.klength > 1 && O.klength < 16);
+    forceassert(strcmp(O.outputformat, "vcf") == 0 || strcmp(O.outputformat, "detailed") == 0);
+    if (argc == optind) { print_help(stderr); return EXIT_FAILURE; }
+    forceassert(argc - optind > 1);
+    t0 = time(0);
+
+    const char* fasta_reference = argv[optind++];
+    char* ptr = argv[optind++];
+    if (strchr(ptr, '=') == NULL)
+        fatalf("annotate mode (indels.vcf argument) is not built in this driver yet");
+    if (strcmp(O.outputformat, "detailed") == 0)
+        fatalf("-o detailed is not built in this driver yet");
+    char* samplename = ptr;
+    while (*ptr != '=') ptr++;
+    *ptr = 0;
+    const char* bam_name = ++ptr;
+    (void)samplename;
+
+    fprintf(stderr, "Reference fasta file: %s\n", fasta_reference);
+    fprintf(stderr, "Chromosomal region  : %s\n", O.region == NULL ? "ALL" : O.region);
+    fprintf(stderr, "BAM file            : %s\n", bam_name);
+
+    driver d;
+    memset(&d, 0, sizeof d);
+    d.bam_name = bam_name;
+    bgzf_reader* r = bgzf_open(bam_name);
+    if (!r) fatalf("error in opening the file %s", bam_name);
+    d.hdr = bam_header_load(r);
+    if (!d.hdr) fatalf("%s is not a BAM file", bam_name);
+    d.idx = bai_load(bam_name);
+    if (!d.idx) fatalf("BAM indexing file is not available.");
+    d.insertlengths = qhash_new(4);
+    d.readpairs = qhash_new(20);
+
+    int chromid = -1, chromstart = -1, chromstop = -1;
+    if (O.region) bam_parse_region_str(d.hdr, O.region, &chromid, &chromstart, &chromstop);
+
+    if (O.configfile) read_configuration(O.configfile, d.insertlengths);
+    else estimate_insertlengths(&d, chromid);
+    fprintf(stderr, "\nRead-group\tMin-value\tMax-value\n----------\t---------\t---------\n");
+    for (uint32_t i = 0; i <= d.insertlengths->mask; i++)
+        for (qbin* it = d.insertlengths->bins[i]; it; it = it->next)
+            fprintf(stderr, "%s\t%d\t%d\n", it->name, ((int32_t*)it->val)[0], ((int32_t*)it->val)[1]);
+    fprintf(stderr, "----------\t---------\t---------\n\n");
+    timestamp("Read insertlengths for the BAM file");
+
+    const int nseq = fasta_load(fasta_reference, d.hdr->n_targets, &d.sequences, &d.seqlen, chromid);
+    if (nseq < 0) fatalf("error in opening the file %s", fasta_reference);
+    forceassert(nseq == d.hdr->n_targets);
+    timestamp("Read the reference sequence");
+
+    /* the GPU: one context, reference resident in HBM */
+    const char* dev_env = getenv("INDELMINER_DEVICE");
+    int rc = im_ctx_create(dev_env ? atoi(dev_env) : 0, &d.gpu);
+    if (rc != IM_OK) fatalf("cannot open the GPU: %s", im_last_error(NULL));
+    {
+        const char** seqs = xcalloc((size_t)d.hdr->n_targets, sizeof(char*));
+        int64_t* lens = xcalloc((size_t)d.hdr->n_targets, sizeof(int64_t));
+        for (int32_t i = 0; i < d.hdr->n_targets; i++) { seqs[i] = d.sequences[i] ? d.sequences[i] : ""; lens[i] = d.sequences[i] ? d.seqlen[i] : 0; }
+        rc = im_set_reference(d.gpu, d.hdr->n_targets, seqs, lens);
+        if (rc != IM_OK) fatalf("im_set_reference: %s", im_last_error(d.gpu));
+        free(seqs); free(lens);
+    }
+
+    if (strncmp(O.outputformat, "vcf", 3) == 0) {
+        print_vcf_preamble();
+        printf("#CHROM\tPOS\tID\tREF\tALT\tQUAL\tFILTER\tINFO\n");
+    }
+
+    for (int32_t i = 0; i < d.hdr->n_targets; i++) {
+        if (chromid != -1 && i != chromid) continue;
+        if (chromid == -1) run_contig(&d, i, 0, d.hdr->target_len[i], r);
+        else run_contig(&d, i, chromstart, chromstop, r);
+    }
+
+    im_ctx_destroy(d.gpu);
+    bgzf_close(r);
+    bai_free(d.idx);
+    qhash_free(d.insertlengths, free_range);
+    return EXIT_SUCCESS;
+}
