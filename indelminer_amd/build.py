@@ -39,5 +39,25 @@ def build(force=False, verbose=False):
     return LIB
 
 
+HOST_DIR = os.path.join(HERE, "host")
+HOST_BIN = os.path.join(HERE, "indelminer")
+HOST_SOURCES = ["imhost.c", "hostio.c"]
+
+
+def build_host(force=False, verbose=False):
+    """The C host driver (same CLI as the reference's indelminer), linked against the HIP library."""
+    srcs = [os.path.join(HOST_DIR, s) for s in HOST_SOURCES]
+    deps = srcs + [os.path.join(HOST_DIR, "imhost.h"), os.path.join(HOST_DIR, "hostio.h"), HEADERS[0], LIB]
+    if not force and os.path.exists(HOST_BIN) and all(os.path.getmtime(d) <= os.path.getmtime(HOST_BIN) for d in deps):
+        return HOST_BIN
+    cmd = ["gcc", "-O2", "-std=c11", "-Wall", "-I" + os.path.join(ROOT, "include"), "-I" + HOST_DIR, "-o", HOST_BIN]
+    cmd += srcs + ["-L" + HERE, "-lindelminer_amd", "-lz", "-lm", "-Wl,-rpath,$ORIGIN"]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.check_call(cmd)
+    return HOST_BIN
+
+
 if __name__ == "__main__":
     print(build(force=True, verbose=True))
+    print(build_host(force=True, verbose=True))

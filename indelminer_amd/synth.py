@@ -28,12 +28,17 @@ def random_genome(rng, length):
     return ACGT[rng.integers(0, 4, size=length, dtype=np.uint8)]
 
 
-def plant_indels(rng, ref_len, spacing=2000, max_size=50, margin=1500):
-    """Indel events on reference coordinates, about one per `spacing` bases."""
+def plant_indels(rng, ref_len, spacing=2000, max_size=50, margin=1500, big_every=0):
+    """Indel events on reference coordinates, about one per `spacing` bases.  With big_every = k
+    every k-th event is a 150-900 bp deletion (discordant pairs -> PAIRED_READ / COMPOSITE calls)."""
     pos = np.arange(margin, ref_len - margin, spacing, dtype=np.int64)
     pos = pos + rng.integers(-spacing // 4, spacing // 4 + 1, size=len(pos))
     size = rng.integers(1, max_size + 1, size=len(pos))
     is_ins = rng.random(len(pos)) < 0.5
+    if big_every:
+        big = (np.arange(len(pos)) % big_every) == (big_every - 1)
+        size = np.where(big, rng.integers(150, 900, size=len(pos)), size)
+        is_ins = np.where(big, False, is_ins)
     return pos, size, is_ins
 
 
@@ -66,16 +71,17 @@ class Reads:
 
 
 def simulate(seed, ref_len=1_000_000, coverage=30, read_len=100, isize_mean=500, isize_sd=50,
-             isize_min=300, isize_max=700, sub_rate=0.005, indel_spacing=2000, n_contigs=1):
+             isize_min=300, isize_max=700, sub_rate=0.005, indel_spacing=2000, n_contigs=1, big_every=0):
     """Returns (refs, reads): refs = list of uint8 arrays (one per contig); reads = Reads."""
     rng = np.random.default_rng(seed)
     L = read_len
     refs = []
-    cols = {k: [] for k in ("tid", "pos", "flag", "mpos", "isize", "seq", "cig_op", "cig_len", "ncig", "mate_first")}
+    cols = {k: [] for k in ("tid", "pos", "flag", "mpos", "isize", "seq", "cig_op", "cig_len", "ncig", "mate_first", "pair_id")}
+    pair_base = 0
     for tid in range(n_contigs):
         ref = random_genome(rng, ref_len)
         refs.append(ref)
-        epos, esize, eins = plant_indels(rng, ref_len, indel_spacing)
+        epos, esize, eins = plant_indels(rng, ref_len, indel_spacing, big_every=big_every)
         donor, edpos = build_donor(rng, ref, epos, esize, eins)
         dlen = len(donor)
         # donor -> reference shift after each event
@@ -137,7 +143,7 @@ def simulate(seed, ref_len=1_000_000, coverage=30, read_len=100, isize_mean=500,
                 ref_left = s + int(cshift[e])
                 if a <= 0 or b <= 0:
                     continue
-                if a >= 20 and b >= 20:
+                if a >= 20 and b >= 20 and esize[e] <= 50:
                     ops = [(a, OP_M), (int(esize[e]), OP_D), (b, OP_M)]; p = ref_left
                 elif a >= b:
                     ops = [(a, OP_M), (b, OP_S)]; p = ref_left
@@ -159,13 +165,14 @@ def simulate(seed, ref_len=1_000_000, coverage=30, read_len=100, isize_mean=500,
         flag |= np.where(np.arange(n) < n_pairs, 0x40, 0x80)
         flag |= np.where(is_rev, 0x10, 0) | np.where(is_rev[mate], 0x20, 0)
         flag |= np.where(unmapped, 0x4, 0) | np.where(m_unm, 0x8, 0)
-        flag |= np.where(~unmapped & ~m_unm, 0x2, 0)
         # reference span of each read for TLEN
         span = np.where(unmapped, 0, (cig_len * np.isin(cig_op, (OP_M, OP_D)) * (np.arange(3)[None, :] < ncig[:, None])).sum(1))
         end = pos + span
         lo = np.minimum(pos, pos[mate]); hi = np.maximum(end, end[mate])
         tl = (hi - lo).astype(np.int64)
         isize = np.where(unmapped | m_unm, 0, np.where(pos <= pos[mate], tl, -tl))
+        # proper pair: both mapped and the observed template within the library's range
+        flag |= np.where(~unmapped & ~m_unm & (tl <= isize_max), 0x2, 0)
         keep = ~both_unm
         order = np.argsort(pos[keep], kind="stable")
         sel = np.nonzero(keep)[0][order]
@@ -174,6 +181,8 @@ def simulate(seed, ref_len=1_000_000, coverage=30, read_len=100, isize_mean=500,
         cols["mpos"].append(mpos[sel].astype(np.int32)); cols["isize"].append(isize[sel].astype(np.int32))
         cols["seq"].append(seq[sel]); cols["cig_op"].append(cig_op[sel]); cols["cig_len"].append(cig_len[sel])
         cols["ncig"].append(ncig[sel]); cols["mate_first"].append((np.arange(n) < n_pairs)[sel])
+        cols["pair_id"].append((pair_base + (np.arange(n) % n_pairs))[sel])
+        pair_base += n_pairs
     rd = Reads()
     for k, v in cols.items():
         setattr(rd, k, np.concatenate(v))

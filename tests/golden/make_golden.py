@@ -153,6 +153,31 @@ def make_vcfs():
     print("vcf/annotate.vcf rc", r.returncode, len(r.stdout.splitlines()), "lines")
 
 
+SYNTH_E2E = {
+    # name: simulate() arguments.  The BAM is regenerated from the seed wherever the test runs.
+    "synth_2ctg_composite": dict(seed=3, ref_len=200_000, coverage=30, n_contigs=2, big_every=5),
+    "synth_1mb_30x": dict(seed=1, ref_len=1_000_000, coverage=30, n_contigs=1, big_every=7),
+}
+
+
+def make_synth_vcfs():
+    """Reference stdout on seeded synthetic BAMs (insertions, COMPOSITE calls, > READCHUNK reads)."""
+    import tempfile
+    from indelminer_amd import bamwrite, synth
+    outdir = os.path.join(HERE, "vcf")
+    for name, kw in SYNTH_E2E.items():
+        with tempfile.TemporaryDirectory() as td:
+            refs, rd = synth.simulate(**kw)
+            contigs = [("ctg%d" % i, len(r)) for i, r in enumerate(refs)]
+            bamwrite.write_fasta(td + "/ref.fa", contigs, refs)
+            bamwrite.write_bam(td + "/aln.bam", contigs, rd)
+            open(td + "/cfg.txt", "w").write("IL generic 300 700\n")
+            for suffix, flags in (("", ["-i", "cfg.txt"]), ("_noconfig", [])):
+                r = subprocess.run([refbind.BIN] + flags + ["ref.fa", "s=aln.bam"], cwd=td, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+                open(os.path.join(outdir, name + suffix + ".vcf"), "wb").write(r.stdout)
+                print("vcf/%s%s.vcf rc %d, %d lines" % (name, suffix, r.returncode, len(r.stdout.splitlines())))
+
+
 if __name__ == "__main__":
     if not refbind.available():
         sys.exit("oracle/_ref/libimref.so missing: run `make -C oracle ref` in the build container")
@@ -160,3 +185,4 @@ if __name__ == "__main__":
     make_testdata(R)
     make_synth(R)
     make_vcfs()
+    make_synth_vcfs()
