@@ -179,6 +179,40 @@ def cpu_reference_baseline(ref, cand, read_len, n_reads_total, budget_s=12.0):
     return info, out
 
 
+def end_to_end(refs, rd):
+    """Whole programs on the bench workload written out as BAM: the reference binary (compiled in
+    place from its sources, oracle/_ref) and the product driver (indelminer_amd/indelminer, GPU),
+    same flags, VCF compared byte for byte.  Reported beside the kernel-level numbers; never `value`."""
+    import subprocess
+    import tempfile
+    from indelminer_amd import bamwrite, build
+    ref_bin = os.path.join(ROOT, "oracle", "_ref", "indelminer")
+    prod = build.HOST_BIN
+    if not os.path.exists(prod):
+        return None
+    with tempfile.TemporaryDirectory() as td:
+        contigs = [("ctg%d" % i, len(r)) for i, r in enumerate(refs)]
+        bamwrite.write_fasta(td + "/ref.fa", contigs, refs)
+        bamwrite.write_bam(td + "/aln.bam", contigs, rd)
+        open(td + "/cfg.txt", "w").write("IL generic 300 %d\n" % rd.range_max)
+        cmd = ["-i", "cfg.txt", "ref.fa", "s=aln.bam"]
+        out = {"reads": int(rd.n)}
+        t = time.perf_counter()
+        p = subprocess.run([prod] + cmd, cwd=td, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+        out["product_wall_s"] = time.perf_counter() - t
+        out["product_rc"] = p.returncode
+        out["vcf_records"] = sum(1 for l in p.stdout.splitlines() if not l.startswith(b"#"))
+        if os.path.exists(ref_bin):
+            t = time.perf_counter()
+            q = subprocess.run([ref_bin] + cmd, cwd=td, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+            out["reference_wall_s"] = time.perf_counter() - t
+            out["reference_reads_per_s"] = rd.n / out["reference_wall_s"]
+            out["vcf_identical_to_reference"] = bool(q.returncode == 0 and q.stdout == p.stdout)
+        out["product_reads_per_s"] = rd.n / out["product_wall_s"]
+        out["note"] = "whole programs incl. process start, BAM decode, GPU context creation and reference upload; 1 host thread"
+        return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -280,6 +314,12 @@ def main():
                 ok &= ~has | ((ev0["cls"] == ref_out[:, 1]) & (ev0["b1"] == ref_out[:, 2]) & (ev0["b2"] == ref_out[:, 3]))
                 parity = "identical to the reference on %d sampled reads" % m if bool(ok.all()) else \
                     "MISMATCH on %d of %d sampled reads" % (int((~ok).sum()), m)
+        e2e = None
+        if world == 1 and not args.no_cpu_baseline:
+            try:
+                e2e = end_to_end(refs, rd)
+            except Exception as ex:              # plumbing; never hides the kernel numbers
+                e2e = {"error": str(ex)}
         line = {
             "metric": "reads/sec through split-read realign+cluster; VCF diff-clean vs reference",
             "value": value, "unit": "reads/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -302,6 +342,7 @@ def main():
                          "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": float(kern_ms.mean()),
                          "min_launch_ms": float(kern_ms.min())},
             "cpu_baseline": cpu,
+            "end_to_end": e2e,
         }
         print(json.dumps(line))
     if dist is not None:
