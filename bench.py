@@ -88,8 +88,11 @@ class Shard:
         self.batch = capi.DevBatch(n, self.d_bases.ptr, self.d_off.ptr, self.d_len.ptr, self.d_tid.ptr,
                                    self.d_anchor.ptr, self.d_range.ptr, self.d_res.ptr,
                                    self.d_cls.ptr, self.d_b1.ptr, self.d_b2.ptr)
+        self.hs_bytes = L_.im_dev_cluster_hist_scratch_bytes(cap)
+        self.d_hs = capi.DevBuf(ctx, self.hs_bytes)
+        ctx._check(L_.im_dev_cluster_hist_init(ctx.h, cap, self.d_hs.ptr, self.hs_bytes, ctx.stream))
         self.P = capi.params()
-        self.small = True                        # single-launch cluster path; cleared if it overflows
+        self.small = True                        # breakpoint-histogram cluster path; cleared if it overflows
         # multi-GPU: per-shard cluster list (16 B records) and the gathered lists of all ranks
         self.tid = 0
         self.rec_cap = 16384
@@ -111,9 +114,9 @@ class Shard:
         if timer is not None:
             timer.stop(st)
         if self.small:
-            ctx._check(L_.im_dev_cluster_slots(ctx.h, self.cap, self.d_cls.ptr, self.d_b1.ptr, self.d_b2.ptr,
-                                               2**31 - 1, 0, self.d_order.ptr, self.d_first.ptr, self.d_count.ptr,
-                                               self.d_used.ptr, self.d_counts.ptr, st))
+            ctx._check(L_.im_dev_cluster_hist(ctx.h, self.cap, self.d_cls.ptr, self.d_b1.ptr, self.d_b2.ptr,
+                                              2**31 - 1, 0, self.d_order.ptr, self.d_first.ptr, self.d_count.ptr,
+                                              self.d_used.ptr, self.d_counts.ptr, self.d_hs.ptr, self.hs_bytes, st))
         else:
             ctx._check(L_.im_dev_gather_evidence(ctx.h, self.d_res.ptr, self.n, self.d_dcls.ptr, self.d_db1.ptr,
                                                  self.d_db2.ptr, self.d_src.ptr, self.cap, self.d_nout.ptr,
@@ -331,7 +334,7 @@ def main():
                        "reads_per_step": total_reads, "candidates_per_step": total_cand,
                        "evidence_per_step_rank0": nev, "clusters_per_step_rank0": ncl,
                        "candidates_per_s": total_cand * args.steps / elapsed,
-                       "cluster_path": "single-workgroup" if shard.small else "radix multi-kernel",
+                       "cluster_path": "breakpoint histogram (4 launches)" if shard.small else "radix multi-kernel",
                        "parallelism": "contig-sharded x%d" % world, "collective": collective,
                        "gathered_clusters": gathered_clusters,
                        "timed_region": "realign kernel + SR cluster kernel(s) on the resident candidate batch; "

@@ -219,6 +219,23 @@ int im_dev_cluster_slots(im_ctx* ctx, int32_t n_slots,
                          uint8_t* used, int32_t* counts, void* stream);
 int im_dev_cluster_slots_max(void);
 
+/* Breakpoint-histogram form (the default for evidence SLOT arrays): hash the live slots into
+ * a table of distinct (b1,b2,class) breakpoints with their support, sort only the distinct
+ * breakpoints, drop every record into its cluster's slice and order the slice by arrival.
+ * Four launches, any n_slots.  Same outputs as im_dev_cluster_slots.  Limits: 8192 distinct
+ * breakpoints and 1024 records per breakpoint per call; beyond them counts[0] = -1 and the
+ * caller takes the im_dev_gather_evidence + im_dev_cluster_sr path (after a distinct-key
+ * overflow the scratch must be re-initialised).  scratch: im_dev_cluster_hist_scratch_bytes(n_slots)
+ * bytes, prepared ONCE with im_dev_cluster_hist_init; every call leaves it clean.  Asynchronous. */
+size_t im_dev_cluster_hist_scratch_bytes(int32_t n_slots);
+int im_dev_cluster_hist_init(im_ctx* ctx, int32_t n_slots, void* scratch, size_t scratch_bytes, void* stream);
+int im_dev_cluster_hist(im_ctx* ctx, int32_t n_slots,
+                        const int32_t* cls, const int32_t* b1, const int32_t* b2,
+                        int32_t marker, int32_t tie_desc,
+                        int32_t* order, int32_t* cl_first, int32_t* cl_count,
+                        uint8_t* used, int32_t* counts,
+                        void* scratch, size_t scratch_bytes, void* stream);
+
 /* Gather the evidence records of a realigned batch into dense SoA arrays
  * (arrival order = read order, then segment order), the input format of
  * im_dev_cluster_sr.  n_out is a device int32 (number of records written);

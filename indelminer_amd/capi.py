@@ -117,6 +117,12 @@ def lib():
         L.im_comm_destroy.argtypes = [C.c_void_p]
         L.im_comm_destroy.restype = None
         L.im_comm_last_error.restype = C.c_char_p
+        L.im_dev_cluster_hist_scratch_bytes.restype = C.c_size_t
+        L.im_dev_cluster_hist_scratch_bytes.argtypes = [C.c_int32]
+        L.im_dev_cluster_hist_init.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_size_t, C.c_void_p]
+        L.im_dev_cluster_hist.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32,
+                                          C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                          C.c_void_p, C.c_size_t, C.c_void_p]
         L.im_dev_alloc.argtypes = [C.c_void_p, C.c_size_t, C.POINTER(C.c_void_p)]
         L.im_dev_free.argtypes = [C.c_void_p, C.c_void_p]
         L.im_dev_upload.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]

@@ -295,6 +295,29 @@ int im_dev_cluster_slots(im_ctx* ctx, int32_t n_slots, const int32_t* cls, const
     return IM_OK;
 }
 
+size_t im_dev_cluster_hist_scratch_bytes(int32_t n_slots) { return im::cluster_hist_scratch_bytes(n_slots); }
+
+int im_dev_cluster_hist_init(im_ctx* ctx, int32_t n_slots, void* scratch, size_t scratch_bytes, void* stream)
+{
+    if (!ctx) return IM_E_ARG;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, im::launch_cluster_hist_init(n_slots, scratch, scratch_bytes, (hipStream_t)stream));
+    return IM_OK;
+}
+
+int im_dev_cluster_hist(im_ctx* ctx, int32_t n_slots, const int32_t* cls, const int32_t* b1, const int32_t* b2,
+                        int32_t marker, int32_t tie_desc,
+                        int32_t* order, int32_t* cl_first, int32_t* cl_count, uint8_t* used, int32_t* counts,
+                        void* scratch, size_t scratch_bytes, void* stream)
+{
+    if (!ctx) return IM_E_ARG;
+    if (n_slots < 0 || !counts) { set_err(ctx, "bad slot arguments"); return IM_E_ARG; }
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, im::launch_cluster_hist(n_slots, cls, b1, b2, marker, tie_desc, order, cl_first, cl_count, used, counts,
+                                         scratch, scratch_bytes, (hipStream_t)stream));
+    return IM_OK;
+}
+
 int im_dev_gather_evidence(im_ctx* ctx, const im_read_result* res, int32_t n,
                            int32_t* cls, int32_t* b1, int32_t* b2, int32_t* src,
                            int32_t cap, int32_t* n_out, void* scratch, size_t scratch_bytes, void* stream)
@@ -316,7 +339,8 @@ int im_cluster_sr(im_ctx* ctx, int32_t n, const int32_t* cls, const int32_t* b1,
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     const size_t a32 = up256(sizeof(int32_t) * (size_t)n);
     const size_t scratch = im::cluster_scratch_bytes(n);
-    int rc = ensure_ws(ctx, 6 * a32 + up256((size_t)n) + 256 + scratch);
+    const size_t hist_bytes = im::cluster_hist_scratch_bytes(n);
+    int rc = ensure_ws(ctx, 6 * a32 + up256((size_t)n) + 256 + up256(scratch) + hist_bytes);
     if (rc) return rc;
     char* w = static_cast<char*>(ctx->ws);
     int32_t* d_cls = (int32_t*)w; w += a32;
@@ -328,19 +352,25 @@ int im_cluster_sr(im_ctx* ctx, int32_t n, const int32_t* cls, const int32_t* b1,
     uint8_t* d_used = (uint8_t*)w; w += up256((size_t)n);
     int32_t* d_ncl = (int32_t*)w; w += 128;
     int32_t* d_n = (int32_t*)w; w += 128;
-    void* d_scratch = w;
+    void* d_scratch = w; w += up256(scratch);
+    void* d_hist = w;
     HIP_TRY(ctx, hipMemcpyAsync(d_cls, cls, sizeof(int32_t) * (size_t)n, hipMemcpyHostToDevice, ctx->stream));
     HIP_TRY(ctx, hipMemcpyAsync(d_b1, b1, sizeof(int32_t) * (size_t)n, hipMemcpyHostToDevice, ctx->stream));
     HIP_TRY(ctx, hipMemcpyAsync(d_b2, b2, sizeof(int32_t) * (size_t)n, hipMemcpyHostToDevice, ctx->stream));
     HIP_TRY(ctx, hipMemcpyAsync(d_n, &n, sizeof(int32_t), hipMemcpyHostToDevice, ctx->stream));
-    if (n <= im::cluster_small_max()) {
-        // every record is live: the slot form with n slots is the same computation in one launch
-        HIP_TRY(ctx, im::launch_cluster_small(n, nullptr, d_cls, d_b1, d_b2, marker, tie_desc, d_order, d_first, d_count,
-                                              d_used, d_ncl, ctx->stream));
-    } else {
-        rc = im_dev_cluster_sr(ctx, n, d_n, d_cls, d_b1, d_b2, marker, tie_desc, d_order, d_first, d_count, d_used, d_ncl,
-                               d_scratch, scratch, ctx->stream);
-        if (rc) return rc;
+    {
+        // breakpoint-histogram path: every record is a live slot
+        HIP_TRY(ctx, im::launch_cluster_hist_init(n, d_hist, hist_bytes, ctx->stream));
+        HIP_TRY(ctx, im::launch_cluster_hist(n, d_cls, d_b1, d_b2, marker, tie_desc, d_order, d_first, d_count, d_used, d_ncl,
+                                             d_hist, hist_bytes, ctx->stream));
+        int32_t got = 0;
+        HIP_TRY(ctx, hipMemcpyAsync(&got, d_ncl, sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        if (got < 0) {      // more distinct breakpoints / deeper clusters than the histogram holds: radix path
+            rc = im_dev_cluster_sr(ctx, n, d_n, d_cls, d_b1, d_b2, marker, tie_desc, d_order, d_first, d_count, d_used, d_ncl,
+                                   d_scratch, scratch, ctx->stream);
+            if (rc) return rc;
+        }
     }
     HIP_TRY(ctx, hipMemcpyAsync(n_clusters, d_ncl, sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));

@@ -25,6 +25,8 @@
 namespace im {
 namespace {
 
+inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
+
 constexpr int kSortThreads = 256;
 constexpr int kSortItems = 8;
 constexpr int kSortTile = kSortThreads * kSortItems;     // 2048 records per workgroup
@@ -362,6 +364,237 @@ __global__ __launch_bounds__(kSmallThreads) void cluster_small_kernel(
     if (tid == 0) { out_counts[0] = (int32_t)ncl; out_counts[1] = (int32_t)nv; }
 }
 
+// ---- breakpoint-histogram path ------------------------------------------------
+//
+// Split-read clusters are exact-key groups, so sorting every evidence record is more
+// than the problem needs: hash the records into a breakpoint histogram (one table
+// entry per distinct (b1,b2,class) with its support count), sort only the DISTINCT
+// breakpoints (typically 10x fewer than records), then drop every record into its
+// cluster's slice and order each slice by arrival.  Four launches, all but the
+// distinct-key sort many-workgroup; the table cleans itself for the next call.
+//
+//   hist_insert   live slot -> table entry (64-bit CAS), support count, list of new entries
+//   hist_sort     one workgroup: bitonic sort of the distinct keys, marker cut, offsets
+//   hist_place    record -> order[first[cluster] + cursor++]
+//   hist_finish   one wave per cluster: order the slice by slot (= arrival), reset the entry
+//
+// Limits (else counts[0] = -1 and the caller takes the radix path): kHistMaxKeys distinct
+// breakpoints, kHistMaxSupport records per breakpoint.
+
+constexpr int kHistMaxKeys = 8192;
+constexpr int kHistMaxSupport = 1024;
+constexpr uint64_t kEmptyKey = ~0ull;
+
+struct HistScratch {
+    uint64_t* keys;         // [H]
+    uint32_t* cnt;          // [H]
+    uint32_t* rank;         // [H] cluster id of a table entry, ~0 = behind the marker cut
+    uint32_t* slot_h;       // [n_slots]
+    uint32_t* uniq;         // [kHistMaxKeys] table positions in first-touch order
+    uint32_t* sorted_h;     // [kHistMaxKeys] table positions in key order
+    uint32_t* cursor;       // [kHistMaxKeys]
+    uint32_t* misc;         // [0] distinct keys, [1] live records, [2] overflow, [3] clusters after the cut
+    uint32_t  H;
+};
+
+__device__ __forceinline__ uint64_t hist_key(int32_t cls, int32_t b1, int32_t b2)
+{
+    // ascending key order == ascending (b1, b2, class)
+    return ((uint64_t)(uint32_t)b1 << 32) | (uint64_t)(((uint32_t)b2 << 1) | (uint32_t)(cls & 1));
+}
+__device__ __forceinline__ int32_t hist_key_b1(uint64_t k) { return (int32_t)(k >> 32); }
+__device__ __forceinline__ int32_t hist_key_b2(uint64_t k) { return (int32_t)((uint32_t)k >> 1); }
+__device__ __forceinline__ uint32_t hist_hash(uint64_t k)
+{
+    k ^= k >> 33; k *= 0xff51afd7ed558ccdull; k ^= k >> 33; k *= 0xc4ceb9fe1a85ec53ull; k ^= k >> 33;
+    return (uint32_t)k;
+}
+
+__global__ __launch_bounds__(256) void hist_insert_kernel(int32_t n_slots, const int32_t* __restrict__ cls,
+                                                         const int32_t* __restrict__ b1, const int32_t* __restrict__ b2,
+                                                         HistScratch s, uint8_t* __restrict__ used)
+{
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n_slots; i += (int64_t)gridDim.x * blockDim.x) {
+        if (used) used[i] = 0;
+        const int32_t c = cls[i];
+        if (c < 0) { s.slot_h[i] = 0xFFFFFFFFu; continue; }
+        const uint64_t key = hist_key(c, b1[i], b2[i]);
+        uint32_t h = hist_hash(key) & (s.H - 1);
+        for (;;) {
+            const uint64_t old = atomicCAS(reinterpret_cast<unsigned long long*>(&s.keys[h]), kEmptyKey, key);
+            if (old == kEmptyKey) {
+                const uint32_t u = atomicAdd(&s.misc[0], 1u);
+                if (u < (uint32_t)kHistMaxKeys) s.uniq[u] = h;
+                break;
+            }
+            if (old == key) break;
+            h = (h + 1) & (s.H - 1);
+        }
+        atomicAdd(&s.cnt[h], 1u);
+        atomicAdd(&s.misc[1], 1u);
+        s.slot_h[i] = h;
+    }
+}
+
+struct HistSortLds {
+    uint64_t key[kHistMaxKeys];
+    uint32_t h[kHistMaxKeys];
+    uint32_t wsum[kSmallThreads / 64];
+    uint32_t cut;
+};
+
+__global__ __launch_bounds__(kSmallThreads) void hist_sort_kernel(HistScratch s, int32_t marker,
+                                                                 int32_t* __restrict__ cl_first, int32_t* __restrict__ cl_count,
+                                                                 int32_t* __restrict__ out_counts)
+{
+    extern __shared__ __align__(16) unsigned char smem_raw[];
+    HistSortLds& L = *reinterpret_cast<HistSortLds*>(smem_raw);
+    const int tid = threadIdx.x;
+    const uint32_t nu = s.misc[0];
+    if (nu > (uint32_t)kHistMaxKeys) {
+        if (tid == 0) { s.misc[2] = 1; s.misc[3] = 0; out_counts[0] = -1; out_counts[1] = (int32_t)s.misc[1]; }
+        return;
+    }
+    uint32_t P = 2;
+    while (P < nu) P <<= 1;
+    for (uint32_t p = tid; p < P; p += kSmallThreads) {
+        if (p < nu) { const uint32_t h = s.uniq[p]; L.h[p] = h; L.key[p] = s.keys[h]; }
+        else { L.h[p] = 0xFFFFFFFFu; L.key[p] = kEmptyKey; }
+    }
+    __syncthreads();
+    for (uint32_t k = 2; k <= P; k <<= 1) {
+        for (uint32_t j = k >> 1; j > 0; j >>= 1) {
+            for (uint32_t t = tid; t < (P >> 1); t += kSmallThreads) {
+                const uint32_t lo = ((t & ~(j - 1)) << 1) | (t & (j - 1));
+                const uint32_t hi = lo | j;
+                const bool asc = (lo & k) == 0;
+                const uint64_t a = L.key[lo], c = L.key[hi];
+                if ((c < a) == asc) {
+                    const uint32_t ha = L.h[lo], hc = L.h[hi];
+                    L.key[lo] = c; L.key[hi] = a; L.h[lo] = hc; L.h[hi] = ha;
+                }
+            }
+            __syncthreads();
+        }
+    }
+    // marker cut: clusters exist only for the sorted prefix before the first b2 >= marker
+    if (tid == 0) L.cut = nu;
+    __syncthreads();
+    {
+        uint32_t best = 0xFFFFFFFFu;
+        for (uint32_t p = tid; p < nu; p += kSmallThreads) if (hist_key_b2(L.key[p]) >= marker) { best = p; break; }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) best = min(best, (uint32_t)__shfl_xor((int)best, o));
+        if ((tid & 63) == 0 && best != 0xFFFFFFFFu) atomicMin(&L.cut, best);
+    }
+    __syncthreads();
+    const uint32_t m = L.cut;
+    // offsets: exclusive scan of the supports in key order (8 consecutive keys per thread)
+    constexpr int kPer = kHistMaxKeys / kSmallThreads;
+    uint32_t c[kPer], tot = 0, big = 0;
+#pragma unroll
+    for (int e = 0; e < kPer; e++) {
+        const uint32_t p = (uint32_t)tid * kPer + e;
+        c[e] = (p < m) ? s.cnt[L.h[p]] : 0u;
+        tot += c[e];
+        big |= (c[e] > (uint32_t)kHistMaxSupport) ? 1u : 0u;
+    }
+    uint32_t total;
+    uint32_t off = block_scan_excl(tot, L.wsum, &total);
+    (void)total;
+#pragma unroll
+    for (int e = 0; e < kPer; e++) {
+        const uint32_t p = (uint32_t)tid * kPer + e;
+        if (p < nu) {
+            const uint32_t h = L.h[p];
+            s.sorted_h[p] = h;
+            if (p < m) { cl_first[p] = (int32_t)off; cl_count[p] = (int32_t)c[e]; s.rank[h] = p; s.cursor[p] = 0; off += c[e]; }
+            else s.rank[h] = 0xFFFFFFFFu;
+        }
+    }
+    if (__syncthreads_or((int)big) && tid == 0) s.misc[2] = 1;
+    if (tid == 0) { s.misc[3] = m; out_counts[0] = (int32_t)m; out_counts[1] = (int32_t)s.misc[1]; }
+}
+
+__global__ __launch_bounds__(256) void hist_place_kernel(int32_t n_slots, HistScratch s, const int32_t* __restrict__ cl_first,
+                                                        int32_t* __restrict__ order, uint8_t* __restrict__ used)
+{
+    if (s.misc[0] > (uint32_t)kHistMaxKeys) return;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n_slots; i += (int64_t)gridDim.x * blockDim.x) {
+        const uint32_t h = s.slot_h[i];
+        if (h == 0xFFFFFFFFu) continue;
+        const uint32_t c = s.rank[h];
+        if (c == 0xFFFFFFFFu) continue;
+        const uint32_t p = atomicAdd(&s.cursor[c], 1u);
+        order[cl_first[c] + (int32_t)p] = (int32_t)i;
+        if (used) used[i] = 1;
+    }
+}
+
+// one wave per distinct key: order the cluster's slice by slot index, then reset the table entry
+__global__ __launch_bounds__(256) void hist_finish_kernel(HistScratch s, const int32_t* __restrict__ cl_first,
+                                                         const int32_t* __restrict__ cl_count, int32_t tie_desc,
+                                                         int32_t* __restrict__ order, int32_t* __restrict__ out_counts)
+{
+    __shared__ int32_t stage[4][kHistMaxSupport];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const uint32_t nu_raw = s.misc[0];
+    const bool overflow_keys = nu_raw > (uint32_t)kHistMaxKeys;
+    const uint32_t nu = overflow_keys ? 0u : nu_raw;
+    const uint32_t m = s.misc[3];
+    const bool bad = s.misc[2] != 0;
+    const uint32_t waves = gridDim.x * 4;
+    for (uint32_t p = blockIdx.x * 4 + wave; p < nu; p += waves) {
+        const uint32_t h = s.sorted_h[p];
+        if (p < m && !bad) {
+            const int32_t f = cl_first[p], cnt = cl_count[p];
+            if (cnt > 1 || tie_desc) {
+                int32_t* st = stage[wave];
+                for (int32_t t = lane; t < cnt; t += 64) st[t] = order[f + t];
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+                for (int32_t t = lane; t < cnt; t += 64) {
+                    const int32_t v = st[t];
+                    int32_t r = 0;
+                    for (int32_t j = 0; j < cnt; j++) r += (st[j] < v) ? 1 : 0;
+                    order[f + (tie_desc ? (cnt - 1 - r) : r)] = v;
+                }
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+                __builtin_amdgcn_wave_barrier();
+            }
+        }
+        if (lane == 0) { s.keys[h] = kEmptyKey; s.cnt[h] = 0; }
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        if (bad && !overflow_keys) out_counts[0] = -1;
+        if (!overflow_keys) { s.misc[0] = 0; s.misc[1] = 0; s.misc[2] = 0; s.misc[3] = 0; }
+    }
+}
+
+inline uint32_t hist_table_size(int32_t n_slots)
+{
+    uint32_t H = 1024;
+    while (H < 2u * (uint32_t)(n_slots > 0 ? n_slots : 1)) H <<= 1;
+    return H;
+}
+
+inline size_t hist_carve(HistScratch* hs, void* base, int32_t n_slots)
+{
+    const uint32_t H = hist_table_size(n_slots);
+    const size_t nn = (size_t)(n_slots > 0 ? n_slots : 1);
+    size_t off = 0;
+    auto take = [&](size_t bytes) { size_t o = off; off = align_up(off + bytes, 256); return o; };
+    const size_t oK = take((size_t)H * 8), oC = take((size_t)H * 4), oR = take((size_t)H * 4), oS = take(nn * 4);
+    const size_t oU = take((size_t)kHistMaxKeys * 4), oSh = take((size_t)kHistMaxKeys * 4), oCu = take((size_t)kHistMaxKeys * 4), oM = take(64);
+    if (hs) {
+        char* b = static_cast<char*>(base);
+        hs->keys = (uint64_t*)(b + oK); hs->cnt = (uint32_t*)(b + oC); hs->rank = (uint32_t*)(b + oR); hs->slot_h = (uint32_t*)(b + oS);
+        hs->uniq = (uint32_t*)(b + oU); hs->sorted_h = (uint32_t*)(b + oSh); hs->cursor = (uint32_t*)(b + oCu); hs->misc = (uint32_t*)(b + oM);
+        hs->H = H;
+    }
+    return off;
+}
+
 // ---- evidence gather ----------------------------------------------------------
 
 __global__ __launch_bounds__(256) void count_ev_kernel(const im_read_result* __restrict__ res, int32_t n, uint32_t* __restrict__ cnt)
@@ -396,7 +629,6 @@ inline int grid_for(int64_t n, int threads)
     return (int)b;
 }
 
-inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 
 struct ClusterScratch {
     uint64_t *keysA, *keysB;
@@ -488,6 +720,42 @@ hipError_t launch_cluster_records(int32_t tid, const int32_t* counts, const int3
 }
 
 int cluster_small_max() { return kSmallMax; }
+
+size_t cluster_hist_scratch_bytes(int32_t n_slots) { return hist_carve(nullptr, nullptr, n_slots); }
+
+// scratch must be prepared once with launch_cluster_hist_init (and again after an overflow return)
+hipError_t launch_cluster_hist_init(int32_t n_slots, void* scratch, size_t scratch_bytes, hipStream_t stream)
+{
+    HistScratch hs;
+    if (hist_carve(&hs, scratch, n_slots) > scratch_bytes) return hipErrorInvalidValue;
+    hipError_t e = hipMemsetAsync(hs.keys, 0xFF, (size_t)hs.H * 8, stream);
+    if (e == hipSuccess) e = hipMemsetAsync(hs.cnt, 0, (size_t)hs.H * 4, stream);
+    if (e == hipSuccess) e = hipMemsetAsync(hs.misc, 0, 64, stream);
+    return e;
+}
+
+hipError_t launch_cluster_hist(int32_t n_slots, const int32_t* cls, const int32_t* b1, const int32_t* b2,
+                               int32_t marker, int32_t tie_desc,
+                               int32_t* order, int32_t* cl_first, int32_t* cl_count,
+                               uint8_t* used, int32_t* out_counts,
+                               void* scratch, size_t scratch_bytes, hipStream_t stream)
+{
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(hist_sort_kernel),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(HistSortLds));
+        if (e != hipSuccess) return e;
+        attr_set = true;
+    }
+    HistScratch hs;
+    if (hist_carve(&hs, scratch, n_slots) > scratch_bytes) return hipErrorInvalidValue;
+    const int g = grid_for(n_slots, 256);
+    hipLaunchKernelGGL(hist_insert_kernel, dim3(g), dim3(256), 0, stream, n_slots, cls, b1, b2, hs, used);
+    hipLaunchKernelGGL(hist_sort_kernel, dim3(1), dim3(kSmallThreads), sizeof(HistSortLds), stream, hs, marker, cl_first, cl_count, out_counts);
+    hipLaunchKernelGGL(hist_place_kernel, dim3(g), dim3(256), 0, stream, n_slots, hs, cl_first, order, used);
+    hipLaunchKernelGGL(hist_finish_kernel, dim3(512), dim3(256), 0, stream, hs, cl_first, cl_count, tie_desc, order, out_counts);
+    return hipGetLastError();
+}
 
 hipError_t launch_cluster_small(int32_t n_slots, const int32_t* n_slots_dev,
                                 const int32_t* cls, const int32_t* b1, const int32_t* b2,

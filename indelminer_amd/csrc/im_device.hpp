@@ -49,6 +49,13 @@ hipError_t launch_cluster_records(int32_t tid, const int32_t* counts, const int3
                                   const int32_t* cl_count, const int32_t* cls, const int32_t* b1, const int32_t* b2,
                                   int32_t* recs, int32_t cap, hipStream_t stream);
 int cluster_small_max();
+size_t cluster_hist_scratch_bytes(int32_t n_slots);
+hipError_t launch_cluster_hist_init(int32_t n_slots, void* scratch, size_t scratch_bytes, hipStream_t stream);
+hipError_t launch_cluster_hist(int32_t n_slots, const int32_t* cls, const int32_t* b1, const int32_t* b2,
+                               int32_t marker, int32_t tie_desc,
+                               int32_t* order, int32_t* cl_first, int32_t* cl_count,
+                               uint8_t* used, int32_t* out_counts,
+                               void* scratch, size_t scratch_bytes, hipStream_t stream);
 hipError_t launch_cluster_small(int32_t n_slots, const int32_t* n_slots_dev,
                                 const int32_t* cls, const int32_t* b1, const int32_t* b2,
                                 int32_t marker, int32_t tie_desc,

@@ -60,9 +60,11 @@ def test_cluster_sortedness_and_grouping_large(gpu_ctx):
     assert np.array_equal(heads[1:], ~same)
 
 
-def test_cluster_slots_matches_oracle(gpu_ctx):
-    """Slot form (empty slots = cls -1) through im_dev_cluster_slots: same clusters as the oracle
-    on the compacted records, order[] in slot indices."""
+@pytest.mark.parametrize("path", ["slots", "hist"])
+def test_cluster_slots_matches_oracle(gpu_ctx, path):
+    """Slot form (empty slots = cls -1) through im_dev_cluster_slots (one workgroup) and
+    im_dev_cluster_hist (breakpoint histogram): same clusters as the oracle on the compacted
+    records, order[] in slot indices; the histogram scratch must come back clean (3 rounds)."""
     import ctypes as C
     from indelminer_amd import capi
     L = capi.lib()
@@ -79,13 +81,24 @@ def test_cluster_slots_matches_oracle(gpu_ctx):
             bufs[name] = capi.DevBuf(gpu_ctx, 4 * n_slots).upload(arr)
         d_order = capi.DevBuf(gpu_ctx, 4 * n_slots); d_first = capi.DevBuf(gpu_ctx, 4 * n_slots)
         d_count = capi.DevBuf(gpu_ctx, 4 * n_slots); d_used = capi.DevBuf(gpu_ctx, n_slots); d_counts = capi.DevBuf(gpu_ctx, 64)
-        gpu_ctx._check(L.im_dev_cluster_slots(gpu_ctx.h, n_slots, bufs["cls"].ptr, bufs["b1"].ptr, bufs["b2"].ptr, marker, tie,
-                                              d_order.ptr, d_first.ptr, d_count.ptr, d_used.ptr, d_counts.ptr, gpu_ctx.stream))
-        gpu_ctx._check(L.im_stream_sync(gpu_ctx.h, gpu_ctx.stream))
-        counts = d_counts.download(np.int32, 2)
-        if len(idx) > L.im_dev_cluster_slots_max():
-            assert counts[0] == -1 and counts[1] == len(idx)
-            continue
+        if path == "slots":
+            gpu_ctx._check(L.im_dev_cluster_slots(gpu_ctx.h, n_slots, bufs["cls"].ptr, bufs["b1"].ptr, bufs["b2"].ptr, marker, tie,
+                                                  d_order.ptr, d_first.ptr, d_count.ptr, d_used.ptr, d_counts.ptr, gpu_ctx.stream))
+            gpu_ctx._check(L.im_stream_sync(gpu_ctx.h, gpu_ctx.stream))
+            counts = d_counts.download(np.int32, 2)
+            if len(idx) > L.im_dev_cluster_slots_max():
+                assert counts[0] == -1 and counts[1] == len(idx)
+                continue
+        else:
+            hb = L.im_dev_cluster_hist_scratch_bytes(n_slots)
+            d_hs = capi.DevBuf(gpu_ctx, hb)
+            gpu_ctx._check(L.im_dev_cluster_hist_init(gpu_ctx.h, n_slots, d_hs.ptr, hb, gpu_ctx.stream))
+            for _round in range(3):     # the table cleans itself: identical answers call after call
+                gpu_ctx._check(L.im_dev_cluster_hist(gpu_ctx.h, n_slots, bufs["cls"].ptr, bufs["b1"].ptr, bufs["b2"].ptr, marker, tie,
+                                                     d_order.ptr, d_first.ptr, d_count.ptr, d_used.ptr, d_counts.ptr,
+                                                     d_hs.ptr, hb, gpu_ctx.stream))
+            gpu_ctx._check(L.im_stream_sync(gpu_ctx.h, gpu_ctx.stream))
+            counts = d_counts.download(np.int32, 2)
         assert counts[1] == len(idx) and counts[0] == o_k
         m = int(o_used.sum())
         assert np.array_equal(d_order.download(np.int32, n_slots)[:m], idx[o_order[:m]])
