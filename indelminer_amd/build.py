@@ -26,6 +26,18 @@ def stale():
     return any(os.path.getmtime(d) > t for d in deps)
 
 
+def build_stamps(verbose=False):
+    """Diagnostic library with per-phase cycle stamps in the realign kernel (profiles/ only)."""
+    out = os.path.join(HERE, "libindelminer_amd_stamps.so")
+    cmd = [hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-DIM_STAMPS",
+           "-I" + os.path.join(ROOT, "include"), "-I" + CSRC]
+    cmd += [os.path.join(CSRC, s) for s in SOURCES] + ["-ldl", "-o", out]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.check_call(cmd)
+    return out
+
+
 def build(force=False, verbose=False):
     if not force and not stale():
         return LIB
@@ -59,5 +71,9 @@ def build_host(force=False, verbose=False):
 
 
 if __name__ == "__main__":
+    import sys
+    if "--stamps" in sys.argv:
+        print(build_stamps(verbose=True))
+        sys.exit(0)
     print(build(force=True, verbose=True))
     print(build_host(force=True, verbose=True))

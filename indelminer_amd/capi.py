@@ -86,9 +86,10 @@ def lib():
     """Load the HIP library; raises if it has not been built (no fallback)."""
     global _lib
     if _lib is None:
-        if not os.path.exists(_build.LIB):
+        path = os.environ.get("INDELMINER_AMD_LIB", _build.LIB)      # diagnostic builds (profiles/) only
+        if not os.path.exists(path):
             raise IMError(E_NOGPU, "libindelminer_amd.so is not built; run __graft_entry__.build()")
-        L = C.CDLL(_build.LIB)
+        L = C.CDLL(path)
         L.im_last_error.restype = C.c_char_p
         L.im_last_error.argtypes = [C.c_void_p]
         L.im_ctx_create.argtypes = [C.c_int, C.POINTER(C.c_void_p)]

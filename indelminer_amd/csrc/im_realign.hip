@@ -25,6 +25,26 @@
 
 #include "im_device.hpp"
 
+// Diagnostic build only (-DIM_STAMPS, `python indelminer_amd/build.py --stamps`): per-phase
+// shader-cycle sums over all waves, read back through im_debug_stamps_read.  The product
+// library is built without it and contains no stamp.
+#ifdef IM_STAMPS
+__device__ unsigned long long im_stamp_acc[32];
+#define IM_STAMP_DECL unsigned long long stamp_prev_ = __builtin_readcyclecounter();
+#define IM_STAMP(id) do { const unsigned long long t_ = __builtin_readcyclecounter(); \
+                          if (threadIdx.x == 0) atomicAdd(&im_stamp_acc[id], t_ - stamp_prev_); \
+                          stamp_prev_ = __builtin_readcyclecounter(); } while (0)
+#define IM_STAMP_ARG , unsigned long long& stamp_prev_, int stamp_base_
+#define IM_STAMP_PASS(base) , stamp_prev_, base
+#define IM_STAMP_B(id) IM_STAMP(stamp_base_ + (id))
+#else
+#define IM_STAMP_DECL
+#define IM_STAMP(id)
+#define IM_STAMP_ARG
+#define IM_STAMP_PASS(base)
+#define IM_STAMP_B(id)
+#endif
+
 namespace im {
 namespace {
 
@@ -44,47 +64,79 @@ struct WaveLds {
 };
 
 // ---- wave helpers (64 lanes) ------------------------------------------------
+//
+// Scans and reductions run on the DPP cross-lane path (row_shr / row_bcast), six
+// VALU steps and no LDS round trip, instead of ds_bpermute shuffles.  Reductions
+// end in v_readlane, so their results live in SGPRs and the control flow that
+// hangs off them is scalar.
 
-__device__ __forceinline__ int wave_scan_add(int v, int lane)
+constexpr int kDppRowShr1 = 0x111, kDppRowShr2 = 0x112, kDppRowShr4 = 0x114, kDppRowShr8 = 0x118;
+constexpr int kDppBcast15 = 0x142, kDppBcast31 = 0x143, kDppWaveShr1 = 0x138, kDppWaveShl1 = 0x130;
+
+// A workgroup is one wavefront, so no s_barrier is ever needed: LDS executes one wave's
+// instructions in order, a later read sees an earlier write of any lane.  What is needed is
+// only that the compiler keeps the order -- and, unlike __syncthreads(), does NOT drain the
+// vector-memory queue (s_waitcnt vmcnt(0)), which is what lets reference-window loads issued
+// before a phase overlap that phase.
+__device__ __forceinline__ void wave_lds_sync()
 {
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) { int t = __shfl_up(v, o); if (lane >= o) v += t; }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+__device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
+__device__ __forceinline__ int64_t uni64(int64_t v)
+{
+    const uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)v);
+    const uint32_t hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)((uint64_t)v >> 32));
+    return (int64_t)(((uint64_t)hi << 32) | lo);
+}
+
+template <int CTRL, int ROW_MASK = 0xf>
+__device__ __forceinline__ int dpp_mov(int old, int src)
+{
+    return __builtin_amdgcn_update_dpp(old, src, CTRL, ROW_MASK, 0xf, false);
+}
+
+__device__ __forceinline__ int wave_scan_add(int v, int /*lane*/)
+{
+    v += dpp_mov<kDppRowShr1>(0, v);
+    v += dpp_mov<kDppRowShr2>(0, v);
+    v += dpp_mov<kDppRowShr4>(0, v);
+    v += dpp_mov<kDppRowShr8>(0, v);
+    v += dpp_mov<kDppBcast15, 0xa>(0, v);
+    v += dpp_mov<kDppBcast31, 0xc>(0, v);
     return v;                                // inclusive
 }
-__device__ __forceinline__ int wave_scan_min_excl(int v, int lane)
+__device__ __forceinline__ int wave_scan_min_incl(int v)
+{
+    v = min(v, dpp_mov<kDppRowShr1>(INT_MAX, v));
+    v = min(v, dpp_mov<kDppRowShr2>(INT_MAX, v));
+    v = min(v, dpp_mov<kDppRowShr4>(INT_MAX, v));
+    v = min(v, dpp_mov<kDppRowShr8>(INT_MAX, v));
+    v = min(v, dpp_mov<kDppBcast15, 0xa>(INT_MAX, v));
+    v = min(v, dpp_mov<kDppBcast31, 0xc>(INT_MAX, v));
+    return v;
+}
+__device__ __forceinline__ int wave_scan_max_incl(int v)
+{
+    v = max(v, dpp_mov<kDppRowShr1>(INT_MIN, v));
+    v = max(v, dpp_mov<kDppRowShr2>(INT_MIN, v));
+    v = max(v, dpp_mov<kDppRowShr4>(INT_MIN, v));
+    v = max(v, dpp_mov<kDppRowShr8>(INT_MIN, v));
+    v = max(v, dpp_mov<kDppBcast15, 0xa>(INT_MIN, v));
+    v = max(v, dpp_mov<kDppBcast31, 0xc>(INT_MIN, v));
+    return v;
+}
+__device__ __forceinline__ int wave_scan_min_excl(int v, int /*lane*/)
 {
     // exclusive running minimum, identity INT_MAX
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) { int t = __shfl_up(v, o); if (lane >= o) v = min(v, t); }
-    int e = __shfl_up(v, 1);
-    return lane == 0 ? INT_MAX : e;
+    return dpp_mov<kDppWaveShr1>(INT_MAX, wave_scan_min_incl(v));
 }
-__device__ __forceinline__ int wave_scan_min_rev_excl(int v, int lane)
-{
-    // exclusive running minimum from the high lanes down
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) { int t = __shfl_down(v, o); if (lane + o < 64) v = min(v, t); }
-    int e = __shfl_down(v, 1);
-    return lane == 63 ? INT_MAX : e;
-}
-__device__ __forceinline__ int wave_max(int v)
-{
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v = max(v, __shfl_xor(v, o));
-    return v;
-}
-__device__ __forceinline__ int wave_min(int v)
-{
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v = min(v, __shfl_xor(v, o));
-    return v;
-}
-__device__ __forceinline__ int wave_sum(int v)
-{
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
-    return v;
-}
+__device__ __forceinline__ int wave_max(int v) { return __builtin_amdgcn_readlane(wave_scan_max_incl(v), 63); }
+__device__ __forceinline__ int wave_min(int v) { return __builtin_amdgcn_readlane(wave_scan_min_incl(v), 63); }
+__device__ __forceinline__ int wave_sum(int v) { return __builtin_amdgcn_readlane(wave_scan_add(v, 0), 63); }
 
 // base2bits, src/alignment.c:11-24
 __device__ __forceinline__ uint32_t code2(uint32_t c)
@@ -120,9 +172,37 @@ struct Band {
 // the read k-mer table: value 0 = k-mer absent from the read piece, 0xFF = occurs
 // more than once (bin_diagonals only lets read-unique k-mers vote, 97-98), else
 // 1 + offset of the k-mer in the piece.
-template <bool DIRECT>
-__device__ __forceinline__ void table_build(WaveLds& s, uint32_t p0, uint32_t nq, uint32_t k, int lane)
+template <int KT, bool DIRECT>
+__device__ __forceinline__ void table_build(WaveLds& s, uint32_t p0, uint32_t nq, uint32_t k, int lane, uint32_t read_pk8)
 {
+    if constexpr (KT == 6) {
+        // k = 6 (the reference default): the read's 2-bit codes travel as one packed byte per lane
+        // (bases 4l..4l+3); the two following lanes' bytes come over DPP, and the lane's four
+        // 6-mers are bit fields of that 24-bit window.  The table is kept clean by un-doing the
+        // entries after the vote (table_undo), so no 4 KiB clear per band search.
+        uint8_t* t8 = reinterpret_cast<uint8_t*>(s.tbl);
+        const uint32_t n1 = (uint32_t)dpp_mov<kDppWaveShl1>(0, (int)read_pk8);
+        const uint32_t n2 = (uint32_t)dpp_mov<kDppWaveShl1>(0, (int)n1);
+        const uint32_t w24 = (read_pk8 << 16) | (n1 << 8) | n2;
+        uint32_t code[4]; bool have[4];
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const uint32_t x = 4u * lane + j;
+            have[j] = x >= p0 && x < p0 + nq;
+            code[j] = (w24 >> (12 - 2 * j)) & 0xFFFu;
+        }
+#pragma unroll
+        for (int j = 0; j < 4; j++) if (have[j]) t8[code[j]] = (uint8_t)(4u * lane + j - p0 + 1u);
+        wave_lds_sync();
+        bool lost[4];
+#pragma unroll
+        for (int j = 0; j < 4; j++) lost[j] = have[j] && (t8[code[j]] != (uint8_t)(4u * lane + j - p0 + 1u));
+        wave_lds_sync();
+#pragma unroll
+        for (int j = 0; j < 4; j++) if (lost[j]) t8[code[j]] = 0xFFu;
+        wave_lds_sync();
+        return;
+    }
     uint8_t* t8 = reinterpret_cast<uint8_t*>(s.tbl);
     // clear
     if (DIRECT) {
@@ -135,7 +215,7 @@ __device__ __forceinline__ void table_build(WaveLds& s, uint32_t p0, uint32_t nq
             s.tbl[kHashSlots + lane + 64 * i] = 0u;             // vals
         }
     }
-    __syncthreads();
+    wave_lds_sync();
     const uint32_t mask = (1u << (2 * k)) - 1u;                  // k <= 15
     uint32_t code[4];
     bool have[4];
@@ -151,11 +231,11 @@ __device__ __forceinline__ void table_build(WaveLds& s, uint32_t p0, uint32_t nq
     if (DIRECT) {
 #pragma unroll
         for (int j = 0; j < 4; j++) if (have[j]) t8[code[j]] = (uint8_t)(4u * lane + j + 1u);
-        __syncthreads();
+        wave_lds_sync();
         bool lost[4];
 #pragma unroll
         for (int j = 0; j < 4; j++) lost[j] = have[j] && (t8[code[j]] != (uint8_t)(4u * lane + j + 1u));
-        __syncthreads();
+        wave_lds_sync();
 #pragma unroll
         for (int j = 0; j < 4; j++) if (lost[j]) t8[code[j]] = 0xFFu;
     } else {
@@ -171,7 +251,21 @@ __device__ __forceinline__ void table_build(WaveLds& s, uint32_t p0, uint32_t nq
             }
         }
     }
-    __syncthreads();
+    wave_lds_sync();
+}
+
+// un-does table_build<6>: every lane zeroes the entries of its own k-mers
+__device__ __forceinline__ void table_undo6(WaveLds& s, uint32_t p0, uint32_t nq, int lane, uint32_t read_pk8)
+{
+    uint8_t* t8 = reinterpret_cast<uint8_t*>(s.tbl);
+    const uint32_t n1 = (uint32_t)dpp_mov<kDppWaveShl1>(0, (int)read_pk8);
+    const uint32_t n2 = (uint32_t)dpp_mov<kDppWaveShl1>(0, (int)n1);
+    const uint32_t w24 = (read_pk8 << 16) | (n1 << 8) | n2;
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        const uint32_t x = 4u * lane + j;
+        if (x >= p0 && x < p0 + nq) t8[(w24 >> (12 - 2 * j)) & 0xFFFu] = 0;
+    }
 }
 
 template <bool DIRECT>
@@ -191,10 +285,10 @@ __device__ __forceinline__ uint32_t table_lookup(const WaveLds& s, uint32_t code
 // find_best_band (src/alignment.c:393-447): read_seeds x2 (29-68), bin_diagonals
 // (70-128), bin_bands (130-140), select_band (142-181).  Window = contig[w0,w1),
 // read piece = read[p0,p1), anchor in contig coordinates.
-template <bool DIRECT>
-__device__ Band band_search(WaveLds& s, const uint64_t* __restrict__ pk,
+template <int KT, bool DIRECT>
+__device__ __forceinline__ Band band_search(WaveLds& s, const uint64_t* __restrict__ pk,
                             uint32_t w0, uint32_t w1, uint32_t anchor,
-                            uint32_t p0, uint32_t p1, uint32_t k, uint32_t g, int lane)
+                            uint32_t p0, uint32_t p1, uint32_t k, uint32_t g, int lane, uint32_t read_pk8 IM_STAMP_ARG)
 {
     Band b;
     const uint32_t W = w1 - w0, Lp = p1 - p0;
@@ -205,49 +299,93 @@ __device__ Band band_search(WaveLds& s, const uint64_t* __restrict__ pk,
     if ((int32_t)numdiag <= 0) { b.st = IM_ST_ABORT; return b; }  // reference would run off its arrays
 
     const uint32_t nq = Lp - k + 1;                               // k-mers in the read piece
-    table_build<DIRECT>(s, p0, nq, k, lane);
-
     const uint32_t npos = (W >= k) ? (W - k + 1) : 0u;            // k-mer starts in the window
     const uint32_t kmask = (1u << (2 * k)) - 1u;
     const int anchor_rel = (int)(anchor - w0);                    // select_band gets it as int (431,146)
     const uint32_t step = kDiagChunk - g;
 
+    // Window words of one histogram chunk: every lane takes 16 positions per sweep of 1024.
+    // All sweeps of a chunk are requested up front (kPre of them into registers) so that the
+    // chunk pays one memory round trip, and chunk 0 is requested BEFORE the read table is
+    // built so that the trip overlaps that work (kPre = 3 sweeps live in registers).
+    constexpr int kPre = 3;
     int bc = 0, bd = INT_MAX, bi = 0;                             // select_band's max, dist, indx
 
     for (uint32_t c0 = 0; c0 < numdiag; c0 += step) {
-        // clear the histogram
-#pragma unroll
-        for (int i = 0; i < (kDiagChunk / 4 + 16 + 63) / 64; i++) {
-            const int w = lane + 64 * i;
-            if (w < kDiagChunk / 4 + 16) s.diag[w] = 0u;
-        }
-        __syncthreads();
-
-        // vote: window k-mer at p and read-unique k-mer at q land on diagonal p - q + nq (102-105)
         const int p_lo = max(0, (int)c0 - (int)nq);
         const int p_hi = min((int)npos - 1, (int)(c0 + kDiagChunk) - 2);
+        const uint32_t g0 = (w0 + (uint32_t)(p_lo <= p_hi ? p_lo : 0)) & ~15u;
+        const uint32_t a_hi = w0 + (uint32_t)(p_lo <= p_hi ? p_hi : 0);
+        uint64_t whi0 = 0, wlo0 = 0, whi1 = 0, wlo1 = 0, whi2 = 0, wlo2 = 0;
         if (p_lo <= p_hi) {
-            const uint32_t a_lo = w0 + (uint32_t)p_lo;
-            const uint32_t a_hi = w0 + (uint32_t)p_hi;
-            const uint32_t g0 = a_lo & ~15u;
-            for (uint32_t A = g0 + 16u * lane; A <= a_hi; A += 1024u) {
-                const uint64_t hi = pk[A >> 5];
-                const uint64_t lo = pk[(A >> 5) + 1];
+            const uint32_t A0 = g0 + 16u * lane, A1 = A0 + 1024u, A2 = A0 + 2048u;
+            if (A0 <= a_hi) { whi0 = pk[A0 >> 5]; wlo0 = pk[(A0 >> 5) + 1]; }
+            if (A1 <= a_hi) { whi1 = pk[A1 >> 5]; wlo1 = pk[(A1 >> 5) + 1]; }
+            if (A2 <= a_hi) { whi2 = pk[A2 >> 5]; wlo2 = pk[(A2 >> 5) + 1]; }
+        }
+        if (c0 == 0) {
+            table_build<KT, DIRECT>(s, p0, nq, k, lane, read_pk8);
+            IM_STAMP_B(0);
+        }
+        // clear the part of the histogram this chunk can touch
+        {
+            const uint32_t nbytes = min(numdiag - c0, (uint32_t)kDiagChunk) + (g ? 64u : 0u);
+            for (uint32_t w = lane; 4u * w < nbytes; w += 64) s.diag[w] = 0u;
+        }
+        wave_lds_sync();
+        IM_STAMP_B(1);
+
+        // vote: window k-mer at p and read-unique k-mer at q land on diagonal p - q + nq (102-105)
+        if (p_lo <= p_hi) {
+            int it = 0;
+            for (uint32_t A = g0 + 16u * lane; A <= a_hi; A += 1024u, it++) {
+                uint64_t hi, lo;
+                if (it == 0) { hi = whi0; lo = wlo0; }
+                else if (it == 1) { hi = whi1; lo = wlo1; }
+                else if (it == 2) { hi = whi2; lo = wlo2; }
+                else { hi = pk[A >> 5]; lo = pk[(A >> 5) + 1]; }
                 const uint64_t pkd = (A & 16u) ? ((hi << 32) | (lo >> 32)) : hi;  // bases A..A+31, first base on top
+                if (DIRECT) {
+                    // all sixteen table reads first, then the (rare) hits
+                    uint32_t v[16];
+                    if constexpr (KT == 6) {
+                        const uint32_t u = (uint32_t)(pkd >> 32), l = (uint32_t)pkd;   // bases 0-15 | 16-31
 #pragma unroll
-                for (int j = 0; j < 16; j++) {
-                    const int p = (int)(A + j - w0);
-                    if (p < p_lo || p > p_hi) continue;
-                    const uint32_t code = (uint32_t)(pkd >> (2 * (32 - j - (int)k))) & kmask;
-                    const uint32_t v = table_lookup<DIRECT>(s, code);
-                    if (v == 0u || v == 0xFFu) continue;
-                    const uint32_t off = (uint32_t)p - (v - 1u) + nq - c0;       // diagonal index - c0
-                    if (off < (uint32_t)kDiagChunk)
-                        atomicAdd(&s.diag[off >> 2], 1u << ((off & 3u) * 8u));
+                        for (int j = 0; j < 16; j++) {
+                            const uint32_t code = (j <= 10) ? ((u >> (20 - 2 * j)) & 0xFFFu)
+                                                            : (__builtin_amdgcn_alignbit(u, l, 52 - 2 * j) & 0xFFFu);
+                            v[j] = lds_byte(s.tbl, code);
+                        }
+                    } else {
+#pragma unroll
+                        for (int j = 0; j < 16; j++)
+                            v[j] = lds_byte(s.tbl, (uint32_t)(pkd >> (2 * (32 - j - (int)k))) & kmask);
+                    }
+#pragma unroll
+                    for (int j = 0; j < 16; j++) {
+                        const int p = (int)(A + j - w0);
+                        if (v[j] - 1u >= 0xFEu || p < p_lo || p > p_hi) continue;
+                        const uint32_t off = (uint32_t)p - (v[j] - 1u) + nq - c0;    // diagonal index - c0
+                        if (off < (uint32_t)kDiagChunk)
+                            atomicAdd(&s.diag[off >> 2], 1u << ((off & 3u) * 8u));
+                    }
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 16; j++) {
+                        const int p = (int)(A + j - w0);
+                        if (p < p_lo || p > p_hi) continue;
+                        const uint32_t code = (uint32_t)(pkd >> (2 * (32 - j - (int)k))) & kmask;
+                        const uint32_t v = table_lookup<DIRECT>(s, code);
+                        if (v == 0u || v == 0xFFu) continue;
+                        const uint32_t off = (uint32_t)p - (v - 1u) + nq - c0;       // diagonal index - c0
+                        if (off < (uint32_t)kDiagChunk)
+                            atomicAdd(&s.diag[off >> 2], 1u << ((off & 3u) * 8u));
+                    }
                 }
             }
         }
-        __syncthreads();
+        wave_lds_sync();
+        IM_STAMP_B(2);
 
         // bin_bands + select_band over i in [c0, iend)
         const uint32_t iend = min(c0 + step, numdiag);
@@ -268,8 +406,10 @@ __device__ Band band_search(WaveLds& s, const uint64_t* __restrict__ pk,
                 if (cnt > bc || (cnt == bc && (d < bd || (d == bd && (int)i < bi)))) { bc = cnt; bd = d; bi = (int)i; }
             }
         }
-        __syncthreads();
+        wave_lds_sync();
+        IM_STAMP_B(3);
     }
+    if constexpr (KT == 6) table_undo6(s, p0, nq, lane, read_pk8);
     // wave argmax with select_band's order: most votes, then nearest the anchor, then smallest index
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) {
@@ -278,6 +418,7 @@ __device__ Band band_search(WaveLds& s, const uint64_t* __restrict__ pk,
     }
     b.votes = bc;
     b.low = bi - (int)nq;                                          // 438
+    IM_STAMP_B(4);
     return b;
 }
 
@@ -294,7 +435,7 @@ struct Aln {
 //   forward : c_t = max(0, c_{t-1} + w_t); end = first t where c_t is the strict maximum
 //   reverse : start = largest s <= end with sum_{s..end} w == best
 // Match flags of the aligned positions go to eqdst[] in read coordinates.
-__device__ Aln diag_scan(WaveLds& s, const uint8_t* __restrict__ contig,
+__device__ __forceinline__ Aln diag_scan(WaveLds& s, const uint8_t* __restrict__ contig,
                          uint32_t w0, uint32_t w1, uint32_t p0, uint32_t p1, int d,
                          uint32_t* eqdst, int lane)
 {
@@ -342,7 +483,7 @@ __device__ Aln diag_scan(WaveLds& s, const uint8_t* __restrict__ contig,
     const int end = wave_min(e_loc);
     const int el = end >> 2, ej = end & 3;
     int s_sel = (ej == 0) ? S[0] : (ej == 1) ? S[1] : (ej == 2) ? S[2] : S[3];
-    const int Send = __shfl(s_sel, el);
+    const int Send = __builtin_amdgcn_readlane(s_sel, el);
     const int target = Send - best;
     int st_loc = -1;
 #pragma unroll
@@ -371,13 +512,13 @@ __device__ Aln diag_scan(WaveLds& s, const uint8_t* __restrict__ contig,
     // scatter flags to read coordinates p0 + t
     {
         uint8_t* e8 = reinterpret_cast<uint8_t*>(eqdst);
-        __syncthreads();
+        wave_lds_sync();
 #pragma unroll
         for (int j = 0; j < 4; j++) {
             const int x = (int)p0 + t0 + j;
             if (x < 256 && ((flags >> (8 * j)) & 1u)) e8[x] = 1;
         }
-        __syncthreads();
+        wave_lds_sync();
     }
     a.q1 = (int)p0 + start;                                         // src/alignment.c:385-388
     a.q2 = (int)p0 + end + 1;
@@ -415,16 +556,20 @@ __device__ __forceinline__ void write_slots(const RealignArgs& A, int c, int n_e
 }
 
 // attempt_pe_alignment -> attempt_diagonal_alignments (src/alignment.c:539-799)
-template <bool DIRECT>
-__device__ void realign_one(WaveLds& s, const RealignArgs& A, int c, int lane)
+template <int KT, bool DIRECT>
+__device__ __forceinline__ void realign_one(WaveLds& s, const RealignArgs& A, int c, int lane)
 {
+    IM_STAMP_DECL
     im_read_result* out = &A.batch.out[c];
-    const int64_t off = A.batch.base_off[c];
-    const int64_t Lraw = A.batch.read_len[c];
-    const int tid = A.batch.tid[c];
-    const int anchor = A.batch.anchor[c];
-    const int R = A.batch.range_max[c];
-    const uint32_t k = A.P.klength, g = A.P.numgaps, eth = A.P.ethreshold;
+    // Every per-read scalar is the same in all 64 lanes.  Saying so (v_readfirstlane) puts the
+    // values in SGPRs and turns the control flow below into scalar branches instead of exec-mask
+    // bookkeeping -- the compiler cannot prove uniformity of loaded values on its own.
+    const int64_t off = uni64(A.batch.base_off[c]);
+    const int64_t Lraw = uni(A.batch.read_len[c]);
+    const int tid = uni(A.batch.tid[c]);
+    const int anchor = uni(A.batch.anchor[c]);
+    const int R = uni(A.batch.range_max[c]);
+    const uint32_t k = KT ? (uint32_t)KT : A.P.klength, g = KT ? 0u : A.P.numgaps, eth = A.P.ethreshold;
 
     if (lane < 16) reinterpret_cast<uint32_t*>(&out->band[0])[lane] = 0u;
     if (lane < 7) out->reserved[lane] = 0;
@@ -434,11 +579,12 @@ __device__ void realign_one(WaveLds& s, const RealignArgs& A, int c, int lane)
         return;
     }
     const int L = (int)Lraw;
-    const uint8_t* contig = A.ref.ascii + A.ref.asc_off[tid];
-    const uint64_t* pk = A.ref.pk + A.ref.pk_off[tid];
-    const int clen = A.ref.len[tid];
+    const uint8_t* contig = A.ref.ascii + uni64(A.ref.asc_off[tid]);
+    const uint64_t* pk = A.ref.pk + uni64(A.ref.pk_off[tid]);
+    const int clen = uni(A.ref.len[tid]);
 
     // stage the read
+    uint32_t read_pk8 = 0;      // 2-bit codes of this lane's four bases, first base on top
     {
         uint32_t v = 0;
         if (4 * lane < L) v = *reinterpret_cast<const uint32_t*>(A.batch.bases + off + 4 * lane);
@@ -446,8 +592,9 @@ __device__ void realign_one(WaveLds& s, const RealignArgs& A, int c, int lane)
         if (rem < 4) v &= (rem <= 0) ? 0u : ((1u << (8 * rem)) - 1u);
         s.rd[lane] = v;
         if (lane < 4) s.rd[64 + lane] = 0u;
+        read_pk8 = (code2(v & 255u) << 6) | (code2((v >> 8) & 255u) << 4) | (code2((v >> 16) & 255u) << 2) | code2(v >> 24);
     }
-    __syncthreads();
+    wave_lds_sync();
 
     // window geometry (src/alignment.c:774-783)
     int distance = R;
@@ -460,10 +607,12 @@ __device__ void realign_one(WaveLds& s, const RealignArgs& A, int c, int lane)
           left2 >= 0 && right2 > 0)) { finish(out, IM_ST_ABORT, 0, lane); return; }      // 548-553
 
     // piece 1: the whole read in [left1,right1) (557-566)
-    const Band b1 = band_search<DIRECT>(s, pk, (uint32_t)left1, (uint32_t)right1, (uint32_t)anchor, 0u, (uint32_t)L, k, g, lane);
+    IM_STAMP(0);
+    const Band b1 = band_search<KT, DIRECT>(s, pk, (uint32_t)left1, (uint32_t)right1, (uint32_t)anchor, 0u, (uint32_t)L, k, g, lane, read_pk8 IM_STAMP_PASS(1));
     if (b1.st) { finish(out, b1.st, 1, lane); return; }
     const Aln a1 = diag_scan(s, contig, (uint32_t)left1, (uint32_t)right1, 0u, (uint32_t)L, b1.low, s.eq[0], lane);
     store_band(out, 0, b1, a1, lane);
+    IM_STAMP(6);
     if (a1.st) { finish(out, a1.st, 1, lane); return; }
     const int r1 = a1.r1, r2 = a1.r2, q1 = a1.q1, q2 = a1.q2;
     if (q1 == q2) { finish(out, IM_ST_NONE, 1, lane); return; }                          // 568-572
@@ -496,10 +645,12 @@ __device__ void realign_one(WaveLds& s, const RealignArgs& A, int c, int lane)
     } else { finish(out, IM_ST_NONE, 1, lane); return; }                                  // r1 == anchor (712-717)
     if ((int32_t)(w1 - w0) <= 0) { finish(out, IM_ST_ABORT, 1, lane); return; }
 
-    const Band b2 = band_search<DIRECT>(s, pk, w0, w1, anc, p0, p1, k, g, lane);
+    IM_STAMP(7);
+    const Band b2 = band_search<KT, DIRECT>(s, pk, w0, w1, anc, p0, p1, k, g, lane, read_pk8 IM_STAMP_PASS(8));
     if (b2.st) { finish(out, b2.st, 2, lane); return; }
     const Aln a2 = diag_scan(s, contig, w0, w1, p0, p1, b2.low, s.eq[1], lane);
     store_band(out, 1, b2, a2, lane);
+    IM_STAMP(13);
     if (a2.st) { finish(out, a2.st, 2, lane); return; }
     const int r3 = a2.r1, r4 = a2.r2, q3 = a2.q1, q4 = a2.q2;
     if (want_tail) { if (q4 != L || q3 == q4) { finish(out, IM_ST_NONE, 2, lane); return; } }   // 623-627, 679-683
@@ -530,7 +681,7 @@ __device__ void realign_one(WaveLds& s, const RealignArgs& A, int c, int lane)
     }
     const int ta = fa[0] + fa[1] + fa[2] + fa[3], tb = fb[0] + fb[1] + fb[2] + fb[3];
     const int ia = wave_scan_add(ta, lane), ib = wave_scan_add(tb, lane);
-    const int totA = __shfl(ia, 63), totB = __shfl(ib, 63);
+    const int totA = __builtin_amdgcn_readlane(ia, 63), totB = __builtin_amdgcn_readlane(ib, 63);
     int pa[4], pb[4];                   // exclusive prefix counts at x
     pa[0] = ia - ta; pb[0] = ib - tb;
 #pragma unroll
@@ -576,8 +727,7 @@ __device__ void realign_one(WaveLds& s, const RealignArgs& A, int c, int lane)
         cls[j] = (x >= L) ? -1 : (x < index) ? (fa[j] ? IM_OP_EQ : IM_OP_X)
                  : (x < nextindex) ? IM_OP_I : (fb[j] ? IM_OP_EQ : IM_OP_X);
     }
-    int prevc = __shfl_up(cls[3], 1);
-    if (lane == 0) prevc = -2;
+    const int prevc = dpp_mov<kDppWaveShr1>(-2, cls[3]);      // lane 0 keeps -2
     int nb = 0;
 #pragma unroll
     for (int j = 0; j < 4; j++) {
@@ -587,20 +737,19 @@ __device__ void realign_one(WaveLds& s, const RealignArgs& A, int c, int lane)
         nb += bnd[j] ? 1 : 0;
     }
     const int inb = wave_scan_add(nb, lane);
-    const int total_b = __shfl(inb, 63);
+    const int total_b = __builtin_amdgcn_readlane(inb, 63);
     const int n_ops = total_b + (hasD ? 1 : 0);
     if (n_ops > IM_MAX_OPS) { finish(out, IM_ST_OVERFLOW, 2, lane); return; }
-    // next boundary after each position
-    int nxt[4];
+    // run length = distance to the next boundary: boundary k leaves its position in LDS
+    // (the vote histogram is idle by now), run k ends where boundary k+1 starts
+    int32_t* bpos = reinterpret_cast<int32_t*>(s.diag);
     {
-        int first_b = INT_MAX;
+        int k = inb - nb;
 #pragma unroll
-        for (int j = 3; j >= 0; j--) if (bnd[j]) first_b = x0 + j;
-        const int after = min(wave_scan_min_rev_excl(first_b, lane), L);
-        nxt[3] = after;
-#pragma unroll
-        for (int j = 2; j >= 0; j--) nxt[j] = bnd[j + 1] ? (x0 + j + 1) : nxt[j + 1];
+        for (int j = 0; j < 4; j++) if (bnd[j]) bpos[k++] = x0 + j;
+        if (lane == 0) bpos[total_b] = L;
     }
+    wave_lds_sync();
     int slot = inb - nb;                 // boundaries before this lane
     int seg_indel = 0;
 #pragma unroll
@@ -608,7 +757,7 @@ __device__ void realign_one(WaveLds& s, const RealignArgs& A, int c, int lane)
         const int x = x0 + j;
         if (bnd[j]) {
             const int sl = slot + ((hasD && x >= nextindex) ? 1 : 0);
-            out->ops[sl] = ((uint32_t)(nxt[j] - x) << 4) | (uint32_t)cls[j];
+            out->ops[sl] = ((uint32_t)(bpos[slot + 1] - x) << 4) | (uint32_t)cls[j];
             if (x == index) seg_indel = slot;       // the I run itself, or the run the D op goes in front of
             slot++;
         }
@@ -637,9 +786,10 @@ __device__ void realign_one(WaveLds& s, const RealignArgs& A, int c, int lane)
         out->n_band = 2;
     }
     write_slots(A, c, 1, hasD ? IM_CLS_DELETION : IM_CLS_INSERTION, refindx, hasD ? rindex : refindx, lane);
+    IM_STAMP(14);
 }
 
-template <bool DIRECT>
+template <int KT, bool DIRECT>
 __global__ __launch_bounds__(64) void realign_kernel(RealignArgs A)
 {
     __shared__ WaveLds s;
@@ -649,10 +799,15 @@ __global__ __launch_bounds__(64) void realign_kernel(RealignArgs A)
     // blocks with equal blockIdx % 8 share an XCD (observed round-robin placement,
     // speed only): give each XCD a contiguous run of `per` reads per sweep.
     const int mine = (blockIdx.x & 7) * per + (blockIdx.x >> 3);
+    if constexpr (KT == 6) {        // table_build<6> / table_undo6 keep the table clean from here on
+#pragma unroll
+        for (int i = 0; i < kTblBytes / 4 / 64; i++) s.tbl[lane + 64 * i] = 0u;
+        wave_lds_sync();
+    }
     for (int base = 0; base < A.batch.n; base += G) {
         const int c = base + mine;
-        if (c < A.batch.n) realign_one<DIRECT>(s, A, c, lane);
-        __syncthreads();
+        if (c < A.batch.n) realign_one<KT, DIRECT>(s, A, c, lane);
+        wave_lds_sync();
     }
 }
 
@@ -674,6 +829,19 @@ __global__ __launch_bounds__(256) void pack_kernel(const uint8_t* __restrict__ a
 
 }  // namespace
 
+#ifdef IM_STAMPS
+extern "C" int im_debug_stamps_read(unsigned long long* out32, int reset)
+{
+    hipError_t e = hipDeviceSynchronize();
+    if (e == hipSuccess) e = hipMemcpyFromSymbol(out32, HIP_SYMBOL(im_stamp_acc), 32 * sizeof(unsigned long long));
+    if (e == hipSuccess && reset) {
+        unsigned long long z[32] = {0};
+        e = hipMemcpyToSymbol(HIP_SYMBOL(im_stamp_acc), z, sizeof z);
+    }
+    return e == hipSuccess ? 0 : -1;
+}
+#endif
+
 hipError_t launch_pack_reference(const uint8_t* ascii, uint64_t* pk, int64_t n_bases_padded, hipStream_t stream)
 {
     const int64_t n_words = n_bases_padded / 32;
@@ -692,10 +860,12 @@ hipError_t launch_realign(const RealignArgs& a, int n_cu, hipStream_t stream)
     int64_t need = ((int64_t)a.batch.n + 7) / 8 * 8;
     int grid = (int)(need < want ? need : want);
     grid = (grid + 7) / 8 * 8;
-    if (a.P.klength <= (uint32_t)kDirectMaxK)
-        hipLaunchKernelGGL(realign_kernel<true>, dim3(grid), dim3(64), 0, stream, a);
+    if (a.P.klength == 6 && a.P.numgaps == 0)
+        hipLaunchKernelGGL((realign_kernel<6, true>), dim3(grid), dim3(64), 0, stream, a);     // reference defaults
+    else if (a.P.klength <= (uint32_t)kDirectMaxK)
+        hipLaunchKernelGGL((realign_kernel<0, true>), dim3(grid), dim3(64), 0, stream, a);
     else
-        hipLaunchKernelGGL(realign_kernel<false>, dim3(grid), dim3(64), 0, stream, a);
+        hipLaunchKernelGGL((realign_kernel<0, false>), dim3(grid), dim3(64), 0, stream, a);
     return hipGetLastError();
 }
 
