@@ -55,9 +55,8 @@ int check_params(im_ctx* ctx, const im_params* p)
     // forceassert((klength > 1) && (klength < 16)), src/indelminer.c:1028
     if (p->klength < 2 || p->klength > 15) { set_err(ctx, "klength %u outside 2..15", p->klength); return IM_E_ARG; }
     if (p->maxdelsize == 0) { set_err(ctx, "maxdelsize must be > 0"); return IM_E_ARG; }
-    if (p->numgaps != 0) {
-        set_err(ctx, "numgaps=%u: the gfx950 realign kernel implements the -g 0 path only "
-                     "(banded affine DP for -g > 0 is not built yet); refusing rather than falling back", p->numgaps);
+    if (p->numgaps > 60) {
+        set_err(ctx, "numgaps=%u: the banded kernel holds bands of at most 61 diagonals", p->numgaps);
         return IM_E_UNSUPPORTED;
     }
     return IM_OK;

@@ -811,6 +811,613 @@ __global__ __launch_bounds__(64) void realign_kernel(RealignArgs A)
     }
 }
 
+// ---- numgaps > 0: banded affine-gap path ------------------------------------------
+//
+// With -g N the band handed to local_align is N+1 diagonals wide and the reference runs a real
+// banded Gotoh pass plus the linear-space global traceback of ALIGN (src/localalign.c:15-196,
+// src/globalalign.c:66-401).  Co-optimal paths are common with +1/-10/-20/-10 scoring and the
+// split-read clusters key on exact breakpoints, so the traceback is restated literally (every
+// comparison keeps its strictness) and runs on ONE lane: the dynamic program
+// of a 100 x (N+1) band is a few thousand dependent steps, the k-mer vote around it stays
+// wave-parallel.  Work arrays live in LDS; the band's slice of the reference window is staged
+// there first so the serial lane never waits on global memory.
+
+constexpr int kGapMaxBand = 64;          // numgaps <= 60
+constexpr int kGapNegInf = -9999999;     // MININT, src/localalign.c:3
+constexpr int kGapOpen = 10, kGapExt = 10;
+
+struct GapLds {
+    int      S[2 * 256 + 96];            // edit script
+    int      CC[kGapMaxBand + 8], DD[kGapMaxBand + 8], CP[kGapMaxBand + 8], DP[kGapMaxBand + 8];
+    int      MP[3][260], FP[260];
+    int8_t   MT[3][260], FT[260];
+    uint8_t  wb[1024];                   // staged window bytes: B index j (1-based) lives at wb[j - wb_base]
+    int      wb_base;
+    int      IP;
+    int      sapp, last;                 // script append index / last op
+    uint32_t ops[2][IM_MAX_OPS];         // the two band alignments' CIGARs
+    int      nops[2];
+    int      aln[2][4];                  // r1 r2 q1 q2
+    int      status;                     // result of the serial section, read by every lane
+};
+
+struct GapCtx {
+    GapLds* G;
+    const uint8_t* A;                    // read bytes (LDS), A1[i] = A[i - 1] for the current piece
+    int a0;                              // piece start offset in the read
+};
+
+__device__ __forceinline__ int gw(uint8_t a, uint8_t b) { return a == b ? kScoreMatch : kScoreMismatch; }
+
+__device__ __forceinline__ void gs_del(GapLds& G, int k) { if (G.last < 0) { G.S[G.sapp - 1] -= k; G.last = G.S[G.sapp - 1]; } else { G.S[G.sapp++] = -k; G.last = -k; } }
+__device__ __forceinline__ void gs_ins(GapLds& G, int k) { if (G.last > 0) { G.S[G.sapp - 1] += k; G.last = G.S[G.sapp - 1]; } else { G.S[G.sapp++] = k; G.last = k; } }
+__device__ __forceinline__ void gs_rep(GapLds& G) { G.S[G.sapp++] = 0; G.last = 0; }
+
+// align() of src/globalalign.c:66-307.  A[i] = Ab[ao + i], B[j] = wb[bo + j] (offsets instead of
+// the reference's pointer arithmetic).
+__device__ int gap_align_rec(GapLds& G, const uint8_t* Ab, int ao, int bo, int M, int N, int low, int up, int tb, int te)
+{
+    const int g = kGapOpen, h = kGapExt, m = g + h;
+    int* CC = G.CC; int* DD = G.DD; int* CP = G.CP; int* DP = G.DP;
+    const uint8_t* Bb = G.wb - G.wb_base;
+    int rmid, k, l, r, v, kt, t1, t2, t3;
+    if (N <= 0) { if (M > 0) gs_del(G, M); return -1; }
+    if (M <= 0) { gs_ins(G, N); return -1; }
+    const int band = up - low + 1;
+    if (band <= 1) { for (int i = 1; i <= M; i++) gs_rep(G); return -1; }
+    {
+        const int midd = band / 2 + 1;
+        rmid = low + midd - 1;
+        int leftd = 1 - low, rightd = up - low + 1;
+        int j, i, c = 0, d = 0, e = 0, t, ib, curd;
+        if (leftd < midd) {
+            for (j = 0; j < midd; j++) CP[j] = DP[j] = -1;
+            for (j = midd; j <= rightd; j++) CP[j] = DP[j] = 0;
+            G.MP[0][0] = G.MP[1][0] = G.MP[2][0] = -1;
+        } else if (leftd > midd) {
+            const int fr = leftd - midd;
+            for (j = 0; j <= midd; j++) CP[j] = DP[j] = fr;
+            for (j = midd + 1; j <= rightd; j++) CP[j] = DP[j] = -1;
+            G.MP[0][fr] = G.MP[1][fr] = G.MP[2][fr] = -1;
+        } else {
+            for (j = 0; j <= rightd; j++) CP[j] = DP[j] = 0;
+            G.MP[0][0] = G.MP[1][0] = G.MP[2][0] = -1;
+        }
+        CC[leftd] = 0;
+        t = (tb == 2) ? 0 : -g;
+        for (j = leftd + 1; j <= rightd; j++) { CC[j] = t = t - h; DD[j] = t - g; }
+        CC[rightd + 1] = kGapNegInf; DD[rightd + 1] = kGapNegInf;
+        DD[leftd] = (tb == 1) ? 0 : -g;
+        CC[leftd - 1] = kGapNegInf;
+        for (i = 1; i <= M; i++) {
+            if (i > N - up) rightd--;
+            if (leftd > 1) leftd--;
+            const uint8_t ai = Ab[ao + i];
+            if ((c = CC[leftd + 1] - m) > (d = DD[leftd + 1] - h)) { d = c; DP[leftd] = CP[leftd + 1]; }
+            else DP[leftd] = DP[leftd + 1];
+            if ((ib = leftd + low - 1 + i) > 0) c = CC[leftd] + gw(ai, Bb[bo + ib]);
+            if (d > c || ib <= 0) { c = d; CP[leftd] = DP[leftd]; }
+            e = c - g;
+            DD[leftd] = d; CC[leftd] = c;
+            G.IP = CP[leftd];
+            if (leftd == midd) CP[leftd] = DP[leftd] = G.IP = i;
+            for (curd = leftd + 1; curd <= rightd; curd++) {
+                if (curd != midd) {
+                    if ((c = c - m) > (e = e - h)) { e = c; G.IP = CP[curd - 1]; }
+                    if ((c = CC[curd + 1] - m) > (d = DD[curd + 1] - h)) { d = c; DP[curd] = CP[curd + 1]; }
+                    else DP[curd] = DP[curd + 1];
+                    c = CC[curd] + gw(ai, Bb[bo + curd + low - 1 + i]);
+                    if (c < d || c < e) {
+                        if (e > d) { c = e; CP[curd] = G.IP; }
+                        else       { c = d; CP[curd] = DP[curd]; }
+                    }
+                    CC[curd] = c; DD[curd] = d;
+                } else {
+                    if ((c = c - m) > (e = e - h)) { e = c; G.MP[1][i] = CP[curd - 1]; G.MT[1][i] = 2; }
+                    else { G.MP[1][i] = G.IP; G.MT[1][i] = 2; }
+                    if ((c = CC[curd + 1] - m) > (d = DD[curd + 1] - h)) { d = c; G.MP[2][i] = CP[curd + 1]; G.MT[2][i] = 1; }
+                    else { G.MP[2][i] = DP[curd + 1]; G.MT[2][i] = 1; }
+                    c = CC[curd] + gw(ai, Bb[bo + curd + low - 1 + i]);
+                    if (c < d || c < e) {
+                        if (e > d) { c = e; G.MP[0][i] = G.MP[1][i]; G.MT[0][i] = 2; }
+                        else       { c = d; G.MP[0][i] = G.MP[2][i]; G.MT[0][i] = 1; }
+                    } else { G.MP[0][i] = i - 1; G.MT[0][i] = 0; }
+                    if (c - g > e) { G.MP[1][i] = G.MP[0][i]; G.MT[1][i] = G.MT[0][i]; }
+                    if (c - g > d) { G.MP[2][i] = G.MP[0][i]; G.MT[2][i] = G.MT[0][i]; }
+                    CP[curd] = DP[curd] = G.IP = i;
+                    CC[curd] = c; DD[curd] = d;
+                }
+            }
+        }
+        if (te == 1 && d + g > c)      { k = DP[rightd]; l = 2; }
+        else if (te == 2 && e + g > c) { k = G.IP;       l = 1; }
+        else                           { k = CP[rightd]; l = 0; }
+        if (rmid > N - M) l = 2;
+        else if (rmid < N - M) l = 1;
+        v = c;
+    }
+    r = -1;
+    for (; k > -1; r = k, k = G.MP[l][r], l = G.MT[l][r]) { G.FP[k] = r; G.FT[k] = (int8_t)l; }
+    if (r == -1) {
+        if (rmid < 0) gap_align_rec(G, Ab, ao, bo, M, N, rmid + 1, up, tb, te);
+        else          gap_align_rec(G, Ab, ao, bo, M, N, low, rmid - 1, tb, te);
+    } else {
+        k = r; l = G.FP[k]; kt = G.FT[k];
+        if (rmid < 0) { gap_align_rec(G, Ab, ao, bo, r - 1, r + rmid, rmid + 1, min(up, r + rmid), tb, 1); gs_del(G, 1); }
+        else if (rmid > 0) { gap_align_rec(G, Ab, ao, bo, r, r + rmid - 1, max(-r, low), rmid - 1, tb, 2); gs_ins(G, 1); }
+        t2 = up - rmid - 1;
+        t3 = low - rmid + 1;
+        for (; l > -1; k = l, l = G.FP[k], kt = G.FT[k]) {
+            if (kt == 0) gs_rep(G);
+            else if (kt == 1) {
+                gs_ins(G, 1);
+                t1 = l - k - 1;
+                gap_align_rec(G, Ab, ao + k, bo + k + rmid + 1, t1, t1, 0, min(t1, t2), 2, 1);
+                gs_del(G, 1);
+            } else {
+                gs_del(G, 1);
+                t1 = l - k - 1;
+                gap_align_rec(G, Ab, ao + k + 1, bo + k + rmid, t1, t1, max(-t1, t3), 0, 1, 2);
+                gs_ins(G, 1);
+            }
+        }
+        if (N - M > rmid) {
+            gs_ins(G, 1);
+            t1 = k + rmid + 1;
+            gap_align_rec(G, Ab, ao + k, bo + t1, M - k, N - t1, 0, min(N - t1, t2), 2, te);
+        } else if (N - M < rmid) {
+            gs_del(G, 1);
+            t1 = M - (k + 1);
+            gap_align_rec(G, Ab, ao + k + 1, bo + k + rmid, t1, N - (k + rmid), max(-t1, t3), 0, 1, te);
+        }
+    }
+    return v;
+}
+
+__device__ __forceinline__ bool gap_push(uint32_t* ops, int& n, int op, int len)
+{
+    if (n >= IM_MAX_OPS) return false;
+    ops[n++] = ((uint32_t)len << 4) | (uint32_t)op;
+    return true;
+}
+
+// attempt_band_alignment = local_align + ALIGN + fetch_cigar, run by lane 0.
+// Window = contig[w0,w0+N), read piece = rd[p0,p0+M).  Writes G.aln[which], G.ops[which].
+// Returns 0, IM_ST_ABORT or IM_ST_OVERFLOW.
+__device__ int gap_band_alignment(GapLds& G, const uint8_t* rd, int p0, int M, int w0, int N, int low_in, int up_in, int which)
+{
+    const uint8_t* Ab = rd + p0 - 1;          // Ab[i], i = 1..M
+    const uint8_t* Bb = G.wb - G.wb_base;     // Bb[j], j = 1..N (staged slice only)
+    const int Gp = kGapOpen, H = kGapExt, m = Gp + H;
+    int* CC = G.CC; int* DD = G.DD;
+    G.aln[which][0] = G.aln[which][1] = G.aln[which][2] = G.aln[which][3] = 0;
+    G.nops[which] = 0;
+    if (low_in > up_in || M <= 0 || N <= 0) return IM_ST_ABORT;
+    int low = max(-M, low_in), up = min(N, up_in);
+    const int band = up - low + 1;
+    if (band < 1) return IM_ST_ABORT;
+    if (band > kGapMaxBand) return IM_ST_OVERFLOW;
+    int i, j, si, ei, c, d, e = 0, t, leftd, rightd, curd, ib;
+    int best = 0, starti = 0, startj = 0, endi, endj, flag = 0;
+    if (low > 0) leftd = 1; else if (up < 0) leftd = band; else leftd = 1 - low;
+    rightd = band;
+    si = max(0, -up); ei = min(M, N - low);
+    CC[leftd] = 0;
+    for (j = leftd + 1; j <= rightd; j++) { CC[j] = 0; DD[j] = -Gp; }
+    CC[rightd + 1] = kGapNegInf; DD[rightd + 1] = kGapNegInf;
+    endi = si; endj = si + low;
+    CC[leftd - 1] = kGapNegInf; DD[leftd] = -Gp;
+    for (i = si + 1; i <= ei; i++) {
+        if (i > N - up) rightd--;
+        if (leftd > 1) leftd--;
+        const uint8_t ai = Ab[i];
+        if ((c = CC[leftd + 1] - m) > (d = DD[leftd + 1] - H)) d = c;
+        if ((ib = leftd + low - 1 + i) > 0) c = CC[leftd] + gw(ai, Bb[ib]);
+        if (d > c) c = d;
+        if (c < 0) c = 0;
+        e = c - Gp;
+        DD[leftd] = d; CC[leftd] = c;
+        if (c > best) { best = c; endi = i; endj = ib; }
+        for (curd = leftd + 1; curd <= rightd; curd++) {
+            if ((c = c - m) > (e = e - H)) e = c;
+            if ((c = CC[curd + 1] - m) > (d = DD[curd + 1] - H)) d = c;
+            c = CC[curd] + gw(ai, Bb[curd + low - 1 + i]);
+            if (e > c) c = e;
+            if (d > c) c = d;
+            if (c < 0) c = 0;
+            CC[curd] = c; DD[curd] = d;
+            if (c > best) { best = c; endi = i; endj = curd + low - 1 + i; }
+        }
+    }
+    leftd = max(1, -endi - low + 1);
+    rightd = band - (up - (endj - endi));
+    CC[rightd] = 0;
+    t = -Gp;
+    for (j = rightd - 1; j >= leftd; j--) { CC[j] = t = t - H; DD[j] = t - Gp; }
+    for (j = rightd + 1; j <= band; ++j) CC[j] = kGapNegInf;
+    CC[leftd - 1] = DD[leftd - 1] = kGapNegInf;
+    DD[rightd] = -Gp;
+    for (i = endi; i >= 1; i--) {
+        if (i + low <= 0) leftd++;
+        if (rightd < band) rightd++;
+        const uint8_t ai = Ab[i];
+        if ((c = CC[rightd - 1] - m) > (d = DD[rightd - 1] - H)) d = c;
+        if ((ib = rightd + low - 1 + i) <= N) c = CC[rightd] + gw(ai, Bb[ib]);
+        if (d > c) c = d;
+        e = c - Gp;
+        DD[rightd] = d; CC[rightd] = c;
+        if (c == best) { starti = i; startj = ib; flag = 1; break; }
+        for (curd = rightd - 1; curd >= leftd; curd--) {
+            if ((c = c - m) > (e = e - H)) e = c;
+            if ((c = CC[curd - 1] - m) > (d = DD[curd - 1] - H)) d = c;
+            c = CC[curd] + gw(ai, Bb[curd + low - 1 + i]);
+            if (e > c) c = e;
+            if (d > c) c = d;
+            CC[curd] = c; DD[curd] = d;
+            if (c == best) { starti = i; startj = curd + low - 1 + i; flag = 1; break; }
+        }
+        if (flag == 1) break;
+    }
+    if (starti < 0 || starti > M || startj < 0 || startj > N) return 0;
+    if ((endi - starti) == 0 || (endj - startj) == 0) return 0;
+
+    // ALIGN (src/globalalign.c:333-401) on the located sub-strings
+    const int Ma = endi - starti + 1, Na = endj - startj + 1;
+    int lo2 = low - (startj - starti), up2 = up - (startj - starti);
+    lo2 = min(max(-Ma, lo2), min(Na - Ma, 0));
+    up2 = max(min(Na, up2), max(Na - Ma, 0));
+    G.sapp = 0; G.last = 0;
+    const int ao = p0 - 1 + starti - 1;       // A'[i] = rd[ao + i]
+    const int bo = startj - 1;                // B'[j] = Bb[bo + j]
+    int score;
+    if (up2 - lo2 + 1 <= 1) {
+        score = 0;
+        for (i = 1; i <= Ma; i++) { gs_rep(G); score += gw(rd[ao + i], Bb[bo + i]); }
+    } else {
+        if (up2 - lo2 + 1 > kGapMaxBand) return IM_ST_OVERFLOW;
+        score = gap_align_rec(G, rd, ao, bo + G.wb_base - G.wb_base, Ma, Na, lo2, up2, 0, 0);
+        // (a CHECK_SCORE mismatch makes the reference print a line and carry on; nothing to do here)
+    }
+    if (score <= 0) return 0;
+
+    // fetch_cigar (src/globalalign.c:507-604); deletion runs are added to the consumed-read total
+    // as well (541-595), kept
+    uint32_t* ops = G.ops[which];
+    int n = 0, mm = 0;
+    int AP = starti - 1;
+    if (AP > 0 && !gap_push(ops, n, IM_OP_S, AP)) return IM_ST_OVERFLOW;
+    int run = -1, numrun = 0, numtotal = AP, op = 0, sp = 0;
+    i = 0; j = 0;
+    while (i < Ma || j < Na) {
+        int kind;
+        if (op == 0 && G.S[sp] == 0) { op = G.S[sp++]; i++; j++; if (rd[ao + i] == Bb[bo + j]) kind = 0; else { kind = 4; mm++; } }
+        else {
+            if (op == 0) op = G.S[sp++];
+            if (op > 0) { op--; j++; kind = 1; }
+            else        { op++; i++; kind = 2; }
+        }
+        if (run != -1 && run != kind) {
+            const int bop = run == 0 ? IM_OP_EQ : run == 1 ? IM_OP_D : run == 2 ? IM_OP_I : IM_OP_X;
+            if (!gap_push(ops, n, bop, numrun)) return IM_ST_OVERFLOW;
+            numtotal += numrun; run = kind; numrun = 1;
+        } else { run = kind; numrun += 1; }
+    }
+    if (run != -1 && numrun > 0) {
+        const int bop = run == 0 ? IM_OP_EQ : run == 1 ? IM_OP_D : run == 2 ? IM_OP_I : IM_OP_X;
+        if (!gap_push(ops, n, bop, numrun)) return IM_ST_OVERFLOW;
+        numtotal += numrun;
+    }
+    if (numtotal < M && !gap_push(ops, n, IM_OP_S, M - numtotal)) return IM_ST_OVERFLOW;
+    (void)mm;
+    G.nops[which] = n;
+    G.aln[which][0] = startj + w0 - 1;     // r1
+    G.aln[which][1] = endj + w0;           // r2
+    G.aln[which][2] = starti + p0 - 1;     // q1
+    G.aln[which][3] = endi + p0;           // q2
+    return 0;
+}
+
+// count_matches / find_best_del_candidate on CIGARs (src/alignment.c:219-339)
+__device__ int gap_split_score(const uint32_t* c1, int n1, int q2, const uint32_t* c2, int n2, int q4, int* pmm)
+{
+    const int q3 = q2;
+    int i, j, matches = 0, mm = 0;
+    for (i = 0, j = 0; i < n1; i++) {
+        const int len = (int)(c1[i] >> 4), op = (int)(c1[i] & 15u);
+        if (op != IM_OP_D) j += len;
+        if (j < q2) { if (op == IM_OP_EQ) matches += len; else if (op == IM_OP_X) mm += len; }
+        if (j >= q2) { if (op == IM_OP_EQ) matches += q2 - (j - len); else if (op == IM_OP_X) mm += q2 - (j - len); break; }
+    }
+    for (i = 0, j = 0; i < n2; i++) {
+        const int len = (int)(c2[i] >> 4), op = (int)(c2[i] & 15u);
+        if (op != IM_OP_D) j += len;
+        if (j >= q3) { if (op == IM_OP_EQ) matches += j - q3; else if (op == IM_OP_X) mm += j - q3; i += 1; break; }
+    }
+    for (; i < n2; i++) {
+        const int len = (int)(c2[i] >> 4), op = (int)(c2[i] & 15u);
+        if (op != IM_OP_D) j += len;
+        if (j < q4) { if (op == IM_OP_EQ) matches += len; else if (op == IM_OP_X) mm += len; }
+        if (j >= q4) { if (op == IM_OP_EQ) matches += q4 - (j - len); else if (op == IM_OP_X) mm += q4 - (j - len); break; }
+    }
+    *pmm = mm;
+    return matches;
+}
+
+__device__ int gap_best_split(int q1, int q2, const uint32_t* c1, int n1, int q3, int q4, const uint32_t* c2, int n2, int L, int* pindex)
+{
+    if (q1 != 0 || q3 > q2) return IM_ST_ABORT;
+    int bestm = 0, bestmm = INT_MAX, index = -1;
+    for (int i = q3; i <= q2; i++) {
+        int mm;
+        const int matches = gap_split_score(c1, n1, i, c2, n2, q4, &mm);
+        if (matches > L) return IM_ST_ABORT;
+        if (matches > bestm || (matches == bestm && mm < bestmm)) { bestm = matches; bestmm = mm; index = i; }
+        if (matches == L && mm == 0) break;
+    }
+    if (index == -1) return IM_ST_ABORT;
+    *pindex = index;
+    return 0;
+}
+
+// update_readsegs (src/readaln.c:348-458) + new_evidence per D/I segment, written straight into
+// the result record by lane 0
+__device__ int gap_build_result(im_read_result* out, int r1, const uint32_t* c1, int n1, int index, int q2, int r2,
+                                const uint32_t* c2, int n2)
+{
+    uint32_t* ops = out->ops;
+    int n = 0, refindx = r1, i, j;
+#define GEMIT(len, op) do { if (!gap_push(ops, n, (op), (len))) return IM_ST_OVERFLOW; \
+                            if ((op) == IM_OP_EQ || (op) == IM_OP_X || (op) == IM_OP_D || (op) == IM_OP_M) refindx += (len); } while (0)
+    for (i = 0, j = 0; i < n1; i++) {
+        const int op = (int)(c1[i] & 15u), len = (int)(c1[i] >> 4);
+        if (len <= 0) return IM_ST_ABORT;
+        if (op != IM_OP_D) j += len;
+        if (j <= index) GEMIT(len, op);
+        if (j > index) { const int part = index - (j - len); if (part > 0) GEMIT(part, op); break; }
+    }
+    int rindex = r2, nextindex = index;
+    if (index >= q2) {
+        int offset = 0;
+        for (i = 0, j = 0; i < n2; i++) {
+            const int op = (int)(c2[i] & 15u), len = (int)(c2[i] >> 4);
+            if (op != IM_OP_D) j += len;
+            if (j <= q2) { }
+            else if (j > q2 && j <= index) { if (op != IM_OP_I) { offset += len; if ((j - len) <= q2) offset -= q2 - (j - len); } }
+            else if (j > index) { if (op != IM_OP_I) { if ((j - len) <= index) offset += index - (j - len); } }
+        }
+        rindex = r2 + offset;
+    } else {
+        GEMIT(q2 - index, IM_OP_I);
+        nextindex += q2 - index;
+    }
+    if (refindx < rindex) GEMIT(rindex - refindx, IM_OP_D);
+    for (i = 0, j = 0; i < n2; i++) {
+        const int op = (int)(c2[i] & 15u), len = (int)(c2[i] >> 4);
+        if (op != IM_OP_D) j += len;
+        if (j > nextindex) { GEMIT(j - nextindex, op); i++; break; }
+    }
+    for (; i < n2; i++) GEMIT((int)(c2[i] >> 4), (int)(c2[i] & 15u));
+#undef GEMIT
+    out->ref_start = r1;
+    out->n_ops = n;
+    // evidence: one per D / I segment with its flank reductions (src/variant.c:217-290,704-775)
+    int ne = 0, refpos = r1, readpos = 0;
+    for (int sg = 0; sg < n; sg++) {
+        const int op = (int)(ops[sg] & 15u), len = (int)(ops[sg] >> 4);
+        if (op == IM_OP_D || op == IM_OP_I) {
+            if (ne >= IM_MAX_EV) return IM_ST_OVERFLOW;
+            im_evidence* e = &out->ev[ne++];
+            e->cls = (op == IM_OP_D) ? IM_CLS_DELETION : IM_CLS_INSERTION;
+            e->b1 = refpos; e->b2 = (op == IM_OP_D) ? refpos + len : refpos;
+            e->seg = sg; e->read_off = readpos;
+            int lf = 0, rf = 0, ndp = 0, ndf = 0;
+            for (int t = 0; t < n; t++) {
+                if (t == sg) continue;
+                const int o = (int)(ops[t] & 15u), ln = (int)(ops[t] >> 4);
+                int& fl = (t < sg) ? lf : rf;
+                if (o == IM_OP_EQ) fl += ln;
+                else if (o == IM_OP_X || o == IM_OP_I) { fl += ln; ndp += ln; ndf += ln; }
+                else if (o == IM_OP_D) { ndp += ln; ndf += ln; }
+                else if (o == IM_OP_S) ndf += ln;
+            }
+            e->lflank = lf; e->rflank = rf; e->nd_print = ndp; e->nd_filter = ndf;
+        }
+        if (op == IM_OP_EQ || op == IM_OP_X || op == IM_OP_D) refpos += len;
+        if (op != IM_OP_D) readpos += len;
+    }
+    out->n_ev = ne;
+    return ne > 0 ? IM_ST_EVIDENCE : IM_ST_NONE;
+}
+
+// stage the slice of the window a band alignment can touch: B indices [jlo, jhi] (1-based)
+__device__ __forceinline__ int gap_stage_window(GapLds& G, const uint8_t* contig, int w0, int N, int M, int low, int up, int lane)
+{
+    const int lo = max(-M, low), hi = min(N, up);
+    int jlo = max(1, lo + 1) - 2, jhi = min(N, M + hi) + 2;         // generous by two on each side
+    if (jlo < 0) jlo = 0;
+    if (jhi - jlo + 1 > (int)sizeof(G.wb)) return IM_ST_OVERFLOW;
+    for (int t = lane; t <= jhi - jlo; t += 64) {
+        const int j = jlo + t;                                       // B[j] = contig[w0 + j - 1]
+        G.wb[t] = (j >= 1 && j <= N) ? contig[(int64_t)w0 + j - 1] : 0;
+    }
+    if (lane == 0) G.wb_base = jlo;
+    wave_lds_sync();
+    return 0;
+}
+
+template <bool DIRECT>
+__global__ __launch_bounds__(64) void realign_gapped_kernel(RealignArgs A)
+{
+    __shared__ WaveLds s;
+    __shared__ GapLds G;
+    const int lane = threadIdx.x;
+    const uint32_t k = A.P.klength, g = A.P.numgaps, eth = A.P.ethreshold;
+    for (int c = blockIdx.x; c < A.batch.n; c += gridDim.x) {
+        im_read_result* out = &A.batch.out[c];
+        const int64_t off = uni64(A.batch.base_off[c]);
+        const int64_t Lraw = uni(A.batch.read_len[c]);
+        const int tid = uni(A.batch.tid[c]);
+        const int anchor = uni(A.batch.anchor[c]);
+        const int R = uni(A.batch.range_max[c]);
+        if (lane < 16) reinterpret_cast<uint32_t*>(&out->band[0])[lane] = 0u;
+        if (lane < 7) out->reserved[lane] = 0;
+        write_slots(A, c, 0, -1, 0, 0, lane);
+        wave_lds_sync();
+        if (Lraw <= 0 || Lraw > IM_MAX_READ || tid < 0 || tid >= A.ref.n_contigs || (off & 3)) {
+            finish(out, (Lraw > IM_MAX_READ || (off & 3)) ? IM_ST_UNSUPPORTED : IM_ST_ABORT, 0, lane);
+            continue;
+        }
+        const int L = (int)Lraw;
+        const uint8_t* contig = A.ref.ascii + uni64(A.ref.asc_off[tid]);
+        const uint64_t* pk = A.ref.pk + uni64(A.ref.pk_off[tid]);
+        const int clen = uni(A.ref.len[tid]);
+        {
+            uint32_t v = 0;
+            if (4 * lane < L) v = *reinterpret_cast<const uint32_t*>(A.batch.bases + off + 4 * lane);
+            const int rem = L - 4 * lane;
+            if (rem < 4) v &= (rem <= 0) ? 0u : ((1u << (8 * rem)) - 1u);
+            s.rd[lane] = v;
+            if (lane < 4) s.rd[64 + lane] = 0u;
+        }
+        wave_lds_sync();
+        const uint8_t* rd = reinterpret_cast<const uint8_t*>(s.rd);
+        int distance = R;
+        const int left1  = anchor >= distance ? anchor - distance : 0;
+        const int right1 = clen < (anchor + distance) ? clen : anchor + distance;
+        distance = R + (int)A.P.maxdelsize;
+        const int left2  = anchor >= distance ? anchor - distance : 0;
+        const int right2 = clen < (anchor + distance) ? clen : anchor + distance;
+        if (!(anchor >= left1 && anchor >= left2 && anchor <= right1 && anchor <= right2 && left2 >= 0 && right2 > 0)) {
+            finish(out, IM_ST_ABORT, 0, lane); continue;
+        }
+        // piece 1
+        const Band b1 = band_search<0, DIRECT>(s, pk, (uint32_t)left1, (uint32_t)right1, (uint32_t)anchor, 0u, (uint32_t)L, k, g, lane, 0u);
+        if (b1.st) { finish(out, b1.st, 1, lane); continue; }
+        const int up1 = ((uint32_t)L < k) ? b1.low : b1.low + (int)g;      // read shorter than k: low == up (408-412)
+        int st = gap_stage_window(G, contig, left1, right1 - left1, L, b1.low, up1, lane);
+        if (st == 0 && lane == 0) G.status = gap_band_alignment(G, rd, 0, L, left1, right1 - left1, b1.low, up1, 0);
+        wave_lds_sync();
+        if (st == 0) st = G.status;
+        const int r1 = G.aln[0][0], r2 = G.aln[0][1], q1 = G.aln[0][2], q2 = G.aln[0][3];
+        if (lane == 0) {
+            im_band_aln* o = &out->band[0];
+            o->r1 = r1; o->r2 = r2; o->q1 = q1; o->q2 = q2; o->low = b1.low; o->votes = b1.votes; o->win_bytes = b1.win; o->piece_bytes = b1.piece;
+        }
+        if (st) { finish(out, st, 1, lane); continue; }
+        if (q1 == q2) { finish(out, IM_ST_NONE, 1, lane); continue; }
+        if (q1 == 0 && q2 == L) {       // whole read aligned: evidence only from I/D ops inside the CIGAR (575-582)
+            if (lane == 0) {
+                const int rs = gap_build_result(out, r1, G.ops[0], G.nops[0], L, 0, -1, G.ops[0], 0);
+                G.status = rs;
+            }
+            wave_lds_sync();
+            const int rs = G.status;
+            finish(out, rs, 1, lane);
+            if (rs == IM_ST_EVIDENCE && lane == 0 && A.batch.ev_cls)
+                for (int e = 0; e < out->n_ev; e++) {
+                    const int64_t sl = (int64_t)c * IM_MAX_EV + e;
+                    A.batch.ev_cls[sl] = out->ev[e].cls; A.batch.ev_b1[sl] = out->ev[e].b1; A.batch.ev_b2[sl] = out->ev[e].b2;
+                }
+            continue;
+        }
+        // leading / trailing '=' runs of the first CIGAR (585-599)
+        uint32_t f = 0, l = 0;
+        {
+            const uint32_t* c1 = G.ops[0]; const int n1 = G.nops[0];
+            int i, j;
+            for (i = 0, j = 0; i < n1; i++) { const int op = (int)(c1[i] & 15u); if (i == 0 && op == IM_OP_S) continue; if (op != IM_OP_EQ) break; j += (int)(c1[i] >> 4); }
+            f = (uint32_t)j;
+            for (i = n1 - 1, j = 0; i >= 0; i--) { const int op = (int)(c1[i] & 15u); if (i == n1 - 1 && op == IM_OP_S) continue; if (op != IM_OP_EQ) break; j += (int)(c1[i] >> 4); }
+            l = (uint32_t)j;
+        }
+        const uint32_t uL = (uint32_t)L;
+        uint32_t w0, w1, anc, p0, p1; bool want_tail; int none = 0, abortc = 0;
+        if (r1 > anchor) {
+            if (q1 == 0) {
+                if (!(uL > f)) abortc = 1;
+                else if ((uL - f) < eth || ((uint32_t)right2 - (uint32_t)r1 - f) < eth) none = 1;
+                w0 = (uint32_t)r1 + f; w1 = (uint32_t)right2; anc = (uint32_t)r1; p0 = f; p1 = uL; want_tail = true;
+            } else if (q2 == L) {
+                if (!(uL > l)) abortc = 1;
+                else if ((uL - l) < eth || ((uint32_t)r2 - l - (uint32_t)anchor) < eth) none = 1;
+                w0 = (uint32_t)anchor; w1 = (uint32_t)r2 - l; anc = (uint32_t)r2; p0 = 0; p1 = uL - l; want_tail = false;
+            } else { none = 1; w0 = w1 = anc = p0 = p1 = 0; want_tail = false; }
+        } else if (r1 < anchor) {
+            if (r2 >= anchor) { none = 1; w0 = w1 = anc = p0 = p1 = 0; want_tail = false; }
+            else if (q1 == 0) {
+                if (!(uL > f)) abortc = 1;
+                else if ((uL - f) < eth || ((uint32_t)anchor - (uint32_t)r1 - f) < eth) none = 1;
+                w0 = (uint32_t)r1 + f; w1 = (uint32_t)anchor; anc = (uint32_t)r1; p0 = f; p1 = uL; want_tail = true;
+            } else if (q2 == L) {
+                if (!(uL > l)) abortc = 1;
+                else if ((uL - l) < eth || ((uint32_t)r2 - l - (uint32_t)left2) < eth) none = 1;
+                w0 = (uint32_t)left2; w1 = (uint32_t)r2 - l; anc = (uint32_t)r2; p0 = 0; p1 = uL - l; want_tail = false;
+            } else { none = 1; w0 = w1 = anc = p0 = p1 = 0; want_tail = false; }
+        } else { none = 1; w0 = w1 = anc = p0 = p1 = 0; want_tail = false; }
+        if (abortc) { finish(out, IM_ST_ABORT, 1, lane); continue; }
+        if (none) { finish(out, IM_ST_NONE, 1, lane); continue; }
+        if ((int32_t)(w1 - w0) <= 0) { finish(out, IM_ST_ABORT, 1, lane); continue; }
+        // piece 2
+        const Band b2 = band_search<0, DIRECT>(s, pk, w0, w1, anc, p0, p1, k, g, lane, 0u);
+        if (b2.st) { finish(out, b2.st, 2, lane); continue; }
+        const int up2 = ((p1 - p0) < k) ? b2.low : b2.low + (int)g;
+        st = gap_stage_window(G, contig, (int)w0, (int)(w1 - w0), (int)(p1 - p0), b2.low, up2, lane);
+        if (st == 0 && lane == 0) {
+            int rs = gap_band_alignment(G, rd, (int)p0, (int)(p1 - p0), (int)w0, (int)(w1 - w0), b2.low, up2, 1);
+            if (rs == 0) {
+                const int r3 = G.aln[1][0], r4 = G.aln[1][1], q3 = G.aln[1][2], q4 = G.aln[1][3];
+                uint32_t* c1 = G.ops[0]; uint32_t* c2 = G.ops[1];
+                int n1 = G.nops[0], n2 = G.nops[1];
+                rs = -100;                                   // "go on to combine"
+                if (want_tail) { if (q4 != L || q3 == q4) rs = IM_ST_NONE; }
+                else           { if (q3 != 0 || q3 == q4) rs = IM_ST_NONE; }
+                if (rs == -100) {
+                    // add_prefix_soft_clip / add_suffix_soft_clip (src/alignment.c:478-532)
+                    if (want_tail && f > 0) {
+                        if ((c2[0] & 15u) == IM_OP_S) c2[0] = (((c2[0] >> 4) + f) << 4) | IM_OP_S;
+                        else if (n2 >= IM_MAX_OPS) rs = IM_ST_OVERFLOW;
+                        else { for (int t = n2; t > 0; t--) c2[t] = c2[t - 1]; c2[0] = (f << 4) | IM_OP_S; n2++; }
+                    } else if (!want_tail && l > 0) {
+                        if (n2 <= 0) rs = IM_ST_ABORT;
+                        else if ((c2[n2 - 1] & 15u) == IM_OP_S) c2[n2 - 1] = (((c2[n2 - 1] >> 4) + l) << 4) | IM_OP_S;
+                        else if (n2 >= IM_MAX_OPS) rs = IM_ST_OVERFLOW;
+                        else c2[n2++] = (l << 4) | IM_OP_S;
+                    }
+                }
+                if (rs == -100) {
+                    if (!(q1 < q2 && q3 < q4)) rs = IM_ST_ABORT;
+                    else {
+                        int index = -1;
+                        if (q1 > q3 && q1 <= q4) {
+                            rs = gap_best_split(q3, q4, c2, n2, q1, q2, c1, n1, L, &index);
+                            if (rs == 0) rs = gap_build_result(out, r3, c2, n2, index, q1, r1, c1, n1);
+                        } else if (q3 > q1 && q3 <= q2) {
+                            rs = gap_best_split(q1, q2, c1, n1, q3, q4, c2, n2, L, &index);
+                            if (rs == 0) rs = gap_build_result(out, r1, c1, n1, index, q3, r3, c2, n2);
+                        } else if (q1 > q4 && r1 == r4) rs = gap_build_result(out, r3, c2, n2, q4, q1, r1, c1, n1);
+                        else if (q3 > q2 && r2 == r3) rs = gap_build_result(out, r1, c1, n1, q2, q3, r3, c2, n2);
+                        else rs = IM_ST_NONE;
+                    }
+                }
+            }
+            G.status = rs;
+        }
+        wave_lds_sync();
+        if (st == 0) st = G.status;
+        if (lane == 0) {
+            im_band_aln* o = &out->band[1];
+            o->r1 = G.aln[1][0]; o->r2 = G.aln[1][1]; o->q1 = G.aln[1][2]; o->q2 = G.aln[1][3];
+            o->low = b2.low; o->votes = b2.votes; o->win_bytes = b2.win; o->piece_bytes = b2.piece;
+        }
+        finish(out, st, 2, lane);
+        if (st == IM_ST_EVIDENCE && lane == 0 && A.batch.ev_cls)
+            for (int e = 0; e < out->n_ev; e++) {
+                const int64_t sl = (int64_t)c * IM_MAX_EV + e;
+                A.batch.ev_cls[sl] = out->ev[e].cls; A.batch.ev_b1[sl] = out->ev[e].b1; A.batch.ev_b2[sl] = out->ev[e].b2;
+            }
+    }
+}
+
 // 2-bit packing of the reference, 32 bases per word, first base in the top bits
 __global__ __launch_bounds__(256) void pack_kernel(const uint8_t* __restrict__ ascii, uint64_t* __restrict__ pk, int64_t n_words)
 {
@@ -860,7 +1467,17 @@ hipError_t launch_realign(const RealignArgs& a, int n_cu, hipStream_t stream)
     int64_t need = ((int64_t)a.batch.n + 7) / 8 * 8;
     int grid = (int)(need < want ? need : want);
     grid = (grid + 7) / 8 * 8;
-    if (a.P.klength == 6 && a.P.numgaps == 0)
+    if (a.P.numgaps > 0) {
+        // the traceback recurses (depth ~ log2 of the band): give the dynamic stack room once
+        static bool stack_set = false;
+        if (!stack_set) { hipError_t e = hipDeviceSetLimit(hipLimitStackSize, 4096); if (e != hipSuccess) return e; stack_set = true; }
+        // one serial lane per read dominates: more, smaller waves in flight than the g = 0 path
+        int gg = (int)(need < (int64_t)n_cu * 8 ? need : (int64_t)n_cu * 8);
+        if (a.P.klength <= (uint32_t)kDirectMaxK)
+            hipLaunchKernelGGL((realign_gapped_kernel<true>), dim3(gg), dim3(64), 0, stream, a);
+        else
+            hipLaunchKernelGGL((realign_gapped_kernel<false>), dim3(gg), dim3(64), 0, stream, a);
+    } else if (a.P.klength == 6 && a.P.numgaps == 0)
         hipLaunchKernelGGL((realign_kernel<6, true>), dim3(grid), dim3(64), 0, stream, a);     // reference defaults
     else if (a.P.klength <= (uint32_t)kDirectMaxK)
         hipLaunchKernelGGL((realign_kernel<0, true>), dim3(grid), dim3(64), 0, stream, a);

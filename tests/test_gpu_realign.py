@@ -54,8 +54,8 @@ def test_hip_matches_oracle_and_golden_on_test_data(gpu_ctx, golden_dir):
 
 def test_hip_matches_oracle_on_synthetic_golden_groups(gpu_ctx):
     from indelminer_amd import capi
-    groups = [g for g in golden.load("realign_synth.json") if g["params"]["numgaps"] == 0]
-    assert len(groups) >= 5
+    groups = golden.load("realign_synth.json")        # -k 4..12, -g 0..5
+    assert len(groups) >= 10
     for gi, grp in enumerate(groups):
         contig = grp["contig"].encode()
         gpu_ctx.set_reference([contig])
@@ -127,11 +127,23 @@ def test_edge_cases(gpu_ctx):
     assert rc == 0 and len(out) == 0
 
 
+@pytest.mark.parametrize("k,g", [(6, 1), (6, 3), (8, 2)])
+def test_hip_gapped_matches_oracle_on_seeded_batch(gpu_ctx, k, g):
+    """-g > 0: banded affine-gap path (local_align + ALIGN traceback on the device)."""
+    from indelminer_amd import capi
+    contig, cases = _synthetic_batch(300 + 10 * k + g, 1500)
+    gpu_ctx.set_reference([contig])
+    out, bad = _run_cases(gpu_ctx, capi, capi.params(klength=k, numgaps=g), ob.params(klength=k, numgaps=g), contig, cases,
+                          dump="gpurun_out/mismatch_gapped_k%d_g%d.txt" % (k, g))
+    assert not bad, "%d of %d differ, first: %r" % (len(bad), len(cases), bad[0][:2])
+    assert int((out["status"] == 1).sum()) > 500
+
+
 def test_unsupported_is_loud(gpu_ctx):
     from indelminer_amd import capi
     gpu_ctx.set_reference([b"ACGT" * 500])
     with pytest.raises(capi.IMError) as ei:
-        gpu_ctx.realign_batch(capi.params(numgaps=2), [b"ACGTACGTACGTACGTACGT"], [0], [100], [300])
+        gpu_ctx.realign_batch(capi.params(numgaps=200), [b"ACGTACGTACGTACGTACGT"], [0], [100], [300])
     assert ei.value.code == capi.E_UNSUPPORTED
     rc, out = gpu_ctx.realign_batch(capi.params(), [b"A" * 300], [0], [100], [300], allow=(capi.E_UNSUPPORTED,))
     assert rc == capi.E_UNSUPPORTED and out[0]["status"] == capi.ST_UNSUPPORTED

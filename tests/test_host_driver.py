@@ -28,6 +28,7 @@ FLAG_MATRIX = {
     "k8": ["-i", "indelminer.config", "-k", "8"],
     "f2": ["-i", "indelminer.config", "-f", "2"],
     "region": ["-i", "indelminer.config", "-c", "reference:1-5000"],
+    "g2": ["-i", "indelminer.config", "-g", "2"],
 }
 
 
@@ -141,7 +142,7 @@ def test_product_synthetic(synth_small, synth_1mb):
 
 
 @pytest.mark.gpu
-def test_product_refuses_g2_loudly():
-    r = subprocess.run([_product(), "-i", "indelminer.config", "-g", "2", "reference.fa", "s=alignments.bam"], cwd=TD,
+def test_product_refuses_out_of_range_band_loudly():
+    r = subprocess.run([_product(), "-i", "indelminer.config", "-g", "200", "reference.fa", "s=alignments.bam"], cwd=TD,
                        stdout=subprocess.PIPE, stderr=subprocess.PIPE)
     assert r.returncode != 0 and b"numgaps" in r.stderr
