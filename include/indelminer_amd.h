@@ -163,6 +163,19 @@ int im_cluster_sr(im_ctx* ctx, int32_t n,
                   int32_t* order, int32_t* cl_first, int32_t* cl_count,
                   uint8_t* used, int32_t* n_clusters);
 
+/* ---- seam 3: region depth (DP=) ------------------------------------------------- */
+
+/* Replaces calculate_cov_params(bam_name, tid, start, stop) (src/shared.c:178-212), which the
+ * reference calls once per printed variant and which re-opens the BAM, reloads the index and
+ * pileups the region each time.  im_depth_build takes, once per contig, the M/=/X segments
+ * (contig start, length) of every record samtools' pileup would count (not unmapped, secondary,
+ * QC-fail or duplicate; bam_pileup.c:171-172) and leaves the per-position depth resident on the
+ * device; im_depth_query returns, per query, the SUM of depths over [beg, end) -- the caller
+ * divides by the length and floors (src/shared.c:205). */
+int im_depth_build(im_ctx* ctx, int64_t contig_len, int32_t n_seg,
+                   const int32_t* seg_start, const int32_t* seg_len);
+int im_depth_query(im_ctx* ctx, int32_t n, const int32_t* beg, const int32_t* end, uint32_t* sum_out);
+
 /* ---- device-resident level --------------------------------------------- */
 
 /* Device buffers of one realign batch.  All pointers are device pointers owned

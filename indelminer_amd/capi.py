@@ -124,6 +124,8 @@ def lib():
         L.im_dev_cluster_hist.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32,
                                           C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                           C.c_void_p, C.c_size_t, C.c_void_p]
+        L.im_depth_build.argtypes = [C.c_void_p, C.c_int64, C.c_int32, C.c_void_p, C.c_void_p]
+        L.im_depth_query.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]
         L.im_dev_alloc.argtypes = [C.c_void_p, C.c_size_t, C.POINTER(C.c_void_p)]
         L.im_dev_free.argtypes = [C.c_void_p, C.c_void_p]
         L.im_dev_upload.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]
@@ -242,6 +244,18 @@ class Context:
         rc = lib().im_realign_batch(self.h, C.byref(params), C.byref(b), _ptr(out))
         self._check(rc, allow=allow)
         return rc, out
+
+    def depth_build(self, contig_len, seg_start, seg_len):
+        seg_start = np.ascontiguousarray(seg_start, dtype=np.int32)
+        seg_len = np.ascontiguousarray(seg_len, dtype=np.int32)
+        self._check(lib().im_depth_build(self.h, contig_len, len(seg_start), _ptr(seg_start), _ptr(seg_len)))
+
+    def depth_query(self, beg, end):
+        beg = np.ascontiguousarray(beg, dtype=np.int32)
+        end = np.ascontiguousarray(end, dtype=np.int32)
+        out = np.zeros(max(len(beg), 1), dtype=np.uint32)
+        self._check(lib().im_depth_query(self.h, len(beg), _ptr(beg), _ptr(end), _ptr(out)))
+        return out[:len(beg)]
 
     def cluster_sr(self, cls, b1, b2, marker=2**31 - 1, tie_desc=0):
         n = len(cls)

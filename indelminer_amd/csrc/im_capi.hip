@@ -25,6 +25,10 @@ struct im_ctx {
     // reusable device workspace for the host-buffer entry points
     void* ws = nullptr;
     size_t ws_bytes = 0;
+    // resident depth array of the current contig (im_depth_build)
+    int32_t* depth = nullptr;
+    int32_t* depth_sums = nullptr;
+    int64_t depth_cap = 0, depth_len = -1;
 };
 
 namespace {
@@ -127,6 +131,8 @@ void im_ctx_destroy(im_ctx* ctx)
     (void)hipSetDevice(ctx->device);
     free_reference(ctx);
     if (ctx->ws) (void)hipFree(ctx->ws);
+    if (ctx->depth) (void)hipFree(ctx->depth);
+    if (ctx->depth_sums) (void)hipFree(ctx->depth_sums);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
 }
@@ -250,6 +256,52 @@ int im_realign_batch(im_ctx* ctx, const im_params* params, const im_read_batch* 
         else if (st == IM_ST_UNSUPPORTED && worst == IM_OK) { worst = IM_E_UNSUPPORTED; set_err(ctx, "read %d: longer than IM_MAX_READ=%d", i, IM_MAX_READ); }
     }
     return worst;
+}
+
+int im_depth_build(im_ctx* ctx, int64_t contig_len, int32_t n_seg, const int32_t* seg_start, const int32_t* seg_len)
+{
+    if (!ctx || contig_len < 0 || n_seg < 0) return IM_E_ARG;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    if (contig_len + 1 > ctx->depth_cap) {
+        if (ctx->depth) { HIP_TRY(ctx, hipFree(ctx->depth)); ctx->depth = nullptr; }
+        if (ctx->depth_sums) { HIP_TRY(ctx, hipFree(ctx->depth_sums)); ctx->depth_sums = nullptr; }
+        HIP_TRY(ctx, hipMalloc((void**)&ctx->depth, (size_t)(contig_len + 1) * sizeof(int32_t)));
+        HIP_TRY(ctx, hipMalloc((void**)&ctx->depth_sums, (size_t)(im::depth_tiles(contig_len) + 1) * sizeof(int32_t)));
+        ctx->depth_cap = contig_len + 1;
+    }
+    const size_t sb = up256(sizeof(int32_t) * (size_t)(n_seg ? n_seg : 1));
+    int rc = ensure_ws(ctx, 2 * sb);
+    if (rc) return rc;
+    int32_t* d_start = (int32_t*)ctx->ws;
+    int32_t* d_len = (int32_t*)((char*)ctx->ws + sb);
+    if (n_seg > 0) {
+        HIP_TRY(ctx, hipMemcpyAsync(d_start, seg_start, sizeof(int32_t) * (size_t)n_seg, hipMemcpyHostToDevice, ctx->stream));
+        HIP_TRY(ctx, hipMemcpyAsync(d_len, seg_len, sizeof(int32_t) * (size_t)n_seg, hipMemcpyHostToDevice, ctx->stream));
+    }
+    HIP_TRY(ctx, im::launch_depth_build(contig_len, n_seg, d_start, d_len, ctx->depth, ctx->depth_sums, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    ctx->depth_len = contig_len;
+    return IM_OK;
+}
+
+int im_depth_query(im_ctx* ctx, int32_t n, const int32_t* beg, const int32_t* end, uint32_t* sum_out)
+{
+    if (!ctx || n < 0) return IM_E_ARG;
+    if (ctx->depth_len < 0) { set_err(ctx, "im_depth_build has not been called"); return IM_E_ARG; }
+    if (n == 0) return IM_OK;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const size_t sb = up256(sizeof(int32_t) * (size_t)n);
+    int rc = ensure_ws(ctx, 3 * sb);
+    if (rc) return rc;
+    int32_t* d_beg = (int32_t*)ctx->ws;
+    int32_t* d_end = (int32_t*)((char*)ctx->ws + sb);
+    uint32_t* d_out = (uint32_t*)((char*)ctx->ws + 2 * sb);
+    HIP_TRY(ctx, hipMemcpyAsync(d_beg, beg, sizeof(int32_t) * (size_t)n, hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(ctx, hipMemcpyAsync(d_end, end, sizeof(int32_t) * (size_t)n, hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(ctx, im::launch_depth_query(n, d_beg, d_end, ctx->depth, ctx->depth_len, d_out, ctx->stream));
+    HIP_TRY(ctx, hipMemcpyAsync(sum_out, d_out, sizeof(uint32_t) * (size_t)n, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return IM_OK;
 }
 
 size_t im_dev_cluster_scratch_bytes(int32_t n) { return im::cluster_scratch_bytes(n); }

@@ -340,6 +340,9 @@ typedef struct {
     cand_batch cb;
     evidence_t** pending; int64_t n_pending, cap_pending;
     int64_t arrival;
+    /* match segments of the contig's pileup-eligible records, for the device depth array */
+    int32_t *seg_start, *seg_len; int64_t n_seg, cap_seg;
+    int depth_tid;              /* contig whose depth array is resident on the device, -1 = none */
 } driver;
 
 static void cb_push(cand_batch* cb, const char* bases, int32_t tid, int32_t anchor, int32_t range_max,
@@ -756,7 +759,23 @@ static void merge_variants(variant_list* pvs, const char* reference, int64_t ref
 }
 
 /* ---- region depth, calculate_cov_params (src/shared.c:178-212) ---- */
+static uint32_t region_depth_from_bam(driver* d, int32_t tid, int32_t start, int32_t stop);
+
 static uint32_t region_depth(driver* d, int32_t tid, int32_t start, int32_t stop)
+{
+    if (stop <= start) return 0;
+    if (d->depth_tid == tid) {
+        /* the device holds the contig's depth array (im_depth_build in run_contig) */
+        uint32_t sum = 0;
+        if (im_depth_query(d->gpu, 1, &start, &stop, &sum) != IM_OK) fatalf("im_depth_query: %s", im_last_error(d->gpu));
+        return (uint32_t)floor(sum * 1.0 / (uint32_t)(stop - start));
+    }
+    /* region runs (-c): the reference pileups the whole BAM around the variant, which can reach
+     * outside the analysed region -- go to the file like it does */
+    return region_depth_from_bam(d, tid, start, stop);
+}
+
+static uint32_t region_depth_from_bam(driver* d, int32_t tid, int32_t start, int32_t stop)
 {
     /* pileup semantics (bam_pileup.c:67-143,238-265): records with flag & (0x4|0x100|0x200|0x400)
      * or tid < 0 are skipped; a position counts a read iff its covering op is M/=/X */
@@ -1190,8 +1209,35 @@ static void run_contig(driver* d, int32_t tid, int32_t beg, int32_t end, bgzf_re
     bam_region_iter it;
     bam_record b; memset(&b, 0, sizeof b);
     if (bam_region_begin(&it, r, d->idx, tid, beg, end) != 0) fatalf("cannot seek in %s", d->bam_name);
-    while (bam_region_next(&it, &b) == 1) dispatch_record(d, &b);
+    d->n_seg = 0;
+    const int whole = (beg <= 0 && end >= d->hdr->target_len[tid]);
+    while (bam_region_next(&it, &b) == 1) {
+        if (whole && b.tid >= 0 && !(b.flag & (0x4 | 0x100 | 0x200 | 0x400))) {
+            /* what samtools' pileup would count for DP= (bam_pileup.c:171-172,238-265) */
+            const uint32_t* cig = BAMR_CIGAR(&b);
+            int32_t x = b.pos;
+            for (int kk = 0; kk < b.n_cigar; kk++) {
+                const int op = CIG_OP(cig[kk]), len = CIG_LEN(cig[kk]);
+                if (op == OP_M || op == OP_EQ || op == OP_X) {
+                    if (d->n_seg == d->cap_seg) {
+                        d->cap_seg = d->cap_seg ? d->cap_seg * 2 : (1 << 16);
+                        d->seg_start = xrealloc(d->seg_start, sizeof(int32_t) * (size_t)d->cap_seg);
+                        d->seg_len = xrealloc(d->seg_len, sizeof(int32_t) * (size_t)d->cap_seg);
+                    }
+                    d->seg_start[d->n_seg] = x; d->seg_len[d->n_seg] = len; d->n_seg++;
+                    x += len;
+                } else if (op == OP_D || op == OP_N) x += len;
+            }
+        }
+        dispatch_record(d, &b);
+    }
     free(b.data);
+    d->depth_tid = -1;
+    if (whole) {
+        if (im_depth_build(d->gpu, d->seqlen[tid], (int32_t)d->n_seg, d->seg_start, d->seg_len) != IM_OK)
+            fatalf("im_depth_build: %s", im_last_error(d->gpu));
+        d->depth_tid = tid;
+    }
 
     im_read_result* res = NULL;
     if (d->cb.n > 0) {
@@ -1323,6 +1369,7 @@ int main(int argc, char** argv)
 
     driver d;
     memset(&d, 0, sizeof d);
+    d.depth_tid = -1;
     d.bam_name = bam_name;
     bgzf_reader* r = bgzf_open(bam_name);
     if (!r) fatalf("error in opening the file %s", bam_name);

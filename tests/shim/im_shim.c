@@ -15,7 +15,7 @@
 #include "indelminer_amd.h"
 #include "../../oracle/im_oracle.h"
 
-struct im_ctx { int n; char** seqs; int32_t* lens; char err[256]; };
+struct im_ctx { int n; char** seqs; int32_t* lens; char err[256]; int32_t* depth; int64_t depth_len; };
 static char g_err[256] = "";
 
 int im_abi_version(void) { return IM_ABI_VERSION; }
@@ -66,5 +66,35 @@ int im_cluster_sr(im_ctx* c, int32_t n, const int32_t* cls, const int32_t* b1, c
 {
     (void)c;
     *n_clusters = imo_cluster_sr(n, cls, b1, b2, marker, tie_desc, order, first, count, used);
+    return IM_OK;
+}
+
+int im_depth_build(im_ctx* c, int64_t contig_len, int32_t n_seg, const int32_t* seg_start, const int32_t* seg_len)
+{
+    free(c->depth);
+    c->depth = calloc((size_t)contig_len + 2, sizeof(int32_t));
+    c->depth_len = contig_len;
+    for (int32_t i = 0; i < n_seg; i++) {
+        int64_t a = seg_start[i], b = (int64_t)seg_start[i] + seg_len[i];
+        if (a < 0) a = 0;
+        if (b > contig_len) b = contig_len;
+        if (a >= b) continue;
+        c->depth[a] += 1; c->depth[b] -= 1;
+    }
+    int32_t run = 0;
+    for (int64_t p = 0; p <= contig_len; p++) { run += c->depth[p]; c->depth[p] = run; }
+    return IM_OK;
+}
+
+int im_depth_query(im_ctx* c, int32_t n, const int32_t* beg, const int32_t* end, uint32_t* sum_out)
+{
+    for (int32_t q = 0; q < n; q++) {
+        int64_t a = beg[q], b = end[q];
+        if (a < 0) a = 0;
+        if (b > c->depth_len) b = c->depth_len;
+        uint32_t s = 0;
+        for (int64_t p = a; p < b; p++) s += (uint32_t)c->depth[p];
+        sum_out[q] = s;
+    }
     return IM_OK;
 }

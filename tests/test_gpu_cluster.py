@@ -136,3 +136,24 @@ def test_cluster_records_and_rccl_allgather_world1(gpu_ctx):
     want, _ = shard.merge_gathered(want.reshape(-1), cap)
     assert not trunc and np.array_equal(got, want)
     comm.close()
+
+
+def test_depth_matches_numpy(gpu_ctx):
+    """Region depth (DP=): difference array + device scan + range sums vs numpy, incl. segments
+    clipped at both contig ends and a contig longer than one scan tile."""
+    rng = np.random.default_rng(11)
+    for clen, nseg in ((5000, 800), (100_000, 60_000), (3_000_000, 900_000)):
+        start = rng.integers(-50, clen + 20, nseg).astype(np.int32)
+        ln = rng.integers(1, 101, nseg).astype(np.int32)
+        gpu_ctx.depth_build(clen, start, ln)
+        diff = np.zeros(clen + 1, np.int64)
+        a = np.clip(start.astype(np.int64), 0, clen); b = np.clip(start.astype(np.int64) + ln, 0, clen)
+        ok = a < b
+        np.add.at(diff, a[ok], 1); np.add.at(diff, b[ok], -1)
+        depth = np.cumsum(diff)[:clen]
+        csum = np.concatenate([[0], np.cumsum(depth)])
+        qb = rng.integers(0, clen - 1, 500).astype(np.int32)
+        qe = np.minimum(qb + rng.integers(1, 1200, 500), clen).astype(np.int32)
+        got = gpu_ctx.depth_query(qb, qe)
+        want = (csum[qe] - csum[qb]).astype(np.uint32)
+        assert np.array_equal(got, want)
