@@ -885,6 +885,153 @@ static void print_vcf_output(driver* d, const variant_t* v)
     free(taildistances);
 }
 
+/* ---- -o detailed: print_det_output and friends (src/variant.c:313-675) ---- */
+
+typedef struct { int op, len, start, end; const char* seq; } segview;
+
+/* the readseg list of a seglist: start/end per new_readseg (src/readaln.c:24-99), bases sliced
+ * from the read ('-' runs for deletions are implied) */
+static int seg_views(const seglist* a, int from, int to, segview* out)
+{
+    int refpos = a->ref_start, readpos = 0, n = 0;
+    for (int i = 0; i < a->n; i++) {
+        const int op = CIG_OP(a->ops[i]), len = CIG_LEN(a->ops[i]);
+        const int start = refpos;
+        if (op == OP_M || op == OP_EQ || op == OP_X || op == OP_D) refpos += len;
+        if (i >= from && i < to) { out[n].op = op; out[n].len = len; out[n].start = start; out[n].end = refpos; out[n].seq = a->bases + readpos; n++; }
+        if (op != OP_D) readpos += len;
+    }
+    return n;
+}
+
+static void det_print_left(const segview* v, int n, int lpos)
+{
+    /* segments of aln1 from the first one that reaches lpos (src/variant.c:549-591) */
+    int k = 0;
+    while (k < n && v[k].end < lpos) k++;
+    forceassert(k < n);
+    int rstart = v[k].start > lpos ? 0 : lpos - v[k].start;
+    if (v[k].start > lpos) for (int i = lpos; i < v[k].start; i++) printf(" ");
+    for (; k < n; k++) {
+        switch (v[k].op) {
+        case OP_EQ: case OP_X: case OP_M:
+            if (rstart < v[k].len) printf("%.*s", v[k].len - rstart, v[k].seq + rstart);
+            break;
+        case OP_I: break;
+        case OP_D: for (int i = rstart; i < v[k].len; i++) printf("-"); break;
+        case OP_S: break;
+        default: fatalf("Unknown CIGAR operation: %d", v[k].op);
+        }
+        rstart = 0;
+    }
+}
+
+static void det_print_right(const segview* v, int n, int idx3, int idx4)
+{
+    int i = idx3;
+    for (int k = 0; k < n && i < idx4; k++) {
+        switch (v[k].op) {
+        case OP_EQ: case OP_X: case OP_M:
+            for (int j = 0; j < v[k].len && i < idx4; j++, i++) printf("%c", v[k].seq[j]);
+            break;
+        case OP_I: break;
+        case OP_D: for (int j = 0; j < v[k].len && i < idx4; j++, i++) printf("-"); break;
+        case OP_S: break;
+        default: fatalf("Unknown CIGAR operation: %d", v[k].op);
+        }
+    }
+    for (; i < idx4; i++) printf(" ");
+}
+
+static void print_deletion_output(driver* d, const variant_t* v)
+{
+    const char* ref = d->sequences[v->tid];
+    const uint32_t sequencelen = (uint32_t)d->hdr->target_len[v->tid];
+    const uint32_t neighborhood = 80;
+    int i, idx2, idx3, idx4, lpos, rpos;
+    char buffer[64];
+    lpos = v->start < neighborhood ? 0 : (int)(v->start - neighborhood);
+    for (i = lpos, idx2 = 0; i < (int)v->start; i++, idx2++) printf("%c", toupper(ref[i]));
+    if ((v->stop - v->start) < 10) {
+        for (idx3 = idx2; i < (int)v->stop; i++, idx3++) printf("%c", tolower(ref[i]));
+    } else {
+        for (idx3 = idx2; i < (int)(v->start + 5); i++, idx3++) printf("%c", tolower(ref[i]));
+        if ((v->stop - v->start - 10) > 0) {
+            printf("<%d>", (int)(v->stop - v->start - 10));
+            sprintf(buffer, "<%d>", (int)(v->stop - v->start - 10));
+            idx3 += (int)strlen(buffer);
+        }
+        for (i = (int)v->stop - 5; i < (int)v->stop; i++, idx3++) printf("%c", tolower(ref[i]));
+    }
+    rpos = (v->stop + neighborhood) > sequencelen ? (int)sequencelen : (int)(v->stop + neighborhood);
+    for (idx4 = idx3; i < rpos; i++, idx4++) printf("%c", toupper(ref[i]));
+    printf("\n");
+    for (uint32_t s = 0; s < v->support; s++) {
+        const evidence_t* e = v->evidence[s];
+        if (e->type == EV_PAIRED_READ) { printf("%s\n", e->qname); continue; }
+        segview* sv = xmalloc(sizeof(segview) * (size_t)(e->aln.n + 1));
+        int n1 = seg_views(&e->aln, 0, e->seg, sv);
+        det_print_left(sv, n1, lpos);
+        if (CIG_OP(e->aln.ops[e->seg]) != OP_D) fatalf("This segment should only contain the variation");
+        for (i = idx2; i < idx3; i++) printf("-");
+        int n3 = seg_views(&e->aln, e->seg + 1, e->aln.n, sv);
+        det_print_right(sv, n3, idx3, idx4);
+        printf("%s\n", e->qname);
+        free(sv);
+    }
+}
+
+static void print_insertion_output(driver* d, const variant_t* v)
+{
+    int maxinsertsize = 0;
+    char* consensus = voted_consensus(v->evidence, v->support, &maxinsertsize);
+    free(consensus);
+    const char* ref = d->sequences[v->tid];
+    const uint32_t sequencelen = (uint32_t)d->hdr->target_len[v->tid];
+    const uint32_t neighborhood = 80;
+    int i, j, idx2, idx3, idx4, lpos, rpos;
+    lpos = v->start < neighborhood ? 0 : (int)(v->start - neighborhood);
+    for (i = lpos, idx2 = 0; i < (int)v->start; i++, idx2++) printf("%c", toupper(ref[i]));
+    for (idx3 = idx2, j = 0; j < maxinsertsize; j++, idx3++) printf("-");
+    rpos = (v->stop + neighborhood) > sequencelen ? (int)sequencelen : (int)(v->stop + neighborhood);
+    for (idx4 = idx3; i < rpos; i++, idx4++) printf("%c", toupper(ref[i]));
+    printf("\n");
+    for (uint32_t s = 0; s < v->support; s++) {
+        const evidence_t* e = v->evidence[s];
+        segview* sv = xmalloc(sizeof(segview) * (size_t)(e->aln.n + 1));
+        int n1 = seg_views(&e->aln, 0, e->seg, sv);
+        int k = 0;
+        while (k < n1 && sv[k].end < lpos) k++;
+        if (k == n1) { free(sv); continue; }          /* src/variant.c:360-361 */
+        det_print_left(sv, n1, lpos);
+        segview one;
+        seg_views(&e->aln, e->seg, e->seg + 1, &one);
+        if (one.op != OP_I) fatalf("This segment should only contain the variation");
+        for (j = 0; j < one.len; j++) printf("%c", tolower(one.seq[j]));
+        for (; j < maxinsertsize; j++) printf("-");
+        int n3 = seg_views(&e->aln, e->seg + 1, e->aln.n, sv);
+        det_print_right(sv, n3, idx3, idx4);
+        printf("%s\n", e->qname);
+        free(sv);
+    }
+}
+
+static void print_det_output(driver* d, const variant_t* v)
+{
+    static int indel_index = 1;
+    printf("###########################################################\n");
+    printf("%d\t%s\t%d\t%d\t%s\t%d\t%d\t%d\n", indel_index++, d->hdr->target_name[v->tid], (int)v->start, (int)v->stop,
+           v->type == CLS_DELETION ? "Deletion" : "Insertion", (int)v->start, (int)(v->stop + v->rw + 1), (int)v->support);
+    if (v->type == CLS_DELETION) print_deletion_output(d, v);
+    else if (v->type == CLS_INSERTION) print_insertion_output(d, v);
+}
+
+static void emit_variant(driver* d, const variant_t* v)
+{
+    if (strcmp(O.outputformat, "vcf") == 0) print_vcf_output(d, v);
+    else if (strcmp(O.outputformat, "detailed") == 0) print_det_output(d, v);
+}
+
 /* print_variants (src/variant.c:678-838) */
 static void print_variants(driver* d, variant_list* vs)
 {
@@ -907,7 +1054,7 @@ static void print_variants(driver* d, variant_list* vs)
         if (ok_flanks && it->support >= O.minsupport && xnumdiffs <= O.maxdiffsallowed && left && right) vl_push(&sel, it);
     }
     if (O.call_all_indels) {
-        for (int i = 0; i < sel.n; i++) print_vcf_output(d, sel.v[i]);
+        for (int i = 0; i < sel.n; i++) emit_variant(d, sel.v[i]);
     } else {
         int i = 0;
         while (i < sel.n) {
@@ -917,7 +1064,7 @@ static void print_variants(driver* d, variant_list* vs)
             uint32_t maxsupport = 0;
             const variant_t* chosen = it;
             for (int t = i; t < j; t++) if (sel.v[t]->support > maxsupport) { maxsupport = sel.v[t]->support; chosen = sel.v[t]; }
-            print_vcf_output(d, chosen);
+            emit_variant(d, chosen);
             i = j;
         }
     }
@@ -1355,8 +1502,6 @@ int main(int argc, char** argv)
     char* ptr = argv[optind++];
     if (strchr(ptr, '=') == NULL)
         fatalf("annotate mode (indels.vcf argument) is not built in this driver yet");
-    if (strcmp(O.outputformat, "detailed") == 0)
-        fatalf("-o detailed is not built in this driver yet");
     char* samplename = ptr;
     while (*ptr != '=') ptr++;
     *ptr = 0;

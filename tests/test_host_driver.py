@@ -29,6 +29,7 @@ FLAG_MATRIX = {
     "f2": ["-i", "indelminer.config", "-f", "2"],
     "region": ["-i", "indelminer.config", "-c", "reference:1-5000"],
     "g2": ["-i", "indelminer.config", "-g", "2"],
+    "detailed": ["-i", "indelminer.config", "-o", "detailed"],
 }
 
 
