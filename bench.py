@@ -33,6 +33,17 @@ from indelminer_amd import capi, shard as shardlib, synth  # noqa: E402
 HBM_PEAK_GBS = 8000.0           # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 
 
+def measured_traffic():
+    """HBM bytes per realign launch from the PMC passes committed under profiles/ (FETCH_SIZE x 2
+    per the gfx950 correction + WRITE_SIZE, collected with separate --pmc runs of this same
+    command); counters cannot be read from inside this process."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "r01_b_traffic.json")) as fh:
+            return int(json.load(fh)["hbm_bytes_per_launch"])
+    except Exception:
+        return None
+
+
 def algorithmic_bytes(res):
     """per candidate, sum over its band searches of (window bytes +
     read-piece bytes) at 1 B/base, + 32 B per band alignment + 64 B per evidence record."""
@@ -341,7 +352,7 @@ def main():
                                        "host BAM decode / candidate filter not included",
                        "parity": parity},
             "roofline": {"bound": "hbm", "kernel": "realign_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": measured_traffic(),
                          "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": float(kern_ms.mean()),
                          "min_launch_ms": float(kern_ms.min())},
             "cpu_baseline": cpu,
