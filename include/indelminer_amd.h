@@ -176,6 +176,21 @@ int im_depth_build(im_ctx* ctx, int64_t contig_len, int32_t n_seg,
                    const int32_t* seg_start, const int32_t* seg_len);
 int im_depth_query(im_ctx* ctx, int32_t n, const int32_t* beg, const int32_t* end, uint32_t* sum_out);
 
+/* ---- seam 4: annotate mode, "is this known indel supported by this read?" ------- */
+
+/* Replaces the Smith-Waterman inside realign_with_indel (src/variant.c:1246-1424), called from
+ * check_for_indel (1427-1556) for every read overlapping a known split-read variant that the
+ * discovery pass did not re-find.  Task i aligns query i (the aligned part of a read,
+ * read[qstart,qstop)) against target i (the reference window with the variant applied, built by
+ * the caller exactly as 1260-1272 do) and returns the three counts check_for_indel compares with
+ * the read's existing alignment (1549-1553): substitutions, inserted+deleted bases, aligned bases.
+ * targets/queries: concatenated bytes with n+1 offsets.  out: n x 4 int32 {subs, indels, aligned,
+ * status (IM_ST_EVIDENCE = valid, IM_ST_UNSUPPORTED = target longer than 4095 or query longer
+ * than IM_MAX_READ)}. */
+int im_support_batch(im_ctx* ctx, int32_t n,
+                     const uint8_t* targets, const int64_t* t_off,
+                     const uint8_t* queries, const int64_t* q_off, int32_t* out);
+
 /* ---- device-resident level --------------------------------------------- */
 
 /* Device buffers of one realign batch.  All pointers are device pointers owned

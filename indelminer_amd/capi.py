@@ -126,6 +126,7 @@ def lib():
                                           C.c_void_p, C.c_size_t, C.c_void_p]
         L.im_depth_build.argtypes = [C.c_void_p, C.c_int64, C.c_int32, C.c_void_p, C.c_void_p]
         L.im_depth_query.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.im_support_batch.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         L.im_dev_alloc.argtypes = [C.c_void_p, C.c_size_t, C.POINTER(C.c_void_p)]
         L.im_dev_free.argtypes = [C.c_void_p, C.c_void_p]
         L.im_dev_upload.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]
@@ -256,6 +257,17 @@ class Context:
         out = np.zeros(max(len(beg), 1), dtype=np.uint32)
         self._check(lib().im_depth_query(self.h, len(beg), _ptr(beg), _ptr(end), _ptr(out)))
         return out[:len(beg)]
+
+    def support_batch(self, targets, queries):
+        """targets / queries: lists of bytes.  Returns int32 [n,4]: subs, indels, aligned, status."""
+        n = len(targets)
+        t = np.frombuffer(b"".join(targets) + b"\0" * 8, dtype=np.uint8).copy()
+        q = np.frombuffer(b"".join(queries) + b"\0" * 8, dtype=np.uint8).copy()
+        to = np.zeros(n + 1, np.int64); np.cumsum([len(x) for x in targets], out=to[1:])
+        qo = np.zeros(n + 1, np.int64); np.cumsum([len(x) for x in queries], out=qo[1:])
+        out = np.zeros((max(n, 1), 4), dtype=np.int32)
+        self._check(lib().im_support_batch(self.h, n, _ptr(t), _ptr(to), _ptr(q), _ptr(qo), _ptr(out)))
+        return out[:n]
 
     def cluster_sr(self, cls, b1, b2, marker=2**31 - 1, tie_desc=0):
         n = len(cls)

@@ -304,6 +304,34 @@ int im_depth_query(im_ctx* ctx, int32_t n, const int32_t* beg, const int32_t* en
     return IM_OK;
 }
 
+int im_support_batch(im_ctx* ctx, int32_t n, const uint8_t* targets, const int64_t* t_off,
+                     const uint8_t* queries, const int64_t* q_off, int32_t* out)
+{
+    if (!ctx || n < 0) return IM_E_ARG;
+    if (n == 0) return IM_OK;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const size_t tb = up256((size_t)t_off[n] + 16), qb = up256((size_t)q_off[n] + 16);
+    const size_t ob = up256(sizeof(int64_t) * ((size_t)n + 1)), rb = up256(sizeof(int32_t) * 4 * (size_t)n);
+    int rc = ensure_ws(ctx, tb + qb + 2 * ob + rb);
+    if (rc) return rc;
+    char* w = static_cast<char*>(ctx->ws);
+    uint8_t* d_t = (uint8_t*)w; w += tb;
+    uint8_t* d_q = (uint8_t*)w; w += qb;
+    int64_t* d_to = (int64_t*)w; w += ob;
+    int64_t* d_qo = (int64_t*)w; w += ob;
+    int32_t* d_out = (int32_t*)w;
+    HIP_TRY(ctx, hipMemcpyAsync(d_t, targets, (size_t)t_off[n], hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(ctx, hipMemcpyAsync(d_q, queries, (size_t)q_off[n], hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(ctx, hipMemcpyAsync(d_to, t_off, sizeof(int64_t) * ((size_t)n + 1), hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(ctx, hipMemcpyAsync(d_qo, q_off, sizeof(int64_t) * ((size_t)n + 1), hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(ctx, im::launch_support(n, d_t, d_to, d_q, d_qo, d_out, ctx->n_cu, ctx->stream));
+    HIP_TRY(ctx, hipMemcpyAsync(out, d_out, sizeof(int32_t) * 4 * (size_t)n, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    for (int32_t i = 0; i < n; i++)
+        if (out[4 * i + 3] == IM_ST_UNSUPPORTED) { set_err(ctx, "support task %d: target or query longer than the kernel holds", i); return IM_E_UNSUPPORTED; }
+    return IM_OK;
+}
+
 size_t im_dev_cluster_scratch_bytes(int32_t n) { return im::cluster_scratch_bytes(n); }
 size_t im_dev_gather_scratch_bytes(int32_t n) { return im::gather_scratch_bytes(n); }
 

@@ -74,4 +74,7 @@ int64_t depth_tiles(int64_t clen);
 hipError_t launch_depth_query(int32_t nq, const int32_t* beg, const int32_t* end, const int32_t* depth, int64_t clen,
                               uint32_t* out, hipStream_t stream);
 
+hipError_t launch_support(int32_t n_tasks, const uint8_t* targets, const int64_t* t_off,
+                          const uint8_t* queries, const int64_t* q_off, int32_t* out, int n_cu, hipStream_t stream);
+
 }  // namespace im

@@ -913,3 +913,49 @@ int32_t imo_cluster_sr(int32_t n, const int32_t* cls, const int32_t* b1, const i
     free(keys);
     return ncl;
 }
+
+/* ------------------------------------------------------------------ K7 -- */
+
+#include <ctype.h>
+
+void imo_sw_indel(const char* t1, int32_t len1, const char* t2, int32_t len2,
+                  int32_t* subs_out, int32_t* indels_out, int32_t* aligned_out)
+{
+    const int match = 2, mismatch = 1, gopen = 4, gextend = 1;      /* src/variant.c:1290-1293 */
+    enum { D_SUB = 0, D_INS = 1, D_DEL = 2 };
+    const size_t W = (size_t)len1 + 1;
+    int* V = calloc(((size_t)len2 + 1) * W, sizeof(int));
+    char* I = calloc(((size_t)len2 + 1) * W, 1);
+    int* F = calloc(W, sizeof(int));
+    for (int i = 0; i <= len2; i++) V[(size_t)i * W] = -gopen - i * gextend;
+    for (int j = 0; j <= len1; j++) V[j] = -gopen - j * gextend;
+    int max_score = 0, max_i = -1, max_j = -1;
+    for (int i = 1; i <= len2; i++) {
+        int E = 0;
+        for (int j = 1; j <= len1; j++) {
+            int ifsub = V[(size_t)(i - 1) * W + j - 1];
+            ifsub = toupper((unsigned char)t1[j - 1]) == toupper((unsigned char)t2[i - 1]) ? ifsub + match : ifsub - mismatch;
+            const int ifins = imax(F[j], V[(size_t)(i - 1) * W + j] - gopen) - gextend;
+            F[j] = ifins;
+            const int ifdel = imax(E, V[(size_t)i * W + j - 1] - gopen) - gextend;
+            E = ifdel;
+            const int ifindel = imax(ifins, ifdel);
+            int v = ifsub; char dir = D_SUB;
+            if (v < ifindel) { dir = (ifins >= ifdel) ? D_INS : D_DEL; v = ifindel; }
+            V[(size_t)i * W + j] = v; I[(size_t)i * W + j] = dir;
+            if (v > max_score) { max_score = v; max_i = i; max_j = j; }
+        }
+    }
+    int subs = 0, ins = 0, dels = 0, aligned = 0;
+    int score = max_score, i = max_i, j = max_j;
+    while (score > 0) {
+        const char dir = I[(size_t)i * W + j];
+        if (dir == D_SUB) { if (t1[j - 1] != t2[i - 1]) subs++; aligned++; i--; j--; }
+        else if (dir == D_INS) { ins++; aligned++; i--; }
+        else { dels++; j--; }
+        score = V[(size_t)i * W + j];
+    }
+    aligned++;      /* the counting loop starts at k = strlen(nt1): NUL == NUL counts as aligned (1392-1404) */
+    free(V); free(I); free(F);
+    *subs_out = subs; *indels_out = ins + dels; *aligned_out = aligned;
+}

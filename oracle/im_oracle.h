@@ -129,6 +129,14 @@ int32_t imo_cluster_sr(int32_t n, const int32_t* cls, const int32_t* b1, const i
                        int32_t* order, int32_t* cl_first, int32_t* cl_count,
                        uint8_t* used);
 
+/* K7: the alignment inside realign_with_indel (src/variant.c:1272-1424): full affine local SW of
+ * query (len2) against the mutated reference window target (len1), match +2, mismatch -1, gap
+ * open 4, extend 1; traceback from the first strictly-greatest cell while the score stays > 0;
+ * counts substitutions, inserted+deleted bases and "aligned" bases exactly as the reference's
+ * final loop does (it also counts the terminating NUL position, hence aligned >= 1). */
+void imo_sw_indel(const char* target, int32_t len1, const char* query, int32_t len2,
+                  int32_t* subs, int32_t* indels, int32_t* aligned);
+
 #ifdef __cplusplus
 }
 #endif

@@ -98,3 +98,16 @@ int im_depth_query(im_ctx* c, int32_t n, const int32_t* beg, const int32_t* end,
     }
     return IM_OK;
 }
+
+int im_support_batch(im_ctx* c, int32_t n, const uint8_t* targets, const int64_t* t_off,
+                     const uint8_t* queries, const int64_t* q_off, int32_t* out)
+{
+    (void)c;
+    for (int32_t i = 0; i < n; i++) {
+        int32_t subs, indels, aligned;
+        imo_sw_indel((const char*)targets + t_off[i], (int32_t)(t_off[i + 1] - t_off[i]),
+                     (const char*)queries + q_off[i], (int32_t)(q_off[i + 1] - q_off[i]), &subs, &indels, &aligned);
+        out[4 * i] = subs; out[4 * i + 1] = indels; out[4 * i + 2] = aligned; out[4 * i + 3] = IM_ST_EVIDENCE;
+    }
+    return IM_OK;
+}

@@ -157,3 +157,44 @@ def test_depth_matches_numpy(gpu_ctx):
         got = gpu_ctx.depth_query(qb, qe)
         want = (csum[qe] - csum[qb]).astype(np.uint32)
         assert np.array_equal(got, want)
+
+
+def test_support_sw_matches_oracle(gpu_ctx):
+    """Annotate-mode SW (K7): forward-carried path statistics vs the oracle's full-matrix DP +
+    traceback on random target/query pairs (planted indels, substitutions, lengths up to 255 x 1500)."""
+    import ctypes as C
+    from tests.support import oraclebind as ob
+    L = ob.lib()
+    rng = np.random.default_rng(5)
+    targets, queries = [], []
+    for it in range(400):
+        len1 = int(rng.choice([40, 120, 200, 260, 700, 1500]))
+        t = rng.choice(list(b"ACGT"), size=len1).astype(np.uint8)
+        len2 = int(rng.choice([20, 64, 65, 100, 100, 128, 150, 255]))
+        p = int(rng.integers(0, max(1, len1 - len2 // 2)))
+        q = t[p:p + len2].copy()
+        if len(q) < len2:
+            q = np.concatenate([q, rng.choice(list(b"ACGT"), size=len2 - len(q)).astype(np.uint8)])
+        typ = rng.random()
+        if typ < 0.35 and len2 > 20:
+            cut = int(rng.integers(5, len2 - 5)); d = int(rng.integers(1, 12))
+            q = np.concatenate([q[:cut], q[cut + d:], rng.choice(list(b"ACGT"), size=d).astype(np.uint8)])
+        elif typ < 0.7 and len2 > 20:
+            cut = int(rng.integers(5, len2 - 5)); d = int(rng.integers(1, 12))
+            q = np.concatenate([q[:cut], rng.choice(list(b"ACGT"), size=d).astype(np.uint8), q[cut:]])[:len2]
+        elif typ < 0.8:
+            q = rng.choice(list(b"ACGT"), size=len2).astype(np.uint8)
+        sub = rng.random(len(q)) < rng.choice([0, 0.02, 0.1])
+        q[sub] = rng.choice(list(b"ACGT"), size=int(sub.sum())).astype(np.uint8)
+        if it % 17 == 0:
+            q[len(q) // 2] = ord("N")
+        if it % 23 == 0:
+            t[len(t) // 3] = ord("N")
+        targets.append(t.tobytes()); queries.append(q.tobytes())
+    targets.append(b"ACGTACGT"); queries.append(b"TTTT")        # nothing positive... (a T matches)
+    targets.append(b"AAAA"); queries.append(b"CCCC")            # all-nonpositive matrix
+    got = gpu_ctx.support_batch(targets, queries)
+    for k, (t, q) in enumerate(zip(targets, queries)):
+        s, i, a = C.c_int32(), C.c_int32(), C.c_int32()
+        L.imo_sw_indel(t, len(t), q, len(q), C.byref(s), C.byref(i), C.byref(a))
+        assert tuple(got[k][:3]) == (s.value, i.value, a.value), (k, len(t), len(q), tuple(got[k]), (s.value, i.value, a.value))
