@@ -1216,12 +1216,263 @@ static void pending_push(driver* d, evidence_t* e)
     d->pending[d->n_pending++] = e;
 }
 
+/* ------------------------------------------------------------ annotate mode -- */
+
+typedef struct {
+    int32_t  tid;
+    uint32_t start;                 /* VCF POS */
+    char*    reference;
+    char*    alternate;
+    int      type, evdnctype;
+    uint32_t support, stop, bpstop;
+    char*    addntlinfo;
+    int      diffsample_support;
+} knownvariant_t;
+
+typedef struct { knownvariant_t** v; int n, cap; int next; } known_list;
+
+static const char* g_vcfname = NULL;
+static const char* g_sample_name = NULL;
+
+/* read_variants (src/variant.c:841-921): the whole VCF is parsed again for every contig */
+static void read_variants(const char* vcfname, int32_t tid, const char* chromname, known_list* out)
+{
+    size_t cap = 2;
+    char* line = xmalloc(cap);
+    out->n = 0; out->next = 0;
+    FILE* fp = fopen(vcfname, "r");
+    if (!fp) fatalf("error in opening the file %s", vcfname);
+    const size_t big = (size_t)O.maxpedelsize + 16;
+    char* reference = xmalloc(big);
+    char* alternate = xmalloc(big);
+    int numread = 0;
+    while (im_getline(&line, &cap, fp) != -1) {
+        if (line[0] == '#') continue;
+        char chrom[128], type[128], evd[128], sup[128], stp[128], bps[128], info[1024];
+        unsigned start;
+        if (sscanf(line, "%127s %u %*c %s %s %*c %*c %127[^;];%127[^;];NS=%127[^;];END=%127[^;];BP_END=%127[^;];%1023s\n",
+                   chrom, &start, reference, alternate, type, evd, sup, stp, bps, info) != 10)
+            fatalf("Error in reading the variant : %s", line);
+        if (strcmp(chrom, chromname) != 0) continue;
+        numread++;
+        knownvariant_t* k = xcalloc(1, sizeof *k);
+        k->tid = tid; k->start = start;
+        k->addntlinfo = xstrdup(info);
+        k->reference = xstrdup(reference); k->alternate = xstrdup(alternate);
+        k->type = strncmp(type, "DELETION", 8) == 0 ? CLS_DELETION : CLS_INSERTION;
+        if (strcmp(evd, "SPLIT_READ") == 0) k->evdnctype = EV_SPLIT_READ;
+        else if (strcmp(evd, "PAIRED_READ") == 0) k->evdnctype = EV_PAIRED_READ;
+        else if (strcmp(evd, "COMPOSITE") == 0) k->evdnctype = EV_COMPOSITE;
+        else fatalf("unknown evidence type for this variant");
+        k->support = (uint32_t)atoi(sup); k->stop = (uint32_t)atoi(stp); k->bpstop = (uint32_t)atoi(bps);
+        if (out->n == out->cap) { out->cap = out->cap ? out->cap * 2 : 64; out->v = xrealloc(out->v, sizeof(knownvariant_t*) * (size_t)out->cap); }
+        out->v[out->n++] = k;
+    }
+    fclose(fp);
+    free(line); free(reference); free(alternate);
+    /* list built by prepending, then the stable sort_by_knownposition (27-37,915): ties come out in
+     * reverse file order */
+    for (int i = 0; i < out->n / 2; i++) { knownvariant_t* t = out->v[i]; out->v[i] = out->v[out->n - 1 - i]; out->v[out->n - 1 - i] = t; }
+    for (int i = 1; i < out->n; i++) {
+        knownvariant_t* k = out->v[i]; int j = i - 1;
+        while (j >= 0 && (out->v[j]->start > k->start || (out->v[j]->start == k->start && (int)out->v[j]->bpstop - (int)k->bpstop > 0))) { out->v[j + 1] = out->v[j]; j--; }
+        out->v[j + 1] = k;
+    }
+    fprintf(stderr, "Read %d variants for %s\n", numread, chromname);
+}
+
+static void known_free(known_list* l)
+{
+    for (int i = 0; i < l->n; i++) { free(l->v[i]->reference); free(l->v[i]->alternate); free(l->v[i]->addntlinfo); free(l->v[i]); }
+    l->n = 0; l->next = 0;
+}
+
+static void print_vcf_line(const driver* d, const knownvariant_t* k)
+{
+    /* src/variant.c:1227-1244 */
+    printf("%s\t%d\t.\t%s\t%s\t.\t.\t%s;", d->hdr->target_name[k->tid], (int)k->start, k->reference, k->alternate,
+           k->type == CLS_DELETION ? "DELETION" : "INSERTION");
+    if (k->evdnctype == EV_SPLIT_READ) printf("SPLIT_READ;");
+    else if (k->evdnctype == EV_PAIRED_READ) printf("PAIRED_READ;");
+    else if (k->evdnctype == EV_COMPOSITE) printf("COMPOSITE;");
+    printf("NS=%d;END=%d;BP_END=%d;%s", (int)k->support, (int)k->stop, (int)k->bpstop, k->addntlinfo);
+}
+
+/* is_indel_supported (src/variant.c:1561-1573) = check_for_indel (1427-1556) over the reads that
+ * overlap [start, stop).  The CIGAR bookkeeping is per read on the host; the Smith-Waterman of
+ * every read that needs one goes to the GPU as one im_support_batch. */
+static int is_indel_supported(driver* d, knownvariant_t* k)
+{
+    const char* seq = d->sequences[k->tid];
+    const int64_t seqlen = d->seqlen[k->tid];
+    bgzf_reader* r = bgzf_open(d->bam_name);
+    if (!r) fatalf("error in opening the file %s", d->bam_name);
+    bam_header* h = bam_header_load(r);
+    bam_region_iter it;
+    bam_record b; memset(&b, 0, sizeof b);
+    /* SW tasks in read order with the read's own counts */
+    uint8_t* tg = NULL; size_t tg_len = 0, tg_cap = 0;
+    uint8_t* qs = NULL; size_t qs_len = 0, qs_cap = 0;
+    int64_t *to = NULL, *qo = NULL; int32_t* own = NULL; int nt = 0, capt = 0;
+    if (h && bam_region_begin(&it, r, d->idx, k->tid, (int32_t)k->start, (int32_t)k->stop) == 0) {
+        while (!k->diffsample_support && bam_region_next(&it, &b) == 1) {
+            if (b.flag & 0x4) continue;
+            if (b.flag & (0x100 | 0x200 | 0x400 | 0x800)) continue;
+            seglist rln = seglist_from_record(&b);
+            int aln1subs = 0, aln1indels = 0, aln1aligned = 0, overlaps = 0, qstart = -1, qstop = -1, readindx = 0;
+            int refpos = rln.ref_start, done = 0;
+            for (int sgi = 0; sgi < rln.n && !done; sgi++) {
+                const int op = CIG_OP(rln.ops[sgi]), len = CIG_LEN(rln.ops[sgi]);
+                const int sstart = refpos;
+                const int send = (op == OP_M || op == OP_EQ || op == OP_X || op == OP_D) ? refpos + len : refpos;
+                if (!(send < (int)k->start || sstart > (int)k->stop)) overlaps = 1;
+                switch (op) {
+                case OP_S:
+                    if (sgi == rln.n - 1) qstop = readindx;
+                    readindx += len;
+                    break;
+                case OP_I:
+                    if (qstart == -1) qstart = readindx;
+                    if (k->type == CLS_INSERTION && sstart == (int)k->start) { k->diffsample_support = 1; done = 1; break; }
+                    readindx += len; aln1indels += len; aln1aligned += len;
+                    break;
+                case OP_D:
+                    if (k->type == CLS_DELETION && sstart == (int)k->start && send == (int)k->stop - 1) { k->diffsample_support = 1; done = 1; break; }
+                    aln1indels += len;
+                    break;
+                case OP_M:
+                    if (qstart == -1) qstart = readindx;
+                    for (int i = 0, j = sstart; i < len; i++, j++) if (rln.bases[readindx + i] != seq[j]) aln1subs++;
+                    readindx += len; aln1aligned += len;
+                    break;
+                default:
+                    fatalf("Unhandled CIGAR op: %d", op);
+                }
+                refpos = send;
+            }
+            if (done) { seglist_free(&rln); break; }
+            if (qstop == -1) qstop = aln1aligned + qstart;
+            forceassert(aln1aligned == (qstop - qstart));
+            if (!overlaps) { seglist_free(&rln); continue; }
+            const int indelsize = abs((int)strlen(k->alternate) - (int)strlen(k->reference));
+            int rstart = b.pos, rstop = bam_record_end(&b);
+            if ((uint32_t)rstop < k->bpstop) { seglist_free(&rln); continue; }
+            forceassert(qstart != -1 && qstop != -1);
+            rstart -= indelsize; rstop += indelsize;
+            /* the fake reference with the variant in it (1259-1272); reads beyond the contig's ends
+             * stop at its terminator there, here they are clipped */
+            if (rstart < 0) rstart = 0;
+            if (rstop > seqlen) rstop = (int)seqlen;
+            const size_t alen = strlen(k->alternate);
+            size_t need = (size_t)(rstop - rstart) + alen + 8;
+            if (tg_len + need > tg_cap) { tg_cap = (tg_cap + need) * 2; tg = xrealloc(tg, tg_cap); }
+            uint8_t* t = tg + tg_len;
+            size_t tl = 0;
+            if (k->type == CLS_DELETION) {
+                /* ref[rstart, start) + ref[stop-1, rstop) */
+                const int a_end = (int)k->start < rstop ? (int)k->start : rstop;
+                if (a_end > rstart) { memcpy(t, seq + rstart, (size_t)(a_end - rstart)); tl = (size_t)(a_end - rstart); }
+                const int b_beg = (int)k->stop - 1;
+                if (rstop > b_beg && b_beg >= 0) { memcpy(t + tl, seq + b_beg, (size_t)(rstop - b_beg)); tl += (size_t)(rstop - b_beg); }
+            } else {
+                /* ref[rstart, start) + alternate[1..] + ref[start, rstop) */
+                const int a_end = (int)k->start < rstop ? (int)k->start : rstop;
+                if (a_end > rstart) { memcpy(t, seq + rstart, (size_t)(a_end - rstart)); tl = (size_t)(a_end - rstart); }
+                if (alen > 1) { memcpy(t + tl, k->alternate + 1, alen - 1); tl += alen - 1; }
+                if (rstop > a_end) { memcpy(t + tl, seq + a_end, (size_t)(rstop - a_end)); tl += (size_t)(rstop - a_end); }
+            }
+            /* query = read[qstart, qstop) of the record's stored bases */
+            int qlen = qstop - qstart;
+            if ((int)strlen(rln.bases + qstart) < qlen) qlen = (int)strlen(rln.bases + qstart);
+            if (qs_len + (size_t)qlen + 8 > qs_cap) { qs_cap = (qs_cap + (size_t)qlen + 8) * 2; qs = xrealloc(qs, qs_cap); }
+            memcpy(qs + qs_len, rln.bases + qstart, (size_t)qlen);
+            if (nt + 2 > capt) { capt = capt ? capt * 2 : 64; to = xrealloc(to, sizeof(int64_t) * (size_t)(capt + 1)); qo = xrealloc(qo, sizeof(int64_t) * (size_t)(capt + 1)); own = xrealloc(own, sizeof(int32_t) * 3 * (size_t)capt); }
+            to[nt] = (int64_t)tg_len; qo[nt] = (int64_t)qs_len;
+            own[3 * nt] = aln1subs; own[3 * nt + 1] = aln1indels; own[3 * nt + 2] = aln1aligned;
+            tg_len += tl; qs_len += (size_t)qlen; nt++;
+            to[nt] = (int64_t)tg_len; qo[nt] = (int64_t)qs_len;
+            seglist_free(&rln);
+        }
+    }
+    free(b.data);
+    bam_header_free(h);
+    bgzf_close(r);
+    if (!k->diffsample_support && nt > 0) {
+        int32_t* res = xmalloc(sizeof(int32_t) * 4 * (size_t)nt);
+        if (im_support_batch(d->gpu, nt, tg, to, qs, qo, res) != IM_OK) fatalf("im_support_batch: %s", im_last_error(d->gpu));
+        for (int i = 0; i < nt; i++)
+            if (res[4 * i] <= own[3 * i] && res[4 * i + 1] <= own[3 * i + 1] && res[4 * i + 2] >= own[3 * i + 2]) { k->diffsample_support = 1; break; }
+        free(res);
+    }
+    free(tg); free(qs); free(to); free(qo); free(own);
+    return k->diffsample_support;
+}
+
+/* print_knownvariants (src/variant.c:1577-1692): known variants from kl->next on; stops at the
+ * first known variant that lies behind the last discovered one (1661-1666) */
+static void print_knownvariants(driver* d, known_list* kl, const variant_list* vars)
+{
+    if (vars->n == 0) return;
+    int ki = kl->next;
+    for (; ki < kl->n; ki++) {
+        knownvariant_t* k = kl->v[ki];
+        int is_found = 0;
+        const uint32_t kstart = k->start, kstop = k->stop;
+        int ui;
+        for (ui = 0; ui < vars->n; ui++) {
+            const variant_t* u = vars->v[ui];
+            const uint32_t ustart = u->start - u->lw;
+            uint32_t ustop = 0;
+            const int reflength = (int)(u->stop + u->rw) - (int)(u->start - u->lw - 1);
+            forceassert(reflength >= 1);
+            if (u->type == CLS_DELETION) {
+                const int altlength = (int)(u->start + u->rw) - (int)(u->start - u->lw - 1);
+                forceassert(altlength >= 1);
+                ustop = u->start - u->lw + (uint32_t)reflength - (uint32_t)altlength + 1;
+            } else if (u->type == CLS_INSERTION) ustop = ustart + 1;
+            forceassert(ustop != 0);
+            if (kstart >= ustop) { }
+            else if (ustart >= kstop) { }
+            else {
+                if ((k->evdnctype == EV_SPLIT_READ || k->evdnctype == EV_COMPOSITE) && u->evdnctype == EV_SPLIT_READ) {
+                    if (kstart == ustart && kstop == ustop) { is_found = 1; break; }
+                } else if (((k->evdnctype == EV_SPLIT_READ || k->evdnctype == EV_COMPOSITE) && u->evdnctype == EV_PAIRED_READ) ||
+                           (k->evdnctype == EV_PAIRED_READ && u->evdnctype == EV_SPLIT_READ) ||
+                           (k->evdnctype == EV_PAIRED_READ && u->evdnctype == EV_PAIRED_READ)) {
+                    const uint32_t sx = k->start > u->start ? k->start : u->start;
+                    const uint32_t ex = k->bpstop < u->stop ? k->bpstop : u->stop;
+                    uint32_t olap = 0;
+                    if (ex >= sx) olap = ex - sx;
+                    if ((olap * 100.00 / (k->bpstop - k->start)) > 50) { is_found = 1; break; }
+                }
+            }
+        }
+        if (ui == vars->n) {
+            const variant_t* last = vars->v[vars->n - 1];
+            if (last->start < kstart) break;
+        }
+        print_vcf_line(d, k);
+        if (is_found) printf(";%s", g_sample_name);
+        else if (k->evdnctype == EV_SPLIT_READ && is_indel_supported(d, k)) printf(";%s", g_sample_name);
+        printf("\n");
+    }
+    kl->next = ki;
+}
+
+static known_list g_known;
+
 static void flush_variants(driver* d, int32_t tid, int marker)
 {
     variant_list vs = {0};
     process_evidence(d, tid, marker, &vs);
-    merge_variants(&vs, d->sequences[tid], d->seqlen[tid], 1);
-    print_variants(d, &vs);
+    if (g_vcfname == NULL) {
+        merge_variants(&vs, d->sequences[tid], d->seqlen[tid], 1);
+        print_variants(d, &vs);
+    } else {
+        /* annotate mode (src/indelminer.c:647-661, 824-855): SR and PE variants stay apart */
+        merge_variants(&vs, d->sequences[tid], d->seqlen[tid], 0);
+        print_knownvariants(d, &g_known, &vs);
+    }
     fflush(stdout);
     free_used_evidence(d);
     for (int i = 0; i < vs.n; i++) variant_free(vs.v[i]);
@@ -1407,6 +1658,16 @@ static void run_contig(driver* d, int32_t tid, int32_t beg, int32_t end, bgzf_re
     }
     free(res);
     flush_variants(d, tid, INT_MAX);        /* end of contig (src/indelminer.c:806-823) */
+    if (g_vcfname != NULL) {
+        /* what print_knownvariants left over (src/indelminer.c:839-847) */
+        for (int ki = g_known.next; ki < g_known.n; ki++) {
+            knownvariant_t* k = g_known.v[ki];
+            print_vcf_line(d, k);
+            if (k->evdnctype == EV_SPLIT_READ && is_indel_supported(d, k)) printf(";%s", g_sample_name);
+            printf("\n");
+        }
+        g_known.next = g_known.n;
+    }
 }
 
 /* -------------------------------------------------------------------- main -- */
@@ -1500,17 +1761,23 @@ int main(int argc, char** argv)
 
     const char* fasta_reference = argv[optind++];
     char* ptr = argv[optind++];
-    if (strchr(ptr, '=') == NULL)
-        fatalf("annotate mode (indels.vcf argument) is not built in this driver yet");
+    if (strchr(ptr, '=') == NULL) {                 /* a VCF: tag its indels only (src/indelminer.c:1046-1053) */
+        g_vcfname = ptr;
+        O.minsupport = 1;
+        O.outputformat = "vcf";
+        ptr = argv[optind++];
+    }
     char* samplename = ptr;
     while (*ptr != '=') ptr++;
     *ptr = 0;
     const char* bam_name = ++ptr;
-    (void)samplename;
+    g_sample_name = samplename;
+    if (g_vcfname != NULL) O.ethreshold_vcfcheck = 0;   /* src/indelminer.c:1074 */
 
     fprintf(stderr, "Reference fasta file: %s\n", fasta_reference);
     fprintf(stderr, "Chromosomal region  : %s\n", O.region == NULL ? "ALL" : O.region);
     fprintf(stderr, "BAM file            : %s\n", bam_name);
+    if (g_vcfname != NULL) fprintf(stderr, "VCF file            : %s\n", g_vcfname);
 
     driver d;
     memset(&d, 0, sizeof d);
@@ -1555,13 +1822,18 @@ int main(int argc, char** argv)
         free(seqs); free(lens);
     }
 
-    if (strncmp(O.outputformat, "vcf", 3) == 0) {
-        print_vcf_preamble();
-        printf("#CHROM\tPOS\tID\tREF\tALT\tQUAL\tFILTER\tINFO\n");
-    }
+    if (strncmp(O.outputformat, "vcf", 3) == 0) print_vcf_preamble();
+    if (g_vcfname != NULL)
+        printf("##INFO=<ID=%s,Number=0,Type=Flag,Description=\"The variant is also present in this sample\">\n", g_sample_name);
+    if (strncmp(O.outputformat, "vcf", 3) == 0) printf("#CHROM\tPOS\tID\tREF\tALT\tQUAL\tFILTER\tINFO\n");
 
     for (int32_t i = 0; i < d.hdr->n_targets; i++) {
         if (chromid != -1 && i != chromid) continue;
+        if (g_vcfname != NULL) {
+            known_free(&g_known);
+            read_variants(g_vcfname, i, d.hdr->target_name[i], &g_known);
+            if (g_known.n == 0) continue;           /* src/indelminer.c:788 */
+        }
         if (chromid == -1) run_contig(&d, i, 0, d.hdr->target_len[i], r);
         else run_contig(&d, i, chromstart, chromstop, r);
     }

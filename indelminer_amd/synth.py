@@ -43,7 +43,8 @@ def plant_indels(rng, ref_len, spacing=2000, max_size=50, margin=1500, big_every
 
 
 def build_donor(rng, ref, pos, size, is_ins):
-    """Apply the events.  Returns donor bases and, per event, its donor coordinate."""
+    """Apply the events.  Returns donor bases and, per event, its donor coordinate.  `rng` is the
+    integer genome seed: inserted bases are a function of (seed, event position)."""
     pieces = []
     dpos = np.zeros(len(pos), dtype=np.int64)
     ins_seqs = []
@@ -54,7 +55,7 @@ def build_donor(rng, ref, pos, size, is_ins):
         pieces.append(ref[cur:p]); dcur += p - cur
         dpos[i] = dcur
         if is_ins[i]:
-            s = ACGT[rng.integers(0, 4, size=int(size[i]), dtype=np.uint8)]
+            s = ACGT[np.random.default_rng([int(rng), p]).integers(0, 4, size=int(size[i]), dtype=np.uint8)]
             ins_seqs.append(s)
             pieces.append(s); dcur += len(s)
             cur = p
@@ -71,9 +72,15 @@ class Reads:
 
 
 def simulate(seed, ref_len=1_000_000, coverage=30, read_len=100, isize_mean=500, isize_sd=50,
-             isize_min=300, isize_max=700, sub_rate=0.005, indel_spacing=2000, n_contigs=1, big_every=0):
-    """Returns (refs, reads): refs = list of uint8 arrays (one per contig); reads = Reads."""
+             isize_min=300, isize_max=700, sub_rate=0.005, indel_spacing=2000, n_contigs=1, big_every=0,
+             read_seed=None, somatic_spacing=0):
+    """Returns (refs, reads): refs = list of uint8 arrays (one per contig); reads = Reads.
+    `seed` fixes the reference and its (germline) indels; `read_seed` (default: derived from seed)
+    the sampled pairs; somatic_spacing > 0 adds extra indels about every that many bases, drawn from
+    the read_seed stream -- a tumour/normal pair shares `seed` and differs in the other two
+    (BASELINE config 5)."""
     rng = np.random.default_rng(seed)
+    rrng = np.random.default_rng(seed + 7919 if read_seed is None else read_seed)
     L = read_len
     refs = []
     cols = {k: [] for k in ("tid", "pos", "flag", "mpos", "isize", "seq", "cig_op", "cig_len", "ncig", "mate_first", "pair_id")}
@@ -82,7 +89,14 @@ def simulate(seed, ref_len=1_000_000, coverage=30, read_len=100, isize_mean=500,
         ref = random_genome(rng, ref_len)
         refs.append(ref)
         epos, esize, eins = plant_indels(rng, ref_len, indel_spacing, big_every=big_every)
-        donor, edpos = build_donor(rng, ref, epos, esize, eins)
+        if somatic_spacing:
+            spos, ssize, sins = plant_indels(rrng, ref_len, somatic_spacing, margin=1500 + indel_spacing // 2)
+            far = np.array([np.min(np.abs(epos - p)) > 300 for p in spos], dtype=bool)
+            epos = np.concatenate([epos, spos[far]]); esize = np.concatenate([esize, ssize[far]]); eins = np.concatenate([eins, sins[far]])
+            o = np.argsort(epos, kind="stable")
+            epos, esize, eins = epos[o], esize[o], eins[o]
+        # inserted bases come from a stream keyed by the event position: same germline insertion in tumour and normal
+        donor, edpos = build_donor(seed, ref, epos, esize, eins)
         dlen = len(donor)
         # donor -> reference shift after each event
         eshift = np.where(eins, -esize, esize).astype(np.int64)
@@ -92,8 +106,8 @@ def simulate(seed, ref_len=1_000_000, coverage=30, read_len=100, isize_mean=500,
         ed_hi = np.where(eins, edpos + esize, edpos)
 
         n_pairs = int(round(coverage * ref_len / (2.0 * L)))
-        isz = np.clip(np.rint(rng.normal(isize_mean, isize_sd, n_pairs)), isize_min, isize_max).astype(np.int64)
-        fs = rng.integers(0, dlen - isize_max - 1, size=n_pairs)
+        isz = np.clip(np.rint(rrng.normal(isize_mean, isize_sd, n_pairs)), isize_min, isize_max).astype(np.int64)
+        fs = rrng.integers(0, dlen - isize_max - 1, size=n_pairs)
         starts = np.concatenate([fs, fs + isz - L])                 # donor start of mate1 (fwd), mate2 (rev)
         is_rev = np.concatenate([np.zeros(n_pairs, bool), np.ones(n_pairs, bool)])
         n = 2 * n_pairs
@@ -101,8 +115,8 @@ def simulate(seed, ref_len=1_000_000, coverage=30, read_len=100, isize_mean=500,
         # bases in forward-reference orientation, with substitutions
         idx = starts[:, None] + np.arange(L)[None, :]
         seq = donor[idx]
-        sub = rng.random(seq.shape) < sub_rate
-        seq[sub] = ACGT[rng.integers(0, 4, size=int(sub.sum()), dtype=np.uint8)]
+        sub = rrng.random(seq.shape) < sub_rate
+        seq[sub] = ACGT[rrng.integers(0, 4, size=int(sub.sum()), dtype=np.uint8)]
 
         # event (if any) overlapping each read: first event with ed_hi > start (strictly inside the read)
         ev = np.searchsorted(ed_hi, starts, side="right")

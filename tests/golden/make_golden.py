@@ -159,6 +159,39 @@ SYNTH_E2E = {
     "synth_1mb_30x": dict(seed=1, ref_len=1_000_000, coverage=30, n_contigs=1, big_every=7),
 }
 
+# BASELINE config 5 in small: tumour = normal's genome and germline indels + somatic indels
+SYNTH_TN = {
+    "normal": dict(seed=4, ref_len=300_000, coverage=30, n_contigs=2),
+    "tumor": dict(seed=4, ref_len=300_000, coverage=30, n_contigs=2, read_seed=55, somatic_spacing=15_000),
+}
+
+
+def write_dataset(td, kw, prefix=""):
+    from indelminer_amd import bamwrite, synth
+    refs, rd = synth.simulate(**kw)
+    contigs = [("ctg%d" % i, len(r)) for i, r in enumerate(refs)]
+    bamwrite.write_fasta(td + "/ref.fa", contigs, refs)
+    bamwrite.write_bam(td + "/%saln.bam" % prefix, contigs, rd)
+    open(td + "/cfg.txt", "w").write("IL generic 300 700\n")
+
+
+def make_tn_vcfs():
+    """Discovery on the tumour, then annotate mode (-q 0 -a -e 1) on the normal (README.md:116)."""
+    import tempfile
+    outdir = os.path.join(HERE, "vcf")
+    with tempfile.TemporaryDirectory() as td:
+        write_dataset(td, SYNTH_TN["tumor"], "tumor_")
+        write_dataset(td, SYNTH_TN["normal"], "normal_")
+        r = subprocess.run([refbind.BIN, "-i", "cfg.txt", "ref.fa", "t=tumor_aln.bam"], cwd=td, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+        open(os.path.join(outdir, "synth_tn_tumor.vcf"), "wb").write(r.stdout)
+        open(td + "/tumor.vcf", "wb").write(r.stdout)
+        a = subprocess.run([refbind.BIN, "-i", "cfg.txt", "-q", "0", "-a", "-e", "1", "ref.fa", "tumor.vcf", "normal=normal_aln.bam"],
+                           cwd=td, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+        open(os.path.join(outdir, "synth_tn_annotate.vcf"), "wb").write(a.stdout)
+        body = [l for l in a.stdout.splitlines() if not l.startswith(b"#")]
+        print("vcf/synth_tn_tumor.vcf rc %d; vcf/synth_tn_annotate.vcf rc %d: %d records, %d tagged ;normal"
+              % (r.returncode, a.returncode, len(body), sum(1 for l in body if l.endswith(b";normal"))))
+
 
 def make_synth_vcfs():
     """Reference stdout on seeded synthetic BAMs (insertions, COMPOSITE calls, > READCHUNK reads)."""
@@ -186,3 +219,4 @@ if __name__ == "__main__":
     make_synth(R)
     make_vcfs()
     make_synth_vcfs()
+    make_tn_vcfs()

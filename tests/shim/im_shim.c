@@ -103,6 +103,7 @@ int im_support_batch(im_ctx* c, int32_t n, const uint8_t* targets, const int64_t
                      const uint8_t* queries, const int64_t* q_off, int32_t* out)
 {
     (void)c;
+    if (getenv("IM_SHIM_TRACE")) fprintf(stderr, "[shim] im_support_batch: %d tasks\n", n);
     for (int32_t i = 0; i < n; i++) {
         int32_t subs, indels, aligned;
         imo_sw_indel((const char*)targets + t_off[i], (int32_t)(t_off[i + 1] - t_off[i]),

@@ -81,6 +81,28 @@ def synth_small(tmp_path_factory):
 
 
 @pytest.fixture(scope="module")
+def synth_tn(tmp_path_factory):
+    spec = importlib.util.spec_from_file_location("make_golden", os.path.join(GOLD, "make_golden.py"))
+    mg = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mg)
+    d = tmp_path_factory.mktemp("tn")
+    mg.write_dataset(str(d), mg.SYNTH_TN["tumor"], "tumor_")
+    mg.write_dataset(str(d), mg.SYNTH_TN["normal"], "normal_")
+    return str(d)
+
+
+def _annotate(binary, cwd):
+    """Discovery on the tumour, then annotate mode on the normal (README.md:116)."""
+    r = subprocess.run([binary, "-i", "cfg.txt", "ref.fa", "t=tumor_aln.bam"], cwd=cwd, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    assert r.returncode == 0, r.stderr.decode()[-2000:]
+    open(os.path.join(cwd, "tumor.vcf"), "wb").write(r.stdout)
+    a = subprocess.run([binary, "-i", "cfg.txt", "-q", "0", "-a", "-e", "1", "ref.fa", "tumor.vcf", "normal=normal_aln.bam"],
+                       cwd=cwd, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    assert a.returncode == 0, a.stderr.decode()[-2000:]
+    return r.stdout, a.stdout
+
+
+@pytest.fixture(scope="module")
 def synth_1mb(tmp_path_factory):
     return _synth_dir(tmp_path_factory, "synth_1mb_30x")
 
@@ -109,6 +131,23 @@ def test_host_logic_synthetic_two_contigs_composite(synth_small):
 def test_host_logic_synthetic_1mb_crosses_flushes(synth_1mb):
     """300 000 reads: three READCHUNK flushes with markers (src/indelminer.c:617-670)."""
     assert _run(_build_shim(), ["-i", "cfg.txt"], synth_1mb, "ref.fa", "aln.bam") == _golden("synth_1mb_30x")
+
+
+def test_host_logic_annotate_test_data():
+    out = subprocess.run([_build_shim(), "-i", "indelminer.config", "-q", "0", "-a", "-e", "1", "reference.fa",
+                          os.path.join(GOLD, "vcf", "default_config.vcf"), "normal=alignments.bam"], cwd=TD,
+                         stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    assert out.returncode == 0 and out.stdout == _golden("annotate")
+
+
+def test_host_logic_annotate_tumor_normal(synth_tn):
+    """BASELINE config 5 in small: somatic indels stay untagged, germline ones are tagged either by
+    re-discovery or by is_indel_supported's Smith-Waterman."""
+    tumor, ann = _annotate(_build_shim(), synth_tn)
+    assert tumor == _golden("synth_tn_tumor")
+    assert ann == _golden("synth_tn_annotate")
+    body = [l for l in ann.splitlines() if not l.startswith(b"#")]
+    assert 0 < sum(1 for l in body if not l.endswith(b";normal")) < len(body)
 
 
 def test_product_binary_refuses_without_gpu():
@@ -147,3 +186,14 @@ def test_product_refuses_out_of_range_band_loudly():
     r = subprocess.run([_product(), "-i", "indelminer.config", "-g", "200", "reference.fa", "s=alignments.bam"], cwd=TD,
                        stdout=subprocess.PIPE, stderr=subprocess.PIPE)
     assert r.returncode != 0 and b"numgaps" in r.stderr
+
+
+@pytest.mark.gpu
+def test_product_annotate(synth_tn):
+    out = subprocess.run([_product(), "-i", "indelminer.config", "-q", "0", "-a", "-e", "1", "reference.fa",
+                          os.path.join(GOLD, "vcf", "default_config.vcf"), "normal=alignments.bam"], cwd=TD,
+                         stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    assert out.returncode == 0 and out.stdout == _golden("annotate")
+    tumor, ann = _annotate(_product(), synth_tn)
+    assert tumor == _golden("synth_tn_tumor")
+    assert ann == _golden("synth_tn_annotate")
