@@ -59,6 +59,22 @@ static void fatalf(const char* fmt, ...)
 }
 #define forceassert(e) do { if (!(e)) { fprintf(stderr, "Assertion failed: %s file %s line %d\n", #e, __FILE__, __LINE__); exit(EXIT_FAILURE); } } while (0)
 
+static double now_ms(void)
+{
+    struct timespec ts;
+    clock_gettime(CLOCK_MONOTONIC, &ts);
+    return ts.tv_sec * 1e3 + ts.tv_nsec * 1e-6;
+}
+static int g_timing = 0;
+static double g_t_last = 0;
+static void phase_time(const char* what)
+{
+    if (!g_timing) return;
+    const double t = now_ms();
+    fprintf(stderr, "[timing] %-34s %9.2f ms\n", what, t - g_t_last);
+    g_t_last = t;
+}
+
 static void timestamp(const char* fmt, ...)
 {
     va_list ap;
@@ -1630,12 +1646,14 @@ static void run_contig(driver* d, int32_t tid, int32_t beg, int32_t end, bgzf_re
         dispatch_record(d, &b);
     }
     free(b.data);
+    phase_time("pass A (BAM decode + dispatch)");
     d->depth_tid = -1;
     if (whole) {
         if (im_depth_build(d->gpu, d->seqlen[tid], (int32_t)d->n_seg, d->seg_start, d->seg_len) != IM_OK)
             fatalf("im_depth_build: %s", im_last_error(d->gpu));
         d->depth_tid = tid;
     }
+    phase_time("depth array (device)");
 
     im_read_result* res = NULL;
     if (d->cb.n > 0) {
@@ -1645,6 +1663,7 @@ static void run_contig(driver* d, int32_t tid, int32_t beg, int32_t end, bgzf_re
         const int rc = im_realign_batch(d->gpu, &P, &batch, res);
         if (rc != IM_OK) fatalf("im_realign_batch: %s", im_last_error(d->gpu));
     }
+    phase_time("realign batch (device, incl. copies)");
     int f = 0;
     for (int64_t i = 0; i <= d->n_items; i++) {
         while (f < d->n_flushes && d->flushes[f].n_items == i) {
@@ -1658,6 +1677,7 @@ static void run_contig(driver* d, int32_t tid, int32_t beg, int32_t end, bgzf_re
     }
     free(res);
     flush_variants(d, tid, INT_MAX);        /* end of contig (src/indelminer.c:806-823) */
+    phase_time("pass B (cluster, merge, print)");
     if (g_vcfname != NULL) {
         /* what print_knownvariants left over (src/indelminer.c:839-847) */
         for (int ki = g_known.next; ki < g_known.n; ki++) {
@@ -1758,6 +1778,8 @@ int main(int argc, char** argv)
     if (argc == optind) { print_help(stderr); return EXIT_FAILURE; }
     forceassert(argc - optind > 1);
     t0 = time(0);
+    g_timing = getenv("INDELMINER_TIMING") != NULL;
+    g_t_last = now_ms();
 
     const char* fasta_reference = argv[optind++];
     char* ptr = argv[optind++];
@@ -1803,11 +1825,13 @@ int main(int argc, char** argv)
             fprintf(stderr, "%s\t%d\t%d\n", it->name, ((int32_t*)it->val)[0], ((int32_t*)it->val)[1]);
     fprintf(stderr, "----------\t---------\t---------\n\n");
     timestamp("Read insertlengths for the BAM file");
+    phase_time("open BAM, index, insert lengths");
 
     const int nseq = fasta_load(fasta_reference, d.hdr->n_targets, &d.sequences, &d.seqlen, chromid);
     if (nseq < 0) fatalf("error in opening the file %s", fasta_reference);
     forceassert(nseq == d.hdr->n_targets);
     timestamp("Read the reference sequence");
+    phase_time("read FASTA");
 
     /* the GPU: one context, reference resident in HBM */
     const char* dev_env = getenv("INDELMINER_DEVICE");
@@ -1822,6 +1846,7 @@ int main(int argc, char** argv)
         free(seqs); free(lens);
     }
 
+    phase_time("GPU context + reference upload");
     if (strncmp(O.outputformat, "vcf", 3) == 0) print_vcf_preamble();
     if (g_vcfname != NULL)
         printf("##INFO=<ID=%s,Number=0,Type=Flag,Description=\"The variant is also present in this sample\">\n", g_sample_name);
