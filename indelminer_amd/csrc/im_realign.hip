@@ -48,7 +48,16 @@ __device__ unsigned long long im_stamp_acc[32];
 namespace im {
 namespace {
 
-constexpr int kDiagChunk = 4096;            // diagonals per histogram pass (1 byte each)
+#ifndef IM_DIAG_CHUNK
+#define IM_DIAG_CHUNK 1920
+#endif
+#ifndef IM_WAVES_PER_SIMD
+#define IM_WAVES_PER_SIMD 4
+#endif
+#ifndef IM_BLOCKS_PER_CU
+#define IM_BLOCKS_PER_CU 16
+#endif
+constexpr int kDiagChunk = IM_DIAG_CHUNK;   // diagonals per histogram pass (1 byte each)
 constexpr int kTblBytes  = 4096;            // 4^6 direct table, or 512-slot hash (keys+vals)
 constexpr int kHashSlots = 512;
 constexpr int kDirectMaxK = 6;
@@ -60,7 +69,6 @@ struct WaveLds {
     uint32_t diag[kDiagChunk / 4 + 16];     // packed byte counters (+ slack for band sums)
     uint32_t tbl[kTblBytes / 4];
     uint32_t rd[(256 + 16) / 4];            // read bases, read coordinates
-    uint32_t eq[2][256 / 4];                // per band alignment: match flag per read position
 };
 
 // ---- wave helpers (64 lanes) ------------------------------------------------
@@ -146,6 +154,16 @@ __device__ __forceinline__ uint32_t code2(uint32_t c)
     x ^= x >> 1;
     const bool valid = (u < 26u) && ((0x80045u >> u) & 1u);
     return valid ? x : 0u;
+}
+
+typedef unsigned short im_u16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t pk_max_u16(uint32_t a, uint32_t b)     // v_pk_max_u16
+{
+    im_u16x2 x, y;
+    __builtin_memcpy(&x, &a, 4); __builtin_memcpy(&y, &b, 4);
+    const im_u16x2 r = __builtin_elementwise_max(x, y);
+    uint32_t o; __builtin_memcpy(&o, &r, 4);
+    return o;
 }
 
 __device__ __forceinline__ uint32_t lds_byte(const uint32_t* base, uint32_t i)
@@ -307,8 +325,7 @@ __device__ __forceinline__ Band band_search(WaveLds& s, const uint64_t* __restri
     // Window words of one histogram chunk: every lane takes 16 positions per sweep of 1024.
     // All sweeps of a chunk are requested up front (kPre of them into registers) so that the
     // chunk pays one memory round trip, and chunk 0 is requested BEFORE the read table is
-    // built so that the trip overlaps that work (kPre = 3 sweeps live in registers).
-    constexpr int kPre = 3;
+    // built so that the trip overlaps that work (two sweeps = 2048 window bases live in registers; a third is rare).
     int bc = 0, bd = INT_MAX, bi = 0;                             // select_band's max, dist, indx
 
     for (uint32_t c0 = 0; c0 < numdiag; c0 += step) {
@@ -316,12 +333,11 @@ __device__ __forceinline__ Band band_search(WaveLds& s, const uint64_t* __restri
         const int p_hi = min((int)npos - 1, (int)(c0 + kDiagChunk) - 2);
         const uint32_t g0 = (w0 + (uint32_t)(p_lo <= p_hi ? p_lo : 0)) & ~15u;
         const uint32_t a_hi = w0 + (uint32_t)(p_lo <= p_hi ? p_hi : 0);
-        uint64_t whi0 = 0, wlo0 = 0, whi1 = 0, wlo1 = 0, whi2 = 0, wlo2 = 0;
+        uint64_t whi0 = 0, wlo0 = 0, whi1 = 0, wlo1 = 0;
         if (p_lo <= p_hi) {
-            const uint32_t A0 = g0 + 16u * lane, A1 = A0 + 1024u, A2 = A0 + 2048u;
+            const uint32_t A0 = g0 + 16u * lane, A1 = A0 + 1024u;
             if (A0 <= a_hi) { whi0 = pk[A0 >> 5]; wlo0 = pk[(A0 >> 5) + 1]; }
             if (A1 <= a_hi) { whi1 = pk[A1 >> 5]; wlo1 = pk[(A1 >> 5) + 1]; }
-            if (A2 <= a_hi) { whi2 = pk[A2 >> 5]; wlo2 = pk[(A2 >> 5) + 1]; }
         }
         if (c0 == 0) {
             table_build<KT, DIRECT>(s, p0, nq, k, lane, read_pk8);
@@ -342,7 +358,6 @@ __device__ __forceinline__ Band band_search(WaveLds& s, const uint64_t* __restri
                 uint64_t hi, lo;
                 if (it == 0) { hi = whi0; lo = wlo0; }
                 else if (it == 1) { hi = whi1; lo = wlo1; }
-                else if (it == 2) { hi = whi2; lo = wlo2; }
                 else { hi = pk[A >> 5]; lo = pk[(A >> 5) + 1]; }
                 const uint64_t pkd = (A & 16u) ? ((hi << 32) | (lo >> 32)) : hi;  // bases A..A+31, first base on top
                 if (DIRECT) {
@@ -390,31 +405,71 @@ __device__ __forceinline__ Band band_search(WaveLds& s, const uint64_t* __restri
         // bin_bands + select_band over i in [c0, iend)
         const uint32_t iend = min(c0 + step, numdiag);
         const uint32_t nband = numdiag - g;                       // bands[i] == 0 for i >= nband (135)
-        for (uint32_t dw = lane; 4u * dw < iend - c0; dw += 64) {
-            const uint32_t v = s.diag[dw];
-            if (g == 0 && v == 0u && bc > 0) continue;            // four empty diagonals cannot beat a vote
+        if (g == 0) {
+            // One diagonal per band.  Pass 1 finds the chunk's largest count M (packed 16-bit maxima
+            // of the even / odd bytes, one wave reduction); pass 2 visits only the words that hold
+            // a byte equal to M and keeps the (distance, index)-least of those diagonals.  bc is
+            // wave-uniform; bd / bi are per lane and compared against the same bc.
+            const uint32_t nb = iend - c0;
+            uint32_t me = 0, mo = 0;
+            for (uint32_t dw = lane; 4u * dw < nb; dw += 64) {
+                const uint32_t v = s.diag[dw];
+                me = pk_max_u16(me, v & 0x00FF00FFu);
+                mo = pk_max_u16(mo, (v >> 8) & 0x00FF00FFu);
+            }
+            const uint32_t m2 = pk_max_u16(me, mo);
+            const int M = wave_max((int)max(m2 & 0xFFFFu, m2 >> 16));
+            if (M > 0 && M >= bc) {
+                if (M > bc) { bc = M; bd = INT_MAX; bi = 0; }
+                const uint32_t rep = (uint32_t)M * 0x01010101u;
+                for (uint32_t dw = lane; 4u * dw < nb; dw += 64) {
+                    const uint32_t v = s.diag[dw];
+                    const uint32_t x = v ^ rep;
+                    if (((x - 0x01010101u) & ~x & 0x80808080u) == 0u) continue;      // no byte equals M
 #pragma unroll
-            for (int bb = 0; bb < 4; bb++) {
-                const uint32_t i = c0 + 4u * dw + bb;
-                if (i >= iend) break;
-                int cnt = (int)((v >> (8 * bb)) & 255u);
-                if (g > 0) {                                      // bin_bands: sum of g+1 neighbouring diagonals
+                    for (int bb = 0; bb < 4; bb++) {
+                        if (((v >> (8 * bb)) & 255u) != (uint32_t)M) continue;
+                        const int i = (int)(c0 + 4u * dw) + bb;
+                        const int d = abs(anchor_rel - i);
+                        if (d < bd || (d == bd && i < bi)) { bd = d; bi = i; }
+                    }
+                }
+            }
+        } else {
+            for (uint32_t dw = lane; 4u * dw < iend - c0; dw += 64) {
+                const uint32_t v = s.diag[dw];
+#pragma unroll
+                for (int bb = 0; bb < 4; bb++) {
+                    const uint32_t i = c0 + 4u * dw + bb;
+                    if (i >= iend) break;
+                    int cnt = (int)((v >> (8 * bb)) & 255u);
+                    // bin_bands: sum of g+1 neighbouring diagonals
                     if (i < nband) for (uint32_t e = 1; e <= g; e++) cnt += (int)lds_byte(s.diag, i - c0 + e);
                     else cnt = 0;
+                    const int d = abs(anchor_rel - (int)i);
+                    if (cnt > bc || (cnt == bc && (d < bd || (d == bd && (int)i < bi)))) { bc = cnt; bd = d; bi = (int)i; }
                 }
-                const int d = abs(anchor_rel - (int)i);
-                if (cnt > bc || (cnt == bc && (d < bd || (d == bd && (int)i < bi)))) { bc = cnt; bd = d; bi = (int)i; }
             }
         }
         wave_lds_sync();
         IM_STAMP_B(3);
     }
     if constexpr (KT == 6) table_undo6(s, p0, nq, lane, read_pk8);
-    // wave argmax with select_band's order: most votes, then nearest the anchor, then smallest index
+    // select_band's order: most votes, then nearest the anchor, then smallest index
+    if (g == 0) {
+        if (bc == 0) {
+            // no vote anywhere: every diagonal ties at 0 and the nearest to the anchor wins
+            bi = min(max(anchor_rel, 0), (int)numdiag - 1);
+        } else {
+            const int D = wave_min(bd);
+            bi = wave_min(bd == D ? bi : INT_MAX);
+        }
+    } else {
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-        const int oc = __shfl_xor(bc, o), od = __shfl_xor(bd, o), oi = __shfl_xor(bi, o);
-        if (oc > bc || (oc == bc && (od < bd || (od == bd && oi < bi)))) { bc = oc; bd = od; bi = oi; }
+        for (int o = 32; o > 0; o >>= 1) {
+            const int oc = __shfl_xor(bc, o), od = __shfl_xor(bd, o), oi = __shfl_xor(bi, o);
+            if (oc > bc || (oc == bc && (od < bd || (od == bd && oi < bi)))) { bc = oc; bd = od; bi = oi; }
+        }
     }
     b.votes = bc;
     b.low = bi - (int)nq;                                          // 438
@@ -428,24 +483,23 @@ struct Aln {
     int st;                 // 0 ok, IM_ST_ABORT
     int q1, q2, r1, r2;     // 0-based half-open read / contig coordinates; q1 == q2: no alignment
     int f, l;               // leading / trailing '=' run (src/alignment.c:585-599)
+    uint32_t eqbits;        // per lane: bit j = read position 4*lane+j is an aligned '=' (read coordinates)
 };
 
 // local_align + ALIGN + fetch_cigar for low == up == d (src/localalign.c:100-176
 // with band == 1; closed form validated in SURVEY.md A.5a):
 //   forward : c_t = max(0, c_{t-1} + w_t); end = first t where c_t is the strict maximum
 //   reverse : start = largest s <= end with sum_{s..end} w == best
-// Match flags of the aligned positions go to eqdst[] in read coordinates.
+// Match flags of the aligned positions come back in Aln::eqbits, in read coordinates.
 __device__ __forceinline__ Aln diag_scan(WaveLds& s, const uint8_t* __restrict__ contig,
-                         uint32_t w0, uint32_t w1, uint32_t p0, uint32_t p1, int d,
-                         uint32_t* eqdst, int lane)
+                         uint32_t w0, uint32_t w1, uint32_t p0, uint32_t p1, int d, int lane)
 {
     Aln a;
-    a.st = 0; a.q1 = a.q2 = a.r1 = a.r2 = 0; a.f = a.l = 0;
+    a.st = 0; a.q1 = a.q2 = a.r1 = a.r2 = 0; a.f = a.l = 0; a.eqbits = 0u;
     const int M = (int)(p1 - p0), N = (int)(w1 - w0);
     if (M <= 0 || N <= 0 || d < -M || d > N) { a.st = IM_ST_ABORT; return a; }   // src/localalign.c:31-32,70-77
     const int t_lo = max(0, -d), t_hi = min(M, N - d);
 
-    eqdst[lane] = 0u;
     const int t0 = 4 * lane;
     uint32_t rdw = 0, rfw = 0;
     if (t0 < t_hi && t0 + 3 >= t_lo) {
@@ -502,23 +556,28 @@ __device__ __forceinline__ Aln diag_scan(WaveLds& s, const uint8_t* __restrict__
     for (int j = 0; j < 4; j++) {
         const int t = t0 + j;
         if (t >= start && t <= end) {
-            if (eq[j]) flags |= 1u << (8 * j);
+            if (eq[j]) flags |= 1u << j;
             else { fm = min(fm, t); lm = max(lm, t); }
         }
     }
     fm = wave_min(fm); lm = wave_max(lm);
     a.f = (fm == INT_MAX ? end + 1 : fm) - start;
     a.l = end - (lm < 0 ? start - 1 : lm);
-    // scatter flags to read coordinates p0 + t
+    // flags live in piece coordinates t (lane owns t0..t0+3); read position x = p0 + t belongs to
+    // lane x >> 2, so lane L collects bits 4L - p0 .. 4L - p0 + 3 of the 256-bit flag string from
+    // the two lanes that hold them (ds_bpermute: no LDS storage, no barrier)
     {
-        uint8_t* e8 = reinterpret_cast<uint8_t*>(eqdst);
-        wave_lds_sync();
-#pragma unroll
-        for (int j = 0; j < 4; j++) {
-            const int x = (int)p0 + t0 + j;
-            if (x < 256 && ((flags >> (8 * j)) & 1u)) e8[x] = 1;
+        const uint32_t f4 = flags;
+        if (p0 == 0u) a.eqbits = f4;
+        else {
+            const int base = 4 * lane - (int)p0;
+            const int ql = base >> 2, r = base & 3;                 // floor division
+            const uint32_t lo = (uint32_t)__builtin_amdgcn_ds_bpermute((ql & 63) << 2, (int)f4);
+            const uint32_t hi = (uint32_t)__builtin_amdgcn_ds_bpermute(((ql + 1) & 63) << 2, (int)f4);
+            const uint32_t lo_ok = (ql >= 0 && ql < 64) ? lo : 0u;
+            const uint32_t hi_ok = (ql + 1 >= 0 && ql + 1 < 64) ? hi : 0u;
+            a.eqbits = ((lo_ok | (hi_ok << 4)) >> r) & 0xFu;
         }
-        wave_lds_sync();
     }
     a.q1 = (int)p0 + start;                                         // src/alignment.c:385-388
     a.q2 = (int)p0 + end + 1;
@@ -610,7 +669,7 @@ __device__ __forceinline__ void realign_one(WaveLds& s, const RealignArgs& A, in
     IM_STAMP(0);
     const Band b1 = band_search<KT, DIRECT>(s, pk, (uint32_t)left1, (uint32_t)right1, (uint32_t)anchor, 0u, (uint32_t)L, k, g, lane, read_pk8 IM_STAMP_PASS(1));
     if (b1.st) { finish(out, b1.st, 1, lane); return; }
-    const Aln a1 = diag_scan(s, contig, (uint32_t)left1, (uint32_t)right1, 0u, (uint32_t)L, b1.low, s.eq[0], lane);
+    const Aln a1 = diag_scan(s, contig, (uint32_t)left1, (uint32_t)right1, 0u, (uint32_t)L, b1.low, lane);
     store_band(out, 0, b1, a1, lane);
     IM_STAMP(6);
     if (a1.st) { finish(out, a1.st, 1, lane); return; }
@@ -648,7 +707,7 @@ __device__ __forceinline__ void realign_one(WaveLds& s, const RealignArgs& A, in
     IM_STAMP(7);
     const Band b2 = band_search<KT, DIRECT>(s, pk, w0, w1, anc, p0, p1, k, g, lane, read_pk8 IM_STAMP_PASS(8));
     if (b2.st) { finish(out, b2.st, 2, lane); return; }
-    const Aln a2 = diag_scan(s, contig, w0, w1, p0, p1, b2.low, s.eq[1], lane);
+    const Aln a2 = diag_scan(s, contig, w0, w1, p0, p1, b2.low, lane);
     store_band(out, 1, b2, a2, lane);
     IM_STAMP(13);
     if (a2.st) { finish(out, a2.st, 2, lane); return; }
@@ -658,26 +717,25 @@ __device__ __forceinline__ void realign_one(WaveLds& s, const RealignArgs& A, in
     if (!(q1 < q2 && q3 < q4)) { finish(out, IM_ST_ABORT, 2, lane); return; }             // 720-721
 
     // combine (723-754).  "A" = the piece that starts at read offset 0, "B" = the one that ends at L.
-    const uint32_t *eqA, *eqB;
+    uint32_t wa, wb;                    // Aln::eqbits of the A / B piece
     int qa2, rA, qb1, rB;               // A = read[0,qa2) at contig rA.. ; B = read[qb1,L) at contig rB..
     bool split;                         // true: overlapping pieces, choose the split point (K4)
-    if (q1 > q3 && q1 <= q4)        { eqA = s.eq[1]; qa2 = q4; rA = r3; eqB = s.eq[0]; qb1 = q1; rB = r1; split = true;  }
-    else if (q3 > q1 && q3 <= q2)   { eqA = s.eq[0]; qa2 = q2; rA = r1; eqB = s.eq[1]; qb1 = q3; rB = r3; split = true;  }
-    else if (q1 > q4 && r1 == r4)   { eqA = s.eq[1]; qa2 = q4; rA = r3; eqB = s.eq[0]; qb1 = q1; rB = r1; split = false; }
-    else if (q3 > q2 && r2 == r3)   { eqA = s.eq[0]; qa2 = q2; rA = r1; eqB = s.eq[1]; qb1 = q3; rB = r3; split = false; }
+    if (q1 > q3 && q1 <= q4)        { wa = a2.eqbits; qa2 = q4; rA = r3; wb = a1.eqbits; qb1 = q1; rB = r1; split = true;  }
+    else if (q3 > q1 && q3 <= q2)   { wa = a1.eqbits; qa2 = q2; rA = r1; wb = a2.eqbits; qb1 = q3; rB = r3; split = true;  }
+    else if (q1 > q4 && r1 == r4)   { wa = a2.eqbits; qa2 = q4; rA = r3; wb = a1.eqbits; qb1 = q1; rB = r1; split = false; }
+    else if (q3 > q2 && r2 == r3)   { wa = a1.eqbits; qa2 = q2; rA = r1; wb = a2.eqbits; qb1 = q3; rB = r3; split = false; }
     else { finish(out, IM_ST_NONE, 2, lane); return; }
     // find_best_del_candidate asserts its first piece starts at read offset 0 (314-315)
     // (holds by the accept conditions above: the A piece has q == 0)
 
     // per-position match flags of A on [0,qa2) and B on [qb1,L)
     const int x0 = 4 * lane;
-    const uint32_t wa = eqA[lane], wb = eqB[lane];
     int fa[4], fb[4];
 #pragma unroll
     for (int j = 0; j < 4; j++) {
         const int x = x0 + j;
-        fa[j] = (x < qa2) ? (int)((wa >> (8 * j)) & 1u) : 0;
-        fb[j] = (x >= qb1 && x < L) ? (int)((wb >> (8 * j)) & 1u) : 0;
+        fa[j] = (x < qa2) ? (int)((wa >> j) & 1u) : 0;
+        fb[j] = (x >= qb1 && x < L) ? (int)((wb >> j) & 1u) : 0;
     }
     const int ta = fa[0] + fa[1] + fa[2] + fa[3], tb = fb[0] + fb[1] + fb[2] + fb[3];
     const int ia = wave_scan_add(ta, lane), ib = wave_scan_add(tb, lane);
@@ -790,7 +848,7 @@ __device__ __forceinline__ void realign_one(WaveLds& s, const RealignArgs& A, in
 }
 
 template <int KT, bool DIRECT>
-__global__ __launch_bounds__(64) void realign_kernel(RealignArgs A)
+__global__ __launch_bounds__(64, IM_WAVES_PER_SIMD) void realign_kernel(RealignArgs A)
 {
     __shared__ WaveLds s;
     const int lane = threadIdx.x;
@@ -1252,6 +1310,7 @@ __global__ __launch_bounds__(64) void realign_gapped_kernel(RealignArgs A)
     __shared__ GapLds G;
     const int lane = threadIdx.x;
     const uint32_t k = A.P.klength, g = A.P.numgaps, eth = A.P.ethreshold;
+    IM_STAMP_DECL
     for (int c = blockIdx.x; c < A.batch.n; c += gridDim.x) {
         im_read_result* out = &A.batch.out[c];
         const int64_t off = uni64(A.batch.base_off[c]);
@@ -1291,7 +1350,7 @@ __global__ __launch_bounds__(64) void realign_gapped_kernel(RealignArgs A)
             finish(out, IM_ST_ABORT, 0, lane); continue;
         }
         // piece 1
-        const Band b1 = band_search<0, DIRECT>(s, pk, (uint32_t)left1, (uint32_t)right1, (uint32_t)anchor, 0u, (uint32_t)L, k, g, lane, 0u);
+        const Band b1 = band_search<0, DIRECT>(s, pk, (uint32_t)left1, (uint32_t)right1, (uint32_t)anchor, 0u, (uint32_t)L, k, g, lane, 0u IM_STAMP_PASS(16));
         if (b1.st) { finish(out, b1.st, 1, lane); continue; }
         const int up1 = ((uint32_t)L < k) ? b1.low : b1.low + (int)g;      // read shorter than k: low == up (408-412)
         int st = gap_stage_window(G, contig, left1, right1 - left1, L, b1.low, up1, lane);
@@ -1358,7 +1417,7 @@ __global__ __launch_bounds__(64) void realign_gapped_kernel(RealignArgs A)
         if (none) { finish(out, IM_ST_NONE, 1, lane); continue; }
         if ((int32_t)(w1 - w0) <= 0) { finish(out, IM_ST_ABORT, 1, lane); continue; }
         // piece 2
-        const Band b2 = band_search<0, DIRECT>(s, pk, w0, w1, anc, p0, p1, k, g, lane, 0u);
+        const Band b2 = band_search<0, DIRECT>(s, pk, w0, w1, anc, p0, p1, k, g, lane, 0u IM_STAMP_PASS(21));
         if (b2.st) { finish(out, b2.st, 2, lane); continue; }
         const int up2 = ((p1 - p0) < k) ? b2.low : b2.low + (int)g;
         st = gap_stage_window(G, contig, (int)w0, (int)(w1 - w0), (int)(p1 - p0), b2.low, up2, lane);
@@ -1463,7 +1522,7 @@ hipError_t launch_realign(const RealignArgs& a, int n_cu, hipStream_t stream)
 {
     if (a.batch.n <= 0) return hipSuccess;
     // ~9 KiB LDS per one-wave workgroup -> up to 17 per CU; ask for 16 per CU.
-    int64_t want = (int64_t)n_cu * 16;
+    int64_t want = (int64_t)n_cu * IM_BLOCKS_PER_CU;
     int64_t need = ((int64_t)a.batch.n + 7) / 8 * 8;
     int grid = (int)(need < want ? need : want);
     grid = (grid + 7) / 8 * 8;
