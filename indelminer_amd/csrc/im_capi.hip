@@ -150,18 +150,18 @@ int im_set_reference(im_ctx* ctx, int32_t n_contigs, const char* const* seqs, co
     for (int32_t i = 0; i < n_contigs; i++) {
         if (lens[i] < 0 || lens[i] > 0x7fffff00LL) { set_err(ctx, "contig %d length %lld unsupported", i, (long long)lens[i]); return IM_E_ARG; }
         asc_off[i] = pos;
-        pk_off[i] = pos / 32;
+        pk_off[i] = pos / 4;
         len32[i] = (int32_t)lens[i];
         pos = (int64_t)up256((size_t)(pos + lens[i] + 64));
     }
     const int64_t total = pos + 256;                 // multiple of 256, hence of 32
     HIP_TRY(ctx, hipMalloc((void**)&ctx->ref_ascii, (size_t)total));
-    HIP_TRY(ctx, hipMalloc((void**)&ctx->ref_pk, (size_t)(total / 32 + 4) * sizeof(uint64_t)));
+    HIP_TRY(ctx, hipMalloc((void**)&ctx->ref_pk, (size_t)(total / 4 + 1024)));
     HIP_TRY(ctx, hipMalloc((void**)&ctx->d_asc_off, sizeof(int64_t) * n_contigs));
     HIP_TRY(ctx, hipMalloc((void**)&ctx->d_pk_off, sizeof(int64_t) * n_contigs));
     HIP_TRY(ctx, hipMalloc((void**)&ctx->d_len, sizeof(int32_t) * n_contigs));
     HIP_TRY(ctx, hipMemsetAsync(ctx->ref_ascii, 0, (size_t)total, ctx->stream));
-    HIP_TRY(ctx, hipMemsetAsync(ctx->ref_pk, 0, (size_t)(total / 32 + 4) * sizeof(uint64_t), ctx->stream));
+    HIP_TRY(ctx, hipMemsetAsync(ctx->ref_pk, 0, (size_t)(total / 4 + 1024), ctx->stream));
     for (int32_t i = 0; i < n_contigs; i++)
         if (lens[i] > 0)
             HIP_TRY(ctx, hipMemcpyAsync(ctx->ref_ascii + asc_off[i], seqs[i], (size_t)lens[i], hipMemcpyHostToDevice, ctx->stream));
@@ -183,7 +183,7 @@ int im_dev_realign(im_ctx* ctx, const im_params* params, const im_dev_batch* bat
     if (batch->n < 0) { set_err(ctx, "negative batch size"); return IM_E_ARG; }
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     im::RealignArgs a;
-    a.ref.ascii = ctx->ref_ascii; a.ref.pk = ctx->ref_pk;
+    a.ref.ascii = ctx->ref_ascii; a.ref.pk = reinterpret_cast<const uint8_t*>(ctx->ref_pk);
     a.ref.asc_off = ctx->d_asc_off; a.ref.pk_off = ctx->d_pk_off; a.ref.len = ctx->d_len;
     a.ref.n_contigs = ctx->n_contigs;
     a.batch = *batch;

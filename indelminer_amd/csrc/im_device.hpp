@@ -15,13 +15,16 @@ namespace im {
 //           Needed by the diagonal scan, which compares raw bytes
 //           (W[i][j] = MATCH iff i == j, src/localalign.c:61-67).
 //   pk    : 2-bit codes (base2bits, src/alignment.c:11-24: A,a=0 C,c=1 G,g=2
-//           T,t=3, anything else 0), 32 bases per 64-bit word, first base in
-//           the most significant bits.  Needed by the k-mer band vote only.
+//           T,t=3, anything else 0), 4 bases per byte, first base in the least
+//           significant bits, so an unaligned dword at byte p/4 shifted right by
+//           2*(p%4) starts with the k-mer at p.  >= 1 KiB of zero bytes follow the
+//           last contig (the vote reads up to a sweep past a window).  Needed by
+//           the k-mer band vote only.
 struct RefDev {
     const uint8_t*  ascii;
-    const uint64_t* pk;
+    const uint8_t*  pk;
     const int64_t*  asc_off;    // [n_contigs] byte offset of contig start in ascii
-    const int64_t*  pk_off;     // [n_contigs] word offset of contig start in pk
+    const int64_t*  pk_off;     // [n_contigs] byte offset of contig start in pk
     const int32_t*  len;        // [n_contigs]
     int32_t         n_contigs;
 };

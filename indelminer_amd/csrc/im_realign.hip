@@ -15,9 +15,10 @@
 // time; the grid is a few workgroups per CU that stride over the batch, with
 // the blockIdx -> read mapping arranged so that the workgroups of one XCD
 // (blockIdx % 8) walk neighbouring reads and share reference windows in that
-// XCD's L2.  Per-wave LDS: a 4 KiB read k-mer table, a 4 KiB packed-byte
-// diagonal histogram, the read and two match-flag strips.  No MFMA: this is
-// integer scan / histogram work bound by LDS atomics and latency.
+// XCD's L2.  Per-wave LDS: a 4 KiB read k-mer table, a 1.9 KiB packed-byte
+// diagonal histogram and the read (6.2 KiB, 24 waves per CU).  No MFMA: this
+// is integer scan / histogram work; measured, it is bound by VALU issue
+// (profiles/README.md), so the design rule is fewest vector instructions per read.
 //
 // Lane layout for everything positional: lane l owns read positions
 // 4l..4l+3 (hence IM_MAX_READ = 255); prefix sums / minima run as lane-local
@@ -37,6 +38,15 @@ __device__ unsigned long long im_stamp_acc[32];
 #define IM_STAMP_ARG , unsigned long long& stamp_prev_, int stamp_base_
 #define IM_STAMP_PASS(base) , stamp_prev_, base
 #define IM_STAMP_B(id) IM_STAMP(stamp_base_ + (id))
+#elif defined(IM_STOP_AFTER)
+// Diagnostic build only (profiles/phase_counts.sh): every read stops after phase IM_STOP_AFTER, so the
+// difference of SQ_INSTS_* between consecutive builds is that phase's dynamic instruction count.
+#define IM_STAMP_DECL
+#define IM_STAMP(id) do { if ((id) == IM_STOP_AFTER) { finish(out, IM_ST_NONE, 0, lane); return; } } while (0)
+#define IM_STAMP_ARG , int stamp_base_
+#define IM_STAMP_PASS(base) , base
+#define IM_STAMP_B(id) do { if (stamp_base_ + (id) == IM_STOP_AFTER) { if constexpr (KT == 6) table_undo6(s, p0, nq, lane, read_pk8); \
+                            b.st = IM_ST_ABORT; return b; } } while (0)   /* the k = 6 table must be left clean */
 #else
 #define IM_STAMP_DECL
 #define IM_STAMP(id)
@@ -52,10 +62,10 @@ namespace {
 #define IM_DIAG_CHUNK 1920
 #endif
 #ifndef IM_WAVES_PER_SIMD
-#define IM_WAVES_PER_SIMD 4
+#define IM_WAVES_PER_SIMD 6
 #endif
 #ifndef IM_BLOCKS_PER_CU
-#define IM_BLOCKS_PER_CU 16
+#define IM_BLOCKS_PER_CU 24
 #endif
 constexpr int kDiagChunk = IM_DIAG_CHUNK;   // diagonals per histogram pass (1 byte each)
 constexpr int kTblBytes  = 4096;            // 4^6 direct table, or 512-slot hash (keys+vals)
@@ -187,9 +197,9 @@ struct Band {
     int win, piece;
 };
 
-// the read k-mer table: value 0 = k-mer absent from the read piece, 0xFF = occurs
-// more than once (bin_diagonals only lets read-unique k-mers vote, 97-98), else
-// 1 + offset of the k-mer in the piece.
+// the read k-mer table: 1 + offset of the k-mer in the piece, for k-mers that occur exactly once
+// (bin_diagonals only lets read-unique k-mers vote, 97-98).  In the direct (k <= 6) table every
+// other entry is 0, so "votes" is simply "non-zero"; the hash table (k > 6) marks repeats 0xFF.
 template <int KT, bool DIRECT>
 __device__ __forceinline__ void table_build(WaveLds& s, uint32_t p0, uint32_t nq, uint32_t k, int lane, uint32_t read_pk8)
 {
@@ -201,13 +211,13 @@ __device__ __forceinline__ void table_build(WaveLds& s, uint32_t p0, uint32_t nq
         uint8_t* t8 = reinterpret_cast<uint8_t*>(s.tbl);
         const uint32_t n1 = (uint32_t)dpp_mov<kDppWaveShl1>(0, (int)read_pk8);
         const uint32_t n2 = (uint32_t)dpp_mov<kDppWaveShl1>(0, (int)n1);
-        const uint32_t w24 = (read_pk8 << 16) | (n1 << 8) | n2;
+        const uint32_t w24 = read_pk8 | (n1 << 8) | (n2 << 16);
         uint32_t code[4]; bool have[4];
 #pragma unroll
         for (int j = 0; j < 4; j++) {
             const uint32_t x = 4u * lane + j;
             have[j] = x >= p0 && x < p0 + nq;
-            code[j] = (w24 >> (12 - 2 * j)) & 0xFFFu;
+            code[j] = (w24 >> (2 * j)) & 0xFFFu;
         }
 #pragma unroll
         for (int j = 0; j < 4; j++) if (have[j]) t8[code[j]] = (uint8_t)(4u * lane + j - p0 + 1u);
@@ -217,7 +227,7 @@ __device__ __forceinline__ void table_build(WaveLds& s, uint32_t p0, uint32_t nq
         for (int j = 0; j < 4; j++) lost[j] = have[j] && (t8[code[j]] != (uint8_t)(4u * lane + j - p0 + 1u));
         wave_lds_sync();
 #pragma unroll
-        for (int j = 0; j < 4; j++) if (lost[j]) t8[code[j]] = 0xFFu;
+        for (int j = 0; j < 4; j++) if (lost[j]) t8[code[j]] = 0u;      // repeated: nobody votes with it
         wave_lds_sync();
         return;
     }
@@ -243,7 +253,7 @@ __device__ __forceinline__ void table_build(WaveLds& s, uint32_t p0, uint32_t nq
         have[j] = q < nq;
         uint32_t c = 0;
         if (have[j])
-            for (uint32_t u = 0; u < k; u++) c = (c << 2) | code2(lds_byte(s.rd, p0 + q + u));
+            for (uint32_t u = 0; u < k; u++) c |= code2(lds_byte(s.rd, p0 + q + u)) << (2u * u);
         code[j] = c & mask;
     }
     if (DIRECT) {
@@ -255,7 +265,7 @@ __device__ __forceinline__ void table_build(WaveLds& s, uint32_t p0, uint32_t nq
         for (int j = 0; j < 4; j++) lost[j] = have[j] && (t8[code[j]] != (uint8_t)(4u * lane + j + 1u));
         wave_lds_sync();
 #pragma unroll
-        for (int j = 0; j < 4; j++) if (lost[j]) t8[code[j]] = 0xFFu;
+        for (int j = 0; j < 4; j++) if (lost[j]) t8[code[j]] = 0u;
     } else {
 #pragma unroll
         for (int j = 0; j < 4; j++) {
@@ -278,11 +288,11 @@ __device__ __forceinline__ void table_undo6(WaveLds& s, uint32_t p0, uint32_t nq
     uint8_t* t8 = reinterpret_cast<uint8_t*>(s.tbl);
     const uint32_t n1 = (uint32_t)dpp_mov<kDppWaveShl1>(0, (int)read_pk8);
     const uint32_t n2 = (uint32_t)dpp_mov<kDppWaveShl1>(0, (int)n1);
-    const uint32_t w24 = (read_pk8 << 16) | (n1 << 8) | n2;
+    const uint32_t w24 = read_pk8 | (n1 << 8) | (n2 << 16);
 #pragma unroll
     for (int j = 0; j < 4; j++) {
         const uint32_t x = 4u * lane + j;
-        if (x >= p0 && x < p0 + nq) t8[(w24 >> (12 - 2 * j)) & 0xFFFu] = 0;
+        if (x >= p0 && x < p0 + nq) t8[(w24 >> (2 * j)) & 0xFFFu] = 0;
     }
 }
 
@@ -304,7 +314,7 @@ __device__ __forceinline__ uint32_t table_lookup(const WaveLds& s, uint32_t code
 // (70-128), bin_bands (130-140), select_band (142-181).  Window = contig[w0,w1),
 // read piece = read[p0,p1), anchor in contig coordinates.
 template <int KT, bool DIRECT>
-__device__ __forceinline__ Band band_search(WaveLds& s, const uint64_t* __restrict__ pk,
+__device__ __forceinline__ Band band_search(WaveLds& s, const uint8_t* __restrict__ pk,
                             uint32_t w0, uint32_t w1, uint32_t anchor,
                             uint32_t p0, uint32_t p1, uint32_t k, uint32_t g, int lane, uint32_t read_pk8 IM_STAMP_ARG)
 {
@@ -322,22 +332,27 @@ __device__ __forceinline__ Band band_search(WaveLds& s, const uint64_t* __restri
     const int anchor_rel = (int)(anchor - w0);                    // select_band gets it as int (431,146)
     const uint32_t step = kDiagChunk - g;
 
-    // Window words of one histogram chunk: every lane takes 16 positions per sweep of 1024.
-    // All sweeps of a chunk are requested up front (kPre of them into registers) so that the
-    // chunk pays one memory round trip, and chunk 0 is requested BEFORE the read table is
-    // built so that the trip overlaps that work (two sweeps = 2048 window bases live in registers; a third is rare).
+    // The window's k-mers are read from the 2-bit packed contig (4 bases per byte, first base in the
+    // low bits).  A unit covers 512 consecutive k-mer starts; lane l takes starts l, l+64, l+128, ...
+    // of it, eight in all, each one unaligned dword load at a fixed 16-byte stride.  Interleaving
+    // matters: the read's true locus is a run of ~L consecutive hits, and with this mapping the run
+    // is spread over all lanes instead of piling up in six of them.
     int bc = 0, bd = INT_MAX, bi = 0;                             // select_band's max, dist, indx
+    const bool multi = numdiag > (uint32_t)kDiagChunk;
 
     for (uint32_t c0 = 0; c0 < numdiag; c0 += step) {
         const int p_lo = max(0, (int)c0 - (int)nq);
         const int p_hi = min((int)npos - 1, (int)(c0 + kDiagChunk) - 2);
-        const uint32_t g0 = (w0 + (uint32_t)(p_lo <= p_hi ? p_lo : 0)) & ~15u;
-        const uint32_t a_hi = w0 + (uint32_t)(p_lo <= p_hi ? p_hi : 0);
-        uint64_t whi0 = 0, wlo0 = 0, whi1 = 0, wlo1 = 0;
-        if (p_lo <= p_hi) {
-            const uint32_t A0 = g0 + 16u * lane, A1 = A0 + 1024u;
-            if (A0 <= a_hi) { whi0 = pk[A0 >> 5]; wlo0 = pk[(A0 >> 5) + 1]; }
-            if (A1 <= a_hi) { whi1 = pk[A1 >> 5]; wlo1 = pk[(A1 >> 5) + 1]; }
+        const bool any = p_lo <= p_hi;
+        const uint32_t span = any ? (uint32_t)(p_hi - p_lo) : 0u;           // starts p_lo + i, i in [0, span]
+        const uint32_t nunit = any ? span / 512u + 1u : 0u;        // units of 512 starts = 8 per lane
+        const uint32_t P0 = w0 + (uint32_t)(any ? p_lo : 0) + (uint32_t)lane;   // contig coordinate of this lane's first start
+        const uint8_t* src = pk + (P0 >> 2);
+        const uint32_t bsh = 2u * (P0 & 3u);                       // the same for all of a lane's starts: 64 starts = 16 bytes
+        uint32_t wd[8];
+        if (DIRECT && any) {
+#pragma unroll
+            for (int j = 0; j < 8; j++) wd[j] = load_u32_unaligned(src + 16 * j);
         }
         if (c0 == 0) {
             table_build<KT, DIRECT>(s, p0, nq, k, lane, read_pk8);
@@ -352,50 +367,50 @@ __device__ __forceinline__ Band band_search(WaveLds& s, const uint64_t* __restri
         IM_STAMP_B(1);
 
         // vote: window k-mer at p and read-unique k-mer at q land on diagonal p - q + nq (102-105)
-        if (p_lo <= p_hi) {
-            int it = 0;
-            for (uint32_t A = g0 + 16u * lane; A <= a_hi; A += 1024u, it++) {
-                uint64_t hi, lo;
-                if (it == 0) { hi = whi0; lo = wlo0; }
-                else if (it == 1) { hi = whi1; lo = wlo1; }
-                else { hi = pk[A >> 5]; lo = pk[(A >> 5) + 1]; }
-                const uint64_t pkd = (A & 16u) ? ((hi << 32) | (lo >> 32)) : hi;  // bases A..A+31, first base on top
-                if (DIRECT) {
-                    // all sixteen table reads first, then the (rare) hits
-                    uint32_t v[16];
-                    if constexpr (KT == 6) {
-                        const uint32_t u = (uint32_t)(pkd >> 32), l = (uint32_t)pkd;   // bases 0-15 | 16-31
+        const uint32_t obase = (uint32_t)p_lo + nq - c0 + 1u;      // off = obase + i - table value
+        for (uint32_t u = 0; u < nunit; u++) {
+            const uint32_t i0 = 512u * u + (uint32_t)lane;         // index of this lane's j = 0 start
+            if (DIRECT) {
+                // all eight table reads first, then the (rare) hits
+                uint32_t v[8];
 #pragma unroll
-                        for (int j = 0; j < 16; j++) {
-                            const uint32_t code = (j <= 10) ? ((u >> (20 - 2 * j)) & 0xFFFu)
-                                                            : (__builtin_amdgcn_alignbit(u, l, 52 - 2 * j) & 0xFFFu);
-                            v[j] = lds_byte(s.tbl, code);
-                        }
-                    } else {
+                for (int j = 0; j < 8; j++) v[j] = (wd[j] >> bsh) & (KT == 6 ? 0xFFFu : kmask);
+                if (u + 1 < nunit) {
 #pragma unroll
-                        for (int j = 0; j < 16; j++)
-                            v[j] = lds_byte(s.tbl, (uint32_t)(pkd >> (2 * (32 - j - (int)k))) & kmask);
-                    }
+                    for (int j = 0; j < 8; j++) wd[j] = load_u32_unaligned(src + 128u * (u + 1u) + 16 * j);
+                }
 #pragma unroll
-                    for (int j = 0; j < 16; j++) {
-                        const int p = (int)(A + j - w0);
-                        if (v[j] - 1u >= 0xFEu || p < p_lo || p > p_hi) continue;
-                        const uint32_t off = (uint32_t)p - (v[j] - 1u) + nq - c0;    // diagonal index - c0
-                        if (off < (uint32_t)kDiagChunk)
-                            atomicAdd(&s.diag[off >> 2], 1u << ((off & 3u) * 8u));
-                    }
-                } else {
-#pragma unroll
-                    for (int j = 0; j < 16; j++) {
-                        const int p = (int)(A + j - w0);
-                        if (p < p_lo || p > p_hi) continue;
-                        const uint32_t code = (uint32_t)(pkd >> (2 * (32 - j - (int)k))) & kmask;
-                        const uint32_t v = table_lookup<DIRECT>(s, code);
-                        if (v == 0u || v == 0xFFu) continue;
-                        const uint32_t off = (uint32_t)p - (v - 1u) + nq - c0;       // diagonal index - c0
-                        if (off < (uint32_t)kDiagChunk)
-                            atomicAdd(&s.diag[off >> 2], 1u << ((off & 3u) * 8u));
-                    }
+                for (int j = 0; j < 8; j++) v[j] = lds_byte(s.tbl, v[j]);
+                // pack the table bytes four to a word, flag the non-zero bytes (bit 7 of each), merge the
+                // two flag words into one mask (bit 8*jj + h for byte jj of word h) and walk only its bits
+                const uint32_t xa = v[0] | (v[1] << 8) | (v[2] << 16) | (v[3] << 24);
+                const uint32_t xb = v[4] | (v[5] << 8) | (v[6] << 16) | (v[7] << 24);
+                const uint32_t ma = (((xa & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | xa) & 0x80808080u;
+                const uint32_t mb = (((xb & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | xb) & 0x80808080u;
+                uint32_t m = (ma >> 7) | (mb >> 6);
+                while (m) {
+                    const uint32_t bit = (uint32_t)__builtin_ctz(m);
+                    m &= m - 1u;
+                    const uint32_t h = bit & 1u, sh = bit & 24u;
+                    const uint32_t x = h ? xb : xa;
+                    const uint32_t i = i0 + (h << 8) + (sh << 3);                    // + 64 * (4h + sh / 8)
+                    if (i > span) continue;
+                    const uint32_t off = obase + i - ((x >> sh) & 255u);             // diagonal index - c0
+                    if (multi && off >= (uint32_t)kDiagChunk) continue;
+                    atomicAdd(&s.diag[off >> 2], 1u << ((off & 3u) * 8u));
+                }
+            } else {
+#pragma unroll 4
+                for (int j = 0; j < 8; j++) {
+                    const uint32_t i = i0 + 64u * j;
+                    if (i > span) continue;
+                    uint64_t dd;
+                    __builtin_memcpy(&dd, src + 128u * u + 16 * j, 8);
+                    const uint32_t v = table_lookup<DIRECT>(s, (uint32_t)(dd >> bsh) & kmask);
+                    if (v == 0u || v == 0xFFu) continue;
+                    const uint32_t off = obase + i - v;
+                    if (off < (uint32_t)kDiagChunk)
+                        atomicAdd(&s.diag[off >> 2], 1u << ((off & 3u) * 8u));
                 }
             }
         }
@@ -639,11 +654,11 @@ __device__ __forceinline__ void realign_one(WaveLds& s, const RealignArgs& A, in
     }
     const int L = (int)Lraw;
     const uint8_t* contig = A.ref.ascii + uni64(A.ref.asc_off[tid]);
-    const uint64_t* pk = A.ref.pk + uni64(A.ref.pk_off[tid]);
+    const uint8_t* pk = A.ref.pk + uni64(A.ref.pk_off[tid]);
     const int clen = uni(A.ref.len[tid]);
 
     // stage the read
-    uint32_t read_pk8 = 0;      // 2-bit codes of this lane's four bases, first base on top
+    uint32_t read_pk8 = 0;      // 2-bit codes of this lane's four bases, first base in the low bits
     {
         uint32_t v = 0;
         if (4 * lane < L) v = *reinterpret_cast<const uint32_t*>(A.batch.bases + off + 4 * lane);
@@ -651,7 +666,7 @@ __device__ __forceinline__ void realign_one(WaveLds& s, const RealignArgs& A, in
         if (rem < 4) v &= (rem <= 0) ? 0u : ((1u << (8 * rem)) - 1u);
         s.rd[lane] = v;
         if (lane < 4) s.rd[64 + lane] = 0u;
-        read_pk8 = (code2(v & 255u) << 6) | (code2((v >> 8) & 255u) << 4) | (code2((v >> 16) & 255u) << 2) | code2(v >> 24);
+        read_pk8 = code2(v & 255u) | (code2((v >> 8) & 255u) << 2) | (code2((v >> 16) & 255u) << 4) | (code2(v >> 24) << 6);
     }
     wave_lds_sync();
 
@@ -1328,7 +1343,7 @@ __global__ __launch_bounds__(64) void realign_gapped_kernel(RealignArgs A)
         }
         const int L = (int)Lraw;
         const uint8_t* contig = A.ref.ascii + uni64(A.ref.asc_off[tid]);
-        const uint64_t* pk = A.ref.pk + uni64(A.ref.pk_off[tid]);
+        const uint8_t* pk = A.ref.pk + uni64(A.ref.pk_off[tid]);
         const int clen = uni(A.ref.len[tid]);
         {
             uint32_t v = 0;
@@ -1484,11 +1499,11 @@ __global__ __launch_bounds__(256) void pack_kernel(const uint8_t* __restrict__ a
         const uint4* src = reinterpret_cast<const uint4*>(ascii + w * 32);
         const uint4 a = src[0], b = src[1];
         const uint32_t d[8] = { a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w };
-        uint64_t v = 0;
+        uint64_t v = 0;                 // base 32w + n in bits 2n, 2n+1: in memory, 4 bases per byte, first base low
 #pragma unroll
         for (int i = 0; i < 8; i++)
 #pragma unroll
-            for (int j = 0; j < 4; j++) v = (v << 2) | code2((d[i] >> (8 * j)) & 255u);
+            for (int j = 0; j < 4; j++) v |= (uint64_t)code2((d[i] >> (8 * j)) & 255u) << (2 * (4 * i + j));
         pk[w] = v;
     }
 }
@@ -1521,7 +1536,7 @@ hipError_t launch_pack_reference(const uint8_t* ascii, uint64_t* pk, int64_t n_b
 hipError_t launch_realign(const RealignArgs& a, int n_cu, hipStream_t stream)
 {
     if (a.batch.n <= 0) return hipSuccess;
-    // ~9 KiB LDS per one-wave workgroup -> up to 17 per CU; ask for 16 per CU.
+    // 6352 B of LDS per one-wave workgroup (6400 allocated) -> 25 fit a CU; <= 80 VGPRs -> 6 waves per SIMD.
     int64_t want = (int64_t)n_cu * IM_BLOCKS_PER_CU;
     int64_t need = ((int64_t)a.batch.n + 7) / 8 * 8;
     int grid = (int)(need < want ? need : want);

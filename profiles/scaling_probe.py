@@ -16,7 +16,8 @@ ctx = capi.Context(0)
 ctx.set_reference([refs[0].tobytes()])
 n_all = len(cand["index"])
 L = capi.lib()
-for n in (64, 256, 1024, 2048, 4096, 6144, 8192, 12046, 24092, 48184, 96368, 192736):
+SIZES = [int(a) for a in sys.argv[1:]] or [64, 256, 1024, 2048, 4096, 6144, 8192, 12046, 24092, 48184, 96368, 192736]
+for n in SIZES:
     reps = (n + n_all - 1) // n_all
     sub = {k: (np.concatenate([v] * reps)[:n] if isinstance(v, np.ndarray) and v.shape[:1] == (n_all,) else v) for k, v in cand.items()}
     sh = bench.Shard(ctx, refs[0], sub, 100)
