@@ -368,14 +368,16 @@ __global__ __launch_bounds__(kSmallThreads) void cluster_small_kernel(
 //
 // Split-read clusters are exact-key groups, so sorting every evidence record is more
 // than the problem needs: hash the records into a breakpoint histogram (one table
-// entry per distinct (b1,b2,class) with its support count), sort only the DISTINCT
+// entry per distinct (b1,b2,class) with its support count), order only the DISTINCT
 // breakpoints (typically 10x fewer than records), then drop every record into its
-// cluster's slice and order each slice by arrival.  Four launches, all but the
-// distinct-key sort many-workgroup; the table cleans itself for the next call.
+// cluster's slice and order each slice by arrival.  Four launches, every one of them
+// many-workgroup; the table cleans itself for the next call.
 //
-//   hist_insert   live slot -> table entry (64-bit CAS), support count, list of new entries
-//   hist_sort     one workgroup: bitonic sort of the distinct keys, marker cut, offsets
-//   hist_place    record -> order[first[cluster] + cursor++]
+//   hist_insert   live slot -> table entry (64-bit CAS), support count, dense list of new keys
+//   hist_rank     distinct key -> its position in key order, by counting the smaller keys
+//                 (keys staged in LDS, broadcast reads): no barrier-per-stage sort network
+//   hist_place    every workgroup redoes the small prologue (marker cut + exclusive scan of the
+//                 supports in key order, in LDS), then record -> order[first[cluster] + cursor++]
 //   hist_finish   one wave per cluster: order the slice by slot (= arrival), reset the entry
 //
 // Limits (else counts[0] = -1 and the caller takes the radix path): kHistMaxKeys distinct
@@ -391,9 +393,12 @@ struct HistScratch {
     uint32_t* rank;         // [H] cluster id of a table entry, ~0 = behind the marker cut
     uint32_t* slot_h;       // [n_slots]
     uint32_t* uniq;         // [kHistMaxKeys] table positions in first-touch order
+    uint64_t* ukey;         // [kHistMaxKeys] their keys, same order
     uint32_t* sorted_h;     // [kHistMaxKeys] table positions in key order
-    uint32_t* cursor;       // [kHistMaxKeys]
-    uint32_t* misc;         // [0] distinct keys, [1] live records, [2] overflow, [3] clusters after the cut
+    uint64_t* skey;         // [kHistMaxKeys] keys in key order
+    uint32_t* scnt;         // [kHistMaxKeys] supports in key order
+    uint32_t* cursor;       // [kHistMaxKeys] zero between calls
+    uint32_t* misc;         // [0] distinct keys, [2] overflow, [3] clusters after the cut
     uint32_t  H;
 };
 
@@ -424,109 +429,115 @@ __global__ __launch_bounds__(256) void hist_insert_kernel(int32_t n_slots, const
             const uint64_t old = atomicCAS(reinterpret_cast<unsigned long long*>(&s.keys[h]), kEmptyKey, key);
             if (old == kEmptyKey) {
                 const uint32_t u = atomicAdd(&s.misc[0], 1u);
-                if (u < (uint32_t)kHistMaxKeys) s.uniq[u] = h;
+                if (u < (uint32_t)kHistMaxKeys) { s.uniq[u] = h; s.ukey[u] = key; }
                 break;
             }
             if (old == key) break;
             h = (h + 1) & (s.H - 1);
         }
         atomicAdd(&s.cnt[h], 1u);
-        atomicAdd(&s.misc[1], 1u);
         s.slot_h[i] = h;
     }
 }
 
-struct HistSortLds {
-    uint64_t key[kHistMaxKeys];
-    uint32_t h[kHistMaxKeys];
-    uint32_t wsum[kSmallThreads / 64];
-    uint32_t cut;
-};
+constexpr int kRankTile = 1024;
 
-__global__ __launch_bounds__(kSmallThreads) void hist_sort_kernel(HistScratch s, int32_t marker,
-                                                                 int32_t* __restrict__ cl_first, int32_t* __restrict__ cl_count,
-                                                                 int32_t* __restrict__ out_counts)
+// position of every distinct key in ascending key order = number of smaller keys (keys are distinct)
+__global__ __launch_bounds__(256) void hist_rank_kernel(HistScratch s, int32_t* __restrict__ out_counts)
 {
-    extern __shared__ __align__(16) unsigned char smem_raw[];
-    HistSortLds& L = *reinterpret_cast<HistSortLds*>(smem_raw);
-    const int tid = threadIdx.x;
+    __shared__ uint64_t tile[kRankTile];
     const uint32_t nu = s.misc[0];
     if (nu > (uint32_t)kHistMaxKeys) {
-        if (tid == 0) { s.misc[2] = 1; s.misc[3] = 0; out_counts[0] = -1; out_counts[1] = (int32_t)s.misc[1]; }
+        if (blockIdx.x == 0 && threadIdx.x == 0) { s.misc[2] = 1; s.misc[3] = 0; out_counts[0] = -1; out_counts[1] = 0; }
         return;
     }
-    uint32_t P = 2;
-    while (P < nu) P <<= 1;
-    for (uint32_t p = tid; p < P; p += kSmallThreads) {
-        if (p < nu) { const uint32_t h = s.uniq[p]; L.h[p] = h; L.key[p] = s.keys[h]; }
-        else { L.h[p] = 0xFFFFFFFFu; L.key[p] = kEmptyKey; }
-    }
-    __syncthreads();
-    for (uint32_t k = 2; k <= P; k <<= 1) {
-        for (uint32_t j = k >> 1; j > 0; j >>= 1) {
-            for (uint32_t t = tid; t < (P >> 1); t += kSmallThreads) {
-                const uint32_t lo = ((t & ~(j - 1)) << 1) | (t & (j - 1));
-                const uint32_t hi = lo | j;
-                const bool asc = (lo & k) == 0;
-                const uint64_t a = L.key[lo], c = L.key[hi];
-                if ((c < a) == asc) {
-                    const uint32_t ha = L.h[lo], hc = L.h[hi];
-                    L.key[lo] = c; L.key[hi] = a; L.h[lo] = hc; L.h[hi] = ha;
-                }
-            }
-            __syncthreads();
+    if (blockIdx.x * 256u >= nu) return;
+    const uint32_t p = blockIdx.x * 256u + threadIdx.x;
+    const uint64_t key = (p < nu) ? s.ukey[p] : kEmptyKey;
+    uint32_t r = 0;
+    for (uint32_t t0 = 0; t0 < nu; t0 += kRankTile) {
+        const uint32_t tn = min((uint32_t)kRankTile, nu - t0);
+        for (uint32_t q = threadIdx.x; q < (uint32_t)kRankTile; q += 256) tile[q] = (q < tn) ? s.ukey[t0 + q] : kEmptyKey;
+        __syncthreads();
+        const uint32_t tn4 = (tn + 3u) & ~3u;                  // the pad compares as "not smaller"
+        for (uint32_t q = 0; q < tn4; q += 4) {
+            r += (tile[q] < key) ? 1u : 0u;
+            r += (tile[q + 1] < key) ? 1u : 0u;
+            r += (tile[q + 2] < key) ? 1u : 0u;
+            r += (tile[q + 3] < key) ? 1u : 0u;
         }
+        __syncthreads();
     }
-    // marker cut: clusters exist only for the sorted prefix before the first b2 >= marker
-    if (tid == 0) L.cut = nu;
-    __syncthreads();
-    {
-        uint32_t best = 0xFFFFFFFFu;
-        for (uint32_t p = tid; p < nu; p += kSmallThreads) if (hist_key_b2(L.key[p]) >= marker) { best = p; break; }
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) best = min(best, (uint32_t)__shfl_xor((int)best, o));
-        if ((tid & 63) == 0 && best != 0xFFFFFFFFu) atomicMin(&L.cut, best);
+    if (p < nu) {
+        const uint32_t h = s.uniq[p];
+        s.sorted_h[r] = h; s.skey[r] = key; s.scnt[r] = s.cnt[h]; s.rank[h] = r;
     }
-    __syncthreads();
-    const uint32_t m = L.cut;
-    // offsets: exclusive scan of the supports in key order (8 consecutive keys per thread)
-    constexpr int kPer = kHistMaxKeys / kSmallThreads;
-    uint32_t c[kPer], tot = 0, big = 0;
-#pragma unroll
-    for (int e = 0; e < kPer; e++) {
-        const uint32_t p = (uint32_t)tid * kPer + e;
-        c[e] = (p < m) ? s.cnt[L.h[p]] : 0u;
-        tot += c[e];
-        big |= (c[e] > (uint32_t)kHistMaxSupport) ? 1u : 0u;
-    }
-    uint32_t total;
-    uint32_t off = block_scan_excl(tot, L.wsum, &total);
-    (void)total;
-#pragma unroll
-    for (int e = 0; e < kPer; e++) {
-        const uint32_t p = (uint32_t)tid * kPer + e;
-        if (p < nu) {
-            const uint32_t h = L.h[p];
-            s.sorted_h[p] = h;
-            if (p < m) { cl_first[p] = (int32_t)off; cl_count[p] = (int32_t)c[e]; s.rank[h] = p; s.cursor[p] = 0; off += c[e]; }
-            else s.rank[h] = 0xFFFFFFFFu;
-        }
-    }
-    if (__syncthreads_or((int)big) && tid == 0) s.misc[2] = 1;
-    if (tid == 0) { s.misc[3] = m; out_counts[0] = (int32_t)m; out_counts[1] = (int32_t)s.misc[1]; }
 }
 
-__global__ __launch_bounds__(256) void hist_place_kernel(int32_t n_slots, HistScratch s, const int32_t* __restrict__ cl_first,
-                                                        int32_t* __restrict__ order, uint8_t* __restrict__ used)
+struct HistPlaceLds {
+    uint32_t first[kHistMaxKeys];
+    uint32_t wsum[4];
+    uint32_t cut;
+    uint32_t big;
+};
+
+__global__ __launch_bounds__(256) void hist_place_kernel(int32_t n_slots, HistScratch s, int32_t marker,
+                                                        int32_t* __restrict__ cl_first, int32_t* __restrict__ cl_count,
+                                                        int32_t* __restrict__ order, uint8_t* __restrict__ used,
+                                                        int32_t* __restrict__ out_counts)
 {
-    if (s.misc[0] > (uint32_t)kHistMaxKeys) return;
+    __shared__ HistPlaceLds L;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const uint32_t nu = s.misc[0];
+    if (nu > (uint32_t)kHistMaxKeys) return;
+    // marker cut: clusters exist only for the sorted prefix before the first b2 >= marker
+    if (tid == 0) { L.cut = nu; L.big = 0; }
+    __syncthreads();
+    for (uint32_t p = tid; p < nu; p += 256)
+        if (hist_key_b2(s.skey[p]) >= marker) { atomicMin(&L.cut, p); break; }
+    __syncthreads();
+    const uint32_t m = L.cut;
+    // exclusive scan of the supports in key order: thread t owns keys [t*per, (t+1)*per)
+    const uint32_t per = (nu + 255u) / 256u;
+    const uint32_t lo = (uint32_t)tid * per, hi = min(lo + per, nu);
+    uint32_t tot = 0, live = 0, big = 0;
+    for (uint32_t p = lo; p < hi; p++) {
+        const uint32_t c = s.scnt[p];
+        live += c;
+        if (p < m) { tot += c; big |= (c > (uint32_t)kHistMaxSupport) ? 1u : 0u; }
+    }
+    uint32_t x = tot;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { const uint32_t t = __shfl_up(x, o); if (lane >= o) x += t; }
+    if (lane == 63) L.wsum[wave] = x;
+    if (big) L.big = 1;
+    __syncthreads();
+    uint32_t off = x - tot;
+    for (int w = 0; w < wave; w++) off += L.wsum[w];
+    for (uint32_t p = lo; p < hi && p < m; p++) { L.first[p] = off; off += s.scnt[p]; }
+    __syncthreads();
+    if (blockIdx.x == 0) {
+        for (uint32_t p = tid; p < m; p += 256) { cl_first[p] = (int32_t)L.first[p]; cl_count[p] = (int32_t)s.scnt[p]; }
+        // total of live records, for the caller's bookkeeping
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) live += __shfl_xor(live, o);
+        __syncthreads();
+        if (lane == 0) L.wsum[wave] = live;
+        __syncthreads();
+        if (tid == 0) {
+            s.misc[3] = m;
+            if (L.big) s.misc[2] = 1;
+            out_counts[0] = (int32_t)m;
+            out_counts[1] = (int32_t)(L.wsum[0] + L.wsum[1] + L.wsum[2] + L.wsum[3]);
+        }
+    }
     for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n_slots; i += (int64_t)gridDim.x * blockDim.x) {
         const uint32_t h = s.slot_h[i];
         if (h == 0xFFFFFFFFu) continue;
         const uint32_t c = s.rank[h];
-        if (c == 0xFFFFFFFFu) continue;
+        if (c >= m) continue;
         const uint32_t p = atomicAdd(&s.cursor[c], 1u);
-        order[cl_first[c] + (int32_t)p] = (int32_t)i;
+        order[L.first[c] + p] = (int32_t)i;
         if (used) used[i] = 1;
     }
 }
@@ -563,7 +574,7 @@ __global__ __launch_bounds__(256) void hist_finish_kernel(HistScratch s, const i
                 __builtin_amdgcn_wave_barrier();
             }
         }
-        if (lane == 0) { s.keys[h] = kEmptyKey; s.cnt[h] = 0; }
+        if (lane == 0) { s.keys[h] = kEmptyKey; s.cnt[h] = 0; s.cursor[p] = 0; }
     }
     if (blockIdx.x == 0 && threadIdx.x == 0) {
         if (bad && !overflow_keys) out_counts[0] = -1;
@@ -586,10 +597,12 @@ inline size_t hist_carve(HistScratch* hs, void* base, int32_t n_slots)
     auto take = [&](size_t bytes) { size_t o = off; off = align_up(off + bytes, 256); return o; };
     const size_t oK = take((size_t)H * 8), oC = take((size_t)H * 4), oR = take((size_t)H * 4), oS = take(nn * 4);
     const size_t oU = take((size_t)kHistMaxKeys * 4), oSh = take((size_t)kHistMaxKeys * 4), oCu = take((size_t)kHistMaxKeys * 4), oM = take(64);
+    const size_t oUk = take((size_t)kHistMaxKeys * 8), oSk = take((size_t)kHistMaxKeys * 8), oSc = take((size_t)kHistMaxKeys * 4);
     if (hs) {
         char* b = static_cast<char*>(base);
         hs->keys = (uint64_t*)(b + oK); hs->cnt = (uint32_t*)(b + oC); hs->rank = (uint32_t*)(b + oR); hs->slot_h = (uint32_t*)(b + oS);
         hs->uniq = (uint32_t*)(b + oU); hs->sorted_h = (uint32_t*)(b + oSh); hs->cursor = (uint32_t*)(b + oCu); hs->misc = (uint32_t*)(b + oM);
+        hs->ukey = (uint64_t*)(b + oUk); hs->skey = (uint64_t*)(b + oSk); hs->scnt = (uint32_t*)(b + oSc);
         hs->H = H;
     }
     return off;
@@ -731,6 +744,7 @@ hipError_t launch_cluster_hist_init(int32_t n_slots, void* scratch, size_t scrat
     hipError_t e = hipMemsetAsync(hs.keys, 0xFF, (size_t)hs.H * 8, stream);
     if (e == hipSuccess) e = hipMemsetAsync(hs.cnt, 0, (size_t)hs.H * 4, stream);
     if (e == hipSuccess) e = hipMemsetAsync(hs.misc, 0, 64, stream);
+    if (e == hipSuccess) e = hipMemsetAsync(hs.cursor, 0, (size_t)kHistMaxKeys * 4, stream);
     return e;
 }
 
@@ -740,19 +754,12 @@ hipError_t launch_cluster_hist(int32_t n_slots, const int32_t* cls, const int32_
                                uint8_t* used, int32_t* out_counts,
                                void* scratch, size_t scratch_bytes, hipStream_t stream)
 {
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(hist_sort_kernel),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(HistSortLds));
-        if (e != hipSuccess) return e;
-        attr_set = true;
-    }
     HistScratch hs;
     if (hist_carve(&hs, scratch, n_slots) > scratch_bytes) return hipErrorInvalidValue;
     const int g = grid_for(n_slots, 256);
     hipLaunchKernelGGL(hist_insert_kernel, dim3(g), dim3(256), 0, stream, n_slots, cls, b1, b2, hs, used);
-    hipLaunchKernelGGL(hist_sort_kernel, dim3(1), dim3(kSmallThreads), sizeof(HistSortLds), stream, hs, marker, cl_first, cl_count, out_counts);
-    hipLaunchKernelGGL(hist_place_kernel, dim3(g), dim3(256), 0, stream, n_slots, hs, cl_first, order, used);
+    hipLaunchKernelGGL(hist_rank_kernel, dim3(kHistMaxKeys / 256), dim3(256), 0, stream, hs, out_counts);
+    hipLaunchKernelGGL(hist_place_kernel, dim3(g), dim3(256), 0, stream, n_slots, hs, marker, cl_first, cl_count, order, used, out_counts);
     hipLaunchKernelGGL(hist_finish_kernel, dim3(512), dim3(256), 0, stream, hs, cl_first, cl_count, tie_desc, order, out_counts);
     return hipGetLastError();
 }
