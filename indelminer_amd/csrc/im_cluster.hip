@@ -374,10 +374,10 @@ __global__ __launch_bounds__(kSmallThreads) void cluster_small_kernel(
 // many-workgroup; the table cleans itself for the next call.
 //
 //   hist_insert   live slot -> table entry (64-bit CAS), support count, dense list of new keys
-//   hist_rank     distinct key -> its position in key order, by counting the smaller keys
-//                 (keys staged in LDS, broadcast reads): no barrier-per-stage sort network
-//   hist_place    every workgroup redoes the small prologue (marker cut + exclusive scan of the
-//                 supports in key order, in LDS), then record -> order[first[cluster] + cursor++]
+//   hist_rank     distinct key -> its position in key order and the start of its slice, by
+//                 counting the smaller keys and their supports (keys staged in LDS, broadcast
+//                 reads); the marker cut is a key comparison.  No sort network, no scan.
+//   hist_place    record -> order[first[entry] + cursor[cluster]++]
 //   hist_finish   one wave per cluster: order the slice by slot (= arrival), reset the entry
 //
 // Limits (else counts[0] = -1 and the caller takes the radix path): kHistMaxKeys distinct
@@ -391,12 +391,11 @@ struct HistScratch {
     uint64_t* keys;         // [H]
     uint32_t* cnt;          // [H]
     uint32_t* rank;         // [H] cluster id of a table entry, ~0 = behind the marker cut
+    uint32_t* first_h;      // [H] where the entry's slice of order[] starts
     uint32_t* slot_h;       // [n_slots]
     uint32_t* uniq;         // [kHistMaxKeys] table positions in first-touch order
     uint64_t* ukey;         // [kHistMaxKeys] their keys, same order
     uint32_t* sorted_h;     // [kHistMaxKeys] table positions in key order
-    uint64_t* skey;         // [kHistMaxKeys] keys in key order
-    uint32_t* scnt;         // [kHistMaxKeys] supports in key order
     uint32_t* cursor;       // [kHistMaxKeys] zero between calls
     uint32_t* misc;         // [0] distinct keys, [2] overflow, [3] clusters after the cut
     uint32_t  H;
@@ -421,9 +420,9 @@ __global__ __launch_bounds__(256) void hist_insert_kernel(int32_t n_slots, const
 {
     for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n_slots; i += (int64_t)gridDim.x * blockDim.x) {
         if (used) used[i] = 0;
-        const int32_t c = cls[i];
+        const int32_t c = cls[i], vb1 = b1[i], vb2 = b2[i];        // one round trip, live or not
         if (c < 0) { s.slot_h[i] = 0xFFFFFFFFu; continue; }
-        const uint64_t key = hist_key(c, b1[i], b2[i]);
+        const uint64_t key = hist_key(c, vb1, vb2);
         uint32_t h = hist_hash(key) & (s.H - 1);
         for (;;) {
             const uint64_t old = atomicCAS(reinterpret_cast<unsigned long long*>(&s.keys[h]), kEmptyKey, key);
@@ -441,103 +440,103 @@ __global__ __launch_bounds__(256) void hist_insert_kernel(int32_t n_slots, const
 }
 
 constexpr int kRankTile = 1024;
+constexpr int kRankThreads = 1024;      // one staged key per thread; 16 waves share the tile scan
 
-// position of every distinct key in ascending key order = number of smaller keys (keys are distinct)
-__global__ __launch_bounds__(256) void hist_rank_kernel(HistScratch s, int32_t* __restrict__ out_counts)
+struct HistRankLds {
+    uint64_t key[kRankTile];
+    uint32_t cnt[kRankTile];
+    uint32_t part_r[kRankThreads / 64][64], part_f[kRankThreads / 64][64];
+    unsigned long long kcut;            // smallest key whose b2 is at or past the marker
+    uint32_t live;
+};
+
+// One workgroup per 64 distinct keys (lane <-> key); its sixteen waves each take a sixteenth of every
+// staged tile of all the distinct keys and count, for their lane's key K, the keys smaller than K
+// (= K's position in key order, keys are distinct) and the records those keys hold (= where K's
+// slice of order[] starts).  The marker cut (clusters exist only before the first key, in key
+// order, whose b2 >= marker) is "K < kcut".  No sort and no scan is ever materialised.
+__global__ __launch_bounds__(kRankThreads) void hist_rank_kernel(HistScratch s, int32_t marker,
+                                                                int32_t* __restrict__ cl_first, int32_t* __restrict__ cl_count,
+                                                                int32_t* __restrict__ out_counts)
 {
-    __shared__ uint64_t tile[kRankTile];
+    __shared__ HistRankLds L;
+    constexpr int kWaves = kRankThreads / 64, kSlice = kRankTile / kWaves;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const uint32_t nu = s.misc[0];
     if (nu > (uint32_t)kHistMaxKeys) {
-        if (blockIdx.x == 0 && threadIdx.x == 0) { s.misc[2] = 1; s.misc[3] = 0; out_counts[0] = -1; out_counts[1] = 0; }
+        if (blockIdx.x == 0 && tid == 0) { s.misc[2] = 1; s.misc[3] = 0; out_counts[0] = -1; out_counts[1] = 0; }
         return;
     }
-    if (blockIdx.x * 256u >= nu) return;
-    const uint32_t p = blockIdx.x * 256u + threadIdx.x;
+    if (blockIdx.x * 64u >= nu && blockIdx.x != 0) return;
+    const uint32_t p = blockIdx.x * 64u + (uint32_t)lane;
+    // this lane's key (every wave holds the same 64), and for wave 0 its table entry and support
     const uint64_t key = (p < nu) ? s.ukey[p] : kEmptyKey;
-    uint32_t r = 0;
+    const uint32_t my_h = (wave == 0 && p < nu) ? s.uniq[p] : 0u;
+    if (tid == 0) { L.kcut = kEmptyKey; L.live = 0; }
+    __syncthreads();
+    uint32_t r = 0, f = 0, live = 0;
+    uint64_t kc = kEmptyKey;
     for (uint32_t t0 = 0; t0 < nu; t0 += kRankTile) {
         const uint32_t tn = min((uint32_t)kRankTile, nu - t0);
-        for (uint32_t q = threadIdx.x; q < (uint32_t)kRankTile; q += 256) tile[q] = (q < tn) ? s.ukey[t0 + q] : kEmptyKey;
+        {   // stage the tile, one element per thread (uniq -> cnt is a dependent pair of loads)
+            const uint32_t q = (uint32_t)tid;
+            const uint64_t k = (q < tn) ? s.ukey[t0 + q] : kEmptyKey;
+            const uint32_t c = (q < tn) ? s.cnt[s.uniq[t0 + q]] : 0u;
+            live += c;
+            if (k != kEmptyKey && hist_key_b2(k) >= marker && k < kc) kc = k;
+            L.key[q] = k; L.cnt[q] = c;                         // the pad compares as "not smaller"
+        }
         __syncthreads();
-        const uint32_t tn4 = (tn + 3u) & ~3u;                  // the pad compares as "not smaller"
-        for (uint32_t q = 0; q < tn4; q += 4) {
-            r += (tile[q] < key) ? 1u : 0u;
-            r += (tile[q + 1] < key) ? 1u : 0u;
-            r += (tile[q + 2] < key) ? 1u : 0u;
-            r += (tile[q + 3] < key) ? 1u : 0u;
+        const uint32_t q0 = (uint32_t)wave * kSlice;
+        const uint32_t q1 = min(q0 + kSlice, (tn + 7u) & ~7u);
+        for (uint32_t q = q0; q < q1; q += 8) {
+            // all sixteen (broadcast) LDS reads first, then the arithmetic: no load behind a compare
+            uint64_t kk[8]; uint32_t cc[8];
+#pragma unroll
+            for (int e = 0; e < 8; e++) { kk[e] = L.key[q + e]; cc[e] = L.cnt[q + e]; }
+#pragma unroll
+            for (int e = 0; e < 8; e++) {
+                const bool lt = kk[e] < key;
+                r += lt ? 1u : 0u;
+                f += lt ? cc[e] : 0u;
+            }
         }
         __syncthreads();
     }
-    if (p < nu) {
-        const uint32_t h = s.uniq[p];
-        s.sorted_h[r] = h; s.skey[r] = key; s.scnt[r] = s.cnt[h]; s.rank[h] = r;
+    L.part_r[wave][lane] = r; L.part_f[wave][lane] = f;
+    if (kc != kEmptyKey) atomicMin(&L.kcut, (unsigned long long)kc);
+    if (blockIdx.x == 0 && live) atomicAdd(&L.live, live);
+    __syncthreads();
+    const uint64_t kcut = L.kcut;
+    if (wave == 0 && p < nu) {
+        r = 0; f = 0;
+#pragma unroll
+        for (int w = 0; w < kWaves; w++) { r += L.part_r[w][lane]; f += L.part_f[w][lane]; }
+        const uint32_t c = s.cnt[my_h];
+        const bool valid = key < kcut;
+        s.sorted_h[r] = my_h;
+        s.rank[my_h] = valid ? r : 0xFFFFFFFFu;
+        s.first_h[my_h] = f;
+        if (valid) { cl_first[r] = (int32_t)f; cl_count[r] = (int32_t)c; if (c > (uint32_t)kHistMaxSupport) s.misc[2] = 1; }
+        if (key == kcut) { s.misc[3] = r; out_counts[0] = (int32_t)r; }
+    }
+    if (blockIdx.x == 0 && tid == 0) {
+        if (kcut == kEmptyKey) { s.misc[3] = nu; out_counts[0] = (int32_t)nu; }
+        out_counts[1] = (int32_t)L.live;
     }
 }
 
-struct HistPlaceLds {
-    uint32_t first[kHistMaxKeys];
-    uint32_t wsum[4];
-    uint32_t cut;
-    uint32_t big;
-};
-
-__global__ __launch_bounds__(256) void hist_place_kernel(int32_t n_slots, HistScratch s, int32_t marker,
-                                                        int32_t* __restrict__ cl_first, int32_t* __restrict__ cl_count,
-                                                        int32_t* __restrict__ order, uint8_t* __restrict__ used,
-                                                        int32_t* __restrict__ out_counts)
+__global__ __launch_bounds__(256) void hist_place_kernel(int32_t n_slots, HistScratch s,
+                                                        int32_t* __restrict__ order, uint8_t* __restrict__ used)
 {
-    __shared__ HistPlaceLds L;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const uint32_t nu = s.misc[0];
-    if (nu > (uint32_t)kHistMaxKeys) return;
-    // marker cut: clusters exist only for the sorted prefix before the first b2 >= marker
-    if (tid == 0) { L.cut = nu; L.big = 0; }
-    __syncthreads();
-    for (uint32_t p = tid; p < nu; p += 256)
-        if (hist_key_b2(s.skey[p]) >= marker) { atomicMin(&L.cut, p); break; }
-    __syncthreads();
-    const uint32_t m = L.cut;
-    // exclusive scan of the supports in key order: thread t owns keys [t*per, (t+1)*per)
-    const uint32_t per = (nu + 255u) / 256u;
-    const uint32_t lo = (uint32_t)tid * per, hi = min(lo + per, nu);
-    uint32_t tot = 0, live = 0, big = 0;
-    for (uint32_t p = lo; p < hi; p++) {
-        const uint32_t c = s.scnt[p];
-        live += c;
-        if (p < m) { tot += c; big |= (c > (uint32_t)kHistMaxSupport) ? 1u : 0u; }
-    }
-    uint32_t x = tot;
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) { const uint32_t t = __shfl_up(x, o); if (lane >= o) x += t; }
-    if (lane == 63) L.wsum[wave] = x;
-    if (big) L.big = 1;
-    __syncthreads();
-    uint32_t off = x - tot;
-    for (int w = 0; w < wave; w++) off += L.wsum[w];
-    for (uint32_t p = lo; p < hi && p < m; p++) { L.first[p] = off; off += s.scnt[p]; }
-    __syncthreads();
-    if (blockIdx.x == 0) {
-        for (uint32_t p = tid; p < m; p += 256) { cl_first[p] = (int32_t)L.first[p]; cl_count[p] = (int32_t)s.scnt[p]; }
-        // total of live records, for the caller's bookkeeping
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) live += __shfl_xor(live, o);
-        __syncthreads();
-        if (lane == 0) L.wsum[wave] = live;
-        __syncthreads();
-        if (tid == 0) {
-            s.misc[3] = m;
-            if (L.big) s.misc[2] = 1;
-            out_counts[0] = (int32_t)m;
-            out_counts[1] = (int32_t)(L.wsum[0] + L.wsum[1] + L.wsum[2] + L.wsum[3]);
-        }
-    }
+    if (s.misc[0] > (uint32_t)kHistMaxKeys) return;
     for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n_slots; i += (int64_t)gridDim.x * blockDim.x) {
         const uint32_t h = s.slot_h[i];
         if (h == 0xFFFFFFFFu) continue;
         const uint32_t c = s.rank[h];
-        if (c >= m) continue;
+        if (c == 0xFFFFFFFFu) continue;
         const uint32_t p = atomicAdd(&s.cursor[c], 1u);
-        order[L.first[c] + p] = (int32_t)i;
+        order[s.first_h[h] + p] = (int32_t)i;
         if (used) used[i] = 1;
     }
 }
@@ -597,12 +596,12 @@ inline size_t hist_carve(HistScratch* hs, void* base, int32_t n_slots)
     auto take = [&](size_t bytes) { size_t o = off; off = align_up(off + bytes, 256); return o; };
     const size_t oK = take((size_t)H * 8), oC = take((size_t)H * 4), oR = take((size_t)H * 4), oS = take(nn * 4);
     const size_t oU = take((size_t)kHistMaxKeys * 4), oSh = take((size_t)kHistMaxKeys * 4), oCu = take((size_t)kHistMaxKeys * 4), oM = take(64);
-    const size_t oUk = take((size_t)kHistMaxKeys * 8), oSk = take((size_t)kHistMaxKeys * 8), oSc = take((size_t)kHistMaxKeys * 4);
+    const size_t oUk = take((size_t)kHistMaxKeys * 8), oFh = take((size_t)H * 4);
     if (hs) {
         char* b = static_cast<char*>(base);
         hs->keys = (uint64_t*)(b + oK); hs->cnt = (uint32_t*)(b + oC); hs->rank = (uint32_t*)(b + oR); hs->slot_h = (uint32_t*)(b + oS);
         hs->uniq = (uint32_t*)(b + oU); hs->sorted_h = (uint32_t*)(b + oSh); hs->cursor = (uint32_t*)(b + oCu); hs->misc = (uint32_t*)(b + oM);
-        hs->ukey = (uint64_t*)(b + oUk); hs->skey = (uint64_t*)(b + oSk); hs->scnt = (uint32_t*)(b + oSc);
+        hs->ukey = (uint64_t*)(b + oUk); hs->first_h = (uint32_t*)(b + oFh);
         hs->H = H;
     }
     return off;
@@ -758,8 +757,8 @@ hipError_t launch_cluster_hist(int32_t n_slots, const int32_t* cls, const int32_
     if (hist_carve(&hs, scratch, n_slots) > scratch_bytes) return hipErrorInvalidValue;
     const int g = grid_for(n_slots, 256);
     hipLaunchKernelGGL(hist_insert_kernel, dim3(g), dim3(256), 0, stream, n_slots, cls, b1, b2, hs, used);
-    hipLaunchKernelGGL(hist_rank_kernel, dim3(kHistMaxKeys / 256), dim3(256), 0, stream, hs, out_counts);
-    hipLaunchKernelGGL(hist_place_kernel, dim3(g), dim3(256), 0, stream, n_slots, hs, marker, cl_first, cl_count, order, used, out_counts);
+    hipLaunchKernelGGL(hist_rank_kernel, dim3(kHistMaxKeys / 64), dim3(kRankThreads), 0, stream, hs, marker, cl_first, cl_count, out_counts);
+    hipLaunchKernelGGL(hist_place_kernel, dim3(g), dim3(256), 0, stream, n_slots, hs, order, used);
     hipLaunchKernelGGL(hist_finish_kernel, dim3(512), dim3(256), 0, stream, hs, cl_first, cl_count, tie_desc, order, out_counts);
     return hipGetLastError();
 }
