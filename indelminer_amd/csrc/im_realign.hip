@@ -75,8 +75,11 @@ constexpr int kDirectMaxK = 6;
 constexpr int kScoreMatch = 1;              // src/localalign.c:10-13
 constexpr int kScoreMismatch = -10;
 
+constexpr int kDiagWords = kDiagChunk / 4 + 16;     // packed byte counters (+ slack for band sums)
+static_assert(kDiagWords % 4 == 0, "the histogram is cleared with 16-byte stores");
+
 struct WaveLds {
-    uint32_t diag[kDiagChunk / 4 + 16];     // packed byte counters (+ slack for band sums)
+    alignas(16) uint32_t diag[kDiagWords];
     uint32_t tbl[kTblBytes / 4];
     uint32_t rd[(256 + 16) / 4];            // read bases, read coordinates
 };
@@ -310,6 +313,48 @@ __device__ __forceinline__ uint32_t table_lookup(const WaveLds& s, uint32_t code
     return 0u;
 }
 
+// One unit of the vote (k <= 6, direct table): the 512 window starts whose packed dwords are in cur[],
+// eight per lane.  Loads the next unit's dwords into nxt[] first (cur and nxt swap roles unit by
+// unit, so nothing is copied).  Returns the largest count any of this lane's votes produced.
+template <int KT>
+__device__ __forceinline__ uint32_t vote_unit_direct(WaveLds& s, const uint32_t (&cur)[8], uint32_t (&nxt)[8],
+                                                     const uint8_t* __restrict__ src_next, bool more,
+                                                     uint32_t bsh, uint32_t kmask, uint32_t i0, uint32_t span,
+                                                     uint32_t obase, bool multi, uint32_t mx)
+{
+    // all eight table reads first, then the (rare) hits
+    uint32_t v[8];
+#pragma unroll
+    for (int j = 0; j < 8; j++) v[j] = (cur[j] >> bsh) & (KT == 6 ? 0xFFFu : kmask);
+    if (more) {
+#pragma unroll
+        for (int j = 0; j < 8; j++) nxt[j] = load_u32_unaligned(src_next + 16 * j);
+    }
+#pragma unroll
+    for (int j = 0; j < 8; j++) v[j] = lds_byte(s.tbl, v[j]);
+    // pack the table bytes four to a word (v_perm), flag the non-zero bytes (bit 7 of each), merge the
+    // two flag words into one mask (bit 8*jj + h for byte jj of word h) and walk only its bits
+    const uint32_t xa = __builtin_amdgcn_perm(__builtin_amdgcn_perm(v[3], v[2], 0x0C0C0400u), __builtin_amdgcn_perm(v[1], v[0], 0x0C0C0400u), 0x05040100u);
+    const uint32_t xb = __builtin_amdgcn_perm(__builtin_amdgcn_perm(v[7], v[6], 0x0C0C0400u), __builtin_amdgcn_perm(v[5], v[4], 0x0C0C0400u), 0x05040100u);
+    const uint32_t ma = (((xa & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | xa) & 0x80808080u;
+    const uint32_t mb = (((xb & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | xb) & 0x80808080u;
+    uint32_t m = (ma >> 7) | (mb >> 6);
+    while (m) {
+        const uint32_t bit = (uint32_t)__builtin_ctz(m);
+        m &= m - 1u;
+        const uint32_t h = bit & 1u, sh = bit & 24u;
+        const uint32_t x = h ? xb : xa;
+        const uint32_t i = i0 + (h << 8) + (sh << 3);                    // + 64 * (4h + sh / 8)
+        if (i > span) continue;
+        const uint32_t off = obase + i - ((x >> sh) & 255u);             // diagonal index - c0
+        if (multi && off >= (uint32_t)kDiagChunk) continue;
+        const uint32_t bsel = (off & 3u) * 8u;
+        const uint32_t old = atomicAdd(&s.diag[off >> 2], 1u << bsel);
+        mx = max(mx, ((old >> bsel) & 255u) + 1u);                       // this diagonal's count after the vote
+    }
+    return mx;
+}
+
 // find_best_band (src/alignment.c:393-447): read_seeds x2 (29-68), bin_diagonals
 // (70-128), bin_bands (130-140), select_band (142-181).  Window = contig[w0,w1),
 // read piece = read[p0,p1), anchor in contig coordinates.
@@ -349,7 +394,7 @@ __device__ __forceinline__ Band band_search(WaveLds& s, const uint8_t* __restric
         const uint32_t P0 = w0 + (uint32_t)(any ? p_lo : 0) + (uint32_t)lane;   // contig coordinate of this lane's first start
         const uint8_t* src = pk + (P0 >> 2);
         const uint32_t bsh = 2u * (P0 & 3u);                       // the same for all of a lane's starts: 64 starts = 16 bytes
-        uint32_t wd[8];
+        uint32_t wd[8], we[8];
         if (DIRECT && any) {
 #pragma unroll
             for (int j = 0; j < 8; j++) wd[j] = load_u32_unaligned(src + 16 * j);
@@ -358,48 +403,30 @@ __device__ __forceinline__ Band band_search(WaveLds& s, const uint8_t* __restric
             table_build<KT, DIRECT>(s, p0, nq, k, lane, read_pk8);
             IM_STAMP_B(0);
         }
-        // clear the part of the histogram this chunk can touch
+        // clear the histogram: 16 bytes per lane and store, whole array (two stores for 1984 bytes)
         {
-            const uint32_t nbytes = min(numdiag - c0, (uint32_t)kDiagChunk) + (g ? 64u : 0u);
-            for (uint32_t w = lane; 4u * w < nbytes; w += 64) s.diag[w] = 0u;
+            uint4* d4 = reinterpret_cast<uint4*>(s.diag);
+#pragma unroll
+            for (int i = 0; i < (kDiagWords / 4 + 63) / 64; i++)
+                if (64 * i + lane < kDiagWords / 4) d4[64 * i + lane] = make_uint4(0u, 0u, 0u, 0u);
         }
         wave_lds_sync();
         IM_STAMP_B(1);
 
         // vote: window k-mer at p and read-unique k-mer at q land on diagonal p - q + nq (102-105)
         const uint32_t obase = (uint32_t)p_lo + nq - c0 + 1u;      // off = obase + i - table value
-        for (uint32_t u = 0; u < nunit; u++) {
-            const uint32_t i0 = 512u * u + (uint32_t)lane;         // index of this lane's j = 0 start
-            if (DIRECT) {
-                // all eight table reads first, then the (rare) hits
-                uint32_t v[8];
-#pragma unroll
-                for (int j = 0; j < 8; j++) v[j] = (wd[j] >> bsh) & (KT == 6 ? 0xFFFu : kmask);
-                if (u + 1 < nunit) {
-#pragma unroll
-                    for (int j = 0; j < 8; j++) wd[j] = load_u32_unaligned(src + 128u * (u + 1u) + 16 * j);
-                }
-#pragma unroll
-                for (int j = 0; j < 8; j++) v[j] = lds_byte(s.tbl, v[j]);
-                // pack the table bytes four to a word, flag the non-zero bytes (bit 7 of each), merge the
-                // two flag words into one mask (bit 8*jj + h for byte jj of word h) and walk only its bits
-                const uint32_t xa = v[0] | (v[1] << 8) | (v[2] << 16) | (v[3] << 24);
-                const uint32_t xb = v[4] | (v[5] << 8) | (v[6] << 16) | (v[7] << 24);
-                const uint32_t ma = (((xa & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | xa) & 0x80808080u;
-                const uint32_t mb = (((xb & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | xb) & 0x80808080u;
-                uint32_t m = (ma >> 7) | (mb >> 6);
-                while (m) {
-                    const uint32_t bit = (uint32_t)__builtin_ctz(m);
-                    m &= m - 1u;
-                    const uint32_t h = bit & 1u, sh = bit & 24u;
-                    const uint32_t x = h ? xb : xa;
-                    const uint32_t i = i0 + (h << 8) + (sh << 3);                    // + 64 * (4h + sh / 8)
-                    if (i > span) continue;
-                    const uint32_t off = obase + i - ((x >> sh) & 255u);             // diagonal index - c0
-                    if (multi && off >= (uint32_t)kDiagChunk) continue;
-                    atomicAdd(&s.diag[off >> 2], 1u << ((off & 3u) * 8u));
-                }
-            } else {
+        uint32_t mx = 0;                                           // largest count this lane's votes produced (direct path)
+        if (DIRECT) {
+            for (uint32_t u = 0; u < nunit; u += 2) {
+                mx = vote_unit_direct<KT>(s, wd, we, src + 128u * (u + 1u), u + 1 < nunit, bsh, kmask,
+                                          512u * u + (uint32_t)lane, span, obase, multi, mx);
+                if (u + 1 < nunit)
+                    mx = vote_unit_direct<KT>(s, we, wd, src + 128u * (u + 2u), u + 2 < nunit, bsh, kmask,
+                                              512u * (u + 1u) + (uint32_t)lane, span, obase, multi, mx);
+            }
+        } else {
+            for (uint32_t u = 0; u < nunit; u++) {
+                const uint32_t i0 = 512u * u + (uint32_t)lane;     // index of this lane's j = 0 start
 #pragma unroll 4
                 for (int j = 0; j < 8; j++) {
                     const uint32_t i = i0 + 64u * j;
@@ -421,19 +448,25 @@ __device__ __forceinline__ Band band_search(WaveLds& s, const uint8_t* __restric
         const uint32_t iend = min(c0 + step, numdiag);
         const uint32_t nband = numdiag - g;                       // bands[i] == 0 for i >= nband (135)
         if (g == 0) {
-            // One diagonal per band.  Pass 1 finds the chunk's largest count M (packed 16-bit maxima
-            // of the even / odd bytes, one wave reduction); pass 2 visits only the words that hold
-            // a byte equal to M and keeps the (distance, index)-least of those diagonals.  bc is
-            // wave-uniform; bd / bi are per lane and compared against the same bc.
+            // One diagonal per band.  The chunk's largest count M comes from the votes themselves (direct
+            // path: every LDS atomic returns the count it replaced) or from a pass of packed 16-bit
+            // maxima; then only the words that hold a byte equal to M are visited and the (distance,
+            // index)-least of those diagonals kept.  bc is wave-uniform; bd / bi are per lane and
+            // compared against the same bc.
             const uint32_t nb = iend - c0;
-            uint32_t me = 0, mo = 0;
-            for (uint32_t dw = lane; 4u * dw < nb; dw += 64) {
-                const uint32_t v = s.diag[dw];
-                me = pk_max_u16(me, v & 0x00FF00FFu);
-                mo = pk_max_u16(mo, (v >> 8) & 0x00FF00FFu);
+            int M;
+            if (DIRECT) {
+                M = wave_max((int)mx);                             // the votes reported their counts as they landed
+            } else {
+                uint32_t me = 0, mo = 0;
+                for (uint32_t dw = lane; 4u * dw < nb; dw += 64) {
+                    const uint32_t v = s.diag[dw];
+                    me = pk_max_u16(me, v & 0x00FF00FFu);
+                    mo = pk_max_u16(mo, (v >> 8) & 0x00FF00FFu);
+                }
+                const uint32_t m2 = pk_max_u16(me, mo);
+                M = wave_max((int)max(m2 & 0xFFFFu, m2 >> 16));
             }
-            const uint32_t m2 = pk_max_u16(me, mo);
-            const int M = wave_max((int)max(m2 & 0xFFFFu, m2 >> 16));
             if (M > 0 && M >= bc) {
                 if (M > bc) { bc = M; bd = INT_MAX; bi = 0; }
                 const uint32_t rep = (uint32_t)M * 0x01010101u;
@@ -506,6 +539,7 @@ struct Aln {
 //   forward : c_t = max(0, c_{t-1} + w_t); end = first t where c_t is the strict maximum
 //   reverse : start = largest s <= end with sum_{s..end} w == best
 // Match flags of the aligned positions come back in Aln::eqbits, in read coordinates.
+template <bool WANT_RUNS>            // the leading / trailing '=' runs are only used of the first piece
 __device__ __forceinline__ Aln diag_scan(WaveLds& s, const uint8_t* __restrict__ contig,
                          uint32_t w0, uint32_t w1, uint32_t p0, uint32_t p1, int d, int lane)
 {
@@ -575,9 +609,11 @@ __device__ __forceinline__ Aln diag_scan(WaveLds& s, const uint8_t* __restrict__
             else { fm = min(fm, t); lm = max(lm, t); }
         }
     }
-    fm = wave_min(fm); lm = wave_max(lm);
-    a.f = (fm == INT_MAX ? end + 1 : fm) - start;
-    a.l = end - (lm < 0 ? start - 1 : lm);
+    if (WANT_RUNS) {
+        fm = wave_min(fm); lm = wave_max(lm);
+        a.f = (fm == INT_MAX ? end + 1 : fm) - start;
+        a.l = end - (lm < 0 ? start - 1 : lm);
+    }
     // flags live in piece coordinates t (lane owns t0..t0+3); read position x = p0 + t belongs to
     // lane x >> 2, so lane L collects bits 4L - p0 .. 4L - p0 + 3 of the 256-bit flag string from
     // the two lanes that hold them (ds_bpermute: no LDS storage, no barrier)
@@ -684,7 +720,7 @@ __device__ __forceinline__ void realign_one(WaveLds& s, const RealignArgs& A, in
     IM_STAMP(0);
     const Band b1 = band_search<KT, DIRECT>(s, pk, (uint32_t)left1, (uint32_t)right1, (uint32_t)anchor, 0u, (uint32_t)L, k, g, lane, read_pk8 IM_STAMP_PASS(1));
     if (b1.st) { finish(out, b1.st, 1, lane); return; }
-    const Aln a1 = diag_scan(s, contig, (uint32_t)left1, (uint32_t)right1, 0u, (uint32_t)L, b1.low, lane);
+    const Aln a1 = diag_scan<true>(s, contig, (uint32_t)left1, (uint32_t)right1, 0u, (uint32_t)L, b1.low, lane);
     store_band(out, 0, b1, a1, lane);
     IM_STAMP(6);
     if (a1.st) { finish(out, a1.st, 1, lane); return; }
@@ -722,7 +758,7 @@ __device__ __forceinline__ void realign_one(WaveLds& s, const RealignArgs& A, in
     IM_STAMP(7);
     const Band b2 = band_search<KT, DIRECT>(s, pk, w0, w1, anc, p0, p1, k, g, lane, read_pk8 IM_STAMP_PASS(8));
     if (b2.st) { finish(out, b2.st, 2, lane); return; }
-    const Aln a2 = diag_scan(s, contig, w0, w1, p0, p1, b2.low, lane);
+    const Aln a2 = diag_scan<false>(s, contig, w0, w1, p0, p1, b2.low, lane);
     store_band(out, 1, b2, a2, lane);
     IM_STAMP(13);
     if (a2.st) { finish(out, a2.st, 2, lane); return; }
