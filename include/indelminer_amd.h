@@ -320,6 +320,17 @@ int  im_timer_start(im_timer* t, void* stream);
 int  im_timer_stop(im_timer* t, void* stream);
 int  im_timer_elapsed_ms(im_timer* t, float* ms);
 
+/* Launch graphs.  One flush is a fixed sequence of dependent im_dev_* launches on one stream
+ * (the reference has no counterpart: its flush, src/indelminer.c:617-640, is host code).  Between
+ * im_capture_begin and im_capture_end the im_dev_* calls on `stream` are recorded instead of run;
+ * im_graph_launch replays them with a single host call.  Device buffers and sizes are baked in:
+ * capture again when they change. */
+typedef struct im_graph im_graph;
+int  im_capture_begin(im_ctx* ctx, void* stream);
+int  im_capture_end(im_ctx* ctx, void* stream, im_graph** out);
+int  im_graph_launch(im_graph* g, void* stream);
+void im_graph_destroy(im_graph* g);
+
 #ifdef __cplusplus
 }
 #endif

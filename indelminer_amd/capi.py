@@ -140,6 +140,11 @@ def lib():
         L.im_timer_start.argtypes = [C.c_void_p, C.c_void_p]
         L.im_timer_stop.argtypes = [C.c_void_p, C.c_void_p]
         L.im_timer_elapsed_ms.argtypes = [C.c_void_p, C.POINTER(C.c_float)]
+        L.im_capture_begin.argtypes = [C.c_void_p, C.c_void_p]
+        L.im_capture_end.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(C.c_void_p)]
+        L.im_graph_launch.argtypes = [C.c_void_p, C.c_void_p]
+        L.im_graph_destroy.argtypes = [C.c_void_p]
+        L.im_graph_destroy.restype = None
         _lib = L
     return _lib
 
@@ -174,6 +179,38 @@ class DevBuf:
         if self.ptr:
             lib().im_dev_free(self.ctx.h, self.ptr)
             self.ptr = None
+
+
+class Graph:
+    """A captured sequence of im_dev_* launches: `with Graph.capture(ctx) as g: ...launches...`, then g.launch()."""
+
+    def __init__(self, ctx):
+        self.ctx = ctx
+        self.h = None
+
+    @classmethod
+    def capture(cls, ctx):
+        return cls(ctx)
+
+    def __enter__(self):
+        self.ctx._check(lib().im_capture_begin(self.ctx.h, self.ctx.stream))
+        return self
+
+    def __exit__(self, et, ev, tb):
+        p = C.c_void_p()
+        rc = lib().im_capture_end(self.ctx.h, self.ctx.stream, C.byref(p))
+        if et is None:
+            self.ctx._check(rc)
+            self.h = p.value
+        return False
+
+    def launch(self):
+        self.ctx._check(lib().im_graph_launch(self.h, self.ctx.stream))
+
+    def close(self):
+        if self.h:
+            lib().im_graph_destroy(self.h)
+            self.h = None
 
 
 class Timer:

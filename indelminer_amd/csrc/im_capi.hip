@@ -540,4 +540,42 @@ int im_timer_elapsed_ms(im_timer* t, float* ms)
     return IM_OK;
 }
 
+// ---- launch graphs -----------------------------------------------------------------
+// A flush is a fixed sequence of small dependent launches (realign, then the cluster kernels); captured
+// once into a HIP graph it is replayed with one host call and without per-launch submission gaps.
+struct im_graph { im_ctx* ctx; hipGraph_t g; hipGraphExec_t x; };
+
+int im_capture_begin(im_ctx* ctx, void* stream)
+{
+    if (!ctx) return IM_E_ARG;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, hipStreamBeginCapture((hipStream_t)stream, hipStreamCaptureModeThreadLocal));
+    return IM_OK;
+}
+int im_capture_end(im_ctx* ctx, void* stream, im_graph** out)
+{
+    if (!ctx || !out) return IM_E_ARG;
+    hipGraph_t g = nullptr;
+    HIP_TRY(ctx, hipStreamEndCapture((hipStream_t)stream, &g));
+    hipGraphExec_t x = nullptr;
+    hipError_t e = hipGraphInstantiate(&x, g, nullptr, nullptr, 0);
+    if (e != hipSuccess) { (void)hipGraphDestroy(g); set_err(ctx, "hipGraphInstantiate: %s", hipGetErrorString(e)); return IM_E_HIP; }
+    im_graph* r = new im_graph();
+    r->ctx = ctx; r->g = g; r->x = x;
+    *out = r;
+    return IM_OK;
+}
+int im_graph_launch(im_graph* g, void* stream)
+{
+    if (!g) return IM_E_ARG;
+    HIP_TRY(g->ctx, hipGraphLaunch(g->x, (hipStream_t)stream));
+    return IM_OK;
+}
+void im_graph_destroy(im_graph* g)
+{
+    if (!g) return;
+    (void)hipGraphExecDestroy(g->x); (void)hipGraphDestroy(g->g);
+    delete g;
+}
+
 }  // extern "C"

@@ -69,7 +69,8 @@ def test_cluster_slots_matches_oracle(gpu_ctx, path):
     from indelminer_amd import capi
     L = capi.lib()
     for seed, n_slots, live_frac, marker, tie in [(1, 4000, 0.5, 2**31 - 1, 0), (2, 30000, 0.25, 2**31 - 1, 1),
-                                                  (3, 9000, 0.9, 40000, 0), (4, 50, 0.5, 2**31 - 1, 0)]:
+                                                  (3, 9000, 0.9, 40000, 0), (4, 50, 0.5, 2**31 - 1, 0),
+                                                  (5, 40000, 0.5, 2**31 - 1, 0)]:
         rng = np.random.default_rng(seed)
         cls, b1, b2 = _random_evidence(seed, n_slots, 80000)
         live = rng.random(n_slots) < live_frac
@@ -97,8 +98,19 @@ def test_cluster_slots_matches_oracle(gpu_ctx, path):
                 gpu_ctx._check(L.im_dev_cluster_hist(gpu_ctx.h, n_slots, bufs["cls"].ptr, bufs["b1"].ptr, bufs["b2"].ptr, marker, tie,
                                                      d_order.ptr, d_first.ptr, d_count.ptr, d_used.ptr, d_counts.ptr,
                                                      d_hs.ptr, hb, gpu_ctx.stream))
+            # ... and once more replayed from a captured launch graph (im_capture_* / im_graph_launch)
+            with capi.Graph.capture(gpu_ctx) as g:
+                gpu_ctx._check(L.im_dev_cluster_hist(gpu_ctx.h, n_slots, bufs["cls"].ptr, bufs["b1"].ptr, bufs["b2"].ptr, marker, tie,
+                                                     d_order.ptr, d_first.ptr, d_count.ptr, d_used.ptr, d_counts.ptr,
+                                                     d_hs.ptr, hb, gpu_ctx.stream))
+            g.launch()
             gpu_ctx._check(L.im_stream_sync(gpu_ctx.h, gpu_ctx.stream))
+            g.close()
             counts = d_counts.download(np.int32, 2)
+            n_keys = len(np.unique(np.stack([cls[idx], b1[idx], b2[idx]]), axis=1).T)
+            if n_keys > 8192:           # more distinct breakpoints than the table lists: refused, caller takes the radix path
+                assert counts[0] == -1
+                continue
         assert counts[1] == len(idx) and counts[0] == o_k
         m = int(o_used.sum())
         assert np.array_equal(d_order.download(np.int32, n_slots)[:m], idx[o_order[:m]])
