@@ -31,6 +31,7 @@ sys.path.insert(0, ROOT)
 from indelminer_amd import capi, shard as shardlib, synth  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0           # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+PIPELINE_DEPTH = int(os.environ.get("IM_BENCH_DEPTH", "4"))   # sets of realign output buffers in flight
 KERNEL_EVENT_STRIDE = 4         # realign launch bracketed by HIP events on every 4th timed step
 
 
@@ -75,12 +76,18 @@ class Shard:
         self.d_tid = capi.DevBuf(ctx, 4 * n).upload(np.zeros(n, np.int32))
         self.d_anchor = capi.DevBuf(ctx, 4 * n).upload(cand["anchor"].astype(np.int32))
         self.d_range = capi.DevBuf(ctx, 4 * n).upload(cand["range_max"].astype(np.int32))
-        self.d_res = capi.DevBuf(ctx, 512 * n)
+        # PIPELINE_DEPTH sets of realign outputs: while the cluster kernels of step i read set i % depth on the
+        # cluster stream, the realign kernels of the following steps write the other sets on the context's stream.
         self.cap = n * capi.MAX_EV               # evidence slots: IM_MAX_EV per read
         cap = self.cap
-        self.d_cls = capi.DevBuf(ctx, 4 * cap)
-        self.d_b1 = capi.DevBuf(ctx, 4 * cap)
-        self.d_b2 = capi.DevBuf(ctx, 4 * cap)
+        self.sets = []
+        for _ in range(PIPELINE_DEPTH):
+            self.sets.append({"res": capi.DevBuf(ctx, 512 * n), "cls": capi.DevBuf(ctx, 4 * cap),
+                              "b1": capi.DevBuf(ctx, 4 * cap), "b2": capi.DevBuf(ctx, 4 * cap),
+                              "realigned": capi.Event(ctx), "clustered": capi.Event(ctx)})
+        self.d_res, self.d_cls, self.d_b1, self.d_b2 = (self.sets[0][k] for k in ("res", "cls", "b1", "b2"))
+        self.cluster_stream = capi.new_stream(ctx)
+        self.k = 0                               # steps issued
         self.d_order = capi.DevBuf(ctx, 4 * cap)
         self.d_first = capi.DevBuf(ctx, 4 * cap)
         self.d_count = capi.DevBuf(ctx, 4 * cap)
@@ -97,12 +104,15 @@ class Shard:
         self.d_gs = capi.DevBuf(ctx, self.gs_bytes)
         self.cs_bytes = L_.im_dev_cluster_scratch_bytes(cap)
         self.d_cs = capi.DevBuf(ctx, self.cs_bytes)
-        self.batch = capi.DevBatch(n, self.d_bases.ptr, self.d_off.ptr, self.d_len.ptr, self.d_tid.ptr,
-                                   self.d_anchor.ptr, self.d_range.ptr, self.d_res.ptr,
-                                   self.d_cls.ptr, self.d_b1.ptr, self.d_b2.ptr)
+        for st_ in self.sets:
+            st_["batch"] = capi.DevBatch(n, self.d_bases.ptr, self.d_off.ptr, self.d_len.ptr, self.d_tid.ptr,
+                                         self.d_anchor.ptr, self.d_range.ptr, st_["res"].ptr,
+                                         st_["cls"].ptr, st_["b1"].ptr, st_["b2"].ptr)
+        self.batch = self.sets[0]["batch"]
         self.hs_bytes = L_.im_dev_cluster_hist_scratch_bytes(cap)
         self.d_hs = capi.DevBuf(ctx, self.hs_bytes)
         ctx._check(L_.im_dev_cluster_hist_init(ctx.h, cap, self.d_hs.ptr, self.hs_bytes, ctx.stream))
+        ctx._check(L_.im_stream_sync(ctx.h, ctx.stream))           # the cluster stream starts after the table is ready
         self.P = capi.params()
         self.small = True                        # breakpoint-histogram cluster path; cleared if it overflows
         # multi-GPU: per-shard cluster list (16 B records) and the gathered lists of all ranks
@@ -116,36 +126,66 @@ class Shard:
         self.comm = comm
         self.d_gather = capi.DevBuf(self.ctx, 16 * self.rec_cap * comm.world)
 
-    def step(self, timer=None):
+    def _bind(self):
+        """Pre-bound foreign calls of one step per buffer set: the step loop is host-issue bound otherwise
+        (a ctypes call with a dozen arguments costs microseconds; profiles/overlap_probe.py)."""
         L_ = capi.lib()
         ctx = self.ctx
-        st = ctx.stream
+        st, sc = ctx.stream, self.cluster_stream
+        for cur in self.sets:
+            calls = []
+            if self.small:
+                calls.append((L_.im_dev_cluster_hist, (ctx.h, self.cap, cur["cls"].ptr, cur["b1"].ptr, cur["b2"].ptr,
+                                                       2**31 - 1, 0, self.d_order.ptr, self.d_first.ptr, self.d_count.ptr,
+                                                       self.d_used.ptr, self.d_counts.ptr, self.d_hs.ptr, self.hs_bytes, sc)))
+            else:
+                calls.append((L_.im_dev_gather_evidence, (ctx.h, cur["res"].ptr, self.n, self.d_dcls.ptr, self.d_db1.ptr,
+                                                          self.d_db2.ptr, self.d_src.ptr, self.cap, self.d_nout.ptr,
+                                                          self.d_gs.ptr, self.gs_bytes, sc)))
+                calls.append((L_.im_dev_cluster_sr, (ctx.h, self.cap, self.d_nout.ptr, self.d_dcls.ptr, self.d_db1.ptr, self.d_db2.ptr,
+                                                     2**31 - 1, 0, self.d_order.ptr, self.d_first.ptr, self.d_count.ptr,
+                                                     self.d_used.ptr, self.d_counts.ptr, self.d_cs.ptr, self.cs_bytes, sc)))
+            if self.comm is not None:
+                # the one collective of the path: all-gather of the per-shard cluster lists (RCCL over xGMI)
+                src = (cur["cls"], cur["b1"], cur["b2"]) if self.small else (self.d_dcls, self.d_db1, self.d_db2)
+                calls.append((L_.im_dev_cluster_records, (ctx.h, self.tid, self.d_counts.ptr, self.d_order.ptr, self.d_first.ptr,
+                                                          self.d_count.ptr, src[0].ptr, src[1].ptr, src[2].ptr,
+                                                          self.d_recs.ptr, self.rec_cap, sc)))
+            cur["realign_args"] = (ctx.h, C.byref(self.P), C.byref(cur["batch"]), st)
+            cur["cluster_calls"] = calls
+            cur["follow_args"] = (cur["realigned"].h, st, sc)
+            cur["done_args"] = (cur["clustered"].h, sc)
+        self._bound = (self.small, self.comm)
+
+    def step(self, timer=None):
+        """One pass of the hot path over the resident batch: realign on the context's stream, the cluster
+        kernels (and the all-gather) behind it on the cluster stream, so that they overlap the NEXT step's
+        realign kernel.  The host throttles on the set's previous use; the realign stream carries no wait."""
+        if getattr(self, "_bound", None) != (self.small, self.comm):
+            self._bind()
+        L_ = capi.lib()
+        cur = self.sets[self.k % PIPELINE_DEPTH]
+        if self.k >= PIPELINE_DEPTH:
+            cur["clustered"].sync()     # step k - PIPELINE_DEPTH has finished reading this set (host waits, not the GPU)
         if timer is not None:
-            timer.start(st)
-        ctx._check(L_.im_dev_realign(ctx.h, C.byref(self.P), C.byref(self.batch), st))
+            timer.start(self.ctx.stream)
+        rc = L_.im_dev_realign(*cur["realign_args"])
         if timer is not None:
-            timer.stop(st)
-        if self.small:
-            ctx._check(L_.im_dev_cluster_hist(ctx.h, self.cap, self.d_cls.ptr, self.d_b1.ptr, self.d_b2.ptr,
-                                              2**31 - 1, 0, self.d_order.ptr, self.d_first.ptr, self.d_count.ptr,
-                                              self.d_used.ptr, self.d_counts.ptr, self.d_hs.ptr, self.hs_bytes, st))
-        else:
-            ctx._check(L_.im_dev_gather_evidence(ctx.h, self.d_res.ptr, self.n, self.d_dcls.ptr, self.d_db1.ptr,
-                                                 self.d_db2.ptr, self.d_src.ptr, self.cap, self.d_nout.ptr,
-                                                 self.d_gs.ptr, self.gs_bytes, st))
-            ctx._check(L_.im_dev_cluster_sr(ctx.h, self.cap, self.d_nout.ptr, self.d_dcls.ptr, self.d_db1.ptr, self.d_db2.ptr,
-                                            2**31 - 1, 0, self.d_order.ptr, self.d_first.ptr, self.d_count.ptr,
-                                            self.d_used.ptr, self.d_counts.ptr, self.d_cs.ptr, self.cs_bytes, st))
+            timer.stop(self.ctx.stream)
+        rc = rc or L_.im_stream_follow(*cur["follow_args"])
+        for fn, args in cur["cluster_calls"]:
+            rc = rc or fn(*args)
         if self.comm is not None:
-            # the one collective of the path: all-gather of the per-shard cluster lists (RCCL over xGMI)
-            src = (self.d_cls, self.d_b1, self.d_b2) if self.small else (self.d_dcls, self.d_db1, self.d_db2)
-            ctx._check(L_.im_dev_cluster_records(ctx.h, self.tid, self.d_counts.ptr, self.d_order.ptr, self.d_first.ptr,
-                                                 self.d_count.ptr, src[0].ptr, src[1].ptr, src[2].ptr,
-                                                 self.d_recs.ptr, self.rec_cap, st))
-            self.comm.allgather(self.d_recs.ptr, self.d_gather.ptr, 16 * self.rec_cap, st)
+            self.comm.allgather(self.d_recs.ptr, self.d_gather.ptr, 16 * self.rec_cap, self.cluster_stream)
+        rc = rc or L_.im_event_record(*cur["done_args"])
+        if rc:
+            self.ctx._check(rc)
+        self.d_res = cur["res"]
+        self.k += 1
 
     def sync(self):
         self.ctx._check(capi.lib().im_stream_sync(self.ctx.h, self.ctx.stream))
+        self.ctx._check(capi.lib().im_stream_sync(self.ctx.h, self.cluster_stream))
 
     def results(self):
         return self.d_res.download(capi.RESULT_DTYPE, self.n)

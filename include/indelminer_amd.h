@@ -320,6 +320,19 @@ int  im_timer_start(im_timer* t, void* stream);
 int  im_timer_stop(im_timer* t, void* stream);
 int  im_timer_elapsed_ms(im_timer* t, float* ms);
 
+/* A second stream and stream-to-stream events, so that the cluster kernels of one flush can run while the
+ * next flush's realign kernel does (two sets of realign output buffers; the reference has no counterpart,
+ * its flushes are sequential host code, src/indelminer.c:617-640). */
+typedef struct im_event im_event;
+int  im_stream_create(im_ctx* ctx, void** out);
+int  im_stream_destroy(im_ctx* ctx, void* stream);
+int  im_event_create(im_ctx* ctx, im_event** out);
+void im_event_destroy(im_event* ev);
+int  im_event_record(im_event* ev, void* stream);
+int  im_event_sync(im_event* ev);                               /* host waits */
+int  im_stream_wait_event(im_ctx* ctx, void* stream, im_event* ev);
+int  im_stream_follow(im_event* ev, void* from, void* to);      /* record on `from`, `to` waits */
+
 /* Launch graphs.  One flush is a fixed sequence of dependent im_dev_* launches on one stream
  * (the reference has no counterpart: its flush, src/indelminer.c:617-640, is host code).  Between
  * im_capture_begin and im_capture_end the im_dev_* calls on `stream` are recorded instead of run;

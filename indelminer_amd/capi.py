@@ -140,6 +140,15 @@ def lib():
         L.im_timer_start.argtypes = [C.c_void_p, C.c_void_p]
         L.im_timer_stop.argtypes = [C.c_void_p, C.c_void_p]
         L.im_timer_elapsed_ms.argtypes = [C.c_void_p, C.POINTER(C.c_float)]
+        L.im_stream_create.argtypes = [C.c_void_p, C.POINTER(C.c_void_p)]
+        L.im_stream_destroy.argtypes = [C.c_void_p, C.c_void_p]
+        L.im_event_create.argtypes = [C.c_void_p, C.POINTER(C.c_void_p)]
+        L.im_event_destroy.argtypes = [C.c_void_p]
+        L.im_event_destroy.restype = None
+        L.im_event_record.argtypes = [C.c_void_p, C.c_void_p]
+        L.im_event_sync.argtypes = [C.c_void_p]
+        L.im_stream_follow.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+        L.im_stream_wait_event.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
         L.im_capture_begin.argtypes = [C.c_void_p, C.c_void_p]
         L.im_capture_end.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(C.c_void_p)]
         L.im_graph_launch.argtypes = [C.c_void_p, C.c_void_p]
@@ -179,6 +188,40 @@ class DevBuf:
         if self.ptr:
             lib().im_dev_free(self.ctx.h, self.ptr)
             self.ptr = None
+
+
+class Event:
+    """Stream-to-stream dependency: record on one stream, wait on another."""
+
+    def __init__(self, ctx):
+        self.ctx = ctx
+        p = C.c_void_p()
+        ctx._check(lib().im_event_create(ctx.h, C.byref(p)))
+        self.h = p.value
+
+    def record(self, stream):
+        self.ctx._check(lib().im_event_record(self.h, stream))
+
+    def wait(self, stream):
+        self.ctx._check(lib().im_stream_wait_event(self.ctx.h, stream, self.h))
+
+    def sync(self):
+        self.ctx._check(lib().im_event_sync(self.h))
+
+    def follow(self, src, dst):
+        """record on stream src, make stream dst wait"""
+        self.ctx._check(lib().im_stream_follow(self.h, src, dst))
+
+    def close(self):
+        if self.h:
+            lib().im_event_destroy(self.h)
+            self.h = None
+
+
+def new_stream(ctx):
+    p = C.c_void_p()
+    ctx._check(lib().im_stream_create(ctx.h, C.byref(p)))
+    return p.value
 
 
 class Graph:

@@ -540,6 +540,72 @@ int im_timer_elapsed_ms(im_timer* t, float* ms)
     return IM_OK;
 }
 
+// ---- extra streams and events: overlap of one flush's clustering with the next flush's realign ------
+struct im_event { im_ctx* ctx; hipEvent_t e; };
+
+int im_stream_create(im_ctx* ctx, void** out)
+{
+    if (!ctx || !out) return IM_E_ARG;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    // highest priority: the work put here is a handful of small kernels that must find wave slots while a
+    // chip-filling realign launch of the context's own stream is in flight
+    int lo = 0, hi = 0;
+    HIP_TRY(ctx, hipDeviceGetStreamPriorityRange(&lo, &hi));
+    hipStream_t st = nullptr;
+    HIP_TRY(ctx, hipStreamCreateWithPriority(&st, hipStreamNonBlocking, hi));
+    *out = (void*)st;
+    return IM_OK;
+}
+int im_stream_destroy(im_ctx* ctx, void* stream)
+{
+    if (!ctx || !stream) return IM_E_ARG;
+    HIP_TRY(ctx, hipStreamDestroy((hipStream_t)stream));
+    return IM_OK;
+}
+int im_event_create(im_ctx* ctx, im_event** out)
+{
+    if (!ctx || !out) return IM_E_ARG;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    hipEvent_t e = nullptr;
+    HIP_TRY(ctx, hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    im_event* r = new im_event();
+    r->ctx = ctx; r->e = e;
+    *out = r;
+    return IM_OK;
+}
+void im_event_destroy(im_event* ev)
+{
+    if (!ev) return;
+    (void)hipEventDestroy(ev->e);
+    delete ev;
+}
+int im_event_record(im_event* ev, void* stream)
+{
+    if (!ev) return IM_E_ARG;
+    HIP_TRY(ev->ctx, hipEventRecord(ev->e, (hipStream_t)stream));
+    return IM_OK;
+}
+// record on `from`, make `to` wait: one call for the usual producer -> consumer hand-over
+int im_stream_follow(im_event* ev, void* from, void* to)
+{
+    if (!ev) return IM_E_ARG;
+    HIP_TRY(ev->ctx, hipEventRecord(ev->e, (hipStream_t)from));
+    HIP_TRY(ev->ctx, hipStreamWaitEvent((hipStream_t)to, ev->e, 0));
+    return IM_OK;
+}
+int im_event_sync(im_event* ev)
+{
+    if (!ev) return IM_E_ARG;
+    HIP_TRY(ev->ctx, hipEventSynchronize(ev->e));
+    return IM_OK;
+}
+int im_stream_wait_event(im_ctx* ctx, void* stream, im_event* ev)
+{
+    if (!ctx || !ev) return IM_E_ARG;
+    HIP_TRY(ctx, hipStreamWaitEvent((hipStream_t)stream, ev->e, 0));
+    return IM_OK;
+}
+
 // ---- launch graphs -----------------------------------------------------------------
 // A flush is a fixed sequence of small dependent launches (realign, then the cluster kernels); captured
 // once into a HIP graph it is replayed with one host call and without per-launch submission gaps.

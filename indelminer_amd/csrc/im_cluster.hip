@@ -375,8 +375,8 @@ __global__ __launch_bounds__(kSmallThreads) void cluster_small_kernel(
 //
 //   hist_insert   live slot -> table entry (64-bit CAS), support count, dense list of new keys
 //   hist_rank     distinct key -> its position in key order and the start of its slice, by
-//                 counting the smaller keys and their supports (keys staged in LDS, broadcast
-//                 reads); the marker cut is a key comparison.  No sort network, no scan.
+//                 counting the smaller keys and their supports (v_readlane broadcasts);
+//                 the marker cut is a key comparison.  No sort network, no scan, no LDS.
 //   hist_place    record -> order[first[entry] + cursor[cluster]++]
 //   hist_finish   one wave per cluster: order the slice by slot (= arrival), reset the entry
 //
@@ -397,7 +397,12 @@ struct HistScratch {
     uint64_t* ukey;         // [kHistMaxKeys] their keys, same order
     uint32_t* sorted_h;     // [kHistMaxKeys] table positions in key order
     uint32_t* cursor;       // [kHistMaxKeys] zero between calls
-    uint32_t* misc;         // [0] distinct keys, [2] overflow, [3] clusters after the cut
+    uint32_t* acc_r;        // [kHistMaxKeys] hist_rank accumulators, zero between calls
+    uint32_t* acc_f;        // [kHistMaxKeys]
+    uint64_t* acc_kcut;     // [kHistMaxKeys / 64] kEmptyKey between calls
+    uint32_t* acc_live;     // [kHistMaxKeys / 64]
+    uint32_t* acc_done;     // [kHistMaxKeys / 64]
+    uint32_t* misc;         // [0] distinct keys, [2] overflow, [3] clusters after the cut, [4] finish workgroups done
     uint32_t  H;
 };
 
@@ -414,7 +419,7 @@ __device__ __forceinline__ uint32_t hist_hash(uint64_t k)
     return (uint32_t)k;
 }
 
-__global__ __launch_bounds__(256) void hist_insert_kernel(int32_t n_slots, const int32_t* __restrict__ cls,
+__global__ __launch_bounds__(64) void hist_insert_kernel(int32_t n_slots, const int32_t* __restrict__ cls,
                                                          const int32_t* __restrict__ b1, const int32_t* __restrict__ b2,
                                                          HistScratch s, uint8_t* __restrict__ used)
 {
@@ -439,94 +444,103 @@ __global__ __launch_bounds__(256) void hist_insert_kernel(int32_t n_slots, const
     }
 }
 
-constexpr int kRankTile = 1024;
-constexpr int kRankThreads = 1024;      // one staged key per thread; 16 waves share the tile scan
+// Every kernel of this path runs one-wave workgroups with no or little LDS, so that its workgroups fit
+// the single wave slots a chip-filling realign launch of another stream leaves as its own one-wave
+// workgroups retire (a four-wave workgroup needs a free slot on all four SIMDs of a CU at once and
+// starves until that launch drains).
 
-struct HistRankLds {
-    uint64_t key[kRankTile];
-    uint32_t cnt[kRankTile];
-    uint32_t part_r[kRankThreads / 64][64], part_f[kRankThreads / 64][64];
-    unsigned long long kcut;            // smallest key whose b2 is at or past the marker
-    uint32_t live;
-};
-
-// One workgroup per 64 distinct keys (lane <-> key); its sixteen waves each take a sixteenth of every
-// staged tile of all the distinct keys and count, for their lane's key K, the keys smaller than K
-// (= K's position in key order, keys are distinct) and the records those keys hold (= where K's
-// slice of order[] starts).  The marker cut (clusters exist only before the first key, in key
-// order, whose b2 >= marker) is "K < kcut".  No sort and no scan is ever materialised.
-__global__ __launch_bounds__(kRankThreads) void hist_rank_kernel(HistScratch s, int32_t marker,
-                                                                int32_t* __restrict__ cl_first, int32_t* __restrict__ cl_count,
-                                                                int32_t* __restrict__ out_counts)
+// One wave per (64 distinct keys, 64 distinct keys) tile: lane <-> key K of the first block, the second
+// block's (key, support) pairs are fetched one per lane and broadcast lane by lane through v_readlane into
+// scalar registers.  Every lane counts the keys smaller than K (= K's position in key order; keys are
+// distinct) and the records those keys hold (= where K's slice of order[] starts); the tiles of one key
+// block add their partial counts into acc_r / acc_f and the LAST tile to arrive (acc_done) writes the
+// results and leaves the accumulators zero for the next call.  The marker cut (clusters exist only before
+// the first key, in key order, whose b2 >= marker) is "K < kcut", kcut accumulated the same way per key
+// block.  No sort, no scan, no LDS; everything cross-workgroup goes through agent-scope atomics.
+__global__ __launch_bounds__(64) void hist_rank_kernel(HistScratch s, int32_t marker,
+                                                      int32_t* __restrict__ cl_first, int32_t* __restrict__ cl_count,
+                                                      int32_t* __restrict__ out_counts)
 {
-    __shared__ HistRankLds L;
-    constexpr int kWaves = kRankThreads / 64, kSlice = kRankTile / kWaves;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int lane = threadIdx.x;
     const uint32_t nu = s.misc[0];
     if (nu > (uint32_t)kHistMaxKeys) {
-        if (blockIdx.x == 0 && tid == 0) { s.misc[2] = 1; s.misc[3] = 0; out_counts[0] = -1; out_counts[1] = 0; }
+        if (blockIdx.x == 0 && lane == 0) { s.misc[2] = 1; s.misc[3] = 0; out_counts[0] = -1; out_counts[1] = 0; }
         return;
     }
-    if (blockIdx.x * 64u >= nu && blockIdx.x != 0) return;
-    const uint32_t p = blockIdx.x * 64u + (uint32_t)lane;
-    // this lane's key (every wave holds the same 64), and for wave 0 its table entry and support
-    const uint64_t key = (p < nu) ? s.ukey[p] : kEmptyKey;
-    const uint32_t my_h = (wave == 0 && p < nu) ? s.uniq[p] : 0u;
-    if (tid == 0) { L.kcut = kEmptyKey; L.live = 0; }
-    __syncthreads();
-    uint32_t r = 0, f = 0, live = 0;
-    uint64_t kc = kEmptyKey;
-    for (uint32_t t0 = 0; t0 < nu; t0 += kRankTile) {
-        const uint32_t tn = min((uint32_t)kRankTile, nu - t0);
-        {   // stage the tile, one element per thread (uniq -> cnt is a dependent pair of loads)
-            const uint32_t q = (uint32_t)tid;
-            const uint64_t k = (q < tn) ? s.ukey[t0 + q] : kEmptyKey;
-            const uint32_t c = (q < tn) ? s.cnt[s.uniq[t0 + q]] : 0u;
-            live += c;
-            if (k != kEmptyKey && hist_key_b2(k) >= marker && k < kc) kc = k;
-            L.key[q] = k; L.cnt[q] = c;                         // the pad compares as "not smaller"
-        }
-        __syncthreads();
-        const uint32_t q0 = (uint32_t)wave * kSlice;
-        const uint32_t q1 = min(q0 + kSlice, (tn + 7u) & ~7u);
-        for (uint32_t q = q0; q < q1; q += 8) {
-            // all sixteen (broadcast) LDS reads first, then the arithmetic: no load behind a compare
-            uint64_t kk[8]; uint32_t cc[8];
-#pragma unroll
-            for (int e = 0; e < 8; e++) { kk[e] = L.key[q + e]; cc[e] = L.cnt[q + e]; }
-#pragma unroll
-            for (int e = 0; e < 8; e++) {
-                const bool lt = kk[e] < key;
-                r += lt ? 1u : 0u;
-                f += lt ? cc[e] : 0u;
-            }
-        }
-        __syncthreads();
+    if (nu == 0) {
+        if (blockIdx.x == 0 && lane == 0) { s.misc[3] = 0; out_counts[0] = 0; out_counts[1] = 0; }
+        return;
     }
-    L.part_r[wave][lane] = r; L.part_f[wave][lane] = f;
-    if (kc != kEmptyKey) atomicMin(&L.kcut, (unsigned long long)kc);
-    if (blockIdx.x == 0 && live) atomicAdd(&L.live, live);
-    __syncthreads();
-    const uint64_t kcut = L.kcut;
-    if (wave == 0 && p < nu) {
-        r = 0; f = 0;
+    const uint32_t nblk = (nu + 63u) / 64u;
+    for (uint32_t w = blockIdx.x; w < nblk * nblk; w += gridDim.x) {
+        const uint32_t pb = w / nblk, qb = w - pb * nblk;
+        const uint32_t p = pb * 64u + (uint32_t)lane, q = qb * 64u + (uint32_t)lane;
+        const uint64_t key = (p < nu) ? s.ukey[p] : kEmptyKey;
+        const uint64_t kq = (q < nu) ? s.ukey[q] : kEmptyKey;               // the pad compares as "not smaller"
+        const uint32_t cq = (q < nu) ? s.cnt[s.uniq[q]] : 0u;
+        const uint32_t klo = (uint32_t)kq, khi = (uint32_t)(kq >> 32);
+        uint32_t r = 0, f = 0;
 #pragma unroll
-        for (int w = 0; w < kWaves; w++) { r += L.part_r[w][lane]; f += L.part_f[w][lane]; }
-        const uint32_t c = s.cnt[my_h];
-        const bool valid = key < kcut;
-        s.sorted_h[r] = my_h;
-        s.rank[my_h] = valid ? r : 0xFFFFFFFFu;
-        s.first_h[my_h] = f;
-        if (valid) { cl_first[r] = (int32_t)f; cl_count[r] = (int32_t)c; if (c > (uint32_t)kHistMaxSupport) s.misc[2] = 1; }
-        if (key == kcut) { s.misc[3] = r; out_counts[0] = (int32_t)r; }
-    }
-    if (blockIdx.x == 0 && tid == 0) {
-        if (kcut == kEmptyKey) { s.misc[3] = nu; out_counts[0] = (int32_t)nu; }
-        out_counts[1] = (int32_t)L.live;
+        for (int e = 0; e < 64; e++) {
+            const uint64_t ke = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)khi, e) << 32) |
+                                (uint32_t)__builtin_amdgcn_readlane((int)klo, e);
+            const uint32_t ce = (uint32_t)__builtin_amdgcn_readlane((int)cq, e);
+            const bool lt = ke < key;
+            r += lt ? 1u : 0u;
+            f += lt ? ce : 0u;
+        }
+        // this tile's share of the cut key and of the live-record count
+        uint64_t kc = (kq != kEmptyKey && hist_key_b2(kq) >= marker) ? kq : kEmptyKey;
+        uint32_t live = cq;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const uint32_t olo = (uint32_t)__shfl_xor((int)(uint32_t)kc, o), ohi = (uint32_t)__shfl_xor((int)(uint32_t)(kc >> 32), o);
+            const uint64_t ok = ((uint64_t)ohi << 32) | olo;
+            if (ok < kc) kc = ok;
+            live += (uint32_t)__shfl_xor((int)live, o);
+        }
+        uint32_t seen = 0;
+        if (p < nu) {
+            seen = atomicAdd(&s.acc_r[p], r);
+            seen |= atomicAdd(&s.acc_f[p], f);
+        }
+        if (lane == 0) {
+            if (kc != kEmptyKey) seen |= (uint32_t)atomicMin(reinterpret_cast<unsigned long long*>(&s.acc_kcut[pb]), (unsigned long long)kc);
+            seen |= atomicAdd(&s.acc_live[pb], live);
+        }
+        asm volatile("" :: "v"(seen));      // the returns are in: those atomics are performed before the count below
+        uint32_t done = 0;
+        if (lane == 0) done = atomicAdd(&s.acc_done[pb], 1u);
+        done = (uint32_t)__builtin_amdgcn_readfirstlane((int)done);
+        if (done != nblk - 1) continue;
+        // last tile of key block pb: collect, publish, and zero the accumulators
+        uint64_t kcut = kEmptyKey; uint32_t tot_live = 0;
+        if (lane == 0) {
+            kcut = atomicExch(reinterpret_cast<unsigned long long*>(&s.acc_kcut[pb]), (unsigned long long)kEmptyKey);
+            tot_live = atomicExch(&s.acc_live[pb], 0u);
+            s.acc_done[pb] = 0;
+        }
+        kcut = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(kcut >> 32)) << 32) |
+               (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)kcut);
+        if (p < nu) {
+            const uint32_t rr = atomicExch(&s.acc_r[p], 0u), ff = atomicExch(&s.acc_f[p], 0u);
+            const uint32_t my_h = s.uniq[p];
+            const uint32_t c = s.cnt[my_h];
+            const bool valid = key < kcut;
+            s.sorted_h[rr] = my_h;
+            s.rank[my_h] = valid ? rr : 0xFFFFFFFFu;
+            s.first_h[my_h] = ff;
+            if (valid) { cl_first[rr] = (int32_t)ff; cl_count[rr] = (int32_t)c; if (c > (uint32_t)kHistMaxSupport) s.misc[2] = 1; }
+            if (key == kcut) { s.misc[3] = rr; out_counts[0] = (int32_t)rr; }
+        }
+        if (pb == 0 && lane == 0) {
+            if (kcut == kEmptyKey) { s.misc[3] = nu; out_counts[0] = (int32_t)nu; }
+            out_counts[1] = (int32_t)tot_live;
+        }
     }
 }
 
-__global__ __launch_bounds__(256) void hist_place_kernel(int32_t n_slots, HistScratch s,
+__global__ __launch_bounds__(64) void hist_place_kernel(int32_t n_slots, HistScratch s,
                                                         int32_t* __restrict__ order, uint8_t* __restrict__ used)
 {
     if (s.misc[0] > (uint32_t)kHistMaxKeys) return;
@@ -541,25 +555,25 @@ __global__ __launch_bounds__(256) void hist_place_kernel(int32_t n_slots, HistSc
     }
 }
 
-// one wave per distinct key: order the cluster's slice by slot index, then reset the table entry
-__global__ __launch_bounds__(256) void hist_finish_kernel(HistScratch s, const int32_t* __restrict__ cl_first,
-                                                         const int32_t* __restrict__ cl_count, int32_t tie_desc,
-                                                         int32_t* __restrict__ order, int32_t* __restrict__ out_counts)
+// one wave per distinct key: order the cluster's slice by slot index, then reset the table entry.  The call's
+// counters are cleared by whichever workgroup finishes LAST (misc[4] counts them): a workgroup scheduled
+// late must still find the counters of this call.
+__global__ __launch_bounds__(64) void hist_finish_kernel(HistScratch s, const int32_t* __restrict__ cl_first,
+                                                        const int32_t* __restrict__ cl_count, int32_t tie_desc,
+                                                        int32_t* __restrict__ order, int32_t* __restrict__ out_counts)
 {
-    __shared__ int32_t stage[4][kHistMaxSupport];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    __shared__ int32_t st[kHistMaxSupport];
+    const int lane = threadIdx.x;
     const uint32_t nu_raw = s.misc[0];
     const bool overflow_keys = nu_raw > (uint32_t)kHistMaxKeys;
     const uint32_t nu = overflow_keys ? 0u : nu_raw;
     const uint32_t m = s.misc[3];
     const bool bad = s.misc[2] != 0;
-    const uint32_t waves = gridDim.x * 4;
-    for (uint32_t p = blockIdx.x * 4 + wave; p < nu; p += waves) {
+    for (uint32_t p = blockIdx.x; p < nu; p += gridDim.x) {
         const uint32_t h = s.sorted_h[p];
         if (p < m && !bad) {
             const int32_t f = cl_first[p], cnt = cl_count[p];
             if (cnt > 1 || tie_desc) {
-                int32_t* st = stage[wave];
                 for (int32_t t = lane; t < cnt; t += 64) st[t] = order[f + t];
                 __builtin_amdgcn_wave_barrier();
                 __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
@@ -575,9 +589,15 @@ __global__ __launch_bounds__(256) void hist_finish_kernel(HistScratch s, const i
         }
         if (lane == 0) { s.keys[h] = kEmptyKey; s.cnt[h] = 0; s.cursor[p] = 0; }
     }
-    if (blockIdx.x == 0 && threadIdx.x == 0) {
-        if (bad && !overflow_keys) out_counts[0] = -1;
-        if (!overflow_keys) { s.misc[0] = 0; s.misc[1] = 0; s.misc[2] = 0; s.misc[3] = 0; }
+    if (lane == 0) {
+        if (blockIdx.x == 0 && bad && !overflow_keys) out_counts[0] = -1;
+        // no fence: the count only has to follow this workgroup's own reads of the counters, which its
+        // loop bounds consumed long ago (an agent-scope fence here is a whole-L2 write-back per workgroup)
+        const uint32_t done = atomicAdd(&s.misc[4], 1u);
+        if (done == gridDim.x - 1) {
+            s.misc[4] = 0;
+            if (!overflow_keys) { s.misc[0] = 0; s.misc[1] = 0; s.misc[2] = 0; s.misc[3] = 0; }
+        }
     }
 }
 
@@ -597,11 +617,15 @@ inline size_t hist_carve(HistScratch* hs, void* base, int32_t n_slots)
     const size_t oK = take((size_t)H * 8), oC = take((size_t)H * 4), oR = take((size_t)H * 4), oS = take(nn * 4);
     const size_t oU = take((size_t)kHistMaxKeys * 4), oSh = take((size_t)kHistMaxKeys * 4), oCu = take((size_t)kHistMaxKeys * 4), oM = take(64);
     const size_t oUk = take((size_t)kHistMaxKeys * 8), oFh = take((size_t)H * 4);
+    const size_t oAr = take((size_t)kHistMaxKeys * 4), oAf = take((size_t)kHistMaxKeys * 4), oAk = take((size_t)kHistMaxKeys / 64 * 8);
+    const size_t oAl = take((size_t)kHistMaxKeys / 64 * 4), oAd = take((size_t)kHistMaxKeys / 64 * 4);
     if (hs) {
         char* b = static_cast<char*>(base);
         hs->keys = (uint64_t*)(b + oK); hs->cnt = (uint32_t*)(b + oC); hs->rank = (uint32_t*)(b + oR); hs->slot_h = (uint32_t*)(b + oS);
         hs->uniq = (uint32_t*)(b + oU); hs->sorted_h = (uint32_t*)(b + oSh); hs->cursor = (uint32_t*)(b + oCu); hs->misc = (uint32_t*)(b + oM);
         hs->ukey = (uint64_t*)(b + oUk); hs->first_h = (uint32_t*)(b + oFh);
+        hs->acc_r = (uint32_t*)(b + oAr); hs->acc_f = (uint32_t*)(b + oAf); hs->acc_kcut = (uint64_t*)(b + oAk);
+        hs->acc_live = (uint32_t*)(b + oAl); hs->acc_done = (uint32_t*)(b + oAd);
         hs->H = H;
     }
     return off;
@@ -744,6 +768,11 @@ hipError_t launch_cluster_hist_init(int32_t n_slots, void* scratch, size_t scrat
     if (e == hipSuccess) e = hipMemsetAsync(hs.cnt, 0, (size_t)hs.H * 4, stream);
     if (e == hipSuccess) e = hipMemsetAsync(hs.misc, 0, 64, stream);
     if (e == hipSuccess) e = hipMemsetAsync(hs.cursor, 0, (size_t)kHistMaxKeys * 4, stream);
+    if (e == hipSuccess) e = hipMemsetAsync(hs.acc_r, 0, (size_t)kHistMaxKeys * 4, stream);
+    if (e == hipSuccess) e = hipMemsetAsync(hs.acc_f, 0, (size_t)kHistMaxKeys * 4, stream);
+    if (e == hipSuccess) e = hipMemsetAsync(hs.acc_kcut, 0xFF, (size_t)kHistMaxKeys / 64 * 8, stream);
+    if (e == hipSuccess) e = hipMemsetAsync(hs.acc_live, 0, (size_t)kHistMaxKeys / 64 * 4, stream);
+    if (e == hipSuccess) e = hipMemsetAsync(hs.acc_done, 0, (size_t)kHistMaxKeys / 64 * 4, stream);
     return e;
 }
 
@@ -755,11 +784,11 @@ hipError_t launch_cluster_hist(int32_t n_slots, const int32_t* cls, const int32_
 {
     HistScratch hs;
     if (hist_carve(&hs, scratch, n_slots) > scratch_bytes) return hipErrorInvalidValue;
-    const int g = grid_for(n_slots, 256);
-    hipLaunchKernelGGL(hist_insert_kernel, dim3(g), dim3(256), 0, stream, n_slots, cls, b1, b2, hs, used);
-    hipLaunchKernelGGL(hist_rank_kernel, dim3(kHistMaxKeys / 64), dim3(kRankThreads), 0, stream, hs, marker, cl_first, cl_count, out_counts);
-    hipLaunchKernelGGL(hist_place_kernel, dim3(g), dim3(256), 0, stream, n_slots, hs, order, used);
-    hipLaunchKernelGGL(hist_finish_kernel, dim3(512), dim3(256), 0, stream, hs, cl_first, cl_count, tie_desc, order, out_counts);
+    const int g = grid_for(n_slots, 64);
+    hipLaunchKernelGGL(hist_insert_kernel, dim3(g), dim3(64), 0, stream, n_slots, cls, b1, b2, hs, used);
+    hipLaunchKernelGGL(hist_rank_kernel, dim3(1024), dim3(64), 0, stream, hs, marker, cl_first, cl_count, out_counts);
+    hipLaunchKernelGGL(hist_place_kernel, dim3(g), dim3(64), 0, stream, n_slots, hs, order, used);
+    hipLaunchKernelGGL(hist_finish_kernel, dim3(512), dim3(64), 0, stream, hs, cl_first, cl_count, tie_desc, order, out_counts);
     return hipGetLastError();
 }
 

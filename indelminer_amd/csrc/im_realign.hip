@@ -65,7 +65,7 @@ namespace {
 #define IM_WAVES_PER_SIMD 6
 #endif
 #ifndef IM_BLOCKS_PER_CU
-#define IM_BLOCKS_PER_CU 24
+#define IM_BLOCKS_PER_CU 4096
 #endif
 constexpr int kDiagChunk = IM_DIAG_CHUNK;   // diagonals per histogram pass (1 byte each)
 constexpr int kTblBytes  = 4096;            // 4^6 direct table, or 512-slot hash (keys+vals)
@@ -80,7 +80,7 @@ static_assert(kDiagWords % 4 == 0, "the histogram is cleared with 16-byte stores
 
 struct WaveLds {
     alignas(16) uint32_t diag[kDiagWords];
-    uint32_t tbl[kTblBytes / 4];
+    alignas(16) uint32_t tbl[kTblBytes / 4];
     uint32_t rd[(256 + 16) / 4];            // read bases, read coordinates
 };
 
@@ -909,8 +909,9 @@ __global__ __launch_bounds__(64, IM_WAVES_PER_SIMD) void realign_kernel(RealignA
     // speed only): give each XCD a contiguous run of `per` reads per sweep.
     const int mine = (blockIdx.x & 7) * per + (blockIdx.x >> 3);
     if constexpr (KT == 6) {        // table_build<6> / table_undo6 keep the table clean from here on
+        uint4* t4 = reinterpret_cast<uint4*>(s.tbl);
 #pragma unroll
-        for (int i = 0; i < kTblBytes / 4 / 64; i++) s.tbl[lane + 64 * i] = 0u;
+        for (int i = 0; i < kTblBytes / 16 / 64; i++) t4[lane + 64 * i] = make_uint4(0u, 0u, 0u, 0u);
         wave_lds_sync();
     }
     for (int base = 0; base < A.batch.n; base += G) {
