@@ -40,7 +40,7 @@ def measured_traffic():
     per the gfx950 correction + WRITE_SIZE, collected with separate --pmc runs of this same
     command); counters cannot be read from inside this process."""
     try:
-        with open(os.path.join(ROOT, "profiles", "r01_b_traffic.json")) as fh:
+        with open(os.path.join(ROOT, "profiles", "r01_c_traffic.json")) as fh:
             return int(json.load(fh)["hbm_bytes_per_launch"])
     except Exception:
         return None
