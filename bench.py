@@ -303,7 +303,16 @@ def main():
             ids = [capi.comm_unique_id() if rank == 0 else None]
             if dist is not None:
                 dist.broadcast_object_list(ids, src=0)
-            shard.attach_comm(capi.Comm(ctx, ids[0], rank, world))
+            # librccl prints a version banner on file descriptor 1 when a communicator is made; stdout of
+            # rank 0 must carry the one JSON line only, so descriptor 1 points at stderr meanwhile
+            sys.stdout.flush()
+            saved_fd = os.dup(1)
+            os.dup2(2, 1)
+            try:
+                shard.attach_comm(capi.Comm(ctx, ids[0], rank, world))
+            finally:
+                os.dup2(saved_fd, 1)
+                os.close(saved_fd)
             collective = "rccl all-gather of per-shard cluster lists, %d B per rank per step" % (16 * shard.rec_cap)
         except Exception as e:                # plumbing failure must not hide the compute numbers
             collective = "NONE (RCCL unavailable: %s); shards ran independently" % e
