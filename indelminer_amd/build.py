@@ -62,7 +62,7 @@ def build_host(force=False, verbose=False):
     deps = srcs + [os.path.join(HOST_DIR, "imhost.h"), os.path.join(HOST_DIR, "hostio.h"), HEADERS[0], LIB]
     if not force and os.path.exists(HOST_BIN) and all(os.path.getmtime(d) <= os.path.getmtime(HOST_BIN) for d in deps):
         return HOST_BIN
-    cmd = ["gcc", "-O2", "-std=c11", "-Wall", "-I" + os.path.join(ROOT, "include"), "-I" + HOST_DIR, "-o", HOST_BIN]
+    cmd = ["gcc", "-O2", "-std=c11", "-Wall", "-pthread", "-I" + os.path.join(ROOT, "include"), "-I" + HOST_DIR, "-o", HOST_BIN]
     cmd += srcs + ["-L" + HERE, "-lindelminer_amd", "-lz", "-lm", "-Wl,-rpath,$ORIGIN"]
     if verbose:
         print(" ".join(cmd))

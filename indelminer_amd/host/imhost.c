@@ -23,6 +23,7 @@
 #include <getopt.h>
 #include <limits.h>
 #include <math.h>
+#include <pthread.h>
 #include <stdarg.h>
 #include <stdlib.h>
 #include <string.h>
@@ -347,6 +348,11 @@ typedef struct {
     bam_header* hdr;
     char** sequences; int64_t* seqlen;
     qhash* insertlengths;
+    /* the GPU context is opened and the reference uploaded by a helper thread while the main
+     * thread decodes the BAM (pass A needs no GPU); gpu_wait() joins it before the first GPU call */
+    pthread_t gpu_thread;
+    int gpu_pending, gpu_rc;
+    char gpu_err[512];
     qhash* readpairs;
     const char* bam_name;
     bai_index* idx;
@@ -360,6 +366,9 @@ typedef struct {
     int32_t *seg_start, *seg_len; int64_t n_seg, cap_seg;
     int depth_tid;              /* contig whose depth array is resident on the device, -1 = none */
 } driver;
+
+static void gpu_wait(driver* d);
+static void print_vcf_preamble(void);
 
 static void cb_push(cand_batch* cb, const char* bases, int32_t tid, int32_t anchor, int32_t range_max,
                     const char* qname, char strand, uint8_t qual)
@@ -783,6 +792,7 @@ static uint32_t region_depth(driver* d, int32_t tid, int32_t start, int32_t stop
     if (d->depth_tid == tid) {
         /* the device holds the contig's depth array (im_depth_build in run_contig) */
         uint32_t sum = 0;
+        gpu_wait(d);
         if (im_depth_query(d->gpu, 1, &start, &stop, &sum) != IM_OK) fatalf("im_depth_query: %s", im_last_error(d->gpu));
         return (uint32_t)floor(sum * 1.0 / (uint32_t)(stop - start));
     }
@@ -1135,6 +1145,7 @@ static void process_evidence(driver* d, int32_t tid, int marker, variant_list* o
         uint8_t* used = xmalloc((size_t)nsr);
         for (int32_t i = 0; i < nsr; i++) { const evidence_t* e = d->pending[sr_idx[i]]; cls[i] = e->cls; b1[i] = e->b1; b2[i] = e->b2; }
         int32_t ncl = 0;
+        gpu_wait(d);
         const int rc = im_cluster_sr(d->gpu, nsr, cls, b1, b2, INT_MAX, O.tie_desc, order, first, count, used, &ncl);
         if (rc != IM_OK) fatalf("im_cluster_sr: %s", im_last_error(d->gpu));
         for (int32_t c = 0; c < ncl; c++) {
@@ -1415,6 +1426,7 @@ static int is_indel_supported(driver* d, knownvariant_t* k)
     bgzf_close(r);
     if (!k->diffsample_support && nt > 0) {
         int32_t* res = xmalloc(sizeof(int32_t) * 4 * (size_t)nt);
+        gpu_wait(d);
         if (im_support_batch(d->gpu, nt, tg, to, qs, qo, res) != IM_OK) fatalf("im_support_batch: %s", im_last_error(d->gpu));
         for (int i = 0; i < nt; i++)
             if (res[4 * i] <= own[3 * i] && res[4 * i + 1] <= own[3 * i + 1] && res[4 * i + 2] >= own[3 * i + 2]) { k->diffsample_support = 1; break; }
@@ -1493,6 +1505,39 @@ static void flush_variants(driver* d, int32_t tid, int marker)
     free_used_evidence(d);
     for (int i = 0; i < vs.n; i++) variant_free(vs.v[i]);
     free(vs.v);
+}
+
+/* ------------------------------------------------------ GPU start-up ------- */
+
+static void* gpu_open_thread(void* arg)
+{
+    driver* d = (driver*)arg;
+    const char* dev_env = getenv("INDELMINER_DEVICE");
+    d->gpu_rc = im_ctx_create(dev_env ? atoi(dev_env) : 0, &d->gpu);
+    if (d->gpu_rc != IM_OK) { snprintf(d->gpu_err, sizeof d->gpu_err, "cannot open the GPU: %s", im_last_error(NULL)); return NULL; }
+    const char** seqs = xcalloc((size_t)d->hdr->n_targets, sizeof(char*));
+    int64_t* lens = xcalloc((size_t)d->hdr->n_targets, sizeof(int64_t));
+    for (int32_t i = 0; i < d->hdr->n_targets; i++) { seqs[i] = d->sequences[i] ? d->sequences[i] : ""; lens[i] = d->sequences[i] ? d->seqlen[i] : 0; }
+    d->gpu_rc = im_set_reference(d->gpu, d->hdr->n_targets, seqs, lens);
+    if (d->gpu_rc != IM_OK) snprintf(d->gpu_err, sizeof d->gpu_err, "im_set_reference: %s", im_last_error(d->gpu));
+    free(seqs); free(lens);
+    return NULL;
+}
+
+/* every GPU call site passes through here first */
+static void gpu_wait(driver* d)
+{
+    if (!d->gpu_pending) return;
+    pthread_join(d->gpu_thread, NULL);
+    d->gpu_pending = 0;
+    if (d->gpu_rc != IM_OK) fatalf("%s", d->gpu_err);
+    phase_time("GPU context + reference upload (helper thread, joined)");
+    /* the output header (src/indelminer.c:745-754) goes out only once the GPU is known to be there:
+     * nothing is printed by a run that cannot compute */
+    if (strncmp(O.outputformat, "vcf", 3) == 0) print_vcf_preamble();
+    if (g_vcfname != NULL)
+        printf("##INFO=<ID=%s,Number=0,Type=Flag,Description=\"The variant is also present in this sample\">\n", g_sample_name);
+    if (strncmp(O.outputformat, "vcf", 3) == 0) printf("#CHROM\tPOS\tID\tREF\tALT\tQUAL\tFILTER\tINFO\n");
 }
 
 /* ------------------------------------------------------ config / estimates -- */
@@ -1649,6 +1694,7 @@ static void run_contig(driver* d, int32_t tid, int32_t beg, int32_t end, bgzf_re
     phase_time("pass A (BAM decode + dispatch)");
     d->depth_tid = -1;
     if (whole) {
+        gpu_wait(d);
         if (im_depth_build(d->gpu, d->seqlen[tid], (int32_t)d->n_seg, d->seg_start, d->seg_len) != IM_OK)
             fatalf("im_depth_build: %s", im_last_error(d->gpu));
         d->depth_tid = tid;
@@ -1660,6 +1706,7 @@ static void run_contig(driver* d, int32_t tid, int32_t beg, int32_t end, bgzf_re
         im_params P = { O.klength, O.numgaps, O.maxdelsize, O.ethreshold };
         im_read_batch batch = { d->cb.n, d->cb.bases, d->cb.base_off, d->cb.tid, d->cb.anchor, d->cb.range_max };
         res = xmalloc(sizeof(im_read_result) * (size_t)d->cb.n);
+        gpu_wait(d);
         const int rc = im_realign_batch(d->gpu, &P, &batch, res);
         if (rc != IM_OK) fatalf("im_realign_batch: %s", im_last_error(d->gpu));
     }
@@ -1833,24 +1880,10 @@ int main(int argc, char** argv)
     timestamp("Read the reference sequence");
     phase_time("read FASTA");
 
-    /* the GPU: one context, reference resident in HBM */
-    const char* dev_env = getenv("INDELMINER_DEVICE");
-    int rc = im_ctx_create(dev_env ? atoi(dev_env) : 0, &d.gpu);
-    if (rc != IM_OK) fatalf("cannot open the GPU: %s", im_last_error(NULL));
-    {
-        const char** seqs = xcalloc((size_t)d.hdr->n_targets, sizeof(char*));
-        int64_t* lens = xcalloc((size_t)d.hdr->n_targets, sizeof(int64_t));
-        for (int32_t i = 0; i < d.hdr->n_targets; i++) { seqs[i] = d.sequences[i] ? d.sequences[i] : ""; lens[i] = d.sequences[i] ? d.seqlen[i] : 0; }
-        rc = im_set_reference(d.gpu, d.hdr->n_targets, seqs, lens);
-        if (rc != IM_OK) fatalf("im_set_reference: %s", im_last_error(d.gpu));
-        free(seqs); free(lens);
-    }
+    /* the GPU: one context, reference resident in HBM -- opened beside the BAM decode */
+    d.gpu_pending = 1;
+    if (pthread_create(&d.gpu_thread, NULL, gpu_open_thread, &d) != 0) fatalf("cannot start the GPU helper thread");
 
-    phase_time("GPU context + reference upload");
-    if (strncmp(O.outputformat, "vcf", 3) == 0) print_vcf_preamble();
-    if (g_vcfname != NULL)
-        printf("##INFO=<ID=%s,Number=0,Type=Flag,Description=\"The variant is also present in this sample\">\n", g_sample_name);
-    if (strncmp(O.outputformat, "vcf", 3) == 0) printf("#CHROM\tPOS\tID\tREF\tALT\tQUAL\tFILTER\tINFO\n");
 
     for (int32_t i = 0; i < d.hdr->n_targets; i++) {
         if (chromid != -1 && i != chromid) continue;
@@ -1863,6 +1896,7 @@ int main(int argc, char** argv)
         else run_contig(&d, i, chromstart, chromstop, r);
     }
 
+    gpu_wait(&d);
     im_ctx_destroy(d.gpu);
     bgzf_close(r);
     bai_free(d.idx);
