@@ -264,7 +264,7 @@ def end_to_end(refs, rd):
             out["reference_reads_per_s"] = rd.n / out["reference_wall_s"]
             out["vcf_identical_to_reference"] = bool(q.returncode == 0 and q.stdout == p.stdout)
         out["product_reads_per_s"] = rd.n / out["product_wall_s"]
-        out["note"] = "whole programs incl. process start, BAM decode, GPU context creation and reference upload; 1 host thread"
+        out["note"] = "whole programs incl. process start, BAM decode, GPU context creation and reference upload; product: 1 record-parsing thread, 4 BGZF inflate workers, a GPU start-up helper thread; reference: 1 thread (it has no other mode)"
         return out
 
 

@@ -7,13 +7,34 @@
 #include "hostio.h"
 
 #include <ctype.h>
+#include <pthread.h>
 #include <stdlib.h>
 #include <string.h>
 #include <zlib.h>
 
 /* ------------------------------------------------------------------ BGZF -- */
+/*
+ * Sequential reads run through a read-ahead ring: the reading thread fetches the compressed blocks
+ * that follow (file I/O stays on one thread) and a few worker threads inflate them, so that the
+ * decode passes of the driver (insert-length estimate, pass A) cost one thread's record parsing and
+ * not one thread's zlib.  A seek empties the ring.  The pool starts only after a run of
+ * consecutive blocks, so short region fetches never pay for threads.  INDELMINER_THREADS sets the
+ * number of inflate workers (default 4, 0 = inflate on the reading thread as before).
+ */
 
 #define BGZF_MAX_BLOCK 65536
+#define BGZF_RING 64
+#define BGZF_WARMUP 8
+
+enum { SLOT_FREE = 0, SLOT_LOADED, SLOT_BUSY, SLOT_DONE, SLOT_BAD };
+
+typedef struct {
+    uint8_t  cbuf[BGZF_MAX_BLOCK + 64];
+    uint8_t  ubuf[BGZF_MAX_BLOCK];
+    int64_t  coff;
+    int32_t  total, hdr, ulen;
+    int      state;
+} bgzf_slot;
 
 struct bgzf_reader {
     FILE*    fp;
@@ -23,6 +44,15 @@ struct bgzf_reader {
     int64_t  block_coff;        /* file offset of the block in ubuf */
     int64_t  next_coff;         /* file offset of the next block */
     int      eof;
+    /* read-ahead */
+    int      nworkers, started, stop, run;
+    pthread_t workers[16];
+    pthread_mutex_t mu;
+    pthread_cond_t  cv_work, cv_done;
+    bgzf_slot* ring;            /* [BGZF_RING] */
+    int      head, tail, next_job;      /* consume at head, fill at tail, inflate at next_job (ring indices, monotone) */
+    int64_t  fill_coff;         /* file offset of the next block to fetch */
+    int      fill_eof;
 };
 
 bgzf_reader* bgzf_open(const char* path)
@@ -31,23 +61,19 @@ bgzf_reader* bgzf_open(const char* path)
     if (!fp) return NULL;
     bgzf_reader* r = calloc(1, sizeof *r);
     r->fp = fp;
+    const char* e = getenv("INDELMINER_THREADS");
+    r->nworkers = e ? atoi(e) : 4;
+    if (r->nworkers < 0) r->nworkers = 0;
+    if (r->nworkers > 16) r->nworkers = 16;
     return r;
 }
 
-void bgzf_close(bgzf_reader* r)
+/* reads the compressed block at coff into cbuf; returns total size, 0 at EOF, -1 on error; *phdr = header size */
+static int bgzf_fetch(FILE* fp, int64_t coff, uint8_t* h, int* phdr)
 {
-    if (!r) return;
-    fclose(r->fp);
-    free(r);
-}
-
-/* loads the block at r->next_coff; returns 1, 0 at EOF, -1 on error */
-static int bgzf_load_block(bgzf_reader* r)
-{
-    uint8_t* h = r->cbuf;
-    if (fseeko(r->fp, r->next_coff, SEEK_SET) != 0) return -1;
-    size_t got = fread(h, 1, 18, r->fp);
-    if (got == 0) { r->eof = 1; r->ulen = r->upos = 0; return 0; }
+    if (fseeko(fp, coff, SEEK_SET) != 0) return -1;
+    size_t got = fread(h, 1, 18, fp);
+    if (got == 0) return 0;
     if (got < 18 || h[0] != 31 || h[1] != 139 || h[2] != 8 || !(h[3] & 4)) return -1;
     const int xlen = h[10] | (h[11] << 8);
     /* find the BC subfield */
@@ -56,31 +82,157 @@ static int bgzf_load_block(bgzf_reader* r)
     else {
         uint8_t* x = malloc((size_t)xlen);
         memcpy(x, h + 12, 6);
-        if (xlen > 6 && fread(x + 6, 1, (size_t)xlen - 6, r->fp) != (size_t)xlen - 6) { free(x); return -1; }
+        if (xlen > 6 && fread(x + 6, 1, (size_t)xlen - 6, fp) != (size_t)xlen - 6) { free(x); return -1; }
         for (int i = 0; i + 4 <= xlen;) {
             const int slen = x[i + 2] | (x[i + 3] << 8);
             if (x[i] == 'B' && x[i + 1] == 'C' && slen == 2) bsize = x[i + 4] | (x[i + 5] << 8);
             i += 4 + slen;
         }
         free(x);
-        if (fseeko(r->fp, r->next_coff + 18, SEEK_SET) != 0) return -1;
+        if (fseeko(fp, coff + 18, SEEK_SET) != 0) return -1;
     }
     if (bsize < 0) return -1;
     const int total = bsize + 1;
     const int hdr = 12 + xlen;
     const int remain = total - 18;
-    if (remain < 0 || total > BGZF_MAX_BLOCK + 64) return -1;
-    if (fread(h + 18, 1, (size_t)remain, r->fp) != (size_t)remain) return -1;
+    if (remain < 0 || total > BGZF_MAX_BLOCK + 64 || total - hdr - 8 < 0) return -1;
+    if (fread(h + 18, 1, (size_t)remain, fp) != (size_t)remain) return -1;
+    *phdr = hdr;
+    return total;
+}
+
+/* raw-deflate payload of a fetched block -> ubuf; returns the inflated size or -1 */
+static int bgzf_inflate(const uint8_t* h, int total, int hdr, uint8_t* ubuf)
+{
     const int clen = total - hdr - 8;
     z_stream zs;
     memset(&zs, 0, sizeof zs);
     if (inflateInit2(&zs, -15) != Z_OK) return -1;
-    zs.next_in = h + hdr; zs.avail_in = (uInt)clen;
-    zs.next_out = r->ubuf; zs.avail_out = BGZF_MAX_BLOCK;
+    zs.next_in = (Bytef*)(h + hdr); zs.avail_in = (uInt)clen;
+    zs.next_out = ubuf; zs.avail_out = BGZF_MAX_BLOCK;
     const int zr = inflate(&zs, Z_FINISH);
     const int ulen = (int)zs.total_out;
     inflateEnd(&zs);
-    if (zr != Z_STREAM_END) return -1;
+    return zr == Z_STREAM_END ? ulen : -1;
+}
+
+static void* bgzf_worker(void* arg)
+{
+    bgzf_reader* r = arg;
+    pthread_mutex_lock(&r->mu);
+    for (;;) {
+        while (!r->stop && !(r->next_job < r->tail && r->ring[r->next_job % BGZF_RING].state == SLOT_LOADED))
+            pthread_cond_wait(&r->cv_work, &r->mu);
+        if (r->stop) break;
+        bgzf_slot* s = &r->ring[r->next_job % BGZF_RING];
+        r->next_job++;
+        s->state = SLOT_BUSY;
+        pthread_mutex_unlock(&r->mu);
+        const int ulen = bgzf_inflate(s->cbuf, s->total, s->hdr, s->ubuf);
+        pthread_mutex_lock(&r->mu);
+        s->ulen = ulen;
+        s->state = ulen < 0 ? SLOT_BAD : SLOT_DONE;
+        pthread_cond_broadcast(&r->cv_done);
+    }
+    pthread_mutex_unlock(&r->mu);
+    return NULL;
+}
+
+static void bgzf_pool_start(bgzf_reader* r)
+{
+    r->ring = calloc(BGZF_RING, sizeof(bgzf_slot));
+    pthread_mutex_init(&r->mu, NULL);
+    pthread_cond_init(&r->cv_work, NULL);
+    pthread_cond_init(&r->cv_done, NULL);
+    r->head = r->tail = r->next_job = 0;
+    r->stop = 0;
+    int ok = 0;
+    for (int i = 0; i < r->nworkers; i++)
+        if (pthread_create(&r->workers[ok], NULL, bgzf_worker, r) == 0) ok++;
+    r->nworkers = ok;
+    r->started = ok > 0;
+}
+
+/* forget everything read ahead (a seek): wait for the inflates in flight, then empty the ring */
+static void bgzf_pool_reset(bgzf_reader* r)
+{
+    if (!r->started) return;
+    pthread_mutex_lock(&r->mu);
+    for (int i = r->head; i < r->tail; i++)
+        while (r->ring[i % BGZF_RING].state == SLOT_BUSY) pthread_cond_wait(&r->cv_done, &r->mu);
+    for (int i = 0; i < BGZF_RING; i++) r->ring[i].state = SLOT_FREE;
+    r->head = r->tail = r->next_job = 0;
+    r->fill_eof = 0;
+    pthread_mutex_unlock(&r->mu);
+}
+
+void bgzf_close(bgzf_reader* r)
+{
+    if (!r) return;
+    if (r->started) {
+        pthread_mutex_lock(&r->mu);
+        r->stop = 1;
+        pthread_cond_broadcast(&r->cv_work);
+        pthread_mutex_unlock(&r->mu);
+        for (int i = 0; i < r->nworkers; i++) pthread_join(r->workers[i], NULL);
+        pthread_mutex_destroy(&r->mu);
+        pthread_cond_destroy(&r->cv_work);
+        pthread_cond_destroy(&r->cv_done);
+    }
+    free(r->ring);
+    fclose(r->fp);
+    free(r);
+}
+
+/* the read-ahead path of bgzf_load_block: block at r->next_coff from the ring */
+static int bgzf_load_ahead(bgzf_reader* r)
+{
+    pthread_mutex_lock(&r->mu);
+    if (r->head == r->tail) { r->fill_coff = r->next_coff; r->fill_eof = 0; }     /* ring empty: (re)start here */
+    /* top the ring up (this thread does all the file I/O) */
+    while (!r->fill_eof && r->tail - r->head < BGZF_RING) {
+        bgzf_slot* s = &r->ring[r->tail % BGZF_RING];
+        pthread_mutex_unlock(&r->mu);
+        int hdr = 0;
+        const int total = bgzf_fetch(r->fp, r->fill_coff, s->cbuf, &hdr);
+        pthread_mutex_lock(&r->mu);
+        s->coff = r->fill_coff;
+        if (total <= 0) { s->total = total; s->state = total == 0 ? SLOT_DONE : SLOT_BAD; s->ulen = total == 0 ? -2 : -1; r->fill_eof = 1; }
+        else { s->total = total; s->hdr = hdr; s->state = SLOT_LOADED; r->fill_coff += total; }
+        r->tail++;
+        pthread_cond_signal(&r->cv_work);
+    }
+    bgzf_slot* s = &r->ring[r->head % BGZF_RING];
+    while (s->state == SLOT_LOADED || s->state == SLOT_BUSY) pthread_cond_wait(&r->cv_done, &r->mu);
+    int rc;
+    if (s->state == SLOT_BAD) rc = -1;
+    else if (s->ulen == -2) { r->eof = 1; r->ulen = r->upos = 0; rc = 0; }
+    else {
+        memcpy(r->ubuf, s->ubuf, (size_t)s->ulen);
+        r->block_coff = s->coff;
+        r->next_coff = s->coff + s->total;
+        r->ulen = s->ulen; r->upos = 0;
+        rc = 1;
+    }
+    s->state = SLOT_FREE;
+    r->head++;
+    pthread_mutex_unlock(&r->mu);
+    return rc;
+}
+
+/* loads the block at r->next_coff; returns 1, 0 at EOF, -1 on error */
+static int bgzf_load_block(bgzf_reader* r)
+{
+    if (r->nworkers > 0 && ++r->run > BGZF_WARMUP) {      /* a run of consecutive blocks: read ahead from here on */
+        if (!r->started) bgzf_pool_start(r);
+        if (r->started) return bgzf_load_ahead(r);
+    }
+    int hdr = 0;
+    const int total = bgzf_fetch(r->fp, r->next_coff, r->cbuf, &hdr);
+    if (total == 0) { r->eof = 1; r->ulen = r->upos = 0; return 0; }
+    if (total < 0) return -1;
+    const int ulen = bgzf_inflate(r->cbuf, total, hdr, r->ubuf);
+    if (ulen < 0) return -1;
     r->block_coff = r->next_coff;
     r->next_coff += total;
     r->ulen = ulen; r->upos = 0;
@@ -116,6 +268,8 @@ int64_t bgzf_tell(const bgzf_reader* r)
 
 int bgzf_seek(bgzf_reader* r, int64_t voffset)
 {
+    bgzf_pool_reset(r);
+    r->run = 0;
     r->eof = 0;
     r->next_coff = voffset >> 16;
     r->ulen = r->upos = 0;

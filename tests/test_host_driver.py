@@ -38,7 +38,7 @@ def _build_shim():
             os.path.join(ROOT, "tests", "shim", "im_shim.c"), os.path.join(ROOT, "oracle", "im_oracle.c")]
     if os.path.exists(SHIM) and all(os.path.getmtime(s) <= os.path.getmtime(SHIM) for s in srcs):
         return SHIM
-    subprocess.check_call(["gcc", "-O2", "-std=c11", "-I" + os.path.join(ROOT, "include"),
+    subprocess.check_call(["gcc", "-O2", "-std=c11", "-pthread", "-I" + os.path.join(ROOT, "include"),
                            "-I" + os.path.join(ROOT, "indelminer_amd", "host"), "-o", SHIM] + srcs + ["-lz", "-lm"])
     return SHIM
 
