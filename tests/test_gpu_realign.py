@@ -93,6 +93,49 @@ def _synthetic_batch(seed, n, clen=200000, L=100, Rm=700):
     return contig.encode(), cases
 
 
+@pytest.mark.parametrize("k,g,Rm,maxdel", [(6, 0, 1500, 1000), (6, 0, 700, 6000), (6, 0, 2600, 9000), (5, 0, 1200, 1000),
+                                           (9, 0, 1500, 3000), (6, 2, 1500, 1000)])
+def test_hip_matches_oracle_on_wide_windows(gpu_ctx, k, g, Rm, maxdel):
+    """Windows wider than one histogram pass (1920 diagonals): the vote runs in chunks, the chunk's best band
+    is carried over, window starts are re-based per chunk.  Insert-size range and -s chosen so that the first,
+    the second, or both band searches of a read need 2 to 6 chunks; k = 6 (specialised), k = 5 (direct table),
+    k = 9 (hash table) and the gapped kernel all share that loop."""
+    from indelminer_amd import capi
+    contig, cases = _synthetic_batch(300 + k + Rm, 1200, clen=120000, Rm=Rm)
+    gpu_ctx.set_reference([contig])
+    kw = dict(klength=k, numgaps=g, maxdelsize=maxdel)
+    out, bad = _run_cases(gpu_ctx, capi, capi.params(**kw), ob.params(**kw), contig, cases,
+                          dump="gpurun_out/mismatch_wide_k%d_g%d_R%d.txt" % (k, g, Rm))
+    assert not bad, "%d of %d differ, first: %r" % (len(bad), len(cases), bad[0][:2])
+    assert int((out["status"] == 1).sum()) > 300
+    assert int(out["band"]["win_bytes"].max()) > 1920
+
+
+@pytest.mark.parametrize("k", [6, 7])
+def test_hip_matches_oracle_with_ambiguity_codes(gpu_ctx, k):
+    """N / IUPAC bytes in the contig and N in the reads: the k-mer code maps them to 0 (src/alignment.c:11-24)
+    while the alignment compares raw bytes (N matches N only, src/localalign.c:61-67) -- the packed and the
+    ASCII copy of the reference must disagree in exactly that way."""
+    from indelminer_amd import capi
+    contig, cases = _synthetic_batch(900 + k, 1500, clen=60000)
+    rng = random.Random(77)
+    cb = bytearray(contig)
+    for _ in range(600):
+        cb[rng.randrange(len(cb))] = ord(rng.choice("NRYKM"))
+    for start in (5000, 20000, 41000):
+        cb[start:start + rng.randint(30, 400)] = b"N" * len(cb[start:start + rng.randint(30, 400)])
+    contig = bytes(cb)
+    for c in cases[::3]:
+        r = list(c["read"])
+        r[rng.randrange(len(r))] = "N"
+        c["read"] = "".join(r)
+    gpu_ctx.set_reference([contig])
+    out, bad = _run_cases(gpu_ctx, capi, capi.params(klength=k), ob.params(klength=k), contig, cases,
+                          dump="gpurun_out/mismatch_iupac_k%d.txt" % k)
+    assert not bad, "%d of %d differ, first: %r" % (len(bad), len(cases), bad[0][:2])
+    assert int((out["status"] == 1).sum()) > 150
+
+
 @pytest.mark.parametrize("k", [6, 8])
 def test_hip_matches_oracle_on_seeded_batch(gpu_ctx, k):
     """5000 seeded reads with planted 1-50 bp indels (BASELINE config-2 shape, smaller)."""
