@@ -25,6 +25,11 @@ struct im_ctx {
     // reusable device workspace for the host-buffer entry points
     void* ws = nullptr;
     size_t ws_bytes = 0;
+    // pinned host staging of the host-buffer entry points, and a second stream for their copies
+    void* pin = nullptr;
+    size_t pin_bytes = 0;
+    hipStream_t copy_stream = nullptr, back_stream = nullptr;     // host -> device, device -> host
+    hipEvent_t ev_in[2] = {nullptr, nullptr}, ev_k[2] = {nullptr, nullptr}, ev_out[2] = {nullptr, nullptr};
     // resident depth array of the current contig (im_depth_build)
     int32_t* depth = nullptr;
     int32_t* depth_sums = nullptr;
@@ -73,6 +78,16 @@ int ensure_ws(im_ctx* ctx, size_t bytes)
     bytes = (bytes + (1u << 20) - 1) / (1u << 20) * (1u << 20);
     HIP_TRY(ctx, hipMalloc(&ctx->ws, bytes));
     ctx->ws_bytes = bytes;
+    return IM_OK;
+}
+
+int ensure_pin(im_ctx* ctx, size_t bytes)
+{
+    if (bytes <= ctx->pin_bytes) return IM_OK;
+    if (ctx->pin) { HIP_TRY(ctx, hipHostFree(ctx->pin)); ctx->pin = nullptr; ctx->pin_bytes = 0; }
+    bytes = (bytes + (1u << 20) - 1) / (1u << 20) * (1u << 20);
+    HIP_TRY(ctx, hipHostMalloc(&ctx->pin, bytes, hipHostMallocDefault));
+    ctx->pin_bytes = bytes;
     return IM_OK;
 }
 
@@ -133,6 +148,14 @@ void im_ctx_destroy(im_ctx* ctx)
     if (ctx->ws) (void)hipFree(ctx->ws);
     if (ctx->depth) (void)hipFree(ctx->depth);
     if (ctx->depth_sums) (void)hipFree(ctx->depth_sums);
+    if (ctx->pin) (void)hipHostFree(ctx->pin);
+    for (int i = 0; i < 2; i++) {
+        if (ctx->ev_in[i]) (void)hipEventDestroy(ctx->ev_in[i]);
+        if (ctx->ev_k[i]) (void)hipEventDestroy(ctx->ev_k[i]);
+        if (ctx->ev_out[i]) (void)hipEventDestroy(ctx->ev_out[i]);
+    }
+    if (ctx->copy_stream) (void)hipStreamDestroy(ctx->copy_stream);
+    if (ctx->back_stream) (void)hipStreamDestroy(ctx->back_stream);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
 }
@@ -192,6 +215,10 @@ int im_dev_realign(im_ctx* ctx, const im_params* params, const im_dev_batch* bat
     return IM_OK;
 }
 
+// Host-buffer entry point.  The batch is cut into chunks that travel through a two-slot pipeline: chunk c is
+// packed into PINNED staging memory and copied in on one copy stream while chunk c-1 runs on the compute stream
+// and the results of chunk c-2 come back on another (hipMemcpyAsync from / to pinned memory throughout, stream-to-stream
+// events between the three stages), so that PCIe, the kernel and the host-side packing overlap.
 int im_realign_batch(im_ctx* ctx, const im_params* params, const im_read_batch* batch, im_read_result* out)
 {
     if (!ctx || !batch || !out) return IM_E_ARG;
@@ -201,51 +228,93 @@ int im_realign_batch(im_ctx* ctx, const im_params* params, const im_read_batch* 
     if (n < 0) { set_err(ctx, "negative batch size"); return IM_E_ARG; }
     if (n == 0) return IM_OK;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
-
-    // re-pack the reads at 4-byte aligned offsets (device layout requirement)
-    std::vector<int64_t> off((size_t)n);
-    std::vector<int32_t> len((size_t)n);
-    int64_t pos = 0;
+    if (!ctx->copy_stream) {
+        HIP_TRY(ctx, hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking));
+        HIP_TRY(ctx, hipStreamCreateWithFlags(&ctx->back_stream, hipStreamNonBlocking));
+        for (int i = 0; i < 2; i++) {
+            HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->ev_in[i], hipEventDisableTiming));
+            HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->ev_k[i], hipEventDisableTiming));
+            HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->ev_out[i], hipEventDisableTiming));
+        }
+    }
     for (int32_t i = 0; i < n; i++) {
         const int64_t l = batch->base_off[i + 1] - batch->base_off[i];
         if (l < 0 || l > 0x7fffffff) { set_err(ctx, "read %d has a bad length", i); return IM_E_ARG; }
-        off[i] = pos;
-        len[i] = (int32_t)l;
-        pos += (l + 3) & ~(int64_t)3;
     }
-    std::vector<uint8_t> packed((size_t)pos + 16, 0);
-    for (int32_t i = 0; i < n; i++)
-        memcpy(packed.data() + off[i], batch->bases + batch->base_off[i], (size_t)len[i]);
 
-    const size_t bases_bytes = up256(packed.size());
-    const size_t off_bytes = up256(sizeof(int64_t) * (size_t)n);
-    const size_t i32_bytes = up256(sizeof(int32_t) * (size_t)n);
-    const size_t res_bytes = up256(sizeof(im_read_result) * (size_t)n);
-    rc = ensure_ws(ctx, bases_bytes + off_bytes + 4 * i32_bytes + res_bytes);
+    constexpr int32_t kChunk = 32768;                      // reads per pipeline stage
+    const int32_t cn = n < kChunk ? n : kChunk;
+    // per-slot layout (identical on the device and in pinned memory): bases (worst case from the batch), off, len, tid, anchor, range, results
+    int64_t max_bases = 0;
+    for (int32_t c0 = 0; c0 < n; c0 += kChunk) {
+        const int32_t c1 = c0 + kChunk < n ? c0 + kChunk : n;
+        int64_t b = 0;
+        for (int32_t i = c0; i < c1; i++) b += ((batch->base_off[i + 1] - batch->base_off[i]) + 3) & ~(int64_t)3;
+        if (b > max_bases) max_bases = b;
+    }
+    const size_t bases_bytes = up256((size_t)max_bases + 16);
+    const size_t off_bytes = up256(sizeof(int64_t) * (size_t)cn);
+    const size_t i32_bytes = up256(sizeof(int32_t) * (size_t)cn);
+    const size_t res_bytes = up256(sizeof(im_read_result) * (size_t)cn);
+    const size_t in_bytes = bases_bytes + off_bytes + 4 * i32_bytes;
+    const size_t slot_bytes = in_bytes + res_bytes;
+    rc = ensure_ws(ctx, 2 * slot_bytes);
     if (rc) return rc;
-    char* w = static_cast<char*>(ctx->ws);
-    uint8_t* d_bases = (uint8_t*)w; w += bases_bytes;
-    int64_t* d_off = (int64_t*)w; w += off_bytes;
-    int32_t* d_len = (int32_t*)w; w += i32_bytes;
-    int32_t* d_tid = (int32_t*)w; w += i32_bytes;
-    int32_t* d_anchor = (int32_t*)w; w += i32_bytes;
-    int32_t* d_range = (int32_t*)w; w += i32_bytes;
-    im_read_result* d_res = (im_read_result*)w;
-
-    HIP_TRY(ctx, hipMemcpyAsync(d_bases, packed.data(), packed.size(), hipMemcpyHostToDevice, ctx->stream));
-    HIP_TRY(ctx, hipMemcpyAsync(d_off, off.data(), sizeof(int64_t) * (size_t)n, hipMemcpyHostToDevice, ctx->stream));
-    HIP_TRY(ctx, hipMemcpyAsync(d_len, len.data(), sizeof(int32_t) * (size_t)n, hipMemcpyHostToDevice, ctx->stream));
-    HIP_TRY(ctx, hipMemcpyAsync(d_tid, batch->tid, sizeof(int32_t) * (size_t)n, hipMemcpyHostToDevice, ctx->stream));
-    HIP_TRY(ctx, hipMemcpyAsync(d_anchor, batch->anchor, sizeof(int32_t) * (size_t)n, hipMemcpyHostToDevice, ctx->stream));
-    HIP_TRY(ctx, hipMemcpyAsync(d_range, batch->range_max, sizeof(int32_t) * (size_t)n, hipMemcpyHostToDevice, ctx->stream));
-
-    im_dev_batch db;
-    db.n = n; db.bases = d_bases; db.base_off = d_off; db.read_len = d_len; db.tid = d_tid; db.anchor = d_anchor; db.range_max = d_range;
-    db.out = d_res;
-    db.ev_cls = nullptr; db.ev_b1 = nullptr; db.ev_b2 = nullptr;
-    rc = im_dev_realign(ctx, params, &db, ctx->stream);
+    rc = ensure_pin(ctx, 2 * slot_bytes);
     if (rc) return rc;
-    HIP_TRY(ctx, hipMemcpyAsync(out, d_res, sizeof(im_read_result) * (size_t)n, hipMemcpyDeviceToHost, ctx->stream));
+
+    const int32_t nchunks = (n + kChunk - 1) / kChunk;
+    auto collect = [&](int32_t c) -> int {                 // results of chunk c: pinned -> caller
+        const int sl = c & 1;
+        HIP_TRY(ctx, hipEventSynchronize(ctx->ev_out[sl]));
+        const int32_t c0 = c * kChunk, c1 = c0 + kChunk < n ? c0 + kChunk : n;
+        memcpy(out + c0, (char*)ctx->pin + (size_t)sl * slot_bytes + in_bytes, sizeof(im_read_result) * (size_t)(c1 - c0));
+        return IM_OK;
+    };
+    for (int32_t c = 0; c < nchunks; c++) {
+        const int sl = c & 1;
+        if (c >= 2) { rc = collect(c - 2); if (rc) return rc; }      // frees this slot's pinned and device halves
+        const int32_t c0 = c * kChunk, c1 = c0 + kChunk < n ? c0 + kChunk : n, m = c1 - c0;
+        char* hp = (char*)ctx->pin + (size_t)sl * slot_bytes;
+        char* dp = (char*)ctx->ws + (size_t)sl * slot_bytes;
+        uint8_t* h_bases = (uint8_t*)hp;
+        int64_t* h_off = (int64_t*)(hp + bases_bytes);
+        int32_t* h_len = (int32_t*)(hp + bases_bytes + off_bytes);
+        int32_t* h_tid = (int32_t*)(hp + bases_bytes + off_bytes + i32_bytes);
+        int32_t* h_anchor = (int32_t*)(hp + bases_bytes + off_bytes + 2 * i32_bytes);
+        int32_t* h_range = (int32_t*)(hp + bases_bytes + off_bytes + 3 * i32_bytes);
+        // re-pack the reads at 4-byte aligned offsets (device layout requirement), straight into pinned memory
+        int64_t pos = 0;
+        for (int32_t i = 0; i < m; i++) {
+            const int64_t l = batch->base_off[c0 + i + 1] - batch->base_off[c0 + i];
+            h_off[i] = pos; h_len[i] = (int32_t)l;
+            memcpy(h_bases + pos, batch->bases + batch->base_off[c0 + i], (size_t)l);
+            const int64_t padded = (l + 3) & ~(int64_t)3;
+            memset(h_bases + pos + l, 0, (size_t)(padded - l));
+            pos += padded;
+        }
+        memset(h_bases + pos, 0, 16);
+        memcpy(h_tid, batch->tid + c0, sizeof(int32_t) * (size_t)m);
+        memcpy(h_anchor, batch->anchor + c0, sizeof(int32_t) * (size_t)m);
+        memcpy(h_range, batch->range_max + c0, sizeof(int32_t) * (size_t)m);
+        HIP_TRY(ctx, hipMemcpyAsync(dp, hp, in_bytes, hipMemcpyHostToDevice, ctx->copy_stream));
+        HIP_TRY(ctx, hipEventRecord(ctx->ev_in[sl], ctx->copy_stream));
+        HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_in[sl], 0));
+
+        im_dev_batch db;
+        db.n = m; db.bases = (uint8_t*)dp; db.base_off = (int64_t*)(dp + bases_bytes);
+        db.read_len = (int32_t*)(dp + bases_bytes + off_bytes); db.tid = (int32_t*)(dp + bases_bytes + off_bytes + i32_bytes);
+        db.anchor = (int32_t*)(dp + bases_bytes + off_bytes + 2 * i32_bytes); db.range_max = (int32_t*)(dp + bases_bytes + off_bytes + 3 * i32_bytes);
+        db.out = (im_read_result*)(dp + in_bytes);
+        db.ev_cls = nullptr; db.ev_b1 = nullptr; db.ev_b2 = nullptr;
+        rc = im_dev_realign(ctx, params, &db, ctx->stream);
+        if (rc) return rc;
+        HIP_TRY(ctx, hipEventRecord(ctx->ev_k[sl], ctx->stream));
+        HIP_TRY(ctx, hipStreamWaitEvent(ctx->back_stream, ctx->ev_k[sl], 0));
+        HIP_TRY(ctx, hipMemcpyAsync(hp + in_bytes, dp + in_bytes, sizeof(im_read_result) * (size_t)m, hipMemcpyDeviceToHost, ctx->back_stream));
+        HIP_TRY(ctx, hipEventRecord(ctx->ev_out[sl], ctx->back_stream));
+    }
+    for (int32_t c = nchunks >= 2 ? nchunks - 2 : 0; c < nchunks; c++) { rc = collect(c); if (rc) return rc; }
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
 
     int worst = IM_OK;

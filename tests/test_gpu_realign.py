@@ -182,6 +182,36 @@ def test_hip_gapped_matches_oracle_on_seeded_batch(gpu_ctx, k, g):
     assert int((out["status"] == 1).sum()) > 500
 
 
+def test_host_entry_pipelines_large_batches(gpu_ctx):
+    """im_realign_batch cuts a batch into 32768-read chunks that overlap packing, PCIe and the kernel (pinned
+    staging, three streams).  70 000 reads = the same 5 000 reads fourteen times: every copy must come back
+    identical to the first, and the first 5 000 identical to a one-chunk call."""
+    from indelminer_amd import capi
+    contig, cases = _synthetic_batch(4242, 5000)
+    gpu_ctx.set_reference([contig])
+    reads = [c["read"].encode() for c in cases]
+    anchor = [c["anchor"] for c in cases]
+    rng = [c["range_max"] for c in cases]
+    rc, small = gpu_ctx.realign_batch(capi.params(), reads, [0] * 5000, anchor, rng)
+    rc, big = gpu_ctx.realign_batch(capi.params(), reads * 14, [0] * 70000, anchor * 14, rng * 14)
+    assert len(big) == 70000
+
+    def canon(r):       # the defined part of a record: ops / ev past their counts are not written by the kernel
+        ok = r["status"] == 1
+        ops = np.where(ok[:, None] & (np.arange(r["ops"].shape[1])[None, :] < r["n_ops"][:, None]), r["ops"], 0)
+        ev = r["ev"][:, 0]
+        evs = [np.where(ok & (r["n_ev"] > 0), ev[f], 0) for f in ("cls", "b1", "b2", "seg", "read_off", "lflank", "rflank", "nd_print", "nd_filter")]
+        return [r["status"], np.where(ok, r["ref_start"], 0), np.where(ok, r["n_ops"], 0), np.where(ok, r["n_ev"], 0),
+                r["n_band"], ops] + evs + [r["band"][f] for f in r["band"].dtype.names]
+
+    want = canon(small)
+    assert int((small["status"] == 1).sum()) > 2000
+    for rep in range(14):
+        got = canon(big[rep * 5000:(rep + 1) * 5000])
+        for a, b in zip(want, got):
+            assert np.array_equal(a, b), "copy %d differs" % rep
+
+
 def test_unsupported_is_loud(gpu_ctx):
     from indelminer_amd import capi
     gpu_ctx.set_reference([b"ACGT" * 500])
