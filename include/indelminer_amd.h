@@ -310,6 +310,7 @@ int  im_dev_upload(im_ctx* ctx, void* dst_dev, const void* src_host, size_t byte
 int  im_dev_download(im_ctx* ctx, void* dst_host, const void* src_dev, size_t bytes);
 /* The context's own stream (a hipStream_t) and a wait for it. */
 void* im_ctx_stream(im_ctx* ctx);
+int   im_ctx_device(im_ctx* ctx);                               /* the HIP device index the context lives on */
 int  im_stream_sync(im_ctx* ctx, void* stream);
 /* HIP-event stopwatch on a stream: create, record start / stop on the stream the
  * kernels are launched on, read the elapsed milliseconds (synchronises on stop). */

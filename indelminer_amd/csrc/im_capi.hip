@@ -564,6 +564,7 @@ int im_dev_download(im_ctx* ctx, void* dst_host, const void* src_dev, size_t byt
     return IM_OK;
 }
 void* im_ctx_stream(im_ctx* ctx) { return ctx ? (void*)ctx->stream : nullptr; }
+int im_ctx_device(im_ctx* ctx) { return ctx ? ctx->device : -1; }
 int im_stream_sync(im_ctx* ctx, void* stream)
 {
     if (!ctx) return IM_E_ARG;

@@ -72,6 +72,11 @@ int im_comm_init(im_ctx* ctx, const void* id_bytes, int rank, int world, im_comm
     if (!load_rccl()) return IM_E_HIP;
     ncclUniqueId id;
     memcpy(&id, id_bytes, IM_COMM_ID_BYTES);
+    // the communicator binds to the calling thread's current device: make that the context's
+    if (hipSetDevice(im_ctx_device(ctx)) != hipSuccess) {
+        snprintf(g_rccl.err, sizeof g_rccl.err, "hipSetDevice(%d) failed", im_ctx_device(ctx));
+        return IM_E_HIP;
+    }
     im_comm* c = new im_comm();
     c->ctx = ctx; c->rank = rank; c->world = world;
     ncclResult_t r = g_rccl.CommInitRank(&c->comm, world, id, rank);
