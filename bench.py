@@ -122,6 +122,10 @@ class Shard:
         self.d_recs = capi.DevBuf(ctx, 16 * self.rec_cap)
         self.d_gather = None
 
+    def set_rec_cap(self, cap):
+        self.rec_cap = int(cap)
+        self.d_recs = capi.DevBuf(self.ctx, 16 * self.rec_cap)
+
     def attach_comm(self, comm):
         self.comm = comm
         self.d_gather = capi.DevBuf(self.ctx, 16 * self.rec_cap * comm.world)
@@ -297,9 +301,27 @@ def main():
     ctx.set_reference([refs[0].tobytes()])
     shard = Shard(ctx, refs[0], cand, L)
     shard.tid = rank                          # contig id = rank: every rank owns one contig
+    # one step without the collective: it tells which cluster path fits and how many cluster records a
+    # shard produces, which sizes the fixed-capacity all-gather buffers (2x headroom, same on every rank)
+    shard.step()
+    shard.sync()
+    if shard.clusters()[0] < 0:          # more distinct breakpoints than the histogram path holds
+        shard.small = False
+        shard.step()
+        shard.sync()
     collective = None
     if world > 1 or os.environ.get("IM_BENCH_FORCE_COMM") == "1":
         try:
+            ncl = max(int(shard.clusters()[0]), 0)
+            if dist is not None:
+                import torch
+                t = torch.tensor([ncl], dtype=torch.int64)
+                dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                ncl = int(t[0])
+            cap = 1024
+            while cap < 2 * ncl:
+                cap *= 2
+            shard.set_rec_cap(cap)
             ids = [capi.comm_unique_id() if rank == 0 else None]
             if dist is not None:
                 dist.broadcast_object_list(ids, src=0)
@@ -322,10 +344,6 @@ def main():
         if dist is not None:
             dist.barrier()
 
-    shard.step()
-    shard.sync()
-    if shard.clusters()[0] < 0:          # more live evidence than the single-workgroup path holds
-        shard.small = False
     for _ in range(args.warmup):
         shard.step()
     barrier()
