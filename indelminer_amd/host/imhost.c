@@ -499,24 +499,33 @@ static void dispatch_record(driver* d, const bam_record* b)
             free(bases);
         }
     } else if (is_aligned && is_mate_aligned && is_proper_pair) {
-        seglist rln = seglist_from_record(b);
+        /* the CIGAR is judged on the record itself; the segment list (two allocations and the base
+         * decode) is only built for the few reads that go on.  The reference builds it for every
+         * proper pair (new_unaligned_readaln, src/indelminer.c:430) and would stop on N / H / P
+         * there, so those checks stay in front. */
         const char strand0 = is_rc ? '-' : '+';
         uint32_t numcdels = 0, numcins = 0, numcsclip = 0;
         int is_threeprime_clip = 0;
-        for (int i = 0; i < rln.n; i++) {
-            const int op = CIG_OP(rln.ops[i]);
+        const uint32_t* cig = BAMR_CIGAR(b);
+        const int ncig = b->n_cigar;
+        for (int i = 0; i < ncig; i++) {
+            const int op = CIG_OP(cig[i]);
+            if (op == OP_N || op == OP_H || op == OP_P) fatalf("Implement new_readseg_bam: CIGAR op %d", op);
+            if (op > OP_X) fatalf("Unhandled cigar operation");
             if (op == OP_D) numcdels++;
             if (op == OP_I) numcins++;
             if (op == OP_S) numcsclip++;
-            if (((strand0 == '+' && i == rln.n - 1) || (strand0 == '-' && i == 0)) && op == OP_S) is_threeprime_clip = 1;
+            if (((strand0 == '+' && i == ncig - 1) || (strand0 == '-' && i == 0)) && op == OP_S) is_threeprime_clip = 1;
         }
         const uint32_t numinteresting = numcdels + numcins + numcsclip;
+        seglist rln; rln.ops = NULL; rln.bases = NULL; rln.n = 0; rln.ref_start = 0;
         if (numinteresting > 0) {
             if (((numcsclip == 0) || (numcsclip == 1 && is_threeprime_clip)) && numcdels == 0 && numcins == 0) {
                 /* nothing to do (src/indelminer.c:457-460) */
             } else {
                 const int mmq = mate_mapq(b, 0);
                 if (mmq >= O.qthreshold) {
+                    rln = seglist_from_record(b);
                     const char* own_ref = d->sequences[b->tid];
                     evidence_t** bwa = xmalloc(sizeof(evidence_t*) * (size_t)(rln.n ? rln.n : 1));
                     const int nbwa = check_variants(&rln, strand0, b->mapq, qname, own_ref, bwa);
