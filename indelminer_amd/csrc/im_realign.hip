@@ -320,7 +320,7 @@ template <int KT>
 __device__ __forceinline__ uint32_t vote_unit_direct(WaveLds& s, const uint32_t (&cur)[8], uint32_t (&nxt)[8],
                                                      const uint8_t* __restrict__ src_next, bool more,
                                                      uint32_t bsh, uint32_t kmask, uint32_t i0, uint32_t span,
-                                                     uint32_t obase, bool multi, uint32_t mx)
+                                                     uint32_t obase, uint32_t off_limit, uint32_t mx)
 {
     // all eight table reads first, then the (rare) hits
     uint32_t v[8];
@@ -345,12 +345,14 @@ __device__ __forceinline__ uint32_t vote_unit_direct(WaveLds& s, const uint32_t 
         const uint32_t h = bit & 1u, sh = bit & 24u;
         const uint32_t x = h ? xb : xa;
         const uint32_t i = i0 + (h << 8) + (sh << 3);                    // + 64 * (4h + sh / 8)
-        if (i > span) continue;
         const uint32_t off = obase + i - ((x >> sh) & 255u);             // diagonal index - c0
-        if (multi && off >= (uint32_t)kDiagChunk) continue;
-        const uint32_t bsel = (off & 3u) * 8u;
-        const uint32_t old = atomicAdd(&s.diag[off >> 2], 1u << bsel);
-        mx = max(mx, ((old >> bsel) & 255u) + 1u);                       // this diagonal's count after the vote
+        // one predicate, one exec-mask change: a start past the window's last k-mer, or (several chunks
+        // only, off_limit is all ones otherwise) a diagonal that belongs to another chunk, does not vote
+        if (i <= span && off < off_limit) {
+            const uint32_t bsel = (off & 3u) * 8u;
+            const uint32_t old = atomicAdd(&s.diag[off >> 2], 1u << bsel);
+            mx = max(mx, ((old >> bsel) & 255u) + 1u);                   // this diagonal's count after the vote
+        }
     }
     return mx;
 }
@@ -383,7 +385,7 @@ __device__ __forceinline__ Band band_search(WaveLds& s, const uint8_t* __restric
     // matters: the read's true locus is a run of ~L consecutive hits, and with this mapping the run
     // is spread over all lanes instead of piling up in six of them.
     int bc = 0, bd = INT_MAX, bi = 0;                             // select_band's max, dist, indx
-    const bool multi = numdiag > (uint32_t)kDiagChunk;
+    const uint32_t off_limit = numdiag > (uint32_t)kDiagChunk ? (uint32_t)kDiagChunk : 0xFFFFFFFFu;
 
     for (uint32_t c0 = 0; c0 < numdiag; c0 += step) {
         const int p_lo = max(0, (int)c0 - (int)nq);
@@ -419,10 +421,10 @@ __device__ __forceinline__ Band band_search(WaveLds& s, const uint8_t* __restric
         if (DIRECT) {
             for (uint32_t u = 0; u < nunit; u += 2) {
                 mx = vote_unit_direct<KT>(s, wd, we, src + 128u * (u + 1u), u + 1 < nunit, bsh, kmask,
-                                          512u * u + (uint32_t)lane, span, obase, multi, mx);
+                                          512u * u + (uint32_t)lane, span, obase, off_limit, mx);
                 if (u + 1 < nunit)
                     mx = vote_unit_direct<KT>(s, we, wd, src + 128u * (u + 2u), u + 2 < nunit, bsh, kmask,
-                                              512u * (u + 1u) + (uint32_t)lane, span, obase, multi, mx);
+                                              512u * (u + 1u) + (uint32_t)lane, span, obase, off_limit, mx);
             }
         } else {
             for (uint32_t u = 0; u < nunit; u++) {
