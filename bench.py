@@ -282,6 +282,13 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
+    # stdout carries ONE JSON line and nothing else: gloo ("[Gloo] Rank 0 is connected ...") and librccl (its
+    # version banner) both print on file descriptor 1, so the descriptor points at stderr for the whole run
+    # and the line is written to the saved original at the end
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
+
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -297,7 +304,9 @@ def main():
     n_reads = rd.n
     n_cand = len(cand["index"])
 
-    ctx = capi.Context(local_rank)
+    # IM_BENCH_ONE_DEVICE=1: rehearsal of the multi-rank control flow on a one-GPU box (every rank on device 0;
+    # RCCL refuses duplicate devices, so the collective falls back to its note and the rest still runs)
+    ctx = capi.Context(0 if os.environ.get("IM_BENCH_ONE_DEVICE") == "1" else local_rank)
     ctx.set_reference([refs[0].tobytes()])
     shard = Shard(ctx, refs[0], cand, L)
     shard.tid = rank                          # contig id = rank: every rank owns one contig
@@ -325,16 +334,7 @@ def main():
             ids = [capi.comm_unique_id() if rank == 0 else None]
             if dist is not None:
                 dist.broadcast_object_list(ids, src=0)
-            # librccl prints a version banner on file descriptor 1 when a communicator is made; stdout of
-            # rank 0 must carry the one JSON line only, so descriptor 1 points at stderr meanwhile
-            sys.stdout.flush()
-            saved_fd = os.dup(1)
-            os.dup2(2, 1)
-            try:
-                shard.attach_comm(capi.Comm(ctx, ids[0], rank, world))
-            finally:
-                os.dup2(saved_fd, 1)
-                os.close(saved_fd)
+            shard.attach_comm(capi.Comm(ctx, ids[0], rank, world))
             collective = "rccl all-gather of per-shard cluster lists, %d B per rank per step" % (16 * shard.rec_cap)
         except Exception as e:                # plumbing failure must not hide the compute numbers
             collective = "NONE (RCCL unavailable: %s); shards ran independently" % e
@@ -429,7 +429,8 @@ def main():
             "cpu_baseline": cpu,
             "end_to_end": e2e,
         }
-        print(json.dumps(line))
+        sys.stdout.flush()
+        os.write(real_stdout, (json.dumps(line) + "\n").encode())
     if dist is not None:
         dist.destroy_process_group()
     ctx.close()

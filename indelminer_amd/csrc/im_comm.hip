@@ -10,6 +10,7 @@
 
 #include <dlfcn.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <rccl/rccl.h>
@@ -32,11 +33,31 @@ struct RcclApi {
     char err[256] = {0};
 } g_rccl;
 
+// The librccl to load is the one that belongs to the HIP runtime THIS library is linked with (found through
+// dladdr of a HIP entry point): a process that has imported torch for its control plane already carries
+// torch's own bundled librccl + libamdhip64 under the same sonames, and a communicator made by that copy would
+// run on a second HIP runtime that knows none of our allocations.  RTLD_LOCAL | RTLD_DEEPBIND keeps the copy
+// we load bound to its own symbols.
 bool load_rccl()
 {
     if (g_rccl.handle) return true;
-    const char* names[] = { "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1" };
-    for (const char* n : names) { g_rccl.handle = dlopen(n, RTLD_NOW | RTLD_GLOBAL); if (g_rccl.handle) break; }
+    char beside_hip[1024] = "";
+    Dl_info info;
+    if (dladdr(reinterpret_cast<const void*>(&hipGetDeviceCount), &info) && info.dli_fname) {
+        const char* slash = strrchr(info.dli_fname, '/');
+        if (slash && (size_t)(slash - info.dli_fname) + 16 < sizeof beside_hip) {
+            memcpy(beside_hip, info.dli_fname, (size_t)(slash - info.dli_fname) + 1);
+            strcat(beside_hip, "librccl.so.1");
+        }
+    }
+    char from_env[1024] = "";
+    if (const char* rp = getenv("ROCM_PATH")) snprintf(from_env, sizeof from_env, "%s/lib/librccl.so.1", rp);
+    const char* names[] = { beside_hip, from_env, "/opt/rocm/lib/librccl.so.1", "librccl.so.1", "librccl.so" };
+    for (const char* n : names) {
+        if (!n[0]) continue;
+        g_rccl.handle = dlopen(n, RTLD_NOW | RTLD_LOCAL | RTLD_DEEPBIND);
+        if (g_rccl.handle) break;
+    }
     if (!g_rccl.handle) { snprintf(g_rccl.err, sizeof g_rccl.err, "cannot load librccl: %s", dlerror()); return false; }
 #define LOAD(field, sym) \
     *(void**)(&g_rccl.field) = dlsym(g_rccl.handle, sym); \
