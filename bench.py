@@ -119,16 +119,21 @@ class Shard:
         self.tid = 0
         self.rec_cap = 16384
         self.comm = None
-        self.d_recs = capi.DevBuf(ctx, 16 * self.rec_cap)
         self.d_gather = None
 
     def set_rec_cap(self, cap):
-        self.rec_cap = int(cap)
-        self.d_recs = capi.DevBuf(self.ctx, 16 * self.rec_cap)
+        self.rec_cap = int(cap)         # before attach_comm, which allocates the record / gather buffers
 
     def attach_comm(self, comm):
+        """The all-gather gets a stream of its own and every buffer set its own record / gather buffers, so that
+        the collective of step i overlaps the cluster kernels of step i + 1 as well as the realign kernels."""
         self.comm = comm
-        self.d_gather = capi.DevBuf(self.ctx, 16 * self.rec_cap * comm.world)
+        self.comm_stream = capi.new_stream(self.ctx)
+        for cur in self.sets:
+            cur["recs"] = capi.DevBuf(self.ctx, 16 * self.rec_cap)
+            cur["gather"] = capi.DevBuf(self.ctx, 16 * self.rec_cap * comm.world)
+            cur["recorded"] = capi.Event(self.ctx)
+        self.d_gather = self.sets[0]["gather"]
 
     def _bind(self):
         """Pre-bound foreign calls of one step per buffer set: the step loop is host-issue bound otherwise
@@ -154,7 +159,9 @@ class Shard:
                 src = (cur["cls"], cur["b1"], cur["b2"]) if self.small else (self.d_dcls, self.d_db1, self.d_db2)
                 calls.append((L_.im_dev_cluster_records, (ctx.h, self.tid, self.d_counts.ptr, self.d_order.ptr, self.d_first.ptr,
                                                           self.d_count.ptr, src[0].ptr, src[1].ptr, src[2].ptr,
-                                                          self.d_recs.ptr, self.rec_cap, sc)))
+                                                          cur["recs"].ptr, self.rec_cap, sc)))
+                cur["to_comm_args"] = (cur["recorded"].h, sc, self.comm_stream)
+                cur["done_args_comm"] = (cur["clustered"].h, self.comm_stream)
             cur["realign_args"] = (ctx.h, C.byref(self.P), C.byref(cur["batch"]), st)
             cur["cluster_calls"] = calls
             cur["follow_args"] = (cur["realigned"].h, st, sc)
@@ -180,8 +187,12 @@ class Shard:
         for fn, args in cur["cluster_calls"]:
             rc = rc or fn(*args)
         if self.comm is not None:
-            self.comm.allgather(self.d_recs.ptr, self.d_gather.ptr, 16 * self.rec_cap, self.cluster_stream)
-        rc = rc or L_.im_event_record(*cur["done_args"])
+            rc = rc or L_.im_stream_follow(*cur["to_comm_args"])
+            self.comm.allgather(cur["recs"].ptr, cur["gather"].ptr, 16 * self.rec_cap, self.comm_stream)
+            rc = rc or L_.im_event_record(*cur["done_args_comm"])      # the set is free again once its gather is done
+            self.d_gather = cur["gather"]
+        else:
+            rc = rc or L_.im_event_record(*cur["done_args"])
         if rc:
             self.ctx._check(rc)
         self.d_res = cur["res"]
@@ -190,6 +201,8 @@ class Shard:
     def sync(self):
         self.ctx._check(capi.lib().im_stream_sync(self.ctx.h, self.ctx.stream))
         self.ctx._check(capi.lib().im_stream_sync(self.ctx.h, self.cluster_stream))
+        if self.comm is not None:
+            self.ctx._check(capi.lib().im_stream_sync(self.ctx.h, self.comm_stream))
 
     def results(self):
         return self.d_res.download(capi.RESULT_DTYPE, self.n)
