@@ -133,6 +133,27 @@ def test_host_logic_synthetic_1mb_crosses_flushes(synth_1mb):
     assert _run(_build_shim(), ["-i", "cfg.txt"], synth_1mb, "ref.fa", "aln.bam") == _golden("synth_1mb_30x")
 
 
+def test_host_io_readahead_is_transparent(synth_1mb, synth_tn):
+    """The BGZF read-ahead ring (inflate worker threads, hostio.c) must not change a byte: whole-contig runs,
+    region runs (a seek, then a run of blocks long enough to start the pool, ending mid-stream) and annotate mode
+    (one fetch per known variant: seek after seek with the pool already running) with 0, 1 and 6 workers."""
+    shim = _build_shim()
+    runs = [(synth_1mb, ["-i", "cfg.txt"], "ref.fa", "aln.bam"),
+            (synth_1mb, ["-i", "cfg.txt", "-c", "ctg0:250000-700000"], "ref.fa", "aln.bam"),
+            (synth_1mb, ["-c", "ctg0:600001-990000"], "ref.fa", "aln.bam")]
+    for cwd, flags, fa, bam in runs:
+        outs = [_run(shim, flags, cwd, fa, bam, env={"INDELMINER_THREADS": t}) for t in ("0", "1", "6")]
+        assert outs[0] == outs[1] == outs[2] and outs[0].count(b"\n") > 20, flags
+    ann = []
+    for t in ("0", "6"):
+        os.environ["INDELMINER_THREADS"] = t
+        try:
+            ann.append(_annotate(shim, synth_tn))
+        finally:
+            del os.environ["INDELMINER_THREADS"]
+    assert ann[0] == ann[1]
+
+
 def test_host_logic_annotate_test_data():
     out = subprocess.run([_build_shim(), "-i", "indelminer.config", "-q", "0", "-a", "-e", "1", "reference.fa",
                           os.path.join(GOLD, "vcf", "default_config.vcf"), "normal=alignments.bam"], cwd=TD,
