@@ -393,7 +393,9 @@ int im_support_batch(im_ctx* ctx, int32_t n, const uint8_t* targets, const int64
     HIP_TRY(ctx, hipMemcpyAsync(d_q, queries, (size_t)q_off[n], hipMemcpyHostToDevice, ctx->stream));
     HIP_TRY(ctx, hipMemcpyAsync(d_to, t_off, sizeof(int64_t) * ((size_t)n + 1), hipMemcpyHostToDevice, ctx->stream));
     HIP_TRY(ctx, hipMemcpyAsync(d_qo, q_off, sizeof(int64_t) * ((size_t)n + 1), hipMemcpyHostToDevice, ctx->stream));
-    HIP_TRY(ctx, im::launch_support(n, d_t, d_to, d_q, d_qo, d_out, ctx->n_cu, ctx->stream));
+    int64_t max_t = 0;                                           // sizes the kernel's LDS
+    for (int32_t i = 0; i < n; i++) { const int64_t l = t_off[i + 1] - t_off[i]; if (l > max_t) max_t = l; }
+    HIP_TRY(ctx, im::launch_support(n, d_t, d_to, d_q, d_qo, d_out, (int32_t)(max_t > 0x7fffffff ? 0x7fffffff : max_t), ctx->n_cu, ctx->stream));
     HIP_TRY(ctx, hipMemcpyAsync(out, d_out, sizeof(int32_t) * 4 * (size_t)n, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     for (int32_t i = 0; i < n; i++)

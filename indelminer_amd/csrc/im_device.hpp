@@ -78,6 +78,6 @@ hipError_t launch_depth_query(int32_t nq, const int32_t* beg, const int32_t* end
                               uint32_t* out, hipStream_t stream);
 
 hipError_t launch_support(int32_t n_tasks, const uint8_t* targets, const int64_t* t_off,
-                          const uint8_t* queries, const int64_t* q_off, int32_t* out, int n_cu, hipStream_t stream);
+                          const uint8_t* queries, const int64_t* q_off, int32_t* out, int32_t max_target, int n_cu, hipStream_t stream);
 
 }  // namespace im

@@ -28,12 +28,25 @@ namespace {
 constexpr int kSwMaxTarget = 4095;
 constexpr int kDppWaveShr1S = 0x138;
 
+// LDS of one workgroup, sized by the launch for the longest target of the batch (cap = that length + 1,
+// rounded up to 4): the target bytes and the parked boundary row (V, F, stats).  A 150-base window costs
+// 2 KiB, so the CU fills with waves; sizing for kSwMaxTarget would leave three.
 struct SwLds {
-    uint8_t t1[kSwMaxTarget + 1];
-    int32_t rowV[kSwMaxTarget + 1];
-    int32_t rowF[kSwMaxTarget + 1];
-    uint32_t rowS[kSwMaxTarget + 1];
+    uint8_t*  t1;
+    int32_t*  rowV;
+    int32_t*  rowF;
+    uint32_t* rowS;
 };
+__device__ __forceinline__ SwLds sw_carve(unsigned char* base, int cap)
+{
+    SwLds s;
+    s.t1 = base;
+    s.rowV = reinterpret_cast<int32_t*>(base + cap);
+    s.rowF = s.rowV + cap;
+    s.rowS = reinterpret_cast<uint32_t*>(s.rowF + cap);
+    return s;
+}
+inline size_t sw_lds_bytes(int cap) { return (size_t)cap * 13; }
 
 __device__ __forceinline__ int sw_shr1(int old, int v) { return __builtin_amdgcn_update_dpp(old, v, kDppWaveShr1S, 0xf, 0xf, false); }
 __device__ __forceinline__ uint32_t up8(uint32_t c) { return (c >= 'a' && c <= 'z') ? c - 32u : c; }
@@ -44,15 +57,16 @@ constexpr uint32_t kStAligned = 1u, kStIndel = 1u << 12, kStSub = 1u << 24;
 __global__ __launch_bounds__(64) void support_kernel(int32_t n_tasks,
                                                     const uint8_t* __restrict__ targets, const int64_t* __restrict__ t_off,
                                                     const uint8_t* __restrict__ queries, const int64_t* __restrict__ q_off,
-                                                    int32_t* __restrict__ out /* n x 4: subs, indels, aligned, status */)
+                                                    int32_t* __restrict__ out /* n x 4: subs, indels, aligned, status */,
+                                                    int cap /* LDS capacity in target bases, multiple of 4 */)
 {
     extern __shared__ __align__(16) unsigned char smem_raw[];
-    SwLds& s = *reinterpret_cast<SwLds*>(smem_raw);
+    const SwLds s = sw_carve(smem_raw, cap);
     const int lane = threadIdx.x;
     for (int task = blockIdx.x; task < n_tasks; task += gridDim.x) {
         const int64_t to = t_off[task], qo = q_off[task];
         const int len1 = (int)(t_off[task + 1] - to), len2 = (int)(q_off[task + 1] - qo);
-        if (len1 > kSwMaxTarget || len2 > IM_MAX_READ || len1 < 0 || len2 < 0) {
+        if (len1 > kSwMaxTarget || len1 >= cap || len2 > IM_MAX_READ || len1 < 0 || len2 < 0) {
             if (lane == 0) { out[4 * task] = 0; out[4 * task + 1] = 0; out[4 * task + 2] = 0; out[4 * task + 3] = IM_ST_UNSUPPORTED; }
             continue;
         }
@@ -133,18 +147,24 @@ __global__ __launch_bounds__(64) void support_kernel(int32_t n_tasks,
 }  // namespace
 
 hipError_t launch_support(int32_t n_tasks, const uint8_t* targets, const int64_t* t_off,
-                          const uint8_t* queries, const int64_t* q_off, int32_t* out, int n_cu, hipStream_t stream)
+                          const uint8_t* queries, const int64_t* q_off, int32_t* out, int32_t max_target, int n_cu, hipStream_t stream)
 {
     if (n_tasks <= 0) return hipSuccess;
-    static bool attr_set = false;
-    if (!attr_set) {
+    if (max_target < 0) max_target = 0;
+    if (max_target > kSwMaxTarget) max_target = kSwMaxTarget;      // longer targets are reported per task
+    const int cap = (max_target + 1 + 3) & ~3;
+    const size_t lds = sw_lds_bytes(cap);
+    static size_t attr_bytes = 0;
+    if (lds > attr_bytes) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(support_kernel),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(SwLds));
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)sw_lds_bytes((kSwMaxTarget + 4) & ~3));
         if (e != hipSuccess) return e;
-        attr_set = true;
+        attr_bytes = sw_lds_bytes((kSwMaxTarget + 4) & ~3);
     }
-    int grid = n_tasks < n_cu * 3 ? n_tasks : n_cu * 3;
-    hipLaunchKernelGGL(support_kernel, dim3(grid), dim3(64), sizeof(SwLds), stream, n_tasks, targets, t_off, queries, q_off, out);
+    // one task per workgroup while that stays a sane grid: the dispatcher balances tasks of different cost
+    (void)n_cu;
+    const int grid = n_tasks < (1 << 20) ? n_tasks : (1 << 20);
+    hipLaunchKernelGGL(support_kernel, dim3(grid), dim3(64), lds, stream, n_tasks, targets, t_off, queries, q_off, out, cap);
     return hipGetLastError();
 }
 
