@@ -33,6 +33,7 @@ def plant_indels(rng, ref_len, spacing=2000, max_size=50, margin=1500, big_every
     every k-th event is a 150-900 bp deletion (discordant pairs -> PAIRED_READ / COMPOSITE calls)."""
     pos = np.arange(margin, ref_len - margin, spacing, dtype=np.int64)
     pos = pos + rng.integers(-spacing // 4, spacing // 4 + 1, size=len(pos))
+    pos = np.clip(pos, 600, ref_len - 600) if spacing > 20000 else pos     # a wide jitter (sparse events) must not leave the contig
     size = rng.integers(1, max_size + 1, size=len(pos))
     is_ins = rng.random(len(pos)) < 0.5
     if big_every:
