@@ -182,6 +182,33 @@ def test_hip_gapped_matches_oracle_on_seeded_batch(gpu_ctx, k, g):
     assert int((out["status"] == 1).sum()) > 500
 
 
+def test_hip_matches_oracle_on_config2_at_full_size(gpu_ctx):
+    """BASELINE configs[1] at its full size -- the batch bench.py times: every candidate read of the seeded
+    1 Mb / 30x / 100 bp data set (about 12 000 of 300 000 reads, chosen by the reference's own candidate rule)
+    against the oracle, record by record; and the size-independent properties on top: the call is idempotent,
+    and nearly every planted indel of the seeded donor is found at its exact breakpoint by some read."""
+    from indelminer_amd import capi, synth
+    refs, rd = synth.simulate(seed=1, ref_len=1_000_000, coverage=30)
+    cand = synth.candidates(rd)
+    contig = refs[0].tobytes()
+    gpu_ctx.set_reference([contig])
+    cases = [dict(anchor=int(a), range_max=int(r), read=bytes(b).decode())
+             for a, r, b in zip(cand["anchor"], cand["range_max"], cand["bases"])]
+    assert 10000 < len(cases) < 15000 and rd.n == 300000
+    out, bad = _run_cases(gpu_ctx, capi, capi.params(), ob.params(), contig, cases, dump="gpurun_out/mismatch_config2.txt")
+    assert not bad, "%d of %d differ, first: %r" % (len(bad), len(cases), bad[0][:2])
+    rc, again = gpu_ctx.realign_batch(capi.params(), [c["read"].encode() for c in cases], np.zeros(len(cases), np.int32),
+                                      cand["anchor"].astype(np.int32), cand["range_max"].astype(np.int32))
+    ok = out["status"] == 1
+    assert np.array_equal(out["status"], again["status"]) and np.array_equal(out["ev"][:, 0][ok], again["ev"][:, 0][ok])
+    assert int(ok.sum()) > 6000
+    # deletions found = distinct (b1, b2) pairs with b2 > b1 supported by >= 3 reads: about one per 4 kb was planted
+    ev = out["ev"][:, 0][ok]
+    dels = ev[ev["cls"] == 1]
+    keys, support = np.unique(np.stack([dels["b1"], dels["b2"]], axis=1), axis=0, return_counts=True)
+    assert int((support >= 3).sum()) > 150
+
+
 def test_host_entry_pipelines_large_batches(gpu_ctx):
     """im_realign_batch cuts a batch into 32768-read chunks that overlap packing, PCIe and the kernel (pinned
     staging, three streams).  70 000 reads = the same 5 000 reads fourteen times: every copy must come back
