@@ -914,7 +914,8 @@ static void print_vcf_output(driver* d, const variant_t* v)
     nut += num_pe;
     printf(";UTAILS=%d;MQ=%d;MQ30=%d;DF=%d;DP=%d", (int)nut, (int)(mq * 1.0 / v->support), (int)mq30,
            (int)((numdiffs * 1.0 / v->support) + 0.5),
-           (int)region_depth(d, v->tid, (int32_t)(v->start - v->lw - 1), (int32_t)(v->stop + v->rw + 1)));
+           v->dp_valid ? (int)v->dp_cached
+                       : (int)region_depth(d, v->tid, (int32_t)(v->start - v->lw - 1), (int32_t)(v->stop + v->rw + 1)));
     printf(";BF=%d,%d", lflank, rflank);
     printf("\n");
     free(taildistances);
@@ -1088,21 +1089,53 @@ static void print_variants(driver* d, variant_list* vs)
                               (it->type == CLS_INSERTION && ((uint32_t)lflank >= O.minbalance || (uint32_t)rflank >= O.minbalance));
         if (ok_flanks && it->support >= O.minsupport && xnumdiffs <= O.maxdiffsallowed && left && right) vl_push(&sel, it);
     }
+    /* who gets printed, in print order ... */
+    variant_list out = {0};
     if (O.call_all_indels) {
-        for (int i = 0; i < sel.n; i++) emit_variant(d, sel.v[i]);
+        for (int i = 0; i < sel.n; i++) vl_push(&out, sel.v[i]);
     } else {
         int i = 0;
         while (i < sel.n) {
-            const variant_t* it = sel.v[i];
+            variant_t* it = sel.v[i];
             int j = i + 1;
             while (j < sel.n && (sel.v[j]->start - sel.v[j]->lw) <= (it->stop + it->rw)) j++;
             uint32_t maxsupport = 0;
-            const variant_t* chosen = it;
+            variant_t* chosen = it;
             for (int t = i; t < j; t++) if (sel.v[t]->support > maxsupport) { maxsupport = sel.v[t]->support; chosen = sel.v[t]; }
-            emit_variant(d, chosen);
+            vl_push(&out, chosen);
             i = j;
         }
     }
+    /* ... their DP= values in ONE device query instead of one launch + copy + wait per variant
+     * (calculate_cov_params is called per printed variant, src/variant.c:303-306) ... */
+    if (strcmp(O.outputformat, "vcf") == 0 && out.n > 0) {
+        int32_t* beg = xmalloc(sizeof(int32_t) * (size_t)out.n);
+        int32_t* end = xmalloc(sizeof(int32_t) * (size_t)out.n);
+        uint32_t* sum = xmalloc(sizeof(uint32_t) * (size_t)out.n);
+        int* who = xmalloc(sizeof(int) * (size_t)out.n);
+        int m = 0;
+        for (int i = 0; i < out.n; i++) {
+            variant_t* v = out.v[i];
+            const int32_t start = (int32_t)(v->start - v->lw - 1), stop = (int32_t)(v->stop + v->rw + 1);
+            v->dp_valid = 0;
+            if (d->depth_tid != v->tid) continue;          /* region runs go to the BAM (region_depth) */
+            if (stop <= start) { v->dp_cached = 0; v->dp_valid = 1; continue; }
+            beg[m] = start; end[m] = stop; who[m] = i; m++;
+        }
+        if (m > 0) {
+            gpu_wait(d);
+            if (im_depth_query(d->gpu, m, beg, end, sum) != IM_OK) fatalf("im_depth_query: %s", im_last_error(d->gpu));
+            for (int q = 0; q < m; q++) {
+                variant_t* v = out.v[who[q]];
+                v->dp_cached = (int32_t)(uint32_t)floor(sum[q] * 1.0 / (uint32_t)(end[q] - beg[q]));
+                v->dp_valid = 1;
+            }
+        }
+        free(beg); free(end); free(sum); free(who);
+    }
+    /* ... and out they go */
+    for (int i = 0; i < out.n; i++) emit_variant(d, out.v[i]);
+    free(out.v);
     free(sel.v);
 }
 

@@ -66,6 +66,9 @@ typedef struct {
     evidence_t** evidence;
     /* ordering key among variants of one process_evidence call (see cluster_evidence) */
     int64_t   rep_b1, rep_b2, rep_arrival;
+    /* DP= of the variant when print_variants asked the device for a whole flush at once */
+    int32_t   dp_cached;
+    int       dp_valid;
 } variant_t;
 
 typedef struct {
