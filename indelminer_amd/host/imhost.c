@@ -348,6 +348,7 @@ typedef struct {
     bam_header* hdr;
     char** sequences; int64_t* seqlen;
     qhash* insertlengths;
+    char rg_last_name[256]; const int32_t* rg_last_val; const int32_t* rg_tmp_val;    /* one-entry cache of the lookup above */
     /* the GPU context is opened and the reference uploaded by a helper thread while the main
      * thread decodes the BAM (pass A needs no GPU); gpu_wait() joins it before the first GPU call */
     pthread_t gpu_thread;
@@ -480,9 +481,16 @@ static void dispatch_record(driver* d, const bam_record* b)
     const uint8_t* rg = bam_aux_find(b, "RG");
     const char* rgname = "generic";
     if (rg) rgname = bam_aux_str(rg);
-    qbin* rb = qhash_lookup(d->insertlengths, rgname, (int)strlen(rgname));
-    if (!rb) fatalf("did not find %s in the hash", rgname);
-    const int32_t* range = rb->val;
+    /* the table is fixed once the run starts and consecutive records nearly always share a read group:
+     * remember the last answer (same lookup, same fatal error on a miss) */
+    if (d->rg_last_val == NULL || strcmp(rgname, d->rg_last_name) != 0) {
+        qbin* rb = qhash_lookup(d->insertlengths, rgname, (int)strlen(rgname));
+        if (!rb) fatalf("did not find %s in the hash", rgname);
+        snprintf(d->rg_last_name, sizeof d->rg_last_name, "%s", rgname);
+        d->rg_last_val = strlen(rgname) < sizeof d->rg_last_name ? rb->val : NULL;     /* over-long names are not cached */
+        d->rg_tmp_val = rb->val;
+    } else d->rg_tmp_val = d->rg_last_val;
+    const int32_t* range = d->rg_tmp_val;
     const char* qname = BAMR_QNAME(b);
 
     if (is_aligned && !is_mate_aligned) {
