@@ -11,6 +11,10 @@ import bench  # noqa: E402
 
 refs, rd = synth.simulate(seed=1, ref_len=1_000_000, coverage=30)
 cand = synth.candidates(rd)
+if len(sys.argv) > 1:                       # fewer reads per step: is the loop bound by the host's launch rate?
+    import numpy as np
+    n_sub = int(sys.argv[1]); n_all = len(cand["index"])
+    cand = {k: (v[:n_sub] if isinstance(v, np.ndarray) and v.shape[:1] == (n_all,) else v) for k, v in cand.items()}
 ctx = capi.Context(0)
 ctx.set_reference([refs[0].tobytes()])
 sh = bench.Shard(ctx, refs[0], cand, 100)
