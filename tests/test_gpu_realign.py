@@ -111,6 +111,77 @@ def test_hip_matches_oracle_on_wide_windows(gpu_ctx, k, g, Rm, maxdel):
     assert int(out["band"]["win_bytes"].max()) > 1920
 
 
+@pytest.mark.parametrize("seed", [11, 12, 13])
+def test_hip_matches_oracle_fuzzed_parameters(gpu_ctx, seed):
+    """Every k the command line accepts (2..15), odd -n / -s values, short contigs (windows clipped at both
+    ends), reads of 4..255 bases, anchors on the contig's first and last bases: 40 parameter sets x 60 reads."""
+    from indelminer_amd import capi
+    rng = random.Random(seed)
+    for trial in range(40):
+        k = rng.choice([2, 3, 4, 5, 6, 7, 8, 10, 12, 13, 14, 15])
+        kw = dict(klength=k, numgaps=0, maxdelsize=rng.choice([50, 300, 1000, 2500]), ethreshold=rng.choice([1, 5, 10, 25]))
+        clen = rng.choice([300, 900, 2500, 20000])
+        contig = "".join(rng.choice("ACGT") for _ in range(clen))
+        cases = []
+        for _ in range(60):
+            L = rng.choice([4, 17, 36, 76, 100, 101, 150, 250, 255])
+            L = min(L, clen - 10)
+            Rm = rng.choice([60, 200, 705, 1500])
+            anchor = rng.choice([0, clen - 1, rng.randint(0, clen - 1)])
+            p = max(0, min(clen - L, anchor + rng.randint(-Rm, Rm)))
+            cut = rng.randint(1, max(1, L - 1))
+            d = rng.randint(1, 60)
+            typ = rng.random()
+            if typ < 0.45:
+                read = (contig[p:p + cut] + contig[p + cut + d:p + cut + d + (L - cut)])
+            elif typ < 0.8:
+                read = (contig[p:p + cut] + "".join(rng.choice("ACGT") for _ in range(d)) + contig[p + cut:p + L])[:L]
+            else:
+                read = contig[p:p + L]
+            if len(read) < 4:
+                read = contig[:4]
+            cases.append(dict(anchor=anchor, range_max=Rm, read=read))
+        gpu_ctx.set_reference([contig.encode()])
+        out, bad = _run_cases(gpu_ctx, capi, capi.params(**kw), ob.params(**kw), contig.encode(), cases,
+                              dump="gpurun_out/mismatch_fuzz_%d_%d.txt" % (seed, trial))
+        assert not bad, "%r: %d of %d differ, first: %r" % (kw, len(bad), len(cases), bad[0][:2])
+
+
+def test_hip_gapped_matches_oracle_fuzzed_parameters(gpu_ctx):
+    """The banded affine-gap kernel over -g 1..12 and k 4..12 on short contigs and odd read lengths: every
+    comparison of the reference's traceback keeps its strictness, so co-optimal paths must come out the same."""
+    from indelminer_amd import capi
+    rng = random.Random(99)
+    for trial in range(14):
+        kw = dict(klength=rng.choice([4, 6, 6, 8, 12]), numgaps=rng.choice([1, 2, 3, 5, 8, 12]),
+                  maxdelsize=rng.choice([300, 1000]), ethreshold=rng.choice([5, 10]))
+        clen = rng.choice([900, 4000, 20000])
+        contig = "".join(rng.choice("ACGT") for _ in range(clen))
+        cases = []
+        for _ in range(40):
+            L = min(rng.choice([36, 76, 100, 150, 250]), clen - 10)
+            Rm = rng.choice([200, 705])
+            anchor = rng.randint(0, clen - 1)
+            p = max(0, min(clen - L, anchor + rng.randint(-Rm, Rm)))
+            cut = rng.randint(1, max(1, L - 1))
+            d = rng.randint(1, 12)
+            typ = rng.random()
+            if typ < 0.45:
+                read = contig[p:p + cut] + contig[p + cut + d:p + cut + d + (L - cut)]
+            elif typ < 0.85:
+                read = (contig[p:p + cut] + "".join(rng.choice("ACGT") for _ in range(d)) + contig[p + cut:p + L])[:L]
+            else:
+                read = contig[p:p + L]
+            read = "".join((rng.choice("ACGT") if rng.random() < 0.01 else ch) for ch in read)
+            if len(read) < 4:
+                read = contig[:4]
+            cases.append(dict(anchor=anchor, range_max=Rm, read=read))
+        gpu_ctx.set_reference([contig.encode()])
+        out, bad = _run_cases(gpu_ctx, capi, capi.params(**kw), ob.params(**kw), contig.encode(), cases,
+                              dump="gpurun_out/mismatch_gapfuzz_%d.txt" % trial)
+        assert not bad, "%r: %d of %d differ, first: %r" % (kw, len(bad), len(cases), bad[0][:2])
+
+
 @pytest.mark.parametrize("k", [6, 7])
 def test_hip_matches_oracle_with_ambiguity_codes(gpu_ctx, k):
     """N / IUPAC bytes in the contig and N in the reads: the k-mer code maps them to 0 (src/alignment.c:11-24)
