@@ -12,7 +12,11 @@ from tests.support import compare, oraclebind as ob, refbind
 pytestmark = pytest.mark.skipif(not refbind.available(), reason="oracle/_ref not built (make -C oracle ref)")
 
 
-@pytest.mark.parametrize("k,g,seed", [(6, 0, 11), (6, 1, 12), (8, 2, 13), (5, 0, 14)])
+@pytest.mark.parametrize("k,g,seed", [(6, 0, 11), (6, 1, 12), (8, 2, 13), (5, 0, 14),
+                                      (2, 0, 21), (3, 0, 22), (4, 0, 23), (7, 0, 24), (10, 0, 25), (11, 0, 26),
+                                      (6, 3, 31), (6, 5, 32), (6, 8, 33), (6, 12, 34), (11, 4, 35)])
+# k stops at 11 here: the reference allocates and clears two 4^k-entry tables per band search
+# (src/alignment.c:38-39), 128 MB per call at k = 12 and 8 GB at k = 15
 def test_fuzz_against_reference(k, g, seed):
     rng = random.Random(seed)
     R = refbind.Ref()
@@ -38,9 +42,11 @@ def test_fuzz_against_reference(k, g, seed):
         if rng.random() < 0.3:
             i = rng.randrange(len(read))
             read = read[:i] + rng.choice("ACGT") + read[i + 1:]
-        ro = R.realign(buf, anchor, 500, read)
         st, res = ob.realign(P, cb, len(cb), anchor, 500, read)
+        if st == -1:             # the reference would exit(1) inside this process (forceassert): nothing to compare
+            continue
+        ro = R.realign(buf, anchor, 500, read)
         msg = compare.ref_vs_oracle(ro, st, res, read)
         assert msg is None, msg
         n_ev += 0 if ro is None else len(ro)
-    assert n_ev > 5
+    assert n_ev > 5 or k < 4          # two- and three-base seeds are never unique in a 100-base read: no band, no evidence
