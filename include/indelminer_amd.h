@@ -275,6 +275,107 @@ int im_dev_gather_evidence(im_ctx* ctx, const im_read_result* res, int32_t n,
                            void* stream);
 size_t im_dev_gather_scratch_bytes(int32_t n);
 
+/* ---- seam 0: record triage -- fetch_func's candidate rules on the device ------- */
+
+/* What fetch_func (src/indelminer.c:339-515) decides per delivered BAM record, done for a whole
+ * chunk of records at once: the flag / pairing filters (348-366), the read-group lookup (369-376),
+ * the three candidate cases with their mapping-quality gates (384-515), new_unaligned_readaln's
+ * 4-bit -> ASCII decode and the reverse complement (src/readaln.c:242-267, src/indelminer.c:404-409,
+ * 479-484), check_variants' CIGAR-derived evidence (285-337), and the read filter + match segments
+ * of the DP= pileup (src/shared.c:160-176, bam_pileup.c:171-172).  Discordant pairs (516-615) stay
+ * with the host's pair table; the kernel only labels them.
+ *
+ * Record classes (rec_class[], one byte per record): */
+#define IM_REC_SKIP          0  /* returned before the read was counted (348-366)                */
+#define IM_REC_COUNTED       1  /* counted (reaches 617), nothing to do                          */
+#define IM_REC_CAND_UNMAPPED 2  /* unmapped read, mapped mate: realign (384-424)                 */
+#define IM_REC_CAND_PROPER   3  /* proper pair with S/I/D: realign (425-515)                     */
+#define IM_REC_PE            4  /* not a proper pair, passes 519-521: the host's readpairs path  */
+#define IM_REC_ERR_RG       16  /* read group not in the insert-length table (must_find_hashtable exits) */
+#define IM_REC_ERR_MQ       17  /* MQ tag of an unmapped read is not an integer (forceassert 395-397) */
+#define IM_REC_ERR_CIGAR    18  /* N/H/P or unknown CIGAR op in a proper pair (new_readseg_bam exits) */
+#define IM_REC_ERR_CLIP     19  /* soft clip inside the CIGAR (forceassert in check_variants, 325) */
+#define IM_REC_ERR_BASE     20  /* base code outside A,C,G,T,N in a candidate (bit2char exits)   */
+#define IM_REC_ERR_LIMIT    21  /* more than IM_MAX_EV CIGAR-derived evidence, or a malformed record */
+
+/* the read-group -> range[1] table with the reference's hashtable semantics (16 bins, chains in
+ * prepend order, prefix match, last hit wins: src/hashtable.c:62-81, src/hashfunc.c:23-30).
+ * names[] in the ORDER THEY WERE ADDED to the table (config file order / first-seen order). */
+int im_set_insert_ranges(im_ctx* ctx, int32_t n, const char* const* names, const int32_t* range_max);
+
+/* A chunk of delivered records on the device: each record is the 32-byte BAM core followed by its
+ * variable part (qname, cigar, seq, qual, aux) exactly as in the file, WITHOUT the block_size word,
+ * starting at a 4-byte aligned offset.  rec_off has n + 1 entries. */
+typedef struct im_dev_records {
+    int32_t         n;
+    const uint8_t*  raw;
+    const uint32_t* rec_off;
+    int32_t         rec_base;   /* index of record 0 in the caller's numbering (goes into cand_rec) */
+} im_dev_records;
+
+typedef struct im_triage_params {
+    int32_t  qthreshold;            /* -q */
+    uint32_t ethreshold_vcfcheck;   /* -n (0 in annotate mode, src/indelminer.c:1074) */
+    uint32_t maxpedelsize;          /* -p */
+    int32_t  want_depth;            /* scatter the pileup match segments into the genome-wide difference array */
+} im_triage_params;
+
+/* Candidate batch under construction.  Candidates are APPENDED in record order: counters[0] = candidates
+ * so far, counters[1] = read bytes so far (both updated by every call), counters[2] = records counted,
+ * counters[3] = records with an IM_REC_ERR_* class.  batch holds the device arrays (capacity cap_cand
+ * reads / cap_bases bytes); batch.n is ignored.  The evidence slots of a candidate receive its
+ * CIGAR-derived evidence (check_variants); im_dev_realign later REPLACES them when the realignment
+ * finds evidence (src/indelminer.c:494-512) -- launch it with keep_slots = 1 (im_dev_realign_keep). */
+typedef struct im_dev_cands {
+    im_dev_batch batch;
+    int32_t*     cand_rec;      /* cap_cand: record index (rec_base + i) of every candidate      */
+    int32_t*     counters;      /* device int32[8]                                               */
+    uint8_t*     rec_class;     /* n records of the chunk (may be NULL)                          */
+    int32_t      cap_cand;
+    int64_t      cap_bases;
+} im_dev_cands;
+
+size_t im_dev_triage_scratch_bytes(int32_t n_records);
+int im_dev_triage(im_ctx* ctx, const im_triage_params* tp, const im_dev_records* recs,
+                  const im_dev_cands* out, void* scratch, size_t scratch_bytes, void* stream);
+
+/* im_dev_realign that leaves the evidence slots of reads WITHOUT realigned evidence untouched (the
+ * CIGAR-derived evidence im_dev_triage put there survives, as at src/indelminer.c:504-510). */
+int im_dev_realign_keep(im_ctx* ctx, const im_params* params, const im_dev_batch* batch, void* stream);
+
+/* ---- seam 2, streaming form: the READCHUNK flushes on the device ---------------- */
+
+/* process_evidence's node selection (src/indelminer.c:123-146) for one flush: among the PENDING
+ * entries (cls >= 0, consumed[] == 0) of up to two slot ranges, the entries that sort before the
+ * first (b1,b2)-sorted entry with b2 >= marker become graph nodes: consumed[slot] = flush_id (> 0).
+ * Range A = split-read evidence slots, range B = the host's paired-read evidence (cls = 2), which
+ * takes part in the cut but is clustered on the host.  cut_word: one device uint64 PER FLUSH, set to
+ * all ones beforehand (it receives the (b1,b2) of the cutting entry).  Asynchronous. */
+int im_dev_flush_cut(im_ctx* ctx, const int32_t* cls, const int32_t* b1, const int32_t* b2, int32_t* consumed,
+                     int32_t a0, int32_t a1, int32_t b0, int32_t b1_end,
+                     int32_t marker, int32_t flush_id, uint64_t* cut_word, void* stream);
+
+/* The split-read rule of add_node (src/graph.c:122-127) over every consumed slot of [0, n_slots):
+ * one cluster per distinct (consumed flush, class, b1, b2).  Output: cl_key[4 * c] = {flush_id, cls, b1,
+ * b2}, cl_first[c], cl_count[c] in no particular cluster order (the host orders the few clusters; the
+ * per-evidence work is done here); order[] = slot indices, cluster after cluster, members ascending in
+ * slot index (= arrival) or descending with tie_desc.  counts (device int32[2]) = {clusters, nodes}.
+ * Entries with cls >= 2 are ignored. */
+size_t im_dev_groupby_scratch_bytes(int32_t n_slots);
+int im_dev_cluster_groupby(im_ctx* ctx, int32_t n_slots, const int32_t* cls, const int32_t* b1, const int32_t* b2,
+                           const int32_t* consumed, int32_t tie_desc,
+                           int32_t* order, int32_t* cl_key, int32_t* cl_first, int32_t* cl_count, int32_t* counts,
+                           void* scratch, size_t scratch_bytes, void* stream);
+
+/* ---- seam 3, genome-wide form ----------------------------------------------------- */
+
+/* One int32 per reference position for ALL contigs (4 bytes per base of HBM), filled by im_dev_triage
+ * (want_depth) as a difference array; im_depth_scan turns contig tid into depths once all its records
+ * have been through triage; im_depth_query_tid sums [beg,end) like im_depth_query. */
+int im_depth_enable(im_ctx* ctx);
+int im_depth_scan(im_ctx* ctx, int32_t tid, void* stream);
+int im_depth_query_tid(im_ctx* ctx, int32_t tid, int32_t n, const int32_t* beg, const int32_t* end, uint32_t* sum_out);
+
 /* ---- multi-GPU: one collective ------------------------------------------------ */
 
 /* Contigs are independent (the reference's own parallel mode is one process per -c
@@ -308,6 +409,7 @@ int  im_dev_alloc(im_ctx* ctx, size_t bytes, void** out);
 int  im_dev_free(im_ctx* ctx, void* p);
 int  im_dev_upload(im_ctx* ctx, void* dst_dev, const void* src_host, size_t bytes);
 int  im_dev_download(im_ctx* ctx, void* dst_host, const void* src_dev, size_t bytes);
+int  im_dev_memset(im_ctx* ctx, void* dst_dev, int byte, size_t bytes, void* stream);     /* asynchronous */
 /* The context's own stream (a hipStream_t) and a wait for it. */
 void* im_ctx_stream(im_ctx* ctx);
 int   im_ctx_device(im_ctx* ctx);                               /* the HIP device index the context lives on */

@@ -69,6 +69,23 @@ class DevBatch(C.Structure):
                 ("ev_cls", C.c_void_p), ("ev_b1", C.c_void_p), ("ev_b2", C.c_void_p)]
 
 
+class DevRecords(C.Structure):
+    _fields_ = [("n", C.c_int32), ("raw", C.c_void_p), ("rec_off", C.c_void_p), ("rec_base", C.c_int32)]
+
+
+class TriageParams(C.Structure):
+    _fields_ = [("qthreshold", C.c_int32), ("ethreshold_vcfcheck", C.c_uint32), ("maxpedelsize", C.c_uint32),
+                ("want_depth", C.c_int32)]
+
+
+class DevCands(C.Structure):
+    _fields_ = [("batch", DevBatch), ("cand_rec", C.c_void_p), ("counters", C.c_void_p), ("rec_class", C.c_void_p),
+                ("cap_cand", C.c_int32), ("cap_bases", C.c_int64)]
+
+
+REC_SKIP, REC_COUNTED, REC_CAND_UNMAPPED, REC_CAND_PROPER, REC_PE = 0, 1, 2, 3, 4
+
+
 class IMError(RuntimeError):
     def __init__(self, code, msg):
         super().__init__("indelminer_amd error %d: %s" % (code, msg))
@@ -149,6 +166,23 @@ def lib():
         L.im_event_sync.argtypes = [C.c_void_p]
         L.im_stream_follow.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
         L.im_stream_wait_event.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+        L.im_dev_realign_keep.argtypes = [C.c_void_p, C.POINTER(Params), C.POINTER(DevBatch), C.c_void_p]
+        L.im_set_insert_ranges.argtypes = [C.c_void_p, C.c_int32, C.POINTER(C.c_char_p), C.c_void_p]
+        L.im_dev_triage_scratch_bytes.restype = C.c_size_t
+        L.im_dev_triage_scratch_bytes.argtypes = [C.c_int32]
+        L.im_dev_triage.argtypes = [C.c_void_p, C.POINTER(TriageParams), C.POINTER(DevRecords), C.POINTER(DevCands),
+                                    C.c_void_p, C.c_size_t, C.c_void_p]
+        L.im_dev_flush_cut.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                       C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]
+        L.im_dev_groupby_scratch_bytes.restype = C.c_size_t
+        L.im_dev_groupby_scratch_bytes.argtypes = [C.c_int32]
+        L.im_dev_cluster_groupby.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32,
+                                             C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                             C.c_void_p, C.c_size_t, C.c_void_p]
+        L.im_depth_enable.argtypes = [C.c_void_p]
+        L.im_depth_scan.argtypes = [C.c_void_p, C.c_int32, C.c_void_p]
+        L.im_depth_query_tid.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.im_dev_memset.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_size_t, C.c_void_p]
         L.im_capture_begin.argtypes = [C.c_void_p, C.c_void_p]
         L.im_capture_end.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(C.c_void_p)]
         L.im_graph_launch.argtypes = [C.c_void_p, C.c_void_p]
@@ -349,6 +383,26 @@ class Context:
         self._check(lib().im_support_batch(self.h, n, _ptr(t), _ptr(to), _ptr(q), _ptr(qo), _ptr(out)))
         return out[:n]
 
+    def set_insert_ranges(self, names, range_max):
+        """names in the order they entered the reference's insert-length table; range_max = range[1] of each."""
+        n = len(names)
+        arr = (C.c_char_p * max(n, 1))(*[x.encode() if isinstance(x, str) else x for x in names])
+        rm = np.ascontiguousarray(range_max, dtype=np.int32)
+        self._check(lib().im_set_insert_ranges(self.h, n, arr, _ptr(rm)))
+
+    def depth_enable(self):
+        self._check(lib().im_depth_enable(self.h))
+
+    def depth_scan(self, tid, stream=None):
+        self._check(lib().im_depth_scan(self.h, tid, self.stream if stream is None else stream))
+
+    def depth_query_tid(self, tid, beg, end):
+        beg = np.ascontiguousarray(beg, dtype=np.int32)
+        end = np.ascontiguousarray(end, dtype=np.int32)
+        out = np.zeros(max(len(beg), 1), dtype=np.uint32)
+        self._check(lib().im_depth_query_tid(self.h, tid, len(beg), _ptr(beg), _ptr(end), _ptr(out)))
+        return out[:len(beg)]
+
     def cluster_sr(self, cls, b1, b2, marker=2**31 - 1, tie_desc=0):
         n = len(cls)
         cls = np.ascontiguousarray(cls, dtype=np.int32)
@@ -363,6 +417,118 @@ class Context:
                                         _ptr(order), _ptr(first), _ptr(count), _ptr(used), C.byref(ncl)))
         k = ncl.value
         return order[:n], first[:k], count[:k], used[:n], k
+
+
+class Pipeline:
+    """The device-resident hot path the product driver runs per batch of contigs (indelminer_amd/host):
+    records -> triage (a1) -> realign (a2-a11) -> flush cuts -> group-by (a12).  Everything stays in HBM
+    between the stages; this class only owns the buffers and issues the im_dev_* calls in order."""
+
+    def __init__(self, ctx, n_records, raw_bytes, cap_cand, read_len_max=256, n_pe=0, n_flushes=64, want_depth=False,
+                 qthreshold=10, ethreshold_vcfcheck=10, maxpedelsize=1000000):
+        L = lib()
+        self.ctx = ctx
+        self.n_records = int(n_records)
+        self.cap_cand = int(cap_cand)
+        self.n_pe = int(n_pe)
+        self.cap_bases = self.cap_cand * ((read_len_max + 3) // 4 * 4) + 64
+        self.n_slots = self.cap_cand * MAX_EV + self.n_pe        # split-read slots, then the host's paired-read entries
+        self.d_raw = DevBuf(ctx, raw_bytes + 64)
+        self.d_off = DevBuf(ctx, 4 * (n_records + 1))
+        self.d_bases = DevBuf(ctx, self.cap_bases)
+        self.d_boff = DevBuf(ctx, 8 * self.cap_cand)
+        self.d_len = DevBuf(ctx, 4 * self.cap_cand)
+        self.d_tid = DevBuf(ctx, 4 * self.cap_cand)
+        self.d_anchor = DevBuf(ctx, 4 * self.cap_cand)
+        self.d_range = DevBuf(ctx, 4 * self.cap_cand)
+        self.d_res = DevBuf(ctx, 512 * self.cap_cand)
+        self.d_cls = DevBuf(ctx, 4 * self.n_slots)
+        self.d_b1 = DevBuf(ctx, 4 * self.n_slots)
+        self.d_b2 = DevBuf(ctx, 4 * self.n_slots)
+        self.d_consumed = DevBuf(ctx, 4 * self.n_slots)
+        self.d_cand_rec = DevBuf(ctx, 4 * self.cap_cand)
+        self.d_counters = DevBuf(ctx, 64)
+        self.d_class = DevBuf(ctx, max(n_records, 1))
+        self.ts_bytes = L.im_dev_triage_scratch_bytes(n_records)
+        self.d_ts = DevBuf(ctx, self.ts_bytes)
+        self.d_cut = DevBuf(ctx, 8 * max(n_flushes, 1))
+        self.n_flushes = n_flushes
+        self.d_order = DevBuf(ctx, 4 * self.n_slots)
+        self.d_clkey = DevBuf(ctx, 16 * self.n_slots)
+        self.d_clfirst = DevBuf(ctx, 4 * self.n_slots)
+        self.d_clcount = DevBuf(ctx, 4 * self.n_slots)
+        self.d_counts = DevBuf(ctx, 64)
+        self.gs_bytes = L.im_dev_groupby_scratch_bytes(self.n_slots)
+        self.d_gs = DevBuf(ctx, self.gs_bytes)
+        self.batch = DevBatch(0, self.d_bases.ptr, self.d_boff.ptr, self.d_len.ptr, self.d_tid.ptr, self.d_anchor.ptr,
+                              self.d_range.ptr, self.d_res.ptr, self.d_cls.ptr, self.d_b1.ptr, self.d_b2.ptr)
+        self.cands = DevCands(self.batch, self.d_cand_rec.ptr, self.d_counters.ptr, self.d_class.ptr, self.cap_cand, self.cap_bases)
+        self.recs = DevRecords(self.n_records, self.d_raw.ptr, self.d_off.ptr, 0)
+        self.tp = TriageParams(qthreshold, ethreshold_vcfcheck, maxpedelsize, 1 if want_depth else 0)
+        self.P = params()
+        self.n_cand = None
+
+    def upload(self, raw, rec_off):
+        self.d_raw.upload(raw)
+        self.d_off.upload(rec_off)
+
+    def set_pe(self, b1, b2):
+        """the host's paired-read evidence: entries behind the split-read slots, class 2"""
+        n = len(b1)
+        assert n <= self.n_pe
+        base = self.cap_cand * MAX_EV
+        L = lib()
+        for buf, arr in ((self.d_cls, np.full(n, 2, np.int32)), (self.d_b1, np.asarray(b1, np.int32)), (self.d_b2, np.asarray(b2, np.int32))):
+            if n:
+                self.ctx._check(L.im_dev_upload(self.ctx.h, buf.ptr + 4 * base, _ptr(np.ascontiguousarray(arr)), 4 * n))
+
+    def triage(self, stream=None):
+        """resets the running counters and the consumed marks, then classifies + compacts the records (asynchronous)"""
+        L = lib()
+        st = self.ctx.stream if stream is None else stream
+        c = self.ctx._check
+        c(L.im_dev_memset(self.ctx.h, self.d_counters.ptr, 0, 64, st))
+        c(L.im_dev_memset(self.ctx.h, self.d_consumed.ptr, 0, 4 * self.n_slots, st))
+        c(L.im_dev_memset(self.ctx.h, self.d_cut.ptr, 0xFF, 8 * self.n_flushes, st))
+        c(L.im_dev_triage(self.ctx.h, C.byref(self.tp), C.byref(self.recs), C.byref(self.cands), self.d_ts.ptr, self.ts_bytes, st))
+
+    def fetch_counts(self):
+        """the one host synchronisation of a batch: candidates found (sizes the realign grid)"""
+        self.sync()                         # the context's stream does not synchronise with the copy below by itself
+        c = self.d_counters.download(np.int32, 8)
+        self.n_cand = int(c[0])
+        return c
+
+    def realign(self, stream=None):
+        st = self.ctx.stream if stream is None else stream
+        self.batch.n = self.n_cand
+        self.ctx._check(lib().im_dev_realign_keep(self.ctx.h, C.byref(self.P), C.byref(self.batch), st))
+
+    def flush(self, k, cand_hi, pe_hi, marker, cand_lo=0, stream=None):
+        """flush number k (0-based; its id is k + 1): pending split-read slots of candidates [cand_lo, cand_hi) and
+        paired-read entries [0, pe_hi)"""
+        st = self.ctx.stream if stream is None else stream
+        base = self.cap_cand * MAX_EV
+        self.ctx._check(lib().im_dev_flush_cut(self.ctx.h, self.d_cls.ptr, self.d_b1.ptr, self.d_b2.ptr, self.d_consumed.ptr,
+                                               cand_lo * MAX_EV, cand_hi * MAX_EV, base, base + pe_hi, marker, k + 1,
+                                               self.d_cut.ptr + 8 * k, st))
+
+    def groupby(self, tie_desc=0, stream=None):
+        st = self.ctx.stream if stream is None else stream
+        n = self.n_cand * MAX_EV
+        self.ctx._check(lib().im_dev_cluster_groupby(self.ctx.h, n, self.d_cls.ptr, self.d_b1.ptr, self.d_b2.ptr, self.d_consumed.ptr,
+                                                     tie_desc, self.d_order.ptr, self.d_clkey.ptr, self.d_clfirst.ptr, self.d_clcount.ptr,
+                                                     self.d_counts.ptr, self.d_gs.ptr, self.gs_bytes, st))
+
+    def sync(self, stream=None):
+        self.ctx._check(lib().im_stream_sync(self.ctx.h, self.ctx.stream if stream is None else stream))
+
+    def clusters(self):
+        """(key[n,4] = flush id, class, b1, b2; first; count; order) after groupby + sync"""
+        k, nodes = (int(x) for x in self.d_counts.download(np.int32, 2))
+        key = self.d_clkey.download(np.int32, 4 * max(k, 1)).reshape(-1, 4)[:k]
+        return key, self.d_clfirst.download(np.int32, max(k, 1))[:k], self.d_clcount.download(np.int32, max(k, 1))[:k], \
+            self.d_order.download(np.int32, max(nodes, 1))[:nodes]
 
 
 COMM_ID_BYTES = 128

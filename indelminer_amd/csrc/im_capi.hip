@@ -34,6 +34,16 @@ struct im_ctx {
     int32_t* depth = nullptr;
     int32_t* depth_sums = nullptr;
     int64_t depth_cap = 0, depth_len = -1;
+    // host copies of the reference layout
+    std::vector<int64_t> h_asc_off;
+    std::vector<int32_t> h_len;
+    int64_t ref_total = 0;
+    // genome-wide depth / difference array (im_depth_enable): one int32 per byte of ref_ascii
+    int32_t* gdepth = nullptr;
+    int32_t* gdepth_sums = nullptr;
+    // read-group -> range[1] table (im_set_insert_ranges), flattened hashtable chains
+    void* rg_blob = nullptr;
+    im::RgTable rg = {nullptr, nullptr, nullptr, nullptr, nullptr};
 };
 
 namespace {
@@ -102,6 +112,10 @@ void free_reference(im_ctx* ctx)
     if (ctx->d_len) (void)hipFree(ctx->d_len);
     ctx->ref_ascii = nullptr; ctx->ref_pk = nullptr; ctx->d_asc_off = nullptr; ctx->d_pk_off = nullptr; ctx->d_len = nullptr;
     ctx->n_contigs = 0;
+    if (ctx->gdepth) (void)hipFree(ctx->gdepth);
+    if (ctx->gdepth_sums) (void)hipFree(ctx->gdepth_sums);
+    ctx->gdepth = nullptr; ctx->gdepth_sums = nullptr;
+    ctx->h_asc_off.clear(); ctx->h_len.clear(); ctx->ref_total = 0;
 }
 
 }  // namespace
@@ -148,6 +162,7 @@ void im_ctx_destroy(im_ctx* ctx)
     if (ctx->ws) (void)hipFree(ctx->ws);
     if (ctx->depth) (void)hipFree(ctx->depth);
     if (ctx->depth_sums) (void)hipFree(ctx->depth_sums);
+    if (ctx->rg_blob) (void)hipFree(ctx->rg_blob);
     if (ctx->pin) (void)hipHostFree(ctx->pin);
     for (int i = 0; i < 2; i++) {
         if (ctx->ev_in[i]) (void)hipEventDestroy(ctx->ev_in[i]);
@@ -194,10 +209,22 @@ int im_set_reference(im_ctx* ctx, int32_t n_contigs, const char* const* seqs, co
     HIP_TRY(ctx, im::launch_pack_reference(ctx->ref_ascii, ctx->ref_pk, total, ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     ctx->n_contigs = n_contigs;
+    ctx->h_asc_off = asc_off; ctx->h_len = len32; ctx->ref_total = total;
     return IM_OK;
 }
 
+static int dev_realign(im_ctx* ctx, const im_params* params, const im_dev_batch* batch, int keep, void* stream);
+
 int im_dev_realign(im_ctx* ctx, const im_params* params, const im_dev_batch* batch, void* stream)
+{
+    return dev_realign(ctx, params, batch, 0, stream);
+}
+int im_dev_realign_keep(im_ctx* ctx, const im_params* params, const im_dev_batch* batch, void* stream)
+{
+    return dev_realign(ctx, params, batch, 1, stream);
+}
+
+static int dev_realign(im_ctx* ctx, const im_params* params, const im_dev_batch* batch, int keep, void* stream)
 {
     if (!ctx || !batch) return IM_E_ARG;
     int rc = check_params(ctx, params);
@@ -211,7 +238,148 @@ int im_dev_realign(im_ctx* ctx, const im_params* params, const im_dev_batch* bat
     a.ref.n_contigs = ctx->n_contigs;
     a.batch = *batch;
     a.P = *params;
+    a.keep_slots = keep;
     HIP_TRY(ctx, im::launch_realign(a, ctx->n_cu, (hipStream_t)stream));
+    return IM_OK;
+}
+
+// ---- seam 0: record triage ---------------------------------------------------------------
+
+int im_set_insert_ranges(im_ctx* ctx, int32_t n, const char* const* names, const int32_t* range_max)
+{
+    if (!ctx || n < 0 || (n > 0 && (!names || !range_max))) return IM_E_ARG;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    // add_hashtable prepends to the chain of bin hash & 15 (src/hashtable.c:44-45): the chain order is the
+    // REVERSE of the order of insertion
+    std::vector<int32_t> bin(n);
+    for (int32_t i = 0; i < n; i++) {
+        const char* nm = names[i];
+        const int len = (int)strlen(nm);
+        uint32_t h = 5381u;
+        for (int k = len - 1; k >= 0; k--) h += (h << 5) + (uint32_t)(int)nm[k];
+        bin[i] = (int32_t)(h & 15u);
+    }
+    std::vector<int32_t> bin_start(17, 0), name_off(n ? n : 1), name_len(n ? n : 1), rmax(n ? n : 1);
+    std::vector<uint8_t> blob;
+    int32_t e = 0;
+    for (int b = 0; b < 16; b++) {
+        bin_start[b] = e;
+        for (int32_t i = n - 1; i >= 0; i--) {
+            if (bin[i] != b) continue;
+            name_off[e] = (int32_t)blob.size();
+            name_len[e] = (int32_t)strlen(names[i]);
+            rmax[e] = range_max[i];
+            blob.insert(blob.end(), names[i], names[i] + name_len[e] + 1);
+            e++;
+        }
+    }
+    bin_start[16] = e;
+    const size_t o1 = up256(17 * 4), o2 = o1 + up256((size_t)(n ? n : 1) * 4), o3 = o2 + up256((size_t)(n ? n : 1) * 4), o4 = o3 + up256((size_t)(n ? n : 1) * 4);
+    const size_t total = o4 + up256(blob.size() + 8);
+    if (ctx->rg_blob) { HIP_TRY(ctx, hipFree(ctx->rg_blob)); ctx->rg_blob = nullptr; }
+    HIP_TRY(ctx, hipMalloc(&ctx->rg_blob, total));
+    std::vector<uint8_t> host(total, 0);
+    memcpy(host.data(), bin_start.data(), 17 * 4);
+    if (n > 0) {
+        memcpy(host.data() + o1, name_off.data(), (size_t)n * 4);
+        memcpy(host.data() + o2, name_len.data(), (size_t)n * 4);
+        memcpy(host.data() + o3, rmax.data(), (size_t)n * 4);
+        memcpy(host.data() + o4, blob.data(), blob.size());
+    }
+    HIP_TRY(ctx, hipMemcpy(ctx->rg_blob, host.data(), total, hipMemcpyHostToDevice));
+    char* d = static_cast<char*>(ctx->rg_blob);
+    ctx->rg.bin_start = (const int32_t*)d; ctx->rg.name_off = (const int32_t*)(d + o1); ctx->rg.name_len = (const int32_t*)(d + o2);
+    ctx->rg.range_max = (const int32_t*)(d + o3); ctx->rg.names = (const uint8_t*)(d + o4);
+    return IM_OK;
+}
+
+size_t im_dev_triage_scratch_bytes(int32_t n_records) { return im::triage_scratch_bytes(n_records); }
+
+int im_dev_triage(im_ctx* ctx, const im_triage_params* tp, const im_dev_records* recs, const im_dev_cands* out,
+                  void* scratch, size_t scratch_bytes, void* stream)
+{
+    if (!ctx || !tp || !recs || !out) return IM_E_ARG;
+    if (!ctx->ref_ascii) { set_err(ctx, "im_set_reference has not been called"); return IM_E_ARG; }
+    if (!ctx->rg_blob) { set_err(ctx, "im_set_insert_ranges has not been called"); return IM_E_ARG; }
+    if (recs->n < 0 || !out->counters || !out->cand_rec) { set_err(ctx, "bad triage arguments"); return IM_E_ARG; }
+    if (scratch_bytes < im::triage_scratch_bytes(recs->n)) { set_err(ctx, "triage scratch too small"); return IM_E_ARG; }
+    if (tp->want_depth && !ctx->gdepth) { set_err(ctx, "want_depth without im_depth_enable"); return IM_E_ARG; }
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    im::RefDev ref;
+    ref.ascii = ctx->ref_ascii; ref.pk = reinterpret_cast<const uint8_t*>(ctx->ref_pk);
+    ref.asc_off = ctx->d_asc_off; ref.pk_off = ctx->d_pk_off; ref.len = ctx->d_len; ref.n_contigs = ctx->n_contigs;
+    HIP_TRY(ctx, im::launch_triage(ref, ctx->rg, ctx->gdepth, *tp, *recs, *out, scratch, (hipStream_t)stream));
+    return IM_OK;
+}
+
+// ---- seam 2, streaming form ------------------------------------------------------------------
+
+int im_dev_flush_cut(im_ctx* ctx, const int32_t* cls, const int32_t* b1, const int32_t* b2, int32_t* consumed,
+                     int32_t a0, int32_t a1, int32_t b0, int32_t b1_end, int32_t marker, int32_t flush_id,
+                     uint64_t* cut_word, void* stream)
+{
+    if (!ctx || !cut_word || flush_id <= 0) return IM_E_ARG;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, im::launch_flush_cut(cls, b1, b2, consumed, a0, a1, b0, b1_end, marker, flush_id, cut_word, (hipStream_t)stream));
+    return IM_OK;
+}
+
+size_t im_dev_groupby_scratch_bytes(int32_t n_slots) { return im::groupby_scratch_bytes(n_slots); }
+
+int im_dev_cluster_groupby(im_ctx* ctx, int32_t n_slots, const int32_t* cls, const int32_t* b1, const int32_t* b2,
+                           const int32_t* consumed, int32_t tie_desc,
+                           int32_t* order, int32_t* cl_key, int32_t* cl_first, int32_t* cl_count, int32_t* counts,
+                           void* scratch, size_t scratch_bytes, void* stream)
+{
+    if (!ctx || n_slots < 0 || !counts) return IM_E_ARG;
+    if (scratch_bytes < im::groupby_scratch_bytes(n_slots)) { set_err(ctx, "group-by scratch too small"); return IM_E_ARG; }
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    if (n_slots == 0) { HIP_TRY(ctx, hipMemsetAsync(counts, 0, 8, (hipStream_t)stream)); return IM_OK; }
+    HIP_TRY(ctx, im::launch_groupby(n_slots, cls, b1, b2, consumed, tie_desc, order, cl_key, cl_first, cl_count, counts, scratch, (hipStream_t)stream));
+    return IM_OK;
+}
+
+// ---- seam 3, genome-wide form ------------------------------------------------------------------
+
+int im_depth_enable(im_ctx* ctx)
+{
+    if (!ctx) return IM_E_ARG;
+    if (!ctx->ref_ascii) { set_err(ctx, "im_set_reference has not been called"); return IM_E_ARG; }
+    if (ctx->gdepth) return IM_OK;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    int64_t longest = 0;
+    for (int32_t l : ctx->h_len) if (l > longest) longest = l;
+    HIP_TRY(ctx, hipMalloc((void**)&ctx->gdepth, (size_t)ctx->ref_total * sizeof(int32_t)));
+    HIP_TRY(ctx, hipMalloc((void**)&ctx->gdepth_sums, (size_t)(im::depth_tiles(longest) + 1) * sizeof(int32_t)));
+    HIP_TRY(ctx, hipMemsetAsync(ctx->gdepth, 0, (size_t)ctx->ref_total * sizeof(int32_t), ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return IM_OK;
+}
+
+int im_depth_scan(im_ctx* ctx, int32_t tid, void* stream)
+{
+    if (!ctx || !ctx->gdepth || tid < 0 || tid >= ctx->n_contigs) return IM_E_ARG;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, im::launch_depth_scan(ctx->gdepth + ctx->h_asc_off[tid], (int64_t)ctx->h_len[tid] + 1, ctx->gdepth_sums, (hipStream_t)stream));
+    return IM_OK;
+}
+
+int im_depth_query_tid(im_ctx* ctx, int32_t tid, int32_t n, const int32_t* beg, const int32_t* end, uint32_t* sum_out)
+{
+    if (!ctx || n < 0 || !ctx->gdepth || tid < 0 || tid >= ctx->n_contigs) return IM_E_ARG;
+    if (n == 0) return IM_OK;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const size_t sb = up256(sizeof(int32_t) * (size_t)n);
+    int rc = ensure_ws(ctx, 3 * sb);
+    if (rc) return rc;
+    int32_t* d_beg = (int32_t*)ctx->ws;
+    int32_t* d_end = (int32_t*)((char*)ctx->ws + sb);
+    uint32_t* d_out = (uint32_t*)((char*)ctx->ws + 2 * sb);
+    HIP_TRY(ctx, hipMemcpyAsync(d_beg, beg, sizeof(int32_t) * (size_t)n, hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(ctx, hipMemcpyAsync(d_end, end, sizeof(int32_t) * (size_t)n, hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(ctx, im::launch_depth_query(n, d_beg, d_end, ctx->gdepth + ctx->h_asc_off[tid], ctx->h_len[tid], d_out, ctx->stream));
+    HIP_TRY(ctx, hipMemcpyAsync(sum_out, d_out, sizeof(uint32_t) * (size_t)n, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     return IM_OK;
 }
 
@@ -549,6 +717,13 @@ int im_dev_free(im_ctx* ctx, void* p)
     if (!ctx) return IM_E_ARG;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     HIP_TRY(ctx, hipFree(p));
+    return IM_OK;
+}
+int im_dev_memset(im_ctx* ctx, void* dst_dev, int byte, size_t bytes, void* stream)
+{
+    if (!ctx) return IM_E_ARG;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, hipMemsetAsync(dst_dev, byte, bytes, (hipStream_t)stream));
     return IM_OK;
 }
 int im_dev_upload(im_ctx* ctx, void* dst_dev, const void* src_host, size_t bytes)

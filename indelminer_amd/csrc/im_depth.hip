@@ -122,6 +122,13 @@ hipError_t launch_depth_build(int64_t clen, int32_t n_seg, const int32_t* seg_st
         if (b > 4096) b = 4096;
         hipLaunchKernelGGL(depth_scatter_kernel, dim3((int)b), dim3(256), 0, stream, n_seg, seg_start, seg_len, clen, depth);
     }
+    return launch_depth_scan(depth, n, sums, stream);
+}
+
+// difference array -> depths, in place: n elements, sums holds depth_tiles(n - 1) entries
+hipError_t launch_depth_scan(int32_t* depth, int64_t n, int32_t* sums, hipStream_t stream)
+{
+    if (n <= 0) return hipSuccess;
     const int64_t tiles = (n + kScanTile - 1) / kScanTile;
     hipLaunchKernelGGL(depth_scan_tiles_kernel, dim3((int)tiles), dim3(kScanBlock), 0, stream, depth, n, sums);
     hipLaunchKernelGGL(depth_scan_sums_kernel, dim3(1), dim3(kScanBlock), 0, stream, sums, tiles);

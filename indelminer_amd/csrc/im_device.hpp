@@ -33,7 +33,31 @@ struct RealignArgs {
     RefDev      ref;
     im_dev_batch batch;
     im_params   P;
+    int32_t     keep_slots;     // 1: evidence slots of reads without realigned evidence are left as they are
 };
+
+// The read-group -> range[1] table of the insert-length hashtable, flattened: 16 bins (qhash of
+// size 2^4, src/indelminer.c:702), entries of a bin in chain order (head first).
+struct RgTable {
+    const int32_t* bin_start;   // [17]
+    const int32_t* name_off;    // [n]
+    const int32_t* name_len;    // [n]
+    const int32_t* range_max;   // [n]
+    const uint8_t* names;
+};
+
+size_t triage_scratch_bytes(int32_t n_records);
+hipError_t launch_triage(const RefDev& ref, const RgTable& rg, int32_t* depth_diff, const im_triage_params& tp,
+                         const im_dev_records& recs, const im_dev_cands& out, void* scratch, hipStream_t stream);
+
+hipError_t launch_flush_cut(const int32_t* cls, const int32_t* b1, const int32_t* b2, int32_t* consumed,
+                            int32_t a0, int32_t a1, int32_t b0, int32_t b1_end, int32_t marker, int32_t flush_id,
+                            uint64_t* cut_word, hipStream_t stream);
+size_t groupby_scratch_bytes(int32_t n_slots);
+hipError_t launch_groupby(int32_t n_slots, const int32_t* cls, const int32_t* b1, const int32_t* b2, const int32_t* consumed,
+                          int32_t tie_desc, int32_t* order, int32_t* cl_key, int32_t* cl_first, int32_t* cl_count,
+                          int32_t* counts, void* scratch, hipStream_t stream);
+hipError_t launch_depth_scan(int32_t* depth, int64_t n, int32_t* sums, hipStream_t stream);
 
 // launchers (im_realign.hip / im_cluster.hip)
 hipError_t launch_pack_reference(const uint8_t* ascii, uint64_t* pk, int64_t n_bases_padded,

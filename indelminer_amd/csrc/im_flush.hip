@@ -1,0 +1,270 @@
+// im_flush.hip -- the READCHUNK flushes of process_evidence on gfx950, streaming form.
+//
+// process_evidence (src/indelminer.c:117-209) sorts the pending evidence by (b1,b2), makes a graph node
+// of every entry in front of the first one whose b2 >= marker (140-142, `break`), links split-read nodes
+// with identical (class, b1, b2) (add_node, src/graph.c:122-127) and turns components into variants.
+// Here that is two steps over evidence SLOT arrays that never leave the device:
+//
+//   flush cut   (once per flush, two small launches)  the cutting entry X = smallest (b1,b2) among the
+//               pending entries with b2 >= marker; every pending entry with (b1,b2) < X is consumed by this
+//               flush: consumed[slot] = flush id.  No sort: "in front of the first one" is a comparison
+//               with a minimum.  Paired-read evidence takes part (a second slot range the host fills) but
+//               is clustered on the host.
+//   group-by    (once per batch of contigs, any number of flushes)  one cluster per distinct
+//               (flush id, class, b1, b2) over all consumed split-read slots: open-addressing table keyed
+//               by a REPRESENTATIVE SLOT (32-bit CAS; keys are compared through the slot arrays, so no
+//               128-bit atomics), counts, one-workgroup offset scan over the distinct clusters, placement,
+//               and a per-cluster ordering of the members by slot index (= arrival order).
+//
+// Both are HBM streaming over 16 B per slot (class, b1, b2, consumed); the group-by adds 4 B per slot for the
+// table position and 4 B for order[].  The host receives cluster records, not evidence, and orders the
+// few clusters of a flush itself (sort_variants, src/variant.c:40-44, is host code in the reference too).
+
+#include "im_device.hpp"
+
+namespace im {
+namespace {
+
+__device__ __forceinline__ uint64_t cut_key(int32_t b1, int32_t b2) { return ((uint64_t)(uint32_t)b1 << 32) | (uint32_t)b2; }
+
+struct Ranges { int32_t a0, na, b0, nb; };
+__device__ __forceinline__ int32_t slot_of(const Ranges& R, int64_t i) { return i < R.na ? R.a0 + (int32_t)i : R.b0 + (int32_t)(i - R.na); }
+
+__global__ __launch_bounds__(256) void flush_min_kernel(Ranges R, const int32_t* __restrict__ cls, const int32_t* __restrict__ b1,
+                                                       const int32_t* __restrict__ b2, const int32_t* __restrict__ consumed,
+                                                       int32_t marker, unsigned long long* __restrict__ cut_word)
+{
+    const int64_t n = (int64_t)R.na + R.nb;
+    uint64_t best = ~0ull;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const int32_t s = slot_of(R, i);
+        if (cls[s] < 0 || consumed[s] != 0) continue;
+        const int32_t vb2 = b2[s];
+        if (vb2 >= marker) { const uint64_t k = cut_key(b1[s], vb2); if (k < best) best = k; }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const uint32_t lo = (uint32_t)__shfl_xor((int)(uint32_t)best, o), hi = (uint32_t)__shfl_xor((int)(uint32_t)(best >> 32), o);
+        const uint64_t ob = ((uint64_t)hi << 32) | lo;
+        if (ob < best) best = ob;
+    }
+    if ((threadIdx.x & 63) == 0 && best != ~0ull) atomicMin(cut_word, (unsigned long long)best);
+}
+
+__global__ __launch_bounds__(256) void flush_mark_kernel(Ranges R, const int32_t* __restrict__ cls, const int32_t* __restrict__ b1,
+                                                        const int32_t* __restrict__ b2, int32_t* __restrict__ consumed,
+                                                        int32_t flush_id, const unsigned long long* __restrict__ cut_word)
+{
+    const int64_t n = (int64_t)R.na + R.nb;
+    const uint64_t X = *cut_word;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const int32_t s = slot_of(R, i);
+        if (cls[s] < 0 || consumed[s] != 0) continue;
+        if (cut_key(b1[s], b2[s]) < X) consumed[s] = flush_id;
+    }
+}
+
+// ---- group-by ---------------------------------------------------------------------------------
+
+struct GroupScratch {
+    uint32_t* head;         // [H] representative slot + 1, 0 = empty
+    uint32_t* cnt;          // [H]
+    uint32_t* uid;          // [H] cluster id of the entry
+    uint32_t* slot_h;       // [n_slots] table position of a consumed split-read slot, ~0 otherwise
+    uint32_t* uniq;         // [n_slots] table positions in first-touch order
+    uint32_t* cursor;       // [n_slots] per cluster
+    uint32_t* misc;         // [0] distinct clusters
+    uint32_t  H;
+};
+
+__device__ __forceinline__ uint32_t mix32(uint32_t f, uint32_t c, uint32_t x1, uint32_t x2)
+{
+    uint64_t k = ((uint64_t)x1 << 32) | x2;
+    k ^= ((uint64_t)f << 17) | c;
+    k ^= k >> 33; k *= 0xff51afd7ed558ccdull; k ^= k >> 33; k *= 0xc4ceb9fe1a85ec53ull; k ^= k >> 33;
+    return (uint32_t)k;
+}
+
+__global__ __launch_bounds__(256) void group_insert_kernel(int32_t n_slots, const int32_t* __restrict__ cls, const int32_t* __restrict__ b1,
+                                                          const int32_t* __restrict__ b2, const int32_t* __restrict__ consumed, GroupScratch s)
+{
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n_slots; i += (int64_t)gridDim.x * blockDim.x) {
+        const int32_t c = cls[i], f = consumed[i];
+        if (c < 0 || c >= 2 || f <= 0) { s.slot_h[i] = 0xFFFFFFFFu; continue; }
+        const int32_t v1 = b1[i], v2 = b2[i];
+        uint32_t h = mix32((uint32_t)f, (uint32_t)c, (uint32_t)v1, (uint32_t)v2) & (s.H - 1);
+        for (;;) {
+            const uint32_t old = atomicCAS(&s.head[h], 0u, (uint32_t)i + 1u);
+            if (old == 0u) {
+                const uint32_t u = atomicAdd(&s.misc[0], 1u);
+                s.uniq[u] = h; s.uid[h] = u;
+                break;
+            }
+            const uint32_t rep = old - 1u;
+            if (consumed[rep] == f && cls[rep] == c && b1[rep] == v1 && b2[rep] == v2) break;
+            h = (h + 1u) & (s.H - 1);
+        }
+        atomicAdd(&s.cnt[h], 1u);
+        s.slot_h[i] = h;
+    }
+}
+
+// one workgroup: exclusive scan of the cluster sizes in first-touch order; writes the cluster records
+__global__ __launch_bounds__(1024) void group_offsets_kernel(GroupScratch s, const int32_t* __restrict__ cls, const int32_t* __restrict__ b1,
+                                                            const int32_t* __restrict__ b2, const int32_t* __restrict__ consumed,
+                                                            int32_t* __restrict__ cl_key, int32_t* __restrict__ cl_first, int32_t* __restrict__ cl_count,
+                                                            int32_t* __restrict__ counts)
+{
+    __shared__ uint32_t wsum[16];
+    __shared__ uint32_t carry_s;
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const uint32_t nu = s.misc[0];
+    if (t == 0) carry_s = 0;
+    __syncthreads();
+    for (uint32_t base = 0; base < nu; base += 1024u) {
+        const uint32_t u = base + (uint32_t)t;
+        uint32_t h = 0, c = 0;
+        if (u < nu) { h = s.uniq[u]; c = s.cnt[h]; }
+        uint32_t x = c;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) { const uint32_t y = (uint32_t)__shfl_up((int)x, o); if (lane >= o) x += y; }
+        if (lane == 63) wsum[wave] = x;
+        __syncthreads();
+        uint32_t woff = 0;
+        for (int w = 0; w < wave; w++) woff += wsum[w];
+        const uint32_t carry = carry_s;
+        if (u < nu) {
+            const uint32_t first = carry + woff + x - c;
+            const uint32_t rep = s.head[h] - 1u;
+            cl_first[u] = (int32_t)first; cl_count[u] = (int32_t)c;
+            cl_key[4 * (size_t)u + 0] = consumed[rep]; cl_key[4 * (size_t)u + 1] = cls[rep];
+            cl_key[4 * (size_t)u + 2] = b1[rep]; cl_key[4 * (size_t)u + 3] = b2[rep];
+        }
+        __syncthreads();
+        if (t == 1023) carry_s = carry + woff + x;
+        __syncthreads();
+    }
+    if (t == 0) { counts[0] = (int32_t)nu; counts[1] = (int32_t)carry_s; }
+}
+
+__global__ __launch_bounds__(256) void group_place_kernel(int32_t n_slots, GroupScratch s, const int32_t* __restrict__ cl_first, int32_t* __restrict__ order)
+{
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n_slots; i += (int64_t)gridDim.x * blockDim.x) {
+        const uint32_t h = s.slot_h[i];
+        if (h == 0xFFFFFFFFu) continue;
+        const uint32_t u = s.uid[h];
+        const uint32_t p = atomicAdd(&s.cursor[u], 1u);
+        order[(uint32_t)cl_first[u] + p] = (int32_t)i;
+    }
+}
+
+// one wave per cluster: members ascending by slot index (descending with tie_desc)
+constexpr int kGroupLds = 1024;
+__global__ __launch_bounds__(64) void group_finish_kernel(GroupScratch s, const int32_t* __restrict__ cl_first, const int32_t* __restrict__ cl_count,
+                                                         int32_t tie_desc, int32_t* __restrict__ order, int32_t* __restrict__ tmp)
+{
+    __shared__ int32_t st[kGroupLds];
+    const int lane = threadIdx.x;
+    const uint32_t nu = s.misc[0];
+    for (uint32_t u = blockIdx.x; u < nu; u += gridDim.x) {
+        const int32_t f = cl_first[u], cnt = cl_count[u];
+        if (cnt <= 1) continue;
+        if (cnt <= kGroupLds) {
+            for (int32_t t = lane; t < cnt; t += 64) st[t] = order[f + t];
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+            __builtin_amdgcn_wave_barrier();
+            for (int32_t t = lane; t < cnt; t += 64) {
+                const int32_t v = st[t];
+                int32_t r = 0;
+                for (int32_t j = 0; j < cnt; j++) r += (st[j] < v) ? 1 : 0;
+                order[f + (tie_desc ? (cnt - 1 - r) : r)] = v;
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+            __builtin_amdgcn_wave_barrier();
+        } else {
+            // rare (a breakpoint with more than 1024 supporting reads): rank by counting through global memory
+            for (int32_t t = lane; t < cnt; t += 64) tmp[f + t] = order[f + t];
+            __threadfence();
+            __builtin_amdgcn_wave_barrier();
+            for (int32_t t = lane; t < cnt; t += 64) {
+                const int32_t v = tmp[f + t];
+                int32_t r = 0;
+                for (int32_t j = 0; j < cnt; j++) r += (tmp[f + j] < v) ? 1 : 0;
+                order[f + (tie_desc ? (cnt - 1 - r) : r)] = v;
+            }
+        }
+    }
+}
+
+inline size_t up256(size_t x) { return (x + 255) / 256 * 256; }
+inline uint32_t group_table_size(int32_t n_slots)
+{
+    uint32_t H = 1024;
+    while (H < 2u * (uint32_t)(n_slots > 0 ? n_slots : 1)) H <<= 1;
+    return H;
+}
+inline size_t group_carve(GroupScratch* g, int32_t** tmp, void* base, int32_t n_slots)
+{
+    const uint32_t H = group_table_size(n_slots);
+    const size_t nn = (size_t)(n_slots > 0 ? n_slots : 1);
+    size_t off = 0;
+    auto take = [&](size_t bytes) { size_t o = off; off = up256(off + bytes); return o; };
+    // head, cnt, cursor, misc are contiguous: one memset clears them
+    const size_t oHead = take((size_t)H * 4), oCnt = take((size_t)H * 4), oCur = take(nn * 4), oMisc = take(64);
+    const size_t oUid = take((size_t)H * 4), oSlot = take(nn * 4), oUniq = take(nn * 4), oTmp = take(nn * 4);
+    if (g) {
+        char* b = static_cast<char*>(base);
+        g->head = (uint32_t*)(b + oHead); g->cnt = (uint32_t*)(b + oCnt); g->cursor = (uint32_t*)(b + oCur); g->misc = (uint32_t*)(b + oMisc);
+        g->uid = (uint32_t*)(b + oUid); g->slot_h = (uint32_t*)(b + oSlot); g->uniq = (uint32_t*)(b + oUniq);
+        g->H = H;
+        *tmp = (int32_t*)(b + oTmp);
+    }
+    (void)oMisc;
+    return off;
+}
+inline int grid_of(int64_t n, int threads, int cap)
+{
+    int64_t b = (n + threads - 1) / threads;
+    if (b < 1) b = 1;
+    if (b > cap) b = cap;
+    return (int)b;
+}
+
+}  // namespace
+
+hipError_t launch_flush_cut(const int32_t* cls, const int32_t* b1, const int32_t* b2, int32_t* consumed,
+                            int32_t a0, int32_t a1, int32_t b0, int32_t b1_end, int32_t marker, int32_t flush_id,
+                            uint64_t* cut_word, hipStream_t stream)
+{
+    Ranges R;
+    R.a0 = a0; R.na = a1 > a0 ? a1 - a0 : 0; R.b0 = b0; R.nb = b1_end > b0 ? b1_end - b0 : 0;
+    const int64_t n = (int64_t)R.na + R.nb;
+    if (n <= 0) return hipSuccess;
+    const int g = grid_of(n, 256, 2048);
+    hipLaunchKernelGGL(flush_min_kernel, dim3(g), dim3(256), 0, stream, R, cls, b1, b2, consumed, marker,
+                       reinterpret_cast<unsigned long long*>(cut_word));
+    hipLaunchKernelGGL(flush_mark_kernel, dim3(g), dim3(256), 0, stream, R, cls, b1, b2, consumed, flush_id,
+                       reinterpret_cast<const unsigned long long*>(cut_word));
+    return hipGetLastError();
+}
+
+size_t groupby_scratch_bytes(int32_t n_slots) { return group_carve(nullptr, nullptr, nullptr, n_slots); }
+
+hipError_t launch_groupby(int32_t n_slots, const int32_t* cls, const int32_t* b1, const int32_t* b2, const int32_t* consumed,
+                          int32_t tie_desc, int32_t* order, int32_t* cl_key, int32_t* cl_first, int32_t* cl_count,
+                          int32_t* counts, void* scratch, hipStream_t stream)
+{
+    GroupScratch g; int32_t* tmp = nullptr;
+    group_carve(&g, &tmp, scratch, n_slots);
+    const size_t clear = (size_t)((char*)g.misc - (char*)g.head) + 64;
+    hipError_t e = hipMemsetAsync(g.head, 0, clear, stream);
+    if (e != hipSuccess) return e;
+    const int gi = grid_of(n_slots, 256, 4096);
+    hipLaunchKernelGGL(group_insert_kernel, dim3(gi), dim3(256), 0, stream, n_slots, cls, b1, b2, consumed, g);
+    hipLaunchKernelGGL(group_offsets_kernel, dim3(1), dim3(1024), 0, stream, g, cls, b1, b2, consumed, cl_key, cl_first, cl_count, counts);
+    hipLaunchKernelGGL(group_place_kernel, dim3(gi), dim3(256), 0, stream, n_slots, g, cl_first, order);
+    hipLaunchKernelGGL(group_finish_kernel, dim3(grid_of(n_slots, 16, 4096)), dim3(64), 0, stream, g, cl_first, cl_count, tie_desc, order, tmp);
+    return hipGetLastError();
+}
+
+}  // namespace im

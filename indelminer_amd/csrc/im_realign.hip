@@ -703,7 +703,7 @@ __device__ __forceinline__ void realign_one(WaveLds& s, const RealignArgs& A, in
 
     if (lane < 16) reinterpret_cast<uint32_t*>(&out->band[0])[lane] = 0u;
     if (lane < 7) out->reserved[lane] = 0;
-    write_slots(A, c, 0, -1, 0, 0, lane);
+    if (!A.keep_slots) write_slots(A, c, 0, -1, 0, 0, lane);      // keep: the CIGAR-derived evidence stays unless replaced (src/indelminer.c:504-510)
     if (Lraw <= 0 || Lraw > IM_MAX_READ || tid < 0 || tid >= A.ref.n_contigs || (off & 3)) {
         finish(out, (Lraw > IM_MAX_READ || (off & 3)) ? IM_ST_UNSUPPORTED : IM_ST_ABORT, 0, lane);
         return;
@@ -1392,7 +1392,7 @@ __global__ __launch_bounds__(64) void realign_gapped_kernel(RealignArgs A)
         const int R = uni(A.batch.range_max[c]);
         if (lane < 16) reinterpret_cast<uint32_t*>(&out->band[0])[lane] = 0u;
         if (lane < 7) out->reserved[lane] = 0;
-        write_slots(A, c, 0, -1, 0, 0, lane);
+        if (!A.keep_slots) write_slots(A, c, 0, -1, 0, 0, lane);
         wave_lds_sync();
         if (Lraw <= 0 || Lraw > IM_MAX_READ || tid < 0 || tid >= A.ref.n_contigs || (off & 3)) {
             finish(out, (Lraw > IM_MAX_READ || (off & 3)) ? IM_ST_UNSUPPORTED : IM_ST_ABORT, 0, lane);
@@ -1445,9 +1445,10 @@ __global__ __launch_bounds__(64) void realign_gapped_kernel(RealignArgs A)
             const int rs = G.status;
             finish(out, rs, 1, lane);
             if (rs == IM_ST_EVIDENCE && lane == 0 && A.batch.ev_cls)
-                for (int e = 0; e < out->n_ev; e++) {
+                for (int e = 0; e < IM_MAX_EV; e++) {
                     const int64_t sl = (int64_t)c * IM_MAX_EV + e;
-                    A.batch.ev_cls[sl] = out->ev[e].cls; A.batch.ev_b1[sl] = out->ev[e].b1; A.batch.ev_b2[sl] = out->ev[e].b2;
+                    const bool live = e < out->n_ev;
+                    A.batch.ev_cls[sl] = live ? out->ev[e].cls : -1; A.batch.ev_b1[sl] = live ? out->ev[e].b1 : 0; A.batch.ev_b2[sl] = live ? out->ev[e].b2 : 0;
                 }
             continue;
         }
@@ -1542,9 +1543,10 @@ __global__ __launch_bounds__(64) void realign_gapped_kernel(RealignArgs A)
         }
         finish(out, st, 2, lane);
         if (st == IM_ST_EVIDENCE && lane == 0 && A.batch.ev_cls)
-            for (int e = 0; e < out->n_ev; e++) {
+            for (int e = 0; e < IM_MAX_EV; e++) {
                 const int64_t sl = (int64_t)c * IM_MAX_EV + e;
-                A.batch.ev_cls[sl] = out->ev[e].cls; A.batch.ev_b1[sl] = out->ev[e].b1; A.batch.ev_b2[sl] = out->ev[e].b2;
+                const bool live = e < out->n_ev;
+                A.batch.ev_cls[sl] = live ? out->ev[e].cls : -1; A.batch.ev_b1[sl] = live ? out->ev[e].b1 : 0; A.batch.ev_b2[sl] = live ? out->ev[e].b2 : 0;
             }
     }
 }

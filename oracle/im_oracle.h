@@ -137,6 +137,27 @@ int32_t imo_cluster_sr(int32_t n, const int32_t* cls, const int32_t* b1, const i
 void imo_sw_indel(const char* target, int32_t len1, const char* query, int32_t len2,
                   int32_t* subs, int32_t* indels, int32_t* aligned);
 
+/* a1 / fetch_func (src/indelminer.c:339-521) for one BAM record (the 32-byte core + variable part, no
+ * block_size word): im_oracle_triage.c.  cls uses the IM_REC_* numbering of include/indelminer_amd.h. */
+typedef struct {
+    int32_t cls;
+    int32_t revcomp;
+    int32_t range_max;          /* range[1] of the record's read group */
+    int32_t qual;               /* evidence qual: mate MQ (unmapped read) or own MAPQ (proper pair) */
+    int32_t strand;             /* '+' / '-' after the flip */
+    int32_t tid, anchor, l_seq; /* arguments of attempt_pe_alignment */
+    int32_t n_ev;               /* check_variants (285-337), segment order */
+    int32_t ev_cls[IMO_MAX_EV], ev_b1[IMO_MAX_EV], ev_b2[IMO_MAX_EV];
+} imo_triage;
+
+void imo_triage_record(const uint8_t* rec, uint32_t len,
+                       int32_t n_rg, const char* const* rg_names, const int32_t* rg_range_max,
+                       int32_t qthreshold, uint32_t ethreshold_vcfcheck, uint32_t maxpedelsize,
+                       imo_triage* out, char* bases_out);
+void imo_depth_add(const uint8_t* rec, uint32_t len, int32_t tid, int32_t* depth, int64_t clen);
+int32_t imo_flush_cut(int32_t n, const int32_t* cls, const int32_t* b1, const int32_t* b2, int32_t* consumed,
+                      int32_t marker, int32_t flush_id);
+
 #ifdef __cplusplus
 }
 #endif

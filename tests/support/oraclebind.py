@@ -46,7 +46,8 @@ _lib = None
 def lib():
     global _lib
     if _lib is None:
-        if not os.path.exists(LIB) or os.path.getmtime(LIB) < os.path.getmtime(os.path.join(ODIR, "im_oracle.c")):
+        srcs = [os.path.join(ODIR, f) for f in ("im_oracle.c", "im_oracle_triage.c", "im_oracle.h")]
+        if not os.path.exists(LIB) or os.path.getmtime(LIB) < max(os.path.getmtime(f) for f in srcs):
             build()
         L = C.CDLL(LIB)
         L.imo_realign.restype = C.c_int
@@ -89,3 +90,55 @@ def realign(P, contig_bytes, contig_len, anchor, range_max, read):
     st = lib().imo_realign(C.byref(P), contig_bytes, contig_len, anchor, range_max,
                            read.encode() if isinstance(read, str) else read, len(read), C.byref(r))
     return st, r
+
+
+class Triage(C.Structure):
+    _fields_ = [("cls", C.c_int32), ("revcomp", C.c_int32), ("range_max", C.c_int32), ("qual", C.c_int32),
+                ("strand", C.c_int32), ("tid", C.c_int32), ("anchor", C.c_int32), ("l_seq", C.c_int32),
+                ("n_ev", C.c_int32), ("ev_cls", C.c_int32 * MAX_EV), ("ev_b1", C.c_int32 * MAX_EV), ("ev_b2", C.c_int32 * MAX_EV)]
+
+
+def triage_records(raw, rec_off, rg_names, rg_range_max, qthreshold=10, eth_vcf=10, maxpedelsize=1000000):
+    """imo_triage_record over every record of a device-layout buffer.  Returns a list of
+    (Triage, bases bytes or None)."""
+    import numpy as np
+    L = lib()
+    L.imo_triage_record.restype = None
+    L.imo_triage_record.argtypes = [C.c_void_p, C.c_uint32, C.c_int32, C.POINTER(C.c_char_p), C.c_void_p,
+                                    C.c_int32, C.c_uint32, C.c_uint32, C.POINTER(Triage), C.c_char_p]
+    n = len(rec_off) - 1
+    names = (C.c_char_p * max(len(rg_names), 1))(*[x.encode() for x in rg_names])
+    rm = np.ascontiguousarray(rg_range_max, dtype=np.int32)
+    raw = np.ascontiguousarray(raw)
+    base = raw.ctypes.data
+    out = []
+    for i in range(n):
+        t = Triage()
+        ln = int(rec_off[i + 1]) - int(rec_off[i])
+        buf = C.create_string_buffer(4096)
+        L.imo_triage_record(base + int(rec_off[i]), ln, len(rg_names), names, rm.ctypes.data, qthreshold, eth_vcf, maxpedelsize,
+                            C.byref(t), buf)
+        out.append((t, buf.raw[:t.l_seq] if t.cls in (2, 3) else None))
+    return out
+
+
+def depth_of(raw, rec_off, tid, clen):
+    import numpy as np
+    L = lib()
+    L.imo_depth_add.restype = None
+    L.imo_depth_add.argtypes = [C.c_void_p, C.c_uint32, C.c_int32, C.c_void_p, C.c_int64]
+    raw = np.ascontiguousarray(raw)
+    depth = np.zeros(clen, dtype=np.int32)
+    for i in range(len(rec_off) - 1):
+        L.imo_depth_add(raw.ctypes.data + int(rec_off[i]), int(rec_off[i + 1]) - int(rec_off[i]), tid, depth.ctypes.data, clen)
+    return depth
+
+
+def flush_cut(cls, b1, b2, consumed, marker, flush_id):
+    import numpy as np
+    L = lib()
+    L.imo_flush_cut.restype = C.c_int32
+    L.imo_flush_cut.argtypes = [C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32]
+    cls = np.ascontiguousarray(cls, np.int32); b1 = np.ascontiguousarray(b1, np.int32); b2 = np.ascontiguousarray(b2, np.int32)
+    assert consumed.dtype == np.int32 and consumed.flags.c_contiguous
+    return L.imo_flush_cut(len(cls), cls.ctypes.data, b1.ctypes.data, b2.ctypes.data, consumed.ctypes.data, marker, flush_id)

@@ -1,0 +1,242 @@
+"""Parity of the device-resident pipeline stages with the CPU oracle (bit-exact):
+record triage (fetch_func's rules, a1), realign with kept CIGAR-derived evidence, the READCHUNK
+flush cuts, the split-read group-by, and the genome-wide depth array."""
+import os
+import struct
+
+import numpy as np
+import pytest
+
+from indelminer_amd import capi, rawrec, synth
+from tests.support import oraclebind as ob
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _compare_triage(pipe, raw, rec_off, rg_names, rg_range, tri=None, **kw):
+    """runs the HIP triage over (raw, rec_off) and checks every output against the oracle"""
+    n = len(rec_off) - 1
+    tri = tri or ob.triage_records(raw, rec_off, rg_names, rg_range, **kw)
+    pipe.upload(raw, rec_off)
+    pipe.triage()
+    c = pipe.fetch_counts()
+    # the kernel holds IM_MAX_EV CIGAR-derived evidence per read: more is IM_REC_ERR_LIMIT there (the oracle has no limit)
+    o_cls = np.array([21 if (t.cls == 3 and t.n_ev > capi.MAX_EV) else t.cls for t, _ in tri], dtype=np.uint8)
+    h_cls = pipe.d_class.download(np.uint8, n)
+    assert np.array_equal(h_cls, o_cls), np.nonzero(h_cls != o_cls)[0][:10]
+    # a bad base code (20), a soft clip inside the CIGAR (19) or the evidence limit are found while the candidate is
+    # being written: it keeps its place in the batch
+    cand = [i for i in range(n) if tri[i][0].cls in (2, 3, 19, 20)]
+    assert c[0] == len(cand)
+    assert c[2] == int((o_cls != 0).sum()) and c[3] == int((o_cls >= 16).sum()) and c[4] == 0
+    m = len(cand)
+    assert np.array_equal(pipe.d_cand_rec.download(np.int32, max(m, 1))[:m], np.array(cand, np.int32))
+    boff = pipe.d_boff.download(np.int64, max(m, 1))[:m]
+    blen = pipe.d_len.download(np.int32, max(m, 1))[:m]
+    bases = pipe.d_bases.download(np.uint8, pipe.cap_bases)
+    tid = pipe.d_tid.download(np.int32, max(m, 1))[:m]
+    anchor = pipe.d_anchor.download(np.int32, max(m, 1))[:m]
+    rng = pipe.d_range.download(np.int32, max(m, 1))[:m]
+    s_cls = pipe.d_cls.download(np.int32, pipe.n_slots).reshape(-1)
+    s_b1 = pipe.d_b1.download(np.int32, pipe.n_slots)
+    s_b2 = pipe.d_b2.download(np.int32, pipe.n_slots)
+    pos = 0
+    for j, i in enumerate(cand):
+        t, b = tri[i]
+        assert boff[j] == pos and boff[j] % 4 == 0
+        if t.cls in (19, 20):
+            pos += (int(blen[j]) + 3) // 4 * 4
+            continue
+        assert blen[j] == t.l_seq
+        assert bases[pos:pos + t.l_seq].tobytes() == b, (i, bases[pos:pos + t.l_seq].tobytes(), b)
+        assert not bases[pos + t.l_seq:pos + (t.l_seq + 3) // 4 * 4].any()
+        pos += (t.l_seq + 3) // 4 * 4
+        assert (tid[j], anchor[j], rng[j]) == (t.tid, t.anchor, t.range_max)
+        for k in range(capi.MAX_EV):
+            sl = j * capi.MAX_EV + k
+            if k < t.n_ev and t.n_ev <= capi.MAX_EV:
+                assert (s_cls[sl], s_b1[sl], s_b2[sl]) == (t.ev_cls[k], t.ev_b1[k], t.ev_b2[k])
+            else:
+                assert s_cls[sl] == -1
+    return tri, cand
+
+
+def _synth(seed=7, ref_len=60_000, coverage=20, **kw):
+    refs, rd = synth.simulate(seed=seed, ref_len=ref_len, coverage=coverage, **kw)
+    raw, off = rawrec.records(rd)
+    return refs, rd, raw, off
+
+
+def test_triage_matches_oracle_synthetic(gpu_ctx):
+    refs, rd, raw, off = _synth(big_every=7)
+    gpu_ctx.set_reference([r.tobytes() for r in refs])
+    gpu_ctx.set_insert_ranges(["generic"], [rd.range_max])
+    pipe = capi.Pipeline(gpu_ctx, rd.n, len(raw), cap_cand=rd.n)
+    tri, cand = _compare_triage(pipe, raw, off, ["generic"], [rd.range_max])
+    # the simulator's own candidate rule agrees (third opinion)
+    sc = synth.candidates(rd)
+    assert np.array_equal(sc["index"], np.array(cand))
+    assert any(t.cls == capi.REC_PE for t, _ in tri)
+    assert any(t.n_ev > 0 for t, _ in tri)
+
+
+def test_triage_matches_oracle_test_data(gpu_ctx, golden_dir):
+    raw, off, contigs = rawrec.records_from_bam(os.path.join(golden_dir, "test_data", "alignments.bam"))
+    fa = open(os.path.join(golden_dir, "test_data", "reference.fa")).read().split("\n", 1)[1].replace("\n", "").upper()
+    gpu_ctx.set_reference([fa.encode()])
+    gpu_ctx.set_insert_ranges(["generic"], [705])
+    n = len(off) - 1
+    for q in (10, 0):
+        pipe = capi.Pipeline(gpu_ctx, n, len(raw), cap_cand=n, qthreshold=q)
+        tri, cand = _compare_triage(pipe, raw, off, ["generic"], [705], qthreshold=q)
+        # SURVEY.md appendix B census: 697 candidates at -q 10; the 6 unmapped-read candidates only pass at -q 0
+        assert len(cand) == (697 if q == 10 else 703)
+
+
+def _rec(flag, tid=0, pos=100, mtid=0, mpos=300, isize=300, mapq=60, cigar=((100, 0),), seq=None, tags=b"", qname=b"q\0", l_seq=100):
+    seq = seq if seq is not None else bytes([0x12] * ((l_seq + 1) // 2))
+    cig = b"".join(struct.pack("<I", (l << 4) | o) for l, o in cigar)
+    body = struct.pack("<iiBBHHHiiii", tid, pos, len(qname), mapq, 0, len(cigar), flag, l_seq, mtid, mpos, isize) + qname + cig + seq + b"\x28" * l_seq + tags
+    return body + b"\0" * ((-len(body)) % 4)
+
+
+def test_triage_edge_records(gpu_ctx):
+    """read groups with the hashtable's prefix / last-hit semantics, MQ tag types, bad CIGARs, every skip rule"""
+    gpu_ctx.set_reference([b"ACGT" * 500])
+    names = ["lib1", "lib10", "generic", "li", "x" * 40, "lib1b"]
+    ranges = [500, 600, 700, 800, 900, 1000]
+    gpu_ctx.set_insert_ranges(names, ranges)
+    P, S = 0x1 | 0x2, ((30, 4), (70, 0))
+    recs = [
+        _rec(P | 0x100), _rec(P | 0x200), _rec(P | 0x400), _rec(P | 0x800), _rec(0x2), _rec(P, mtid=1),         # skips
+        _rec(P, cigar=S, tags=b"RGZlib1\0"), _rec(P, cigar=S, tags=b"RGZlib10\0"), _rec(P, cigar=S, tags=b"RGZli\0"),
+        _rec(P, cigar=S, tags=b"RGZl\0"), _rec(P, cigar=S, tags=b"RGZnope\0"), _rec(P, cigar=S, tags=b"RGZ" + b"x" * 40 + b"\0"),
+        _rec(P, cigar=S, tags=b"RGAx"), _rec(P, cigar=S, tags=b"XYi\1\0\0\0RGZlib1b\0MQC\x05"),                    # MQ 5 < q
+        _rec(P, cigar=S, tags=b"MQC\x0a"), _rec(P, cigar=S, tags=b"MQf\0\0\x80\x3f"), _rec(P, cigar=S, tags=b"MQs\xff\xff"),
+        _rec(0x1 | 0x4 | 0x40, cigar=(), tags=b"MQZ12\0"), _rec(0x1 | 0x4 | 0x40, cigar=(), tags=b"MQI\x3c\0\0\0"),
+        _rec(0x1 | 0x4 | 0x20 | 0x80, cigar=(), mapq=5), _rec(0x1 | 0x8),                                          # mate forward / reverse; mapped with unmapped mate
+        _rec(0x1 | 0x4 | 0x8, cigar=()),                                                                           # both unmapped
+        _rec(P, cigar=((50, 0), (10, 3), (50, 0))), _rec(P, cigar=((10, 5), (90, 0))), _rec(P, cigar=((100, 9),)),
+        _rec(P, cigar=((40, 0), (5, 4), (55, 0))), _rec(P | 0x10, cigar=((30, 4), (70, 0))), _rec(P | 0x10, cigar=((70, 0), (30, 4))),
+        _rec(P, cigar=((70, 0), (30, 4))), _rec(P, cigar=((20, 0), (3, 1), (30, 0), (7, 2), (47, 0))),
+        _rec(P, cigar=((5, 0), (3, 1), (92, 0))), _rec(P, cigar=((10, 0),) + ((1, 1), (10, 0)) * 6 + ((24, 0),)),  # > 4 CIGAR evidence
+        _rec(0x1 | 0x20, isize=5000), _rec(0x1 | 0x10, isize=-5000), _rec(0x1 | 0x20, isize=650), _rec(0x1 | 0x20 | 0x10, isize=5000),
+        _rec(0x1 | 0x20, isize=2000000), _rec(P, cigar=S, seq=bytes([0x13] * 50)), _rec(P, cigar=S, l_seq=33, seq=bytes([0x48] * 17)),
+        _rec(P, cigar=((20, 4), (13, 0)), l_seq=33, seq=bytes([0x48] * 17)), _rec(P | 0x10 | 0x20, cigar=((20, 4), (13, 0)), l_seq=33, seq=bytes([0x84, 0x21] * 8 + [0xf0])),
+        _rec(P, cigar=S)[:60],                                                                                     # truncated record
+    ]
+    raw = np.frombuffer(b"".join(recs), dtype=np.uint8).copy()
+    off = np.zeros(len(recs) + 1, dtype=np.uint32)
+    np.cumsum([len(r) for r in recs], out=off[1:])
+    pipe = capi.Pipeline(gpu_ctx, len(recs), len(raw), cap_cand=len(recs), maxpedelsize=1000000)
+    tri, cand = _compare_triage(pipe, raw, off, names, ranges)
+    seen = {t.cls for t, _ in tri}
+    assert {0, 1, 2, 3, 4, 16, 17, 18, 19, 20, 21} <= seen, seen
+
+
+def test_realign_keep_flush_groupby(gpu_ctx):
+    """triage -> realign (CIGAR-derived evidence survives where realignment finds none) -> three flushes with
+    paired-read entries in the cut -> group-by, against the oracle's realign + flush + a plain group-by"""
+    refs, rd, raw, off = _synth(seed=11, ref_len=120_000, coverage=25)
+    contig = refs[0].tobytes()
+    gpu_ctx.set_reference([contig])
+    gpu_ctx.set_insert_ranges(["generic"], [rd.range_max])
+    rng = np.random.default_rng(3)
+    n_pe = 40
+    pe_b1 = rng.integers(0, 120_000, n_pe).astype(np.int32)
+    pe_b2 = (pe_b1 + rng.integers(200, 900, n_pe)).astype(np.int32)
+    pipe = capi.Pipeline(gpu_ctx, rd.n, len(raw), cap_cand=rd.n // 4, n_pe=n_pe)
+    tri, cand = _compare_triage(pipe, raw, off, ["generic"], [rd.range_max])
+    pipe.set_pe(pe_b1, pe_b2)
+    pipe.realign()
+    m = len(cand)
+    # oracle: realigned evidence replaces the CIGAR-derived evidence, else the latter stays (src/indelminer.c:494-512)
+    P = ob.params()
+    E = capi.MAX_EV
+    o_cls = np.full(m * E + n_pe, -1, np.int32); o_b1 = np.zeros(m * E + n_pe, np.int32); o_b2 = np.zeros(m * E + n_pe, np.int32)
+    kept = 0
+    for j, i in enumerate(cand):
+        t, b = tri[i]
+        st, res = ob.realign(P, contig, len(contig), t.anchor, t.range_max, b)
+        if st == 1 and res.n_ev > 0:
+            ev = [(res.ev[k].cls, res.ev[k].b1, res.ev[k].b2) for k in range(res.n_ev)]
+        else:
+            ev = [(t.ev_cls[k], t.ev_b1[k], t.ev_b2[k]) for k in range(t.n_ev)]
+            kept += bool(ev)
+        for k, (c, x1, x2) in enumerate(ev):
+            o_cls[j * E + k], o_b1[j * E + k], o_b2[j * E + k] = c, x1, x2
+    assert kept > 0
+    base = pipe.cap_cand * E
+    nsl = m * E
+    h_cls = pipe.d_cls.download(np.int32, pipe.n_slots); h_b1 = pipe.d_b1.download(np.int32, pipe.n_slots); h_b2 = pipe.d_b2.download(np.int32, pipe.n_slots)
+    assert np.array_equal(h_cls[:nsl], o_cls[:nsl]) and np.array_equal(h_b1[:nsl], o_b1[:nsl]) and np.array_equal(h_b2[:nsl], o_b2[:nsl])
+    o_cls[nsl:] = 2; o_b1[nsl:] = pe_b1; o_b2[nsl:] = pe_b2
+    # flushes: (candidate prefix, PE prefix, marker); the last one takes everything
+    flushes = [(m // 3, 10, 30_000), (2 * m // 3, 25, 70_000), (m, n_pe, 60_000), (m, n_pe, 2**31 - 1)]
+    o_cons = np.zeros(nsl + n_pe, np.int32)
+    for k, (ch, ph, marker) in enumerate(flushes):
+        pipe.flush(k, ch, ph, marker)
+        vis = np.full(nsl + n_pe, -1, np.int32)            # what this flush can see
+        vis[:ch * E] = o_cls[:ch * E]; vis[nsl:nsl + ph] = 2
+        ob.flush_cut(vis, o_b1, o_b2, o_cons, marker, k + 1)
+    pipe.groupby()
+    pipe.sync()
+    h_cons = pipe.d_consumed.download(np.int32, pipe.n_slots)
+    assert np.array_equal(h_cons[:nsl], o_cons[:nsl]) and np.array_equal(h_cons[base:base + n_pe], o_cons[nsl:])
+    assert len(set(o_cons[:nsl][o_cls[:nsl] >= 0])) >= 3 and (o_cons[:nsl][o_cls[:nsl] >= 0] > 0).all()
+    key, first, count, order = pipe.clusters()
+    want = {}
+    for s in range(nsl):
+        if o_cls[s] >= 0 and o_cons[s] > 0:
+            want.setdefault((int(o_cons[s]), int(o_cls[s]), int(o_b1[s]), int(o_b2[s])), []).append(s)
+    got = {tuple(int(x) for x in key[c]): list(order[first[c]:first[c] + count[c]]) for c in range(len(key))}
+    assert got == want
+    # tie_desc reverses the members
+    pipe.groupby(tie_desc=1)
+    pipe.sync()
+    key, first, count, order = pipe.clusters()
+    got = {tuple(int(x) for x in key[c]): list(order[first[c]:first[c] + count[c]]) for c in range(len(key))}
+    assert got == {k: v[::-1] for k, v in want.items()}
+
+
+def test_groupby_large_support(gpu_ctx):
+    """a breakpoint with more than 1024 supporting reads takes the global-memory ordering path"""
+    n = 5000
+    pipe = capi.Pipeline(gpu_ctx, 1, 64, cap_cand=n)
+    E = capi.MAX_EV
+    cls = np.full(n * E, -1, np.int32); b1 = np.zeros(n * E, np.int32); b2 = np.zeros(n * E, np.int32)
+    cls[::E] = 1; b1[::E] = 1000; b2[::E] = 1010
+    cls[1::E][:700] = 0; b1[1::E][:700] = 555; b2[1::E][:700] = 555
+    pipe.d_cls.upload(cls); pipe.d_b1.upload(b1); pipe.d_b2.upload(b2)
+    pipe.d_consumed.upload(np.where(cls >= 0, 1, 0).astype(np.int32))
+    pipe.n_cand = n
+    pipe.groupby()
+    pipe.sync()
+    key, first, count, order = pipe.clusters()
+    got = {tuple(int(x) for x in key[c]): order[first[c]:first[c] + count[c]] for c in range(len(key))}
+    assert set(got) == {(1, 1, 1000, 1010), (1, 0, 555, 555)}
+    assert np.array_equal(got[(1, 1, 1000, 1010)], np.arange(0, n * E, E))
+    assert np.array_equal(got[(1, 0, 555, 555)], np.arange(1, 700 * E, E))
+
+
+def test_depth_genome_wide(gpu_ctx):
+    refs, rd, raw, off = _synth(seed=5, ref_len=40_000, coverage=15, n_contigs=2)
+    gpu_ctx.set_reference([r.tobytes() for r in refs])
+    gpu_ctx.set_insert_ranges(["generic"], [rd.range_max])
+    gpu_ctx.depth_enable()
+    pipe = capi.Pipeline(gpu_ctx, rd.n, len(raw), cap_cand=rd.n, want_depth=True)
+    pipe.upload(raw, off)
+    pipe.triage()
+    pipe.sync()
+    rng = np.random.default_rng(1)
+    for tid in (0, 1):
+        gpu_ctx.depth_scan(tid)
+        want = ob.depth_of(raw, off, tid, 40_000)
+        beg = rng.integers(0, 39_000, 200).astype(np.int32)
+        end = (beg + rng.integers(1, 900, 200)).astype(np.int32)
+        beg[0], end[0] = 0, 40_000
+        got = gpu_ctx.depth_query_tid(tid, beg, end)
+        cs = np.concatenate([[0], np.cumsum(want.astype(np.int64))])
+        assert np.array_equal(got.astype(np.int64), cs[np.minimum(end, 40_000)] - cs[beg])
