@@ -410,6 +410,13 @@ int  im_dev_free(im_ctx* ctx, void* p);
 int  im_dev_upload(im_ctx* ctx, void* dst_dev, const void* src_host, size_t bytes);
 int  im_dev_download(im_ctx* ctx, void* dst_host, const void* src_dev, size_t bytes);
 int  im_dev_memset(im_ctx* ctx, void* dst_dev, int byte, size_t bytes, void* stream);     /* asynchronous */
+/* Pinned host memory and asynchronous copies on a stream ("reads are pre-staged into pinned buffers and
+ * hipMemcpyAsync'd"): the host driver inflates BAM records straight into im_host_alloc'd chunks. */
+int  im_host_alloc(im_ctx* ctx, size_t bytes, void** out);
+int  im_host_free(im_ctx* ctx, void* p);
+int  im_dev_upload_async(im_ctx* ctx, void* dst_dev, const void* src_host, size_t bytes, void* stream);
+int  im_dev_download_async(im_ctx* ctx, void* dst_host, const void* src_dev, size_t bytes, void* stream);
+int  im_dev_copy_async(im_ctx* ctx, void* dst_dev, const void* src_dev, size_t bytes, void* stream);
 /* The context's own stream (a hipStream_t) and a wait for it. */
 void* im_ctx_stream(im_ctx* ctx);
 int   im_ctx_device(im_ctx* ctx);                               /* the HIP device index the context lives on */

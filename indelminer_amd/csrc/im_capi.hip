@@ -726,6 +726,40 @@ int im_dev_memset(im_ctx* ctx, void* dst_dev, int byte, size_t bytes, void* stre
     HIP_TRY(ctx, hipMemsetAsync(dst_dev, byte, bytes, (hipStream_t)stream));
     return IM_OK;
 }
+int im_host_alloc(im_ctx* ctx, size_t bytes, void** out)
+{
+    if (!ctx || !out) return IM_E_ARG;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, hipHostMalloc(out, bytes ? bytes : 1, hipHostMallocDefault));
+    return IM_OK;
+}
+int im_host_free(im_ctx* ctx, void* p)
+{
+    if (!ctx) return IM_E_ARG;
+    HIP_TRY(ctx, hipHostFree(p));
+    return IM_OK;
+}
+int im_dev_upload_async(im_ctx* ctx, void* dst_dev, const void* src_host, size_t bytes, void* stream)
+{
+    if (!ctx) return IM_E_ARG;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    if (bytes) HIP_TRY(ctx, hipMemcpyAsync(dst_dev, src_host, bytes, hipMemcpyHostToDevice, (hipStream_t)stream));
+    return IM_OK;
+}
+int im_dev_download_async(im_ctx* ctx, void* dst_host, const void* src_dev, size_t bytes, void* stream)
+{
+    if (!ctx) return IM_E_ARG;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    if (bytes) HIP_TRY(ctx, hipMemcpyAsync(dst_host, src_dev, bytes, hipMemcpyDeviceToHost, (hipStream_t)stream));
+    return IM_OK;
+}
+int im_dev_copy_async(im_ctx* ctx, void* dst_dev, const void* src_dev, size_t bytes, void* stream)
+{
+    if (!ctx) return IM_E_ARG;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    if (bytes) HIP_TRY(ctx, hipMemcpyAsync(dst_dev, src_dev, bytes, hipMemcpyDeviceToDevice, (hipStream_t)stream));
+    return IM_OK;
+}
 int im_dev_upload(im_ctx* ctx, void* dst_dev, const void* src_host, size_t bytes)
 {
     if (!ctx) return IM_E_ARG;

@@ -512,6 +512,50 @@ int bam_region_next(bam_region_iter* it, bam_record* b)
     return 0;
 }
 
+static void core_view(const uint8_t* c, bam_record* b)
+{
+#define U32(o) ((uint32_t)c[o] | ((uint32_t)c[(o) + 1] << 8) | ((uint32_t)c[(o) + 2] << 16) | ((uint32_t)c[(o) + 3] << 24))
+    b->tid = (int32_t)U32(0); b->pos = (int32_t)U32(4);
+    b->l_qname = c[8]; b->mapq = c[9]; b->bin = (uint16_t)(c[10] | (c[11] << 8));
+    b->n_cigar = (uint16_t)(c[12] | (c[13] << 8)); b->flag = (uint16_t)(c[14] | (c[15] << 8));
+    b->l_seq = (int32_t)U32(16); b->mtid = (int32_t)U32(20); b->mpos = (int32_t)U32(24); b->isize = (int32_t)U32(28);
+#undef U32
+}
+
+void bam_record_view(const uint8_t* rec, int32_t len, bam_record* view)
+{
+    core_view(rec, view);
+    view->data = (uint8_t*)rec + 32;
+    view->l_data = len - 32;
+    view->m_data = 0;
+}
+
+int bam_region_next_raw(bam_region_iter* it, uint8_t* dst, int64_t cap, int32_t* len_out, bam_record* view)
+{
+    while (!it->done) {
+        if (it->pending_size == 0) {
+            uint8_t c[4];
+            const int64_t got = bgzf_read(it->r, c, 4);
+            if (got == 0) { it->done = 1; return 0; }
+            if (got != 4) { it->done = 1; return -1; }
+            const int32_t bs = (int32_t)((uint32_t)c[0] | ((uint32_t)c[1] << 8) | ((uint32_t)c[2] << 16) | ((uint32_t)c[3] << 24));
+            if (bs < 32) { it->done = 1; return -1; }
+            it->pending_size = bs;
+        }
+        if ((int64_t)it->pending_size > cap) return -2;
+        const int32_t bs = it->pending_size;
+        it->pending_size = 0;
+        if (bgzf_read(it->r, dst, bs) != bs) { it->done = 1; return -1; }
+        bam_record_view(dst, bs, view);
+        if (view->tid != it->tid || view->pos >= it->end) { it->done = 1; return 0; }    /* bam_index.c:704-707 */
+        if (32 + (int64_t)view->l_qname + 4 * (int64_t)view->n_cigar > bs) { it->done = 1; return -1; }
+        const uint32_t rbeg = (uint32_t)view->pos;
+        const uint32_t rend = view->n_cigar ? (uint32_t)bam_record_end(view) : (uint32_t)view->pos + 1u;
+        if (rend > (uint32_t)it->beg && rbeg < (uint32_t)it->end) { *len_out = bs; return 1; }
+    }
+    return 0;
+}
+
 int bam_parse_region_str(const bam_header* h, const char* str, int* tid, int* beg, int* end)
 {
     /* bam_parse_region (bam_aux.c:107-161): spaces dropped, last ':' splits the name, commas

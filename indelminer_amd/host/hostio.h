@@ -59,9 +59,17 @@ typedef struct {
     bgzf_reader* r;
     int32_t tid, beg, end;
     int done;
+    int32_t pending_size;   /* block_size of a record whose body has not been read yet (bam_region_next_raw) */
 } bam_region_iter;
 int bam_region_begin(bam_region_iter* it, bgzf_reader* r, const bai_index* idx, int32_t tid, int32_t beg, int32_t end);
 int bam_region_next(bam_region_iter* it, bam_record* b);   /* 1 = record, 0 = done, -1 = error */
+/* The same iteration, but the record's bytes (32-byte core + variable part, as in the file, without the
+ * block_size word) land in the caller's buffer dst[0..cap) -- the host driver points it into a pinned chunk
+ * that goes to the GPU as it is.  view receives the decoded core and view->data = dst + 32 (not owned).
+ * Returns 1 = record (*len_out bytes written), 0 = done, -1 = error, -2 = the next record needs more than
+ * cap bytes (nothing consumed: call again with a bigger / fresh buffer). */
+void bam_record_view(const uint8_t* rec, int32_t len, bam_record* view);   /* decode a raw record in place (view->data not owned) */
+int bam_region_next_raw(bam_region_iter* it, uint8_t* dst, int64_t cap, int32_t* len_out, bam_record* view);
 
 /* region string "chr", "chr:beg", "chr:beg-end" (bam_aux.c:107-161): returns 0 on success */
 int bam_parse_region_str(const bam_header* h, const char* str, int* tid, int* beg, int* end);

@@ -366,6 +366,9 @@ typedef struct {
     /* match segments of the contig's pileup-eligible records, for the device depth array */
     int32_t *seg_start, *seg_len; int64_t n_seg, cap_seg;
     int depth_tid;              /* contig whose depth array is resident on the device, -1 = none */
+    int pipe_mode;              /* device pipeline: depth queries go to the genome-wide array */
+    /* live entries of the pair table (find_marker walks these) */
+    evidence_t** live; int32_t n_live, cap_live;
 } driver;
 
 static void gpu_wait(driver* d);
@@ -415,15 +418,13 @@ static item_t* push_item(driver* d)
     return it;
 }
 
-static int find_marker(const qhash* readpairs)
+/* find_marker (src/indelminer.c:211-233): smallest aln1->start among the pairs still waiting for a mate.
+ * The reference walks all 2^20 bins of the pair table; the live entries are kept in a list here. */
+static int find_marker_live(const driver* d)
 {
-    /* src/indelminer.c:211-233: smallest aln1->start among the pairs still waiting for a mate */
     int m = INT_MAX;
-    for (uint32_t i = 0; i <= readpairs->mask; i++)
-        for (const qbin* it = readpairs->bins[i]; it; it = it->next) {
-            const evidence_t* e = it->val;
-            if (seglist_first_start(&e->aln) < m) m = seglist_first_start(&e->aln);
-        }
+    for (int32_t i = 0; i < d->n_live; i++)
+        if (seglist_first_start(&d->live[i]->aln) < m) m = seglist_first_start(&d->live[i]->aln);
     return m;
 }
 
@@ -464,6 +465,95 @@ static int mate_mapq(const bam_record* b, int strict)
     return bam_aux_int(p);
 }
 
+static void live_add(driver* d, evidence_t* e)
+{
+    if (d->n_live == d->cap_live) { d->cap_live = d->cap_live ? d->cap_live * 2 : 1024; d->live = xrealloc(d->live, sizeof(evidence_t*) * (size_t)d->cap_live); }
+    e->live_slot = d->n_live;
+    d->live[d->n_live++] = e;
+}
+static void live_del(driver* d, evidence_t* e)
+{
+    if (!e) return;
+    const int32_t s = e->live_slot;
+    if (s < 0 || s >= d->n_live || d->live[s] != e) return;
+    d->live[s] = d->live[--d->n_live];
+    d->live[s]->live_slot = s;
+    e->live_slot = -1;
+}
+
+/* the discordant-pair branch of fetch_func (src/indelminer.c:516-615): the first mate waits in the pair
+ * table, the second completes the evidence.  Returns the completed evidence or NULL. */
+static evidence_t* discordant_pair(driver* d, const bam_record* b, const int32_t* range)
+{
+    const int flag = b->flag;
+    const int is_rc = (flag & 0x10) == 0x10, is_mate_rc = (flag & 0x20) == 0x20;
+    const char* qname = BAMR_QNAME(b);
+    evidence_t* done = NULL;
+    if (abs(b->isize) > range[1] && (uint32_t)abs(b->isize) < O.maxpedelsize && is_rc != is_mate_rc) {
+        if (b->pos < b->mpos) {
+            evidence_t* e = xcalloc(1, sizeof *e);
+            e->type = EV_PAIRED_READ; e->cls = CLS_DELETION;
+            e->qual = b->mapq; e->strand = is_rc ? '-' : '+';
+            e->qname = xstrdup(qname);
+            e->aln = seglist_from_record(b);
+            qhash_add(d->readpairs, qname, b->l_qname, e);
+            live_add(d, e);
+        } else {
+            qbin* hb = qhash_lookup(d->readpairs, qname, b->l_qname);
+            evidence_t* e = hb ? hb->val : NULL;
+            int skip = 0;
+            if (!e) {
+                seglist m; char mstrand = '+';
+                const char want = (flag & 0x40) ? '2' : '1';
+                if (!find_mate(d, b->mtid, b->mpos, want, qname, &m, &mstrand)) skip = 1;
+                else {
+                    e = xcalloc(1, sizeof *e);
+                    e->type = EV_PAIRED_READ; e->cls = CLS_DELETION;
+                    e->qual = 0;            /* find_mate_rln never copies the mate's MAPQ (src/indelminer.c:243-251) */
+                    e->strand = mstrand;
+                    e->qname = xstrdup(qname);
+                    e->aln = m;
+                    if (b->mapq < e->qual) e->qual = b->mapq;
+                    qhash_add(d->readpairs, qname, b->l_qname, e);
+                    live_add(d, e);
+                }
+            }
+            if (!skip) {
+                e->aln3 = seglist_from_record(b);
+                e->b1 = seglist_last_end(&e->aln);
+                e->b2 = seglist_first_start(&e->aln3);
+                e->mindelsize = abs(b->isize) - range[1];
+                e->max = range[1];
+                const int smq = b->mapq, mmq = mate_mapq(b, 0);
+                if (smq >= O.qthreshold || mmq >= O.qthreshold) {
+                    const char* r = d->sequences[b->tid];
+                    seg_reduce(&e->aln, 0, e->aln.n, r, &e->lflank, &e->nd_print, &e->nd_filter);
+                    seg_reduce(&e->aln3, 0, e->aln3.n, r, &e->rflank, &e->nd_print, &e->nd_filter);
+                    done = e;
+                } else evidence_free(e);
+            }
+            live_del(d, qhash_remove(d->readpairs, qname, b->l_qname));
+        }
+    }
+    return done;
+}
+
+/* must_find_hashtable(insertlengths, rgname) (src/indelminer.c:369-376) with a one-entry cache */
+static const int32_t* record_range(driver* d, const bam_record* b)
+{
+    const uint8_t* rg = bam_aux_find(b, "RG");
+    const char* rgname = "generic";
+    if (rg) rgname = bam_aux_str(rg);
+    if (d->rg_last_val == NULL || strcmp(rgname, d->rg_last_name) != 0) {
+        qbin* rb = qhash_lookup(d->insertlengths, rgname, (int)strlen(rgname));
+        if (!rb) fatalf("did not find %s in the hash", rgname);
+        snprintf(d->rg_last_name, sizeof d->rg_last_name, "%s", rgname);
+        d->rg_last_val = strlen(rgname) < sizeof d->rg_last_name ? rb->val : NULL;     /* over-long names are not cached */
+        d->rg_tmp_val = rb->val;
+    } else d->rg_tmp_val = d->rg_last_val;
+    return d->rg_tmp_val;
+}
+
 /* fetch_func (src/indelminer.c:339-673) for one record, pass A part */
 static void dispatch_record(driver* d, const bam_record* b)
 {
@@ -478,19 +568,7 @@ static void dispatch_record(driver* d, const bam_record* b)
     if (is_se) return;
     if (is_aligned && is_mate_aligned && b->tid != b->mtid) return;
 
-    const uint8_t* rg = bam_aux_find(b, "RG");
-    const char* rgname = "generic";
-    if (rg) rgname = bam_aux_str(rg);
-    /* the table is fixed once the run starts and consecutive records nearly always share a read group:
-     * remember the last answer (same lookup, same fatal error on a miss) */
-    if (d->rg_last_val == NULL || strcmp(rgname, d->rg_last_name) != 0) {
-        qbin* rb = qhash_lookup(d->insertlengths, rgname, (int)strlen(rgname));
-        if (!rb) fatalf("did not find %s in the hash", rgname);
-        snprintf(d->rg_last_name, sizeof d->rg_last_name, "%s", rgname);
-        d->rg_last_val = strlen(rgname) < sizeof d->rg_last_name ? rb->val : NULL;     /* over-long names are not cached */
-        d->rg_tmp_val = rb->val;
-    } else d->rg_tmp_val = d->rg_last_val;
-    const int32_t* range = d->rg_tmp_val;
+    const int32_t* range = record_range(d, b);
     const char* qname = BAMR_QNAME(b);
 
     if (is_aligned && !is_mate_aligned) {
@@ -549,56 +627,13 @@ static void dispatch_record(driver* d, const bam_record* b)
         }
         seglist_free(&rln);
     } else if (is_aligned && is_mate_aligned && !is_proper_pair) {
-        if (abs(b->isize) > range[1] && (uint32_t)abs(b->isize) < O.maxpedelsize && is_rc != is_mate_rc) {
-            if (b->pos < b->mpos) {
-                evidence_t* e = xcalloc(1, sizeof *e);
-                e->type = EV_PAIRED_READ; e->cls = CLS_DELETION;
-                e->qual = b->mapq; e->strand = is_rc ? '-' : '+';
-                e->qname = xstrdup(qname);
-                e->aln = seglist_from_record(b);
-                qhash_add(d->readpairs, qname, b->l_qname, e);
-            } else {
-                qbin* hb = qhash_lookup(d->readpairs, qname, b->l_qname);
-                evidence_t* e = hb ? hb->val : NULL;
-                int skip = 0;
-                if (!e) {
-                    seglist m; char mstrand = '+';
-                    const char want = (flag & 0x40) ? '2' : '1';
-                    if (!find_mate(d, b->mtid, b->mpos, want, qname, &m, &mstrand)) skip = 1;
-                    else {
-                        e = xcalloc(1, sizeof *e);
-                        e->type = EV_PAIRED_READ; e->cls = CLS_DELETION;
-                        e->qual = 0;            /* find_mate_rln never copies the mate's MAPQ (src/indelminer.c:243-251) */
-                        e->strand = mstrand;
-                        e->qname = xstrdup(qname);
-                        e->aln = m;
-                        if (b->mapq < e->qual) e->qual = b->mapq;
-                        qhash_add(d->readpairs, qname, b->l_qname, e);
-                    }
-                }
-                if (!skip) {
-                    e->aln3 = seglist_from_record(b);
-                    e->b1 = seglist_last_end(&e->aln);
-                    e->b2 = seglist_first_start(&e->aln3);
-                    e->mindelsize = abs(b->isize) - range[1];
-                    e->max = range[1];
-                    const int smq = b->mapq, mmq = mate_mapq(b, 0);
-                    if (smq >= O.qthreshold || mmq >= O.qthreshold) {
-                        const char* r = d->sequences[b->tid];
-                        seg_reduce(&e->aln, 0, e->aln.n, r, &e->lflank, &e->nd_print, &e->nd_filter);
-                        seg_reduce(&e->aln3, 0, e->aln3.n, r, &e->rflank, &e->nd_print, &e->nd_filter);
-                        item_t* it = push_item(d);
-                        it->kind = ITEM_PE; it->pe = e;
-                    } else evidence_free(e);
-                }
-                qhash_remove(d->readpairs, qname, b->l_qname);
-            }
-        }
+        evidence_t* e = discordant_pair(d, b, range);
+        if (e) { item_t* it = push_item(d); it->kind = ITEM_PE; it->pe = e; }
     }
 
     if ((++d->numread % READCHUNK) == 0) {
         timestamp("Read %ld reads", (long)d->numread);
-        int marker = find_marker(d->readpairs);
+        int marker = find_marker_live(d);
         if (b->pos < marker) marker = b->pos;
         if (d->n_flushes == d->cap_flushes) {
             d->cap_flushes = d->cap_flushes ? d->cap_flushes * 2 : 64;
@@ -810,7 +845,8 @@ static uint32_t region_depth(driver* d, int32_t tid, int32_t start, int32_t stop
         /* the device holds the contig's depth array (im_depth_build in run_contig) */
         uint32_t sum = 0;
         gpu_wait(d);
-        if (im_depth_query(d->gpu, 1, &start, &stop, &sum) != IM_OK) fatalf("im_depth_query: %s", im_last_error(d->gpu));
+        if ((d->pipe_mode ? im_depth_query_tid(d->gpu, tid, 1, &start, &stop, &sum) : im_depth_query(d->gpu, 1, &start, &stop, &sum)) != IM_OK)
+            fatalf("im_depth_query: %s", im_last_error(d->gpu));
         return (uint32_t)floor(sum * 1.0 / (uint32_t)(stop - start));
     }
     /* region runs (-c): the reference pileups the whole BAM around the variant, which can reach
@@ -1132,7 +1168,8 @@ static void print_variants(driver* d, variant_list* vs)
         }
         if (m > 0) {
             gpu_wait(d);
-            if (im_depth_query(d->gpu, m, beg, end, sum) != IM_OK) fatalf("im_depth_query: %s", im_last_error(d->gpu));
+            if ((d->pipe_mode ? im_depth_query_tid(d->gpu, d->depth_tid, m, beg, end, sum) : im_depth_query(d->gpu, m, beg, end, sum)) != IM_OK)
+                fatalf("im_depth_query: %s", im_last_error(d->gpu));
             for (int q = 0; q < m; q++) {
                 variant_t* v = out.v[who[q]];
                 v->dp_cached = (int32_t)(uint32_t)floor(sum[q] * 1.0 / (uint32_t)(end[q] - beg[q]));
@@ -1592,6 +1629,18 @@ static void gpu_wait(driver* d)
 
 /* ------------------------------------------------------ config / estimates -- */
 
+/* the insert-length table's entries in the order they were added: the device rebuilds the chains from it */
+static const char** g_rg_name; static int32_t** g_rg_range; static int g_rg_n, g_rg_cap;
+static void rg_order_push(const char* name, int32_t* range)
+{
+    if (g_rg_n == g_rg_cap) {
+        g_rg_cap = g_rg_cap ? g_rg_cap * 2 : 16;
+        g_rg_name = xrealloc(g_rg_name, sizeof(char*) * (size_t)g_rg_cap);
+        g_rg_range = xrealloc(g_rg_range, sizeof(int32_t*) * (size_t)g_rg_cap);
+    }
+    g_rg_name[g_rg_n] = xstrdup(name); g_rg_range[g_rg_n] = range; g_rg_n++;
+}
+
 static void read_configuration(const char* filename, qhash* insertlengths)
 {
     /* src/shared.c:5-44 */
@@ -1606,6 +1655,7 @@ static void read_configuration(const char* filename, qhash* insertlengths)
             int32_t* range = xmalloc(2 * sizeof(int32_t));
             range[0] = (int32_t)a; range[1] = (int32_t)b;
             qhash_add(insertlengths, name, (int)strlen(name), range);
+            rg_order_push(name, range);
         } else if (strncmp(line, "RC", 2) == 0) {
             if (sscanf(line, "RC %127s %u\n", name, &a) != 2) fatalf("error in reading the mean coverage: %s", line);
         } else fatalf("unknown tag in configuration: %s", line);
@@ -1640,6 +1690,7 @@ static void estimate_insertlengths(driver* d, int chromid)
                 int32_t* range = xmalloc(2 * sizeof(int32_t));
                 range[0] = range[1] = isize;
                 qhash_add(d->insertlengths, rgname, (int)strlen(rgname), range);
+                rg_order_push(rgname, range);
             } else {
                 int32_t* range = q->val;
                 if (range[0] > isize) range[0] = isize;
@@ -1785,6 +1836,691 @@ static void run_contig(driver* d, int32_t tid, int32_t beg, int32_t end, bgzf_re
         }
         g_known.next = g_known.n;
     }
+}
+
+/* ======================================================== device pipeline == */
+/*
+ * Whole-contig runs.  The host's part shrinks to what north_star keeps on it -- BGZF inflate, walking
+ * the record stream, the discordant-pair table, merge / filter / print -- and everything per read
+ * happens on the device without coming back in between:
+ *
+ *   walk     records are inflated STRAIGHT INTO PINNED CHUNKS (bam_region_next_raw), each chunk goes
+ *            to the GPU with one asynchronous copy and is triaged there (im_dev_triage: fetch_func's
+ *            candidate rules, base decode + reverse complement, CIGAR-derived evidence, the DP=
+ *            pileup segments); the walking thread itself only counts reads (READCHUNK flush points
+ *            and their markers, src/indelminer.c:617-623) and serves the pair table (516-615).
+ *            Candidates accumulate on the device over the chunks of a GROUP of contigs, so that one
+ *            realign launch fills the chip.
+ *   run      one im_dev_realign_keep over the group's candidates, one im_dev_flush_cut per flush
+ *            point in file order (which evidence each flush consumes), one im_dev_cluster_groupby;
+ *            back come the realign results, the consumed marks and the cluster records.
+ *   replay   per flush: variants from the device's clusters + the host's paired-read components,
+ *            merge_variants, print_variants -- the reference's own order of output.
+ */
+
+#define PIPE_CHUNK_BYTES   (32u << 20)
+#define PIPE_CHUNK_RECS    (PIPE_CHUNK_BYTES / 64u)
+#define PIPE_NCHUNK        4
+#define PIPE_GROUP_RECORDS 3000000      /* a group closes at the first contig end past this many records */
+
+typedef struct {
+    uint8_t*  h_raw; uint32_t* h_off; int32_t* h_cnt;        /* pinned */
+    void     *d_raw, *d_off, *d_class, *d_scratch;
+    size_t    scratch_bytes;
+    int32_t   n; uint32_t bytes; int64_t rec_base, seq_bytes;
+    im_event* done;
+    int       busy;
+} pchunk;
+
+typedef struct { int64_t rec; int32_t pe; int marker; int32_t tid; } gflush;
+typedef struct { int32_t tid; int64_t rec0, rec1; int32_t pe0, pe1; int fl0, fl1; } gcontig;
+
+typedef struct {
+    int64_t n_rec;
+    gcontig* ctg; int n_ctg, cap_ctg;
+    gflush* fl; int n_fl, cap_fl;
+    evidence_t** pe; int64_t* pe_rec; int32_t n_pe, cap_pe;
+    /* candidates as the device found them: record index + a host copy of the raw record */
+    int32_t n_cand, cap_cand; int32_t* cand_rec; int64_t* craw_off; uint8_t* craw; int64_t craw_len, craw_cap;
+    /* what came back from the run stage */
+    im_read_result* res; int32_t *s_cls, *cons_sr, *cons_pe;
+    int32_t n_cl, n_nodes; int32_t *cl_key, *cl_first, *cl_count, *order, *cl_sorted;
+    evidence_t** ev_cache;
+} pgroup;
+
+typedef struct {
+    driver* d;
+    void* stream;
+    pchunk ck[PIPE_NCHUNK];
+    int cur, oldest, n_busy;
+    /* device arrays of the group (growable) */
+    int32_t cap_cand; int64_t cap_bases; int32_t cap_pe, cap_fl;
+    void *bases, *boff, *len, *tid, *anchor, *range, *res, *cls, *b1, *b2, *consumed, *cand_rec, *counters, *cut;
+    void *order, *clkey, *clfirst, *clcount, *counts, *gscratch; size_t gscratch_bytes;
+    /* confirmed by harvested chunks / still in flight */
+    int32_t conf_cand, conf_err; int64_t conf_bytes, fly_recs, fly_seq;
+    im_triage_params tp;
+    int ready;
+} ppipe;
+
+#define GPU(call) do { if ((call) != IM_OK) fatalf("%s: %s", #call, im_last_error(P->d->gpu)); } while (0)
+
+static void* pdev_alloc(ppipe* P, size_t bytes) { void* p = NULL; GPU(im_dev_alloc(P->d->gpu, bytes ? bytes : 256, &p)); return p; }
+
+static void pipe_alloc_cands(ppipe* P, int32_t cap_cand, int64_t cap_bases, int32_t cap_pe)
+{
+    const size_t nsl = (size_t)cap_cand * IM_MAX_EV + (size_t)cap_pe;
+    P->bases = pdev_alloc(P, (size_t)cap_bases);
+    P->boff = pdev_alloc(P, 8 * (size_t)cap_cand); P->len = pdev_alloc(P, 4 * (size_t)cap_cand);
+    P->tid = pdev_alloc(P, 4 * (size_t)cap_cand); P->anchor = pdev_alloc(P, 4 * (size_t)cap_cand);
+    P->range = pdev_alloc(P, 4 * (size_t)cap_cand); P->cand_rec = pdev_alloc(P, 4 * (size_t)cap_cand);
+    P->res = pdev_alloc(P, sizeof(im_read_result) * (size_t)cap_cand);
+    P->cls = pdev_alloc(P, 4 * nsl); P->b1 = pdev_alloc(P, 4 * nsl); P->b2 = pdev_alloc(P, 4 * nsl); P->consumed = pdev_alloc(P, 4 * nsl);
+    P->order = pdev_alloc(P, 4 * nsl); P->clkey = pdev_alloc(P, 16 * nsl); P->clfirst = pdev_alloc(P, 4 * nsl); P->clcount = pdev_alloc(P, 4 * nsl);
+    P->gscratch_bytes = im_dev_groupby_scratch_bytes((int32_t)nsl);
+    P->gscratch = pdev_alloc(P, P->gscratch_bytes);
+    P->cap_cand = cap_cand; P->cap_bases = cap_bases; P->cap_pe = cap_pe;
+}
+
+static void pipe_free_cands(ppipe* P)
+{
+    void* all[] = { P->bases, P->boff, P->len, P->tid, P->anchor, P->range, P->cand_rec, P->res, P->cls, P->b1, P->b2, P->consumed,
+                    P->order, P->clkey, P->clfirst, P->clcount, P->gscratch };
+    for (size_t i = 0; i < sizeof all / sizeof all[0]; i++) if (all[i]) im_dev_free(P->d->gpu, all[i]);
+}
+
+static void pipe_init(ppipe* P, driver* d)
+{
+    memset(P, 0, sizeof *P);
+    P->d = d;
+    gpu_wait(d);
+    /* the insert-length table in the order its entries were added, range[1] of each */
+    int32_t* rmax = xmalloc(sizeof(int32_t) * (size_t)(g_rg_n ? g_rg_n : 1));
+    for (int i = 0; i < g_rg_n; i++) rmax[i] = g_rg_range[i][1];
+    GPU(im_set_insert_ranges(d->gpu, g_rg_n, g_rg_name, rmax));
+    free(rmax);
+    GPU(im_depth_enable(d->gpu));
+    GPU(im_stream_create(d->gpu, &P->stream));
+    for (int i = 0; i < PIPE_NCHUNK; i++) {
+        pchunk* c = &P->ck[i];
+        GPU(im_host_alloc(d->gpu, PIPE_CHUNK_BYTES, (void**)&c->h_raw));
+        GPU(im_host_alloc(d->gpu, 4 * ((size_t)PIPE_CHUNK_RECS + 1), (void**)&c->h_off));
+        GPU(im_host_alloc(d->gpu, 64, (void**)&c->h_cnt));
+        c->d_raw = pdev_alloc(P, PIPE_CHUNK_BYTES + 64);
+        c->d_off = pdev_alloc(P, 4 * ((size_t)PIPE_CHUNK_RECS + 1));
+        c->d_class = pdev_alloc(P, PIPE_CHUNK_RECS);
+        c->scratch_bytes = im_dev_triage_scratch_bytes((int32_t)PIPE_CHUNK_RECS);
+        c->d_scratch = pdev_alloc(P, c->scratch_bytes);
+        GPU(im_event_create(d->gpu, &c->done));
+    }
+    P->counters = pdev_alloc(P, 64);
+    P->counts = pdev_alloc(P, 64);
+    P->cap_fl = 4096;
+    P->cut = pdev_alloc(P, 8 * (size_t)P->cap_fl);
+    pipe_alloc_cands(P, 1 << 20, (int64_t)(1 << 20) * 160, 1 << 16);
+    P->tp.qthreshold = O.qthreshold; P->tp.ethreshold_vcfcheck = O.ethreshold_vcfcheck; P->tp.maxpedelsize = O.maxpedelsize;
+    P->tp.want_depth = 1;
+    P->ready = 1;
+}
+
+static void pipe_destroy(ppipe* P)
+{
+    if (!P->ready) return;
+    for (int i = 0; i < PIPE_NCHUNK; i++) {
+        pchunk* c = &P->ck[i];
+        im_host_free(P->d->gpu, c->h_raw); im_host_free(P->d->gpu, c->h_off); im_host_free(P->d->gpu, c->h_cnt);
+        im_dev_free(P->d->gpu, c->d_raw); im_dev_free(P->d->gpu, c->d_off); im_dev_free(P->d->gpu, c->d_class); im_dev_free(P->d->gpu, c->d_scratch);
+        im_event_destroy(c->done);
+    }
+    pipe_free_cands(P);
+    im_dev_free(P->d->gpu, P->counters); im_dev_free(P->d->gpu, P->counts); im_dev_free(P->d->gpu, P->cut);
+    im_stream_destroy(P->d->gpu, P->stream);
+    P->ready = 0;
+}
+
+static void group_reset(pgroup* G)
+{
+    G->n_rec = 0; G->n_ctg = 0; G->n_fl = 0; G->n_pe = 0; G->n_cand = 0; G->craw_len = 0;
+    G->n_cl = 0; G->n_nodes = 0;
+}
+
+static void group_free(pgroup* G)
+{
+    free(G->ctg); free(G->fl); free(G->pe); free(G->pe_rec); free(G->cand_rec); free(G->craw_off); free(G->craw);
+    free(G->res); free(G->s_cls); free(G->cons_sr); free(G->cons_pe);
+    free(G->cl_key); free(G->cl_first); free(G->cl_count); free(G->order); free(G->cl_sorted); free(G->ev_cache);
+    memset(G, 0, sizeof *G);
+}
+
+/* the chunk's triage is complete: note what it found, copy its candidates' records to the host side store */
+static void pipe_harvest(ppipe* P, pgroup* G, pchunk* c)
+{
+    GPU(im_event_sync(c->done));
+    const int32_t n_after = c->h_cnt[0], n_err = c->h_cnt[3];
+    if (c->h_cnt[4] != 0) fatalf("internal: candidate buffers overflowed on the device");
+    if (n_err > P->conf_err) {
+        /* a record the reference exits on: replay it through the host's own fetch_func restatement for the
+         * reference's message, or name the limit it ran into */
+        uint8_t* cls = xmalloc((size_t)c->n);
+        GPU(im_dev_download(P->d->gpu, cls, c->d_class, (size_t)c->n));
+        for (int32_t i = 0; i < c->n; i++) {
+            if (cls[i] < IM_REC_ERR_RG) continue;
+            bam_record b;
+            bam_record_view(c->h_raw + c->h_off[i], (int32_t)(c->h_off[i + 1] - c->h_off[i]), &b);
+            if (cls[i] == IM_REC_ERR_LIMIT)
+                fatalf("read %s: more than %d indels in its CIGAR pass the end-distance rule, or the record is malformed (kernel limit IM_MAX_EV)", BAMR_QNAME(&b), IM_MAX_EV);
+            if (cls[i] == IM_REC_ERR_BASE) { char* s = decode_bases(&b); free(s); }
+            dispatch_record(P->d, &b);
+            fatalf("read %s: record rejected by the device triage (class %d)", BAMR_QNAME(&b), (int)cls[i]);
+        }
+        free(cls);
+    }
+    const int32_t fresh = n_after - P->conf_cand;
+    if (fresh > 0) {
+        if (n_after > G->cap_cand) {
+            G->cap_cand = n_after * 2 + 1024;
+            G->cand_rec = xrealloc(G->cand_rec, sizeof(int32_t) * (size_t)G->cap_cand);
+            G->craw_off = xrealloc(G->craw_off, sizeof(int64_t) * ((size_t)G->cap_cand + 1));
+        }
+        GPU(im_dev_download(P->d->gpu, G->cand_rec + P->conf_cand, (char*)P->cand_rec + 4 * (size_t)P->conf_cand, 4 * (size_t)fresh));
+        for (int32_t j = P->conf_cand; j < n_after; j++) {
+            const int64_t li = (int64_t)G->cand_rec[j] - c->rec_base;
+            forceassert(li >= 0 && li < c->n);
+            const uint32_t o = c->h_off[li], l = c->h_off[li + 1] - o;
+            if (G->craw_len + l > G->craw_cap) { G->craw_cap = (G->craw_cap + l) * 2 + (1 << 20); G->craw = xrealloc(G->craw, (size_t)G->craw_cap); }
+            memcpy(G->craw + G->craw_len, c->h_raw + o, l);
+            G->craw_off[j] = G->craw_len;
+            G->craw_len += l;
+            G->craw_off[j + 1] = G->craw_len;
+        }
+    }
+    P->conf_cand = n_after; P->conf_err = n_err; P->conf_bytes = c->h_cnt[1];
+    G->n_cand = n_after;
+    P->fly_recs -= c->n; P->fly_seq -= c->seq_bytes;
+    c->busy = 0; c->n = 0; c->bytes = 0; c->seq_bytes = 0;
+    P->n_busy--;
+    P->oldest = (P->oldest + 1) % PIPE_NCHUNK;
+}
+
+static void pipe_drain(ppipe* P, pgroup* G) { while (P->n_busy > 0) pipe_harvest(P, G, &P->ck[P->oldest]); }
+
+/* every record in flight may turn out to be a candidate: make room before a chunk is sent */
+static void pipe_ensure_capacity(ppipe* P, pgroup* G, int64_t add_recs, int64_t add_seq)
+{
+    int64_t need_c = (int64_t)P->conf_cand + P->fly_recs + add_recs;
+    int64_t need_b = P->conf_bytes + P->fly_seq + add_seq + 64;
+    if (need_c <= P->cap_cand && need_b <= P->cap_bases) return;
+    pipe_drain(P, G);
+    need_c = (int64_t)P->conf_cand + add_recs; need_b = P->conf_bytes + add_seq + 64;
+    if (need_c <= P->cap_cand && need_b <= P->cap_bases) return;
+    if (need_c > 0x1fffffff) fatalf("more than 2^29 candidate reads in one group of contigs");
+    ppipe old = *P;
+    int32_t nc = P->cap_cand; int64_t nb = P->cap_bases;
+    while (nc < need_c) nc *= 2;
+    while (nb < need_b) nb *= 2;
+    pipe_alloc_cands(P, nc, nb, P->cap_pe);
+    const size_t n = (size_t)P->conf_cand;
+    im_ctx* g = P->d->gpu;
+    GPU(im_dev_copy_async(g, P->bases, old.bases, (size_t)P->conf_bytes, P->stream));
+    GPU(im_dev_copy_async(g, P->boff, old.boff, 8 * n, P->stream)); GPU(im_dev_copy_async(g, P->len, old.len, 4 * n, P->stream));
+    GPU(im_dev_copy_async(g, P->tid, old.tid, 4 * n, P->stream)); GPU(im_dev_copy_async(g, P->anchor, old.anchor, 4 * n, P->stream));
+    GPU(im_dev_copy_async(g, P->range, old.range, 4 * n, P->stream)); GPU(im_dev_copy_async(g, P->cand_rec, old.cand_rec, 4 * n, P->stream));
+    GPU(im_dev_copy_async(g, P->cls, old.cls, 4 * n * IM_MAX_EV, P->stream)); GPU(im_dev_copy_async(g, P->b1, old.b1, 4 * n * IM_MAX_EV, P->stream));
+    GPU(im_dev_copy_async(g, P->b2, old.b2, 4 * n * IM_MAX_EV, P->stream));
+    GPU(im_stream_sync(g, P->stream));
+    pipe_free_cands(&old);
+}
+
+static void pipe_submit(ppipe* P, pgroup* G)
+{
+    pchunk* c = &P->ck[P->cur];
+    if (c->n == 0) return;
+    c->h_off[c->n] = c->bytes;
+    pipe_ensure_capacity(P, G, c->n, c->seq_bytes);
+    im_ctx* g = P->d->gpu;
+    GPU(im_dev_upload_async(g, c->d_raw, c->h_raw, c->bytes, P->stream));
+    GPU(im_dev_upload_async(g, c->d_off, c->h_off, 4 * ((size_t)c->n + 1), P->stream));
+    im_dev_records recs = { c->n, c->d_raw, c->d_off, (int32_t)c->rec_base };
+    im_dev_cands out;
+    memset(&out, 0, sizeof out);
+    out.batch.bases = P->bases; out.batch.base_off = P->boff; out.batch.read_len = P->len; out.batch.tid = P->tid;
+    out.batch.anchor = P->anchor; out.batch.range_max = P->range; out.batch.out = P->res;
+    out.batch.ev_cls = P->cls; out.batch.ev_b1 = P->b1; out.batch.ev_b2 = P->b2;
+    out.cand_rec = P->cand_rec; out.counters = P->counters; out.rec_class = c->d_class;
+    out.cap_cand = P->cap_cand; out.cap_bases = P->cap_bases;
+    GPU(im_dev_triage(g, &P->tp, &recs, &out, c->d_scratch, c->scratch_bytes, P->stream));
+    GPU(im_dev_download_async(g, c->h_cnt, P->counters, 32, P->stream));
+    GPU(im_event_record(c->done, P->stream));
+    c->busy = 1; P->n_busy++;
+    P->fly_recs += c->n; P->fly_seq += c->seq_bytes;
+    P->cur = (P->cur + 1) % PIPE_NCHUNK;
+    if (P->ck[P->cur].busy) pipe_harvest(P, G, &P->ck[P->cur]);     /* the ring is full: its oldest chunk comes back first */
+    P->ck[P->cur].rec_base = G->n_rec;
+}
+
+/* the host's share of fetch_func for one record: count it, serve the pair table, note flush points */
+static void pipe_host_record(driver* d, pgroup* G, const bam_record* b)
+{
+    const int flag = b->flag;
+    if (flag & (0x100 | 0x200 | 0x400 | 0x800)) return;
+    if ((flag & 0x1) == 0) return;
+    const int is_aligned = (flag & 0x4) == 0, is_mate_aligned = (flag & 0x8) == 0;
+    if (is_aligned && is_mate_aligned && b->tid != b->mtid) return;
+    if (is_aligned && is_mate_aligned && (flag & 0x2) == 0) {
+        evidence_t* e = discordant_pair(d, b, record_range(d, b));
+        if (e) {
+            if (G->n_pe == G->cap_pe) {
+                G->cap_pe = G->cap_pe ? G->cap_pe * 2 : 1024;
+                G->pe = xrealloc(G->pe, sizeof(evidence_t*) * (size_t)G->cap_pe);
+                G->pe_rec = xrealloc(G->pe_rec, sizeof(int64_t) * (size_t)G->cap_pe);
+            }
+            e->arrival = (G->n_rec - 1) * 8 + 7;
+            G->pe[G->n_pe] = e; G->pe_rec[G->n_pe] = G->n_rec - 1; G->n_pe++;
+        }
+    }
+    if ((++d->numread % READCHUNK) == 0) {
+        timestamp("Read %ld reads", (long)d->numread);
+        int marker = find_marker_live(d);
+        if (b->pos < marker) marker = b->pos;
+        if (G->n_fl == G->cap_fl) { G->cap_fl = G->cap_fl ? G->cap_fl * 2 : 256; G->fl = xrealloc(G->fl, sizeof(gflush) * (size_t)G->cap_fl); }
+        gflush* f = &G->fl[G->n_fl++];
+        f->rec = G->n_rec; f->pe = G->n_pe; f->marker = marker; f->tid = b->tid;
+    }
+}
+
+static void pipe_walk_contig(ppipe* P, pgroup* G, int32_t tid, bgzf_reader* r)
+{
+    driver* d = P->d;
+    if (G->n_ctg == G->cap_ctg) { G->cap_ctg = G->cap_ctg ? G->cap_ctg * 2 : 32; G->ctg = xrealloc(G->ctg, sizeof(gcontig) * (size_t)G->cap_ctg); }
+    gcontig* cg = &G->ctg[G->n_ctg++];
+    cg->tid = tid; cg->rec0 = G->n_rec; cg->pe0 = G->n_pe; cg->fl0 = G->n_fl;
+    bam_region_iter it;
+    if (bam_region_begin(&it, r, d->idx, tid, 0, d->hdr->target_len[tid]) != 0) fatalf("cannot seek in %s", d->bam_name);
+    bam_record b; memset(&b, 0, sizeof b);
+    for (;;) {
+        pchunk* c = &P->ck[P->cur];
+        if (c->n == 0) c->rec_base = G->n_rec;
+        int32_t len = 0;
+        const int rc = (c->n < (int32_t)PIPE_CHUNK_RECS)
+            ? bam_region_next_raw(&it, c->h_raw + c->bytes, (int64_t)PIPE_CHUNK_BYTES - c->bytes, &len, &b) : -2;
+        if (rc == -2) {
+            if (c->n == 0) fatalf("a BAM record larger than %u bytes", PIPE_CHUNK_BYTES);
+            pipe_submit(P, G);
+            continue;
+        }
+        if (rc < 0) fatalf("error while reading %s", d->bam_name);
+        if (rc == 0) break;
+        c->h_off[c->n++] = c->bytes;
+        c->bytes += ((uint32_t)len + 3u) & ~3u;
+        c->seq_bytes += ((int64_t)b.l_seq + 3) & ~(int64_t)3;
+        G->n_rec++;
+        pipe_host_record(d, G, &b);
+    }
+    /* end of contig (src/indelminer.c:806-823): everything still pending is consumed */
+    if (G->n_fl == G->cap_fl) { G->cap_fl = G->cap_fl ? G->cap_fl * 2 : 256; G->fl = xrealloc(G->fl, sizeof(gflush) * (size_t)G->cap_fl); }
+    gflush* f = &G->fl[G->n_fl++];
+    f->rec = G->n_rec; f->pe = G->n_pe; f->marker = INT_MAX; f->tid = tid;
+    cg = &G->ctg[G->n_ctg - 1];
+    cg->rec1 = G->n_rec; cg->pe1 = G->n_pe; cg->fl1 = G->n_fl;
+    /* the contig's last records go out now, so that its depth array can be finished behind them */
+    pipe_submit(P, G);
+    GPU(im_depth_scan(d->gpu, tid, P->stream));
+}
+
+static int32_t lower_bound_i32(const int32_t* a, int32_t n, int64_t v)
+{
+    int32_t lo = 0, hi = n;
+    while (lo < hi) { const int32_t mid = lo + (hi - lo) / 2; if (a[mid] < v) lo = mid + 1; else hi = mid; }
+    return lo;
+}
+
+static int g_tie_for_sort;
+static const int32_t* g_key_for_sort;
+static int cmp_cluster_idx(const void* x, const void* y)
+{
+    const int32_t* a = g_key_for_sort + 4 * (size_t)*(const int32_t*)x;
+    const int32_t* b = g_key_for_sort + 4 * (size_t)*(const int32_t*)y;
+    if (a[0] != b[0]) return a[0] < b[0] ? -1 : 1;          /* flush */
+    if (a[2] != b[2]) return a[2] < b[2] ? -1 : 1;          /* b1 */
+    if (a[3] != b[3]) return a[3] < b[3] ? -1 : 1;          /* b2 */
+    if (a[1] != b[1]) return a[1] < b[1] ? -1 : 1;          /* class */
+    return 0;
+}
+
+/* realign + flush cuts + group-by for the whole group, results to the host */
+static void pipe_run_group(ppipe* P, pgroup* G)
+{
+    driver* d = P->d;
+    im_ctx* g = d->gpu;
+    pipe_submit(P, G);
+    pipe_drain(P, G);
+    const int32_t nc = G->n_cand;
+    if (G->n_pe > P->cap_pe || G->n_fl > P->cap_fl) {
+        /* rare: more discordant pairs / flushes than the arrays were sized for */
+        GPU(im_stream_sync(g, P->stream));
+        if (G->n_fl > P->cap_fl) { im_dev_free(g, P->cut); while (P->cap_fl < G->n_fl) P->cap_fl *= 2; P->cut = pdev_alloc(P, 8 * (size_t)P->cap_fl); }
+        if (G->n_pe > P->cap_pe) {
+            ppipe old = *P;
+            int32_t np = P->cap_pe; while (np < G->n_pe) np *= 2;
+            pipe_alloc_cands(P, old.cap_cand, old.cap_bases, np);
+            const size_t n = (size_t)nc;
+            GPU(im_dev_copy_async(g, P->bases, old.bases, (size_t)P->conf_bytes, P->stream));
+            GPU(im_dev_copy_async(g, P->boff, old.boff, 8 * n, P->stream)); GPU(im_dev_copy_async(g, P->len, old.len, 4 * n, P->stream));
+            GPU(im_dev_copy_async(g, P->tid, old.tid, 4 * n, P->stream)); GPU(im_dev_copy_async(g, P->anchor, old.anchor, 4 * n, P->stream));
+            GPU(im_dev_copy_async(g, P->range, old.range, 4 * n, P->stream)); GPU(im_dev_copy_async(g, P->cand_rec, old.cand_rec, 4 * n, P->stream));
+            GPU(im_dev_copy_async(g, P->cls, old.cls, 4 * n * IM_MAX_EV, P->stream)); GPU(im_dev_copy_async(g, P->b1, old.b1, 4 * n * IM_MAX_EV, P->stream));
+            GPU(im_dev_copy_async(g, P->b2, old.b2, 4 * n * IM_MAX_EV, P->stream));
+            GPU(im_stream_sync(g, P->stream));
+            pipe_free_cands(&old);
+        }
+    }
+    const size_t pe_base = (size_t)P->cap_cand * IM_MAX_EV;
+    if (G->n_pe > 0) {
+        int32_t* t = xmalloc(sizeof(int32_t) * 3 * (size_t)G->n_pe);
+        for (int32_t i = 0; i < G->n_pe; i++) { t[i] = 2; t[G->n_pe + i] = G->pe[i]->b1; t[2 * (size_t)G->n_pe + i] = G->pe[i]->b2; }
+        GPU(im_dev_upload(g, (char*)P->cls + 4 * pe_base, t, 4 * (size_t)G->n_pe));
+        GPU(im_dev_upload(g, (char*)P->b1 + 4 * pe_base, t + G->n_pe, 4 * (size_t)G->n_pe));
+        GPU(im_dev_upload(g, (char*)P->b2 + 4 * pe_base, t + 2 * (size_t)G->n_pe, 4 * (size_t)G->n_pe));
+        free(t);
+    }
+    GPU(im_dev_memset(g, P->consumed, 0, 4 * (pe_base + (size_t)G->n_pe), P->stream));
+    GPU(im_dev_memset(g, P->cut, 0xFF, 8 * (size_t)G->n_fl, P->stream));
+    im_params prm = { O.klength, O.numgaps, O.maxdelsize, O.ethreshold };
+    if (nc > 0) {
+        im_dev_batch bt;
+        memset(&bt, 0, sizeof bt);
+        bt.n = nc; bt.bases = P->bases; bt.base_off = P->boff; bt.read_len = P->len; bt.tid = P->tid; bt.anchor = P->anchor;
+        bt.range_max = P->range; bt.out = P->res; bt.ev_cls = P->cls; bt.ev_b1 = P->b1; bt.ev_b2 = P->b2;
+        GPU(im_dev_realign_keep(g, &prm, &bt, P->stream));
+    }
+    for (int ci = 0; ci < G->n_ctg; ci++) {
+        const gcontig* cg = &G->ctg[ci];
+        const int32_t cand_lo = lower_bound_i32(G->cand_rec, nc, cg->rec0);
+        for (int f = cg->fl0; f < cg->fl1; f++) {
+            const gflush* fl = &G->fl[f];
+            const int32_t cand_hi = lower_bound_i32(G->cand_rec, nc, fl->rec);
+            GPU(im_dev_flush_cut(g, P->cls, P->b1, P->b2, P->consumed, cand_lo * IM_MAX_EV, cand_hi * IM_MAX_EV,
+                                 (int32_t)pe_base + cg->pe0, (int32_t)pe_base + fl->pe, fl->marker, f + 1,
+                                 (uint64_t*)P->cut + f, P->stream));
+        }
+    }
+    GPU(im_dev_cluster_groupby(g, nc * IM_MAX_EV, P->cls, P->b1, P->b2, P->consumed, O.tie_desc,
+                               P->order, P->clkey, P->clfirst, P->clcount, P->counts, P->gscratch, P->gscratch_bytes, P->stream));
+    GPU(im_stream_sync(g, P->stream));
+    phase_time("device: realign + flush cuts + group-by");
+
+    G->res = xrealloc(G->res, sizeof(im_read_result) * (size_t)(nc ? nc : 1));
+    G->s_cls = xrealloc(G->s_cls, 4 * (size_t)(nc ? nc : 1) * IM_MAX_EV);
+    G->cons_sr = xrealloc(G->cons_sr, 4 * (size_t)(nc ? nc : 1) * IM_MAX_EV);
+    G->cons_pe = xrealloc(G->cons_pe, 4 * (size_t)(G->n_pe ? G->n_pe : 1));
+    int32_t counts[2] = { 0, 0 };
+    if (nc > 0) {
+        GPU(im_dev_download(g, G->res, P->res, sizeof(im_read_result) * (size_t)nc));
+        GPU(im_dev_download(g, G->s_cls, P->cls, 4 * (size_t)nc * IM_MAX_EV));
+        GPU(im_dev_download(g, G->cons_sr, P->consumed, 4 * (size_t)nc * IM_MAX_EV));
+    }
+    if (G->n_pe > 0) GPU(im_dev_download(g, G->cons_pe, (char*)P->consumed + 4 * pe_base, 4 * (size_t)G->n_pe));
+    GPU(im_dev_download(g, counts, P->counts, 8));
+    G->n_cl = counts[0]; G->n_nodes = counts[1];
+    G->cl_key = xrealloc(G->cl_key, 16 * (size_t)(G->n_cl ? G->n_cl : 1));
+    G->cl_first = xrealloc(G->cl_first, 4 * (size_t)(G->n_cl ? G->n_cl : 1));
+    G->cl_count = xrealloc(G->cl_count, 4 * (size_t)(G->n_cl ? G->n_cl : 1));
+    G->cl_sorted = xrealloc(G->cl_sorted, 4 * (size_t)(G->n_cl ? G->n_cl : 1));
+    G->order = xrealloc(G->order, 4 * (size_t)(G->n_nodes ? G->n_nodes : 1));
+    if (G->n_cl > 0) {
+        GPU(im_dev_download(g, G->cl_key, P->clkey, 16 * (size_t)G->n_cl));
+        GPU(im_dev_download(g, G->cl_first, P->clfirst, 4 * (size_t)G->n_cl));
+        GPU(im_dev_download(g, G->cl_count, P->clcount, 4 * (size_t)G->n_cl));
+        GPU(im_dev_download(g, G->order, P->order, 4 * (size_t)G->n_nodes));
+    }
+    /* the device groups; the host puts the few clusters in (flush, b1, b2, class) order */
+    for (int32_t i = 0; i < G->n_cl; i++) G->cl_sorted[i] = i;
+    g_key_for_sort = G->cl_key;
+    qsort(G->cl_sorted, (size_t)G->n_cl, sizeof(int32_t), cmp_cluster_idx);
+    G->ev_cache = xrealloc(G->ev_cache, sizeof(evidence_t*) * (size_t)(nc ? nc : 1) * IM_MAX_EV);
+    memset(G->ev_cache, 0, sizeof(evidence_t*) * (size_t)(nc ? nc : 1) * IM_MAX_EV);
+    for (int32_t i = 0; i < nc; i++) {
+        const int st = G->res[i].status;
+        if (st == IM_ST_ABORT) fatalf("im_dev_realign: read %d: the reference would abort on this input", i);
+        if (st == IM_ST_OVERFLOW) fatalf("im_dev_realign: read %d: segment list longer than IM_MAX_OPS", i);
+        if (st == IM_ST_UNSUPPORTED) fatalf("im_dev_realign: read %d: longer than IM_MAX_READ=%d", i, IM_MAX_READ);
+    }
+    P->conf_cand = 0; P->conf_err = 0; P->conf_bytes = 0;
+    GPU(im_dev_memset(g, P->counters, 0, 64, P->stream));
+    phase_time("results to the host");
+}
+
+/* the evidence objects of candidate `cand`: the realigned segments when the device found any (they
+ * replace the CIGAR-derived ones, src/indelminer.c:494-502), else the CIGAR-derived */
+static void group_candidate_evidence(driver* d, pgroup* G, int32_t cand)
+{
+    bam_record b;
+    bam_record_view(G->craw + G->craw_off[cand], (int32_t)(G->craw_off[cand + 1] - G->craw_off[cand]), &b);
+    const int flag = b.flag;
+    const int is_aligned = (flag & 0x4) == 0, is_rc = (flag & 0x10) != 0, is_mate_rc = (flag & 0x20) != 0;
+    const char* qname = BAMR_QNAME(&b);
+    const im_read_result* r = &G->res[cand];
+    evidence_t** slot = &G->ev_cache[(size_t)cand * IM_MAX_EV];
+    const int64_t arrival0 = (int64_t)G->cand_rec[cand] * 8;
+    if (r->status == IM_ST_EVIDENCE && r->n_ev > 0) {
+        char* bases = decode_bases(&b);
+        char strand = is_rc ? '-' : '+';
+        uint8_t qual;
+        if (!is_aligned) {
+            qual = (uint8_t)mate_mapq(&b, 1);
+            if (!is_mate_rc) { revcomp_inplace(bases); strand = (strand == '+') ? '-' : '+'; }
+        } else {
+            qual = b.mapq;
+            if (is_rc == is_mate_rc) { revcomp_inplace(bases); strand = (strand == '+') ? '-' : '+'; }
+        }
+        seglist whole;
+        whole.ref_start = r->ref_start; whole.n = r->n_ops; whole.ops = (uint32_t*)r->ops; whole.bases = bases;
+        for (int k = 0; k < r->n_ev && k < IM_MAX_EV; k++) {
+            const im_evidence* ge = &r->ev[k];
+            evidence_t* e = xcalloc(1, sizeof *e);
+            e->type = EV_SPLIT_READ; e->cls = ge->cls; e->strand = strand; e->qual = qual;
+            e->qname = xstrdup(qname);
+            e->aln = seglist_copy(&whole);
+            e->seg = ge->seg; e->b1 = ge->b1; e->b2 = ge->b2;
+            e->lflank = ge->lflank; e->rflank = ge->rflank; e->nd_print = ge->nd_print; e->nd_filter = ge->nd_filter;
+            e->arrival = arrival0 + k;
+            slot[k] = e;
+        }
+        free(bases);
+    } else if (is_aligned) {
+        seglist rln = seglist_from_record(&b);
+        evidence_t** bwa = xmalloc(sizeof(evidence_t*) * (size_t)(rln.n ? rln.n : 1));
+        const int n = check_variants(&rln, is_rc ? '-' : '+', b.mapq, qname, d->sequences[b.tid], bwa);
+        forceassert(n <= IM_MAX_EV);
+        for (int k = 0; k < n; k++) { bwa[k]->arrival = arrival0 + k; slot[k] = bwa[k]; }
+        free(bwa);
+        seglist_free(&rln);
+    }
+}
+
+static evidence_t* group_sr_evidence(driver* d, pgroup* G, int32_t slot)
+{
+    if (!G->ev_cache[slot]) group_candidate_evidence(d, G, slot / IM_MAX_EV);
+    forceassert(G->ev_cache[slot] != NULL);
+    return G->ev_cache[slot];
+}
+
+/* position of evidence in process_evidence's sorted list, as a comparison (src/evidence.c:50-58 + the stable
+ * sort of a prepend list): (b1, b2), then newest first -- oldest first with tie_desc */
+static int sorted_before(int32_t a1, int32_t a2, int64_t aarr, int32_t b1, int32_t b2, int64_t barr)
+{
+    if (a1 != b1) return a1 < b1;
+    if (a2 != b2) return a2 < b2;
+    return O.tie_desc ? aarr < barr : aarr > barr;
+}
+
+static int cmp_pe_sorted(const void* x, const void* y)
+{
+    const evidence_t* a = *(evidence_t* const*)x; const evidence_t* b = *(evidence_t* const*)y;
+    if (a->b1 != b->b1) return a->b1 < b->b1 ? -1 : 1;
+    if (a->b2 != b->b2) return a->b2 < b->b2 ? -1 : 1;
+    if (a->arrival == b->arrival) return 0;
+    if (g_tie_for_sort) return a->arrival < b->arrival ? -1 : 1;
+    return a->arrival > b->arrival ? -1 : 1;
+}
+
+/* process_evidence (src/indelminer.c:117-209) for flush f of the group: the nodes are what the device
+ * marked with this flush's id; split-read components are the device's clusters, paired-read components
+ * are made here (src/graph.c:100-121) */
+static void group_process_flush(driver* d, pgroup* G, const gcontig* cg, int f, int32_t* cl_cursor,
+                                variant_list* out, evidence_t*** used_out, int64_t* n_used_out)
+{
+    variant_list vars = {0};
+    const int id = f + 1;
+    int64_t n_used = 0, cap_used = 64;
+    evidence_t** used = xmalloc(sizeof(evidence_t*) * (size_t)cap_used);
+#define USED_PUSH(e) do { if (n_used == cap_used) { cap_used *= 2; used = xrealloc(used, sizeof(evidence_t*) * (size_t)cap_used); } used[n_used++] = (e); } while (0)
+    while (*cl_cursor < G->n_cl && G->cl_key[4 * (size_t)G->cl_sorted[*cl_cursor]] == id) {
+        const int32_t c = G->cl_sorted[(*cl_cursor)++];
+        const int32_t* key = G->cl_key + 4 * (size_t)c;
+        const int32_t first = G->cl_first[c], cnt = G->cl_count[c];
+        variant_t* v = xcalloc(1, sizeof *v);
+        v->type = key[1]; v->evdnctype = EV_SPLIT_READ; v->tid = cg->tid;
+        v->start = (uint32_t)key[2]; v->stop = (uint32_t)key[3]; v->support = (uint32_t)cnt;
+        v->evidence = xmalloc(sizeof(evidence_t*) * (size_t)cnt);
+        int64_t rep = -1;
+        for (int32_t k = 0; k < cnt; k++) {
+            evidence_t* e = group_sr_evidence(d, G, G->order[first + k]);
+            v->evidence[k] = e;
+            USED_PUSH(e);
+            /* the member with the largest sorted position: oldest arrival, newest with tie_desc */
+            if (rep < 0 || (O.tie_desc ? e->arrival > rep : e->arrival < rep)) rep = e->arrival;
+        }
+        v->rep_b1 = key[2]; v->rep_b2 = key[3]; v->rep_arrival = rep;
+        if (v->start <= v->stop) vl_push(&vars, v); else variant_free(v);
+    }
+    /* paired-read nodes of this flush, in sorted order */
+    int npe = 0;
+    for (int32_t i = cg->pe0; i < G->fl[f].pe; i++) if (G->cons_pe[i] == id) npe++;
+    if (npe > 0) {
+        evidence_t** pe = xmalloc(sizeof(evidence_t*) * (size_t)npe);
+        int m = 0;
+        for (int32_t i = cg->pe0; i < G->fl[f].pe; i++) if (G->cons_pe[i] == id) { pe[m++] = G->pe[i]; USED_PUSH(G->pe[i]); }
+        g_tie_for_sort = O.tie_desc;
+        qsort(pe, (size_t)npe, sizeof(evidence_t*), cmp_pe_sorted);
+        int* parent = xmalloc(sizeof(int) * (size_t)npe);
+        for (int i = 0; i < npe; i++) parent[i] = i;
+        for (int j = 0; j < npe; j++) {
+            const evidence_t* e1 = pe[j];
+            for (int i = 0; i < j; i++) {
+                const evidence_t* e2 = pe[i];
+                forceassert(e2->b1 <= e1->b1);
+                if (e2->b1 < e1->b2 && e1->cls == e2->cls) {
+                    const int32_t bb1 = e1->b1 > e2->b1 ? e1->b1 : e2->b1;
+                    const int32_t bb2 = e1->b2 < e2->b2 ? e1->b2 : e2->b2;
+                    const int32_t d1 = bb1 - seglist_first_start(&e1->aln) + seglist_last_end(&e1->aln3) - bb2;
+                    const int32_t d2 = bb1 - seglist_first_start(&e2->aln) + seglist_last_end(&e2->aln3) - bb2;
+                    if (d1 < e1->max && d2 < e2->max) { int a = uf_find(parent, i), c = uf_find(parent, j); if (a != c) parent[a] = c; }
+                }
+            }
+        }
+        uint8_t* done = xcalloc((size_t)npe, 1);
+        for (int j = npe - 1; j >= 0; j--) {
+            if (done[j]) continue;
+            const int root = uf_find(parent, j);
+            variant_t* v = xcalloc(1, sizeof *v);
+            v->evidence = xmalloc(sizeof(evidence_t*) * (size_t)npe);
+            int left = -1, right = -1;
+            for (int t = j; t >= 0; t--) {
+                if (done[t] || uf_find(parent, t) != root) continue;
+                done[t] = 1;
+                evidence_t* e = pe[t];
+                v->evidence[v->support++] = e;
+                if (left == -1 || e->b1 > left) left = e->b1;
+                if (right == -1 || e->b2 < right) right = e->b2;
+            }
+            const evidence_t* e0 = v->evidence[0];
+            v->type = e0->cls; v->evdnctype = e0->type; v->tid = cg->tid;
+            v->start = (uint32_t)left; v->stop = (uint32_t)right;
+            v->rep_b1 = pe[j]->b1; v->rep_b2 = pe[j]->b2; v->rep_arrival = pe[j]->arrival;
+            if (v->start <= v->stop) vl_push(&vars, v); else variant_free(v);
+        }
+        free(parent); free(done); free(pe);
+    }
+    /* components are numbered from the largest sorted position down, the variant list is built by
+     * prepending, and sort_variants is stable: equal (start,stop) come out in ascending order of the
+     * component's largest sorted position */
+    for (int i = 1; i < vars.n; i++) {
+        variant_t* v = vars.v[i]; int j = i - 1;
+        while (j >= 0 && sorted_before((int32_t)v->rep_b1, (int32_t)v->rep_b2, v->rep_arrival,
+                                       (int32_t)vars.v[j]->rep_b1, (int32_t)vars.v[j]->rep_b2, vars.v[j]->rep_arrival)) { vars.v[j + 1] = vars.v[j]; j--; }
+        vars.v[j + 1] = v;
+    }
+    sort_variants(&vars);
+    *out = vars;
+    *used_out = used; *n_used_out = n_used;
+#undef USED_PUSH
+}
+
+static void group_replay(driver* d, pgroup* G)
+{
+    int32_t cursor = 0;
+    for (int ci = 0; ci < G->n_ctg; ci++) {
+        const gcontig* cg = &G->ctg[ci];
+        const int32_t tid = cg->tid;
+        d->depth_tid = tid;
+        for (int f = cg->fl0; f < cg->fl1; f++) {
+            variant_list vs = {0};
+            evidence_t** used = NULL; int64_t n_used = 0;
+            group_process_flush(d, G, cg, f, &cursor, &vs, &used, &n_used);
+            if (g_vcfname == NULL) {
+                merge_variants(&vs, d->sequences[tid], d->seqlen[tid], 1);
+                print_variants(d, &vs);
+            } else {
+                merge_variants(&vs, d->sequences[tid], d->seqlen[tid], 0);
+                print_knownvariants(d, &g_known, &vs);
+            }
+            fflush(stdout);
+            for (int i = 0; i < vs.n; i++) variant_free(vs.v[i]);
+            free(vs.v);
+            for (int64_t i = 0; i < n_used; i++) evidence_free(used[i]);
+            free(used);
+        }
+        if (g_vcfname != NULL) {
+            for (int ki = g_known.next; ki < g_known.n; ki++) {
+                knownvariant_t* k = g_known.v[ki];
+                print_vcf_line(d, k);
+                if (k->evdnctype == EV_SPLIT_READ && is_indel_supported(d, k)) printf(";%s", g_sample_name);
+                printf("\n");
+            }
+            g_known.next = g_known.n;
+        }
+    }
+    /* evidence objects that were built for a read but never reached a cluster (a consumed slot whose
+     * cluster was dropped is freed with its flush; nothing else is ever built) */
+    phase_time("replay (variants, merge, print)");
+}
+
+static void run_pipeline(driver* d, bgzf_reader* r)
+{
+    ppipe P; pgroup G;
+    memset(&P, 0, sizeof P); memset(&G, 0, sizeof G);
+    P.d = d;
+    d->pipe_mode = 1;
+    pipe_init(&P, d);               /* the records are inflated into pinned chunks: the GPU context comes first */
+    for (int32_t i = 0; i < d->hdr->n_targets; i++) {
+        if (g_vcfname != NULL) {
+            known_free(&g_known);
+            read_variants(g_vcfname, i, d->hdr->target_name[i], &g_known);
+            if (g_known.n == 0) continue;           /* src/indelminer.c:788 */
+        }
+        pipe_walk_contig(&P, &G, i, r);
+        phase_time("walk (inflate + count + pair table; triage on the device)");
+        const int last = i == d->hdr->n_targets - 1;
+        if (g_vcfname != NULL || last || G.n_rec >= PIPE_GROUP_RECORDS) {
+            pipe_run_group(&P, &G);
+            group_replay(d, &G);
+            group_reset(&G);
+        }
+    }
+    if (G.n_ctg > 0) { pipe_run_group(&P, &G); group_replay(d, &G); }
+    pipe_destroy(&P);
+    group_free(&G);
 }
 
 /* -------------------------------------------------------------------- main -- */
@@ -1935,7 +2671,12 @@ int main(int argc, char** argv)
     if (pthread_create(&d.gpu_thread, NULL, gpu_open_thread, &d) != 0) fatalf("cannot start the GPU helper thread");
 
 
-    for (int32_t i = 0; i < d.hdr->n_targets; i++) {
+    /* whole-contig runs take the device pipeline; region runs (-c) keep the per-contig host path, whose
+     * mate look-ups and depth queries go to the BAM file like the reference's */
+    const char* pl = getenv("INDELMINER_PIPELINE");
+    const int use_pipeline = chromid == -1 && !(pl && strcmp(pl, "host") == 0);
+    if (use_pipeline) run_pipeline(&d, r);
+    for (int32_t i = 0; i < d.hdr->n_targets && !use_pipeline; i++) {
         if (chromid != -1 && i != chromid) continue;
         if (g_vcfname != NULL) {
             known_free(&g_known);

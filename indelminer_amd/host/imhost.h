@@ -55,6 +55,7 @@ typedef struct {
     int32_t  lflank, rflank, nd_print, nd_filter;   /* src/variant.c:217-290,704-775 */
     int      used;
     int64_t  arrival;               /* position in arrival order */
+    int32_t  live_slot;             /* paired-read evidence waiting for its second mate: index in the driver's live list */
 } evidence_t;
 
 typedef struct {

@@ -7,6 +7,7 @@
  * It lives under tests/ and is linked only into tests/shim/indelminer_shim; the product
  * binary links the HIP library and has no CPU path.
  */
+#define _POSIX_C_SOURCE 200809L
 #include <limits.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -110,5 +111,205 @@ int im_support_batch(im_ctx* c, int32_t n, const uint8_t* targets, const int64_t
                      (const char*)queries + q_off[i], (int32_t)(q_off[i + 1] - q_off[i]), &subs, &indels, &aligned);
         out[4 * i] = subs; out[4 * i + 1] = indels; out[4 * i + 2] = aligned; out[4 * i + 3] = IM_ST_EVIDENCE;
     }
+    return IM_OK;
+}
+
+/* ---- the device-pipeline entry points, CPU edition (host pointers stand in for device pointers,
+ * everything runs synchronously) ------------------------------------------------------------------ */
+
+struct im_event { int dummy; };
+static int g_n_rg; static char** g_rg_names; static int32_t* g_rg_range;
+static int32_t** g_gdepth;      /* per contig, length + 1 */
+
+int im_set_insert_ranges(im_ctx* c, int32_t n, const char* const* names, const int32_t* range_max)
+{
+    (void)c;
+    g_n_rg = n; g_rg_names = calloc((size_t)n + 1, sizeof(char*)); g_rg_range = calloc((size_t)n + 1, sizeof(int32_t));
+    for (int i = 0; i < n; i++) { g_rg_names[i] = strdup(names[i]); g_rg_range[i] = range_max[i]; }
+    return IM_OK;
+}
+int im_depth_enable(im_ctx* c)
+{
+    if (g_gdepth) return IM_OK;
+    g_gdepth = calloc((size_t)c->n, sizeof(int32_t*));
+    for (int i = 0; i < c->n; i++) g_gdepth[i] = calloc((size_t)c->lens[i] + 2, sizeof(int32_t));
+    return IM_OK;
+}
+int im_depth_scan(im_ctx* c, int32_t tid, void* stream)
+{
+    (void)stream;
+    int32_t run = 0;
+    for (int64_t p = 0; p <= c->lens[tid]; p++) { run += g_gdepth[tid][p]; g_gdepth[tid][p] = run; }
+    return IM_OK;
+}
+int im_depth_query_tid(im_ctx* c, int32_t tid, int32_t n, const int32_t* beg, const int32_t* end, uint32_t* sum_out)
+{
+    for (int32_t q = 0; q < n; q++) {
+        int64_t a = beg[q], b = end[q];
+        if (a < 0) a = 0;
+        if (b > c->lens[tid]) b = c->lens[tid];
+        uint32_t s = 0;
+        for (int64_t p = a; p < b; p++) s += (uint32_t)g_gdepth[tid][p];
+        sum_out[q] = s;
+    }
+    return IM_OK;
+}
+int im_stream_create(im_ctx* c, void** out) { (void)c; *out = NULL; return IM_OK; }
+int im_stream_destroy(im_ctx* c, void* s) { (void)c; (void)s; return IM_OK; }
+int im_stream_sync(im_ctx* c, void* s) { (void)c; (void)s; return IM_OK; }
+int im_host_alloc(im_ctx* c, size_t bytes, void** out) { (void)c; *out = malloc(bytes ? bytes : 1); return IM_OK; }
+int im_host_free(im_ctx* c, void* p) { (void)c; free(p); return IM_OK; }
+int im_dev_alloc(im_ctx* c, size_t bytes, void** out) { (void)c; *out = calloc(bytes ? bytes : 1, 1); return IM_OK; }
+int im_dev_free(im_ctx* c, void* p) { (void)c; free(p); return IM_OK; }
+int im_dev_upload(im_ctx* c, void* dst, const void* src, size_t bytes) { (void)c; memcpy(dst, src, bytes); return IM_OK; }
+int im_dev_download(im_ctx* c, void* dst, const void* src, size_t bytes) { (void)c; memcpy(dst, src, bytes); return IM_OK; }
+int im_dev_upload_async(im_ctx* c, void* dst, const void* src, size_t bytes, void* s) { (void)c; (void)s; memcpy(dst, src, bytes); return IM_OK; }
+int im_dev_download_async(im_ctx* c, void* dst, const void* src, size_t bytes, void* s) { (void)c; (void)s; memcpy(dst, src, bytes); return IM_OK; }
+int im_dev_copy_async(im_ctx* c, void* dst, const void* src, size_t bytes, void* s) { (void)c; (void)s; memcpy(dst, src, bytes); return IM_OK; }
+int im_dev_memset(im_ctx* c, void* dst, int byte, size_t bytes, void* s) { (void)c; (void)s; memset(dst, byte, bytes); return IM_OK; }
+int im_event_create(im_ctx* c, im_event** out) { (void)c; *out = calloc(1, sizeof(im_event)); return IM_OK; }
+void im_event_destroy(im_event* e) { free(e); }
+int im_event_record(im_event* e, void* s) { (void)e; (void)s; return IM_OK; }
+int im_event_sync(im_event* e) { (void)e; return IM_OK; }
+size_t im_dev_triage_scratch_bytes(int32_t n) { (void)n; return 256; }
+size_t im_dev_groupby_scratch_bytes(int32_t n) { (void)n; return 256; }
+
+int im_dev_triage(im_ctx* c, const im_triage_params* tp, const im_dev_records* recs, const im_dev_cands* out,
+                  void* scratch, size_t scratch_bytes, void* stream)
+{
+    (void)scratch; (void)scratch_bytes; (void)stream;
+    int32_t* cnt = out->counters;
+    imo_triage t;
+    char* bases = malloc(1 << 20);
+    for (int32_t i = 0; i < recs->n; i++) {
+        const uint8_t* rec = recs->raw + recs->rec_off[i];
+        const uint32_t len = recs->rec_off[i + 1] - recs->rec_off[i];
+        imo_triage_record(rec, len, g_n_rg, (const char* const*)g_rg_names, g_rg_range, tp->qthreshold, tp->ethreshold_vcfcheck,
+                          tp->maxpedelsize, &t, bases);
+        int cls = t.cls;
+        if (cls == 3 && t.n_ev > IM_MAX_EV) cls = IM_REC_ERR_LIMIT;
+        if (out->rec_class) out->rec_class[i] = (uint8_t)cls;
+        if (cls != IM_REC_SKIP) cnt[2]++;
+        if (cls >= IM_REC_ERR_RG) cnt[3]++;
+        if (tp->want_depth && g_gdepth) {
+            /* the pileup's read filter and match segments (src/shared.c:160-176, bam_pileup.c:171-172), difference form */
+#define RD32(o) ((int32_t)((uint32_t)rec[o] | ((uint32_t)rec[(o) + 1] << 8) | ((uint32_t)rec[(o) + 2] << 16) | ((uint32_t)rec[(o) + 3] << 24)))
+            const int32_t tid = RD32(0);
+            const int flag = rec[14] | (rec[15] << 8), ncig = rec[12] | (rec[13] << 8), lq = rec[8];
+            if (len >= 32 && tid >= 0 && tid < c->n && !(flag & (0x4 | 0x100 | 0x200 | 0x400)) && 32u + (uint32_t)lq + 4u * (uint32_t)ncig <= len) {
+                int64_t x = RD32(4);
+                for (int k = 0; k < ncig; k++) {
+                    const uint32_t w = (uint32_t)RD32(32 + lq + 4 * k);
+                    const int op = (int)(w & 15u); const int64_t l = w >> 4;
+                    if (op == 0 || op == 7 || op == 8) {
+                        int64_t a = x < 0 ? 0 : x, b = x + l > c->lens[tid] ? c->lens[tid] : x + l;
+                        if (a < b) { g_gdepth[tid][a] += 1; g_gdepth[tid][b] -= 1; }
+                        x += l;
+                    } else if (op == 2 || op == 3) x += l;
+                }
+            }
+#undef RD32
+        }
+        if (t.cls != 2 && t.cls != 3) continue;
+        const int32_t ci = cnt[0];
+        const int64_t bo = cnt[1];
+        const int32_t padded = (t.l_seq + 3) & ~3;
+        if (ci >= out->cap_cand || bo + padded + 16 > out->cap_bases) { cnt[4]++; cnt[0]++; cnt[1] += padded; continue; }
+        memset((uint8_t*)out->batch.bases + bo, 0, (size_t)padded);
+        memcpy((uint8_t*)out->batch.bases + bo, bases, (size_t)t.l_seq);
+        ((int64_t*)out->batch.base_off)[ci] = bo; ((int32_t*)out->batch.read_len)[ci] = t.l_seq;
+        ((int32_t*)out->batch.tid)[ci] = t.tid; ((int32_t*)out->batch.anchor)[ci] = t.anchor; ((int32_t*)out->batch.range_max)[ci] = t.range_max;
+        out->cand_rec[ci] = recs->rec_base + i;
+        for (int k = 0; k < IM_MAX_EV; k++) {
+            const int live = k < t.n_ev && t.n_ev <= IM_MAX_EV;
+            out->batch.ev_cls[(size_t)ci * IM_MAX_EV + k] = live ? t.ev_cls[k] : -1;
+            out->batch.ev_b1[(size_t)ci * IM_MAX_EV + k] = live ? t.ev_b1[k] : 0;
+            out->batch.ev_b2[(size_t)ci * IM_MAX_EV + k] = live ? t.ev_b2[k] : 0;
+        }
+        cnt[0]++; cnt[1] += padded;
+    }
+    free(bases);
+    return IM_OK;
+}
+
+int im_dev_realign_keep(im_ctx* c, const im_params* p, const im_dev_batch* b, void* stream)
+{
+    (void)stream;
+    im_read_batch hb;
+    int64_t* off = malloc(sizeof(int64_t) * ((size_t)b->n + 1));
+    uint8_t* bases = malloc(1);
+    int64_t tot = 0;
+    for (int32_t i = 0; i < b->n; i++) tot += b->read_len[i];
+    bases = realloc(bases, (size_t)tot + 16);
+    tot = 0;
+    for (int32_t i = 0; i < b->n; i++) { off[i] = tot; memcpy(bases + tot, b->bases + b->base_off[i], (size_t)b->read_len[i]); tot += b->read_len[i]; }
+    off[b->n] = tot;
+    hb.n = b->n; hb.bases = bases; hb.base_off = off; hb.tid = b->tid; hb.anchor = b->anchor; hb.range_max = b->range_max;
+    (void)im_realign_batch(c, p, &hb, b->out);      /* per-read statuses are checked by the caller */
+    for (int32_t i = 0; i < b->n; i++) {
+        const im_read_result* r = &b->out[i];
+        if (r->status != IM_ST_EVIDENCE || r->n_ev <= 0 || !b->ev_cls) continue;
+        for (int k = 0; k < IM_MAX_EV; k++) {
+            const int live = k < r->n_ev;
+            b->ev_cls[(size_t)i * IM_MAX_EV + k] = live ? r->ev[k].cls : -1;
+            b->ev_b1[(size_t)i * IM_MAX_EV + k] = live ? r->ev[k].b1 : 0;
+            b->ev_b2[(size_t)i * IM_MAX_EV + k] = live ? r->ev[k].b2 : 0;
+        }
+    }
+    free(off); free(bases);
+    return IM_OK;
+}
+
+int im_dev_flush_cut(im_ctx* c, const int32_t* cls, const int32_t* b1, const int32_t* b2, int32_t* consumed,
+                     int32_t a0, int32_t a1, int32_t b0, int32_t b1_end, int32_t marker, int32_t flush_id,
+                     uint64_t* cut_word, void* stream)
+{
+    (void)c; (void)cut_word; (void)stream;
+    const int32_t na = a1 > a0 ? a1 - a0 : 0, nb = b1_end > b0 ? b1_end - b0 : 0, n = na + nb;
+    if (n == 0) return IM_OK;
+    int32_t *tc = malloc(4 * (size_t)n), *t1 = malloc(4 * (size_t)n), *t2 = malloc(4 * (size_t)n), *tu = malloc(4 * (size_t)n);
+    for (int32_t i = 0; i < n; i++) {
+        const int32_t s = i < na ? a0 + i : b0 + (i - na);
+        tc[i] = cls[s]; t1[i] = b1[s]; t2[i] = b2[s]; tu[i] = consumed[s];
+    }
+    imo_flush_cut(n, tc, t1, t2, tu, marker, flush_id);
+    for (int32_t i = 0; i < n; i++) consumed[i < na ? a0 + i : b0 + (i - na)] = tu[i];
+    free(tc); free(t1); free(t2); free(tu);
+    return IM_OK;
+}
+
+typedef struct { int32_t f, c, b1, b2, slot; } gkey;
+static int cmp_gkey(const void* x, const void* y)
+{
+    const gkey* a = x; const gkey* b = y;
+    if (a->f != b->f) return a->f < b->f ? -1 : 1;
+    if (a->b1 != b->b1) return a->b1 < b->b1 ? -1 : 1;
+    if (a->b2 != b->b2) return a->b2 < b->b2 ? -1 : 1;
+    if (a->c != b->c) return a->c < b->c ? -1 : 1;
+    return a->slot < b->slot ? -1 : a->slot > b->slot;
+}
+int im_dev_cluster_groupby(im_ctx* c, int32_t n_slots, const int32_t* cls, const int32_t* b1, const int32_t* b2,
+                           const int32_t* consumed, int32_t tie_desc,
+                           int32_t* order, int32_t* cl_key, int32_t* cl_first, int32_t* cl_count, int32_t* counts,
+                           void* scratch, size_t scratch_bytes, void* stream)
+{
+    (void)c; (void)scratch; (void)scratch_bytes; (void)stream;
+    gkey* k = malloc(sizeof(gkey) * (size_t)(n_slots > 0 ? n_slots : 1));
+    int32_t m = 0;
+    for (int32_t i = 0; i < n_slots; i++)
+        if (cls[i] >= 0 && cls[i] < 2 && consumed[i] > 0) { k[m].f = consumed[i]; k[m].c = cls[i]; k[m].b1 = b1[i]; k[m].b2 = b2[i]; k[m].slot = i; m++; }
+    qsort(k, (size_t)m, sizeof(gkey), cmp_gkey);
+    int32_t ncl = 0;
+    for (int32_t i = 0; i < m;) {
+        int32_t j = i;
+        while (j < m && k[j].f == k[i].f && k[j].c == k[i].c && k[j].b1 == k[i].b1 && k[j].b2 == k[i].b2) j++;
+        cl_key[4 * ncl] = k[i].f; cl_key[4 * ncl + 1] = k[i].c; cl_key[4 * ncl + 2] = k[i].b1; cl_key[4 * ncl + 3] = k[i].b2;
+        cl_first[ncl] = i; cl_count[ncl] = j - i;
+        for (int32_t t = i; t < j; t++) order[tie_desc ? (j - 1 - (t - i)) : t] = k[t].slot;
+        ncl++;
+        i = j;
+    }
+    counts[0] = ncl; counts[1] = m;
+    free(k);
     return IM_OK;
 }

@@ -35,7 +35,8 @@ FLAG_MATRIX = {
 
 def _build_shim():
     srcs = [os.path.join(ROOT, "indelminer_amd", "host", "imhost.c"), os.path.join(ROOT, "indelminer_amd", "host", "hostio.c"),
-            os.path.join(ROOT, "tests", "shim", "im_shim.c"), os.path.join(ROOT, "oracle", "im_oracle.c")]
+            os.path.join(ROOT, "tests", "shim", "im_shim.c"), os.path.join(ROOT, "oracle", "im_oracle.c"),
+            os.path.join(ROOT, "oracle", "im_oracle_triage.c")]
     if os.path.exists(SHIM) and all(os.path.getmtime(s) <= os.path.getmtime(SHIM) for s in srcs):
         return SHIM
     subprocess.check_call(["gcc", "-O2", "-std=c11", "-pthread", "-I" + os.path.join(ROOT, "include"),
