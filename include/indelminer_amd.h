@@ -342,6 +342,9 @@ int im_dev_triage(im_ctx* ctx, const im_triage_params* tp, const im_dev_records*
 /* im_dev_realign that leaves the evidence slots of reads WITHOUT realigned evidence untouched (the
  * CIGAR-derived evidence im_dev_triage put there survives, as at src/indelminer.c:504-510). */
 int im_dev_realign_keep(im_ctx* ctx, const im_params* params, const im_dev_batch* batch, void* stream);
+/* the same with the batch size read from DEVICE memory (*n_dev, e.g. counters[0] of im_dev_cands), so that no host
+ * round trip sits between triage and realignment; batch->n is the upper bound the launch is sized for. */
+int im_dev_realign_n(im_ctx* ctx, const im_params* params, const im_dev_batch* batch, const int32_t* n_dev, int32_t keep_slots, void* stream);
 
 /* ---- seam 2, streaming form: the READCHUNK flushes on the device ---------------- */
 
@@ -354,6 +357,12 @@ int im_dev_realign_keep(im_ctx* ctx, const im_params* params, const im_dev_batch
 int im_dev_flush_cut(im_ctx* ctx, const int32_t* cls, const int32_t* b1, const int32_t* b2, int32_t* consumed,
                      int32_t a0, int32_t a1, int32_t b0, int32_t b1_end,
                      int32_t marker, int32_t flush_id, uint64_t* cut_word, void* stream);
+/* the same with range A given as RECORD bounds [rec0, rec1): the slots of the candidates whose record index
+ * (cand_rec[], ascending, *n_cand_dev of them, both on the device as im_dev_triage left them) lies inside --
+ * the flush points are known to the host as record counts, the candidate list only to the device. */
+int im_dev_flush_cut_rec(im_ctx* ctx, const int32_t* cls, const int32_t* b1, const int32_t* b2, int32_t* consumed,
+                         int32_t rec0, int32_t rec1, const int32_t* cand_rec, const int32_t* n_cand_dev, int32_t cand_cap,
+                         int32_t b0, int32_t b1_end, int32_t marker, int32_t flush_id, uint64_t* cut_word, void* stream);
 
 /* The split-read rule of add_node (src/graph.c:122-127) over every consumed slot of [0, n_slots):
  * one cluster per distinct (consumed flush, class, b1, b2).  Output: cl_key[4 * c] = {flush_id, cls, b1,
@@ -366,6 +375,12 @@ int im_dev_cluster_groupby(im_ctx* ctx, int32_t n_slots, const int32_t* cls, con
                            const int32_t* consumed, int32_t tie_desc,
                            int32_t* order, int32_t* cl_key, int32_t* cl_first, int32_t* cl_count, int32_t* counts,
                            void* scratch, size_t scratch_bytes, void* stream);
+/* n_slots = IM_MAX_EV * *n_cand_dev (device), at most n_slots_cap */
+int im_dev_cluster_groupby_n(im_ctx* ctx, int32_t n_slots_cap, const int32_t* n_cand_dev,
+                             const int32_t* cls, const int32_t* b1, const int32_t* b2,
+                             const int32_t* consumed, int32_t tie_desc,
+                             int32_t* order, int32_t* cl_key, int32_t* cl_first, int32_t* cl_count, int32_t* counts,
+                             void* scratch, size_t scratch_bytes, void* stream);
 
 /* ---- seam 3, genome-wide form ----------------------------------------------------- */
 

@@ -179,10 +179,17 @@ def lib():
         L.im_dev_cluster_groupby.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32,
                                              C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                              C.c_void_p, C.c_size_t, C.c_void_p]
+        L.im_dev_realign_n.argtypes = [C.c_void_p, C.POINTER(Params), C.POINTER(DevBatch), C.c_void_p, C.c_int32, C.c_void_p]
+        L.im_dev_flush_cut_rec.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32,
+                                           C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]
+        L.im_dev_cluster_groupby_n.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32,
+                                               C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                               C.c_void_p, C.c_size_t, C.c_void_p]
         L.im_depth_enable.argtypes = [C.c_void_p]
         L.im_depth_scan.argtypes = [C.c_void_p, C.c_int32, C.c_void_p]
         L.im_depth_query_tid.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]
         L.im_dev_memset.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_size_t, C.c_void_p]
+        L.im_dev_copy_async.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
         L.im_capture_begin.argtypes = [C.c_void_p, C.c_void_p]
         L.im_capture_end.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(C.c_void_p)]
         L.im_graph_launch.argtypes = [C.c_void_p, C.c_void_p]
@@ -222,6 +229,19 @@ class DevBuf:
         if self.ptr:
             lib().im_dev_free(self.ctx.h, self.ptr)
             self.ptr = None
+
+
+class DevView:
+    """A window into somebody else's device allocation (same download interface as DevBuf)."""
+
+    def __init__(self, ctx, ptr, nbytes):
+        self.ctx, self.ptr, self.nbytes = ctx, ptr, int(nbytes)
+
+    def download(self, dtype, count):
+        out = np.empty(count, dtype=dtype)
+        assert out.nbytes <= self.nbytes
+        self.ctx._check(lib().im_dev_download(self.ctx.h, _ptr(out), self.ptr, out.nbytes))
+        return out
 
 
 class Event:
@@ -425,7 +445,7 @@ class Pipeline:
     between the stages; this class only owns the buffers and issues the im_dev_* calls in order."""
 
     def __init__(self, ctx, n_records, raw_bytes, cap_cand, read_len_max=256, n_pe=0, n_flushes=64, want_depth=False,
-                 qthreshold=10, ethreshold_vcfcheck=10, maxpedelsize=1000000):
+                 qthreshold=10, ethreshold_vcfcheck=10, maxpedelsize=1000000, input_from=None):
         L = lib()
         self.ctx = ctx
         self.n_records = int(n_records)
@@ -433,8 +453,11 @@ class Pipeline:
         self.n_pe = int(n_pe)
         self.cap_bases = self.cap_cand * ((read_len_max + 3) // 4 * 4) + 64
         self.n_slots = self.cap_cand * MAX_EV + self.n_pe        # split-read slots, then the host's paired-read entries
-        self.d_raw = DevBuf(ctx, raw_bytes + 64)
-        self.d_off = DevBuf(ctx, 4 * (n_records + 1))
+        if input_from is not None:          # several output sets over one resident record buffer (bench.py's pipelined steps)
+            self.d_raw, self.d_off = input_from.d_raw, input_from.d_off
+        else:
+            self.d_raw = DevBuf(ctx, raw_bytes + 64)
+            self.d_off = DevBuf(ctx, 4 * (n_records + 1))
         self.d_bases = DevBuf(ctx, self.cap_bases)
         self.d_boff = DevBuf(ctx, 8 * self.cap_cand)
         self.d_len = DevBuf(ctx, 4 * self.cap_cand)
@@ -454,10 +477,12 @@ class Pipeline:
         self.d_cut = DevBuf(ctx, 8 * max(n_flushes, 1))
         self.n_flushes = n_flushes
         self.d_order = DevBuf(ctx, 4 * self.n_slots)
-        self.d_clkey = DevBuf(ctx, 16 * self.n_slots)
+        # {clusters, nodes, 0, 0} then the 16-byte cluster keys, contiguous: the unit a rank contributes to the all-gather
+        self.d_clbuf = DevBuf(ctx, 16 + 16 * self.n_slots)
+        self.d_counts = DevView(ctx, self.d_clbuf.ptr, 16)
+        self.d_clkey = DevView(ctx, self.d_clbuf.ptr + 16, 16 * self.n_slots)
         self.d_clfirst = DevBuf(ctx, 4 * self.n_slots)
         self.d_clcount = DevBuf(ctx, 4 * self.n_slots)
-        self.d_counts = DevBuf(ctx, 64)
         self.gs_bytes = L.im_dev_groupby_scratch_bytes(self.n_slots)
         self.d_gs = DevBuf(ctx, self.gs_bytes)
         self.batch = DevBatch(0, self.d_bases.ptr, self.d_boff.ptr, self.d_len.ptr, self.d_tid.ptr, self.d_anchor.ptr,
@@ -519,6 +544,29 @@ class Pipeline:
         self.ctx._check(lib().im_dev_cluster_groupby(self.ctx.h, n, self.d_cls.ptr, self.d_b1.ptr, self.d_b2.ptr, self.d_consumed.ptr,
                                                      tie_desc, self.d_order.ptr, self.d_clkey.ptr, self.d_clfirst.ptr, self.d_clcount.ptr,
                                                      self.d_counts.ptr, self.d_gs.ptr, self.gs_bytes, st))
+
+    # ---- the same three stages without a host round trip: the candidate count stays on the device ----
+    def bind_async(self, flushes, stream, tie_desc=0, grid_bound=None):
+        """pre-binds one whole pass (triage -> realign -> flush cuts -> group-by) on `stream`; flushes =
+        [(rec0, rec1, pe_hi, marker)] with record bounds.  Returns a list of (fn, args) to call in order."""
+        L = lib()
+        h = self.ctx.h
+        base = self.cap_cand * MAX_EV
+        self.batch_bound = DevBatch(min(self.cap_cand, grid_bound or self.cap_cand), self.d_bases.ptr, self.d_boff.ptr, self.d_len.ptr,
+                                    self.d_tid.ptr, self.d_anchor.ptr, self.d_range.ptr, self.d_res.ptr, self.d_cls.ptr, self.d_b1.ptr, self.d_b2.ptr)
+        calls = [(L.im_dev_memset, (h, self.d_counters.ptr, 0, 64, stream)),
+                 (L.im_dev_memset, (h, self.d_consumed.ptr, 0, 4 * self.n_slots, stream)),
+                 (L.im_dev_memset, (h, self.d_cut.ptr, 0xFF, 8 * self.n_flushes, stream)),
+                 (L.im_dev_triage, (h, C.byref(self.tp), C.byref(self.recs), C.byref(self.cands), self.d_ts.ptr, self.ts_bytes, stream)),
+                 (L.im_dev_realign_n, (h, C.byref(self.P), C.byref(self.batch_bound), self.d_counters.ptr, 1, stream))]
+        for k, (rec0, rec1, pe_hi, marker) in enumerate(flushes):
+            calls.append((L.im_dev_flush_cut_rec, (h, self.d_cls.ptr, self.d_b1.ptr, self.d_b2.ptr, self.d_consumed.ptr, rec0, rec1,
+                                                   self.d_cand_rec.ptr, self.d_counters.ptr, self.cap_cand, base, base + pe_hi, marker, k + 1,
+                                                   self.d_cut.ptr + 8 * k, stream)))
+        calls.append((L.im_dev_cluster_groupby_n, (h, self.batch_bound.n * MAX_EV, self.d_counters.ptr, self.d_cls.ptr, self.d_b1.ptr, self.d_b2.ptr,
+                                                   self.d_consumed.ptr, tie_desc, self.d_order.ptr, self.d_clkey.ptr, self.d_clfirst.ptr,
+                                                   self.d_clcount.ptr, self.d_counts.ptr, self.d_gs.ptr, self.gs_bytes, stream)))
+        return calls
 
     def sync(self, stream=None):
         self.ctx._check(lib().im_stream_sync(self.ctx.h, self.ctx.stream if stream is None else stream))

@@ -213,18 +213,22 @@ int im_set_reference(im_ctx* ctx, int32_t n_contigs, const char* const* seqs, co
     return IM_OK;
 }
 
-static int dev_realign(im_ctx* ctx, const im_params* params, const im_dev_batch* batch, int keep, void* stream);
+static int dev_realign(im_ctx* ctx, const im_params* params, const im_dev_batch* batch, int keep, const int32_t* n_dev, void* stream);
 
 int im_dev_realign(im_ctx* ctx, const im_params* params, const im_dev_batch* batch, void* stream)
 {
-    return dev_realign(ctx, params, batch, 0, stream);
+    return dev_realign(ctx, params, batch, 0, nullptr, stream);
+}
+int im_dev_realign_n(im_ctx* ctx, const im_params* params, const im_dev_batch* batch, const int32_t* n_dev, int32_t keep_slots, void* stream)
+{
+    return dev_realign(ctx, params, batch, keep_slots ? 1 : 0, n_dev, stream);
 }
 int im_dev_realign_keep(im_ctx* ctx, const im_params* params, const im_dev_batch* batch, void* stream)
 {
-    return dev_realign(ctx, params, batch, 1, stream);
+    return dev_realign(ctx, params, batch, 1, nullptr, stream);
 }
 
-static int dev_realign(im_ctx* ctx, const im_params* params, const im_dev_batch* batch, int keep, void* stream)
+static int dev_realign(im_ctx* ctx, const im_params* params, const im_dev_batch* batch, int keep, const int32_t* n_dev, void* stream)
 {
     if (!ctx || !batch) return IM_E_ARG;
     int rc = check_params(ctx, params);
@@ -239,6 +243,7 @@ static int dev_realign(im_ctx* ctx, const im_params* params, const im_dev_batch*
     a.batch = *batch;
     a.P = *params;
     a.keep_slots = keep;
+    a.n_dev = n_dev;
     HIP_TRY(ctx, im::launch_realign(a, ctx->n_cu, (hipStream_t)stream));
     return IM_OK;
 }
@@ -320,7 +325,17 @@ int im_dev_flush_cut(im_ctx* ctx, const int32_t* cls, const int32_t* b1, const i
 {
     if (!ctx || !cut_word || flush_id <= 0) return IM_E_ARG;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
-    HIP_TRY(ctx, im::launch_flush_cut(cls, b1, b2, consumed, a0, a1, b0, b1_end, marker, flush_id, cut_word, (hipStream_t)stream));
+    HIP_TRY(ctx, im::launch_flush_cut(cls, b1, b2, consumed, a0, a1, b0, b1_end, marker, flush_id, cut_word, nullptr, nullptr, 0, (hipStream_t)stream));
+    return IM_OK;
+}
+
+int im_dev_flush_cut_rec(im_ctx* ctx, const int32_t* cls, const int32_t* b1, const int32_t* b2, int32_t* consumed,
+                         int32_t rec0, int32_t rec1, const int32_t* cand_rec, const int32_t* n_cand_dev, int32_t cand_cap,
+                         int32_t b0, int32_t b1_end, int32_t marker, int32_t flush_id, uint64_t* cut_word, void* stream)
+{
+    if (!ctx || !cut_word || flush_id <= 0 || !cand_rec || !n_cand_dev || cand_cap < 0) return IM_E_ARG;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, im::launch_flush_cut(cls, b1, b2, consumed, rec0, rec1, b0, b1_end, marker, flush_id, cut_word, cand_rec, n_cand_dev, cand_cap, (hipStream_t)stream));
     return IM_OK;
 }
 
@@ -335,7 +350,19 @@ int im_dev_cluster_groupby(im_ctx* ctx, int32_t n_slots, const int32_t* cls, con
     if (scratch_bytes < im::groupby_scratch_bytes(n_slots)) { set_err(ctx, "group-by scratch too small"); return IM_E_ARG; }
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     if (n_slots == 0) { HIP_TRY(ctx, hipMemsetAsync(counts, 0, 8, (hipStream_t)stream)); return IM_OK; }
-    HIP_TRY(ctx, im::launch_groupby(n_slots, cls, b1, b2, consumed, tie_desc, order, cl_key, cl_first, cl_count, counts, scratch, (hipStream_t)stream));
+    HIP_TRY(ctx, im::launch_groupby(n_slots, nullptr, cls, b1, b2, consumed, tie_desc, order, cl_key, cl_first, cl_count, counts, scratch, (hipStream_t)stream));
+    return IM_OK;
+}
+
+int im_dev_cluster_groupby_n(im_ctx* ctx, int32_t n_slots_cap, const int32_t* n_cand_dev, const int32_t* cls, const int32_t* b1, const int32_t* b2,
+                             const int32_t* consumed, int32_t tie_desc,
+                             int32_t* order, int32_t* cl_key, int32_t* cl_first, int32_t* cl_count, int32_t* counts,
+                             void* scratch, size_t scratch_bytes, void* stream)
+{
+    if (!ctx || n_slots_cap <= 0 || !counts || !n_cand_dev) return IM_E_ARG;
+    if (scratch_bytes < im::groupby_scratch_bytes(n_slots_cap)) { set_err(ctx, "group-by scratch too small"); return IM_E_ARG; }
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, im::launch_groupby(n_slots_cap, n_cand_dev, cls, b1, b2, consumed, tie_desc, order, cl_key, cl_first, cl_count, counts, scratch, (hipStream_t)stream));
     return IM_OK;
 }
 

@@ -34,6 +34,7 @@ struct RealignArgs {
     im_dev_batch batch;
     im_params   P;
     int32_t     keep_slots;     // 1: evidence slots of reads without realigned evidence are left as they are
+    const int32_t* n_dev;       // device-resident batch size (null: batch.n), batch.n is then the upper bound
 };
 
 // The read-group -> range[1] table of the insert-length hashtable, flattened: 16 bins (qhash of
@@ -52,9 +53,9 @@ hipError_t launch_triage(const RefDev& ref, const RgTable& rg, int32_t* depth_di
 
 hipError_t launch_flush_cut(const int32_t* cls, const int32_t* b1, const int32_t* b2, int32_t* consumed,
                             int32_t a0, int32_t a1, int32_t b0, int32_t b1_end, int32_t marker, int32_t flush_id,
-                            uint64_t* cut_word, hipStream_t stream);
+                            uint64_t* cut_word, const int32_t* cand_rec, const int32_t* n_cand_dev, int32_t cand_cap, hipStream_t stream);
 size_t groupby_scratch_bytes(int32_t n_slots);
-hipError_t launch_groupby(int32_t n_slots, const int32_t* cls, const int32_t* b1, const int32_t* b2, const int32_t* consumed,
+hipError_t launch_groupby(int32_t n_slots, const int32_t* n_cand_dev, const int32_t* cls, const int32_t* b1, const int32_t* b2, const int32_t* consumed,
                           int32_t tie_desc, int32_t* order, int32_t* cl_key, int32_t* cl_first, int32_t* cl_count,
                           int32_t* counts, void* scratch, hipStream_t stream);
 hipError_t launch_depth_scan(int32_t* depth, int64_t n, int32_t* sums, hipStream_t stream);

@@ -27,13 +27,34 @@ namespace {
 
 __device__ __forceinline__ uint64_t cut_key(int32_t b1, int32_t b2) { return ((uint64_t)(uint32_t)b1 << 32) | (uint32_t)b2; }
 
-struct Ranges { int32_t a0, na, b0, nb; };
+struct Ranges {
+    int32_t a0, na, b0, nb;
+    // range A given as RECORD bounds [a0, a0 + na) of a candidate list that lives on the device: the slots of
+    // the candidates whose record index falls inside (null: a0 / na are slot bounds)
+    const int32_t* cand_rec; const int32_t* n_cand; int32_t cand_cap;
+};
+__device__ __forceinline__ int32_t lower_bound_dev(const int32_t* a, int32_t n, int32_t v)
+{
+    int32_t lo = 0, hi = n;
+    while (lo < hi) { const int32_t mid = lo + ((hi - lo) >> 1); if (a[mid] < v) lo = mid + 1; else hi = mid; }
+    return lo;
+}
+__device__ __forceinline__ Ranges resolve(Ranges R)
+{
+    if (R.cand_rec) {
+        const int32_t nc = min(*R.n_cand, R.cand_cap);
+        const int32_t lo = lower_bound_dev(R.cand_rec, nc, R.a0), hi = lower_bound_dev(R.cand_rec, nc, R.a0 + R.na);
+        R.a0 = lo * IM_MAX_EV; R.na = (hi - lo) * IM_MAX_EV;
+    }
+    return R;
+}
 __device__ __forceinline__ int32_t slot_of(const Ranges& R, int64_t i) { return i < R.na ? R.a0 + (int32_t)i : R.b0 + (int32_t)(i - R.na); }
 
-__global__ __launch_bounds__(256) void flush_min_kernel(Ranges R, const int32_t* __restrict__ cls, const int32_t* __restrict__ b1,
+__global__ __launch_bounds__(256) void flush_min_kernel(Ranges R0, const int32_t* __restrict__ cls, const int32_t* __restrict__ b1,
                                                        const int32_t* __restrict__ b2, const int32_t* __restrict__ consumed,
                                                        int32_t marker, unsigned long long* __restrict__ cut_word)
 {
+    const Ranges R = resolve(R0);
     const int64_t n = (int64_t)R.na + R.nb;
     uint64_t best = ~0ull;
     for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
@@ -51,10 +72,11 @@ __global__ __launch_bounds__(256) void flush_min_kernel(Ranges R, const int32_t*
     if ((threadIdx.x & 63) == 0 && best != ~0ull) atomicMin(cut_word, (unsigned long long)best);
 }
 
-__global__ __launch_bounds__(256) void flush_mark_kernel(Ranges R, const int32_t* __restrict__ cls, const int32_t* __restrict__ b1,
+__global__ __launch_bounds__(256) void flush_mark_kernel(Ranges R0, const int32_t* __restrict__ cls, const int32_t* __restrict__ b1,
                                                         const int32_t* __restrict__ b2, int32_t* __restrict__ consumed,
                                                         int32_t flush_id, const unsigned long long* __restrict__ cut_word)
 {
+    const Ranges R = resolve(R0);
     const int64_t n = (int64_t)R.na + R.nb;
     const uint64_t X = *cut_word;
     for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
@@ -85,9 +107,10 @@ __device__ __forceinline__ uint32_t mix32(uint32_t f, uint32_t c, uint32_t x1, u
     return (uint32_t)k;
 }
 
-__global__ __launch_bounds__(256) void group_insert_kernel(int32_t n_slots, const int32_t* __restrict__ cls, const int32_t* __restrict__ b1,
+__global__ __launch_bounds__(256) void group_insert_kernel(int32_t n_cap, const int32_t* __restrict__ n_cand, const int32_t* __restrict__ cls, const int32_t* __restrict__ b1,
                                                           const int32_t* __restrict__ b2, const int32_t* __restrict__ consumed, GroupScratch s)
 {
+    const int32_t n_slots = n_cand ? min(n_cap, *n_cand * IM_MAX_EV) : n_cap;
     for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n_slots; i += (int64_t)gridDim.x * blockDim.x) {
         const int32_t c = cls[i], f = consumed[i];
         if (c < 0 || c >= 2 || f <= 0) { s.slot_h[i] = 0xFFFFFFFFu; continue; }
@@ -147,8 +170,9 @@ __global__ __launch_bounds__(1024) void group_offsets_kernel(GroupScratch s, con
     if (t == 0) { counts[0] = (int32_t)nu; counts[1] = (int32_t)carry_s; }
 }
 
-__global__ __launch_bounds__(256) void group_place_kernel(int32_t n_slots, GroupScratch s, const int32_t* __restrict__ cl_first, int32_t* __restrict__ order)
+__global__ __launch_bounds__(256) void group_place_kernel(int32_t n_cap, const int32_t* __restrict__ n_cand, GroupScratch s, const int32_t* __restrict__ cl_first, int32_t* __restrict__ order)
 {
+    const int32_t n_slots = n_cand ? min(n_cap, *n_cand * IM_MAX_EV) : n_cap;
     for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n_slots; i += (int64_t)gridDim.x * blockDim.x) {
         const uint32_t h = s.slot_h[i];
         if (h == 0xFFFFFFFFu) continue;
@@ -234,11 +258,14 @@ inline int grid_of(int64_t n, int threads, int cap)
 
 hipError_t launch_flush_cut(const int32_t* cls, const int32_t* b1, const int32_t* b2, int32_t* consumed,
                             int32_t a0, int32_t a1, int32_t b0, int32_t b1_end, int32_t marker, int32_t flush_id,
-                            uint64_t* cut_word, hipStream_t stream)
+                            uint64_t* cut_word, const int32_t* cand_rec, const int32_t* n_cand_dev, int32_t cand_cap, hipStream_t stream)
 {
     Ranges R;
     R.a0 = a0; R.na = a1 > a0 ? a1 - a0 : 0; R.b0 = b0; R.nb = b1_end > b0 ? b1_end - b0 : 0;
-    const int64_t n = (int64_t)R.na + R.nb;
+    R.cand_rec = cand_rec; R.n_cand = n_cand_dev; R.cand_cap = cand_cap;
+    // with record bounds the slot count is only known on the device: size the launch for the most it can be
+    int64_t n = (int64_t)R.na + R.nb;
+    if (cand_rec) { const int64_t most = (int64_t)R.na < cand_cap ? R.na : cand_cap; n = most * IM_MAX_EV + R.nb; }
     if (n <= 0) return hipSuccess;
     const int g = grid_of(n, 256, 2048);
     hipLaunchKernelGGL(flush_min_kernel, dim3(g), dim3(256), 0, stream, R, cls, b1, b2, consumed, marker,
@@ -250,7 +277,7 @@ hipError_t launch_flush_cut(const int32_t* cls, const int32_t* b1, const int32_t
 
 size_t groupby_scratch_bytes(int32_t n_slots) { return group_carve(nullptr, nullptr, nullptr, n_slots); }
 
-hipError_t launch_groupby(int32_t n_slots, const int32_t* cls, const int32_t* b1, const int32_t* b2, const int32_t* consumed,
+hipError_t launch_groupby(int32_t n_slots, const int32_t* n_cand_dev, const int32_t* cls, const int32_t* b1, const int32_t* b2, const int32_t* consumed,
                           int32_t tie_desc, int32_t* order, int32_t* cl_key, int32_t* cl_first, int32_t* cl_count,
                           int32_t* counts, void* scratch, hipStream_t stream)
 {
@@ -260,9 +287,9 @@ hipError_t launch_groupby(int32_t n_slots, const int32_t* cls, const int32_t* b1
     hipError_t e = hipMemsetAsync(g.head, 0, clear, stream);
     if (e != hipSuccess) return e;
     const int gi = grid_of(n_slots, 256, 4096);
-    hipLaunchKernelGGL(group_insert_kernel, dim3(gi), dim3(256), 0, stream, n_slots, cls, b1, b2, consumed, g);
+    hipLaunchKernelGGL(group_insert_kernel, dim3(gi), dim3(256), 0, stream, n_slots, n_cand_dev, cls, b1, b2, consumed, g);
     hipLaunchKernelGGL(group_offsets_kernel, dim3(1), dim3(1024), 0, stream, g, cls, b1, b2, consumed, cl_key, cl_first, cl_count, counts);
-    hipLaunchKernelGGL(group_place_kernel, dim3(gi), dim3(256), 0, stream, n_slots, g, cl_first, order);
+    hipLaunchKernelGGL(group_place_kernel, dim3(gi), dim3(256), 0, stream, n_slots, n_cand_dev, g, cl_first, order);
     hipLaunchKernelGGL(group_finish_kernel, dim3(grid_of(n_slots, 16, 4096)), dim3(64), 0, stream, g, cl_first, cl_count, tie_desc, order, tmp);
     return hipGetLastError();
 }

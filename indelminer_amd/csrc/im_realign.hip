@@ -923,7 +923,11 @@ __global__ __launch_bounds__(64, IM_WAVES_PER_SIMD) void realign_kernel(RealignA
 {
     __shared__ WaveLds s;
     const int lane = threadIdx.x;
-    const int G = gridDim.x;                    // multiple of 8
+    // the batch size may live on the device (the triage kernel's running count): the launch is sized for an upper
+    // bound and the workgroups beyond the count leave at once
+    const int n = A.n_dev ? min(sload(A.n_dev), A.batch.n) : A.batch.n;
+    const int G = min((int)gridDim.x, (n + 7) / 8 * 8);     // multiple of 8
+    if ((int)blockIdx.x >= G) return;
     const int per = G >> 3;
     // blocks with equal blockIdx % 8 share an XCD (observed round-robin placement,
     // speed only): give each XCD a contiguous run of `per` reads per sweep.
@@ -934,9 +938,9 @@ __global__ __launch_bounds__(64, IM_WAVES_PER_SIMD) void realign_kernel(RealignA
         for (int i = 0; i < kTblBytes / 16 / 64; i++) t4[lane + 64 * i] = make_uint4(0u, 0u, 0u, 0u);
         wave_lds_sync();
     }
-    for (int base = 0; base < A.batch.n; base += G) {
+    for (int base = 0; base < n; base += G) {
         const int c = base + mine;
-        if (c < A.batch.n) realign_one<KT, DIRECT>(s, A, c, lane);
+        if (c < n) realign_one<KT, DIRECT>(s, A, c, lane);
         wave_lds_sync();
     }
 }
@@ -1383,7 +1387,8 @@ __global__ __launch_bounds__(64) void realign_gapped_kernel(RealignArgs A)
     const int lane = threadIdx.x;
     const uint32_t k = A.P.klength, g = A.P.numgaps, eth = A.P.ethreshold;
     IM_STAMP_DECL
-    for (int c = blockIdx.x; c < A.batch.n; c += gridDim.x) {
+    const int n_reads = A.n_dev ? min(*A.n_dev, A.batch.n) : A.batch.n;
+    for (int c = blockIdx.x; c < n_reads; c += gridDim.x) {
         im_read_result* out = &A.batch.out[c];
         const int64_t off = uni64(A.batch.base_off[c]);
         const int64_t Lraw = uni(A.batch.read_len[c]);

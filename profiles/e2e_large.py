@@ -11,7 +11,7 @@ import time
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-from indelminer_amd import bamwrite, build, synth  # noqa: E402
+from indelminer_amd import bamwrite, build, rawrec, synth  # noqa: E402
 
 n_contigs = int(sys.argv[1]) if len(sys.argv) > 1 else 8
 ref_len = int(sys.argv[2]) if len(sys.argv) > 2 else 1_000_000      # 6250000 = BASELINE config 3 at full size
@@ -23,7 +23,7 @@ with tempfile.TemporaryDirectory() as td:
     contigs = [("ctg%d" % i, len(r)) for i, r in enumerate(refs)]
     bamwrite.write_fasta(td + "/ref.fa", contigs, refs)
     t = time.perf_counter()
-    bamwrite.write_bam(td + "/aln.bam", contigs, rd)
+    rawrec.write_bam_fast(td + "/aln.bam", contigs, rd)
     print("BAM written in %.1f s, %d bytes" % (time.perf_counter() - t, os.path.getsize(td + "/aln.bam")), flush=True)
     cmd = ["ref.fa", "s=aln.bam"]
     t = time.perf_counter()

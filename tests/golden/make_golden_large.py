@@ -1,0 +1,66 @@
+#!/usr/bin/env python3
+"""Goldens of the large BASELINE configurations, made by the REFERENCE compiled in place
+(oracle/_ref/indelminer, oracle/Makefile) in the build container.  Only digests are committed
+(tests/golden/large_*.json): the inputs are regenerated from their seeds wherever the tests run.
+
+  python tests/golden/make_golden_large.py config3        # 8 x 6.25 Mb, 30x, 15 M reads (~5 min of reference time)
+  python tests/golden/make_golden_large.py config4like    # 24 contigs, human-like length spread, > 2^31 reference bytes, low coverage
+"""
+import hashlib
+import json
+import os
+import subprocess
+import sys
+import tempfile
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+from indelminer_amd import bamwrite, rawrec, synth  # noqa: E402
+
+REF_BIN = os.path.join(ROOT, "oracle", "_ref", "indelminer")
+
+LARGE = {
+    # BASELINE configs[2]: 50 Mb in 8 contigs, 30x 100 bp PE; every seventh planted event a 150-900 bp deletion
+    "config3": dict(sim=dict(seed=2, ref_len=6_250_000, coverage=30, n_contigs=8, big_every=7), flags=[]),
+}
+
+
+def materialise(name, td):
+    """writes ref.fa / aln.bam (+ .bai) for the named configuration into td; returns (n_reads, flags)"""
+    cfg = LARGE[name]
+    refs, rd = synth.simulate(**cfg["sim"])
+    contigs = [("ctg%d" % i, len(r)) for i, r in enumerate(refs)]
+    bamwrite.write_fasta(os.path.join(td, "ref.fa"), contigs, refs)
+    rawrec.write_bam_fast(os.path.join(td, "aln.bam"), contigs, rd)
+    return rd.n, cfg["flags"]
+
+
+def digest(vcf_bytes):
+    body = [l for l in vcf_bytes.splitlines() if not l.startswith(b"#")]
+    return dict(md5=hashlib.md5(vcf_bytes).hexdigest(), records=len(body),
+                composite=sum(b"COMPOSITE" in l for l in body), insertions=sum(b"INSERTION" in l for l in body),
+                bytes=len(vcf_bytes))
+
+
+def main():
+    name = sys.argv[1]
+    with tempfile.TemporaryDirectory() as td:
+        t = time.perf_counter()
+        n, flags = materialise(name, td)
+        print("%s: %d reads written in %.1f s" % (name, n, time.perf_counter() - t), flush=True)
+        t = time.perf_counter()
+        q = subprocess.run([REF_BIN] + flags + ["ref.fa", "s=aln.bam"], cwd=td, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+        dt = time.perf_counter() - t
+        assert q.returncode == 0, q.stderr.decode()[-2000:]
+        out = digest(q.stdout)
+        out.update(reads=int(n), reference_wall_s=round(dt, 1), flags=flags, sim=LARGE[name]["sim"],
+                   made_by="oracle/_ref/indelminer (the reference's own sources, oracle/Makefile), 1 thread, build container")
+        print(json.dumps(out))
+        with open(os.path.join(ROOT, "tests", "golden", "large_%s.json" % name), "w") as fh:
+            json.dump(out, fh, indent=1)
+            fh.write("\n")
+
+
+if __name__ == "__main__":
+    main()
