@@ -36,7 +36,7 @@ from indelminer_amd import capi, rawrec, shard as shardlib, synth  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0           # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 PIPELINE_DEPTH = int(os.environ.get("IM_BENCH_DEPTH", "4"))   # sets of realign output buffers in flight
-KERNEL_EVENT_STRIDE = 4         # realign launch bracketed by HIP events on every 4th timed step
+KERNEL_EVENT_STRIDE = 8         # one launch bracketed by HIP events on every 8th timed step (those steps are issued call by call, not as a graph)
 
 
 def measured_traffic():
@@ -289,21 +289,43 @@ class PipeStep:
             pipe.set_pe(pe_b1, pe_b2)
             stream = capi.new_stream(ctx)
             self.sets.append({"pipe": pipe, "stream": stream, "done": capi.Event(ctx),
-                              "calls": pipe.bind_async(flushes, stream, grid_bound=cap)})
+                              "calls": pipe.bind_async(flushes, stream, grid_bound=cap), "graph": None, "tail": []})
         self.k = 0
+
+    def capture(self):
+        """One HIP graph per buffer set: the step's launches (3 fills, 4 triage kernels, realign, the flush list, 4 group-by
+        kernels + its table fill) are recorded once and replayed with one host call, like the product's per-batch sequence
+        would be if the host, not the GPU, were the limit.  Anything appended to a set's `tail` (the all-gather) follows the
+        graph on the same stream."""
+        L_ = capi.lib()
+        for cur in self.sets:
+            self.ctx._check(L_.im_capture_begin(self.ctx.h, cur["stream"]))
+            rc = 0
+            for fn, args in cur["calls"]:
+                rc = rc or fn(*args)
+            g = C.c_void_p()
+            rc2 = L_.im_capture_end(self.ctx.h, cur["stream"], C.byref(g))
+            self.ctx._check(rc)
+            self.ctx._check(rc2)
+            cur["graph"] = g.value
 
     def step(self, timer=None, timer_at=None):
         cur = self.sets[self.k % len(self.sets)]
         if self.k >= len(self.sets):
             cur["done"].sync()
         rc = 0
-        for j, (fn, args) in enumerate(cur["calls"]):
-            if timer is not None and j == timer_at:
-                timer.start(cur["stream"])
-                rc = rc or fn(*args)
-                timer.stop(cur["stream"])
-            else:
-                rc = rc or fn(*args)
+        if timer is None and cur["graph"] is not None:
+            rc = capi.lib().im_graph_launch(cur["graph"], cur["stream"])
+        else:
+            for j, (fn, args) in enumerate(cur["calls"]):
+                if timer is not None and j == timer_at:
+                    timer.start(cur["stream"])
+                    rc = rc or fn(*args)
+                    timer.stop(cur["stream"])
+                else:
+                    rc = rc or fn(*args)
+        for fn, args in cur["tail"]:
+            rc = rc or fn(*args)
         if rc:
             self.ctx._check(rc)
         cur["done"].record(cur["stream"])
@@ -518,7 +540,7 @@ def main():
         gbytes = 16 + 16 * rec_cap
         for st_ in ps.sets:
             st_["gather"] = capi.DevBuf(ctx, gbytes * world)
-            st_["calls"].append((capi.lib().im_comm_allgather, (comm.h, st_["pipe"].d_clbuf.ptr, st_["gather"].ptr, gbytes, st_["stream"])))
+            st_["tail"].append((capi.lib().im_comm_allgather, (comm.h, st_["pipe"].d_clbuf.ptr, st_["gather"].ptr, gbytes, st_["stream"])))
         collective = "rccl all-gather of per-shard cluster lists, %d B per rank per step" % gbytes
 
     def barrier():
@@ -526,6 +548,8 @@ def main():
         if dist is not None:
             dist.barrier()
 
+    if os.environ.get("IM_BENCH_GRAPH", "1") == "1":
+        ps.capture()
     for _ in range(args.warmup):
         ps.step()
     barrier()
@@ -535,7 +559,8 @@ def main():
     timers = []
     for i in range(args.steps):
         if i % KERNEL_EVENT_STRIDE == 0:
-            timers.append((capi.Timer(ctx), 4 if (i // KERNEL_EVENT_STRIDE) % 2 == 0 else 3))
+            p0 = ps.sets[0]["pipe"]
+            timers.append((capi.Timer(ctx), p0.realign_call_index if (i // KERNEL_EVENT_STRIDE) % 2 == 0 else p0.triage_call_index))
         else:
             timers.append((None, None))
     t0 = time.perf_counter()
@@ -556,8 +581,9 @@ def main():
     else:
         total_reads, total_cand = n_reads, n_cand
 
-    realign_ms = np.array([tm.elapsed_ms() for tm, at in timers if tm is not None and at == 4])
-    triage_ms = np.array([tm.elapsed_ms() for tm, at in timers if tm is not None and at == 3])
+    p0 = ps.sets[0]["pipe"]
+    realign_ms = np.array([tm.elapsed_ms() for tm, at in timers if tm is not None and at == p0.realign_call_index])
+    triage_ms = np.array([tm.elapsed_ms() for tm, at in timers if tm is not None and at == p0.triage_call_index])
     cnt, res, counts = ps.results()
     ncl, nodes = int(counts[0]), int(counts[1])
     alg_bytes = algorithmic_bytes(res)
@@ -616,7 +642,7 @@ def main():
                        "candidates_per_s": total_cand * args.steps / elapsed,
                        "band_alignments_per_s": n_band * world * args.steps / elapsed,
                        "gcups": 2.0 * L * n_band * world * args.steps / elapsed / 1e9,
-                       "pipeline_depth": PIPELINE_DEPTH,
+                       "pipeline_depth": PIPELINE_DEPTH, "hip_graph": os.environ.get("IM_BENCH_GRAPH", "1") == "1",
                        "parallelism": "contig-sharded x%d" % world, "collective": collective,
                        "gathered_clusters": gathered_clusters,
                        "timed_region": "the product driver's device pass over EVERY delivered record of the shard: triage "

@@ -333,9 +333,13 @@ typedef struct im_dev_cands {
     uint8_t*     rec_class;     /* n records of the chunk (may be NULL)                          */
     int32_t      cap_cand;
     int64_t      cap_bases;
+    int32_t*     consumed;      /* optional: the flush marks of the evidence slots (im_dev_flush_*); a new candidate's
+                                   IM_MAX_EV marks are cleared here, so that no separate fill is needed per batch    */
 } im_dev_cands;
 
 size_t im_dev_triage_scratch_bytes(int32_t n_records);
+/* once per scratch buffer, before its first use (asynchronous; the launches leave it ready for the next one) */
+int im_dev_triage_scratch_init(im_ctx* ctx, int32_t n_records, void* scratch, size_t scratch_bytes, void* stream);
 int im_dev_triage(im_ctx* ctx, const im_triage_params* tp, const im_dev_records* recs,
                   const im_dev_cands* out, void* scratch, size_t scratch_bytes, void* stream);
 
@@ -364,6 +368,17 @@ int im_dev_flush_cut_rec(im_ctx* ctx, const int32_t* cls, const int32_t* b1, con
                          int32_t rec0, int32_t rec1, const int32_t* cand_rec, const int32_t* n_cand_dev, int32_t cand_cap,
                          int32_t b0, int32_t b1_end, int32_t marker, int32_t flush_id, uint64_t* cut_word, void* stream);
 
+/* Every flush of a batch of contigs in ONE launch, in list order (the order of the file): desc[f] gives flush f's
+ * record bounds [rec0, rec1) (records of its contig up to the flush point), its paired-read entries [pe0, pe1)
+ * relative to slot pe_base, its marker and its id (> 0).  desc lives on the device.  A flush sees a few thousand
+ * pending slots at the reference's READCHUNK, so one workgroup walks the list; callers with very long pending
+ * ranges (no mid-contig flush ever consumes anything) use im_dev_flush_cut_rec per flush instead. */
+typedef struct im_flush_desc { int32_t rec0, rec1, pe0, pe1, marker, id; } im_flush_desc;
+int im_dev_flush_cuts(im_ctx* ctx, const im_flush_desc* desc_dev, int32_t n_flushes,
+                      const int32_t* cls, const int32_t* b1, const int32_t* b2, int32_t* consumed,
+                      const int32_t* cand_rec, const int32_t* n_cand_dev, int32_t cand_cap,
+                      int32_t pe_base, int32_t pe_count /* their marks are cleared first */, void* stream);
+
 /* The split-read rule of add_node (src/graph.c:122-127) over every consumed slot of [0, n_slots):
  * one cluster per distinct (consumed flush, class, b1, b2).  Output: cl_key[4 * c] = {flush_id, cls, b1,
  * b2}, cl_first[c], cl_count[c] in no particular cluster order (the host orders the few clusters; the
@@ -371,6 +386,8 @@ int im_dev_flush_cut_rec(im_ctx* ctx, const int32_t* cls, const int32_t* b1, con
  * slot index (= arrival) or descending with tie_desc.  counts (device int32[2]) = {clusters, nodes}.
  * Entries with cls >= 2 are ignored. */
 size_t im_dev_groupby_scratch_bytes(int32_t n_slots);
+/* once per scratch buffer (asynchronous); every group-by call leaves the scratch ready for the next one */
+int im_dev_groupby_scratch_init(im_ctx* ctx, int32_t n_slots, void* scratch, size_t scratch_bytes, void* stream);
 int im_dev_cluster_groupby(im_ctx* ctx, int32_t n_slots, const int32_t* cls, const int32_t* b1, const int32_t* b2,
                            const int32_t* consumed, int32_t tie_desc,
                            int32_t* order, int32_t* cl_key, int32_t* cl_first, int32_t* cl_count, int32_t* counts,

@@ -80,7 +80,7 @@ class TriageParams(C.Structure):
 
 class DevCands(C.Structure):
     _fields_ = [("batch", DevBatch), ("cand_rec", C.c_void_p), ("counters", C.c_void_p), ("rec_class", C.c_void_p),
-                ("cap_cand", C.c_int32), ("cap_bases", C.c_int64)]
+                ("cap_cand", C.c_int32), ("cap_bases", C.c_int64), ("consumed", C.c_void_p)]
 
 
 REC_SKIP, REC_COUNTED, REC_CAND_UNMAPPED, REC_CAND_PROPER, REC_PE = 0, 1, 2, 3, 4
@@ -182,6 +182,10 @@ def lib():
         L.im_dev_realign_n.argtypes = [C.c_void_p, C.POINTER(Params), C.POINTER(DevBatch), C.c_void_p, C.c_int32, C.c_void_p]
         L.im_dev_flush_cut_rec.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32,
                                            C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]
+        L.im_dev_flush_cuts.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                        C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]
+        L.im_dev_triage_scratch_init.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_size_t, C.c_void_p]
+        L.im_dev_groupby_scratch_init.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_size_t, C.c_void_p]
         L.im_dev_cluster_groupby_n.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32,
                                                C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                                C.c_void_p, C.c_size_t, C.c_void_p]
@@ -474,6 +478,7 @@ class Pipeline:
         self.d_class = DevBuf(ctx, max(n_records, 1))
         self.ts_bytes = L.im_dev_triage_scratch_bytes(n_records)
         self.d_ts = DevBuf(ctx, self.ts_bytes)
+        ctx._check(L.im_dev_triage_scratch_init(ctx.h, n_records, self.d_ts.ptr, self.ts_bytes, ctx.stream))
         self.d_cut = DevBuf(ctx, 8 * max(n_flushes, 1))
         self.n_flushes = n_flushes
         self.d_order = DevBuf(ctx, 4 * self.n_slots)
@@ -485,9 +490,14 @@ class Pipeline:
         self.d_clcount = DevBuf(ctx, 4 * self.n_slots)
         self.gs_bytes = L.im_dev_groupby_scratch_bytes(self.n_slots)
         self.d_gs = DevBuf(ctx, self.gs_bytes)
+        ctx._check(L.im_dev_groupby_scratch_init(ctx.h, self.n_slots, self.d_gs.ptr, self.gs_bytes, ctx.stream))
+        ctx._check(L.im_stream_sync(ctx.h, ctx.stream))
         self.batch = DevBatch(0, self.d_bases.ptr, self.d_boff.ptr, self.d_len.ptr, self.d_tid.ptr, self.d_anchor.ptr,
                               self.d_range.ptr, self.d_res.ptr, self.d_cls.ptr, self.d_b1.ptr, self.d_b2.ptr)
-        self.cands = DevCands(self.batch, self.d_cand_rec.ptr, self.d_counters.ptr, self.d_class.ptr, self.cap_cand, self.cap_bases)
+        self.cands = DevCands(self.batch, self.d_cand_rec.ptr, self.d_counters.ptr, self.d_class.ptr, self.cap_cand, self.cap_bases, None)
+        # the same with the flush marks of new candidates cleared by the triage itself (bind_async: no fill per pass)
+        self.cands_clear = DevCands(self.batch, self.d_cand_rec.ptr, self.d_counters.ptr, self.d_class.ptr, self.cap_cand, self.cap_bases,
+                                    self.d_consumed.ptr)
         self.recs = DevRecords(self.n_records, self.d_raw.ptr, self.d_off.ptr, 0)
         self.tp = TriageParams(qthreshold, ethreshold_vcfcheck, maxpedelsize, 1 if want_depth else 0)
         self.P = params()
@@ -546,7 +556,7 @@ class Pipeline:
                                                      self.d_counts.ptr, self.d_gs.ptr, self.gs_bytes, st))
 
     # ---- the same three stages without a host round trip: the candidate count stays on the device ----
-    def bind_async(self, flushes, stream, tie_desc=0, grid_bound=None):
+    def bind_async(self, flushes, stream, tie_desc=0, grid_bound=None, one_launch_flushes=True):
         """pre-binds one whole pass (triage -> realign -> flush cuts -> group-by) on `stream`; flushes =
         [(rec0, rec1, pe_hi, marker)] with record bounds.  Returns a list of (fn, args) to call in order."""
         L = lib()
@@ -554,15 +564,25 @@ class Pipeline:
         base = self.cap_cand * MAX_EV
         self.batch_bound = DevBatch(min(self.cap_cand, grid_bound or self.cap_cand), self.d_bases.ptr, self.d_boff.ptr, self.d_len.ptr,
                                     self.d_tid.ptr, self.d_anchor.ptr, self.d_range.ptr, self.d_res.ptr, self.d_cls.ptr, self.d_b1.ptr, self.d_b2.ptr)
-        calls = [(L.im_dev_memset, (h, self.d_counters.ptr, 0, 64, stream)),
-                 (L.im_dev_memset, (h, self.d_consumed.ptr, 0, 4 * self.n_slots, stream)),
-                 (L.im_dev_memset, (h, self.d_cut.ptr, 0xFF, 8 * self.n_flushes, stream)),
-                 (L.im_dev_triage, (h, C.byref(self.tp), C.byref(self.recs), C.byref(self.cands), self.d_ts.ptr, self.ts_bytes, stream)),
-                 (L.im_dev_realign_n, (h, C.byref(self.P), C.byref(self.batch_bound), self.d_counters.ptr, 1, stream))]
-        for k, (rec0, rec1, pe_hi, marker) in enumerate(flushes):
-            calls.append((L.im_dev_flush_cut_rec, (h, self.d_cls.ptr, self.d_b1.ptr, self.d_b2.ptr, self.d_consumed.ptr, rec0, rec1,
-                                                   self.d_cand_rec.ptr, self.d_counters.ptr, self.cap_cand, base, base + pe_hi, marker, k + 1,
-                                                   self.d_cut.ptr + 8 * k, stream)))
+        calls = [(L.im_dev_memset, (h, self.d_counters.ptr, 0, 64, stream))]
+        if not one_launch_flushes:
+            calls += [(L.im_dev_memset, (h, self.d_consumed.ptr, 0, 4 * self.n_slots, stream)),
+                      (L.im_dev_memset, (h, self.d_cut.ptr, 0xFF, 8 * self.n_flushes, stream))]
+        calls += [(L.im_dev_triage, (h, C.byref(self.tp), C.byref(self.recs), C.byref(self.cands_clear if one_launch_flushes else self.cands),
+                                     self.d_ts.ptr, self.ts_bytes, stream)),
+                  (L.im_dev_realign_n, (h, C.byref(self.P), C.byref(self.batch_bound), self.d_counters.ptr, 1, stream))]
+        self.realign_call_index = len(calls) - 1
+        self.triage_call_index = len(calls) - 2
+        if one_launch_flushes:
+            desc = np.array([(rec0, rec1, 0, pe_hi, marker, k + 1) for k, (rec0, rec1, pe_hi, marker) in enumerate(flushes)], dtype=np.int32)
+            self.d_desc = DevBuf(self.ctx, max(desc.nbytes, 24)).upload(desc)
+            calls.append((L.im_dev_flush_cuts, (h, self.d_desc.ptr, len(flushes), self.d_cls.ptr, self.d_b1.ptr, self.d_b2.ptr, self.d_consumed.ptr,
+                                                self.d_cand_rec.ptr, self.d_counters.ptr, self.cap_cand, base, self.n_pe, stream)))
+        else:
+            for k, (rec0, rec1, pe_hi, marker) in enumerate(flushes):
+                calls.append((L.im_dev_flush_cut_rec, (h, self.d_cls.ptr, self.d_b1.ptr, self.d_b2.ptr, self.d_consumed.ptr, rec0, rec1,
+                                                       self.d_cand_rec.ptr, self.d_counters.ptr, self.cap_cand, base, base + pe_hi, marker, k + 1,
+                                                       self.d_cut.ptr + 8 * k, stream)))
         calls.append((L.im_dev_cluster_groupby_n, (h, self.batch_bound.n * MAX_EV, self.d_counters.ptr, self.d_cls.ptr, self.d_b1.ptr, self.d_b2.ptr,
                                                    self.d_consumed.ptr, tie_desc, self.d_order.ptr, self.d_clkey.ptr, self.d_clfirst.ptr,
                                                    self.d_clcount.ptr, self.d_counts.ptr, self.d_gs.ptr, self.gs_bytes, stream)))

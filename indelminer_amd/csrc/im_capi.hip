@@ -43,7 +43,7 @@ struct im_ctx {
     int32_t* gdepth_sums = nullptr;
     // read-group -> range[1] table (im_set_insert_ranges), flattened hashtable chains
     void* rg_blob = nullptr;
-    im::RgTable rg = {nullptr, nullptr, nullptr, nullptr, nullptr};
+    im::RgTable rg = {nullptr, 0, 0};
 };
 
 namespace {
@@ -250,55 +250,62 @@ static int dev_realign(im_ctx* ctx, const im_params* params, const im_dev_batch*
 
 // ---- seam 0: record triage ---------------------------------------------------------------
 
-int im_set_insert_ranges(im_ctx* ctx, int32_t n, const char* const* names, const int32_t* range_max)
+int im_set_insert_ranges(im_ctx* ctx, int32_t n, const char* const* names_in, const int32_t* range_max)
 {
-    if (!ctx || n < 0 || (n > 0 && (!names || !range_max))) return IM_E_ARG;
+    if (!ctx || n < 0 || (n > 0 && (!names_in || !range_max))) return IM_E_ARG;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     // add_hashtable prepends to the chain of bin hash & 15 (src/hashtable.c:44-45): the chain order is the
     // REVERSE of the order of insertion
     std::vector<int32_t> bin(n);
     for (int32_t i = 0; i < n; i++) {
-        const char* nm = names[i];
+        const char* nm = names_in[i];
         const int len = (int)strlen(nm);
         uint32_t h = 5381u;
         for (int k = len - 1; k >= 0; k--) h += (h << 5) + (uint32_t)(int)nm[k];
         bin[i] = (int32_t)(h & 15u);
     }
-    std::vector<int32_t> bin_start(17, 0), name_off(n ? n : 1), name_len(n ? n : 1), rmax(n ? n : 1);
-    std::vector<uint8_t> blob;
+    const int32_t m = n > 0 ? n : 1;
+    std::vector<int32_t> bin_start(20, 0), name_off(m, 0), name_len(m, 0), rmax(m, 0);
+    std::vector<uint8_t> names;
     int32_t e = 0;
     for (int b = 0; b < 16; b++) {
         bin_start[b] = e;
         for (int32_t i = n - 1; i >= 0; i--) {
             if (bin[i] != b) continue;
-            name_off[e] = (int32_t)blob.size();
-            name_len[e] = (int32_t)strlen(names[i]);
+            name_off[e] = (int32_t)names.size();
+            name_len[e] = (int32_t)strlen(names_in[i]);
             rmax[e] = range_max[i];
-            blob.insert(blob.end(), names[i], names[i] + name_len[e] + 1);
+            names.insert(names.end(), names_in[i], names_in[i] + name_len[e] + 1);
             e++;
         }
     }
     bin_start[16] = e;
-    const size_t o1 = up256(17 * 4), o2 = o1 + up256((size_t)(n ? n : 1) * 4), o3 = o2 + up256((size_t)(n ? n : 1) * 4), o4 = o3 + up256((size_t)(n ? n : 1) * 4);
-    const size_t total = o4 + up256(blob.size() + 8);
+    std::vector<uint8_t> host((size_t)4 * (20 + 3 * (size_t)m) + names.size() + 8, 0);
+    memcpy(host.data(), bin_start.data(), 80);
+    memcpy(host.data() + 80, name_off.data(), 4 * (size_t)m);
+    memcpy(host.data() + 80 + 4 * (size_t)m, name_len.data(), 4 * (size_t)m);
+    memcpy(host.data() + 80 + 8 * (size_t)m, rmax.data(), 4 * (size_t)m);
+    if (!names.empty()) memcpy(host.data() + 80 + 12 * (size_t)m, names.data(), names.size());
+    const size_t total = (host.size() + 3) / 4 * 4;
+    host.resize(total, 0);
     if (ctx->rg_blob) { HIP_TRY(ctx, hipFree(ctx->rg_blob)); ctx->rg_blob = nullptr; }
-    HIP_TRY(ctx, hipMalloc(&ctx->rg_blob, total));
-    std::vector<uint8_t> host(total, 0);
-    memcpy(host.data(), bin_start.data(), 17 * 4);
-    if (n > 0) {
-        memcpy(host.data() + o1, name_off.data(), (size_t)n * 4);
-        memcpy(host.data() + o2, name_len.data(), (size_t)n * 4);
-        memcpy(host.data() + o3, rmax.data(), (size_t)n * 4);
-        memcpy(host.data() + o4, blob.data(), blob.size());
-    }
+    HIP_TRY(ctx, hipMalloc(&ctx->rg_blob, total + 256));
     HIP_TRY(ctx, hipMemcpy(ctx->rg_blob, host.data(), total, hipMemcpyHostToDevice));
-    char* d = static_cast<char*>(ctx->rg_blob);
-    ctx->rg.bin_start = (const int32_t*)d; ctx->rg.name_off = (const int32_t*)(d + o1); ctx->rg.name_len = (const int32_t*)(d + o2);
-    ctx->rg.range_max = (const int32_t*)(d + o3); ctx->rg.names = (const uint8_t*)(d + o4);
+    ctx->rg.blob = (const uint8_t*)ctx->rg_blob; ctx->rg.n = n; ctx->rg.bytes = (int32_t)total;
     return IM_OK;
 }
 
 size_t im_dev_triage_scratch_bytes(int32_t n_records) { return im::triage_scratch_bytes(n_records); }
+
+int im_dev_triage_scratch_init(im_ctx* ctx, int32_t n_records, void* scratch, size_t scratch_bytes, void* stream)
+{
+    if (!ctx || !scratch || scratch_bytes < im::triage_scratch_bytes(n_records)) return IM_E_ARG;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    size_t zb = 0;
+    const size_t off = im::triage_scratch_zero_offset(n_records, &zb);
+    HIP_TRY(ctx, hipMemsetAsync((char*)scratch + off, 0, zb, (hipStream_t)stream));
+    return IM_OK;
+}
 
 int im_dev_triage(im_ctx* ctx, const im_triage_params* tp, const im_dev_records* recs, const im_dev_cands* out,
                   void* scratch, size_t scratch_bytes, void* stream)
@@ -339,7 +346,25 @@ int im_dev_flush_cut_rec(im_ctx* ctx, const int32_t* cls, const int32_t* b1, con
     return IM_OK;
 }
 
+int im_dev_flush_cuts(im_ctx* ctx, const im_flush_desc* desc_dev, int32_t n_flushes,
+                      const int32_t* cls, const int32_t* b1, const int32_t* b2, int32_t* consumed,
+                      const int32_t* cand_rec, const int32_t* n_cand_dev, int32_t cand_cap, int32_t pe_base, int32_t pe_count, void* stream)
+{
+    if (!ctx || n_flushes < 0 || !desc_dev || !cand_rec || !n_cand_dev || pe_count < 0) return IM_E_ARG;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, im::launch_flush_seq(desc_dev, n_flushes, cls, b1, b2, consumed, cand_rec, n_cand_dev, cand_cap, pe_base, pe_count, (hipStream_t)stream));
+    return IM_OK;
+}
+
 size_t im_dev_groupby_scratch_bytes(int32_t n_slots) { return im::groupby_scratch_bytes(n_slots); }
+
+int im_dev_groupby_scratch_init(im_ctx* ctx, int32_t n_slots, void* scratch, size_t scratch_bytes, void* stream)
+{
+    if (!ctx || !scratch || scratch_bytes < im::groupby_scratch_bytes(n_slots)) return IM_E_ARG;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, im::launch_groupby_init(n_slots, scratch, (hipStream_t)stream));
+    return IM_OK;
+}
 
 int im_dev_cluster_groupby(im_ctx* ctx, int32_t n_slots, const int32_t* cls, const int32_t* b1, const int32_t* b2,
                            const int32_t* consumed, int32_t tie_desc,

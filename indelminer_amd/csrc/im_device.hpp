@@ -37,24 +37,28 @@ struct RealignArgs {
     const int32_t* n_dev;       // device-resident batch size (null: batch.n), batch.n is then the upper bound
 };
 
-// The read-group -> range[1] table of the insert-length hashtable, flattened: 16 bins (qhash of
-// size 2^4, src/indelminer.c:702), entries of a bin in chain order (head first).
+// The read-group -> range[1] table of the insert-length hashtable, flattened into one blob:
+// int32 bin_start[20] (17 used; 16 bins of the qhash of size 2^4, src/indelminer.c:702), name_off[m], name_len[m],
+// range_max[m] (m = max(n,1); the entries of a bin in chain order, head first), then the names.
 struct RgTable {
-    const int32_t* bin_start;   // [17]
-    const int32_t* name_off;    // [n]
-    const int32_t* name_len;    // [n]
-    const int32_t* range_max;   // [n]
-    const uint8_t* names;
+    const uint8_t* blob;
+    int32_t n;
+    int32_t bytes;
 };
 
 size_t triage_scratch_bytes(int32_t n_records);
+size_t triage_scratch_zero_offset(int32_t n_records, size_t* bytes);
 hipError_t launch_triage(const RefDev& ref, const RgTable& rg, int32_t* depth_diff, const im_triage_params& tp,
                          const im_dev_records& recs, const im_dev_cands& out, void* scratch, hipStream_t stream);
 
 hipError_t launch_flush_cut(const int32_t* cls, const int32_t* b1, const int32_t* b2, int32_t* consumed,
                             int32_t a0, int32_t a1, int32_t b0, int32_t b1_end, int32_t marker, int32_t flush_id,
                             uint64_t* cut_word, const int32_t* cand_rec, const int32_t* n_cand_dev, int32_t cand_cap, hipStream_t stream);
+hipError_t launch_flush_seq(const im_flush_desc* desc, int32_t n_fl, const int32_t* cls, const int32_t* b1, const int32_t* b2,
+                            int32_t* consumed, const int32_t* cand_rec, const int32_t* n_cand_dev, int32_t cand_cap, int32_t pe_base,
+                            int32_t pe_count, hipStream_t stream);
 size_t groupby_scratch_bytes(int32_t n_slots);
+hipError_t launch_groupby_init(int32_t n_slots, void* scratch, hipStream_t stream);
 hipError_t launch_groupby(int32_t n_slots, const int32_t* n_cand_dev, const int32_t* cls, const int32_t* b1, const int32_t* b2, const int32_t* consumed,
                           int32_t tie_desc, int32_t* order, int32_t* cl_key, int32_t* cl_first, int32_t* cl_count,
                           int32_t* counts, void* scratch, hipStream_t stream);

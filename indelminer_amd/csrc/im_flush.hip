@@ -86,6 +86,111 @@ __global__ __launch_bounds__(256) void flush_mark_kernel(Ranges R0, const int32_
     }
 }
 
+// All flushes of a batch in ONE launch: a flush touches only the slots that arrived since the contig began (a few
+// thousand at the reference's chunk size), so a single workgroup walks the flush list in order -- the sequence is
+// inherently serial (what flush f consumes is not pending for f + 1), and one launch replaces two per flush.
+__global__ __launch_bounds__(1024) void flush_seq_kernel(const im_flush_desc* __restrict__ desc, int32_t n_fl,
+                                                        const int32_t* __restrict__ cls, const int32_t* __restrict__ b1,
+                                                        const int32_t* __restrict__ b2, int32_t* __restrict__ consumed,
+                                                        const int32_t* __restrict__ cand_rec, const int32_t* __restrict__ n_cand, int32_t cand_cap,
+                                                        int32_t pe_base, int32_t pe_count)
+{
+    __shared__ unsigned long long s_best[16];
+    __shared__ int32_t s_first[16];
+    __shared__ unsigned long long s_cut;
+    __shared__ Ranges s_R;
+    __shared__ int32_t s_lo, s_lo_rec0;           // first split-read slot of the current contig that may still be pending
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    // the paired-read entries are pending for the batch's first flush: their marks are cleared here (the split-read
+    // marks are cleared where the candidates are written, im_dev_cands.consumed)
+    for (int32_t i = t; i < pe_count; i += 1024) consumed[pe_base + i] = 0;
+    if (t == 0) { s_lo = 0; s_lo_rec0 = -1; }
+    __syncthreads();
+    __shared__ int32_t s_bound[1024];             // candidate bounds of up to 512 flushes: [2k] = first, [2k + 1] = end
+    const int32_t ncand = min(*n_cand, cand_cap);
+    for (int32_t f = 0; f < n_fl; f++) {
+        if ((f & 511) == 0) {
+            // the record bounds of the next 512 flushes -> candidate bounds, one binary search per thread, all at once
+            // (a search is a chain of dependent loads: done flush by flush by one lane it is most of the kernel's time)
+            __syncthreads();
+            const int32_t ff = f + (t >> 1);
+            if (ff < n_fl) s_bound[t] = lower_bound_dev(cand_rec, ncand, (t & 1) ? desc[ff].rec1 : desc[ff].rec0);
+            __syncthreads();
+        }
+        if (t == 0) {
+            Ranges R;
+            const int32_t lo = s_bound[2 * (f & 511)], hi = max(lo, s_bound[2 * (f & 511) + 1]);
+            R.a0 = lo * IM_MAX_EV; R.na = (hi - lo) * IM_MAX_EV; R.b0 = pe_base + desc[f].pe0; R.nb = desc[f].pe1 - desc[f].pe0;
+            R.cand_rec = nullptr; R.n_cand = nullptr; R.cand_cap = 0;
+            if (R.nb < 0) R.nb = 0;
+            // Everything in front of s_lo was consumed by earlier flushes of this contig (a flush consumes a prefix of
+            // what is pending, in slot order nearly all of it): start there, not at the contig's first slot.
+            if (desc[f].rec0 != s_lo_rec0) { s_lo_rec0 = desc[f].rec0; s_lo = R.a0; }
+            const int32_t end = R.a0 + R.na;
+            if (s_lo > R.a0) { R.a0 = s_lo < end ? s_lo : end; R.na = end - R.a0; }
+            s_R = R;
+        }
+        __syncthreads();
+        const Ranges R = s_R;
+        const int64_t n = (int64_t)R.na + R.nb;
+        const int32_t marker = desc[f].marker, id = desc[f].id;
+        // One workgroup cannot hide memory latency with occupancy, so every thread keeps kU x 4 loads in flight
+        uint64_t best = ~0ull;
+        constexpr int kU = 4;
+        for (int64_t i0 = t; i0 < n; i0 += 1024 * kU) {
+            int32_t c[kU], u[kU], v1[kU], v2[kU];
+#pragma unroll
+            for (int e = 0; e < kU; e++) {
+                const int64_t i = i0 + 1024 * e;
+                const bool in = i < n;
+                const int32_t s = in ? slot_of(R, i) : 0;
+                c[e] = in ? cls[s] : -1; u[e] = in ? consumed[s] : 1; v2[e] = in ? b2[s] : 0; v1[e] = in ? b1[s] : 0;
+            }
+#pragma unroll
+            for (int e = 0; e < kU; e++)
+                if (c[e] >= 0 && u[e] == 0 && v2[e] >= marker) { const uint64_t k = cut_key(v1[e], v2[e]); if (k < best) best = k; }
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const uint32_t lo = (uint32_t)__shfl_xor((int)(uint32_t)best, o), hi = (uint32_t)__shfl_xor((int)(uint32_t)(best >> 32), o);
+            const uint64_t ob = ((uint64_t)hi << 32) | lo;
+            if (ob < best) best = ob;
+        }
+        if (lane == 0) s_best[wave] = best;
+        __syncthreads();
+        if (t == 0) { unsigned long long m = ~0ull; for (int w = 0; w < 16; w++) if (s_best[w] < m) m = s_best[w]; s_cut = m; }
+        __syncthreads();
+        const uint64_t X = s_cut;
+        int32_t first = 0x7fffffff;                 // smallest split-read slot of the range that stays pending
+        for (int64_t i0 = t; i0 < n; i0 += 1024 * kU) {
+            int32_t c[kU], u[kU], v1[kU], v2[kU], sl[kU];
+#pragma unroll
+            for (int e = 0; e < kU; e++) {
+                const int64_t i = i0 + 1024 * e;
+                const bool in = i < n;
+                sl[e] = in ? slot_of(R, i) : 0;
+                c[e] = in ? cls[sl[e]] : -1; u[e] = in ? consumed[sl[e]] : 1; v2[e] = in ? b2[sl[e]] : 0; v1[e] = in ? b1[sl[e]] : 0;
+            }
+#pragma unroll
+            for (int e = 0; e < kU; e++) {
+                if (c[e] < 0 || u[e] != 0) continue;
+                if (cut_key(v1[e], v2[e]) < X) consumed[sl[e]] = id;
+                else if (i0 + 1024 * e < R.na && sl[e] < first) first = sl[e];
+            }
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) { const int32_t of = __shfl_xor(first, o); if (of < first) first = of; }
+        if (lane == 0) s_first[wave] = first;
+        __syncthreads();        // one workgroup = one CU = one vector L1: the marks are visible to the next flush's reads
+        if (t == 0) {
+            int32_t m = 0x7fffffff;
+            for (int w = 0; w < 16; w++) if (s_first[w] < m) m = s_first[w];
+            s_lo = m == 0x7fffffff ? R.a0 + R.na : m;
+        }
+        __syncthreads();
+    }
+}
+
 // ---- group-by ---------------------------------------------------------------------------------
 
 struct GroupScratch {
@@ -95,7 +200,7 @@ struct GroupScratch {
     uint32_t* slot_h;       // [n_slots] table position of a consumed split-read slot, ~0 otherwise
     uint32_t* uniq;         // [n_slots] table positions in first-touch order
     uint32_t* cursor;       // [n_slots] per cluster
-    uint32_t* misc;         // [0] distinct clusters
+    uint32_t* misc;         // [0] distinct clusters while they are being counted (zero between calls), [3] the count for place / finish
     uint32_t  H;
 };
 
@@ -167,7 +272,9 @@ __global__ __launch_bounds__(1024) void group_offsets_kernel(GroupScratch s, con
         if (t == 1023) carry_s = carry + woff + x;
         __syncthreads();
     }
-    if (t == 0) { counts[0] = (int32_t)nu; counts[1] = (int32_t)carry_s; }
+    // the running count is handed on and cleared for the next call here, by the one workgroup that runs between the
+    // insert and the place kernels: no end-of-kernel counter, which would be thousands of atomics on one address
+    if (t == 0) { counts[0] = (int32_t)nu; counts[1] = (int32_t)carry_s; s.misc[3] = nu; s.misc[0] = 0u; }
 }
 
 __global__ __launch_bounds__(256) void group_place_kernel(int32_t n_cap, const int32_t* __restrict__ n_cand, GroupScratch s, const int32_t* __restrict__ cl_first, int32_t* __restrict__ order)
@@ -189,9 +296,11 @@ __global__ __launch_bounds__(64) void group_finish_kernel(GroupScratch s, const 
 {
     __shared__ int32_t st[kGroupLds];
     const int lane = threadIdx.x;
-    const uint32_t nu = s.misc[0];
+    const uint32_t nu = s.misc[3];
     for (uint32_t u = blockIdx.x; u < nu; u += gridDim.x) {
         const int32_t f = cl_first[u], cnt = cl_count[u];
+        // the table cleans itself: the entry, its count and the cluster's cursor are zero again for the next call
+        if (lane == 0) { const uint32_t h = s.uniq[u]; s.head[h] = 0u; s.cnt[h] = 0u; s.cursor[u] = 0u; }
         if (cnt <= 1) continue;
         if (cnt <= kGroupLds) {
             for (int32_t t = lane; t < cnt; t += 64) st[t] = order[f + t];
@@ -275,17 +384,30 @@ hipError_t launch_flush_cut(const int32_t* cls, const int32_t* b1, const int32_t
     return hipGetLastError();
 }
 
+hipError_t launch_flush_seq(const im_flush_desc* desc, int32_t n_fl, const int32_t* cls, const int32_t* b1, const int32_t* b2,
+                            int32_t* consumed, const int32_t* cand_rec, const int32_t* n_cand_dev, int32_t cand_cap, int32_t pe_base,
+                            int32_t pe_count, hipStream_t stream)
+{
+    if (n_fl <= 0) return hipSuccess;
+    hipLaunchKernelGGL(flush_seq_kernel, dim3(1), dim3(1024), 0, stream, desc, n_fl, cls, b1, b2, consumed, cand_rec, n_cand_dev, cand_cap, pe_base, pe_count);
+    return hipGetLastError();
+}
+
 size_t groupby_scratch_bytes(int32_t n_slots) { return group_carve(nullptr, nullptr, nullptr, n_slots); }
+
+hipError_t launch_groupby_init(int32_t n_slots, void* scratch, hipStream_t stream)
+{
+    GroupScratch g; int32_t* tmp = nullptr;
+    group_carve(&g, &tmp, scratch, n_slots);
+    return hipMemsetAsync(g.head, 0, (size_t)((char*)g.misc - (char*)g.head) + 64, stream);
+}
 
 hipError_t launch_groupby(int32_t n_slots, const int32_t* n_cand_dev, const int32_t* cls, const int32_t* b1, const int32_t* b2, const int32_t* consumed,
                           int32_t tie_desc, int32_t* order, int32_t* cl_key, int32_t* cl_first, int32_t* cl_count,
                           int32_t* counts, void* scratch, hipStream_t stream)
 {
     GroupScratch g; int32_t* tmp = nullptr;
-    group_carve(&g, &tmp, scratch, n_slots);
-    const size_t clear = (size_t)((char*)g.misc - (char*)g.head) + 64;
-    hipError_t e = hipMemsetAsync(g.head, 0, clear, stream);
-    if (e != hipSuccess) return e;
+    group_carve(&g, &tmp, scratch, n_slots);       // zeroed once by launch_groupby_init; every call leaves it clean
     const int gi = grid_of(n_slots, 256, 4096);
     hipLaunchKernelGGL(group_insert_kernel, dim3(gi), dim3(256), 0, stream, n_slots, n_cand_dev, cls, b1, b2, consumed, g);
     hipLaunchKernelGGL(group_offsets_kernel, dim3(1), dim3(1024), 0, stream, g, cls, b1, b2, consumed, cl_key, cl_first, cl_count, counts);

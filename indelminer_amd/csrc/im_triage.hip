@@ -39,8 +39,11 @@ struct RecView {
     int32_t tid, pos, mtid, mpos, isize, l_seq;
     uint32_t l_qname, mapq, n_cigar, flag;
     uint32_t o_cigar, o_seq, o_aux;
+    uint32_t cig[4];        // the first four CIGAR words, loaded together with the aux window
     bool ok;
 };
+
+constexpr int kAuxWin = 24;     // bytes of the aux area staged per record (MQ + a short RG fit; longer walks go to memory)
 
 __device__ __forceinline__ RecView view_record(const uint8_t* raw, uint32_t off, uint32_t end)
 {
@@ -48,6 +51,7 @@ __device__ __forceinline__ RecView view_record(const uint8_t* raw, uint32_t off,
     r.p = raw + off; r.len = end - off; r.ok = false;
     r.tid = r.pos = r.mtid = r.mpos = r.isize = r.l_seq = 0;
     r.l_qname = r.mapq = r.n_cigar = r.flag = 0; r.o_cigar = r.o_seq = r.o_aux = 0;
+    r.cig[0] = r.cig[1] = r.cig[2] = r.cig[3] = 0;
     if (end < off || r.len < 32u) return r;
     const uint32_t* c = reinterpret_cast<const uint32_t*>(r.p);     // 4-byte aligned by contract
     r.tid = (int32_t)c[0]; r.pos = (int32_t)c[1];
@@ -65,6 +69,12 @@ __device__ __forceinline__ RecView view_record(const uint8_t* raw, uint32_t off,
     return r;
 }
 
+// CIGAR word k: the first four travel in registers (one round trip with the aux window), the rest come from memory
+__device__ __forceinline__ uint32_t cigar_word(const RecView& r, uint32_t k)
+{
+    return k == 0u ? r.cig[0] : k == 1u ? r.cig[1] : k == 2u ? r.cig[2] : k == 3u ? r.cig[3] : ld_u32(r.p + r.o_cigar + 4u * k);
+}
+
 __device__ __forceinline__ int aux_size(uint32_t t)
 {
     switch (t) {
@@ -76,24 +86,32 @@ __device__ __forceinline__ int aux_size(uint32_t t)
     }
 }
 
+// a byte of the record at offset o: the staged aux window (LDS) when it covers o, memory otherwise
+struct AuxWin { const uint8_t* lds; uint32_t o0; };
+__device__ __forceinline__ uint32_t rec_byte(const RecView& r, const AuxWin& w, uint32_t o)
+{
+    const uint32_t d = o - w.o0;
+    return d < (uint32_t)kAuxWin ? w.lds[d] : r.p[o];
+}
+
 // bam_aux_get for RG and MQ in one walk (bam_aux.c:27-54): offsets of the TYPE byte of the first
 // occurrence, 0 = absent.  The walk stops where samtools' would (unknown type, truncated B array).
-__device__ __forceinline__ void find_rg_mq(const RecView& r, uint32_t& o_rg, uint32_t& o_mq)
+__device__ __forceinline__ void find_rg_mq(const RecView& r, const AuxWin& w, uint32_t& o_rg, uint32_t& o_mq)
 {
     o_rg = 0; o_mq = 0;
     uint32_t s = r.o_aux;
     const uint32_t end = r.len;
     while (s + 3u <= end) {
-        const uint32_t t0 = r.p[s], t1 = r.p[s + 1], type = r.p[s + 2];
+        const uint32_t t0 = rec_byte(r, w, s), t1 = rec_byte(r, w, s + 1), type = rec_byte(r, w, s + 2);
         if (t0 == 'R' && t1 == 'G' && !o_rg) o_rg = s + 2u;
         if (t0 == 'M' && t1 == 'Q' && !o_mq) o_mq = s + 2u;
         if (o_rg && o_mq) return;
         s += 3u;
-        if (type == 'Z' || type == 'H') { while (s < end && r.p[s]) s++; s++; }
+        if (type == 'Z' || type == 'H') { while (s < end && rec_byte(r, w, s)) s++; s++; }
         else if (type == 'B') {
             if (s + 5u > end) return;
-            const int sz = aux_size(r.p[s]);
-            const uint32_t cnt = ld_u32(r.p + s + 1);
+            const int sz = aux_size(rec_byte(r, w, s));
+            const uint32_t cnt = rec_byte(r, w, s + 1) | (rec_byte(r, w, s + 2) << 8) | (rec_byte(r, w, s + 3) << 16) | (rec_byte(r, w, s + 4) << 24);
             const uint64_t ns = (uint64_t)s + 5u + (uint64_t)sz * cnt;
             if (ns > end) return;
             s = (uint32_t)ns;
@@ -106,28 +124,45 @@ __device__ __forceinline__ void find_rg_mq(const RecView& r, uint32_t& o_rg, uin
 }
 
 // bam_aux2i (bam_aux.c:163-174)
-__device__ __forceinline__ int32_t aux_int(const RecView& r, uint32_t o)
+__device__ __forceinline__ int32_t aux_int(const RecView& r, const AuxWin& w, uint32_t o)
 {
-    const uint32_t type = r.p[o];
-    const uint8_t* s = r.p + o + 1;
+    const uint32_t type = rec_byte(r, w, o);
     if (o + 1u >= r.len) return 0;
+    const uint32_t b0 = rec_byte(r, w, o + 1);
     switch (type) {
-    case 'c': return (int32_t)(int8_t)s[0];
-    case 'C': return (int32_t)s[0];
-    case 's': return (o + 3u <= r.len) ? (int32_t)(int16_t)ld_u16(s) : 0;
-    case 'S': return (o + 3u <= r.len) ? (int32_t)ld_u16(s) : 0;
-    case 'i': case 'I': return (o + 5u <= r.len) ? (int32_t)ld_u32(s) : 0;
+    case 'c': return (int32_t)(int8_t)b0;
+    case 'C': return (int32_t)b0;
+    case 's': return (o + 3u <= r.len) ? (int32_t)(int16_t)(b0 | (rec_byte(r, w, o + 2) << 8)) : 0;
+    case 'S': return (o + 3u <= r.len) ? (int32_t)(b0 | (rec_byte(r, w, o + 2) << 8)) : 0;
+    case 'i': case 'I':
+        return (o + 5u <= r.len) ? (int32_t)(b0 | (rec_byte(r, w, o + 2) << 8) | (rec_byte(r, w, o + 3) << 16) | (rec_byte(r, w, o + 4) << 24)) : 0;
     default: return 0;
     }
+}
+
+// The insert-length table as one blob (LDS copy when it is small, else the device original):
+// [bin_start 17][name_off n][name_len n][range_max n][names]
+struct RgView {
+    const int32_t* bin_start; const int32_t* name_off; const int32_t* name_len; const int32_t* range_max; const uint8_t* names;
+};
+__device__ __forceinline__ RgView rg_view(const uint8_t* blob, int32_t n)
+{
+    RgView v;
+    const int32_t* w = reinterpret_cast<const int32_t*>(blob);
+    const int32_t m = n > 0 ? n : 1;
+    v.bin_start = w; v.name_off = w + 20; v.name_len = w + 20 + m; v.range_max = w + 20 + 2 * m;
+    v.names = blob + 4 * (20 + 3 * m);
+    return v;
 }
 
 // must_find_hashtable(insertlengths, rgname, strlen(rgname)) (src/indelminer.c:374-376): DJB2 over the
 // bytes back to front (src/hashfunc.c:23-30), 16 bins, the chain walked head to tail, strncmp prefix
 // match, LAST hit wins (src/hashtable.c:62-81).  Returns false when the reference would exit.
-__device__ __forceinline__ bool rg_lookup(const RgTable& T, const uint8_t* name, uint32_t len, int32_t& range_max)
+template <typename NameAt>
+__device__ __forceinline__ bool rg_lookup(const RgView& T, NameAt name_at, uint32_t len, int32_t& range_max)
 {
     uint32_t h = 5381u;
-    for (int i = (int)len - 1; i >= 0; i--) h += (h << 5) + (uint32_t)(int32_t)(int8_t)name[i];
+    for (int i = (int)len - 1; i >= 0; i--) h += (h << 5) + (uint32_t)(int32_t)(int8_t)name_at((uint32_t)i);
     const uint32_t bin = h & 15u;
     bool hit = false;
     for (int32_t e = T.bin_start[bin]; e < T.bin_start[bin + 1]; e++) {
@@ -135,13 +170,11 @@ __device__ __forceinline__ bool rg_lookup(const RgTable& T, const uint8_t* name,
         if (el < len) continue;                      // the stored name ends first: strncmp sees NUL != byte
         const uint8_t* en = T.names + T.name_off[e];
         bool same = true;
-        for (uint32_t i = 0; i < len && same; i++) same = en[i] == name[i];
+        for (uint32_t i = 0; i < len && same; i++) same = en[i] == name_at(i);
         if (same) { hit = true; range_max = T.range_max[e]; }
     }
     return hit;
 }
-
-__device__ const uint8_t kGeneric[8] = { 'g', 'e', 'n', 'e', 'r', 'i', 'c', 0 };      // src/indelminer.c:370
 
 struct Verdict {
     uint32_t cls;           // IM_REC_*
@@ -149,7 +182,9 @@ struct Verdict {
     int32_t range_max;
 };
 
-__device__ __forceinline__ Verdict classify(const RecView& r, const im_triage_params& tp, const RgTable& T)
+// generic_ok / generic_range: the lookup of "generic" (records without an RG tag, src/indelminer.c:370), done once per workgroup
+__device__ __forceinline__ Verdict classify(const RecView& r, const AuxWin& w, const im_triage_params& tp, const RgView& T,
+                                            bool generic_ok, int32_t generic_range)
 {
     Verdict v; v.cls = IM_REC_SKIP; v.revcomp = false; v.range_max = 0;
     if (!r.ok) { v.cls = IM_REC_ERR_LIMIT; return v; }
@@ -162,28 +197,29 @@ __device__ __forceinline__ Verdict classify(const RecView& r, const im_triage_pa
     v.cls = IM_REC_COUNTED;
 
     uint32_t o_rg, o_mq;
-    find_rg_mq(r, o_rg, o_mq);
-    {
-        const uint8_t* name = kGeneric; uint32_t len = 7;
-        bool bad = false;
-        if (o_rg) {
-            const uint32_t type = r.p[o_rg];
-            if (type != 'Z' && type != 'H') bad = true;                        // bam_aux2Z returns NULL: strlen(NULL)
-            else {
-                name = r.p + o_rg + 1; len = 0;
-                while (o_rg + 1u + len < r.len && name[len]) len++;
-            }
+    find_rg_mq(r, w, o_rg, o_mq);
+    if (!o_rg) {
+        if (!generic_ok) { v.cls = IM_REC_ERR_RG; return v; }
+        v.range_max = generic_range;
+    } else {
+        const uint32_t type = rec_byte(r, w, o_rg);
+        bool ok = type == 'Z' || type == 'H';                                  // else bam_aux2Z returns NULL: strlen(NULL)
+        if (ok) {
+            uint32_t len = 0;
+            while (o_rg + 1u + len < r.len && rec_byte(r, w, o_rg + 1u + len)) len++;
+            const uint32_t o_name = o_rg + 1u;
+            ok = rg_lookup(T, [&](uint32_t k) { return rec_byte(r, w, o_name + k); }, len, v.range_max);
         }
-        if (bad || !rg_lookup(T, name, len, v.range_max)) { v.cls = IM_REC_ERR_RG; return v; }
+        if (!ok) { v.cls = IM_REC_ERR_RG; return v; }
     }
 
     if (aligned && !mate_aligned) return v;                                    // 384-385
     if (!aligned && mate_aligned) {                                            // 386-424
         int32_t mmq = (int32_t)r.mapq;
         if (o_mq) {
-            const uint32_t t = r.p[o_mq];
+            const uint32_t t = rec_byte(r, w, o_mq);
             if (!(t == 'I' || t == 'i' || t == 'C' || t == 'c' || t == 'S' || t == 's')) { v.cls = IM_REC_ERR_MQ; return v; }
-            mmq = aux_int(r, o_mq);
+            mmq = aux_int(r, w, o_mq);
         }
         if (mmq >= tp.qthreshold) { v.cls = IM_REC_CAND_UNMAPPED; v.revcomp = !mate_rc; }
         return v;
@@ -191,14 +227,14 @@ __device__ __forceinline__ Verdict classify(const RecView& r, const im_triage_pa
     if (aligned && mate_aligned && proper) {                                   // 425-515
         uint32_t ndel = 0, nins = 0, nclip = 0; bool three = false;
         for (uint32_t i = 0; i < r.n_cigar; i++) {
-            const uint32_t op = ld_u32(r.p + r.o_cigar + 4u * i) & 15u;
+            const uint32_t op = cigar_word(r, i) & 15u;
             if (op == 3u || op == 5u || op == 6u || op > 8u) { v.cls = IM_REC_ERR_CIGAR; return v; }   // new_readseg_bam
             ndel += op == 2u; nins += op == 1u; nclip += op == 4u;
             if (op == 4u && ((!is_rc && i == r.n_cigar - 1u) || (is_rc && i == 0u))) three = true;
         }
         if (ndel + nins + nclip == 0u) return v;
         if ((nclip == 0u || (nclip == 1u && three)) && ndel == 0u && nins == 0u) return v;            // 457-460
-        const int32_t mmq = o_mq ? aux_int(r, o_mq) : (int32_t)r.mapq;
+        const int32_t mmq = o_mq ? aux_int(r, w, o_mq) : (int32_t)r.mapq;
         if (mmq >= tp.qthreshold) { v.cls = IM_REC_CAND_PROPER; v.revcomp = is_rc == mate_rc; }
         return v;
     }
@@ -221,20 +257,53 @@ struct TriageArgs {
     uint32_t* info;         // [n] class | revcomp << 8
     int32_t* rmax;          // [n]
     uint2* blk;             // [blocks] candidates, padded read bytes -> exclusive bases after the scan
+    uint32_t* blocks_done;  // [1] zero between launches: the workgroup that finishes last scans blk[]
+    uint32_t* seq_at;       // [cap_cand] byte offset of a candidate's packed bases in recs.raw, | 1 << 31 = reverse complement
+    int32_t* chunk_base;    // [1] candidates before this chunk (written by the scan)
 };
 
 __device__ __forceinline__ uint32_t padded4(int32_t l) { return ((uint32_t)l + 3u) & ~3u; }
 
+constexpr int kRgLds = 2048;        // an insert-length table up to this size is copied to LDS
+
 __global__ __launch_bounds__(kTriBlock) void triage_classify_kernel(TriageArgs A)
 {
     __shared__ uint32_t s_cnt[kTriBlock / 64], s_bytes[kTriBlock / 64], s_counted[kTriBlock / 64], s_err[kTriBlock / 64];
+    __shared__ uint32_t s_aux[kTriBlock][kAuxWin / 4];
+    __shared__ uint32_t s_rg[kRgLds / 4];
+    __shared__ int32_t s_generic[2];
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int64_t i = (int64_t)blockIdx.x * kTriBlock + t;
+
+    // the record: offsets, core, then CIGAR head + aux window in one round trip
+    RecView r; r.ok = false; r.l_seq = 0; r.flag = 0; r.n_cigar = 0; r.tid = -1; r.pos = 0; r.o_cigar = 0; r.p = A.recs.raw; r.len = 0; r.o_aux = 0;
+    if (i < A.recs.n) {
+        r = view_record(A.recs.raw, A.recs.rec_off[i], A.recs.rec_off[i + 1]);
+        if (r.ok) {
+            // reads past the record stay inside the chunk buffer (>= 64 spare bytes behind the last record)
+#pragma unroll
+            for (int k = 0; k < 4; k++) r.cig[k] = ld_u32(r.p + r.o_cigar + 4u * k);
+#pragma unroll
+            for (int k = 0; k < kAuxWin / 4; k++) s_aux[t][k] = ld_u32(r.p + r.o_aux + 4u * k);
+        }
+    }
+    // the insert-length table: LDS copy when it is small
+    const bool rg_lds = A.rg.bytes <= kRgLds;
+    if (rg_lds) for (int k = t; 4 * k < A.rg.bytes; k += kTriBlock) s_rg[k] = reinterpret_cast<const uint32_t*>(A.rg.blob)[k];
+    __syncthreads();
+    const RgView T = rg_view(rg_lds ? reinterpret_cast<const uint8_t*>(s_rg) : A.rg.blob, A.rg.n);
+    if (t == 0) {
+        int32_t rm = 0;
+        const bool ok = rg_lookup(T, [](uint32_t k) { return (uint32_t)("generic"[k]); }, 7u, rm);
+        s_generic[0] = ok ? 1 : 0; s_generic[1] = rm;
+    }
+    __syncthreads();
+
     uint32_t cls = IM_REC_SKIP, bytes = 0;
     bool cand = false;
     if (i < A.recs.n) {
-        const RecView r = view_record(A.recs.raw, A.recs.rec_off[i], A.recs.rec_off[i + 1]);
-        const Verdict v = classify(r, A.tp, A.rg);
+        AuxWin w; w.lds = reinterpret_cast<const uint8_t*>(s_aux[t]); w.o0 = r.o_aux;
+        const Verdict v = classify(r, w, A.tp, T, s_generic[0] != 0, s_generic[1]);
         cls = v.cls;
         cand = cls == IM_REC_CAND_UNMAPPED || cls == IM_REC_CAND_PROPER;
         if (cand) bytes = padded4(r.l_seq);
@@ -248,8 +317,8 @@ __global__ __launch_bounds__(kTriBlock) void triage_classify_kernel(TriageArgs A
             const int64_t clen = A.ref.len[r.tid];
             int64_t x = r.pos;
             for (uint32_t k = 0; k < r.n_cigar; k++) {
-                const uint32_t w = ld_u32(r.p + r.o_cigar + 4u * k), op = w & 15u;
-                const int64_t len = w >> 4;
+                const uint32_t cw = cigar_word(r, k), op = cw & 15u;
+                const int64_t len = cw >> 4;
                 if (op == 0u || op == 7u || op == 8u) {
                     int64_t a = x < 0 ? 0 : x, b = x + len > clen ? clen : x + len;
                     if (a < b) { atomicAdd(&A.depth_diff[base + a], 1); atomicAdd(&A.depth_diff[base + b], -1); }
@@ -266,55 +335,65 @@ __global__ __launch_bounds__(kTriBlock) void triage_classify_kernel(TriageArgs A
     const uint64_t mk = __ballot(cls != IM_REC_SKIP), me = __ballot(cls >= IM_REC_ERR_RG);
     if (lane == 0) { s_cnt[wave] = (uint32_t)__popcll(mc); s_bytes[wave] = wb; s_counted[wave] = (uint32_t)__popcll(mk); s_err[wave] = (uint32_t)__popcll(me); }
     __syncthreads();
+    __shared__ uint32_t s_last;
     if (t == 0) {
         uint32_t c = 0, b = 0, k = 0, e = 0;
-        for (int w = 0; w < kTriBlock / 64; w++) { c += s_cnt[w]; b += s_bytes[w]; k += s_counted[w]; e += s_err[w]; }
-        A.blk[blockIdx.x] = make_uint2(c, b);
+        for (int wv = 0; wv < kTriBlock / 64; wv++) { c += s_cnt[wv]; b += s_bytes[wv]; k += s_counted[wv]; e += s_err[wv]; }
+        // Published with a RETURNING agent-scope atomic and counted only once the return is in: the count below cannot
+        // overtake the totals, and no fence is needed (an agent-scope fence is a whole-L2 write-back per workgroup on
+        // this chip, profiles/README.md).
+        unsigned long long seen = atomicExch(reinterpret_cast<unsigned long long*>(&A.blk[blockIdx.x]), ((unsigned long long)b << 32) | c);
         if (k) atomicAdd(&A.out.counters[2], (int32_t)k);
         if (e) atomicAdd(&A.out.counters[3], (int32_t)e);
+        asm volatile("" :: "v"(seen));
+        s_last = atomicAdd(A.blocks_done, 1u) == gridDim.x - 1u ? 1u : 0u;
     }
-}
-
-// exclusive scan of the workgroup totals by one workgroup, on top of the running counters
-__global__ __launch_bounds__(1024) void triage_scan_kernel(uint2* __restrict__ blk, int32_t n_blocks, int32_t* __restrict__ counters)
-{
-    __shared__ uint32_t wc[16], wb[16];
-    __shared__ uint32_t carry_c, carry_b;
-    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
-    if (t == 0) { carry_c = (uint32_t)counters[0]; carry_b = (uint32_t)counters[1]; }
     __syncthreads();
-    for (int32_t base = 0; base < n_blocks; base += 1024) {
-        const int32_t i = base + t;
-        const uint2 v = (i < n_blocks) ? blk[i] : make_uint2(0u, 0u);
+    if (!s_last) return;
+    // Last workgroup to finish: exclusive scan of the workgroup totals on top of the running counters (candidates are
+    // appended in record order).  One launch less than a scan kernel of its own; a few thousand totals at most, read
+    // back through the same atomic path they were published on.
+    __shared__ uint32_t wc[kTriBlock / 64], wbb[kTriBlock / 64];
+    __shared__ uint32_t carry_c, carry_b;
+    if (t == 0) { carry_c = (uint32_t)A.out.counters[0]; carry_b = (uint32_t)A.out.counters[1]; A.chunk_base[0] = A.out.counters[0]; }
+    __syncthreads();
+    const int32_t n_blocks = (int32_t)gridDim.x;
+    uint2* blk = A.blk;
+    for (int32_t base = 0; base < n_blocks; base += kTriBlock) {
+        const int32_t j = base + t;
+        uint2 v = make_uint2(0u, 0u);
+        if (j < n_blocks) {
+            const unsigned long long pv = atomicAdd(reinterpret_cast<unsigned long long*>(&blk[j]), 0ull);
+            v.x = (uint32_t)pv; v.y = (uint32_t)(pv >> 32);
+        }
         uint32_t c = v.x, b = v.y;
 #pragma unroll
         for (int o = 1; o < 64; o <<= 1) {
             const uint32_t tc = (uint32_t)__shfl_up((int)c, o), tb = (uint32_t)__shfl_up((int)b, o);
             if (lane >= o) { c += tc; b += tb; }
         }
-        if (lane == 63) { wc[wave] = c; wb[wave] = b; }
+        if (lane == 63) { wc[wave] = c; wbb[wave] = b; }
         __syncthreads();
         uint32_t oc = 0, ob = 0;
-        for (int w = 0; w < wave; w++) { oc += wc[w]; ob += wb[w]; }
+        for (int wv = 0; wv < wave; wv++) { oc += wc[wv]; ob += wbb[wv]; }
         const uint32_t cc = carry_c, cb = carry_b;
-        if (i < n_blocks) blk[i] = make_uint2(cc + oc + c - v.x, cb + ob + b - v.y);
+        if (j < n_blocks) blk[j] = make_uint2(cc + oc + c - v.x, cb + ob + b - v.y);
         __syncthreads();
-        if (t == 1023) { carry_c = cc + oc + c; carry_b = cb + ob + b; }
+        if (t == kTriBlock - 1) { carry_c = cc + oc + c; carry_b = cb + ob + b; }
         __syncthreads();
     }
-    if (t == 0) { counters[0] = (int32_t)carry_c; counters[1] = (int32_t)carry_b; }
+    if (t == 0) { A.out.counters[0] = (int32_t)carry_c; A.out.counters[1] = (int32_t)carry_b; *A.blocks_done = 0u; }
 }
 
 // 4-bit base code -> ASCII (bit2char, src/readaln.c:4-17); 0 = a code the reference exits on
 __device__ __forceinline__ uint32_t base_ascii(uint32_t code)
 {
-    // index:        0  1   2   3  4   5  6  7  8   9 10 11 12 13 14 15
-    //               -  A   C   -  G   -  -  -  T   -  -  -  -  -  -  N
     return code == 1u ? 'A' : code == 2u ? 'C' : code == 4u ? 'G' : code == 8u ? 'T' : code == 15u ? 'N' : 0u;
 }
 // complement in code space (A<->T, C<->G, N<->N: src/sequences.c:22-26) = reversal of the four bits
 __device__ __forceinline__ uint32_t comp_code(uint32_t c) { return ((c & 1u) << 3) | ((c & 2u) << 1) | ((c & 4u) >> 1) | ((c & 8u) >> 3); }
 
+// per candidate, by the lane that owns its record: place in the batch, scalars, CIGAR-derived evidence slots
 __global__ __launch_bounds__(kTriBlock) void triage_emit_kernel(TriageArgs A)
 {
     __shared__ uint32_t s_cnt[kTriBlock / 64], s_bytes[kTriBlock / 64];
@@ -325,7 +404,11 @@ __global__ __launch_bounds__(kTriBlock) void triage_emit_kernel(TriageArgs A)
     if (i < A.recs.n) {
         info = A.info[i];
         const uint32_t cls = info & 255u;
-        if (cls == IM_REC_CAND_UNMAPPED || cls == IM_REC_CAND_PROPER) r = view_record(A.recs.raw, A.recs.rec_off[i], A.recs.rec_off[i + 1]);
+        if (cls == IM_REC_CAND_UNMAPPED || cls == IM_REC_CAND_PROPER) {
+            r = view_record(A.recs.raw, A.recs.rec_off[i], A.recs.rec_off[i + 1]);
+#pragma unroll
+            for (int k = 0; k < 4; k++) r.cig[k] = ld_u32(r.p + r.o_cigar + 4u * k);
+        }
     }
     const bool cand = r.ok;
     const uint32_t bytes = cand ? padded4(r.l_seq) : 0u;
@@ -337,72 +420,84 @@ __global__ __launch_bounds__(kTriBlock) void triage_emit_kernel(TriageArgs A)
     for (int o = 1; o < 64; o <<= 1) { const uint32_t tb = (uint32_t)__shfl_up((int)ib, o); if (lane >= o) ib += tb; }
     if (lane == 63) { s_cnt[wave] = (uint32_t)__popcll(mc); s_bytes[wave] = ib; }
     __syncthreads();
+    if (!cand) return;
     uint32_t oc = 0, ob = 0;
     for (int w = 0; w < wave; w++) { oc += s_cnt[w]; ob += s_bytes[w]; }
     const uint2 base = A.blk[blockIdx.x];
     const uint32_t ci = base.x + oc + below;
     const uint32_t bo = base.y + ob + ib - bytes;
-    const bool fits = cand && ci < (uint32_t)A.out.cap_cand && (uint64_t)bo + bytes + 16u <= (uint64_t)A.out.cap_bases;
-    if (cand && !fits) atomicAdd(&A.out.counters[4], 1);
+    if (!(ci < (uint32_t)A.out.cap_cand && (uint64_t)bo + bytes + 16u <= (uint64_t)A.out.cap_bases)) { atomicAdd(&A.out.counters[4], 1); return; }
+    const im_dev_batch& B = A.out.batch;
+    const_cast<int64_t*>(B.base_off)[ci] = (int64_t)bo;
+    const_cast<int32_t*>(B.read_len)[ci] = r.l_seq;
+    const_cast<int32_t*>(B.tid)[ci] = r.mtid;
+    const_cast<int32_t*>(B.anchor)[ci] = r.mpos;
+    const_cast<int32_t*>(B.range_max)[ci] = A.rmax[i];
+    A.out.cand_rec[ci] = A.recs.rec_base + (int32_t)i;
+    // chunk offsets fit 31 bits (chunks are far below 2 GiB); indexed by the candidate's place in THIS chunk
+    A.seq_at[ci - (uint32_t)A.chunk_base[0]] = ((uint32_t)(r.p - A.recs.raw) + r.o_seq) | ((info & 0x100u) ? 0x80000000u : 0u);
+    // check_variants (src/indelminer.c:285-337): one evidence per I / D op that is far enough from both ends
+    int ne = 0;
     uint32_t err = 0;
-    if (fits) {
-        const im_dev_batch& B = A.out.batch;
-        const_cast<int64_t*>(B.base_off)[ci] = (int64_t)bo;
-        const_cast<int32_t*>(B.read_len)[ci] = r.l_seq;
-        const_cast<int32_t*>(B.tid)[ci] = r.mtid;
-        const_cast<int32_t*>(B.anchor)[ci] = r.mpos;
-        const_cast<int32_t*>(B.range_max)[ci] = A.rmax[i];
-        A.out.cand_rec[ci] = A.recs.rec_base + (int32_t)i;
-        // check_variants (src/indelminer.c:285-337): one evidence per I / D op that is far enough from both ends
-        int ne = 0;
-        int32_t ecls[IM_MAX_EV], eb1[IM_MAX_EV], eb2[IM_MAX_EV];
-        if ((info & 255u) == IM_REC_CAND_PROPER) {
-            uint32_t tpos = 0, rpos = 0;
-            for (uint32_t k = 0; k < r.n_cigar; k++) {
-                const uint32_t w = ld_u32(r.p + r.o_cigar + 4u * k), op = w & 15u;
-                if (op == 7u || op == 8u || op == 0u || op == 1u) tpos += w >> 4;
-            }
-            int32_t refpos = r.pos;
-            for (uint32_t k = 0; k < r.n_cigar && !err; k++) {
-                const uint32_t w = ld_u32(r.p + r.o_cigar + 4u * k), op = w & 15u, len = w >> 4;
-                if (op == 2u || op == 1u) {
-                    if (rpos > A.tp.ethreshold_vcfcheck && (tpos - rpos) > A.tp.ethreshold_vcfcheck) {
-                        if (ne >= IM_MAX_EV) { err = IM_REC_ERR_LIMIT; break; }
-                        ecls[ne] = op == 2u ? IM_CLS_DELETION : IM_CLS_INSERTION;
-                        eb1[ne] = refpos; eb2[ne] = op == 2u ? refpos + (int32_t)len : refpos;
-                        ne++;
-                    }
-                } else if (op == 0u || op == 7u || op == 8u) rpos += len;
-                else if (op == 4u) { if (!(k == 0u || k == r.n_cigar - 1u)) err = IM_REC_ERR_CLIP; }
-                else err = IM_REC_ERR_CIGAR;
-                if (op == 0u || op == 7u || op == 8u || op == 2u) refpos += (int32_t)len;
-            }
+    int32_t e_cls[IM_MAX_EV] = { -1, -1, -1, -1 }, e_b1[IM_MAX_EV] = { 0, 0, 0, 0 }, e_b2[IM_MAX_EV] = { 0, 0, 0, 0 };
+    if ((info & 255u) == IM_REC_CAND_PROPER) {
+        uint32_t tpos = 0, rpos = 0;
+        for (uint32_t k = 0; k < r.n_cigar; k++) {
+            const uint32_t w = cigar_word(r, k), op = w & 15u;
+            if (op == 7u || op == 8u || op == 0u || op == 1u) tpos += w >> 4;
         }
-        if (B.ev_cls) {
-#pragma unroll
-            for (int k = 0; k < IM_MAX_EV; k++) {
-                const int64_t sl = (int64_t)ci * IM_MAX_EV + k;
-                const bool live = k < ne && !err;
-                B.ev_cls[sl] = live ? ecls[k] : -1;
-                B.ev_b1[sl] = live ? eb1[k] : 0;
-                B.ev_b2[sl] = live ? eb2[k] : 0;
-            }
+        int32_t refpos = r.pos;
+        for (uint32_t k = 0; k < r.n_cigar && !err; k++) {
+            const uint32_t w = cigar_word(r, k), op = w & 15u, len = w >> 4;
+            if (op == 2u || op == 1u) {
+                if (rpos > A.tp.ethreshold_vcfcheck && (tpos - rpos) > A.tp.ethreshold_vcfcheck) {
+                    if (ne >= IM_MAX_EV) { err = IM_REC_ERR_LIMIT; break; }
+                    const int32_t c = op == 2u ? IM_CLS_DELETION : IM_CLS_INSERTION, x1 = refpos, x2 = op == 2u ? refpos + (int32_t)len : refpos;
+                    // static slot selection keeps the three small arrays in registers
+                    if (ne == 0) { e_cls[0] = c; e_b1[0] = x1; e_b2[0] = x2; }
+                    else if (ne == 1) { e_cls[1] = c; e_b1[1] = x1; e_b2[1] = x2; }
+                    else if (ne == 2) { e_cls[2] = c; e_b1[2] = x1; e_b2[2] = x2; }
+                    else { e_cls[3] = c; e_b1[3] = x1; e_b2[3] = x2; }
+                    ne++;
+                }
+            } else if (op == 0u || op == 7u || op == 8u) rpos += len;
+            else if (op == 4u) { if (!(k == 0u || k == r.n_cigar - 1u)) err = IM_REC_ERR_CLIP; }
+            else err = IM_REC_ERR_CIGAR;
+            if (op == 0u || op == 7u || op == 8u || op == 2u) refpos += (int32_t)len;
         }
     }
-    // the wave decodes the bases of its candidates one read at a time, four bases per lane and pass
-    uint64_t todo = __ballot(fits);
-    while (todo) {
-        const int src = (int)__builtin_ctzll(todo);
-        todo &= todo - 1ull;
-        const uint32_t s_off = (uint32_t)__shfl((int)(uint32_t)(r.p - A.recs.raw), src);     // chunk offsets fit 32 bits
-        const uint32_t s_seq = (uint32_t)__shfl((int)r.o_seq, src);
-        const int32_t L = __shfl(r.l_seq, src);
-        const uint32_t s_bo = (uint32_t)__shfl((int)bo, src);
-        const bool rc = (__shfl((int)info, src) & 0x100) != 0;
-        const uint8_t* seq = A.recs.raw + s_off + s_seq;
-        uint8_t* dst = const_cast<uint8_t*>(A.out.batch.bases) + s_bo;
+    if (B.ev_cls) {
+#pragma unroll
+        for (int k = 0; k < IM_MAX_EV; k++) {
+            const int64_t sl = (int64_t)ci * IM_MAX_EV + k;
+            if (A.out.consumed) A.out.consumed[sl] = 0;        // a fresh candidate: no flush has consumed its evidence
+            B.ev_cls[sl] = err ? -1 : e_cls[k];
+            B.ev_b1[sl] = err ? 0 : e_b1[k];
+            B.ev_b2[sl] = err ? 0 : e_b2[k];
+        }
+    }
+    if (err) {
+        if (A.out.rec_class) A.out.rec_class[i] = (uint8_t)err;
+        atomicAdd(&A.out.counters[3], 1);
+    }
+}
+
+// new_unaligned_readaln's decode (src/readaln.c:242-267) + reverse_complement_string (src/sequences.c:204-220) for the
+// chunk's candidates, 32 lanes per read, four bases per lane and pass: candidates cluster around the indel sites, so
+// the work is spread over the candidate list and not over the records
+__global__ __launch_bounds__(256) void triage_decode_kernel(TriageArgs A)
+{
+    const int sub = threadIdx.x >> 5, l32 = threadIdx.x & 31;
+    const int32_t c0 = A.chunk_base[0];
+    const int32_t c1 = min(A.out.counters[0], A.out.cap_cand);
+    for (int32_t ci = c0 + (int32_t)blockIdx.x * 8 + sub; ci < c1; ci += (int32_t)gridDim.x * 8) {
+        const uint32_t at = A.seq_at[ci - c0];
+        const bool rc = (at & 0x80000000u) != 0;
+        const uint8_t* seq = A.recs.raw + (at & 0x7FFFFFFFu);
+        const int32_t L = A.out.batch.read_len[ci];
+        uint8_t* dst = const_cast<uint8_t*>(A.out.batch.bases) + A.out.batch.base_off[ci];
         bool bad = false;
-        for (int32_t p0 = 4 * lane; p0 < (int32_t)padded4(L); p0 += 256) {
+        for (int32_t p0 = 4 * l32; p0 < (int32_t)padded4(L); p0 += 128) {
             uint32_t word = 0;
 #pragma unroll
             for (int j = 0; j < 4; j++) {
@@ -418,11 +513,13 @@ __global__ __launch_bounds__(kTriBlock) void triage_emit_kernel(TriageArgs A)
             }
             *reinterpret_cast<uint32_t*>(dst + p0) = word;
         }
-        if (__ballot(bad) && lane == src) err = IM_REC_ERR_BASE;
-    }
-    if (err) {
-        if (A.out.rec_class) A.out.rec_class[i] = (uint8_t)err;
-        atomicAdd(&A.out.counters[3], 1);
+        // a base code the reference exits on (bit2char): the candidate's record gets the error class
+        const uint64_t mb = __ballot(bad);
+        const uint32_t half = (uint32_t)(mb >> (32 * ((threadIdx.x >> 5) & 1)));
+        if (half != 0u && l32 == 0) {
+            if (A.out.rec_class) A.out.rec_class[A.out.cand_rec[ci] - A.recs.rec_base] = (uint8_t)IM_REC_ERR_BASE;
+            atomicAdd(&A.out.counters[3], 1);
+        }
     }
 }
 
@@ -433,7 +530,15 @@ size_t triage_scratch_bytes(int32_t n_records)
     const size_t n = (size_t)(n_records > 0 ? n_records : 1);
     const size_t blocks = (n + kTriBlock - 1) / kTriBlock;
     auto up = [](size_t x) { return (x + 255) / 256 * 256; };
-    return up(n * 4) + up(n * 4) + up(blocks * 8);
+    return up(n * 4) + up(n * 4) + up(blocks * 8) + up(n * 4) + 512;
+}
+
+// offset of the words that must be zero before the first launch on a scratch buffer
+size_t triage_scratch_zero_offset(int32_t n_records, size_t* bytes)
+{
+    (void)n_records;
+    *bytes = 512;
+    return 0;
 }
 
 hipError_t launch_triage(const RefDev& ref, const RgTable& rg, int32_t* depth_diff, const im_triage_params& tp,
@@ -446,13 +551,19 @@ hipError_t launch_triage(const RefDev& ref, const RgTable& rg, int32_t* depth_di
     TriageArgs A;
     A.recs = recs; A.out = out; A.tp = tp; A.ref = ref; A.rg = rg;
     A.depth_diff = tp.want_depth ? depth_diff : nullptr;
+    // fixed words first (their place must not depend on the launch's record count), then the per-record arrays
     char* s = static_cast<char*>(scratch);
+    A.chunk_base = reinterpret_cast<int32_t*>(s); s += 256;
+    A.blocks_done = reinterpret_cast<uint32_t*>(s); s += 256;      // zeroed by im_dev_triage_scratch_init, left zero by every launch
     A.info = reinterpret_cast<uint32_t*>(s); s += up(n * 4);
     A.rmax = reinterpret_cast<int32_t*>(s); s += up(n * 4);
-    A.blk = reinterpret_cast<uint2*>(s);
+    A.blk = reinterpret_cast<uint2*>(s); s += up((size_t)blocks * 8);
+    A.seq_at = reinterpret_cast<uint32_t*>(s);
     hipLaunchKernelGGL(triage_classify_kernel, dim3(blocks), dim3(kTriBlock), 0, stream, A);
-    hipLaunchKernelGGL(triage_scan_kernel, dim3(1), dim3(1024), 0, stream, A.blk, blocks, out.counters);
     hipLaunchKernelGGL(triage_emit_kernel, dim3(blocks), dim3(kTriBlock), 0, stream, A);
+    int dgrid = (int)((n + 63) / 64);           // one 32-lane group per candidate, 8 per workgroup; ~1/8 of the records at most pays off
+    if (dgrid > 2048) dgrid = 2048;
+    hipLaunchKernelGGL(triage_decode_kernel, dim3(dgrid), dim3(256), 0, stream, A);
     return hipGetLastError();
 }
 

@@ -1896,7 +1896,7 @@ typedef struct {
     /* device arrays of the group (growable) */
     int32_t cap_cand; int64_t cap_bases; int32_t cap_pe, cap_fl;
     void *bases, *boff, *len, *tid, *anchor, *range, *res, *cls, *b1, *b2, *consumed, *cand_rec, *counters, *cut;
-    void *order, *clkey, *clfirst, *clcount, *counts, *gscratch; size_t gscratch_bytes;
+    void *order, *clkey, *clfirst, *clcount, *counts, *gscratch, *fdesc; size_t gscratch_bytes;
     /* confirmed by harvested chunks / still in flight */
     int32_t conf_cand, conf_err; int64_t conf_bytes, fly_recs, fly_seq;
     im_triage_params tp;
@@ -1919,6 +1919,7 @@ static void pipe_alloc_cands(ppipe* P, int32_t cap_cand, int64_t cap_bases, int3
     P->order = pdev_alloc(P, 4 * nsl); P->clkey = pdev_alloc(P, 16 * nsl); P->clfirst = pdev_alloc(P, 4 * nsl); P->clcount = pdev_alloc(P, 4 * nsl);
     P->gscratch_bytes = im_dev_groupby_scratch_bytes((int32_t)nsl);
     P->gscratch = pdev_alloc(P, P->gscratch_bytes);
+    GPU(im_dev_groupby_scratch_init(P->d->gpu, (int32_t)nsl, P->gscratch, P->gscratch_bytes, P->stream));
     P->cap_cand = cap_cand; P->cap_bases = cap_bases; P->cap_pe = cap_pe;
 }
 
@@ -1951,12 +1952,14 @@ static void pipe_init(ppipe* P, driver* d)
         c->d_class = pdev_alloc(P, PIPE_CHUNK_RECS);
         c->scratch_bytes = im_dev_triage_scratch_bytes((int32_t)PIPE_CHUNK_RECS);
         c->d_scratch = pdev_alloc(P, c->scratch_bytes);
+        GPU(im_dev_triage_scratch_init(d->gpu, (int32_t)PIPE_CHUNK_RECS, c->d_scratch, c->scratch_bytes, P->stream));
         GPU(im_event_create(d->gpu, &c->done));
     }
     P->counters = pdev_alloc(P, 64);
     P->counts = pdev_alloc(P, 64);
     P->cap_fl = 4096;
     P->cut = pdev_alloc(P, 8 * (size_t)P->cap_fl);
+    P->fdesc = pdev_alloc(P, sizeof(im_flush_desc) * (size_t)P->cap_fl);
     pipe_alloc_cands(P, 1 << 20, (int64_t)(1 << 20) * 160, 1 << 16);
     P->tp.qthreshold = O.qthreshold; P->tp.ethreshold_vcfcheck = O.ethreshold_vcfcheck; P->tp.maxpedelsize = O.maxpedelsize;
     P->tp.want_depth = 1;
@@ -1973,7 +1976,7 @@ static void pipe_destroy(ppipe* P)
         im_event_destroy(c->done);
     }
     pipe_free_cands(P);
-    im_dev_free(P->d->gpu, P->counters); im_dev_free(P->d->gpu, P->counts); im_dev_free(P->d->gpu, P->cut);
+    im_dev_free(P->d->gpu, P->counters); im_dev_free(P->d->gpu, P->counts); im_dev_free(P->d->gpu, P->cut); im_dev_free(P->d->gpu, P->fdesc);
     im_stream_destroy(P->d->gpu, P->stream);
     P->ready = 0;
 }
@@ -2087,7 +2090,7 @@ static void pipe_submit(ppipe* P, pgroup* G)
     out.batch.anchor = P->anchor; out.batch.range_max = P->range; out.batch.out = P->res;
     out.batch.ev_cls = P->cls; out.batch.ev_b1 = P->b1; out.batch.ev_b2 = P->b2;
     out.cand_rec = P->cand_rec; out.counters = P->counters; out.rec_class = c->d_class;
-    out.cap_cand = P->cap_cand; out.cap_bases = P->cap_bases;
+    out.cap_cand = P->cap_cand; out.cap_bases = P->cap_bases; out.consumed = NULL;     /* cleared once per group in pipe_run_group */
     GPU(im_dev_triage(g, &P->tp, &recs, &out, c->d_scratch, c->scratch_bytes, P->stream));
     GPU(im_dev_download_async(g, c->h_cnt, P->counters, 32, P->stream));
     GPU(im_event_record(c->done, P->stream));
@@ -2167,13 +2170,6 @@ static void pipe_walk_contig(ppipe* P, pgroup* G, int32_t tid, bgzf_reader* r)
     GPU(im_depth_scan(d->gpu, tid, P->stream));
 }
 
-static int32_t lower_bound_i32(const int32_t* a, int32_t n, int64_t v)
-{
-    int32_t lo = 0, hi = n;
-    while (lo < hi) { const int32_t mid = lo + (hi - lo) / 2; if (a[mid] < v) lo = mid + 1; else hi = mid; }
-    return lo;
-}
-
 static int g_tie_for_sort;
 static const int32_t* g_key_for_sort;
 static int cmp_cluster_idx(const void* x, const void* y)
@@ -2198,7 +2194,7 @@ static void pipe_run_group(ppipe* P, pgroup* G)
     if (G->n_pe > P->cap_pe || G->n_fl > P->cap_fl) {
         /* rare: more discordant pairs / flushes than the arrays were sized for */
         GPU(im_stream_sync(g, P->stream));
-        if (G->n_fl > P->cap_fl) { im_dev_free(g, P->cut); while (P->cap_fl < G->n_fl) P->cap_fl *= 2; P->cut = pdev_alloc(P, 8 * (size_t)P->cap_fl); }
+        if (G->n_fl > P->cap_fl) { im_dev_free(g, P->cut); while (P->cap_fl < G->n_fl) P->cap_fl *= 2; P->cut = pdev_alloc(P, 8 * (size_t)P->cap_fl); im_dev_free(g, P->fdesc); P->fdesc = pdev_alloc(P, sizeof(im_flush_desc) * (size_t)P->cap_fl); }
         if (G->n_pe > P->cap_pe) {
             ppipe old = *P;
             int32_t np = P->cap_pe; while (np < G->n_pe) np *= 2;
@@ -2233,16 +2229,35 @@ static void pipe_run_group(ppipe* P, pgroup* G)
         bt.range_max = P->range; bt.out = P->res; bt.ev_cls = P->cls; bt.ev_b1 = P->b1; bt.ev_b2 = P->b2;
         GPU(im_dev_realign_keep(g, &prm, &bt, P->stream));
     }
-    for (int ci = 0; ci < G->n_ctg; ci++) {
-        const gcontig* cg = &G->ctg[ci];
-        const int32_t cand_lo = lower_bound_i32(G->cand_rec, nc, cg->rec0);
-        for (int f = cg->fl0; f < cg->fl1; f++) {
-            const gflush* fl = &G->fl[f];
-            const int32_t cand_hi = lower_bound_i32(G->cand_rec, nc, fl->rec);
-            GPU(im_dev_flush_cut(g, P->cls, P->b1, P->b2, P->consumed, cand_lo * IM_MAX_EV, cand_hi * IM_MAX_EV,
-                                 (int32_t)pe_base + cg->pe0, (int32_t)pe_base + fl->pe, fl->marker, f + 1,
-                                 (uint64_t*)P->cut + f, P->stream));
+    {
+        /* the flush list of the group, in file order.  One launch walks it when every flush sees a short pending
+         * range (the usual case: a flush consumes nearly everything that arrived since the previous one); a group
+         * whose pending ranges grow long (markers pinned low by stale pair-table entries) takes one launch pair per
+         * flush, which spreads each range over the whole chip */
+        im_flush_desc* fd = xmalloc(sizeof(im_flush_desc) * (size_t)(G->n_fl ? G->n_fl : 1));
+        int64_t longest = 0;
+        for (int ci = 0; ci < G->n_ctg; ci++) {
+            const gcontig* cg = &G->ctg[ci];
+            for (int f = cg->fl0; f < cg->fl1; f++) {
+                const gflush* fl = &G->fl[f];
+                fd[f].rec0 = (int32_t)cg->rec0; fd[f].rec1 = (int32_t)fl->rec; fd[f].pe0 = cg->pe0; fd[f].pe1 = fl->pe;
+                fd[f].marker = fl->marker; fd[f].id = f + 1;
+                if (fl->rec - cg->rec0 > longest) longest = fl->rec - cg->rec0;
+            }
         }
+        const char* fm = getenv("INDELMINER_FLUSH_MODE");
+        const int per_flush = fm ? strcmp(fm, "per-flush") == 0 : (longest > 16 * (int64_t)READCHUNK && G->n_fl > 64);
+        if (!per_flush) {
+            GPU(im_dev_upload(g, P->fdesc, fd, sizeof(im_flush_desc) * (size_t)G->n_fl));    /* synchronous: complete before the launch below */
+            GPU(im_dev_flush_cuts(g, (const im_flush_desc*)P->fdesc, G->n_fl, P->cls, P->b1, P->b2, P->consumed,
+                                  P->cand_rec, P->counters, P->cap_cand, (int32_t)pe_base, G->n_pe, P->stream));
+        } else {
+            for (int f = 0; f < G->n_fl; f++)
+                GPU(im_dev_flush_cut_rec(g, P->cls, P->b1, P->b2, P->consumed, fd[f].rec0, fd[f].rec1, P->cand_rec, P->counters, P->cap_cand,
+                                         (int32_t)pe_base + fd[f].pe0, (int32_t)pe_base + fd[f].pe1, fd[f].marker, fd[f].id,
+                                         (uint64_t*)P->cut + f, P->stream));
+        }
+        free(fd);
     }
     GPU(im_dev_cluster_groupby(g, nc * IM_MAX_EV, P->cls, P->b1, P->b2, P->consumed, O.tie_desc,
                                P->order, P->clkey, P->clfirst, P->clcount, P->counts, P->gscratch, P->gscratch_bytes, P->stream));

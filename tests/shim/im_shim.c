@@ -172,6 +172,8 @@ void im_event_destroy(im_event* e) { free(e); }
 int im_event_record(im_event* e, void* s) { (void)e; (void)s; return IM_OK; }
 int im_event_sync(im_event* e) { (void)e; return IM_OK; }
 size_t im_dev_triage_scratch_bytes(int32_t n) { (void)n; return 256; }
+int im_dev_triage_scratch_init(im_ctx* c, int32_t n, void* s, size_t b, void* st) { (void)c; (void)n; (void)s; (void)b; (void)st; return IM_OK; }
+int im_dev_groupby_scratch_init(im_ctx* c, int32_t n, void* s, size_t b, void* st) { (void)c; (void)n; (void)s; (void)b; (void)st; return IM_OK; }
 size_t im_dev_groupby_scratch_bytes(int32_t n) { (void)n; return 256; }
 
 int im_dev_triage(im_ctx* c, const im_triage_params* tp, const im_dev_records* recs, const im_dev_cands* out,
@@ -222,6 +224,7 @@ int im_dev_triage(im_ctx* c, const im_triage_params* tp, const im_dev_records* r
         out->cand_rec[ci] = recs->rec_base + i;
         for (int k = 0; k < IM_MAX_EV; k++) {
             const int live = k < t.n_ev && t.n_ev <= IM_MAX_EV;
+            if (out->consumed) out->consumed[(size_t)ci * IM_MAX_EV + k] = 0;
             out->batch.ev_cls[(size_t)ci * IM_MAX_EV + k] = live ? t.ev_cls[k] : -1;
             out->batch.ev_b1[(size_t)ci * IM_MAX_EV + k] = live ? t.ev_b1[k] : 0;
             out->batch.ev_b2[(size_t)ci * IM_MAX_EV + k] = live ? t.ev_b2[k] : 0;
@@ -275,6 +278,36 @@ int im_dev_flush_cut(im_ctx* c, const int32_t* cls, const int32_t* b1, const int
     imo_flush_cut(n, tc, t1, t2, tu, marker, flush_id);
     for (int32_t i = 0; i < n; i++) consumed[i < na ? a0 + i : b0 + (i - na)] = tu[i];
     free(tc); free(t1); free(t2); free(tu);
+    return IM_OK;
+}
+
+int im_dev_flush_cut_rec(im_ctx* c, const int32_t* cls, const int32_t* b1, const int32_t* b2, int32_t* consumed,
+                         int32_t rec0, int32_t rec1, const int32_t* cand_rec, const int32_t* n_cand_dev, int32_t cand_cap,
+                         int32_t b0, int32_t b1_end, int32_t marker, int32_t flush_id, uint64_t* cut_word, void* stream)
+{
+    const int32_t nc = *n_cand_dev < cand_cap ? *n_cand_dev : cand_cap;
+    int32_t lo = 0, hi;
+    while (lo < nc && cand_rec[lo] < rec0) lo++;
+    hi = lo;
+    while (hi < nc && cand_rec[hi] < rec1) hi++;
+    return im_dev_flush_cut(c, cls, b1, b2, consumed, lo * IM_MAX_EV, hi * IM_MAX_EV, b0, b1_end, marker, flush_id, cut_word, stream);
+}
+
+int im_dev_flush_cuts(im_ctx* c, const im_flush_desc* desc, int32_t n_flushes,
+                      const int32_t* cls, const int32_t* b1, const int32_t* b2, int32_t* consumed,
+                      const int32_t* cand_rec, const int32_t* n_cand_dev, int32_t cand_cap, int32_t pe_base, int32_t pe_count, void* stream)
+{
+    for (int32_t i = 0; i < pe_count; i++) consumed[pe_base + i] = 0;
+    const int32_t nc = *n_cand_dev < cand_cap ? *n_cand_dev : cand_cap;
+    for (int32_t f = 0; f < n_flushes; f++) {
+        int32_t lo = 0, hi = 0;
+        while (lo < nc && cand_rec[lo] < desc[f].rec0) lo++;
+        hi = lo;
+        while (hi < nc && cand_rec[hi] < desc[f].rec1) hi++;
+        uint64_t dummy = ~0ull;
+        im_dev_flush_cut(c, cls, b1, b2, consumed, lo * IM_MAX_EV, hi * IM_MAX_EV, pe_base + desc[f].pe0, pe_base + desc[f].pe1,
+                         desc[f].marker, desc[f].id, &dummy, stream);
+    }
     return IM_OK;
 }
 

@@ -201,6 +201,47 @@ def test_realign_keep_flush_groupby(gpu_ctx):
     assert got == {k: v[::-1] for k, v in want.items()}
 
 
+@pytest.mark.parametrize("one_launch", [True, False])
+def test_async_pass_matches_stepwise(gpu_ctx, one_launch):
+    """the whole pass bound on one stream without host round trips (device-resident candidate count, record bounds,
+    all flushes in one launch) gives the stepwise results"""
+    refs, rd, raw, off = _synth(seed=13, ref_len=150_000, coverage=25, big_every=5)
+    contig = refs[0].tobytes()
+    gpu_ctx.set_reference([contig])
+    gpu_ctx.set_insert_ranges(["generic"], [rd.range_max])
+    import bench
+    flushes, pe_b1, pe_b2 = bench.flush_schedule(rd)
+    # finer flush points than READCHUNK, with the pair table's markers replaced by positions along the contig
+    cuts = [rd.n // 4, rd.n // 2, 3 * rd.n // 4]
+    flushes = [(0, c, int(np.searchsorted(np.arange(len(pe_b1)), len(pe_b1) * c // rd.n)), int(rd.pos[c - 1])) for c in cuts] + [flushes[-1]]
+    ref_pipe = capi.Pipeline(gpu_ctx, rd.n, len(raw), cap_cand=rd.n // 4, n_pe=max(len(pe_b1), 1), n_flushes=len(flushes))
+    ref_pipe.upload(raw, off); ref_pipe.set_pe(pe_b1, pe_b2)
+    ref_pipe.triage(); ref_pipe.fetch_counts(); ref_pipe.realign()
+    cand_rec = ref_pipe.d_cand_rec.download(np.int32, ref_pipe.n_cand)
+    for k, (r0, r1, pe_hi, marker) in enumerate(flushes):
+        ref_pipe.flush(k, int(np.searchsorted(cand_rec, r1)), pe_hi, marker, cand_lo=int(np.searchsorted(cand_rec, r0)))
+    ref_pipe.groupby(); ref_pipe.sync()
+    want_cons = ref_pipe.d_consumed.download(np.int32, ref_pipe.n_slots)
+    key, first, count, order = ref_pipe.clusters()
+    want = {tuple(int(x) for x in key[c]): list(order[first[c]:first[c] + count[c]]) for c in range(len(key))}
+    assert len(want) > 10 and len({k[0] for k in want}) == len(flushes)
+
+    pipe = capi.Pipeline(gpu_ctx, rd.n, len(raw), cap_cand=rd.n // 4, n_pe=max(len(pe_b1), 1), n_flushes=len(flushes), input_from=ref_pipe)
+    pipe.set_pe(pe_b1, pe_b2)
+    st = capi.new_stream(gpu_ctx)
+    for fn, args in pipe.bind_async(flushes, st, grid_bound=rd.n // 8, one_launch_flushes=one_launch):
+        gpu_ctx._check(fn(*args))
+    pipe.sync(st)
+    pipe.fetch_counts()
+    assert pipe.n_cand == ref_pipe.n_cand
+    assert np.array_equal(pipe.d_consumed.download(np.int32, pipe.n_slots), want_cons)
+    key, first, count, order = pipe.clusters()
+    got = {tuple(int(x) for x in key[c]): list(order[first[c]:first[c] + count[c]]) for c in range(len(key))}
+    assert got == want
+    a = pipe.d_res.download(capi.RESULT_DTYPE, pipe.n_cand); b = ref_pipe.d_res.download(capi.RESULT_DTYPE, pipe.n_cand)
+    assert a.tobytes() == b.tobytes()
+
+
 def test_groupby_large_support(gpu_ctx):
     """a breakpoint with more than 1024 supporting reads takes the global-memory ordering path"""
     n = 5000
