@@ -527,21 +527,27 @@ def main():
                 ids = [capi.comm_unique_id()]
         except Exception as e:
             err = e
-        if not agree(err is None):
-            sys.exit("bench: RCCL unique id could not be made: %s" % err)
-        if dist is not None:
+        ok = agree(err is None)
+        if ok and dist is not None:
             dist.broadcast_object_list(ids, src=0)
-        try:
-            comm = capi.Comm(ctx, ids[0], rank, world)
-        except Exception as e:
-            err = e
-        if not agree(err is None and comm is not None):
-            sys.exit("bench: RCCL communicator bring-up failed on at least one rank: %s" % err)
-        gbytes = 16 + 16 * rec_cap
-        for st_ in ps.sets:
-            st_["gather"] = capi.DevBuf(ctx, gbytes * world)
-            st_["tail"].append((capi.lib().im_comm_allgather, (comm.h, st_["pipe"].d_clbuf.ptr, st_["gather"].ptr, gbytes, st_["stream"])))
-        collective = "rccl all-gather of per-shard cluster lists, %d B per rank per step" % gbytes
+        if ok:
+            try:
+                comm = capi.Comm(ctx, ids[0], rank, world)
+            except Exception as e:
+                err = e
+            ok = agree(err is None and comm is not None)
+        if ok:
+            gbytes = 16 + 16 * rec_cap
+            for st_ in ps.sets:
+                st_["gather"] = capi.DevBuf(ctx, gbytes * world)
+                st_["tail"].append((capi.lib().im_comm_allgather, (comm.h, st_["pipe"].d_clbuf.ptr, st_["gather"].ptr, gbytes, st_["stream"])))
+            collective = "rccl all-gather of per-shard cluster lists, %d B per rank per step" % gbytes
+        else:
+            # agreed by ALL ranks: nobody attaches a communicator, the shards run independently and the line says so
+            if comm is not None:
+                comm.close()
+                comm = None
+            collective = "NONE (RCCL bring-up failed on at least one rank%s); shards ran independently" % (": %s" % err if err else "")
 
     def barrier():
         ps.sync()

@@ -947,312 +947,510 @@ __global__ __launch_bounds__(64, IM_WAVES_PER_SIMD) void realign_kernel(RealignA
 
 // ---- numgaps > 0: banded affine-gap path ------------------------------------------
 //
-// With -g N the band handed to local_align is N+1 diagonals wide and the reference runs a real
-// banded Gotoh pass plus the linear-space global traceback of ALIGN (src/localalign.c:15-196,
-// src/globalalign.c:66-401).  Co-optimal paths are common with +1/-10/-20/-10 scoring and the
-// split-read clusters key on exact breakpoints, so the traceback is restated literally (every
-// comparison keeps its strictness) and runs on ONE lane: the dynamic program
-// of a 100 x (N+1) band is a few thousand dependent steps, the k-mer vote around it stays
-// wave-parallel.  Work arrays live in LDS; the band's slice of the reference window is staged
-// there first so the serial lane never waits on global memory.
+// With -g N the band handed to local_align is N+1 diagonals wide and the reference runs a banded Gotoh
+// local pass forward, a reverse pass from the end cell, and ALIGN's linear-space global alignment through
+// the middle diagonal's crossing points (src/localalign.c:15-196, src/globalalign.c:66-401).  Co-optimal
+// paths are common with +1/-10/-20/-10 scoring and split-read clusters key on exact breakpoints, so every
+// comparison keeps the reference's strictness.  Here the dynamic programs run across the
+// wave: LANE = DIAGONAL of the band (band <= 61), one step per read row:
+//   * the vertical gap state and the diagonal move come from the neighbouring lane's previous row (DPP shifts);
+//   * the horizontal gap chain along a row -- the only sequential dependency inside a row -- is a prefix maximum:
+//       e(curd) = max over origins o < curd of  x(o) - g - h (curd - o),   x = max(diagonal, vertical) of cell o
+//     (a cell whose best is itself the horizontal state never re-opens a gap profitably: g > 0), ties to the
+//     leftmost origin because the reference lets an extension win over a new opening; one 6-step wave scan of a
+//     packed (value + h lane, lane) key, the crossing-point pointer of the winning origin fetched with one bpermute;
+//   * ALIGN's recursion (middle diagonal, the triangles on either side) is an explicit frame stack in LDS;
+//     the crossing-point records of the middle diagonal (MP/MT) are one packed word per row.
+// The alignment is kept per READ POSITION (class =/X/I plus the length of the reference gap in front of the
+// position), from which the CIGAR, the split-point search (lane = candidate split) and the final segment
+// list (lane = op) are made without a serial pass over the read.
 
-constexpr int kGapMaxBand = 64;          // numgaps <= 60
+#define BFAIL(G, code) do { if (threadIdx.x == 0) (G).tmp[IM_MAX_OPS + 7] = (code); } while (0)
+constexpr int kGapMaxBand = 62;          // numgaps <= 60; lane band and band + 1 hold the MININT borders
 constexpr int kGapNegInf = -9999999;     // MININT, src/localalign.c:3
 constexpr int kGapOpen = 10, kGapExt = 10;
+constexpr int kKeyBias = 30000;          // scores of cells that can be gap origins stay far inside +-30000 (M, N <= ~1300)
 
-struct GapLds {
-    int      S[2 * 256 + 96];            // edit script
-    int      CC[kGapMaxBand + 8], DD[kGapMaxBand + 8], CP[kGapMaxBand + 8], DP[kGapMaxBand + 8];
-    int      MP[3][260], FP[260];
-    int8_t   MT[3][260], FT[260];
+enum : uint8_t { kPosEq = 0, kPosX = 1, kPosI = 2, kPosNone = 255 };
+
+struct BandLds {
+    uint32_t mp[264];                    // per row of the middle diagonal: MP0+1 (9) | MT0 (2) | copy1 | MP1+1 (9) | copy2 | MP2+1 (9)
+    uint16_t fp[264];                    // forward dividing points: (next + 1) | type << 10
     uint8_t  wb[1024];                   // staged window bytes: B index j (1-based) lives at wb[j - wb_base]
-    int      wb_base;
-    int      IP;
-    int      sapp, last;                 // script append index / last op
-    uint32_t ops[2][IM_MAX_OPS];         // the two band alignments' CIGARs
-    int      nops[2];
-    int      aln[2][4];                  // r1 r2 q1 q2
-    int      status;                     // result of the serial section, read by every lane
+    uint8_t  kind[2][260];               // per piece position p (0-based): class of read base p
+    uint16_t dlen[2][264];               // reference bases skipped in front of position p (p = 0 .. M)
+    uint32_t ops[2][IM_MAX_OPS + 4];     // the two band alignments' CIGARs
+    int32_t  stk[10][16];                // ALIGN's recursion as frames
+    int32_t  nops[2];
+    int32_t  aln[2][4];                  // r1 r2 q1 q2
+    int32_t  wb_base;
+    int32_t  tmp[IM_MAX_OPS + 8];
 };
 
-struct GapCtx {
-    GapLds* G;
-    const uint8_t* A;                    // read bytes (LDS), A1[i] = A[i - 1] for the current piece
-    int a0;                              // piece start offset in the read
-};
+__device__ __forceinline__ int gw(uint32_t a, uint32_t b) { return a == b ? kScoreMatch : kScoreMismatch; }
+__device__ __forceinline__ int wshl1(int v, int fill) { return dpp_mov<kDppWaveShl1>(fill, v); }    // lane i <- lane i + 1
+__device__ __forceinline__ int wshr1(int v, int fill) { return dpp_mov<kDppWaveShr1>(fill, v); }    // lane i <- lane i - 1
+__device__ __forceinline__ int lane_get(int v, int src) { return __builtin_amdgcn_readlane(v, src); }
 
-__device__ __forceinline__ int gw(uint8_t a, uint8_t b) { return a == b ? kScoreMatch : kScoreMismatch; }
-
-__device__ __forceinline__ void gs_del(GapLds& G, int k) { if (G.last < 0) { G.S[G.sapp - 1] -= k; G.last = G.S[G.sapp - 1]; } else { G.S[G.sapp++] = -k; G.last = -k; } }
-__device__ __forceinline__ void gs_ins(GapLds& G, int k) { if (G.last > 0) { G.S[G.sapp - 1] += k; G.last = G.S[G.sapp - 1]; } else { G.S[G.sapp++] = k; G.last = k; } }
-__device__ __forceinline__ void gs_rep(GapLds& G) { G.S[G.sapp++] = 0; G.last = 0; }
-
-// align() of src/globalalign.c:66-307.  A[i] = Ab[ao + i], B[j] = wb[bo + j] (offsets instead of
-// the reference's pointer arithmetic).
-__device__ int gap_align_rec(GapLds& G, const uint8_t* Ab, int ao, int bo, int M, int N, int low, int up, int tb, int te)
+// inclusive running maximum over the lanes of the band: a band of <= 16 diagonals lies in one DPP row (four steps)
+template <bool NARROW>
+__device__ __forceinline__ int band_scan_max(int v)
 {
-    const int g = kGapOpen, h = kGapExt, m = g + h;
-    int* CC = G.CC; int* DD = G.DD; int* CP = G.CP; int* DP = G.DP;
-    const uint8_t* Bb = G.wb - G.wb_base;
-    int rmid, k, l, r, v, kt, t1, t2, t3;
-    if (N <= 0) { if (M > 0) gs_del(G, M); return -1; }
-    if (M <= 0) { gs_ins(G, N); return -1; }
-    const int band = up - low + 1;
-    if (band <= 1) { for (int i = 1; i <= M; i++) gs_rep(G); return -1; }
-    {
-        const int midd = band / 2 + 1;
-        rmid = low + midd - 1;
-        int leftd = 1 - low, rightd = up - low + 1;
-        int j, i, c = 0, d = 0, e = 0, t, ib, curd;
-        if (leftd < midd) {
-            for (j = 0; j < midd; j++) CP[j] = DP[j] = -1;
-            for (j = midd; j <= rightd; j++) CP[j] = DP[j] = 0;
-            G.MP[0][0] = G.MP[1][0] = G.MP[2][0] = -1;
-        } else if (leftd > midd) {
-            const int fr = leftd - midd;
-            for (j = 0; j <= midd; j++) CP[j] = DP[j] = fr;
-            for (j = midd + 1; j <= rightd; j++) CP[j] = DP[j] = -1;
-            G.MP[0][fr] = G.MP[1][fr] = G.MP[2][fr] = -1;
-        } else {
-            for (j = 0; j <= rightd; j++) CP[j] = DP[j] = 0;
-            G.MP[0][0] = G.MP[1][0] = G.MP[2][0] = -1;
-        }
-        CC[leftd] = 0;
-        t = (tb == 2) ? 0 : -g;
-        for (j = leftd + 1; j <= rightd; j++) { CC[j] = t = t - h; DD[j] = t - g; }
-        CC[rightd + 1] = kGapNegInf; DD[rightd + 1] = kGapNegInf;
-        DD[leftd] = (tb == 1) ? 0 : -g;
-        CC[leftd - 1] = kGapNegInf;
-        for (i = 1; i <= M; i++) {
-            if (i > N - up) rightd--;
-            if (leftd > 1) leftd--;
-            const uint8_t ai = Ab[ao + i];
-            if ((c = CC[leftd + 1] - m) > (d = DD[leftd + 1] - h)) { d = c; DP[leftd] = CP[leftd + 1]; }
-            else DP[leftd] = DP[leftd + 1];
-            if ((ib = leftd + low - 1 + i) > 0) c = CC[leftd] + gw(ai, Bb[bo + ib]);
-            if (d > c || ib <= 0) { c = d; CP[leftd] = DP[leftd]; }
-            e = c - g;
-            DD[leftd] = d; CC[leftd] = c;
-            G.IP = CP[leftd];
-            if (leftd == midd) CP[leftd] = DP[leftd] = G.IP = i;
-            for (curd = leftd + 1; curd <= rightd; curd++) {
-                if (curd != midd) {
-                    if ((c = c - m) > (e = e - h)) { e = c; G.IP = CP[curd - 1]; }
-                    if ((c = CC[curd + 1] - m) > (d = DD[curd + 1] - h)) { d = c; DP[curd] = CP[curd + 1]; }
-                    else DP[curd] = DP[curd + 1];
-                    c = CC[curd] + gw(ai, Bb[bo + curd + low - 1 + i]);
-                    if (c < d || c < e) {
-                        if (e > d) { c = e; CP[curd] = G.IP; }
-                        else       { c = d; CP[curd] = DP[curd]; }
-                    }
-                    CC[curd] = c; DD[curd] = d;
-                } else {
-                    if ((c = c - m) > (e = e - h)) { e = c; G.MP[1][i] = CP[curd - 1]; G.MT[1][i] = 2; }
-                    else { G.MP[1][i] = G.IP; G.MT[1][i] = 2; }
-                    if ((c = CC[curd + 1] - m) > (d = DD[curd + 1] - h)) { d = c; G.MP[2][i] = CP[curd + 1]; G.MT[2][i] = 1; }
-                    else { G.MP[2][i] = DP[curd + 1]; G.MT[2][i] = 1; }
-                    c = CC[curd] + gw(ai, Bb[bo + curd + low - 1 + i]);
-                    if (c < d || c < e) {
-                        if (e > d) { c = e; G.MP[0][i] = G.MP[1][i]; G.MT[0][i] = 2; }
-                        else       { c = d; G.MP[0][i] = G.MP[2][i]; G.MT[0][i] = 1; }
-                    } else { G.MP[0][i] = i - 1; G.MT[0][i] = 0; }
-                    if (c - g > e) { G.MP[1][i] = G.MP[0][i]; G.MT[1][i] = G.MT[0][i]; }
-                    if (c - g > d) { G.MP[2][i] = G.MP[0][i]; G.MT[2][i] = G.MT[0][i]; }
-                    CP[curd] = DP[curd] = G.IP = i;
-                    CC[curd] = c; DD[curd] = d;
-                }
-            }
-        }
-        if (te == 1 && d + g > c)      { k = DP[rightd]; l = 2; }
-        else if (te == 2 && e + g > c) { k = G.IP;       l = 1; }
-        else                           { k = CP[rightd]; l = 0; }
-        if (rmid > N - M) l = 2;
-        else if (rmid < N - M) l = 1;
-        v = c;
-    }
-    r = -1;
-    for (; k > -1; r = k, k = G.MP[l][r], l = G.MT[l][r]) { G.FP[k] = r; G.FT[k] = (int8_t)l; }
-    if (r == -1) {
-        if (rmid < 0) gap_align_rec(G, Ab, ao, bo, M, N, rmid + 1, up, tb, te);
-        else          gap_align_rec(G, Ab, ao, bo, M, N, low, rmid - 1, tb, te);
-    } else {
-        k = r; l = G.FP[k]; kt = G.FT[k];
-        if (rmid < 0) { gap_align_rec(G, Ab, ao, bo, r - 1, r + rmid, rmid + 1, min(up, r + rmid), tb, 1); gs_del(G, 1); }
-        else if (rmid > 0) { gap_align_rec(G, Ab, ao, bo, r, r + rmid - 1, max(-r, low), rmid - 1, tb, 2); gs_ins(G, 1); }
-        t2 = up - rmid - 1;
-        t3 = low - rmid + 1;
-        for (; l > -1; k = l, l = G.FP[k], kt = G.FT[k]) {
-            if (kt == 0) gs_rep(G);
-            else if (kt == 1) {
-                gs_ins(G, 1);
-                t1 = l - k - 1;
-                gap_align_rec(G, Ab, ao + k, bo + k + rmid + 1, t1, t1, 0, min(t1, t2), 2, 1);
-                gs_del(G, 1);
-            } else {
-                gs_del(G, 1);
-                t1 = l - k - 1;
-                gap_align_rec(G, Ab, ao + k + 1, bo + k + rmid, t1, t1, max(-t1, t3), 0, 1, 2);
-                gs_ins(G, 1);
-            }
-        }
-        if (N - M > rmid) {
-            gs_ins(G, 1);
-            t1 = k + rmid + 1;
-            gap_align_rec(G, Ab, ao + k, bo + t1, M - k, N - t1, 0, min(N - t1, t2), 2, te);
-        } else if (N - M < rmid) {
-            gs_del(G, 1);
-            t1 = M - (k + 1);
-            gap_align_rec(G, Ab, ao + k + 1, bo + k + rmid, t1, N - (k + rmid), max(-t1, t3), 0, 1, te);
-        }
+    v = max(v, dpp_mov<kDppRowShr1>(INT_MIN, v));
+    v = max(v, dpp_mov<kDppRowShr2>(INT_MIN, v));
+    v = max(v, dpp_mov<kDppRowShr4>(INT_MIN, v));
+    v = max(v, dpp_mov<kDppRowShr8>(INT_MIN, v));
+    if (!NARROW) {
+        v = max(v, dpp_mov<kDppBcast15, 0xa>(INT_MIN, v));
+        v = max(v, dpp_mov<kDppBcast31, 0xc>(INT_MIN, v));
     }
     return v;
 }
 
-__device__ __forceinline__ bool gap_push(uint32_t* ops, int& n, int op, int len)
+// key of the horizontal-gap scan: larger value wins, then the smaller lane
+__device__ __forceinline__ int ekey_pack(int x, int lane) { const int v = max(x, -kKeyBias + 1) + kGapExt * lane + kKeyBias; return (v << 6) | (63 - lane); }
+
+struct BandAln { int st, r1, r2, q1, q2; };
+
+// stage the slice of the window a band alignment can touch: B indices [jlo, jhi] (1-based); outside the window 0
+__device__ __forceinline__ int band_stage_window(BandLds& G, const uint8_t* contig, int w0, int N, int M, int low, int up, int lane)
 {
-    if (n >= IM_MAX_OPS) return false;
-    ops[n++] = ((uint32_t)len << 4) | (uint32_t)op;
-    return true;
+    const int lo = max(-M, low), hi = min(N, up);
+    int jlo = max(1, lo + 1) - 2, jhi = min(N, M + hi) + 2;
+    if (jlo < 0) jlo = 0;
+    if (jhi - jlo + 1 > (int)sizeof(G.wb)) { BFAIL(G, 1); return IM_ST_OVERFLOW; }
+    for (int t = lane; t <= jhi - jlo; t += 64) {
+        const int j = jlo + t;
+        G.wb[t] = (j >= 1 && j <= N) ? contig[(int64_t)w0 + j - 1] : 0;
+    }
+    if (lane == 0) G.wb_base = jlo;
+    wave_lds_sync();
+    return 0;
 }
 
-// attempt_band_alignment = local_align + ALIGN + fetch_cigar, run by lane 0.
-// Window = contig[w0,w0+N), read piece = rd[p0,p0+M).  Writes G.aln[which], G.ops[which].
-// Returns 0, IM_ST_ABORT or IM_ST_OVERFLOW.
-__device__ int gap_band_alignment(GapLds& G, const uint8_t* rd, int p0, int M, int w0, int N, int low_in, int up_in, int which)
+// ---- ALIGN (src/globalalign.c:333-401): per-position emission ----------------------------------
+
+struct Emit { int ia, jb; };     // cursors: read bases / reference bases of the aligned sub-strings consumed so far
+
+__device__ __forceinline__ void emit_rep1(BandLds& G, int which, const uint8_t* A1, const uint8_t* B1, int pos0, Emit& E, int lane)
 {
-    const uint8_t* Ab = rd + p0 - 1;          // Ab[i], i = 1..M
-    const uint8_t* Bb = G.wb - G.wb_base;     // Bb[j], j = 1..N (staged slice only)
-    const int Gp = kGapOpen, H = kGapExt, m = Gp + H;
-    int* CC = G.CC; int* DD = G.DD;
-    G.aln[which][0] = G.aln[which][1] = G.aln[which][2] = G.aln[which][3] = 0;
-    G.nops[which] = 0;
-    if (low_in > up_in || M <= 0 || N <= 0) return IM_ST_ABORT;
-    int low = max(-M, low_in), up = min(N, up_in);
+    // A1[i], B1[j]: 1-based sub-strings
+    if (lane == 0) G.kind[which][pos0 + E.ia] = A1[E.ia + 1] == B1[E.jb + 1] ? kPosEq : kPosX;
+    E.ia++; E.jb++;
+}
+__device__ __forceinline__ void emit_rep_run(BandLds& G, int which, const uint8_t* A1, const uint8_t* B1, int pos0, Emit& E, int n, int lane)
+{
+    for (int p = lane; p < n; p += 64) G.kind[which][pos0 + E.ia + p] = A1[E.ia + p + 1] == B1[E.jb + p + 1] ? kPosEq : kPosX;
+    E.ia += n; E.jb += n;
+}
+__device__ __forceinline__ void emit_del(BandLds& G, int which, int pos0, Emit& E, int n, int lane)     // read bases without a partner
+{
+    for (int p = lane; p < n; p += 64) G.kind[which][pos0 + E.ia + p] = kPosI;
+    E.ia += n;
+}
+__device__ __forceinline__ void emit_ins(BandLds& G, int which, int pos0, Emit& E, int n, int lane)     // reference bases skipped
+{
+    if (lane == 0) G.dlen[which][pos0 + E.ia] = (uint16_t)(G.dlen[which][pos0 + E.ia] + n);
+    E.jb += n;
+}
+
+// The forward pass of align() (src/globalalign.c:100-248) on A1[1..M], B1[1..N] with the band [low, up]: fills the
+// crossing records of the middle diagonal and returns the trace start (k, l) and the score.  lane = curd - 1.
+struct FwdOut { int k, l, v, rmid; };
+__device__ __forceinline__ FwdOut band_global_forward(BandLds& G, const uint8_t* A1, const uint8_t* B1, int M, int N, int low, int up,
+                                                      int tb, int te, int lane)
+{
+    const int g = kGapOpen, h = kGapExt, m = g + h;
     const int band = up - low + 1;
-    if (band < 1) return IM_ST_ABORT;
-    if (band > kGapMaxBand) return IM_ST_OVERFLOW;
-    int i, j, si, ei, c, d, e = 0, t, leftd, rightd, curd, ib;
-    int best = 0, starti = 0, startj = 0, endi, endj, flag = 0;
-    if (low > 0) leftd = 1; else if (up < 0) leftd = band; else leftd = 1 - low;
-    rightd = band;
-    si = max(0, -up); ei = min(M, N - low);
-    CC[leftd] = 0;
-    for (j = leftd + 1; j <= rightd; j++) { CC[j] = 0; DD[j] = -Gp; }
-    CC[rightd + 1] = kGapNegInf; DD[rightd + 1] = kGapNegInf;
-    endi = si; endj = si + low;
-    CC[leftd - 1] = kGapNegInf; DD[leftd] = -Gp;
-    for (i = si + 1; i <= ei; i++) {
+    const int midd = band / 2 + 1;
+    FwdOut o; o.rmid = low + midd - 1;
+    int leftd = 1 - low, rightd = up - low + 1;
+    const int curd = lane + 1;
+    // initialisation (112-146)
+    int CP, DP;
+    if (leftd < midd)      { CP = DP = curd < midd ? -1 : 0; if (lane == 0) G.mp[0] = 0u; }
+    else if (leftd > midd) { const int fr = leftd - midd; CP = DP = curd <= midd ? fr : -1; if (lane == 0) G.mp[fr] = 0u; }
+    else                   { CP = DP = 0; if (lane == 0) G.mp[0] = 0u; }
+    int CC = kGapNegInf, DD = kGapNegInf;
+    {
+        const int t0 = (tb == 2) ? 0 : -g;
+        if (curd == leftd) { CC = 0; DD = (tb == 1) ? 0 : -g; }
+        else if (curd > leftd && curd <= rightd) { CC = t0 - h * (curd - leftd); DD = CC - g; }
+    }
+    int c_fin = 0, d_fin = 0, e_fin = 0, ip_fin = 0;
+    for (int i = 1; i <= M; i++) {
         if (i > N - up) rightd--;
         if (leftd > 1) leftd--;
-        const uint8_t ai = Ab[i];
-        if ((c = CC[leftd + 1] - m) > (d = DD[leftd + 1] - H)) d = c;
-        if ((ib = leftd + low - 1 + i) > 0) c = CC[leftd] + gw(ai, Bb[ib]);
-        if (d > c) c = d;
-        if (c < 0) c = 0;
-        e = c - Gp;
-        DD[leftd] = d; CC[leftd] = c;
-        if (c > best) { best = c; endi = i; endj = ib; }
-        for (curd = leftd + 1; curd <= rightd; curd++) {
-            if ((c = c - m) > (e = e - H)) e = c;
-            if ((c = CC[curd + 1] - m) > (d = DD[curd + 1] - H)) d = c;
-            c = CC[curd] + gw(ai, Bb[curd + low - 1 + i]);
-            if (e > c) c = e;
-            if (d > c) c = d;
-            if (c < 0) c = 0;
-            CC[curd] = c; DD[curd] = d;
-            if (c > best) { best = c; endi = i; endj = curd + low - 1 + i; }
+        const uint32_t ai = A1[i];
+        const int ccn = wshl1(CC, kGapNegInf), ddn = wshl1(DD, kGapNegInf), cpn = wshl1(CP, -1), dpn = wshl1(DP, -1);
+        const int co = ccn - m, dx = ddn - h;
+        const bool opend = co > dx;
+        const int d = opend ? co : dx;
+        const int dpt = opend ? cpn : dpn;
+        const int jb = curd + low - 1 + i;
+        const bool active = curd >= leftd && curd <= rightd;
+        const uint32_t bch = (active && jb >= 1) ? B1[jb] : 256u;
+        const int diag = CC + gw(ai, bch);
+        const bool is_left = curd == leftd;
+        // the cell without its horizontal state: value x, pointer xp
+        int x, xp;
+        if (is_left) {
+            const int c0 = jb > 0 ? diag : co;
+            if (d > c0 || jb <= 0) { x = d; xp = dpt; } else { x = c0; xp = CP; }
+        } else if (diag < d) { x = d; xp = dpt; } else { x = diag; xp = CP; }
+        // horizontal chain: prefix maximum over the origins to the left
+        const int key = active ? ekey_pack(x, lane) : 0;
+        const int ex = wshr1(band <= 16 ? band_scan_max<true>(key) : band_scan_max<false>(key), 0);
+        const bool has_e = !is_left && ex != 0;
+        const int e = has_e ? (ex >> 6) - kKeyBias - h * lane - g : kGapNegInf;
+        const int origin = 63 - (ex & 63);
+        const int xpf = (curd == midd) ? i : xp;             // the middle cell hands on its own row as the crossing point
+        int ip = __builtin_amdgcn_ds_bpermute(origin << 2, xpf);
+        if (origin + 1 <= midd && curd > midd) ip = i;
+        // the cell (168-187)
+        int c = x, cp = xp;
+        if (!is_left) {
+            c = diag; cp = CP;
+            if (diag < d || diag < e) { if (e > d) { c = e; cp = ip; } else { c = d; cp = dpt; } }
+        }
+        int dpn_new = dpt;
+        if (curd == midd) {
+            if (!is_left && active) {
+                // the crossing records of row i (189-231)
+                const int mp1 = ip, mp2 = dpt;
+                int mp0, mt0;
+                if (diag < d || diag < e) { if (e > d) { mp0 = mp1; mt0 = 2; } else { mp0 = mp2; mt0 = 1; } }
+                else { mp0 = i - 1; mt0 = 0; }
+                const uint32_t copy1 = (c - g > e) ? 1u : 0u, copy2 = (c - g > d) ? 1u : 0u;
+                G.mp[i] = (uint32_t)(mp0 + 1) | ((uint32_t)mt0 << 9) | (copy1 << 11) | ((uint32_t)(mp1 + 1) << 12) | (copy2 << 21) | ((uint32_t)(mp2 + 1) << 22);
+            }
+            cp = i; dpn_new = i;
+        }
+        const int e_out = is_left ? c - g : e;
+        const int ip_out = (curd == midd) ? i : (is_left ? cp : ip);
+        if (active) { CC = c; DD = d; CP = cp; DP = dpn_new; }
+        if (i == M) {
+            const int last = rightd - 1;                        // lane of the row's last cell
+            c_fin = lane_get(c, last); d_fin = lane_get(d, last); e_fin = lane_get(e_out, last); ip_fin = lane_get(ip_out, last);
         }
     }
-    leftd = max(1, -endi - low + 1);
-    rightd = band - (up - (endj - endi));
-    CC[rightd] = 0;
-    t = -Gp;
-    for (j = rightd - 1; j >= leftd; j--) { CC[j] = t = t - H; DD[j] = t - Gp; }
-    for (j = rightd + 1; j <= band; ++j) CC[j] = kGapNegInf;
-    CC[leftd - 1] = DD[leftd - 1] = kGapNegInf;
-    DD[rightd] = -Gp;
-    for (i = endi; i >= 1; i--) {
+    const int last = rightd - 1;
+    // which state the trace starts in (233-248)
+    if (te == 1 && d_fin + g > c_fin)      { o.k = lane_get(DP, last); o.l = 2; }
+    else if (te == 2 && e_fin + g > c_fin) { o.k = ip_fin;             o.l = 1; }
+    else                                   { o.k = lane_get(CP, last); o.l = 0; }
+    if (o.rmid > N - M) o.l = 2;
+    else if (o.rmid < N - M) o.l = 1;
+    o.v = c_fin;
+    wave_lds_sync();
+    return o;
+}
+
+__device__ __forceinline__ void mp_fetch(const BandLds& G, int l, int r, int& k_out, int& l_out)
+{
+    const uint32_t w = G.mp[r];
+    const int mp0 = (int)(w & 511u) - 1, mt0 = (int)((w >> 9) & 3u);
+    if (l == 0) { k_out = mp0; l_out = mt0; }
+    else if (l == 1) { if ((w >> 11) & 1u) { k_out = mp0; l_out = mt0; } else { k_out = (int)((w >> 12) & 511u) - 1; l_out = 2; } }
+    else { if ((w >> 21) & 1u) { k_out = mp0; l_out = mt0; } else { k_out = (int)((w >> 22) & 511u) - 1; l_out = 1; } }
+}
+__device__ __forceinline__ void fp_fetch(const BandLds& G, int k, int& l_out, int& kt_out)
+{
+    const uint32_t w = G.fp[k];
+    l_out = (int)(w & 1023u) - 1; kt_out = (int)(w >> 10);
+}
+
+// ALIGN's divide and conquer (src/globalalign.c:66-307) on sub-strings A0[1..Ma], B0[1..Na]: frames instead of recursion
+__device__ int band_global_align(BandLds& G, int which, const uint8_t* A0, const uint8_t* B0, int Ma, int Na, int low, int up,
+                                 int pos0, int lane, int* score_out)
+{
+    enum { F_AO, F_BO, F_M, F_N, F_LOW, F_UP, F_TB, F_TE, F_PHASE, F_K, F_L, F_KT, F_RMID };
+    Emit E; E.ia = 0; E.jb = 0;
+    int sp = 0, top_score = 0, guard = 0; bool first = true;
+    auto push = [&](int ao, int bo, int M, int N, int lo, int u, int tb, int te) {
+        if (lane == 0) { int32_t* f = G.stk[sp]; f[F_AO] = ao; f[F_BO] = bo; f[F_M] = M; f[F_N] = N; f[F_LOW] = lo; f[F_UP] = u; f[F_TB] = tb; f[F_TE] = te; f[F_PHASE] = 0; }
+        sp++;
+    };
+    push(0, 0, Ma, Na, low, up, 0, 0);
+    wave_lds_sync();
+    while (sp > 0) {
+        if (sp > 9) { BFAIL(G, 2); return IM_ST_OVERFLOW; }
+        int32_t* f = G.stk[sp - 1];
+        const int ao = uni(f[F_AO]), bo = uni(f[F_BO]), M = uni(f[F_M]), N = uni(f[F_N]), lo = uni(f[F_LOW]), u = uni(f[F_UP]);
+        const int tb = uni(f[F_TB]), te = uni(f[F_TE]), phase = uni(f[F_PHASE]);
+        int k = uni(f[F_K]), l = uni(f[F_L]), kt = uni(f[F_KT]);
+        int rmid = uni(f[F_RMID]);
+        const uint8_t* A1 = A0 + ao; const uint8_t* B1 = B0 + bo;
+        int nphase = phase;
+        if (++guard > 4096) { BFAIL(G, 3); return IM_ST_ABORT; }               // every frame makes progress; this only bounds a corrupted walk
+        bool do_push = false; int c_ao = 0, c_bo = 0, c_M = 0, c_N = 0, c_lo = 0, c_u = 0, c_tb = 0, c_te = 0;
+        bool pop = false;
+        wave_lds_sync();
+        if (phase == 0) {
+            if (N <= 0) { if (M > 0) emit_del(G, which, pos0, E, M, lane); pop = true; if (first) { top_score = -1; first = false; } }
+            else if (M <= 0) { emit_ins(G, which, pos0, E, N, lane); pop = true; if (first) { top_score = -1; first = false; } }
+            else if (u - lo + 1 <= 1) { emit_rep_run(G, which, A0, B0, pos0, E, M, lane); pop = true; if (first) { top_score = -1; first = false; } }
+            else {
+                if (u - lo + 1 > kGapMaxBand) { BFAIL(G, 4); return IM_ST_OVERFLOW; }
+                const FwdOut fo = band_global_forward(G, A1, B1, M, N, lo, u, tb, te, lane);
+                if (first) { top_score = fo.v; first = false; }
+                // trace back through the crossing records, turning them into forward pointers (252-257)
+                int kk = fo.k, ll = fo.l, r = -1;
+                while (kk > -1) {
+                    if (kk > M) { BFAIL(G, 5); return IM_ST_ABORT; }
+                    if (lane == 0) G.fp[kk] = (uint16_t)((uint32_t)(r + 1) | ((uint32_t)ll << 10));
+                    const int rr = kk; int nk, nl;
+                    mp_fetch(G, ll, rr, nk, nl);
+                    if (nk >= rr) { BFAIL(G, 6); return IM_ST_ABORT; }           // crossing points strictly descend
+                    r = rr; kk = nk; ll = nl;
+                }
+                wave_lds_sync();
+                if (r == -1) {
+                    // the optimal alignment did not cross the middle diagonal: same strings, half the band (259-262)
+                    if (lane == 0) { if (fo.rmid < 0) f[F_LOW] = fo.rmid + 1; else f[F_UP] = fo.rmid - 1; }
+                } else {
+                    k = r; fp_fetch(G, k, l, kt);
+                    rmid = fo.rmid;
+                    if (lane == 0) f[F_RMID] = fo.rmid;
+                    // first block (268-275)
+                    if (fo.rmid < 0) { nphase = 1; do_push = true; c_ao = ao; c_bo = bo; c_M = r - 1; c_N = r + fo.rmid; c_lo = fo.rmid + 1; c_u = min(u, r + fo.rmid); c_tb = tb; c_te = 1; }
+                    else if (fo.rmid > 0) { nphase = 2; do_push = true; c_ao = ao; c_bo = bo; c_M = r; c_N = r + fo.rmid - 1; c_lo = max(-r, lo); c_u = fo.rmid - 1; c_tb = tb; c_te = 2; }
+                    else nphase = 3;
+                }
+            }
+        } else if (phase == 1) { emit_del(G, which, pos0, E, 1, lane); nphase = 3; }
+        else if (phase == 2) { emit_ins(G, which, pos0, E, 1, lane); nphase = 3; }
+        else if (phase == 4) { emit_del(G, which, pos0, E, 1, lane); k = l; fp_fetch(G, k, l, kt); nphase = 3; }
+        else if (phase == 5) { emit_ins(G, which, pos0, E, 1, lane); k = l; fp_fetch(G, k, l, kt); nphase = 3; }
+        else if (phase == 6) pop = true;
+        if (nphase == 3 && !do_push && !pop) {
+            const int t2 = u - rmid - 1, t3 = lo - rmid + 1;
+            // intermediate blocks (280-295): runs of diagonal crossings are walked here without touching the stack
+            while (l > -1 && kt == 0) { emit_rep1(G, which, A0, B0, pos0, E, lane); k = l; fp_fetch(G, k, l, kt); }
+            if (l > -1) {
+                const int t1 = l - k - 1;
+                if (kt == 1) { emit_ins(G, which, pos0, E, 1, lane); nphase = 4; do_push = true; c_ao = ao + k; c_bo = bo + k + rmid + 1; c_M = t1; c_N = t1; c_lo = 0; c_u = min(t1, t2); c_tb = 2; c_te = 1; }
+                else { emit_del(G, which, pos0, E, 1, lane); nphase = 5; do_push = true; c_ao = ao + k + 1; c_bo = bo + k + rmid; c_M = t1; c_N = t1; c_lo = max(-t1, t3); c_u = 0; c_tb = 1; c_te = 2; }
+            } else {
+                // last block (297-305)
+                if (N - M > rmid) { emit_ins(G, which, pos0, E, 1, lane); const int t1 = k + rmid + 1; nphase = 6; do_push = true; c_ao = ao + k; c_bo = bo + t1; c_M = M - k; c_N = N - t1; c_lo = 0; c_u = min(N - t1, t2); c_tb = 2; c_te = te; }
+                else if (N - M < rmid) { emit_del(G, which, pos0, E, 1, lane); const int t1 = M - (k + 1); nphase = 6; do_push = true; c_ao = ao + k + 1; c_bo = bo + k + rmid; c_M = t1; c_N = N - (k + rmid); c_lo = max(-t1, t3); c_u = 0; c_tb = 1; c_te = te; }
+                else pop = true;
+            }
+        }
+        if (lane == 0) { f[F_PHASE] = nphase; f[F_K] = k; f[F_L] = l; f[F_KT] = kt; }
+        if (pop) sp--;
+        if (do_push) push(c_ao, c_bo, c_M, c_N, c_lo, c_u, c_tb, c_te);
+        wave_lds_sync();
+    }
+    *score_out = top_score;
+    return 0;
+}
+
+// local_align's forward pass (src/localalign.c:88-133): best cell (first strict maximum in row-major order)
+__device__ __forceinline__ void band_local_forward(const uint8_t* A1, const uint8_t* B1, int M, int N, int low, int up, int lane,
+                                                   int& best, int& endi, int& endj)
+{
+    const int g = kGapOpen, h = kGapExt, m = g + h;
+    const int band = up - low + 1;
+    int leftd = low > 0 ? 1 : (up < 0 ? band : 1 - low), rightd = band;
+    const int si = max(0, -up), ei = min(M, N - low);
+    const int curd = lane + 1;
+    int CC = kGapNegInf, DD = kGapNegInf;
+    if (curd == leftd) { CC = 0; DD = -g; }
+    else if (curd > leftd && curd <= rightd) { CC = 0; DD = -g; }
+    best = 0; endi = si; endj = si + low;
+    for (int i = si + 1; i <= ei; i++) {
+        if (i > N - up) rightd--;
+        if (leftd > 1) leftd--;
+        const uint32_t ai = A1[i];
+        const int ccn = wshl1(CC, kGapNegInf), ddn = wshl1(DD, kGapNegInf);
+        const int co = ccn - m, dx = ddn - h;
+        const int d = co > dx ? co : dx;
+        const int jb = curd + low - 1 + i;
+        const bool active = curd >= leftd && curd <= rightd;
+        const uint32_t bch = (active && jb >= 1) ? B1[jb] : 256u;
+        const int diag = CC + gw(ai, bch);
+        const bool is_left = curd == leftd;
+        int x = is_left ? (jb > 0 ? diag : co) : diag;
+        if (d > x) x = d;
+        const int x0 = max(x, 0);                              // a cell clamped at 0 opens gaps from 0
+        const int key = active ? ekey_pack(x0, lane) : 0;
+        const int ex = wshr1(band <= 16 ? band_scan_max<true>(key) : band_scan_max<false>(key), 0);
+        const int e = (!is_left && ex != 0) ? (ex >> 6) - kKeyBias - h * lane - g : kGapNegInf;
+        int c = max(x0, e);
+        if (active) { CC = c; DD = d; }
+        // first strict maximum: the leftmost cell of the row that reaches the row's maximum, if that beats the best so far
+        const int cv = active ? c : -1;
+        const int rowmax = wave_max(cv);
+        if (rowmax > best) {
+            const int at = wave_min(cv == rowmax ? lane : 64);
+            best = rowmax; endi = i; endj = at + 1 + low - 1 + i;
+        }
+    }
+}
+
+// local_align's reverse pass (src/localalign.c:135-176) from the end cell: the first cell, rows upwards and diagonals
+// downwards, whose score equals best.  lane = band - curd (the row is walked from its right end).
+__device__ __forceinline__ bool band_local_reverse(const uint8_t* A1, const uint8_t* B1, int N, int low, int up, int lane,
+                                                   int best, int endi, int endj, int& starti, int& startj)
+{
+    const int g = kGapOpen, h = kGapExt, m = g + h;
+    const int band = up - low + 1;
+    int leftd = max(1, -endi - low + 1);
+    int rightd = band - (up - (endj - endi));
+    const int curd = band - lane;                              // lanes >= band: curd <= 0, never active
+    int CC = kGapNegInf, DD = kGapNegInf;
+    if (curd == rightd) { CC = 0; DD = -g; }
+    else if (curd < rightd && curd >= leftd) { CC = -g - h * (rightd - curd); DD = CC - g; }
+    for (int i = endi; i >= 1; i--) {
         if (i + low <= 0) leftd++;
         if (rightd < band) rightd++;
-        const uint8_t ai = Ab[i];
-        if ((c = CC[rightd - 1] - m) > (d = DD[rightd - 1] - H)) d = c;
-        if ((ib = rightd + low - 1 + i) <= N) c = CC[rightd] + gw(ai, Bb[ib]);
-        if (d > c) c = d;
-        e = c - Gp;
-        DD[rightd] = d; CC[rightd] = c;
-        if (c == best) { starti = i; startj = ib; flag = 1; break; }
-        for (curd = rightd - 1; curd >= leftd; curd--) {
-            if ((c = c - m) > (e = e - H)) e = c;
-            if ((c = CC[curd - 1] - m) > (d = DD[curd - 1] - H)) d = c;
-            c = CC[curd] + gw(ai, Bb[curd + low - 1 + i]);
-            if (e > c) c = e;
-            if (d > c) c = d;
-            CC[curd] = c; DD[curd] = d;
-            if (c == best) { starti = i; startj = curd + low - 1 + i; flag = 1; break; }
-        }
-        if (flag == 1) break;
+        const uint32_t ai = A1[i];
+        const int ccn = wshl1(CC, kGapNegInf), ddn = wshl1(DD, kGapNegInf);     // curd - 1 lives one lane up
+        const int co = ccn - m, dx = ddn - h;
+        const int d = co > dx ? co : dx;
+        const int jb = curd + low - 1 + i;
+        const bool active = curd >= leftd && curd <= rightd;
+        const bool is_right = curd == rightd;
+        const uint32_t bch = (active && jb >= 1 && jb <= N + 2) ? B1[jb] : 256u;
+        const int diag = CC + gw(ai, bch);
+        int x = is_right ? (jb <= N ? diag : co) : diag;
+        if (d > x) x = d;
+        const int key = active ? ekey_pack(x, lane) : 0;
+        const int ex = wshr1(band <= 16 ? band_scan_max<true>(key) : band_scan_max<false>(key), 0);
+        const int e = (!is_right && ex != 0) ? (ex >> 6) - kKeyBias - h * lane - g : kGapNegInf;
+        const int c = max(x, e);
+        if (active) { CC = c; DD = d; }
+        const int hit = wave_min((active && c == best) ? lane : 64);
+        if (hit < 64) { starti = i; startj = (band - hit) + low - 1 + i; return true; }
     }
-    if (starti < 0 || starti > M || startj < 0 || startj > N) return 0;
-    if ((endi - starti) == 0 || (endj - startj) == 0) return 0;
+    return false;
+}
 
-    // ALIGN (src/globalalign.c:333-401) on the located sub-strings
+// fetch_cigar (src/globalalign.c:507-604) from the per-position form: [AP S] runs of = / X / I with the D ops in front of
+// the positions that carry one, [tail S].  The tail clip keeps the reference's arithmetic (deletion lengths are counted
+// into the consumed total, 541-595).  Returns 0 or IM_ST_OVERFLOW; ops land in G.ops[which].
+__device__ __forceinline__ int band_make_cigar(BandLds& G, int which, int M, int starti, int endi, int lane)
+{
+    const int Ma = endi - starti + 1, pos0 = starti - 1;
+    const uint8_t* kind = G.kind[which] + pos0;
+    const uint16_t* dl = G.dlen[which] + pos0;
+    // ops in front of / at position p: a D if dl[p] > 0, then a new run if the class changes (or a D sat in between)
+    int nb = 0, dsum = 0;
+    int cnt[4], isb[4], isd[4];
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        const int p = 4 * lane + j;
+        isd[j] = (p <= Ma) && dl[p] > 0;                        // p == Ma: a D behind the last base
+        isb[j] = (p < Ma) && (p == 0 || kind[p] != kind[p - 1] || isd[j]);
+        cnt[j] = isd[j] + isb[j];
+        nb += cnt[j];
+        if (isd[j]) dsum += dl[p];
+    }
+    const int inb = wave_scan_add(nb, lane);
+    const int total = lane_get(inb, 63);
+    const int dtot = wave_sum(dsum);
+    const int lead = pos0 > 0 ? 1 : 0;
+    const int numtotal = pos0 + Ma + dtot;
+    const int tail = numtotal < M ? 1 : 0;
+    const int n = lead + total + tail;
+    if (n > IM_MAX_OPS) { BFAIL(G, 7); return IM_ST_OVERFLOW; }
+    uint32_t* ops = G.ops[which];
+    // run starts, in order, so that a run's length is the distance to the next start
+    int32_t* bpos = G.tmp;
+    {
+        int r = 0;
+        // rank among run starts only
+        int nbs = isb[0] + isb[1] + isb[2] + isb[3];
+        const int ib = wave_scan_add(nbs, lane);
+        r = ib - nbs;
+#pragma unroll
+        for (int j = 0; j < 4; j++) if (isb[j]) bpos[r++] = 4 * lane + j;
+        if (lane == 63) bpos[ib] = Ma;
+    }
+    wave_lds_sync();
+    {
+        int slot = lead + inb - nb, r;
+        int nbs = isb[0] + isb[1] + isb[2] + isb[3];
+        r = wave_scan_add(nbs, lane) - nbs;
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const int p = 4 * lane + j;
+            if (isd[j]) ops[slot++] = ((uint32_t)dl[p] << 4) | IM_OP_D;
+            if (isb[j]) {
+                const uint32_t op = kind[p] == kPosEq ? IM_OP_EQ : kind[p] == kPosX ? IM_OP_X : IM_OP_I;
+                ops[slot++] = ((uint32_t)(bpos[r + 1] - p) << 4) | op;
+                r++;
+            }
+        }
+    }
+    if (lane == 0) {
+        if (lead) ops[0] = ((uint32_t)pos0 << 4) | IM_OP_S;
+        if (tail) ops[n - 1] = ((uint32_t)(M - numtotal) << 4) | IM_OP_S;
+        G.nops[which] = n;
+    }
+    wave_lds_sync();
+    return 0;
+}
+
+// attempt_band_alignment = local_align + ALIGN + fetch_cigar (src/alignment.c:343-391) across the wave.
+// Window = contig[w0, w0 + N), read piece = rd[p0, p0 + M).
+__device__ BandAln band_alignment(BandLds& G, const uint8_t* contig, const uint8_t* rd, int p0, int M, int w0, int N,
+                                  int low_in, int up_in, int which, int lane)
+{
+    BandAln a; a.st = 0; a.r1 = a.r2 = a.q1 = a.q2 = 0;
+    if (lane == 0) { G.nops[which] = 0; G.aln[which][0] = G.aln[which][1] = G.aln[which][2] = G.aln[which][3] = 0; }
+    if (low_in > up_in || M <= 0 || N <= 0) { BFAIL(G, 101); a.st = IM_ST_ABORT; return a; }
+    const int low = max(-M, low_in), up = min(N, up_in);
+    const int band = up - low + 1;
+    if (band < 1) { BFAIL(G, 102); a.st = IM_ST_ABORT; return a; }
+    if (band > kGapMaxBand) { a.st = IM_ST_OVERFLOW; return a; }
+    a.st = band_stage_window(G, contig, w0, N, M, low_in, up_in, lane);
+    if (a.st) return a;
+    const uint8_t* A1 = rd + p0 - 1;                            // A1[i], i = 1..M
+    const uint8_t* B1 = G.wb - G.wb_base;                       // B1[j], staged slice
+    int best, endi, endj, starti = 0, startj = 0;
+    band_local_forward(A1, B1, M, N, low, up, lane, best, endi, endj);
+    if (!band_local_reverse(A1, B1, N, low, up, lane, best, endi, endj, starti, startj)) return a;   // starti = startj = 0: rejected below in the reference too
+    if (starti < 0 || starti > M || startj < 0 || startj > N) return a;
+    if (endi - starti == 0 || endj - startj == 0) return a;
+    // ALIGN on the located sub-strings (src/globalalign.c:333-401)
     const int Ma = endi - starti + 1, Na = endj - startj + 1;
     int lo2 = low - (startj - starti), up2 = up - (startj - starti);
     lo2 = min(max(-Ma, lo2), min(Na - Ma, 0));
     up2 = max(min(Na, up2), max(Na - Ma, 0));
-    G.sapp = 0; G.last = 0;
-    const int ao = p0 - 1 + starti - 1;       // A'[i] = rd[ao + i]
-    const int bo = startj - 1;                // B'[j] = Bb[bo + j]
+    const uint8_t* A0 = A1 + starti - 1;                        // A0[i] = A1[starti - 1 + i]
+    const uint8_t* B0 = B1 + startj - 1;
+    const int pos0 = starti - 1;
+    for (int p = lane; p <= M; p += 64) { if (p < M) G.kind[which][p] = kPosNone; G.dlen[which][p] = 0; }
+    wave_lds_sync();
     int score;
     if (up2 - lo2 + 1 <= 1) {
-        score = 0;
-        for (i = 1; i <= Ma; i++) { gs_rep(G); score += gw(rd[ao + i], Bb[bo + i]); }
+        int s = 0;
+        for (int p = lane; p < Ma; p += 64) {
+            const bool eq = A0[p + 1] == B0[p + 1];
+            G.kind[which][pos0 + p] = eq ? kPosEq : kPosX;
+            s += eq ? kScoreMatch : kScoreMismatch;
+        }
+        score = wave_sum(s);
+        wave_lds_sync();
     } else {
-        if (up2 - lo2 + 1 > kGapMaxBand) return IM_ST_OVERFLOW;
-        score = gap_align_rec(G, rd, ao, bo + G.wb_base - G.wb_base, Ma, Na, lo2, up2, 0, 0);
+        const int st = band_global_align(G, which, A0, B0, Ma, Na, lo2, up2, pos0, lane, &score);
+        if (st) { a.st = st; return a; }
         // (a CHECK_SCORE mismatch makes the reference print a line and carry on; nothing to do here)
     }
-    if (score <= 0) return 0;
-
-    // fetch_cigar (src/globalalign.c:507-604); deletion runs are added to the consumed-read total
-    // as well (541-595), kept
-    uint32_t* ops = G.ops[which];
-    int n = 0, mm = 0;
-    int AP = starti - 1;
-    if (AP > 0 && !gap_push(ops, n, IM_OP_S, AP)) return IM_ST_OVERFLOW;
-    int run = -1, numrun = 0, numtotal = AP, op = 0, sp = 0;
-    i = 0; j = 0;
-    while (i < Ma || j < Na) {
-        int kind;
-        if (op == 0 && G.S[sp] == 0) { op = G.S[sp++]; i++; j++; if (rd[ao + i] == Bb[bo + j]) kind = 0; else { kind = 4; mm++; } }
-        else {
-            if (op == 0) op = G.S[sp++];
-            if (op > 0) { op--; j++; kind = 1; }
-            else        { op++; i++; kind = 2; }
-        }
-        if (run != -1 && run != kind) {
-            const int bop = run == 0 ? IM_OP_EQ : run == 1 ? IM_OP_D : run == 2 ? IM_OP_I : IM_OP_X;
-            if (!gap_push(ops, n, bop, numrun)) return IM_ST_OVERFLOW;
-            numtotal += numrun; run = kind; numrun = 1;
-        } else { run = kind; numrun += 1; }
-    }
-    if (run != -1 && numrun > 0) {
-        const int bop = run == 0 ? IM_OP_EQ : run == 1 ? IM_OP_D : run == 2 ? IM_OP_I : IM_OP_X;
-        if (!gap_push(ops, n, bop, numrun)) return IM_ST_OVERFLOW;
-        numtotal += numrun;
-    }
-    if (numtotal < M && !gap_push(ops, n, IM_OP_S, M - numtotal)) return IM_ST_OVERFLOW;
-    (void)mm;
-    G.nops[which] = n;
-    G.aln[which][0] = startj + w0 - 1;     // r1
-    G.aln[which][1] = endj + w0;           // r2
-    G.aln[which][2] = starti + p0 - 1;     // q1
-    G.aln[which][3] = endi + p0;           // q2
-    return 0;
+    if (score <= 0) return a;
+    a.st = band_make_cigar(G, which, M, starti, endi, lane);
+    if (a.st) return a;
+    a.r1 = startj + w0 - 1; a.r2 = endj + w0; a.q1 = starti + p0 - 1; a.q2 = endi + p0;
+    if (lane == 0) { G.aln[which][0] = a.r1; G.aln[which][1] = a.r2; G.aln[which][2] = a.q1; G.aln[which][3] = a.q2; }
+    return a;
 }
 
-// count_matches / find_best_del_candidate on CIGARs (src/alignment.c:219-339)
-__device__ int gap_split_score(const uint32_t* c1, int n1, int q2, const uint32_t* c2, int n2, int q4, int* pmm)
+// count_matches (src/alignment.c:219-303) for one candidate split i: '=' and 'X' bases of piece 1 over read[0, i)
+// plus piece 2 over read[i, q4).  Every lane runs it for its own candidate; the op words come from LDS.
+__device__ __forceinline__ int band_split_score(const uint32_t* c1, int n1, int q2, const uint32_t* c2, int n2, int q4, int* pmm)
 {
     const int q3 = q2;
     int i, j, matches = 0, mm = 0;
@@ -1277,116 +1475,134 @@ __device__ int gap_split_score(const uint32_t* c1, int n1, int q2, const uint32_
     return matches;
 }
 
-__device__ int gap_best_split(int q1, int q2, const uint32_t* c1, int n1, int q3, int q4, const uint32_t* c2, int n2, int L, int* pindex)
+// find_best_del_candidate (src/alignment.c:306-339): lane = candidate split (i = q3 + lane, + 64, ...); most matches,
+// then fewest mismatches, then the first; candidates behind the first perfect one are never looked at by the reference
+__device__ __forceinline__ int band_best_split(BandLds& G, int q1, int q2, const uint32_t* c1, int n1, int q3, int q4, const uint32_t* c2, int n2,
+                                               int L, int lane, int* pindex)
 {
-    if (q1 != 0 || q3 > q2) return IM_ST_ABORT;
-    int bestm = 0, bestmm = INT_MAX, index = -1;
-    for (int i = q3; i <= q2; i++) {
+    if (q1 != 0 || q3 > q2) { BFAIL(G, 8); return IM_ST_ABORT; }
+    int bm = -1, bmm = INT_MAX, bi = INT_MAX, perfect = INT_MAX, over = INT_MAX;
+    for (int i = q3 + lane; i <= q2; i += 64) {
         int mm;
-        const int matches = gap_split_score(c1, n1, i, c2, n2, q4, &mm);
-        if (matches > L) return IM_ST_ABORT;
-        if (matches > bestm || (matches == bestm && mm < bestmm)) { bestm = matches; bestmm = mm; index = i; }
-        if (matches == L && mm == 0) break;
+        const int matches = band_split_score(c1, n1, i, c2, n2, q4, &mm);
+        if (matches > L) over = min(over, i);
+        if (matches == L && mm == 0) perfect = min(perfect, i);
+        if (matches > bm || (matches == bm && mm < bmm)) { bm = matches; bmm = mm; bi = i; }      // ascending i per lane: first wins
     }
-    if (index == -1) return IM_ST_ABORT;
-    *pindex = index;
+    perfect = wave_min(perfect);
+    over = wave_min(over);
+    if (over != INT_MAX && over <= perfect) { BFAIL(G, 9); return IM_ST_ABORT; }                     // forceassert(matches <= readlength)
+    if (perfect != INT_MAX) { *pindex = perfect; return 0; }     // nothing in front of it can be better, nothing behind it is seen
+    const int M = wave_max(bm);
+    const int MM = wave_min(bm == M ? bmm : INT_MAX);
+    const int idx = wave_min((bm == M && bmm == MM) ? bi : INT_MAX);
+    if (idx == INT_MAX) { BFAIL(G, 10); return IM_ST_ABORT; }
+    *pindex = idx;
     return 0;
 }
 
-// update_readsegs (src/readaln.c:348-458) + new_evidence per D/I segment, written straight into
-// the result record by lane 0
-__device__ int gap_build_result(im_read_result* out, int r1, const uint32_t* c1, int n1, int index, int q2, int r2,
-                                const uint32_t* c2, int n2)
+// update_readsegs (src/readaln.c:348-458) + one evidence per D / I segment (new_evidence, src/evidence.c:4-34, with the flank
+// reductions of src/variant.c:217-290,704-775): lane = CIGAR op.  c1 / c2 live in LDS, the result goes to the record.
+__device__ int band_build_result(im_read_result* out, BandLds& G, int r1, const uint32_t* c1, int n1, int index, int q2, int r2,
+                                 const uint32_t* c2, int n2, int lane, const RealignArgs& A, int cidx)
 {
-    uint32_t* ops = out->ops;
-    int n = 0, refindx = r1, i, j;
-#define GEMIT(len, op) do { if (!gap_push(ops, n, (op), (len))) return IM_ST_OVERFLOW; \
-                            if ((op) == IM_OP_EQ || (op) == IM_OP_X || (op) == IM_OP_D || (op) == IM_OP_M) refindx += (len); } while (0)
-    for (i = 0, j = 0; i < n1; i++) {
-        const int op = (int)(c1[i] & 15u), len = (int)(c1[i] >> 4);
-        if (len <= 0) return IM_ST_ABORT;
-        if (op != IM_OP_D) j += len;
-        if (j <= index) GEMIT(len, op);
-        if (j > index) { const int part = index - (j - len); if (part > 0) GEMIT(part, op); break; }
-    }
-    int rindex = r2, nextindex = index;
+    // --- piece 1 up to read offset `index` (362-385)
+    const bool h1 = lane < n1;
+    const int op1 = h1 ? (int)(c1[lane] & 15u) : 0, len1 = h1 ? (int)(c1[lane] >> 4) : 0;
+    if (wave_max((h1 && len1 <= 0) ? 1 : 0)) { BFAIL(G, 11); return IM_ST_ABORT; }            // forceassert(oplen > 0)
+    const int J1 = wave_scan_add((h1 && op1 != IM_OP_D) ? len1 : 0, lane);
+    const int tstop = wave_min((h1 && J1 > index) ? lane : 64);             // first op that runs past index: cut there
+    int e1 = 0;                                                             // emitted length of this lane's op
+    if (h1 && lane < tstop) e1 = len1;
+    else if (h1 && lane == tstop) { const int part = index - (J1 - len1); e1 = part > 0 ? part : 0; }
+    const bool refc1 = op1 == IM_OP_EQ || op1 == IM_OP_X || op1 == IM_OP_D || op1 == IM_OP_M;
+    const int refindx = r1 + wave_sum(refc1 ? e1 : 0);
+    const int nA = wave_sum(e1 > 0 ? 1 : 0);
+    // --- where piece 2 takes over (389-421)
+    const bool h2 = lane < n2;
+    const int op2 = h2 ? (int)(c2[lane] & 15u) : 0, len2 = h2 ? (int)(c2[lane] >> 4) : 0;
+    const int J2 = wave_scan_add((h2 && op2 != IM_OP_D) ? len2 : 0, lane);
+    int rindex = r2, nextindex = index, ilen = 0;
     if (index >= q2) {
-        int offset = 0;
-        for (i = 0, j = 0; i < n2; i++) {
-            const int op = (int)(c2[i] & 15u), len = (int)(c2[i] >> 4);
-            if (op != IM_OP_D) j += len;
-            if (j <= q2) { }
-            else if (j > q2 && j <= index) { if (op != IM_OP_I) { offset += len; if ((j - len) <= q2) offset -= q2 - (j - len); } }
-            else if (j > index) { if (op != IM_OP_I) { if ((j - len) <= index) offset += index - (j - len); } }
+        int off = 0;
+        if (h2 && op2 != IM_OP_I) {
+            if (J2 > q2 && J2 <= index) { off = len2; if (J2 - len2 <= q2) off -= q2 - (J2 - len2); }
+            else if (J2 > index) { if (J2 - len2 <= index) off = index - (J2 - len2); }
         }
-        rindex = r2 + offset;
-    } else {
-        GEMIT(q2 - index, IM_OP_I);
-        nextindex += q2 - index;
-    }
-    if (refindx < rindex) GEMIT(rindex - refindx, IM_OP_D);
-    for (i = 0, j = 0; i < n2; i++) {
-        const int op = (int)(c2[i] & 15u), len = (int)(c2[i] >> 4);
-        if (op != IM_OP_D) j += len;
-        if (j > nextindex) { GEMIT(j - nextindex, op); i++; break; }
-    }
-    for (; i < n2; i++) GEMIT((int)(c2[i] >> 4), (int)(c2[i] & 15u));
-#undef GEMIT
-    out->ref_start = r1;
-    out->n_ops = n;
-    // evidence: one per D / I segment with its flank reductions (src/variant.c:217-290,704-775)
-    int ne = 0, refpos = r1, readpos = 0;
-    for (int sg = 0; sg < n; sg++) {
-        const int op = (int)(ops[sg] & 15u), len = (int)(ops[sg] >> 4);
-        if (op == IM_OP_D || op == IM_OP_I) {
-            if (ne >= IM_MAX_EV) return IM_ST_OVERFLOW;
-            im_evidence* e = &out->ev[ne++];
-            e->cls = (op == IM_OP_D) ? IM_CLS_DELETION : IM_CLS_INSERTION;
-            e->b1 = refpos; e->b2 = (op == IM_OP_D) ? refpos + len : refpos;
-            e->seg = sg; e->read_off = readpos;
-            int lf = 0, rf = 0, ndp = 0, ndf = 0;
-            for (int t = 0; t < n; t++) {
-                if (t == sg) continue;
-                const int o = (int)(ops[t] & 15u), ln = (int)(ops[t] >> 4);
-                int& fl = (t < sg) ? lf : rf;
-                if (o == IM_OP_EQ) fl += ln;
-                else if (o == IM_OP_X || o == IM_OP_I) { fl += ln; ndp += ln; ndf += ln; }
-                else if (o == IM_OP_D) { ndp += ln; ndf += ln; }
-                else if (o == IM_OP_S) ndf += ln;
-            }
-            e->lflank = lf; e->rflank = rf; e->nd_print = ndp; e->nd_filter = ndf;
+        rindex = r2 + wave_sum(off);
+    } else { ilen = q2 - index; nextindex = q2; }
+    const int dlen = refindx < rindex ? rindex - refindx : 0;
+    // --- piece 2 from read offset nextindex (432-453)
+    const int tgo = wave_min((h2 && J2 > nextindex) ? lane : 64);
+    int e2 = 0;
+    if (h2 && lane == tgo) e2 = J2 - nextindex;
+    else if (h2 && lane > tgo) e2 = len2;
+    const int nB = wave_sum(e2 > 0 || (h2 && lane > tgo) ? 1 : 0);
+    const int n = nA + (ilen > 0 ? 1 : 0) + (dlen > 0 ? 1 : 0) + nB;
+    if (n > IM_MAX_OPS) { BFAIL(G, 12); return IM_ST_OVERFLOW; }
+    // --- assemble the final list in LDS (G.tmp), then one lane per final op
+    uint32_t* fin = reinterpret_cast<uint32_t*>(G.tmp);
+    {
+        const int ra = wave_scan_add(e1 > 0 ? 1 : 0, lane) - (e1 > 0 ? 1 : 0);
+        if (e1 > 0) fin[ra] = ((uint32_t)e1 << 4) | (uint32_t)op1;
+        int at = nA;
+        if (lane == 0) {
+            if (ilen > 0) fin[at++] = ((uint32_t)ilen << 4) | IM_OP_I;
+            if (dlen > 0) fin[at++] = ((uint32_t)dlen << 4) | IM_OP_D;
         }
-        if (op == IM_OP_EQ || op == IM_OP_X || op == IM_OP_D) refpos += len;
-        if (op != IM_OP_D) readpos += len;
+        at = nA + (ilen > 0 ? 1 : 0) + (dlen > 0 ? 1 : 0);
+        const bool emitB = h2 && lane >= tgo && tgo < 64;
+        const int rb = wave_scan_add(emitB ? 1 : 0, lane) - (emitB ? 1 : 0);
+        if (emitB) fin[at + rb] = ((uint32_t)e2 << 4) | (uint32_t)op2;
     }
-    out->n_ev = ne;
+    wave_lds_sync();
+    const bool hf = lane < n;
+    const uint32_t w = hf ? fin[lane] : 0u;
+    const int op = (int)(w & 15u), len = (int)(w >> 4);
+    if (hf) out->ops[lane] = w;
+    const bool refc = hf && (op == IM_OP_EQ || op == IM_OP_X || op == IM_OP_D);
+    const int refpos = r1 + wave_scan_add(refc ? len : 0, lane) - (refc ? len : 0);
+    const int readpos = wave_scan_add((hf && op != IM_OP_D) ? len : 0, lane) - ((hf && op != IM_OP_D) ? len : 0);
+    const int fl = hf && (op == IM_OP_EQ || op == IM_OP_X || op == IM_OP_I) ? len : 0;
+    const int ndp = hf && (op == IM_OP_X || op == IM_OP_I || op == IM_OP_D) ? len : 0;
+    const int ndf = ndp + ((hf && op == IM_OP_S) ? len : 0);
+    const int fl_in = wave_scan_add(fl, lane), fl_tot = lane_get(fl_in, 63);
+    const int ndp_tot = wave_sum(ndp), ndf_tot = wave_sum(ndf);
+    const bool indel = hf && (op == IM_OP_D || op == IM_OP_I);
+    const int erank = wave_scan_add(indel ? 1 : 0, lane) - (indel ? 1 : 0);
+    const int ne = wave_sum(indel ? 1 : 0);
+    if (ne > IM_MAX_EV) { BFAIL(G, 13); return IM_ST_OVERFLOW; }
+    if (indel) {
+        im_evidence* e = &out->ev[erank];
+        e->cls = op == IM_OP_D ? IM_CLS_DELETION : IM_CLS_INSERTION;
+        e->b1 = refpos; e->b2 = op == IM_OP_D ? refpos + len : refpos;
+        e->seg = lane; e->read_off = readpos;
+        e->lflank = fl_in - fl; e->rflank = fl_tot - fl_in;
+        e->nd_print = ndp_tot - ndp; e->nd_filter = ndf_tot - ndf;
+        if (A.batch.ev_cls) {
+            const int64_t sl = (int64_t)cidx * IM_MAX_EV + erank;
+            A.batch.ev_cls[sl] = e->cls; A.batch.ev_b1[sl] = e->b1; A.batch.ev_b2[sl] = e->b2;
+        }
+    }
+    if (ne > 0 && A.batch.ev_cls && lane < IM_MAX_EV && lane >= ne) {
+        const int64_t sl = (int64_t)cidx * IM_MAX_EV + lane;
+        A.batch.ev_cls[sl] = -1; A.batch.ev_b1[sl] = 0; A.batch.ev_b2[sl] = 0;
+    }
+    if (lane == 0) { out->ref_start = r1; out->n_ops = n; out->n_ev = ne; }
     return ne > 0 ? IM_ST_EVIDENCE : IM_ST_NONE;
 }
 
-// stage the slice of the window a band alignment can touch: B indices [jlo, jhi] (1-based)
-__device__ __forceinline__ int gap_stage_window(GapLds& G, const uint8_t* contig, int w0, int N, int M, int low, int up, int lane)
-{
-    const int lo = max(-M, low), hi = min(N, up);
-    int jlo = max(1, lo + 1) - 2, jhi = min(N, M + hi) + 2;         // generous by two on each side
-    if (jlo < 0) jlo = 0;
-    if (jhi - jlo + 1 > (int)sizeof(G.wb)) return IM_ST_OVERFLOW;
-    for (int t = lane; t <= jhi - jlo; t += 64) {
-        const int j = jlo + t;                                       // B[j] = contig[w0 + j - 1]
-        G.wb[t] = (j >= 1 && j <= N) ? contig[(int64_t)w0 + j - 1] : 0;
-    }
-    if (lane == 0) G.wb_base = jlo;
-    wave_lds_sync();
-    return 0;
-}
-
 template <bool DIRECT>
-__global__ __launch_bounds__(64) void realign_gapped_kernel(RealignArgs A)
+__global__ __launch_bounds__(64, 4) void realign_band_kernel(RealignArgs A)
 {
+    // The band alignment's state lives where the vote's histogram and k-mer table are (both dead between two band
+    // searches; band_search<0, ..> rebuilds them from scratch): 6.4 KB of LDS per wave instead of 12, twice the waves per CU.
     __shared__ WaveLds s;
-    __shared__ GapLds G;
+    static_assert(sizeof(BandLds) <= sizeof(s.diag) + sizeof(s.tbl), "BandLds must fit over the vote's histogram + table");
+    static_assert(offsetof(WaveLds, tbl) == sizeof(s.diag), "diag and tbl are contiguous");
+    BandLds& G = *reinterpret_cast<BandLds*>(s.diag);
     const int lane = threadIdx.x;
     const uint32_t k = A.P.klength, g = A.P.numgaps, eth = A.P.ethreshold;
-    IM_STAMP_DECL
     const int n_reads = A.n_dev ? min(*A.n_dev, A.batch.n) : A.batch.n;
     for (int c = blockIdx.x; c < n_reads; c += gridDim.x) {
         im_read_result* out = &A.batch.out[c];
@@ -1426,49 +1642,36 @@ __global__ __launch_bounds__(64) void realign_gapped_kernel(RealignArgs A)
         if (!(anchor >= left1 && anchor >= left2 && anchor <= right1 && anchor <= right2 && left2 >= 0 && right2 > 0)) {
             finish(out, IM_ST_ABORT, 0, lane); continue;
         }
-        // piece 1
+        // piece 1: the whole read in [left1, right1)
         const Band b1 = band_search<0, DIRECT>(s, pk, contig, (uint32_t)left1, (uint32_t)right1, (uint32_t)anchor, 0u, (uint32_t)L, k, g, lane, 0u IM_STAMP_PASS(16));
         if (b1.st) { finish(out, b1.st, 1, lane); continue; }
         const int up1 = ((uint32_t)L < k) ? b1.low : b1.low + (int)g;      // read shorter than k: low == up (408-412)
-        int st = gap_stage_window(G, contig, left1, right1 - left1, L, b1.low, up1, lane);
-        if (st == 0 && lane == 0) G.status = gap_band_alignment(G, rd, 0, L, left1, right1 - left1, b1.low, up1, 0);
-        wave_lds_sync();
-        if (st == 0) st = G.status;
-        const int r1 = G.aln[0][0], r2 = G.aln[0][1], q1 = G.aln[0][2], q2 = G.aln[0][3];
+        const BandAln a1 = band_alignment(G, contig, rd, 0, L, left1, right1 - left1, b1.low, up1, 0, lane);
+        const int r1 = a1.r1, r2 = a1.r2, q1 = a1.q1, q2 = a1.q2;
         if (lane == 0) {
             im_band_aln* o = &out->band[0];
             o->r1 = r1; o->r2 = r2; o->q1 = q1; o->q2 = q2; o->low = b1.low; o->votes = b1.votes; o->win_bytes = b1.win; o->piece_bytes = b1.piece;
         }
-        if (st) { finish(out, st, 1, lane); continue; }
+        if (a1.st) { if (lane == 0) out->reserved[6] = G.tmp[IM_MAX_OPS + 7]; finish(out, a1.st, 1, lane); continue; }
         if (q1 == q2) { finish(out, IM_ST_NONE, 1, lane); continue; }
+        wave_lds_sync();
+        const uint32_t* c1 = G.ops[0]; const int n1 = uni(G.nops[0]);
         if (q1 == 0 && q2 == L) {       // whole read aligned: evidence only from I/D ops inside the CIGAR (575-582)
-            if (lane == 0) {
-                const int rs = gap_build_result(out, r1, G.ops[0], G.nops[0], L, 0, -1, G.ops[0], 0);
-                G.status = rs;
-            }
-            wave_lds_sync();
-            const int rs = G.status;
+            const int rs = band_build_result(out, G, r1, c1, n1, L, 0, -1, c1, 0, lane, A, c);
             finish(out, rs, 1, lane);
-            if (rs == IM_ST_EVIDENCE && lane == 0 && A.batch.ev_cls)
-                for (int e = 0; e < IM_MAX_EV; e++) {
-                    const int64_t sl = (int64_t)c * IM_MAX_EV + e;
-                    const bool live = e < out->n_ev;
-                    A.batch.ev_cls[sl] = live ? out->ev[e].cls : -1; A.batch.ev_b1[sl] = live ? out->ev[e].b1 : 0; A.batch.ev_b2[sl] = live ? out->ev[e].b2 : 0;
-                }
             continue;
         }
-        // leading / trailing '=' runs of the first CIGAR (585-599)
+        // leading / trailing '=' runs of the first CIGAR (585-599): runs are maximal, so it is the first / last op behind a clip
         uint32_t f = 0, l = 0;
         {
-            const uint32_t* c1 = G.ops[0]; const int n1 = G.nops[0];
-            int i, j;
-            for (i = 0, j = 0; i < n1; i++) { const int op = (int)(c1[i] & 15u); if (i == 0 && op == IM_OP_S) continue; if (op != IM_OP_EQ) break; j += (int)(c1[i] >> 4); }
-            f = (uint32_t)j;
-            for (i = n1 - 1, j = 0; i >= 0; i--) { const int op = (int)(c1[i] & 15u); if (i == n1 - 1 && op == IM_OP_S) continue; if (op != IM_OP_EQ) break; j += (int)(c1[i] >> 4); }
-            l = (uint32_t)j;
+            const int i0 = (n1 > 0 && (c1[0] & 15u) == IM_OP_S) ? 1 : 0;
+            if (i0 < n1 && (c1[i0] & 15u) == IM_OP_EQ) f = c1[i0] >> 4;
+            const int i1 = (n1 > 0 && (c1[n1 - 1] & 15u) == IM_OP_S) ? n1 - 2 : n1 - 1;
+            if (i1 >= 0 && (c1[i1] & 15u) == IM_OP_EQ) l = c1[i1] >> 4;
+            f = (uint32_t)uni((int)f); l = (uint32_t)uni((int)l);
         }
         const uint32_t uL = (uint32_t)L;
-        uint32_t w0, w1, anc, p0, p1; bool want_tail; int none = 0, abortc = 0;
+        uint32_t w0 = 0, w1 = 0, anc = 0, p0 = 0, p1 = 0; bool want_tail = false; int none = 0, abortc = 0;
         if (r1 > anchor) {
             if (q1 == 0) {
                 if (!(uL > f)) abortc = 1;
@@ -1477,10 +1680,10 @@ __global__ __launch_bounds__(64) void realign_gapped_kernel(RealignArgs A)
             } else if (q2 == L) {
                 if (!(uL > l)) abortc = 1;
                 else if ((uL - l) < eth || ((uint32_t)r2 - l - (uint32_t)anchor) < eth) none = 1;
-                w0 = (uint32_t)anchor; w1 = (uint32_t)r2 - l; anc = (uint32_t)r2; p0 = 0; p1 = uL - l; want_tail = false;
-            } else { none = 1; w0 = w1 = anc = p0 = p1 = 0; want_tail = false; }
+                w0 = (uint32_t)anchor; w1 = (uint32_t)r2 - l; anc = (uint32_t)r2; p0 = 0; p1 = uL - l;
+            } else none = 1;
         } else if (r1 < anchor) {
-            if (r2 >= anchor) { none = 1; w0 = w1 = anc = p0 = p1 = 0; want_tail = false; }
+            if (r2 >= anchor) none = 1;
             else if (q1 == 0) {
                 if (!(uL > f)) abortc = 1;
                 else if ((uL - f) < eth || ((uint32_t)anchor - (uint32_t)r1 - f) < eth) none = 1;
@@ -1488,9 +1691,9 @@ __global__ __launch_bounds__(64) void realign_gapped_kernel(RealignArgs A)
             } else if (q2 == L) {
                 if (!(uL > l)) abortc = 1;
                 else if ((uL - l) < eth || ((uint32_t)r2 - l - (uint32_t)left2) < eth) none = 1;
-                w0 = (uint32_t)left2; w1 = (uint32_t)r2 - l; anc = (uint32_t)r2; p0 = 0; p1 = uL - l; want_tail = false;
-            } else { none = 1; w0 = w1 = anc = p0 = p1 = 0; want_tail = false; }
-        } else { none = 1; w0 = w1 = anc = p0 = p1 = 0; want_tail = false; }
+                w0 = (uint32_t)left2; w1 = (uint32_t)r2 - l; anc = (uint32_t)r2; p0 = 0; p1 = uL - l;
+            } else none = 1;
+        } else none = 1;
         if (abortc) { finish(out, IM_ST_ABORT, 1, lane); continue; }
         if (none) { finish(out, IM_ST_NONE, 1, lane); continue; }
         if ((int32_t)(w1 - w0) <= 0) { finish(out, IM_ST_ABORT, 1, lane); continue; }
@@ -1498,61 +1701,58 @@ __global__ __launch_bounds__(64) void realign_gapped_kernel(RealignArgs A)
         const Band b2 = band_search<0, DIRECT>(s, pk, contig, w0, w1, anc, p0, p1, k, g, lane, 0u IM_STAMP_PASS(21));
         if (b2.st) { finish(out, b2.st, 2, lane); continue; }
         const int up2 = ((p1 - p0) < k) ? b2.low : b2.low + (int)g;
-        st = gap_stage_window(G, contig, (int)w0, (int)(w1 - w0), (int)(p1 - p0), b2.low, up2, lane);
-        if (st == 0 && lane == 0) {
-            int rs = gap_band_alignment(G, rd, (int)p0, (int)(p1 - p0), (int)w0, (int)(w1 - w0), b2.low, up2, 1);
-            if (rs == 0) {
-                const int r3 = G.aln[1][0], r4 = G.aln[1][1], q3 = G.aln[1][2], q4 = G.aln[1][3];
-                uint32_t* c1 = G.ops[0]; uint32_t* c2 = G.ops[1];
-                int n1 = G.nops[0], n2 = G.nops[1];
-                rs = -100;                                   // "go on to combine"
-                if (want_tail) { if (q4 != L || q3 == q4) rs = IM_ST_NONE; }
-                else           { if (q3 != 0 || q3 == q4) rs = IM_ST_NONE; }
-                if (rs == -100) {
-                    // add_prefix_soft_clip / add_suffix_soft_clip (src/alignment.c:478-532)
-                    if (want_tail && f > 0) {
-                        if ((c2[0] & 15u) == IM_OP_S) c2[0] = (((c2[0] >> 4) + f) << 4) | IM_OP_S;
-                        else if (n2 >= IM_MAX_OPS) rs = IM_ST_OVERFLOW;
-                        else { for (int t = n2; t > 0; t--) c2[t] = c2[t - 1]; c2[0] = (f << 4) | IM_OP_S; n2++; }
-                    } else if (!want_tail && l > 0) {
-                        if (n2 <= 0) rs = IM_ST_ABORT;
-                        else if ((c2[n2 - 1] & 15u) == IM_OP_S) c2[n2 - 1] = (((c2[n2 - 1] >> 4) + l) << 4) | IM_OP_S;
-                        else if (n2 >= IM_MAX_OPS) rs = IM_ST_OVERFLOW;
-                        else c2[n2++] = (l << 4) | IM_OP_S;
-                    }
-                }
-                if (rs == -100) {
-                    if (!(q1 < q2 && q3 < q4)) rs = IM_ST_ABORT;
-                    else {
-                        int index = -1;
-                        if (q1 > q3 && q1 <= q4) {
-                            rs = gap_best_split(q3, q4, c2, n2, q1, q2, c1, n1, L, &index);
-                            if (rs == 0) rs = gap_build_result(out, r3, c2, n2, index, q1, r1, c1, n1);
-                        } else if (q3 > q1 && q3 <= q2) {
-                            rs = gap_best_split(q1, q2, c1, n1, q3, q4, c2, n2, L, &index);
-                            if (rs == 0) rs = gap_build_result(out, r1, c1, n1, index, q3, r3, c2, n2);
-                        } else if (q1 > q4 && r1 == r4) rs = gap_build_result(out, r3, c2, n2, q4, q1, r1, c1, n1);
-                        else if (q3 > q2 && r2 == r3) rs = gap_build_result(out, r1, c1, n1, q2, q3, r3, c2, n2);
-                        else rs = IM_ST_NONE;
-                    }
-                }
-            }
-            G.status = rs;
-        }
-        wave_lds_sync();
-        if (st == 0) st = G.status;
+        const BandAln a2 = band_alignment(G, contig, rd, (int)p0, (int)(p1 - p0), (int)w0, (int)(w1 - w0), b2.low, up2, 1, lane);
         if (lane == 0) {
             im_band_aln* o = &out->band[1];
-            o->r1 = G.aln[1][0]; o->r2 = G.aln[1][1]; o->q1 = G.aln[1][2]; o->q2 = G.aln[1][3];
+            o->r1 = a2.r1; o->r2 = a2.r2; o->q1 = a2.q1; o->q2 = a2.q2;
             o->low = b2.low; o->votes = b2.votes; o->win_bytes = b2.win; o->piece_bytes = b2.piece;
         }
-        finish(out, st, 2, lane);
-        if (st == IM_ST_EVIDENCE && lane == 0 && A.batch.ev_cls)
-            for (int e = 0; e < IM_MAX_EV; e++) {
-                const int64_t sl = (int64_t)c * IM_MAX_EV + e;
-                const bool live = e < out->n_ev;
-                A.batch.ev_cls[sl] = live ? out->ev[e].cls : -1; A.batch.ev_b1[sl] = live ? out->ev[e].b1 : 0; A.batch.ev_b2[sl] = live ? out->ev[e].b2 : 0;
+        int st = a2.st;
+        if (st == 0) {
+            const int r3 = a2.r1, r4 = a2.r2, q3 = a2.q1, q4 = a2.q2;
+            uint32_t* c2 = G.ops[1]; int n2 = uni(G.nops[1]);
+            st = -100;                                      // "go on to combine"
+            if (want_tail) { if (q4 != L || q3 == q4) st = IM_ST_NONE; }
+            else           { if (q3 != 0 || q3 == q4) st = IM_ST_NONE; }
+            if (st == -100) {
+                // add_prefix_soft_clip / add_suffix_soft_clip (src/alignment.c:478-532)
+                if (want_tail && f > 0) {
+                    if (n2 > 0 && (c2[0] & 15u) == IM_OP_S) { if (lane == 0) c2[0] = (((c2[0] >> 4) + f) << 4) | IM_OP_S; }
+                    else if (n2 >= IM_MAX_OPS) st = IM_ST_OVERFLOW;
+                    else {
+                        const uint32_t mine = lane < n2 ? c2[lane] : 0u;
+                        wave_lds_sync();
+                        if (lane < n2) c2[lane + 1] = mine;
+                        if (lane == 0) c2[0] = (f << 4) | IM_OP_S;
+                        n2++;
+                    }
+                } else if (!want_tail && l > 0) {
+                    if (n2 <= 0) st = IM_ST_ABORT;
+                    else if ((c2[n2 - 1] & 15u) == IM_OP_S) { if (lane == 0) c2[n2 - 1] = (((c2[n2 - 1] >> 4) + l) << 4) | IM_OP_S; }
+                    else if (n2 >= IM_MAX_OPS) st = IM_ST_OVERFLOW;
+                    else { if (lane == 0) c2[n2] = (l << 4) | IM_OP_S; n2++; }
+                }
+                wave_lds_sync();
             }
+            if (st == -100) {
+                if (!(q1 < q2 && q3 < q4)) { BFAIL(G, 103); st = IM_ST_ABORT; }
+                else {
+                    int index = -1;
+                    if (q1 > q3 && q1 <= q4) {
+                        st = band_best_split(G, q3, q4, c2, n2, q1, q2, c1, n1, L, lane, &index);
+                        if (st == 0) st = band_build_result(out, G, r3, c2, n2, index, q1, r1, c1, n1, lane, A, c);
+                    } else if (q3 > q1 && q3 <= q2) {
+                        st = band_best_split(G, q1, q2, c1, n1, q3, q4, c2, n2, L, lane, &index);
+                        if (st == 0) st = band_build_result(out, G, r1, c1, n1, index, q3, r3, c2, n2, lane, A, c);
+                    } else if (q1 > q4 && r1 == r4) st = band_build_result(out, G, r3, c2, n2, q4, q1, r1, c1, n1, lane, A, c);
+                    else if (q3 > q2 && r2 == r3) st = band_build_result(out, G, r1, c1, n1, q2, q3, r3, c2, n2, lane, A, c);
+                    else st = IM_ST_NONE;
+                }
+            }
+        }
+        if (st < 0 && lane == 0) out->reserved[6] = G.tmp[IM_MAX_OPS + 7];
+        finish(out, st, 2, lane);
+        wave_lds_sync();
     }
 }
 
@@ -1606,15 +1806,12 @@ hipError_t launch_realign(const RealignArgs& a, int n_cu, hipStream_t stream)
     int grid = (int)(need < want ? need : want);
     grid = (grid + 7) / 8 * 8;
     if (a.P.numgaps > 0) {
-        // the traceback recurses (depth ~ log2 of the band): give the dynamic stack room once
-        static bool stack_set = false;
-        if (!stack_set) { hipError_t e = hipDeviceSetLimit(hipLimitStackSize, 4096); if (e != hipSuccess) return e; stack_set = true; }
-        // one serial lane per read dominates: more, smaller waves in flight than the g = 0 path
-        int gg = (int)(need < (int64_t)n_cu * 8 ? need : (int64_t)n_cu * 8);
+        // one wave per read; the band kernel holds more LDS per wave than the single-diagonal one
+        int gg = (int)(need < (int64_t)n_cu * 24 ? need : (int64_t)n_cu * 24);
         if (a.P.klength <= (uint32_t)kDirectMaxK)
-            hipLaunchKernelGGL((realign_gapped_kernel<true>), dim3(gg), dim3(64), 0, stream, a);
+            hipLaunchKernelGGL((realign_band_kernel<true>), dim3(gg), dim3(64), 0, stream, a);
         else
-            hipLaunchKernelGGL((realign_gapped_kernel<false>), dim3(gg), dim3(64), 0, stream, a);
+            hipLaunchKernelGGL((realign_band_kernel<false>), dim3(gg), dim3(64), 0, stream, a);
     } else if (a.P.klength == 6 && a.P.numgaps == 0)
         hipLaunchKernelGGL((realign_kernel<6, true>), dim3(grid), dim3(64), 0, stream, a);     // reference defaults
     else if (a.P.klength <= (uint32_t)kDirectMaxK)

@@ -28,6 +28,9 @@
 #include <stdlib.h>
 #include <string.h>
 #include <time.h>
+#include <unistd.h>
+#include <errno.h>
+#include <sys/stat.h>
 
 #define INDELMINER_VERSION 0.2          /* src/indelminer.c:26 */
 
@@ -367,12 +370,15 @@ typedef struct {
     int32_t *seg_start, *seg_len; int64_t n_seg, cap_seg;
     int depth_tid;              /* contig whose depth array is resident on the device, -1 = none */
     int pipe_mode;              /* device pipeline: depth queries go to the genome-wide array */
+    int marker_floor;           /* multi-GPU: smallest start of a stale pair-table entry of an earlier contig on another rank */
     /* live entries of the pair table (find_marker walks these) */
     evidence_t** live; int32_t n_live, cap_live;
 } driver;
 
 static void gpu_wait(driver* d);
 static void print_vcf_preamble(void);
+static int g_mg_rank = 0, g_mg_local = -1;
+static char g_mg_header_path[512] = "";
 
 static void cb_push(cand_batch* cb, const char* bases, int32_t tid, int32_t anchor, int32_t range_max,
                     const char* qname, char strand, uint8_t qual)
@@ -1600,7 +1606,7 @@ static void* gpu_open_thread(void* arg)
 {
     driver* d = (driver*)arg;
     const char* dev_env = getenv("INDELMINER_DEVICE");
-    d->gpu_rc = im_ctx_create(dev_env ? atoi(dev_env) : 0, &d->gpu);
+    d->gpu_rc = im_ctx_create(dev_env ? atoi(dev_env) : (g_mg_local >= 0 ? g_mg_local : 0), &d->gpu);
     if (d->gpu_rc != IM_OK) { snprintf(d->gpu_err, sizeof d->gpu_err, "cannot open the GPU: %s", im_last_error(NULL)); return NULL; }
     const char** seqs = xcalloc((size_t)d->hdr->n_targets, sizeof(char*));
     int64_t* lens = xcalloc((size_t)d->hdr->n_targets, sizeof(int64_t));
@@ -1621,10 +1627,15 @@ static void gpu_wait(driver* d)
     phase_time("GPU context + reference upload (helper thread, joined)");
     /* the output header (src/indelminer.c:745-754) goes out only once the GPU is known to be there:
      * nothing is printed by a run that cannot compute */
+    if (g_mg_rank > 0) return;                          /* multi-GPU: rank 0 prints the header */
+    if (g_mg_header_path[0] && !freopen(g_mg_header_path, "w", stdout)) fatalf("cannot write %s", g_mg_header_path);   /* ... as the first part */
     if (strncmp(O.outputformat, "vcf", 3) == 0) print_vcf_preamble();
     if (g_vcfname != NULL)
         printf("##INFO=<ID=%s,Number=0,Type=Flag,Description=\"The variant is also present in this sample\">\n", g_sample_name);
     if (strncmp(O.outputformat, "vcf", 3) == 0) printf("#CHROM\tPOS\tID\tREF\tALT\tQUAL\tFILTER\tINFO\n");
+    fflush(stdout);
+    /* the header part is complete; whatever a library prints on stdout from here on (librccl's banner) is not VCF */
+    if (g_mg_header_path[0] && !freopen("/dev/stderr", "w", stdout)) { }
 }
 
 /* ------------------------------------------------------ config / estimates -- */
@@ -1837,6 +1848,26 @@ static void run_contig(driver* d, int32_t tid, int32_t beg, int32_t end, bgzf_re
         g_known.next = g_known.n;
     }
 }
+
+/* multi-GPU state (the section further down): declared here because the replay writes one part per contig */
+#define MG_MAX_RG    64
+#define MG_RG_WORDS  16         /* name[48] + min + max + first_tid + first_rec */
+#define MG_MAX_LEFT  32
+#define MG_CTG_WORDS (4 + 3 * MG_MAX_LEFT)
+
+typedef struct {
+    int rank, world, local_rank;
+    im_comm* comm;
+    char dir[400];
+    int64_t* prefix;            /* [n_targets] counted reads of all earlier contigs */
+    int*     floor;             /* [n_targets] smallest start of a stale pair-table entry of an earlier contig */
+    int      out_fd;            /* rank 0: the real stdout */
+    uint8_t* skip;              /* [n_targets] annotate mode: contigs without known variants are not walked at all */
+} mgpu;
+
+static mgpu* g_mg = NULL;
+
+static void mg_path(const mgpu* m, char* out, size_t cap, const char* what, int idx) { snprintf(out, cap, "%s/%s.%d", m->dir, what, idx); }
 
 /* ======================================================== device pipeline == */
 /*
@@ -2124,6 +2155,7 @@ static void pipe_host_record(driver* d, pgroup* G, const bam_record* b)
     if ((++d->numread % READCHUNK) == 0) {
         timestamp("Read %ld reads", (long)d->numread);
         int marker = find_marker_live(d);
+        if (d->marker_floor < marker) marker = d->marker_floor;       /* stale pair-table entries of contigs other ranks own */
         if (b->pos < marker) marker = b->pos;
         if (G->n_fl == G->cap_fl) { G->cap_fl = G->cap_fl ? G->cap_fl * 2 : 256; G->fl = xrealloc(G->fl, sizeof(gflush) * (size_t)G->cap_fl); }
         gflush* f = &G->fl[G->n_fl++];
@@ -2479,6 +2511,12 @@ static void group_replay(driver* d, pgroup* G)
         const gcontig* cg = &G->ctg[ci];
         const int32_t tid = cg->tid;
         d->depth_tid = tid;
+        if (g_mg) {                                     /* one VCF part per contig, concatenated by rank 0 in contig order */
+            char path[512];
+            mg_path(g_mg, path, sizeof path, "part", tid);
+            fflush(stdout);
+            if (!freopen(path, "w", stdout)) fatalf("cannot write %s", path);
+        }
         for (int f = cg->fl0; f < cg->fl1; f++) {
             variant_list vs = {0};
             evidence_t** used = NULL; int64_t n_used = 0;
@@ -2511,6 +2549,255 @@ static void group_replay(driver* d, pgroup* G)
     phase_time("replay (variants, merge, print)");
 }
 
+/* ============================================================== multi-GPU == */
+/*
+ * One process per GPU (RANK / WORLD_SIZE / LOCAL_RANK in the environment, as torch.distributed.run sets
+ * them), contigs sharded tid % world.  Contigs are independent in the reference except for three things that
+ * are carried from one contig to the next, and those are what the ranks exchange -- in ONE all-gather (RCCL
+ * over xGMI) of fixed-size per-shard summaries, before any rank starts its main pass:
+ *   the global read counter that places the READCHUNK flushes (numread is never reset, src/indelminer.c:617,764)
+ *       -> counted reads per contig, so that a rank starts contig c at the single run's count;
+ *   the pair table, whose stale entries (first mates whose second mate never comes) lower every later marker
+ *       (find_marker, 211-233)  -> the unpaired first mates of every contig (start, |isize|, read group);
+ *   the insert-length table when no config file is given (estimate_insertlengths, src/bamoperations.c:15-86)
+ *       -> per read group min / max and where it was first seen, merged in file order.
+ * Each rank gets them from ONE pre-walk over its own contigs (the estimation pass the reference runs anyway).
+ * Then every rank runs the device pipeline over its contigs, writes one VCF part per contig, and rank 0
+ * concatenates the parts in contig order behind the header: the single run's bytes.
+ */
+
+static void mg_rendezvous(mgpu* m, driver* d)
+{
+    /* the RCCL unique id travels through a file in a directory every rank can see (one node) */
+    const char* dir = getenv("INDELMINER_RENDEZVOUS");
+    if (dir) snprintf(m->dir, sizeof m->dir, "%s", dir);
+    else snprintf(m->dir, sizeof m->dir, "/tmp/indelminer_mgpu_%s", getenv("MASTER_PORT") ? getenv("MASTER_PORT") : "0");
+    char path[512], tmp[520];
+    snprintf(path, sizeof path, "%s/rccl_id", m->dir);
+    uint8_t id[IM_COMM_ID_BYTES];
+    if (m->rank == 0) {
+        /* no fork() here: the GPU helper thread is inside the HIP runtime's start-up */
+        if (mkdir(m->dir, 0700) != 0 && errno != EEXIST) fatalf("cannot create the rendezvous directory %s", m->dir);
+        unlink(path);
+        snprintf(g_mg_header_path, sizeof g_mg_header_path, "%s/part.header", m->dir);
+        gpu_wait(d);                                    /* the HIP runtime is up before librccl is asked for anything */
+        if (im_comm_unique_id(id) != IM_OK) fatalf("im_comm_unique_id: %s", im_comm_last_error());
+        snprintf(tmp, sizeof tmp, "%s.tmp", path);
+        FILE* fp = fopen(tmp, "wb");
+        if (!fp || fwrite(id, 1, sizeof id, fp) != sizeof id) fatalf("cannot write %s", tmp);
+        fclose(fp);
+        if (rename(tmp, path) != 0) fatalf("cannot publish %s", path);
+    } else {
+        const double t_end = now_ms() + 120e3;
+        for (;;) {
+            FILE* fp = fopen(path, "rb");
+            if (fp) { const size_t got = fread(id, 1, sizeof id, fp); fclose(fp); if (got == sizeof id) break; }
+            if (now_ms() > t_end) fatalf("rank %d: no RCCL id at %s after 120 s", m->rank, path);
+            struct timespec ts = { 0, 20 * 1000 * 1000 };
+            nanosleep(&ts, NULL);
+        }
+    }
+    gpu_wait(d);
+    if (im_comm_init(d->gpu, id, m->rank, m->world, &m->comm) != IM_OK) fatalf("im_comm_init: %s", im_comm_last_error());
+}
+
+/* every rank contributes `words` int32; all[] receives world * words */
+static void mg_allgather(mgpu* m, driver* d, const int32_t* mine, int32_t* all, size_t words)
+{
+    void *ds = NULL, *dr = NULL;
+    if (im_dev_alloc(d->gpu, 4 * words, &ds) != IM_OK || im_dev_alloc(d->gpu, 4 * words * (size_t)m->world, &dr) != IM_OK) fatalf("im_dev_alloc: %s", im_last_error(d->gpu));
+    if (im_dev_upload(d->gpu, ds, mine, 4 * words) != IM_OK) fatalf("im_dev_upload: %s", im_last_error(d->gpu));
+    void* st = im_ctx_stream(d->gpu);
+    if (im_comm_allgather(m->comm, ds, dr, 4 * words, st) != IM_OK) fatalf("im_comm_allgather: %s", im_comm_last_error());
+    if (im_stream_sync(d->gpu, st) != IM_OK) fatalf("im_stream_sync: %s", im_last_error(d->gpu));
+    if (im_dev_download(d->gpu, all, dr, 4 * words * (size_t)m->world) != IM_OK) fatalf("im_dev_download: %s", im_last_error(d->gpu));
+    im_dev_free(d->gpu, ds); im_dev_free(d->gpu, dr);
+}
+
+typedef struct { char name[48]; int32_t min, max, first_tid, first_rec; int seen; } mg_rg;
+
+/* The pre-walk over this rank's contigs.  Fills this rank's words of the exchange buffer. */
+static void mg_prewalk(mgpu* m, driver* d, int estimate, int32_t* mine, size_t words)
+{
+    memset(mine, 0, 4 * words);
+    mg_rg* rgs = xcalloc(MG_MAX_RG, sizeof(mg_rg));
+    int n_rg = 0;
+    bgzf_reader* r = bgzf_open(d->bam_name);
+    if (!r) fatalf("error in opening the file %s", d->bam_name);
+    bam_header* h = bam_header_load(r);
+    bam_record b; memset(&b, 0, sizeof b);
+    for (int32_t t = m->rank; t < h->n_targets; t += m->world) {
+        int32_t* cw = mine + 2 + MG_MAX_RG * MG_RG_WORDS + (size_t)t * MG_CTG_WORDS;
+        cw[3] = 1;                                      /* walked by this rank */
+        if (m->skip && m->skip[t]) continue;
+        bam_region_iter it;
+        if (bam_region_begin(&it, r, d->idx, t, 0, h->target_len[t]) != 0) continue;
+        qhash* waiting = qhash_new(16);                 /* unpaired first mates of this contig: name -> {start, |isize|, rg} */
+        int64_t counted = 0;
+        int32_t rec = 0;
+        while (bam_region_next(&it, &b) == 1) {
+            const int flag = b.flag;
+            const int32_t this_rec = rec++;
+            if (estimate && (flag & 0x1) && !(flag & 0x4) && (flag & 0x2) && !(flag & (0x100 | 0x200 | 0x400)) &&
+                b.isize >= 0 && b.mpos - b.pos >= 0 && b.isize >= b.mpos - b.pos) {
+                /* estimate_insertlengths (src/bamoperations.c:15-86) */
+                const uint8_t* rg = bam_aux_find(&b, "RG");
+                const char* rgname = "generic";
+                if (rg) { forceassert(rg[0] == 'Z'); rgname = bam_aux_str(rg); }
+                int k = 0;
+                while (k < n_rg && strcmp(rgs[k].name, rgname) != 0) k++;
+                if (k == n_rg) {
+                    if (n_rg == MG_MAX_RG || strlen(rgname) >= sizeof rgs[0].name) fatalf("multi-GPU runs take at most %d read groups with names under %zu bytes", MG_MAX_RG, sizeof rgs[0].name);
+                    snprintf(rgs[k].name, sizeof rgs[k].name, "%s", rgname);
+                    rgs[k].min = rgs[k].max = b.isize; rgs[k].first_tid = t; rgs[k].first_rec = this_rec;
+                    n_rg++;
+                } else {
+                    if (rgs[k].min > b.isize) rgs[k].min = b.isize;
+                    if (rgs[k].max < b.isize) rgs[k].max = b.isize;
+                }
+            }
+            if (flag & (0x100 | 0x200 | 0x400 | 0x800)) continue;
+            if (!(flag & 0x1)) continue;
+            const int aligned = !(flag & 0x4), mate_aligned = !(flag & 0x8);
+            if (aligned && mate_aligned && b.tid != b.mtid) continue;
+            counted++;
+            /* the pair table's bookkeeping, independent of range[1]: both mates of a pair carry the same |isize|, so the
+             * threshold |isize| > range[1] (src/indelminer.c:519) keeps or drops them together -- applied after the exchange */
+            if (aligned && mate_aligned && !(flag & 0x2) && ((flag & 0x10) != 0) != ((flag & 0x20) != 0) &&
+                (uint32_t)abs(b.isize) < O.maxpedelsize) {
+                const char* qname = BAMR_QNAME(&b);
+                if (b.pos < b.mpos) {
+                    int32_t* v = xmalloc(3 * sizeof(int32_t));
+                    const uint8_t* rg = bam_aux_find(&b, "RG");
+                    const char* rgname = rg ? bam_aux_str(rg) : "generic";
+                    v[0] = b.pos; v[1] = abs(b.isize);
+                    v[2] = (int32_t)djb2_rev(rgname, (int)strlen(rgname));
+                    qhash_add(waiting, qname, b.l_qname, v);
+                } else free(qhash_remove(waiting, qname, b.l_qname));
+            }
+        }
+        cw[0] = (int32_t)(counted & 0xffffffff); cw[1] = (int32_t)(counted >> 32);
+        int n_left = 0;
+        for (uint32_t i = 0; i <= waiting->mask; i++)
+            for (qbin* q = waiting->bins[i]; q; q = q->next) {
+                const int32_t* v = q->val;
+                /* keep the MG_MAX_LEFT smallest starts */
+                int pos = n_left < MG_MAX_LEFT ? n_left++ : -1;
+                if (pos < 0) { int worst = 0; for (int k = 1; k < MG_MAX_LEFT; k++) if (cw[4 + 3 * k] > cw[4 + 3 * worst]) worst = k; if (v[0] < cw[4 + 3 * worst]) pos = worst; }
+                if (pos >= 0) { cw[4 + 3 * pos] = v[0]; cw[5 + 3 * pos] = v[1]; cw[6 + 3 * pos] = v[2]; }
+            }
+        cw[2] = n_left;
+        qhash_free(waiting, free);
+    }
+    free(b.data);
+    bam_header_free(h);
+    bgzf_close(r);
+    mine[0] = 0x4d47; mine[1] = n_rg;
+    for (int k = 0; k < n_rg; k++) {
+        int32_t* w = mine + 2 + (size_t)k * MG_RG_WORDS;
+        memcpy(w, rgs[k].name, 48);
+        w[12] = rgs[k].min; w[13] = rgs[k].max; w[14] = rgs[k].first_tid; w[15] = rgs[k].first_rec;
+    }
+    free(rgs);
+}
+
+static int cmp_mg_rg(const void* x, const void* y)
+{
+    const mg_rg* a = x; const mg_rg* b = y;
+    if (a->first_tid != b->first_tid) return a->first_tid < b->first_tid ? -1 : 1;
+    if (a->first_rec != b->first_rec) return a->first_rec < b->first_rec ? -1 : 1;
+    return 0;
+}
+
+/* exchange + merge: the insert-length table (when estimated), the counter prefix and the marker floor of every contig */
+static void mg_exchange(mgpu* m, driver* d, int estimate)
+{
+    const int32_t nt = d->hdr->n_targets;
+    const size_t words = 2 + (size_t)MG_MAX_RG * MG_RG_WORDS + (size_t)nt * MG_CTG_WORDS;
+    int32_t* mine = xmalloc(4 * words);
+    int32_t* all = xmalloc(4 * words * (size_t)m->world);
+    mg_prewalk(m, d, estimate, mine, words);
+    phase_time("pre-walk of this rank's contigs (count, unpaired mates, insert lengths)");
+    mg_allgather(m, d, mine, all, words);
+    if (estimate) {
+        mg_rg* rgs = xcalloc((size_t)MG_MAX_RG * (size_t)m->world, sizeof(mg_rg));
+        int n = 0;
+        for (int rk = 0; rk < m->world; rk++) {
+            const int32_t* a = all + (size_t)rk * words;
+            forceassert(a[0] == 0x4d47);
+            for (int k = 0; k < a[1]; k++) {
+                const int32_t* w = a + 2 + (size_t)k * MG_RG_WORDS;
+                char name[48]; memcpy(name, w, 48); name[47] = 0;
+                int j = 0;
+                while (j < n && strcmp(rgs[j].name, name) != 0) j++;
+                if (j == n) { snprintf(rgs[j].name, sizeof rgs[j].name, "%s", name); rgs[j].min = w[12]; rgs[j].max = w[13]; rgs[j].first_tid = w[14]; rgs[j].first_rec = w[15]; n++; }
+                else {
+                    if (w[12] < rgs[j].min) rgs[j].min = w[12];
+                    if (w[13] > rgs[j].max) rgs[j].max = w[13];
+                    if (w[14] < rgs[j].first_tid || (w[14] == rgs[j].first_tid && w[15] < rgs[j].first_rec)) { rgs[j].first_tid = w[14]; rgs[j].first_rec = w[15]; }
+                }
+            }
+        }
+        qsort(rgs, (size_t)n, sizeof(mg_rg), cmp_mg_rg);        /* the order in which one process would have met them */
+        for (int j = 0; j < n; j++) {
+            int32_t* range = xmalloc(2 * sizeof(int32_t));
+            range[0] = rgs[j].min; range[1] = rgs[j].max;
+            qhash_add(d->insertlengths, rgs[j].name, (int)strlen(rgs[j].name), range);
+            rg_order_push(rgs[j].name, range);
+        }
+        free(rgs);
+    }
+    m->prefix = xcalloc((size_t)nt + 1, sizeof(int64_t));
+    m->floor = xmalloc(sizeof(int) * ((size_t)nt + 1));
+    int64_t run = 0; int fl = INT_MAX;
+    for (int32_t t = 0; t < nt; t++) {
+        m->prefix[t] = run; m->floor[t] = fl;
+        const int32_t* cw = all + (size_t)(t % m->world) * words + 2 + (size_t)MG_MAX_RG * MG_RG_WORDS + (size_t)t * MG_CTG_WORDS;
+        forceassert(cw[3] == 1);
+        run += (int64_t)(uint32_t)cw[0] | ((int64_t)cw[1] << 32);
+        for (int k = 0; k < cw[2]; k++) {
+            /* stale iff the pair passes src/indelminer.c:519 with its read group's range[1] */
+            int32_t rmax = -1;
+            for (int j = 0; j < g_rg_n; j++) if ((int32_t)djb2_rev(g_rg_name[j], (int)strlen(g_rg_name[j])) == cw[6 + 3 * k]) rmax = g_rg_range[j][1];
+            if (rmax >= 0 && cw[5 + 3 * k] > rmax && cw[4 + 3 * k] < fl) fl = cw[4 + 3 * k];
+        }
+    }
+    free(mine); free(all);
+}
+
+/* rank 0, at the very end: the parts in contig order behind the header that is already on the real stdout */
+static void mg_finish(mgpu* m, driver* d)
+{
+    fflush(stdout);
+    if (!freopen("/dev/null", "w", stdout)) { }        /* the last part is closed */
+    int32_t one = 1;
+    int32_t* all = xmalloc(4 * (size_t)m->world);
+    mg_allgather(m, d, &one, all, 1);                   /* every rank has closed its parts */
+    free(all);
+    if (m->rank == 0) {
+        char path[512], buf[1 << 16];
+        for (int32_t t = -1; t < d->hdr->n_targets; t++) {
+            if (t < 0) snprintf(path, sizeof path, "%s", g_mg_header_path); else mg_path(m, path, sizeof path, "part", t);
+            FILE* fp = fopen(path, "rb");
+            if (!fp) continue;                          /* a contig nobody printed for */
+            size_t got;
+            while ((got = fread(buf, 1, sizeof buf, fp)) > 0) {
+                size_t off = 0;
+                while (off < got) { const ssize_t w = write(m->out_fd, buf + off, got - off); if (w <= 0) fatalf("write to stdout failed"); off += (size_t)w; }
+            }
+            fclose(fp);
+        }
+        for (int32_t t = -1; t < d->hdr->n_targets; t++) {
+            if (t < 0) snprintf(path, sizeof path, "%s", g_mg_header_path); else mg_path(m, path, sizeof path, "part", t);
+            unlink(path);
+        }
+        snprintf(path, sizeof path, "%s/rccl_id", m->dir);
+        unlink(path);
+        rmdir(m->dir);
+    }
+    im_comm_destroy(m->comm);
+}
+
 static void run_pipeline(driver* d, bgzf_reader* r)
 {
     ppipe P; pgroup G;
@@ -2519,14 +2806,16 @@ static void run_pipeline(driver* d, bgzf_reader* r)
     d->pipe_mode = 1;
     pipe_init(&P, d);               /* the records are inflated into pinned chunks: the GPU context comes first */
     for (int32_t i = 0; i < d->hdr->n_targets; i++) {
+        if (g_mg && i % g_mg->world != g_mg->rank) continue;       /* another rank's contig */
         if (g_vcfname != NULL) {
             known_free(&g_known);
             read_variants(g_vcfname, i, d->hdr->target_name[i], &g_known);
             if (g_known.n == 0) continue;           /* src/indelminer.c:788 */
         }
+        if (g_mg) { d->numread = g_mg->prefix[i]; d->marker_floor = g_mg->floor[i]; }   /* where the single run would stand */
         pipe_walk_contig(&P, &G, i, r);
         phase_time("walk (inflate + count + pair table; triage on the device)");
-        const int last = i == d->hdr->n_targets - 1;
+        const int last = i + (g_mg ? g_mg->world : 1) >= d->hdr->n_targets;
         if (g_vcfname != NULL || last || G.n_rec >= PIPE_GROUP_RECORDS) {
             pipe_run_group(&P, &G);
             group_replay(d, &G);
@@ -2665,8 +2954,30 @@ int main(int argc, char** argv)
     int chromid = -1, chromstart = -1, chromstop = -1;
     if (O.region) bam_parse_region_str(d.hdr, O.region, &chromid, &chromstart, &chromstop);
 
+    /* one process per GPU (torch.distributed.run's environment): contigs are sharded over the ranks */
+    mgpu mg;
+    memset(&mg, 0, sizeof mg);
+    {
+        const char* ws = getenv("WORLD_SIZE");
+        const int world = ws ? atoi(ws) : 1;
+        const char* pl = getenv("INDELMINER_PIPELINE");
+        if ((world > 1 || getenv("INDELMINER_FORCE_MGPU")) && chromid == -1 && !(pl && strcmp(pl, "host") == 0)) {
+            mg.world = world > 0 ? world : 1;
+            mg.rank = getenv("RANK") ? atoi(getenv("RANK")) : 0;
+            mg.local_rank = getenv("LOCAL_RANK") ? atoi(getenv("LOCAL_RANK")) : mg.rank;
+            forceassert(mg.rank >= 0 && mg.rank < mg.world);
+            g_mg = &mg; g_mg_rank = mg.rank; g_mg_local = mg.local_rank;
+            /* librccl prints a banner on descriptor 1: the VCF goes through part files and the saved descriptor, and
+             * descriptor 1 points at stderr for the whole run */
+            fflush(stdout);
+            mg.out_fd = dup(1);
+            if (mg.out_fd < 0 || dup2(2, 1) < 0) fatalf("cannot redirect stdout");
+        }
+    }
+    d.marker_floor = INT_MAX;
+
     if (O.configfile) read_configuration(O.configfile, d.insertlengths);
-    else estimate_insertlengths(&d, chromid);
+    else if (!g_mg) estimate_insertlengths(&d, chromid);
     fprintf(stderr, "\nRead-group\tMin-value\tMax-value\n----------\t---------\t---------\n");
     for (uint32_t i = 0; i <= d.insertlengths->mask; i++)
         for (qbin* it = d.insertlengths->bins[i]; it; it = it->next)
@@ -2690,7 +3001,25 @@ int main(int argc, char** argv)
      * mate look-ups and depth queries go to the BAM file like the reference's */
     const char* pl = getenv("INDELMINER_PIPELINE");
     const int use_pipeline = chromid == -1 && !(pl && strcmp(pl, "host") == 0);
+    if (g_mg) {
+        if (g_vcfname != NULL) {
+            /* annotate mode walks only the contigs the variant file names (src/indelminer.c:788) */
+            mg.skip = xcalloc((size_t)d.hdr->n_targets, 1);
+            for (int32_t i = 0; i < d.hdr->n_targets; i++) {
+                known_free(&g_known);
+                read_variants(g_vcfname, i, d.hdr->target_name[i], &g_known);
+                mg.skip[i] = g_known.n == 0;
+            }
+        }
+        mg_rendezvous(&mg, &d);
+        mg_exchange(&mg, &d, O.configfile == NULL);
+        if (O.configfile == NULL && mg.rank == 0) {
+            fprintf(stderr, "\nRead-group\tMin-value\tMax-value (estimated over all ranks' contigs)\n");
+            for (int j = 0; j < g_rg_n; j++) fprintf(stderr, "%s\t%d\t%d\n", g_rg_name[j], g_rg_range[j][0], g_rg_range[j][1]);
+        }
+    }
     if (use_pipeline) run_pipeline(&d, r);
+    if (g_mg) mg_finish(&mg, &d);
     for (int32_t i = 0; i < d.hdr->n_targets && !use_pipeline; i++) {
         if (chromid != -1 && i != chromid) continue;
         if (g_vcfname != NULL) {

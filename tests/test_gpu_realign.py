@@ -253,6 +253,51 @@ def test_hip_gapped_matches_oracle_on_seeded_batch(gpu_ctx, k, g):
     assert int((out["status"] == 1).sum()) > 500
 
 
+@pytest.mark.parametrize("k,g,seed", [(6, 0, 1), (6, 0, 2), (6, 1, 3), (6, 2, 4), (6, 5, 5), (8, 3, 6), (4, 0, 7), (6, 12, 8)])
+def test_hip_left_edge_bands(gpu_ctx, k, g, seed):
+    """The constructed left-edge cases of tests/support/leftedge.py (bands without a k-mer vote that hang off the window's
+    left edge, -g 0 and -g > 0): the oracle is pinned on them against the reference compiled from its own sources
+    (tests/test_oracle_vs_ref.py::test_left_edge_bands_against_reference); the kernels must agree with the oracle."""
+    from indelminer_amd import capi
+    from tests.support import leftedge
+    contig, cases = leftedge.cases(seed)
+    gpu_ctx.set_reference([contig.encode()])
+    kw = dict(klength=k, numgaps=g, maxdelsize=1000, ethreshold=10)
+    out, bad = _run_cases(gpu_ctx, capi, capi.params(**kw), ob.params(**kw), contig.encode(), cases,
+                          dump="gpurun_out/mismatch_leftedge_%d.txt" % seed)
+    assert not bad, "%r: %d of %d differ, first: %r" % (kw, len(bad), len(cases), bad[0][:2])
+
+
+@pytest.mark.parametrize("k,g", [(6, 20), (6, 40), (8, 60), (4, 33)])
+def test_hip_gapped_wide_bands(gpu_ctx, k, g):
+    """the widest bands the library accepts (-g up to 60: 61 diagonals across one wave), indels up to the band width"""
+    from indelminer_amd import capi
+    rng = random.Random(1000 + g)
+    clen = 6000
+    contig = "".join(rng.choice("ACGT") for _ in range(clen))
+    cases = []
+    for _ in range(60):
+        L = rng.choice([100, 150, 250])
+        anchor = rng.randint(0, clen - 1)
+        p = max(0, min(clen - L - 80, anchor + rng.randint(-600, 450)))
+        cut = rng.randint(20, L - 20)
+        d = rng.randint(1, g)
+        typ = rng.random()
+        if typ < 0.45:
+            read = contig[p:p + cut] + contig[p + cut + d:p + cut + d + (L - cut)]
+        elif typ < 0.9:
+            read = (contig[p:p + cut] + "".join(rng.choice("ACGT") for _ in range(d)) + contig[p + cut:p + L])[:L]
+        else:
+            read = contig[p:p + L]
+        read = "".join((rng.choice("ACGT") if rng.random() < 0.01 else ch) for ch in read)
+        cases.append(dict(anchor=anchor, range_max=705, read=read))
+    gpu_ctx.set_reference([contig.encode()])
+    out, bad = _run_cases(gpu_ctx, capi, capi.params(klength=k, numgaps=g), ob.params(klength=k, numgaps=g), contig.encode(), cases,
+                          dump="gpurun_out/mismatch_wideband_g%d.txt" % g)
+    assert not bad, "%d of %d differ, first: %r" % (len(bad), len(cases), bad[0][:2])
+    assert int((out["status"] == 1).sum()) > 10
+
+
 def test_hip_matches_oracle_on_config2_at_full_size(gpu_ctx):
     """BASELINE configs[1] at its full size -- the batch bench.py times: every candidate read of the seeded
     1 Mb / 30x / 100 bp data set (about 12 000 of 300 000 reads, chosen by the reference's own candidate rule)

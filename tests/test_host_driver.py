@@ -219,3 +219,16 @@ def test_product_annotate(synth_tn):
     tumor, ann = _annotate(_product(), synth_tn)
     assert tumor == _golden("synth_tn_tumor")
     assert ann == _golden("synth_tn_annotate")
+
+
+@pytest.mark.gpu
+def test_product_multi_gpu_path_one_rank(synth_small, tmp_path):
+    """The multi-GPU flow of the product with a world of ONE rank on the one GPU of this box: RCCL unique id through the
+    rendezvous file, communicator bring-up, the pre-walk, the all-gather of the shard summaries (RCCL, one rank), one
+    VCF part per contig, the closing all-gather, rank 0's concatenation.  More ranks need more GPUs (RCCL refuses two
+    ranks on one device); the two- and three-rank flows run against the CPU shim in tests/test_multi_rank_driver.py."""
+    for flags, gold in ((["-i", "cfg.txt"], "synth_2ctg_composite"), ([], "synth_2ctg_composite_noconfig")):
+        out = _run(_product(), flags, synth_small, "ref.fa", "aln.bam",
+                   env={"INDELMINER_FORCE_MGPU": "1", "RANK": "0", "WORLD_SIZE": "1", "LOCAL_RANK": "0",
+                        "INDELMINER_RENDEZVOUS": str(tmp_path / "rdv")})
+        assert out == _golden(gold)

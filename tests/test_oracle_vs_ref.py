@@ -50,3 +50,30 @@ def test_fuzz_against_reference(k, g, seed):
         assert msg is None, msg
         n_ev += 0 if ro is None else len(ro)
     assert n_ev > 5 or k < 4          # two- and three-base seeds are never unique in a 100-base read: no band, no evidence
+
+
+@pytest.mark.parametrize("k,g,seed", [(6, 0, 1), (6, 0, 2), (6, 1, 3), (6, 2, 4), (6, 5, 5), (8, 3, 6), (4, 0, 7), (6, 12, 8)])
+def test_left_edge_bands_against_reference(k, g, seed):
+    """Pins the left-edge behaviour of local_align's reverse pass (tests/support/leftedge.py): bands without a single
+    k-mer vote that hang off the window's left edge, for -g 0 and -g > 0 (where endj - startj = -g != 0 lets the
+    result reach ALIGN).  The oracle -- and through tests/test_gpu_realign.py the HIP kernels -- must give exactly
+    what the reference compiled from its own sources gives, byte in front of the window included."""
+    from tests.support import leftedge
+    R = refbind.Ref()
+    R.set_params(k, g, 1000, 10)
+    P = ob.params(k, g, 1000, 10)
+    contig, cases = leftedge.cases(seed)
+    cb = contig.encode()
+    # one byte in front of the contig that never equals a base: what the reference reads for a window at the contig's start
+    raw = C.create_string_buffer(b"#" + cb)
+    buf = C.cast(C.addressof(raw) + 1, C.POINTER(C.c_char * (len(cb) + 1))).contents
+    seen = 0
+    for c in cases:
+        st, res = ob.realign(P, cb, len(cb), c["anchor"], c["range_max"], c["read"])
+        if st == -1:
+            continue
+        ro = R.realign(buf, c["anchor"], c["range_max"], c["read"])
+        msg = compare.ref_vs_oracle(ro, st, res, c["read"])
+        assert msg is None, (c, msg)
+        seen += 1
+    assert seen > 60
