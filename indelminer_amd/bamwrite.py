@@ -151,9 +151,15 @@ def write_bam(path, contigs, rd, qname_prefix="r"):
 
 
 def write_fasta(path, contigs, refs, width=60):
-    with open(path, "w") as fh:
+    with open(path, "wb") as fh:
         for (name, _), ref in zip(contigs, refs):
-            fh.write(">%s\n" % name)
-            s = ref.tobytes().decode()
-            for i in range(0, len(s), width):
-                fh.write(s[i:i + width] + "\n")
+            fh.write((">%s\n" % name).encode())
+            ref = np.asarray(ref, dtype=np.uint8)
+            full = len(ref) // width * width
+            if full:                        # whole lines in one go: rows of `width` bases + a newline column
+                rows = np.empty((full // width, width + 1), dtype=np.uint8)
+                rows[:, :width] = ref[:full].reshape(-1, width)
+                rows[:, width] = 10
+                fh.write(rows.tobytes())
+            if full < len(ref):
+                fh.write(ref[full:].tobytes() + b"\n")

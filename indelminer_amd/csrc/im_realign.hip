@@ -1601,6 +1601,7 @@ __global__ __launch_bounds__(64, 4) void realign_band_kernel(RealignArgs A)
     static_assert(sizeof(BandLds) <= sizeof(s.diag) + sizeof(s.tbl), "BandLds must fit over the vote's histogram + table");
     static_assert(offsetof(WaveLds, tbl) == sizeof(s.diag), "diag and tbl are contiguous");
     BandLds& G = *reinterpret_cast<BandLds*>(s.diag);
+    __shared__ uint32_t c1_keep[IM_MAX_OPS + 4];            // the first piece's CIGAR outlives the second band search
     const int lane = threadIdx.x;
     const uint32_t k = A.P.klength, g = A.P.numgaps, eth = A.P.ethreshold;
     const int n_reads = A.n_dev ? min(*A.n_dev, A.batch.n) : A.batch.n;
@@ -1655,7 +1656,10 @@ __global__ __launch_bounds__(64, 4) void realign_band_kernel(RealignArgs A)
         if (a1.st) { if (lane == 0) out->reserved[6] = G.tmp[IM_MAX_OPS + 7]; finish(out, a1.st, 1, lane); continue; }
         if (q1 == q2) { finish(out, IM_ST_NONE, 1, lane); continue; }
         wave_lds_sync();
-        const uint32_t* c1 = G.ops[0]; const int n1 = uni(G.nops[0]);
+        const int n1 = uni(G.nops[0]);
+        if (lane < n1) c1_keep[lane] = G.ops[0][lane];
+        wave_lds_sync();
+        const uint32_t* c1 = c1_keep;
         if (q1 == 0 && q2 == L) {       // whole read aligned: evidence only from I/D ops inside the CIGAR (575-582)
             const int rs = band_build_result(out, G, r1, c1, n1, L, 0, -1, c1, 0, lane, A, c);
             finish(out, rs, 1, lane);

@@ -356,6 +356,7 @@ typedef struct {
      * thread decodes the BAM (pass A needs no GPU); gpu_wait() joins it before the first GPU call */
     pthread_t gpu_thread;
     int gpu_pending, gpu_rc;
+    pthread_mutex_t gpu_mu; pthread_cond_t gpu_cv; int seq_ready;      /* the helper opens the context at once and uploads the reference when the FASTA is in */
     char gpu_err[512];
     qhash* readpairs;
     const char* bam_name;
@@ -1262,11 +1263,15 @@ static void process_evidence(driver* d, int32_t tid, int marker, variant_list* o
         /* paired-read nodes: add_node's O(N^2) rule (src/graph.c:100-121), union-find for the components */
         int* parent = xmalloc(sizeof(int) * (size_t)npe);
         for (int i = 0; i < npe; i++) parent[i] = i;
+        /* the partners of e1 lie within the largest insert-length bound below it in (b1)-sorted order (see group_process_flush) */
+        int32_t widest = 0;
+        for (int j = 0; j < npe; j++) if (d->pending[keys[pe_pos[j]].idx]->max > widest) widest = d->pending[keys[pe_pos[j]].idx]->max;
         for (int j = 0; j < npe; j++) {
             const evidence_t* e1 = d->pending[keys[pe_pos[j]].idx];
-            for (int i = 0; i < j; i++) {
+            for (int i = j - 1; i >= 0; i--) {
                 const evidence_t* e2 = d->pending[keys[pe_pos[i]].idx];
                 forceassert(e2->b1 <= e1->b1);
+                if (e1->b1 - e2->b1 >= widest) break;
                 if (e2->b1 < e1->b2 && e1->cls == e2->cls) {
                     const int32_t bb1 = e1->b1 > e2->b1 ? e1->b1 : e2->b1;
                     const int32_t bb2 = e1->b2 < e2->b2 ? e1->b2 : e2->b2;
@@ -1608,6 +1613,9 @@ static void* gpu_open_thread(void* arg)
     const char* dev_env = getenv("INDELMINER_DEVICE");
     d->gpu_rc = im_ctx_create(dev_env ? atoi(dev_env) : (g_mg_local >= 0 ? g_mg_local : 0), &d->gpu);
     if (d->gpu_rc != IM_OK) { snprintf(d->gpu_err, sizeof d->gpu_err, "cannot open the GPU: %s", im_last_error(NULL)); return NULL; }
+    pthread_mutex_lock(&d->gpu_mu);
+    while (!d->seq_ready) pthread_cond_wait(&d->gpu_cv, &d->gpu_mu);
+    pthread_mutex_unlock(&d->gpu_mu);
     const char** seqs = xcalloc((size_t)d->hdr->n_targets, sizeof(char*));
     int64_t* lens = xcalloc((size_t)d->hdr->n_targets, sizeof(int64_t));
     for (int32_t i = 0; i < d->hdr->n_targets; i++) { seqs[i] = d->sequences[i] ? d->sequences[i] : ""; lens[i] = d->sequences[i] ? d->seqlen[i] : 0; }
@@ -1892,7 +1900,7 @@ static void mg_path(const mgpu* m, char* out, size_t cap, const char* what, int 
 #define PIPE_CHUNK_BYTES   (32u << 20)
 #define PIPE_CHUNK_RECS    (PIPE_CHUNK_BYTES / 64u)
 #define PIPE_NCHUNK        4
-#define PIPE_GROUP_RECORDS 3000000      /* a group closes at the first contig end past this many records */
+static int64_t PIPE_GROUP_RECORDS = 3000000;    /* a group closes at the first contig end past this many records (INDELMINER_GROUP_RECORDS) */
 
 typedef struct {
     uint8_t*  h_raw; uint32_t* h_off; int32_t* h_cnt;        /* pinned */
@@ -2220,8 +2228,6 @@ static void pipe_run_group(ppipe* P, pgroup* G)
 {
     driver* d = P->d;
     im_ctx* g = d->gpu;
-    pipe_submit(P, G);
-    pipe_drain(P, G);
     const int32_t nc = G->n_cand;
     if (G->n_pe > P->cap_pe || G->n_fl > P->cap_fl) {
         /* rare: more discordant pairs / flushes than the arrays were sized for */
@@ -2452,11 +2458,17 @@ static void group_process_flush(driver* d, pgroup* G, const gcontig* cg, int f, 
         qsort(pe, (size_t)npe, sizeof(evidence_t*), cmp_pe_sorted);
         int* parent = xmalloc(sizeof(int) * (size_t)npe);
         for (int i = 0; i < npe; i++) parent[i] = i;
+        /* add_node compares every pair (src/graph.c:94-121); an edge needs d2 = (e1.b1 - start of e2's first read) + ... < e2.max,
+         * and that first term alone is already >= e1.b1 - e2.b1: in (b1)-sorted order the partners of e1 lie within the largest
+         * insert-length bound below it, so the sweep stops there -- same edges, same components, without the N^2 */
+        int32_t widest = 0;
+        for (int j = 0; j < npe; j++) if (pe[j]->max > widest) widest = pe[j]->max;
         for (int j = 0; j < npe; j++) {
             const evidence_t* e1 = pe[j];
-            for (int i = 0; i < j; i++) {
+            for (int i = j - 1; i >= 0; i--) {
                 const evidence_t* e2 = pe[i];
                 forceassert(e2->b1 <= e1->b1);
+                if (e1->b1 - e2->b1 >= widest) break;
                 if (e2->b1 < e1->b2 && e1->cls == e2->cls) {
                     const int32_t bb1 = e1->b1 > e2->b1 ? e1->b1 : e2->b1;
                     const int32_t bb2 = e1->b2 < e2->b2 ? e1->b2 : e2->b2;
@@ -2616,6 +2628,76 @@ static void mg_allgather(mgpu* m, driver* d, const int32_t* mine, int32_t* all, 
 
 typedef struct { char name[48]; int32_t min, max, first_tid, first_rec; int seen; } mg_rg;
 
+/* One contig of the pre-walk: insert-length statistics per read group (estimate_insertlengths, src/bamoperations.c:15-86),
+ * counted reads, and the first mates left waiting in the pair table.  cw = the contig's MG_CTG_WORDS of an exchange buffer
+ * (NULL: statistics only).  Thread-safe: everything it touches is the caller's. */
+static void prewalk_contig(const driver* d, bgzf_reader* r, const bam_header* h, int32_t t, int estimate, mg_rg* rgs, int* pn_rg, int32_t* cw)
+{
+    int n_rg = *pn_rg;
+    bam_region_iter it;
+    if (bam_region_begin(&it, r, d->idx, t, 0, h->target_len[t]) != 0) return;
+    qhash* waiting = cw ? qhash_new(16) : NULL;         /* unpaired first mates of this contig: name -> {start, |isize|, rg} */
+    bam_record b; memset(&b, 0, sizeof b);
+    int64_t counted = 0;
+    int32_t rec = 0;
+    while (bam_region_next(&it, &b) == 1) {
+        const int flag = b.flag;
+        const int32_t this_rec = rec++;
+        if (estimate && (flag & 0x1) && !(flag & 0x4) && (flag & 0x2) && !(flag & (0x100 | 0x200 | 0x400)) &&
+            b.isize >= 0 && b.mpos - b.pos >= 0 && b.isize >= b.mpos - b.pos) {
+            const uint8_t* rg = bam_aux_find(&b, "RG");
+            const char* rgname = "generic";
+            if (rg) { forceassert(rg[0] == 'Z'); rgname = bam_aux_str(rg); }
+            int k = 0;
+            while (k < n_rg && strcmp(rgs[k].name, rgname) != 0) k++;
+            if (k == n_rg) {
+                if (n_rg == MG_MAX_RG || strlen(rgname) >= sizeof rgs[0].name) fatalf("at most %d read groups with names under %zu bytes are supported here", MG_MAX_RG, sizeof rgs[0].name);
+                snprintf(rgs[k].name, sizeof rgs[k].name, "%s", rgname);
+                rgs[k].min = rgs[k].max = b.isize; rgs[k].first_tid = t; rgs[k].first_rec = this_rec;
+                n_rg++;
+            } else {
+                if (rgs[k].min > b.isize) rgs[k].min = b.isize;
+                if (rgs[k].max < b.isize) rgs[k].max = b.isize;
+            }
+        }
+        if (!cw) continue;
+        if (flag & (0x100 | 0x200 | 0x400 | 0x800)) continue;
+        if (!(flag & 0x1)) continue;
+        const int aligned = !(flag & 0x4), mate_aligned = !(flag & 0x8);
+        if (aligned && mate_aligned && b.tid != b.mtid) continue;
+        counted++;
+        /* the pair table's bookkeeping, independent of range[1]: both mates of a pair carry the same |isize|, so the
+         * threshold |isize| > range[1] (src/indelminer.c:519) keeps or drops them together -- applied after the exchange */
+        if (aligned && mate_aligned && !(flag & 0x2) && ((flag & 0x10) != 0) != ((flag & 0x20) != 0) &&
+            (uint32_t)abs(b.isize) < O.maxpedelsize) {
+            const char* qname = BAMR_QNAME(&b);
+            if (b.pos < b.mpos) {
+                int32_t* v = xmalloc(3 * sizeof(int32_t));
+                const uint8_t* rg = bam_aux_find(&b, "RG");
+                const char* rgname = rg ? bam_aux_str(rg) : "generic";
+                v[0] = b.pos; v[1] = abs(b.isize);
+                v[2] = (int32_t)djb2_rev(rgname, (int)strlen(rgname));
+                qhash_add(waiting, qname, b.l_qname, v);
+            } else free(qhash_remove(waiting, qname, b.l_qname));
+        }
+    }
+    free(b.data);
+    *pn_rg = n_rg;
+    if (!cw) return;
+    cw[0] = (int32_t)(counted & 0xffffffff); cw[1] = (int32_t)(counted >> 32);
+    int n_left = 0;
+    for (uint32_t i = 0; i <= waiting->mask; i++)
+        for (qbin* q = waiting->bins[i]; q; q = q->next) {
+            const int32_t* v = q->val;
+            /* keep the MG_MAX_LEFT smallest starts */
+            int pos = n_left < MG_MAX_LEFT ? n_left++ : -1;
+            if (pos < 0) { int worst = 0; for (int k = 1; k < MG_MAX_LEFT; k++) if (cw[4 + 3 * k] > cw[4 + 3 * worst]) worst = k; if (v[0] < cw[4 + 3 * worst]) pos = worst; }
+            if (pos >= 0) { cw[4 + 3 * pos] = v[0]; cw[5 + 3 * pos] = v[1]; cw[6 + 3 * pos] = v[2]; }
+        }
+    cw[2] = n_left;
+    qhash_free(waiting, free);
+}
+
 /* The pre-walk over this rank's contigs.  Fills this rank's words of the exchange buffer. */
 static void mg_prewalk(mgpu* m, driver* d, int estimate, int32_t* mine, size_t words)
 {
@@ -2625,71 +2707,12 @@ static void mg_prewalk(mgpu* m, driver* d, int estimate, int32_t* mine, size_t w
     bgzf_reader* r = bgzf_open(d->bam_name);
     if (!r) fatalf("error in opening the file %s", d->bam_name);
     bam_header* h = bam_header_load(r);
-    bam_record b; memset(&b, 0, sizeof b);
     for (int32_t t = m->rank; t < h->n_targets; t += m->world) {
         int32_t* cw = mine + 2 + MG_MAX_RG * MG_RG_WORDS + (size_t)t * MG_CTG_WORDS;
         cw[3] = 1;                                      /* walked by this rank */
         if (m->skip && m->skip[t]) continue;
-        bam_region_iter it;
-        if (bam_region_begin(&it, r, d->idx, t, 0, h->target_len[t]) != 0) continue;
-        qhash* waiting = qhash_new(16);                 /* unpaired first mates of this contig: name -> {start, |isize|, rg} */
-        int64_t counted = 0;
-        int32_t rec = 0;
-        while (bam_region_next(&it, &b) == 1) {
-            const int flag = b.flag;
-            const int32_t this_rec = rec++;
-            if (estimate && (flag & 0x1) && !(flag & 0x4) && (flag & 0x2) && !(flag & (0x100 | 0x200 | 0x400)) &&
-                b.isize >= 0 && b.mpos - b.pos >= 0 && b.isize >= b.mpos - b.pos) {
-                /* estimate_insertlengths (src/bamoperations.c:15-86) */
-                const uint8_t* rg = bam_aux_find(&b, "RG");
-                const char* rgname = "generic";
-                if (rg) { forceassert(rg[0] == 'Z'); rgname = bam_aux_str(rg); }
-                int k = 0;
-                while (k < n_rg && strcmp(rgs[k].name, rgname) != 0) k++;
-                if (k == n_rg) {
-                    if (n_rg == MG_MAX_RG || strlen(rgname) >= sizeof rgs[0].name) fatalf("multi-GPU runs take at most %d read groups with names under %zu bytes", MG_MAX_RG, sizeof rgs[0].name);
-                    snprintf(rgs[k].name, sizeof rgs[k].name, "%s", rgname);
-                    rgs[k].min = rgs[k].max = b.isize; rgs[k].first_tid = t; rgs[k].first_rec = this_rec;
-                    n_rg++;
-                } else {
-                    if (rgs[k].min > b.isize) rgs[k].min = b.isize;
-                    if (rgs[k].max < b.isize) rgs[k].max = b.isize;
-                }
-            }
-            if (flag & (0x100 | 0x200 | 0x400 | 0x800)) continue;
-            if (!(flag & 0x1)) continue;
-            const int aligned = !(flag & 0x4), mate_aligned = !(flag & 0x8);
-            if (aligned && mate_aligned && b.tid != b.mtid) continue;
-            counted++;
-            /* the pair table's bookkeeping, independent of range[1]: both mates of a pair carry the same |isize|, so the
-             * threshold |isize| > range[1] (src/indelminer.c:519) keeps or drops them together -- applied after the exchange */
-            if (aligned && mate_aligned && !(flag & 0x2) && ((flag & 0x10) != 0) != ((flag & 0x20) != 0) &&
-                (uint32_t)abs(b.isize) < O.maxpedelsize) {
-                const char* qname = BAMR_QNAME(&b);
-                if (b.pos < b.mpos) {
-                    int32_t* v = xmalloc(3 * sizeof(int32_t));
-                    const uint8_t* rg = bam_aux_find(&b, "RG");
-                    const char* rgname = rg ? bam_aux_str(rg) : "generic";
-                    v[0] = b.pos; v[1] = abs(b.isize);
-                    v[2] = (int32_t)djb2_rev(rgname, (int)strlen(rgname));
-                    qhash_add(waiting, qname, b.l_qname, v);
-                } else free(qhash_remove(waiting, qname, b.l_qname));
-            }
-        }
-        cw[0] = (int32_t)(counted & 0xffffffff); cw[1] = (int32_t)(counted >> 32);
-        int n_left = 0;
-        for (uint32_t i = 0; i <= waiting->mask; i++)
-            for (qbin* q = waiting->bins[i]; q; q = q->next) {
-                const int32_t* v = q->val;
-                /* keep the MG_MAX_LEFT smallest starts */
-                int pos = n_left < MG_MAX_LEFT ? n_left++ : -1;
-                if (pos < 0) { int worst = 0; for (int k = 1; k < MG_MAX_LEFT; k++) if (cw[4 + 3 * k] > cw[4 + 3 * worst]) worst = k; if (v[0] < cw[4 + 3 * worst]) pos = worst; }
-                if (pos >= 0) { cw[4 + 3 * pos] = v[0]; cw[5 + 3 * pos] = v[1]; cw[6 + 3 * pos] = v[2]; }
-            }
-        cw[2] = n_left;
-        qhash_free(waiting, free);
+        prewalk_contig(d, r, h, t, estimate, rgs, &n_rg, cw);
     }
-    free(b.data);
     bam_header_free(h);
     bgzf_close(r);
     mine[0] = 0x4d47; mine[1] = n_rg;
@@ -2709,6 +2732,63 @@ static int cmp_mg_rg(const void* x, const void* y)
     return 0;
 }
 
+/* read groups met in several places -> one list in the order ONE sequential pass would have met them */
+static int merge_rgs(mg_rg* all, int n_all, mg_rg* out)
+{
+    int n = 0;
+    for (int i = 0; i < n_all; i++) {
+        int j = 0;
+        while (j < n && strcmp(out[j].name, all[i].name) != 0) j++;
+        if (j == n) out[n++] = all[i];
+        else {
+            if (all[i].min < out[j].min) out[j].min = all[i].min;
+            if (all[i].max > out[j].max) out[j].max = all[i].max;
+            if (all[i].first_tid < out[j].first_tid || (all[i].first_tid == out[j].first_tid && all[i].first_rec < out[j].first_rec)) { out[j].first_tid = all[i].first_tid; out[j].first_rec = all[i].first_rec; }
+        }
+    }
+    qsort(out, (size_t)n, sizeof(mg_rg), cmp_mg_rg);
+    return n;
+}
+
+/* estimate_insertlengths (src/bamoperations.c:15-86) with the contigs spread over threads: the pass is pure decode + a
+ * min / max per read group, so contigs are independent and the per-thread tables merge exactly (read groups enter the table
+ * in the order of their first record in the file, as in a single pass; names that are prefixes of one another and share a
+ * hash bin would alias in the reference's lookup -- not reproduced across threads) */
+typedef struct { const driver* d; int t0, step; mg_rg rgs[MG_MAX_RG]; int n_rg; } est_job;
+static void* est_thread(void* arg)
+{
+    est_job* j = arg;
+    bgzf_reader* r = bgzf_open(j->d->bam_name);
+    if (!r) fatalf("error in opening the file %s", j->d->bam_name);
+    bam_header* h = bam_header_load(r);
+    for (int32_t t = j->t0; t < h->n_targets; t += j->step) prewalk_contig(j->d, r, h, t, 1, j->rgs, &j->n_rg, NULL);
+    bam_header_free(h);
+    bgzf_close(r);
+    return NULL;
+}
+static void estimate_insertlengths_threads(driver* d)
+{
+    const char* e = getenv("INDELMINER_WALKERS");
+    int nt = e ? atoi(e) : 8;
+    if (nt > d->hdr->n_targets) nt = d->hdr->n_targets;
+    if (nt < 1) nt = 1;
+    est_job* jobs = xcalloc((size_t)nt, sizeof(est_job));
+    pthread_t* th = xmalloc(sizeof(pthread_t) * (size_t)nt);
+    for (int i = 0; i < nt; i++) { jobs[i].d = d; jobs[i].t0 = i; jobs[i].step = nt; if (pthread_create(&th[i], NULL, est_thread, &jobs[i]) != 0) fatalf("cannot start an estimation thread"); }
+    mg_rg* all = xcalloc((size_t)nt * MG_MAX_RG, sizeof(mg_rg));
+    int n_all = 0;
+    for (int i = 0; i < nt; i++) { pthread_join(th[i], NULL); for (int k = 0; k < jobs[i].n_rg; k++) all[n_all++] = jobs[i].rgs[k]; }
+    mg_rg* merged = xcalloc((size_t)(n_all ? n_all : 1), sizeof(mg_rg));
+    const int n = merge_rgs(all, n_all, merged);
+    for (int j = 0; j < n; j++) {
+        int32_t* range = xmalloc(2 * sizeof(int32_t));
+        range[0] = merged[j].min; range[1] = merged[j].max;
+        qhash_add(d->insertlengths, merged[j].name, (int)strlen(merged[j].name), range);
+        rg_order_push(merged[j].name, range);
+    }
+    free(all); free(merged); free(jobs); free(th);
+}
+
 /* exchange + merge: the insert-length table (when estimated), the counter prefix and the marker floor of every contig */
 static void mg_exchange(mgpu* m, driver* d, int estimate)
 {
@@ -2720,25 +2800,21 @@ static void mg_exchange(mgpu* m, driver* d, int estimate)
     phase_time("pre-walk of this rank's contigs (count, unpaired mates, insert lengths)");
     mg_allgather(m, d, mine, all, words);
     if (estimate) {
-        mg_rg* rgs = xcalloc((size_t)MG_MAX_RG * (size_t)m->world, sizeof(mg_rg));
-        int n = 0;
+        mg_rg* got = xcalloc((size_t)MG_MAX_RG * (size_t)m->world, sizeof(mg_rg));
+        int n_got = 0;
         for (int rk = 0; rk < m->world; rk++) {
             const int32_t* a = all + (size_t)rk * words;
             forceassert(a[0] == 0x4d47);
             for (int k = 0; k < a[1]; k++) {
                 const int32_t* w = a + 2 + (size_t)k * MG_RG_WORDS;
-                char name[48]; memcpy(name, w, 48); name[47] = 0;
-                int j = 0;
-                while (j < n && strcmp(rgs[j].name, name) != 0) j++;
-                if (j == n) { snprintf(rgs[j].name, sizeof rgs[j].name, "%s", name); rgs[j].min = w[12]; rgs[j].max = w[13]; rgs[j].first_tid = w[14]; rgs[j].first_rec = w[15]; n++; }
-                else {
-                    if (w[12] < rgs[j].min) rgs[j].min = w[12];
-                    if (w[13] > rgs[j].max) rgs[j].max = w[13];
-                    if (w[14] < rgs[j].first_tid || (w[14] == rgs[j].first_tid && w[15] < rgs[j].first_rec)) { rgs[j].first_tid = w[14]; rgs[j].first_rec = w[15]; }
-                }
+                mg_rg* g = &got[n_got++];
+                memcpy(g->name, w, 48); g->name[47] = 0;
+                g->min = w[12]; g->max = w[13]; g->first_tid = w[14]; g->first_rec = w[15];
             }
         }
-        qsort(rgs, (size_t)n, sizeof(mg_rg), cmp_mg_rg);        /* the order in which one process would have met them */
+        mg_rg* rgs = xcalloc((size_t)(n_got ? n_got : 1), sizeof(mg_rg));
+        const int n = merge_rgs(got, n_got, rgs);          /* the order in which one process would have met them */
+        free(got);
         for (int j = 0; j < n; j++) {
             int32_t* range = xmalloc(2 * sizeof(int32_t));
             range[0] = rgs[j].min; range[1] = rgs[j].max;
@@ -2798,33 +2874,81 @@ static void mg_finish(mgpu* m, driver* d)
     im_comm_destroy(m->comm);
 }
 
-static void run_pipeline(driver* d, bgzf_reader* r)
+/* The walk of group g + 1 (inflate, count, pair table, triage launches: one thread's worth of host work) runs beside
+ * the replay of group g (evidence objects, merge, print: another thread's worth): two buffers of group state, the
+ * device arrays handed back and forth.  Order of output is the order of the groups. */
+typedef struct {
+    ppipe* P; driver* d; bgzf_reader* r;
+    pgroup G[2];
+    pthread_mutex_t mu; pthread_cond_t cv;
+    int walked, device_free, replayed, done;
+} overlap_t;
+
+static void* walker_thread(void* arg)
 {
-    ppipe P; pgroup G;
-    memset(&P, 0, sizeof P); memset(&G, 0, sizeof G);
-    P.d = d;
-    d->pipe_mode = 1;
-    pipe_init(&P, d);               /* the records are inflated into pinned chunks: the GPU context comes first */
+    overlap_t* o = arg;
+    driver* d = o->d; ppipe* P = o->P;
+    const int serial = g_vcfname != NULL;               /* annotate mode shares the known-variant list with the replay */
+    int gi = 0, open_group = 0;
     for (int32_t i = 0; i < d->hdr->n_targets; i++) {
         if (g_mg && i % g_mg->world != g_mg->rank) continue;       /* another rank's contig */
+        if (!open_group) {
+            pthread_mutex_lock(&o->mu);
+            while (o->device_free < gi || o->replayed < (serial ? gi : gi - 1)) pthread_cond_wait(&o->cv, &o->mu);
+            pthread_mutex_unlock(&o->mu);
+            open_group = 1;
+        }
+        pgroup* G = &o->G[gi & 1];
         if (g_vcfname != NULL) {
             known_free(&g_known);
             read_variants(g_vcfname, i, d->hdr->target_name[i], &g_known);
             if (g_known.n == 0) continue;           /* src/indelminer.c:788 */
         }
         if (g_mg) { d->numread = g_mg->prefix[i]; d->marker_floor = g_mg->floor[i]; }   /* where the single run would stand */
-        pipe_walk_contig(&P, &G, i, r);
-        phase_time("walk (inflate + count + pair table; triage on the device)");
-        const int last = i + (g_mg ? g_mg->world : 1) >= d->hdr->n_targets;
-        if (g_vcfname != NULL || last || G.n_rec >= PIPE_GROUP_RECORDS) {
-            pipe_run_group(&P, &G);
-            group_replay(d, &G);
-            group_reset(&G);
+        pipe_walk_contig(P, G, i, o->r);
+        if (g_vcfname != NULL || G->n_rec >= PIPE_GROUP_RECORDS) {
+            pipe_submit(P, G);
+            pipe_drain(P, G);
+            pthread_mutex_lock(&o->mu); o->walked = ++gi; pthread_cond_broadcast(&o->cv); pthread_mutex_unlock(&o->mu);
+            open_group = 0;
         }
     }
-    if (G.n_ctg > 0) { pipe_run_group(&P, &G); group_replay(d, &G); }
+    if (open_group && o->G[gi & 1].n_ctg > 0) { pipe_submit(P, &o->G[gi & 1]); pipe_drain(P, &o->G[gi & 1]); gi++; }
+    pthread_mutex_lock(&o->mu); o->walked = gi; o->done = 1; pthread_cond_broadcast(&o->cv); pthread_mutex_unlock(&o->mu);
+    return NULL;
+}
+
+static void run_pipeline(driver* d, bgzf_reader* r)
+{
+    ppipe P;
+    memset(&P, 0, sizeof P);
+    P.d = d;
+    d->pipe_mode = 1;
+    if (getenv("INDELMINER_GROUP_RECORDS")) PIPE_GROUP_RECORDS = atoll(getenv("INDELMINER_GROUP_RECORDS"));
+    pipe_init(&P, d);               /* the records are inflated into pinned chunks: the GPU context comes first */
+    overlap_t* o = xcalloc(1, sizeof *o);
+    o->P = &P; o->d = d; o->r = r;
+    pthread_mutex_init(&o->mu, NULL); pthread_cond_init(&o->cv, NULL);
+    pthread_t th;
+    if (pthread_create(&th, NULL, walker_thread, o) != 0) fatalf("cannot start the walking thread");
+    for (int gi = 0;; gi++) {
+        pthread_mutex_lock(&o->mu);
+        while (o->walked <= gi && !o->done) pthread_cond_wait(&o->cv, &o->mu);
+        const int have = o->walked > gi;
+        pthread_mutex_unlock(&o->mu);
+        if (!have) break;
+        phase_time("waited for the walk (inflate + count + pair table; triage on the device)");
+        pgroup* G = &o->G[gi & 1];
+        pipe_run_group(&P, G);
+        pthread_mutex_lock(&o->mu); o->device_free = gi + 1; pthread_cond_broadcast(&o->cv); pthread_mutex_unlock(&o->mu);
+        group_replay(d, G);
+        group_reset(G);
+        pthread_mutex_lock(&o->mu); o->replayed = gi + 1; pthread_cond_broadcast(&o->cv); pthread_mutex_unlock(&o->mu);
+    }
+    pthread_join(th, NULL);
     pipe_destroy(&P);
-    group_free(&G);
+    group_free(&o->G[0]); group_free(&o->G[1]);
+    free(o);
 }
 
 /* -------------------------------------------------------------------- main -- */
@@ -2976,8 +3100,14 @@ int main(int argc, char** argv)
     }
     d.marker_floor = INT_MAX;
 
+    /* the GPU: one context, opened by a helper thread while this thread reads the BAM (insert lengths) and the FASTA --
+     * HIP start-up is 0.15-0.3 s of nothing but waiting */
+    pthread_mutex_init(&d.gpu_mu, NULL); pthread_cond_init(&d.gpu_cv, NULL);
+    d.gpu_pending = 1;
+    if (pthread_create(&d.gpu_thread, NULL, gpu_open_thread, &d) != 0) fatalf("cannot start the GPU helper thread");
+
     if (O.configfile) read_configuration(O.configfile, d.insertlengths);
-    else if (!g_mg) estimate_insertlengths(&d, chromid);
+    else if (!g_mg) { if (chromid == -1 && !getenv("INDELMINER_ESTIMATE_SERIAL")) estimate_insertlengths_threads(&d); else estimate_insertlengths(&d, chromid); }
     fprintf(stderr, "\nRead-group\tMin-value\tMax-value\n----------\t---------\t---------\n");
     for (uint32_t i = 0; i <= d.insertlengths->mask; i++)
         for (qbin* it = d.insertlengths->bins[i]; it; it = it->next)
@@ -2992,9 +3122,11 @@ int main(int argc, char** argv)
     timestamp("Read the reference sequence");
     phase_time("read FASTA");
 
-    /* the GPU: one context, reference resident in HBM -- opened beside the BAM decode */
-    d.gpu_pending = 1;
-    if (pthread_create(&d.gpu_thread, NULL, gpu_open_thread, &d) != 0) fatalf("cannot start the GPU helper thread");
+    /* the reference is in: the GPU helper (started before the insert-length pass) uploads it */
+    pthread_mutex_lock(&d.gpu_mu);
+    d.seq_ready = 1;
+    pthread_cond_signal(&d.gpu_cv);
+    pthread_mutex_unlock(&d.gpu_mu);
 
 
     /* whole-contig runs take the device pipeline; region runs (-c) keep the per-contig host path, whose

@@ -74,7 +74,7 @@ class Reads:
 
 def simulate(seed, ref_len=1_000_000, coverage=30, read_len=100, isize_mean=500, isize_sd=50,
              isize_min=300, isize_max=700, sub_rate=0.005, indel_spacing=2000, n_contigs=1, big_every=0,
-             read_seed=None, somatic_spacing=0):
+             read_seed=None, somatic_spacing=0, ref_lens=None):
     """Returns (refs, reads): refs = list of uint8 arrays (one per contig); reads = Reads.
     `seed` fixes the reference and its (germline) indels; `read_seed` (default: derived from seed)
     the sampled pairs; somatic_spacing > 0 adds extra indels about every that many bases, drawn from
@@ -86,7 +86,11 @@ def simulate(seed, ref_len=1_000_000, coverage=30, read_len=100, isize_mean=500,
     refs = []
     cols = {k: [] for k in ("tid", "pos", "flag", "mpos", "isize", "seq", "cig_op", "cig_len", "ncig", "mate_first", "pair_id")}
     pair_base = 0
+    if ref_lens is not None:            # one length per contig (human-like spreads, BASELINE config 4)
+        n_contigs = len(ref_lens)
     for tid in range(n_contigs):
+        if ref_lens is not None:
+            ref_len = int(ref_lens[tid])
         ref = random_genome(rng, ref_len)
         refs.append(ref)
         epos, esize, eins = plant_indels(rng, ref_len, indel_spacing, big_every=big_every)

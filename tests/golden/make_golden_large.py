@@ -23,6 +23,12 @@ REF_BIN = os.path.join(ROOT, "oracle", "_ref", "indelminer")
 LARGE = {
     # BASELINE configs[2]: 50 Mb in 8 contigs, 30x 100 bp PE; every seventh planted event a 150-900 bp deletion
     "config3": dict(sim=dict(seed=2, ref_len=6_250_000, coverage=30, n_contigs=8, big_every=7), flags=[]),
+    # the distinguishing properties of BASELINE configs[3] (3 Gb / 24 contigs) at low coverage: 24 contigs with a human-like
+    # length spread, the longest above 2^27 bases, the reference above 2^31 bytes in total (64-bit offsets on the device),
+    # the read counter carried over all 24 contigs; coverage 0.01x and sparse events keep the reference's per-candidate
+    # strlen of the contig (src/alignment.c:771) affordable
+    "config4like": dict(sim=dict(seed=3, ref_lens=[140_000_000 - 3_900_000 * i for i in range(24)], coverage=0.01,
+                                 indel_spacing=5_000, big_every=7), flags=["-e", "1"]),      # support 1 is enough at this depth
 }
 
 
