@@ -305,7 +305,9 @@ int im_set_insert_ranges(im_ctx* ctx, int32_t n, const char* const* names, const
 
 /* A chunk of delivered records on the device: each record is the 32-byte BAM core followed by its
  * variable part (qname, cigar, seq, qual, aux) exactly as in the file, WITHOUT the block_size word,
- * starting at a 4-byte aligned offset.  rec_off has n + 1 entries. */
+ * starting at a 4-byte aligned offset.  rec_off has n + 1 entries; record i spans rec_off[i]..rec_off[i+1], which may
+ * include up to three bytes of alignment padding behind the aux area: the tag walk treats a tail shorter than the
+ * smallest possible field (tag, type, one value byte = 4 bytes) as the end of the record. */
 typedef struct im_dev_records {
     int32_t         n;
     const uint8_t*  raw;

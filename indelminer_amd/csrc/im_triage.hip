@@ -101,7 +101,7 @@ __device__ __forceinline__ void find_rg_mq(const RecView& r, const AuxWin& w, ui
     o_rg = 0; o_mq = 0;
     uint32_t s = r.o_aux;
     const uint32_t end = r.len;
-    while (s + 3u <= end) {
+    while (s + 4u <= end) {      // a tail of < 4 bytes is alignment padding (include/indelminer_amd.h, im_dev_records)
         const uint32_t t0 = rec_byte(r, w, s), t1 = rec_byte(r, w, s + 1), type = rec_byte(r, w, s + 2);
         if (t0 == 'R' && t1 == 'G' && !o_rg) o_rg = s + 2u;
         if (t0 == 'M' && t1 == 'Q' && !o_mq) o_mq = s + 2u;

@@ -372,7 +372,7 @@ const uint8_t* bam_aux_find(const bam_record* b, const char tag[2])
 {
     const uint8_t* s = BAMR_AUX(b);
     const uint8_t* end = b->data + b->l_data;
-    while (s + 3 <= end) {
+    while (s + 4 <= end) {        /* the shortest field is 4 bytes; views of padded records end with up to 3 spare ones */
         const int hit = (s[0] == (uint8_t)tag[0] && s[1] == (uint8_t)tag[1]);
         const int type = s[2];
         const uint8_t* v = s + 2;

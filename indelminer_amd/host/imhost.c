@@ -2194,6 +2194,7 @@ static void pipe_walk_contig(ppipe* P, pgroup* G, int32_t tid, bgzf_reader* r)
         if (rc < 0) fatalf("error while reading %s", d->bam_name);
         if (rc == 0) break;
         c->h_off[c->n++] = c->bytes;
+        for (uint32_t z = (uint32_t)len; z & 3u; z++) c->h_raw[c->bytes + z] = 0;
         c->bytes += ((uint32_t)len + 3u) & ~3u;
         c->seq_bytes += ((int64_t)b.l_seq + 3) & ~(int64_t)3;
         G->n_rec++;

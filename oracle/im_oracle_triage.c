@@ -46,7 +46,7 @@ static int parse(const uint8_t* p, uint32_t len, rec_t* r)
 static const uint8_t* aux_get(const rec_t* r, char a, char b)
 {
     const uint8_t* s = r->aux;
-    while (s + 3 <= r->end) {
+    while (s + 4 <= r->end) {        /* a tail of < 4 bytes is alignment padding (im_dev_records), not a field */
         const int match = s[0] == (uint8_t)a && s[1] == (uint8_t)b;
         const uint8_t* val = s + 2;
         const int type = s[2];

@@ -26,9 +26,13 @@ with tempfile.TemporaryDirectory() as td:
     rawrec.write_bam_fast(td + "/aln.bam", contigs, rd)
     print("BAM written in %.1f s, %d bytes" % (time.perf_counter() - t, os.path.getsize(td + "/aln.bam")), flush=True)
     cmd = ["ref.fa", "s=aln.bam"]
-    t = time.perf_counter()
-    p = subprocess.run([build.HOST_BIN] + cmd, cwd=td, stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=dict(os.environ, INDELMINER_TIMING="1"))
-    tp = time.perf_counter() - t
+    tp = None
+    for _ in range(int(os.environ.get("E2E_REPEAT", "1"))):      # the first run also pages the binary and the inputs in
+        t = time.perf_counter()
+        p = subprocess.run([build.HOST_BIN] + cmd, cwd=td, stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=dict(os.environ, INDELMINER_TIMING="1"))
+        dt = time.perf_counter() - t
+        print("product run: %.2f s" % dt, flush=True)
+        tp = dt if tp is None else min(tp, dt)
     body = [l for l in p.stdout.splitlines() if not l.startswith(b"#")]
     print("product   rc %d  %.2f s  %d VCF records (%d COMPOSITE, %d PAIRED_READ only)" %
           (p.returncode, tp, len(body), sum(b"COMPOSITE" in l for l in body), sum(b"PAIRED_READ" in l and b"COMPOSITE" not in l for l in body)), flush=True)

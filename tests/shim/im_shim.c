@@ -351,7 +351,7 @@ int im_dev_cluster_groupby(im_ctx* c, int32_t n_slots, const int32_t* cls, const
 #include <time.h>
 #include <unistd.h>
 struct im_comm { int rank, world, seq; char dir[200]; };
-static char g_comm_err[256] = "";
+static char g_comm_err[1024] = "";
 const char* im_comm_last_error(void) { return g_comm_err; }
 void* im_ctx_stream(im_ctx* c) { (void)c; return NULL; }
 int im_comm_unique_id(void* id_bytes)

@@ -1,7 +1,11 @@
 """BASELINE configs[2] at full size through the product driver on one MI355X: 8 contigs x 6.25 Mb, 30x,
 15 M reads, every seventh planted event a 150-900 bp deletion (COMPOSITE calls), crossing ~150 READCHUNK
 flushes with the global read counter carried over the contigs (src/indelminer.c:617,764).  The expected
-digest was made by the reference itself in the build container (tests/golden/make_golden_large.py)."""
+digest was made by the reference itself in the build container (tests/golden/make_golden_large.py).
+
+config4like carries what distinguishes BASELINE configs[3] (3 Gb, 24 contigs) at a coverage the reference can finish:
+24 contigs with a human-like length spread, the longest above 2^27 bases, 2.28e9 reference bytes in total -- past
+2^31, so every contig offset on the device is 64-bit -- and the read counter carried over all 24 contigs."""
 import hashlib
 import importlib.util
 import json
@@ -23,7 +27,7 @@ def _mg():
     return m
 
 
-@pytest.mark.parametrize("name", ["config3"])
+@pytest.mark.parametrize("name", ["config3", "config4like"])
 def test_large_config_matches_reference_digest(tmp_path, name):
     from indelminer_amd import build
     mg = _mg()

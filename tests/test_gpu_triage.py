@@ -95,11 +95,11 @@ def test_triage_matches_oracle_test_data(gpu_ctx, golden_dir):
         assert len(cand) == (697 if q == 10 else 703)
 
 
-def _rec(flag, tid=0, pos=100, mtid=0, mpos=300, isize=300, mapq=60, cigar=((100, 0),), seq=None, tags=b"", qname=b"q\0", l_seq=100):
+def _rec(flag, tid=0, pos=100, mtid=0, mpos=300, isize=300, mapq=60, cigar=((100, 0),), seq=None, tags=b"", qname=b"q\0", l_seq=100, pad=b"\0\0\0"):
     seq = seq if seq is not None else bytes([0x12] * ((l_seq + 1) // 2))
     cig = b"".join(struct.pack("<I", (l << 4) | o) for l, o in cigar)
     body = struct.pack("<iiBBHHHiiii", tid, pos, len(qname), mapq, 0, len(cigar), flag, l_seq, mtid, mpos, isize) + qname + cig + seq + b"\x28" * l_seq + tags
-    return body + b"\0" * ((-len(body)) % 4)
+    return body + pad[:(-len(body)) % 4]
 
 
 def test_triage_edge_records(gpu_ctx):
@@ -126,6 +126,7 @@ def test_triage_edge_records(gpu_ctx):
         _rec(0x1 | 0x20, isize=2000000), _rec(P, cigar=S, seq=bytes([0x13] * 50)), _rec(P, cigar=S, l_seq=33, seq=bytes([0x48] * 17)),
         _rec(P, cigar=((20, 4), (13, 0)), l_seq=33, seq=bytes([0x48] * 17)), _rec(P | 0x10 | 0x20, cigar=((20, 4), (13, 0)), l_seq=33, seq=bytes([0x84, 0x21] * 8 + [0xf0])),
         _rec(P, cigar=S)[:60],                                                                                     # truncated record
+        _rec(P, cigar=S, qname=b"qq\0", tags=b"MQC\x0a", pad=b"RGZ"), _rec(P, cigar=S, qname=b"qqq\0", pad=b"MQ"),   # alignment padding is no aux field
     ]
     raw = np.frombuffer(b"".join(recs), dtype=np.uint8).copy()
     off = np.zeros(len(recs) + 1, dtype=np.uint32)
