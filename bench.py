@@ -457,6 +457,55 @@ def cpu_port_baseline(ref, cand, read_len, n_reads_total, m):
             "candidates_per_s": m / dt}
 
 
+def shard3_measure(device, steps=24, warmup=4):
+    """The same device pass on ONE GPU's share of BASELINE configs[2] (a 6.25 Mb contig at 30x, every seventh planted event a
+    150-900 bp deletion: 1.9 M delivered reads, ~76 k candidates, ~19 READCHUNK flushes per step): the launch sizes a real
+    per-GPU shard gives, beside the configs[1] step `value` is quoted on."""
+    L = 100
+    refs, rd = synth.simulate(seed=2, ref_len=6_250_000, coverage=30, read_len=L, big_every=7)
+    cand = synth.candidates(rd)
+    ctx = capi.Context(device)
+    try:
+        ctx.set_reference([refs[0].tobytes()])
+        ctx.set_insert_ranges(["generic"], [rd.range_max])
+        ps = PipeStep(ctx, rd, PIPELINE_DEPTH)
+        ps.step(); ps.sync()
+        c0, _, _ = ps.results()
+        assert int(c0[0]) == len(cand["index"]) and int(c0[3]) == 0 and int(c0[4]) == 0, c0
+        ps.capture()
+        for _ in range(warmup):
+            ps.step()
+        ps.sync()
+        p0 = ps.sets[0]["pipe"]
+        timers = [(capi.Timer(ctx), p0.realign_call_index if (i // 4) % 2 == 0 else p0.triage_call_index) if i % 4 == 0 else (None, None)
+                  for i in range(steps)]
+        t0 = time.perf_counter()
+        for i in range(steps):
+            ps.step(timers[i][0], timers[i][1])
+        ps.sync()
+        elapsed = time.perf_counter() - t0
+        realign_ms = np.array([tm.elapsed_ms() for tm, at in timers if tm is not None and at == p0.realign_call_index])
+        triage_ms = np.array([tm.elapsed_ms() for tm, at in timers if tm is not None and at == p0.triage_call_index])
+        cnt, res, counts = ps.results()
+        alg = algorithmic_bytes(res)
+        n_band = int(res["n_band"].sum())
+        tri_bytes = ps.record_bytes + 4 * (rd.n + 1) + rd.n + len(cand["index"]) * (((L + 3) // 4) * 4 + 24 + 48)
+        ach = alg / (float(realign_ms.mean()) * 1e-3) / 1e9
+        return {"workload": "one GPU's share of BASELINE configs[2]: 6.25 Mb contig, 30x, big_every=7",
+                "reads_per_step": int(rd.n), "candidates_per_step": int(len(cand["index"])), "flushes_per_step": len(ps.flushes),
+                "evidence_nodes_per_step": int(counts[1]), "clusters_per_step": int(counts[0]),
+                "steps": steps, "ms_per_step": elapsed / steps * 1e3, "reads_per_s": rd.n * steps / elapsed,
+                "candidates_per_s": len(cand["index"]) * steps / elapsed,
+                "band_alignments_per_s": n_band * steps / elapsed, "gcups": 2.0 * L * n_band * steps / elapsed / 1e9,
+                "realign": {"avg_launch_ms": float(realign_ms.mean()), "algorithmic_bytes_per_launch": alg, "achieved_gbs": ach,
+                            "frac_of_hbm_peak": ach / HBM_PEAK_GBS,
+                            "occupancy_rounds": len(cand["index"]) / (256.0 * 24)},
+                "triage": {"avg_ms_3_launches": float(triage_ms.mean()), "algorithmic_bytes_per_launch": int(tri_bytes),
+                           "achieved_gbs": tri_bytes / (float(triage_ms.mean()) * 1e-3) / 1e9}}
+    finally:
+        ctx.close()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -466,6 +515,7 @@ def main():
     ap.add_argument("--coverage", type=float, default=30.0)
     ap.add_argument("--big-every", type=int, default=0, help="every k-th planted event a 150-900 bp deletion (config-3 style shards)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-shard3", action="store_true", help="skip the config-3 per-GPU shard measurement (N=1 only)")
     args = ap.parse_args()
 
     # stdout carries ONE JSON line and nothing else: gloo ("[Gloo] Rank 0 is connected ...") and librccl (its
@@ -669,6 +719,11 @@ def main():
             "cpu_baseline_hoisted": cpu_port,
             "end_to_end": e2e,
         }
+        if world == 1 and not args.no_shard3:
+            try:
+                line["shard_config3"] = shard3_measure(0 if os.environ.get("IM_BENCH_ONE_DEVICE") == "1" else local_rank)
+            except Exception as ex:
+                line["shard_config3"] = {"error": str(ex)}
         sys.stdout.flush()
         os.write(real_stdout, (json.dumps(line) + "\n").encode())
     if comm is not None:

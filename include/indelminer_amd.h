@@ -53,6 +53,7 @@ extern "C" {
 #define IM_OP_X  8
 
 #define IM_MAX_READ  255        /* longest read the kernels take                     */
+#define IM_MAX_SW_TARGET 4095   /* longest annotate-mode window (reference span + variant) im_support_batch takes */
 #define IM_MAX_OPS   64         /* packed segment words per realigned read           */
 #define IM_MAX_EV    4          /* indel segments (= evidence) per realigned read    */
 
@@ -185,7 +186,7 @@ int im_depth_query(im_ctx* ctx, int32_t n, const int32_t* beg, const int32_t* en
  * the caller exactly as 1260-1272 do) and returns the three counts check_for_indel compares with
  * the read's existing alignment (1549-1553): substitutions, inserted+deleted bases, aligned bases.
  * targets/queries: concatenated bytes with n+1 offsets.  out: n x 4 int32 {subs, indels, aligned,
- * status (IM_ST_EVIDENCE = valid, IM_ST_UNSUPPORTED = target longer than 4095 or query longer
+ * status (IM_ST_EVIDENCE = valid, IM_ST_UNSUPPORTED = target longer than IM_MAX_SW_TARGET or query longer
  * than IM_MAX_READ)}. */
 int im_support_batch(im_ctx* ctx, int32_t n,
                      const uint8_t* targets, const int64_t* t_off,

@@ -25,7 +25,7 @@
 namespace im {
 namespace {
 
-constexpr int kSwMaxTarget = 4095;
+constexpr int kSwMaxTarget = IM_MAX_SW_TARGET;
 constexpr int kDppWaveShr1S = 0x138;
 
 // LDS of one workgroup, sized by the launch for the longest target of the batch (cap = that length + 1,

@@ -41,3 +41,35 @@ def test_large_config_matches_reference_digest(tmp_path, name):
     got = mg.digest(p.stdout)
     for k in ("records", "composite", "insertions", "bytes", "md5"):
         assert got[k] == want[k], (k, got[k], want[k])
+
+
+def test_config4like_candidates_match_oracle_record_by_record(gpu_ctx):
+    """the 24-contig, 2.28e9-byte reference resident in HBM at once (contig offsets beyond 2^31, the longest contig beyond
+    2^27 bases): device triage of every delivered record, then the realign kernel on every candidate of every contig,
+    each checked against the CPU oracle on that read's own contig"""
+    import numpy as np
+    from indelminer_amd import capi, rawrec, synth
+    from tests.support import gpucmp, oraclebind as ob
+    from tests.test_gpu_triage import _compare_triage
+    mg = _mg()
+    refs, rd = synth.simulate(**mg.LARGE["config4like"]["sim"])
+    assert len(refs) == 24 and max(len(r) for r in refs) > 2**27 and sum(len(r) for r in refs) > 2**31
+    raw, off = rawrec.records(rd)
+    contigs = [r.tobytes() for r in refs]
+    gpu_ctx.set_reference(contigs)
+    gpu_ctx.set_insert_ranges(["generic"], [rd.range_max])
+    pipe = capi.Pipeline(gpu_ctx, rd.n, len(raw), cap_cand=rd.n // 4)
+    tri, cand = _compare_triage(pipe, raw, off, ["generic"], [rd.range_max])
+    assert len({tri[i][0].tid for i in cand}) == 24
+    pipe.realign()
+    pipe.sync()
+    out = pipe.d_res.download(capi.RESULT_DTYPE, len(cand))
+    P = ob.params()
+    found = 0
+    for j, i in enumerate(cand):
+        t, b = tri[i]
+        st, res = ob.realign(P, contigs[t.tid], len(contigs[t.tid]), t.anchor, t.range_max, b)
+        msg = gpucmp.hip_vs_oracle(out[j], st, res)
+        assert msg is None, (j, i, t.tid, t.anchor, msg)
+        found += st == 1 and res.n_ev > 0
+    assert found > 1000

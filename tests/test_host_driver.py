@@ -182,7 +182,45 @@ def test_product_binary_refuses_without_gpu():
     assert b"#CHROM" not in r.stdout
 
 
+def _long_read_dir(tmp_path):
+    from indelminer_amd import bamwrite, synth
+    refs, rd = synth.simulate(seed=5, ref_len=20_000, coverage=4, read_len=300, isize_mean=900, isize_min=700, isize_max=1100)
+    contigs = [("ctg0", len(refs[0]))]
+    bamwrite.write_fasta(str(tmp_path / "ref.fa"), contigs, refs)
+    bamwrite.write_bam(str(tmp_path / "aln.bam"), contigs, rd)
+    (tmp_path / "cfg.txt").write_text("IL generic 700 1100\n")
+    return str(tmp_path)
+
+
+def test_host_rejects_long_read_library_at_startup(tmp_path):
+    """reads beyond IM_MAX_READ (255): the reference has no bound (src/readaln.c:242-267), the kernels do -- the driver
+    says so before any work instead of dying at the first long candidate inside a contig"""
+    d = _long_read_dir(tmp_path)
+    r = subprocess.run([_build_shim(), "-i", "cfg.txt", "ref.fa", "s=aln.bam"], cwd=d, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    assert r.returncode != 0 and b"IM_MAX_READ" in r.stderr and b"300 bases" in r.stderr
+    assert r.stdout == b""
+
+
+def test_host_rejects_oversized_known_indel_at_startup(tmp_path):
+    """annotate mode realigns reads against windows of up to IM_MAX_SW_TARGET bytes: a split-read deletion of 2500 bases in
+    the variant file is named at startup (the reference's own line buffers are sized by -s, src/variant.c:853-856)"""
+    vcf = tmp_path / "known.vcf"
+    vcf.write_text("##fileformat=VCFv4.1\n#CHROM\tPOS\tID\tREF\tALT\tQUAL\tFILTER\tINFO\n"
+                   "reference\t1000\t.\t%s\tA\t.\t.\tDELETION;SPLIT_READ;NS=3;END=3500;BP_END=3500;UTAILS=3\n" % ("A" * 2501))
+    r = subprocess.run([_build_shim(), "-i", "indelminer.config", "-s", "3000", "reference.fa", str(vcf), "s=alignments.bam"], cwd=TD,
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    assert r.returncode != 0 and b"IM_MAX_SW_TARGET" in r.stderr and b"2500 bases" in r.stderr
+    assert r.stdout == b""
+
+
 # ---------------------------------------------------------------- product binary on the GPU
+
+@pytest.mark.gpu
+def test_product_rejects_long_read_library_at_startup(tmp_path):
+    d = _long_read_dir(tmp_path)
+    r = subprocess.run([_product(), "-i", "cfg.txt", "ref.fa", "s=aln.bam"], cwd=d, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    assert r.returncode != 0 and b"IM_MAX_READ" in r.stderr and r.stdout == b""
+
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("name", sorted(FLAG_MATRIX))
