@@ -40,14 +40,16 @@ KERNEL_EVENT_STRIDE = 8         # one launch bracketed by HIP events on every 8t
 
 
 def measured_traffic():
-    """HBM bytes per realign launch from the PMC passes committed under profiles/ (FETCH_SIZE x 2
-    per the gfx950 correction + WRITE_SIZE, collected with separate --pmc runs of this same
-    command); counters cannot be read from inside this process."""
+    """(HBM bytes per realign launch, source file) from the newest PMC passes committed under profiles/ (FETCH_SIZE x 2
+    per the gfx950 correction + WRITE_SIZE, collected with separate --pmc runs of this same command by
+    profiles/collect.sh); counters cannot be read from inside this process."""
+    import glob
+    files = sorted(f for f in glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_*_traffic.json")) if "shard3" not in f)
     try:
-        with open(os.path.join(ROOT, "profiles", "r01_c_traffic.json")) as fh:
-            return int(json.load(fh)["hbm_bytes_per_launch"])
+        with open(files[-1]) as fh:
+            return int(json.load(fh)["hbm_bytes_per_launch"]), os.path.relpath(files[-1], ROOT)
     except Exception:
-        return None
+        return None, None
 
 
 def algorithmic_bytes(res):
@@ -707,8 +709,8 @@ def main():
                                        "(north_star) and are in end_to_end, not here",
                        "parity": parity},
             "roofline": {"bound": "hbm", "kernel": "realign_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": measured_traffic(),
-                         "traffic_source": "profiles/ PMC passes of an earlier run of this command (FETCH_SIZE x 2 + WRITE_SIZE), not measured in this run",
+                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": measured_traffic()[0],
+                         "traffic_source": "%s: PMC passes of an EARLIER run of this command (FETCH_SIZE x 2 + WRITE_SIZE per launch), not measured in this run" % measured_traffic()[1],
                          "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": float(realign_ms.mean()), "launches_timed": int(len(realign_ms)),
                          "min_launch_ms": float(realign_ms.min()),
                          "peak_measured_copy_gbs": peak_measured,

@@ -41,6 +41,7 @@ struct im_ctx {
     // genome-wide depth / difference array (im_depth_enable): one int32 per byte of ref_ascii
     int32_t* gdepth = nullptr;
     int32_t* gdepth_sums = nullptr;
+    std::vector<int64_t> h_sums_off;    // each contig's own run of tile sums: scans of different contigs may be in flight on different streams
     // read-group -> range[1] table (im_set_insert_ranges), flattened hashtable chains
     void* rg_blob = nullptr;
     im::RgTable rg = {nullptr, 0, 0};
@@ -399,10 +400,11 @@ int im_depth_enable(im_ctx* ctx)
     if (!ctx->ref_ascii) { set_err(ctx, "im_set_reference has not been called"); return IM_E_ARG; }
     if (ctx->gdepth) return IM_OK;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
-    int64_t longest = 0;
-    for (int32_t l : ctx->h_len) if (l > longest) longest = l;
+    int64_t tiles = 0;
+    ctx->h_sums_off.clear();
+    for (int32_t l : ctx->h_len) { ctx->h_sums_off.push_back(tiles); tiles += im::depth_tiles(l) + 1; }
     HIP_TRY(ctx, hipMalloc((void**)&ctx->gdepth, (size_t)ctx->ref_total * sizeof(int32_t)));
-    HIP_TRY(ctx, hipMalloc((void**)&ctx->gdepth_sums, (size_t)(im::depth_tiles(longest) + 1) * sizeof(int32_t)));
+    HIP_TRY(ctx, hipMalloc((void**)&ctx->gdepth_sums, (size_t)(tiles + 1) * sizeof(int32_t)));
     HIP_TRY(ctx, hipMemsetAsync(ctx->gdepth, 0, (size_t)ctx->ref_total * sizeof(int32_t), ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     return IM_OK;
@@ -412,7 +414,7 @@ int im_depth_scan(im_ctx* ctx, int32_t tid, void* stream)
 {
     if (!ctx || !ctx->gdepth || tid < 0 || tid >= ctx->n_contigs) return IM_E_ARG;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
-    HIP_TRY(ctx, im::launch_depth_scan(ctx->gdepth + ctx->h_asc_off[tid], (int64_t)ctx->h_len[tid] + 1, ctx->gdepth_sums, (hipStream_t)stream));
+    HIP_TRY(ctx, im::launch_depth_scan(ctx->gdepth + ctx->h_asc_off[tid], (int64_t)ctx->h_len[tid] + 1, ctx->gdepth_sums + ctx->h_sums_off[tid], (hipStream_t)stream));
     return IM_OK;
 }
 

@@ -356,7 +356,7 @@ typedef struct {
      * thread decodes the BAM (pass A needs no GPU); gpu_wait() joins it before the first GPU call */
     pthread_t gpu_thread;
     int gpu_pending, gpu_rc;
-    pthread_mutex_t gpu_mu; pthread_cond_t gpu_cv; int seq_ready;      /* the helper opens the context at once and uploads the reference when the FASTA is in */
+    pthread_mutex_t gpu_mu; pthread_cond_t gpu_cv; int seq_ready; int ctx_ready, ctx_rc;   /* ctx_ready: im_ctx_create has returned (gpu_rc says how) */      /* the helper opens the context at once and uploads the reference when the FASTA is in */
     char gpu_err[512];
     qhash* readpairs;
     const char* bam_name;
@@ -374,6 +374,7 @@ typedef struct {
     int marker_floor;           /* multi-GPU: smallest start of a stale pair-table entry of an earlier contig on another rank */
     /* live entries of the pair table (find_marker walks these) */
     evidence_t** live; int32_t n_live, cap_live;
+    int live_changed;           /* set by live_add / live_del: the walk logs the list's minimum when it moves */
 } driver;
 
 static void gpu_wait(driver* d);
@@ -477,6 +478,7 @@ static void live_add(driver* d, evidence_t* e)
     if (d->n_live == d->cap_live) { d->cap_live = d->cap_live ? d->cap_live * 2 : 1024; d->live = xrealloc(d->live, sizeof(evidence_t*) * (size_t)d->cap_live); }
     e->live_slot = d->n_live;
     d->live[d->n_live++] = e;
+    d->live_changed = 1;
 }
 static void live_del(driver* d, evidence_t* e)
 {
@@ -486,6 +488,7 @@ static void live_del(driver* d, evidence_t* e)
     d->live[s] = d->live[--d->n_live];
     d->live[s]->live_slot = s;
     e->live_slot = -1;
+    d->live_changed = 1;
 }
 
 /* the discordant-pair branch of fetch_func (src/indelminer.c:516-615): the first mate waits in the pair
@@ -1612,7 +1615,13 @@ static void* gpu_open_thread(void* arg)
     driver* d = (driver*)arg;
     const char* dev_env = getenv("INDELMINER_DEVICE");
     d->gpu_rc = im_ctx_create(dev_env ? atoi(dev_env) : (g_mg_local >= 0 ? g_mg_local : 0), &d->gpu);
-    if (d->gpu_rc != IM_OK) { snprintf(d->gpu_err, sizeof d->gpu_err, "cannot open the GPU: %s", im_last_error(NULL)); return NULL; }
+    if (d->gpu_rc != IM_OK) snprintf(d->gpu_err, sizeof d->gpu_err, "cannot open the GPU: %s", im_last_error(NULL));
+    pthread_mutex_lock(&d->gpu_mu);
+    d->ctx_rc = d->gpu_rc;
+    d->ctx_ready = 1;                                   /* the walkers' buffers can be set up from here on */
+    pthread_cond_broadcast(&d->gpu_cv);
+    pthread_mutex_unlock(&d->gpu_mu);
+    if (d->gpu_rc != IM_OK) return NULL;
     pthread_mutex_lock(&d->gpu_mu);
     while (!d->seq_ready) pthread_cond_wait(&d->gpu_cv, &d->gpu_mu);
     pthread_mutex_unlock(&d->gpu_mu);
@@ -1900,7 +1909,6 @@ static void mg_path(const mgpu* m, char* out, size_t cap, const char* what, int 
 #define PIPE_CHUNK_BYTES   (32u << 20)
 #define PIPE_CHUNK_RECS    (PIPE_CHUNK_BYTES / 64u)
 #define PIPE_NCHUNK        4
-static int64_t PIPE_GROUP_RECORDS = 3000000;    /* a group closes at the first contig end past this many records (INDELMINER_GROUP_RECORDS) */
 
 typedef struct {
     uint8_t*  h_raw; uint32_t* h_off; int32_t* h_cnt;        /* pinned */
@@ -1912,13 +1920,23 @@ typedef struct {
 } pchunk;
 
 typedef struct { int64_t rec; int32_t pe; int marker; int32_t tid; } gflush;
-typedef struct { int32_t tid; int64_t rec0, rec1; int32_t pe0, pe1; int fl0, fl1; } gcontig;
+typedef struct {
+    int32_t tid; int64_t rec0, rec1; int32_t pe0, pe1; int fl0, fl1;
+    int64_t cn0, cn1; int32_t lm0, lm1;     /* this contig's runs in the counted-read log and the live-minimum log */
+    int left_min;                           /* smallest start among the pair-table entries still waiting at the contig's end */
+} gcontig;
 
 typedef struct {
     int64_t n_rec;
     gcontig* ctg; int n_ctg, cap_ctg;
     gflush* fl; int n_fl, cap_fl;
     evidence_t** pe; int64_t* pe_rec; int32_t n_pe, cap_pe;
+    /* The walk does not know the global read counter it starts from (several contigs are walked at once), so it cannot
+     * place the READCHUNK flush points itself (src/indelminer.c:617-670).  It logs what placing them needs -- for every
+     * counted read its record bound and position, and the pair table's smallest waiting start whenever that moves --
+     * and group_resolve_flushes places them once the contigs before this one have been counted. */
+    int32_t *cn_rec, *cn_pos; int64_t n_cn, cap_cn;
+    int32_t *lm_rec; int *lm_val; int32_t n_lm, cap_lm;
     /* candidates as the device found them: record index + a host copy of the raw record */
     int32_t n_cand, cap_cand; int32_t* cand_rec; int64_t* craw_off; uint8_t* craw; int64_t craw_len, craw_cap;
     /* what came back from the run stage */
@@ -1969,17 +1987,22 @@ static void pipe_free_cands(ppipe* P)
     for (size_t i = 0; i < sizeof all / sizeof all[0]; i++) if (all[i]) im_dev_free(P->d->gpu, all[i]);
 }
 
+/* once per run, when the reference is on the device and the insert lengths are known */
+static void pipe_global_init(driver* d)
+{
+    /* the insert-length table in the order its entries were added, range[1] of each */
+    int32_t* rmax = xmalloc(sizeof(int32_t) * (size_t)(g_rg_n ? g_rg_n : 1));
+    for (int i = 0; i < g_rg_n; i++) rmax[i] = g_rg_range[i][1];
+    if (im_set_insert_ranges(d->gpu, g_rg_n, g_rg_name, rmax) != IM_OK) fatalf("im_set_insert_ranges: %s", im_last_error(d->gpu));
+    free(rmax);
+    if (im_depth_enable(d->gpu) != IM_OK) fatalf("im_depth_enable: %s", im_last_error(d->gpu));
+}
+
+/* one walker's buffers: needs the GPU context (d->gpu), nothing else of the driver yet */
 static void pipe_init(ppipe* P, driver* d)
 {
     memset(P, 0, sizeof *P);
     P->d = d;
-    gpu_wait(d);
-    /* the insert-length table in the order its entries were added, range[1] of each */
-    int32_t* rmax = xmalloc(sizeof(int32_t) * (size_t)(g_rg_n ? g_rg_n : 1));
-    for (int i = 0; i < g_rg_n; i++) rmax[i] = g_rg_range[i][1];
-    GPU(im_set_insert_ranges(d->gpu, g_rg_n, g_rg_name, rmax));
-    free(rmax);
-    GPU(im_depth_enable(d->gpu));
     GPU(im_stream_create(d->gpu, &P->stream));
     for (int i = 0; i < PIPE_NCHUNK; i++) {
         pchunk* c = &P->ck[i];
@@ -2000,7 +2023,7 @@ static void pipe_init(ppipe* P, driver* d)
     P->cut = pdev_alloc(P, 8 * (size_t)P->cap_fl);
     P->fdesc = pdev_alloc(P, sizeof(im_flush_desc) * (size_t)P->cap_fl);
     pipe_alloc_cands(P, 1 << 20, (int64_t)(1 << 20) * 160, 1 << 16);
-    P->tp.qthreshold = O.qthreshold; P->tp.ethreshold_vcfcheck = O.ethreshold_vcfcheck; P->tp.maxpedelsize = O.maxpedelsize;
+    P->tp.qthreshold = O.qthreshold; P->tp.ethreshold_vcfcheck = O.ethreshold_vcfcheck; P->tp.maxpedelsize = O.maxpedelsize;   /* options are parsed before any thread starts */
     P->tp.want_depth = 1;
     P->ready = 1;
 }
@@ -2022,13 +2045,14 @@ static void pipe_destroy(ppipe* P)
 
 static void group_reset(pgroup* G)
 {
-    G->n_rec = 0; G->n_ctg = 0; G->n_fl = 0; G->n_pe = 0; G->n_cand = 0; G->craw_len = 0;
+    G->n_rec = 0; G->n_ctg = 0; G->n_fl = 0; G->n_pe = 0; G->n_cand = 0; G->craw_len = 0; G->n_cn = 0; G->n_lm = 0;
     G->n_cl = 0; G->n_nodes = 0;
 }
 
 static void group_free(pgroup* G)
 {
     free(G->ctg); free(G->fl); free(G->pe); free(G->pe_rec); free(G->cand_rec); free(G->craw_off); free(G->craw);
+    free(G->cn_rec); free(G->cn_pos); free(G->lm_rec); free(G->lm_val);
     free(G->res); free(G->s_cls); free(G->cons_sr); free(G->cons_pe);
     free(G->cl_key); free(G->cl_first); free(G->cl_count); free(G->order); free(G->cl_sorted); free(G->ev_cache);
     memset(G, 0, sizeof *G);
@@ -2140,7 +2164,7 @@ static void pipe_submit(ppipe* P, pgroup* G)
     P->ck[P->cur].rec_base = G->n_rec;
 }
 
-/* the host's share of fetch_func for one record: count it, serve the pair table, note flush points */
+/* the host's share of fetch_func for one record: count it, serve the pair table, log what the flush points need */
 static void pipe_host_record(driver* d, pgroup* G, const bam_record* b)
 {
     const int flag = b->flag;
@@ -2159,15 +2183,67 @@ static void pipe_host_record(driver* d, pgroup* G, const bam_record* b)
             e->arrival = (G->n_rec - 1) * 8 + 7;
             G->pe[G->n_pe] = e; G->pe_rec[G->n_pe] = G->n_rec - 1; G->n_pe++;
         }
+        if (d->live_changed) {
+            /* find_marker (src/indelminer.c:211-233) is a function of the pair table alone: its value is logged where it moves */
+            d->live_changed = 0;
+            const int m = find_marker_live(d);
+            if (G->n_lm == G->ctg[G->n_ctg - 1].lm0 || G->lm_val[G->n_lm - 1] != m) {
+                if (G->n_lm == G->cap_lm) {
+                    G->cap_lm = G->cap_lm ? G->cap_lm * 2 : 4096;
+                    G->lm_rec = xrealloc(G->lm_rec, sizeof(int32_t) * (size_t)G->cap_lm);
+                    G->lm_val = xrealloc(G->lm_val, sizeof(int) * (size_t)G->cap_lm);
+                }
+                G->lm_rec[G->n_lm] = (int32_t)G->n_rec; G->lm_val[G->n_lm] = m; G->n_lm++;
+            }
+        }
     }
-    if ((++d->numread % READCHUNK) == 0) {
-        timestamp("Read %ld reads", (long)d->numread);
-        int marker = find_marker_live(d);
-        if (d->marker_floor < marker) marker = d->marker_floor;       /* stale pair-table entries of contigs other ranks own */
-        if (b->pos < marker) marker = b->pos;
-        if (G->n_fl == G->cap_fl) { G->cap_fl = G->cap_fl ? G->cap_fl * 2 : 256; G->fl = xrealloc(G->fl, sizeof(gflush) * (size_t)G->cap_fl); }
-        gflush* f = &G->fl[G->n_fl++];
-        f->rec = G->n_rec; f->pe = G->n_pe; f->marker = marker; f->tid = b->tid;
+    /* a counted read (src/indelminer.c:617): every READCHUNK-th of the whole run is a flush point */
+    if (G->n_cn == G->cap_cn) {
+        G->cap_cn = G->cap_cn ? G->cap_cn * 2 : (1 << 20);
+        G->cn_rec = xrealloc(G->cn_rec, sizeof(int32_t) * (size_t)G->cap_cn);
+        G->cn_pos = xrealloc(G->cn_pos, sizeof(int32_t) * (size_t)G->cap_cn);
+    }
+    G->cn_rec[G->n_cn] = (int32_t)G->n_rec; G->cn_pos[G->n_cn] = b->pos; G->n_cn++;
+}
+
+static void group_push_flush(pgroup* G, int64_t rec, int32_t pe, int marker, int32_t tid)
+{
+    if (G->n_fl == G->cap_fl) { G->cap_fl = G->cap_fl ? G->cap_fl * 2 : 256; G->fl = xrealloc(G->fl, sizeof(gflush) * (size_t)G->cap_fl); }
+    gflush* f = &G->fl[G->n_fl++];
+    f->rec = rec; f->pe = pe; f->marker = marker; f->tid = tid;
+}
+
+/* Places the flush points of a walked group (src/indelminer.c:617-670, 806-823), contig by contig, from the logs of the
+ * walk: *numread is the run's read counter in front of the group's first contig, *floor the smallest start among the
+ * pair-table entries that contigs before it left waiting (the reference never removes those, so find_marker keeps seeing
+ * them).  Both are advanced past the group.  In a multi-GPU run they come per contig from the exchanged summaries. */
+static void group_resolve_flushes(pgroup* G, int64_t* numread, int* floor)
+{
+    G->n_fl = 0;
+    for (int ci = 0; ci < G->n_ctg; ci++) {
+        gcontig* cg = &G->ctg[ci];
+        if (g_mg) { *numread = g_mg->prefix[cg->tid]; *floor = g_mg->floor[cg->tid]; }
+        cg->fl0 = G->n_fl;
+        int32_t lm = cg->lm0, pe = cg->pe0;
+        int live_min = INT_MAX;
+        const int64_t ncount = cg->cn1 - cg->cn0;
+        /* the k-th counted read of the contig (k from 0) is read number *numread + k + 1 of the run */
+        int64_t k = (READCHUNK - 1 - (*numread % READCHUNK)) % READCHUNK;
+        for (; k < ncount; k += READCHUNK) {
+            const int64_t rec = G->cn_rec[cg->cn0 + k];
+            while (lm < cg->lm1 && G->lm_rec[lm] <= rec) live_min = G->lm_val[lm++];
+            while (pe < cg->pe1 && G->pe_rec[pe] < rec) pe++;
+            timestamp("Read %ld reads", (long)(*numread + k + 1));
+            int marker = live_min;
+            if (*floor < marker) marker = *floor;
+            if (G->cn_pos[cg->cn0 + k] < marker) marker = G->cn_pos[cg->cn0 + k];
+            group_push_flush(G, rec, pe, marker, cg->tid);
+        }
+        /* end of contig (src/indelminer.c:806-823): everything still pending is consumed */
+        group_push_flush(G, cg->rec1, cg->pe1, INT_MAX, cg->tid);
+        cg->fl1 = G->n_fl;
+        *numread += ncount;
+        if (cg->left_min < *floor) *floor = cg->left_min;
     }
 }
 
@@ -2176,7 +2252,17 @@ static void pipe_walk_contig(ppipe* P, pgroup* G, int32_t tid, bgzf_reader* r)
     driver* d = P->d;
     if (G->n_ctg == G->cap_ctg) { G->cap_ctg = G->cap_ctg ? G->cap_ctg * 2 : 32; G->ctg = xrealloc(G->ctg, sizeof(gcontig) * (size_t)G->cap_ctg); }
     gcontig* cg = &G->ctg[G->n_ctg++];
-    cg->tid = tid; cg->rec0 = G->n_rec; cg->pe0 = G->n_pe; cg->fl0 = G->n_fl;
+    cg->tid = tid; cg->rec0 = G->n_rec; cg->pe0 = G->n_pe; cg->fl0 = cg->fl1 = 0;
+    cg->cn0 = G->n_cn; cg->lm0 = G->n_lm;
+    /* the pair table starts empty: what earlier contigs left waiting reaches this one as the marker floor
+     * (group_resolve_flushes), not as table entries */
+    while (d->n_live > 0) {
+        evidence_t* e = d->live[d->n_live - 1];
+        live_del(d, e);
+        qhash_remove(d->readpairs, e->qname, (int)strlen(e->qname) + 1);
+        evidence_free(e);
+    }
+    d->live_changed = 0;
     bam_region_iter it;
     if (bam_region_begin(&it, r, d->idx, tid, 0, d->hdr->target_len[tid]) != 0) fatalf("cannot seek in %s", d->bam_name);
     bam_record b; memset(&b, 0, sizeof b);
@@ -2198,14 +2284,12 @@ static void pipe_walk_contig(ppipe* P, pgroup* G, int32_t tid, bgzf_reader* r)
         c->bytes += ((uint32_t)len + 3u) & ~3u;
         c->seq_bytes += ((int64_t)b.l_seq + 3) & ~(int64_t)3;
         G->n_rec++;
+        if (G->n_rec >= 0x7fffffff) fatalf("more than 2^31 records in one group of contigs");
         pipe_host_record(d, G, &b);
     }
-    /* end of contig (src/indelminer.c:806-823): everything still pending is consumed */
-    if (G->n_fl == G->cap_fl) { G->cap_fl = G->cap_fl ? G->cap_fl * 2 : 256; G->fl = xrealloc(G->fl, sizeof(gflush) * (size_t)G->cap_fl); }
-    gflush* f = &G->fl[G->n_fl++];
-    f->rec = G->n_rec; f->pe = G->n_pe; f->marker = INT_MAX; f->tid = tid;
     cg = &G->ctg[G->n_ctg - 1];
-    cg->rec1 = G->n_rec; cg->pe1 = G->n_pe; cg->fl1 = G->n_fl;
+    cg->rec1 = G->n_rec; cg->pe1 = G->n_pe; cg->cn1 = G->n_cn; cg->lm1 = G->n_lm;
+    cg->left_min = find_marker_live(d);
     /* the contig's last records go out now, so that its depth array can be finished behind them */
     pipe_submit(P, G);
     GPU(im_depth_scan(d->gpu, tid, P->stream));
@@ -2875,81 +2959,190 @@ static void mg_finish(mgpu* m, driver* d)
     im_comm_destroy(m->comm);
 }
 
-/* The walk of group g + 1 (inflate, count, pair table, triage launches: one thread's worth of host work) runs beside
- * the replay of group g (evidence objects, merge, print: another thread's worth): two buffers of group state, the
- * device arrays handed back and forth.  Order of output is the order of the groups. */
+/* Several contigs are walked at once (inflate, count, pair table, triage launches: one thread's worth of host work per
+ * walker), each walker with its own BAM reader, pinned chunk ring, device arrays and stream; the main thread takes the
+ * walked groups in contig order, places their flush points (group_resolve_flushes: the only step that needs the contigs
+ * before it), runs the device stage and replays.  A claim is a run of consecutive contigs that goes into one group; a
+ * walker holds two groups' worth of host state, so it walks its next claim while its previous one is replayed.  Order of
+ * output is the order of the contigs. */
+struct walkpool_s;
 typedef struct {
-    ppipe* P; driver* d; bgzf_reader* r;
+    struct walkpool_s* pool;
+    driver wd;                          /* private: pair table, read-group cache */
+    ppipe P;
+    bgzf_reader* r; bam_header* hdr;
     pgroup G[2];
+    int n_started, device_free, replayed;
+    pthread_t th;
+} walker_t;
+
+typedef struct { int first, count; walker_t* W; pgroup* G; int walked; } claim_t;
+
+typedef struct walkpool_s {
+    driver* d;
+    int32_t* order; int n_order;        /* the contigs this process handles, ascending */
+    claim_t* claims; int n_claims, next_claim;
+    walker_t* w; int nw;
+    int serial, go;
     pthread_mutex_t mu; pthread_cond_t cv;
-    int walked, device_free, replayed, done;
-} overlap_t;
+} walkpool_t;
+
+static void walker_adopt_driver(walker_t* W, driver* d)
+{
+    W->wd = *d;                                 /* shared, read-only from here on: header, index, reference, insert lengths, GPU */
+    W->wd.readpairs = qhash_new(16);
+    W->wd.live = NULL; W->wd.n_live = W->wd.cap_live = 0; W->wd.live_changed = 0;
+    W->wd.rg_last_val = NULL; W->wd.rg_last_name[0] = 0;
+    W->wd.gpu_pending = 0;
+}
+
+static void walker_setup(walker_t* W, driver* d)
+{
+    W->wd.gpu = d->gpu;
+    pipe_init(&W->P, &W->wd);
+    W->r = bgzf_open(d->bam_name);
+    if (!W->r) fatalf("error in opening the file %s", d->bam_name);
+    W->hdr = bam_header_load(W->r);
+    if (!W->hdr) fatalf("%s is not a BAM file", d->bam_name);
+}
 
 static void* walker_thread(void* arg)
 {
-    overlap_t* o = arg;
-    driver* d = o->d; ppipe* P = o->P;
-    const int serial = g_vcfname != NULL;               /* annotate mode shares the known-variant list with the replay */
-    int gi = 0, open_group = 0;
-    for (int32_t i = 0; i < d->hdr->n_targets; i++) {
-        if (g_mg && i % g_mg->world != g_mg->rank) continue;       /* another rank's contig */
-        if (!open_group) {
-            pthread_mutex_lock(&o->mu);
-            while (o->device_free < gi || o->replayed < (serial ? gi : gi - 1)) pthread_cond_wait(&o->cv, &o->mu);
-            pthread_mutex_unlock(&o->mu);
-            open_group = 1;
-        }
-        pgroup* G = &o->G[gi & 1];
-        if (g_vcfname != NULL) {
-            known_free(&g_known);
-            read_variants(g_vcfname, i, d->hdr->target_name[i], &g_known);
-            if (g_known.n == 0) continue;           /* src/indelminer.c:788 */
-        }
-        if (g_mg) { d->numread = g_mg->prefix[i]; d->marker_floor = g_mg->floor[i]; }   /* where the single run would stand */
-        pipe_walk_contig(P, G, i, o->r);
-        if (g_vcfname != NULL || G->n_rec >= PIPE_GROUP_RECORDS) {
-            pipe_submit(P, G);
-            pipe_drain(P, G);
-            pthread_mutex_lock(&o->mu); o->walked = ++gi; pthread_cond_broadcast(&o->cv); pthread_mutex_unlock(&o->mu);
-            open_group = 0;
-        }
+    walker_t* W = arg;
+    walkpool_t* o = W->pool;
+    driver* d = o->d;
+    /* buffers as soon as the GPU context exists -- beside the insert-length pass and the FASTA read of the main thread */
+    pthread_mutex_lock(&d->gpu_mu);
+    while (!d->ctx_ready) pthread_cond_wait(&d->gpu_cv, &d->gpu_mu);
+    pthread_mutex_unlock(&d->gpu_mu);
+    if (d->ctx_rc != IM_OK) return NULL;            /* the main thread reports it (gpu_wait) */
+    walker_setup(W, d);
+    pthread_mutex_lock(&o->mu);
+    while (!o->go) pthread_cond_wait(&o->cv, &o->mu);
+    pthread_mutex_unlock(&o->mu);
+    walker_adopt_driver(W, d);
+    for (;;) {
+        pthread_mutex_lock(&o->mu);
+        const int ci = o->next_claim < o->n_claims ? o->next_claim++ : -1;
+        /* this walker's device arrays are free once its previous group went through the device stage, the group buffer
+         * once the group before that has been replayed */
+        while (ci >= 0 && (W->device_free < W->n_started || W->replayed < W->n_started - 1)) pthread_cond_wait(&o->cv, &o->mu);
+        pthread_mutex_unlock(&o->mu);
+        if (ci < 0) break;
+        claim_t* c = &o->claims[ci];
+        pgroup* G = &W->G[W->n_started & 1];
+        for (int k = 0; k < c->count; k++) pipe_walk_contig(&W->P, G, o->order[c->first + k], W->r);
+        pipe_submit(&W->P, G);
+        pipe_drain(&W->P, G);
+        pthread_mutex_lock(&o->mu);
+        c->W = W; c->G = G; c->walked = 1; W->n_started++;
+        pthread_cond_broadcast(&o->cv);
+        pthread_mutex_unlock(&o->mu);
     }
-    if (open_group && o->G[gi & 1].n_ctg > 0) { pipe_submit(P, &o->G[gi & 1]); pipe_drain(P, &o->G[gi & 1]); gi++; }
-    pthread_mutex_lock(&o->mu); o->walked = gi; o->done = 1; pthread_cond_broadcast(&o->cv); pthread_mutex_unlock(&o->mu);
     return NULL;
 }
 
-static void run_pipeline(driver* d, bgzf_reader* r)
+/* Called as soon as the BAM header is known: plans the claims and starts the walkers, which set their buffers up in the
+ * background and then wait for run_pipeline's go. */
+static walkpool_t* walkpool_start(driver* d)
 {
-    ppipe P;
-    memset(&P, 0, sizeof P);
-    P.d = d;
-    d->pipe_mode = 1;
-    if (getenv("INDELMINER_GROUP_RECORDS")) PIPE_GROUP_RECORDS = atoll(getenv("INDELMINER_GROUP_RECORDS"));
-    pipe_init(&P, d);               /* the records are inflated into pinned chunks: the GPU context comes first */
-    overlap_t* o = xcalloc(1, sizeof *o);
-    o->P = &P; o->d = d; o->r = r;
+    walkpool_t* o = xcalloc(1, sizeof *o);
+    o->d = d;
     pthread_mutex_init(&o->mu, NULL); pthread_cond_init(&o->cv, NULL);
-    pthread_t th;
-    if (pthread_create(&th, NULL, walker_thread, o) != 0) fatalf("cannot start the walking thread");
-    for (int gi = 0;; gi++) {
-        pthread_mutex_lock(&o->mu);
-        while (o->walked <= gi && !o->done) pthread_cond_wait(&o->cv, &o->mu);
-        const int have = o->walked > gi;
-        pthread_mutex_unlock(&o->mu);
-        if (!have) break;
+    const int32_t nt = d->hdr->n_targets;
+    o->order = xmalloc(sizeof(int32_t) * (size_t)(nt ? nt : 1));
+    int64_t total_len = 0;
+    for (int32_t i = 0; i < nt; i++) {
+        if (g_mg && i % g_mg->world != g_mg->rank) continue;        /* another rank's contig */
+        o->order[o->n_order++] = i;
+        total_len += d->hdr->target_len[i];
+    }
+    /* annotate mode shares the known-variant list with the replay and skips contigs without variants: one walker, one contig
+     * per claim, walked by the main thread only after the previous one has been replayed */
+    o->serial = g_vcfname != NULL;
+    const char* e = getenv("INDELMINER_WALKERS");
+    int nw = e ? atoi(e) : 4;
+    if (o->serial || nw < 1) nw = 1;
+    if (nw > 16) nw = 16;
+    /* claims: consecutive contigs up to about 1/(4 walkers) of the reference each, so that small contigs share a group
+     * (the device stage and the replay have fixed costs per group) and large ones spread over the walkers */
+    int64_t claim_len = total_len / (4 * (int64_t)nw);
+    if (claim_len < 2000000) claim_len = 2000000;
+    if (getenv("INDELMINER_CLAIM_BASES")) claim_len = atoll(getenv("INDELMINER_CLAIM_BASES"));
+    o->claims = xcalloc((size_t)(o->n_order ? o->n_order : 1), sizeof(claim_t));
+    for (int k = 0; k < o->n_order;) {
+        claim_t* c = &o->claims[o->n_claims++];
+        c->first = k;
+        int64_t len = 0;
+        do { len += d->hdr->target_len[o->order[k]]; k++; } while (!o->serial && k < o->n_order && len + d->hdr->target_len[o->order[k]] <= claim_len);
+        c->count = k - c->first;
+    }
+    if (nw > o->n_claims) nw = o->n_claims ? o->n_claims : 1;
+    o->nw = nw;
+    o->w = xcalloc((size_t)nw, sizeof(walker_t));
+    for (int i = 0; i < nw; i++) o->w[i].pool = o;
+    if (!o->serial)
+        for (int i = 0; i < nw; i++)
+            if (pthread_create(&o->w[i].th, NULL, walker_thread, &o->w[i]) != 0) fatalf("cannot start a walking thread");
+    return o;
+}
+
+static void run_pipeline(driver* d, walkpool_t* o)
+{
+    d->pipe_mode = 1;
+    gpu_wait(d);                    /* the reference is on the device */
+    pipe_global_init(d);
+    if (o->serial) { walker_setup(&o->w[0], d); walker_adopt_driver(&o->w[0], d); }
+    pthread_mutex_lock(&o->mu); o->go = 1; pthread_cond_broadcast(&o->cv); pthread_mutex_unlock(&o->mu);
+    int64_t numread = d->numread;
+    int floor_ = d->marker_floor;
+    for (int ci = 0; ci < o->n_claims; ci++) {
+        claim_t* c = &o->claims[ci];
+        if (o->serial) {
+            /* walked here, after the replay of the previous contig let go of the known-variant list */
+            const int32_t tid = o->order[c->first];
+            known_free(&g_known);
+            read_variants(g_vcfname, tid, d->hdr->target_name[tid], &g_known);
+            if (g_known.n == 0) continue;           /* src/indelminer.c:788 */
+            walker_t* W = &o->w[0];
+            pgroup* G = &W->G[0];
+            pipe_walk_contig(&W->P, G, tid, W->r);
+            pipe_submit(&W->P, G);
+            pipe_drain(&W->P, G);
+            c->W = W; c->G = G; c->walked = 1;
+        } else {
+            pthread_mutex_lock(&o->mu);
+            while (!c->walked) pthread_cond_wait(&o->cv, &o->mu);
+            pthread_mutex_unlock(&o->mu);
+        }
         phase_time("waited for the walk (inflate + count + pair table; triage on the device)");
-        pgroup* G = &o->G[gi & 1];
-        pipe_run_group(&P, G);
-        pthread_mutex_lock(&o->mu); o->device_free = gi + 1; pthread_cond_broadcast(&o->cv); pthread_mutex_unlock(&o->mu);
+        walker_t* W = c->W;
+        pgroup* G = c->G;
+        group_resolve_flushes(G, &numread, &floor_);
+        pipe_run_group(&W->P, G);
+        pthread_mutex_lock(&o->mu); W->device_free++; pthread_cond_broadcast(&o->cv); pthread_mutex_unlock(&o->mu);
         group_replay(d, G);
         group_reset(G);
-        pthread_mutex_lock(&o->mu); o->replayed = gi + 1; pthread_cond_broadcast(&o->cv); pthread_mutex_unlock(&o->mu);
+        pthread_mutex_lock(&o->mu); W->replayed++; pthread_cond_broadcast(&o->cv); pthread_mutex_unlock(&o->mu);
     }
-    pthread_join(th, NULL);
-    pipe_destroy(&P);
-    group_free(&o->G[0]); group_free(&o->G[1]);
-    free(o);
+    d->numread = numread;
+    for (int i = 0; i < o->nw && !o->serial; i++) pthread_join(o->w[i].th, NULL);
+    /* the walkers' pinned rings and device arrays go with the process unless a tidy exit is asked for (leak checkers):
+     * un-pinning and freeing them costs more than the whole device stage of a run */
+    if (getenv("INDELMINER_TIDY_EXIT")) {
+        for (int i = 0; i < o->nw; i++) {
+            walker_t* W = &o->w[i];
+            pipe_destroy(&W->P);
+            group_free(&W->G[0]); group_free(&W->G[1]);
+            bam_header_free(W->hdr);
+            bgzf_close(W->r);
+            while (W->wd.n_live > 0) { evidence_t* ev = W->wd.live[W->wd.n_live - 1]; live_del(&W->wd, ev); evidence_free(ev); }
+            free(W->wd.live);
+            qhash_free(W->wd.readpairs, NULL);
+        }
+        free(o->w); free(o->claims); free(o->order);
+        free(o);
+    }
 }
 
 /* -------------------------------------------------------------------- main -- */
@@ -3161,6 +3354,13 @@ int main(int argc, char** argv)
     pthread_mutex_init(&d.gpu_mu, NULL); pthread_cond_init(&d.gpu_cv, NULL);
     d.gpu_pending = 1;
     if (pthread_create(&d.gpu_thread, NULL, gpu_open_thread, &d) != 0) fatalf("cannot start the GPU helper thread");
+    /* whole-contig runs take the device pipeline (region runs, -c, keep the per-contig host path, whose mate look-ups and
+     * depth queries go to the BAM file like the reference's): its walkers set their buffers up from now on */
+    walkpool_t* pool = NULL;
+    {
+        const char* pl0 = getenv("INDELMINER_PIPELINE");
+        if (chromid == -1 && !(pl0 && strcmp(pl0, "host") == 0)) pool = walkpool_start(&d);
+    }
 
     if (O.configfile) read_configuration(O.configfile, d.insertlengths);
     else if (!g_mg) { if (chromid == -1 && !getenv("INDELMINER_ESTIMATE_SERIAL")) estimate_insertlengths_threads(&d); else estimate_insertlengths(&d, chromid); }
@@ -3181,7 +3381,7 @@ int main(int argc, char** argv)
     /* the reference is in: the GPU helper (started before the insert-length pass) uploads it */
     pthread_mutex_lock(&d.gpu_mu);
     d.seq_ready = 1;
-    pthread_cond_signal(&d.gpu_cv);
+    pthread_cond_broadcast(&d.gpu_cv);
     pthread_mutex_unlock(&d.gpu_mu);
 
 
@@ -3206,7 +3406,7 @@ int main(int argc, char** argv)
             for (int j = 0; j < g_rg_n; j++) fprintf(stderr, "%s\t%d\t%d\n", g_rg_name[j], g_rg_range[j][0], g_rg_range[j][1]);
         }
     }
-    if (use_pipeline) run_pipeline(&d, r);
+    if (use_pipeline) run_pipeline(&d, pool);
     if (g_mg) mg_finish(&mg, &d);
     for (int32_t i = 0; i < d.hdr->n_targets && !use_pipeline; i++) {
         if (chromid != -1 && i != chromid) continue;

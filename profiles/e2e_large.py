@@ -27,12 +27,18 @@ with tempfile.TemporaryDirectory() as td:
     print("BAM written in %.1f s, %d bytes" % (time.perf_counter() - t, os.path.getsize(td + "/aln.bam")), flush=True)
     cmd = ["ref.fa", "s=aln.bam"]
     tp = None
-    for _ in range(int(os.environ.get("E2E_REPEAT", "1"))):      # the first run also pages the binary and the inputs in
-        t = time.perf_counter()
-        p = subprocess.run([build.HOST_BIN] + cmd, cwd=td, stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=dict(os.environ, INDELMINER_TIMING="1"))
-        dt = time.perf_counter() - t
-        print("product run: %.2f s" % dt, flush=True)
-        tp = dt if tp is None else min(tp, dt)
+    for thr in os.environ.get("E2E_THREADS", "").split(","):     # inflate workers per reader (INDELMINER_THREADS), "" = default
+        for _ in range(int(os.environ.get("E2E_REPEAT", "1"))):      # the first run also pages the binary and the inputs in
+            env = dict(os.environ, INDELMINER_TIMING="1")
+            if thr:                                   # "4" = inflate workers; "4:3" = inflate workers : walkers
+                env["INDELMINER_THREADS"] = thr.split(":")[0]
+                if ":" in thr:
+                    env["INDELMINER_WALKERS"] = thr.split(":")[1]
+            t = time.perf_counter()
+            p = subprocess.run([build.HOST_BIN] + cmd, cwd=td, stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env)
+            dt = time.perf_counter() - t
+            print("product run (inflate workers %s): %.2f s" % (thr or "default", dt), flush=True)
+            tp = dt if tp is None else min(tp, dt)
     body = [l for l in p.stdout.splitlines() if not l.startswith(b"#")]
     print("product   rc %d  %.2f s  %d VCF records (%d COMPOSITE, %d PAIRED_READ only)" %
           (p.returncode, tp, len(body), sum(b"COMPOSITE" in l for l in body), sum(b"PAIRED_READ" in l and b"COMPOSITE" not in l for l in body)), flush=True)

@@ -182,6 +182,29 @@ def test_product_binary_refuses_without_gpu():
     assert b"#CHROM" not in r.stdout
 
 
+def test_host_parallel_walkers_give_the_single_walk(tmp_path):
+    """Several contigs walked at once, flush points placed afterwards from the walk's logs (group_resolve_flushes): any
+    number of walkers and any grouping of contigs into claims must print what the one-record-at-a-time host path prints
+    (and the reference, where its binary is present).  Six contigs, ~360 000 reads: the READCHUNK flush points fall inside
+    contigs 1, 3 and 4, discordant pairs keep the pair table busy."""
+    from indelminer_amd import bamwrite, rawrec, synth
+    refs, rd = synth.simulate(seed=21, ref_len=200_000, coverage=30, n_contigs=6, big_every=4)
+    contigs = [("ctg%d" % i, len(r)) for i, r in enumerate(refs)]
+    bamwrite.write_fasta(str(tmp_path / "ref.fa"), contigs, refs)
+    rawrec.write_bam_fast(str(tmp_path / "aln.bam"), contigs, rd)
+    shim = _build_shim()
+    want = _run(shim, [], str(tmp_path), ref="ref.fa", bam="aln.bam", env={"INDELMINER_PIPELINE": "host"})
+    assert want.count(b"COMPOSITE") > 20
+    ref_bin = os.path.join(ROOT, "oracle", "_ref", "indelminer")
+    if os.path.exists(ref_bin):
+        assert _run(ref_bin, [], str(tmp_path), ref="ref.fa", bam="aln.bam") == want
+    for walkers, claim in (("1", None), ("3", None), ("2", "1"), ("6", "1"), ("4", "450000")):
+        env = {"INDELMINER_WALKERS": walkers}
+        if claim:
+            env["INDELMINER_CLAIM_BASES"] = claim
+        assert _run(shim, [], str(tmp_path), ref="ref.fa", bam="aln.bam", env=env) == want, env
+
+
 def _long_read_dir(tmp_path):
     from indelminer_amd import bamwrite, synth
     refs, rd = synth.simulate(seed=5, ref_len=20_000, coverage=4, read_len=300, isize_mean=900, isize_min=700, isize_max=1100)
