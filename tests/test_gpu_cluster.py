@@ -210,3 +210,33 @@ def test_support_sw_matches_oracle(gpu_ctx):
         s, i, a = C.c_int32(), C.c_int32(), C.c_int32()
         L.imo_sw_indel(t, len(t), q, len(q), C.byref(s), C.byref(i), C.byref(a))
         assert tuple(got[k][:3]) == (s.value, i.value, a.value), (k, len(t), len(q), tuple(got[k]), (s.value, i.value, a.value))
+
+
+def test_cluster_kernels_match_reference_process_evidence(gpu_ctx):
+    """the device cluster path against vectors the reference's own process_evidence produced (tests/golden/units_cluster.json)"""
+    import json
+    from tests.test_oracle_units import reference_clusters
+    cases = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "units_cluster.json")))["cases"]
+    for case in cases:
+        cls, b1, b2 = case["cls"], case["b1"], case["b2"]
+        for tie in (0, 1):
+            order, first, count, used, k = gpu_ctx.cluster_sr(cls, b1, b2, case["marker"], tie)
+            got = []
+            for f, c in zip(first, count):
+                m = [int(x) for x in order[f:f + c]]
+                got.append(((cls[m[0]], b1[m[0]], b2[m[0]]), m))
+            want = reference_clusters(case)
+            assert got == (want if tie == 0 else [(key, m[::-1]) for key, m in want]), case["seed"]
+            assert [int(x) for x in used] == case["used"]
+
+
+def test_support_kernel_matches_reference_realign_with_indel(gpu_ctx):
+    """the annotate-mode Smith-Waterman against vectors the reference's own realign_with_indel produced"""
+    import json
+    from tests.test_oracle_units import variant_window
+    cases = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "units_sw.json")))["cases"]
+    targets = [variant_window(c) for c in cases]
+    queries = [c["read"][c["qstart"]:c["qstop"]].encode() for c in cases]
+    got = gpu_ctx.support_batch(targets, queries)
+    for k, c in enumerate(cases):
+        assert [int(x) for x in got[k][:3]] == c["expect"], (k, c["expect"], tuple(got[k]))
