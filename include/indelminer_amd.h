@@ -332,7 +332,7 @@ typedef struct im_triage_params {
 typedef struct im_dev_cands {
     im_dev_batch batch;
     int32_t*     cand_rec;      /* cap_cand: record index (rec_base + i) of every candidate      */
-    int32_t*     counters;      /* device int32[8]                                               */
+    int32_t*     counters;      /* device int32[8]; zero it before the first call (im_dev_alloc does not) */
     uint8_t*     rec_class;     /* n records of the chunk (may be NULL)                          */
     int32_t      cap_cand;
     int64_t      cap_bases;

@@ -2019,6 +2019,9 @@ static void pipe_init(ppipe* P, driver* d)
     }
     P->counters = pdev_alloc(P, 64);
     P->counts = pdev_alloc(P, 64);
+    /* device allocations are not zeroed (a recycled block keeps what its previous owner wrote): the triage's running counts start from 0 */
+    GPU(im_dev_memset(d->gpu, P->counters, 0, 64, P->stream));
+    GPU(im_dev_memset(d->gpu, P->counts, 0, 64, P->stream));
     P->cap_fl = 4096;
     P->cut = pdev_alloc(P, 8 * (size_t)P->cap_fl);
     P->fdesc = pdev_alloc(P, sizeof(im_flush_desc) * (size_t)P->cap_fl);

@@ -159,7 +159,15 @@ int im_stream_destroy(im_ctx* c, void* s) { (void)c; (void)s; return IM_OK; }
 int im_stream_sync(im_ctx* c, void* s) { (void)c; (void)s; return IM_OK; }
 int im_host_alloc(im_ctx* c, size_t bytes, void** out) { (void)c; *out = malloc(bytes ? bytes : 1); return IM_OK; }
 int im_host_free(im_ctx* c, void* p) { (void)c; free(p); return IM_OK; }
-int im_dev_alloc(im_ctx* c, size_t bytes, void** out) { (void)c; *out = calloc(bytes ? bytes : 1, 1); return IM_OK; }
+/* like hipMalloc, the block is NOT zeroed: filled with a pattern so that a caller relying on zeros fails here, on the CPU */
+int im_dev_alloc(im_ctx* c, size_t bytes, void** out)
+{
+    (void)c;
+    *out = malloc(bytes ? bytes : 1);
+    if (!*out) return IM_E_HIP;
+    if (bytes <= ((size_t)1 << 26)) memset(*out, 0xA5, bytes ? bytes : 1);      /* the large arrays are written before they are read; skip their fill */
+    return IM_OK;
+}
 int im_dev_free(im_ctx* c, void* p) { (void)c; free(p); return IM_OK; }
 int im_dev_upload(im_ctx* c, void* dst, const void* src, size_t bytes) { (void)c; memcpy(dst, src, bytes); return IM_OK; }
 int im_dev_download(im_ctx* c, void* dst, const void* src, size_t bytes) { (void)c; memcpy(dst, src, bytes); return IM_OK; }

@@ -1,4 +1,6 @@
 """Parity of the HIP split-read cluster kernels with the CPU oracle (bit-exact)."""
+import os
+
 import numpy as np
 import pytest
 
