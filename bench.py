@@ -338,6 +338,23 @@ class PipeStep:
         for st_ in self.sets:
             self.ctx._check(capi.lib().im_stream_sync(self.ctx.h, st_["stream"]))
 
+    def digest(self, st_):
+        """what a pass left in one buffer set, in a form that does not depend on hash-table order: the candidate count, every
+        read's status / evidence, the consumed marks and the clusters as a sorted list of (key, members)"""
+        p = st_["pipe"]
+        c = p.fetch_counts()
+        nc = int(c[0])
+        res = p.d_res.download(capi.RESULT_DTYPE, max(nc, 1))[:nc]
+        key, first, count, order = p.clusters()
+        cl = sorted((tuple(int(x) for x in key[i]), tuple(int(x) for x in order[first[i]:first[i] + count[i]])) for i in range(len(key)))
+        cons = p.d_consumed.download(np.int32, p.n_slots)
+        import hashlib
+        h = hashlib.md5()
+        h.update(np.ascontiguousarray(res["status"]).tobytes()); h.update(np.ascontiguousarray(res["n_ev"]).tobytes())
+        h.update(np.ascontiguousarray(res["ev"]["b1"]).tobytes()); h.update(np.ascontiguousarray(res["ev"]["b2"]).tobytes())
+        h.update(cons[:nc * capi.MAX_EV].tobytes()); h.update(cons[p.cap_cand * capi.MAX_EV:p.cap_cand * capi.MAX_EV + p.n_pe].tobytes()); h.update(repr(cl).encode())
+        return nc, len(cl), h.hexdigest()
+
     def results(self):
         p = self.last["pipe"]
         c = p.fetch_counts()
@@ -553,6 +570,7 @@ def main():
     ps.step(); ps.sync()
     c0, res0, counts0 = ps.results()
     assert int(c0[0]) == n_cand and int(c0[3]) == 0 and int(c0[4]) == 0, (c0, n_cand)
+    digest0 = ps.digest(ps.last)           # the pass on its own, nothing else on the device
     comm = None
     collective = None
     if world > 1 or os.environ.get("IM_BENCH_FORCE_COMM") == "1":
@@ -639,6 +657,9 @@ def main():
     else:
         total_reads, total_cand = n_reads, n_cand
 
+    # every buffer set must hold exactly what the pass leaves when it runs alone: the timed passes overlap on PIPELINE_DEPTH streams
+    digests = [ps.digest(st_) for st_ in ps.sets[:min(len(ps.sets), args.steps + args.warmup)]]
+    overlap_ok = all(dg == digest0 for dg in digests)
     p0 = ps.sets[0]["pipe"]
     realign_ms = np.array([tm.elapsed_ms() for tm, at in timers if tm is not None and at == p0.realign_call_index])
     triage_ms = np.array([tm.elapsed_ms() for tm, at in timers if tm is not None and at == p0.triage_call_index])
@@ -707,7 +728,10 @@ def main():
                                        "(candidate rules, base decode, CIGAR evidence) -> realign -> one flush cut per READCHUNK "
                                        "flush point -> split-read group-by; BGZF inflate and the pair table stay on the host "
                                        "(north_star) and are in end_to_end, not here",
-                       "parity": parity},
+                       "parity": parity,
+                       "overlapped_passes_equal_the_pass_alone": overlap_ok,
+                       "pass_digest": {"candidates": digest0[0], "clusters": digest0[1], "md5": digest0[2],
+                                       "of_each_buffer_set_after_the_timed_region": [dg[2] for dg in digests]}},
             "roofline": {"bound": "hbm", "kernel": "realign_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": measured_traffic()[0],
                          "traffic_source": "%s: PMC passes of an EARLIER run of this command (FETCH_SIZE x 2 + WRITE_SIZE per launch), not measured in this run" % measured_traffic()[1],

@@ -389,7 +389,9 @@ int im_dev_flush_cuts(im_ctx* ctx, const im_flush_desc* desc_dev, int32_t n_flus
  * slot index (= arrival) or descending with tie_desc.  counts (device int32[2]) = {clusters, nodes}.
  * Entries with cls >= 2 are ignored. */
 size_t im_dev_groupby_scratch_bytes(int32_t n_slots);
-/* once per scratch buffer (asynchronous); every group-by call leaves the scratch ready for the next one */
+/* once per scratch buffer (asynchronous); every group-by call leaves the scratch ready for the next one.  The scratch is
+ * laid out for THIS n_slots for its whole life: later calls may pass any n_slots up to it (the context remembers the
+ * layout per scratch pointer; a scratch that was never initialised is refused) */
 int im_dev_groupby_scratch_init(im_ctx* ctx, int32_t n_slots, void* scratch, size_t scratch_bytes, void* stream);
 int im_dev_cluster_groupby(im_ctx* ctx, int32_t n_slots, const int32_t* cls, const int32_t* b1, const int32_t* b2,
                            const int32_t* consumed, int32_t tie_desc,

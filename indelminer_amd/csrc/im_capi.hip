@@ -9,6 +9,8 @@
 #include <string.h>
 
 #include <vector>
+#include <unordered_map>
+#include <mutex>
 
 struct im_ctx {
     int device = -1;
@@ -41,6 +43,8 @@ struct im_ctx {
     // genome-wide depth / difference array (im_depth_enable): one int32 per byte of ref_ascii
     int32_t* gdepth = nullptr;
     int32_t* gdepth_sums = nullptr;
+    std::mutex gb_mu;
+    std::unordered_map<void*, int32_t> gb_layout;   // group-by scratch -> the slot count it was initialised (and is carved) for
     std::vector<int64_t> h_sums_off;    // each contig's own run of tile sums: scans of different contigs may be in flight on different streams
     // read-group -> range[1] table (im_set_insert_ranges), flattened hashtable chains
     void* rg_blob = nullptr;
@@ -364,7 +368,16 @@ int im_dev_groupby_scratch_init(im_ctx* ctx, int32_t n_slots, void* scratch, siz
     if (!ctx || !scratch || scratch_bytes < im::groupby_scratch_bytes(n_slots)) return IM_E_ARG;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     HIP_TRY(ctx, im::launch_groupby_init(n_slots, scratch, (hipStream_t)stream));
+    { std::lock_guard<std::mutex> lk(ctx->gb_mu); ctx->gb_layout[scratch] = n_slots; }
     return IM_OK;
+}
+
+// the slot count a group-by scratch was initialised for, or -1
+static int32_t groupby_layout(im_ctx* ctx, void* scratch)
+{
+    std::lock_guard<std::mutex> lk(ctx->gb_mu);
+    auto it = ctx->gb_layout.find(scratch);
+    return it == ctx->gb_layout.end() ? -1 : it->second;
 }
 
 int im_dev_cluster_groupby(im_ctx* ctx, int32_t n_slots, const int32_t* cls, const int32_t* b1, const int32_t* b2,
@@ -373,10 +386,12 @@ int im_dev_cluster_groupby(im_ctx* ctx, int32_t n_slots, const int32_t* cls, con
                            void* scratch, size_t scratch_bytes, void* stream)
 {
     if (!ctx || n_slots < 0 || !counts) return IM_E_ARG;
-    if (scratch_bytes < im::groupby_scratch_bytes(n_slots)) { set_err(ctx, "group-by scratch too small"); return IM_E_ARG; }
+    const int32_t n_layout = groupby_layout(ctx, scratch);
+    if (n_layout < 0) { set_err(ctx, "group-by scratch was not initialised (im_dev_groupby_scratch_init)"); return IM_E_ARG; }
+    if (n_slots > n_layout || scratch_bytes < im::groupby_scratch_bytes(n_layout)) { set_err(ctx, "group-by scratch too small"); return IM_E_ARG; }
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     if (n_slots == 0) { HIP_TRY(ctx, hipMemsetAsync(counts, 0, 8, (hipStream_t)stream)); return IM_OK; }
-    HIP_TRY(ctx, im::launch_groupby(n_slots, nullptr, cls, b1, b2, consumed, tie_desc, order, cl_key, cl_first, cl_count, counts, scratch, (hipStream_t)stream));
+    HIP_TRY(ctx, im::launch_groupby(n_layout, n_slots, nullptr, cls, b1, b2, consumed, tie_desc, order, cl_key, cl_first, cl_count, counts, scratch, (hipStream_t)stream));
     return IM_OK;
 }
 
@@ -386,9 +401,11 @@ int im_dev_cluster_groupby_n(im_ctx* ctx, int32_t n_slots_cap, const int32_t* n_
                              void* scratch, size_t scratch_bytes, void* stream)
 {
     if (!ctx || n_slots_cap <= 0 || !counts || !n_cand_dev) return IM_E_ARG;
-    if (scratch_bytes < im::groupby_scratch_bytes(n_slots_cap)) { set_err(ctx, "group-by scratch too small"); return IM_E_ARG; }
+    const int32_t n_layout = groupby_layout(ctx, scratch);
+    if (n_layout < 0) { set_err(ctx, "group-by scratch was not initialised (im_dev_groupby_scratch_init)"); return IM_E_ARG; }
+    if (n_slots_cap > n_layout || scratch_bytes < im::groupby_scratch_bytes(n_layout)) { set_err(ctx, "group-by scratch too small"); return IM_E_ARG; }
     HIP_TRY(ctx, hipSetDevice(ctx->device));
-    HIP_TRY(ctx, im::launch_groupby(n_slots_cap, n_cand_dev, cls, b1, b2, consumed, tie_desc, order, cl_key, cl_first, cl_count, counts, scratch, (hipStream_t)stream));
+    HIP_TRY(ctx, im::launch_groupby(n_layout, n_slots_cap, n_cand_dev, cls, b1, b2, consumed, tie_desc, order, cl_key, cl_first, cl_count, counts, scratch, (hipStream_t)stream));
     return IM_OK;
 }
 
@@ -770,6 +787,7 @@ int im_dev_free(im_ctx* ctx, void* p)
 {
     if (!ctx) return IM_E_ARG;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
+    { std::lock_guard<std::mutex> lk(ctx->gb_mu); ctx->gb_layout.erase(p); }     // a group-by scratch: its address may come back as something else
     HIP_TRY(ctx, hipFree(p));
     return IM_OK;
 }

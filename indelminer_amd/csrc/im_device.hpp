@@ -59,7 +59,7 @@ hipError_t launch_flush_seq(const im_flush_desc* desc, int32_t n_fl, const int32
                             int32_t pe_count, hipStream_t stream);
 size_t groupby_scratch_bytes(int32_t n_slots);
 hipError_t launch_groupby_init(int32_t n_slots, void* scratch, hipStream_t stream);
-hipError_t launch_groupby(int32_t n_slots, const int32_t* n_cand_dev, const int32_t* cls, const int32_t* b1, const int32_t* b2, const int32_t* consumed,
+hipError_t launch_groupby(int32_t n_layout, int32_t n_slots, const int32_t* n_cand_dev, const int32_t* cls, const int32_t* b1, const int32_t* b2, const int32_t* consumed,
                           int32_t tie_desc, int32_t* order, int32_t* cl_key, int32_t* cl_first, int32_t* cl_count,
                           int32_t* counts, void* scratch, hipStream_t stream);
 hipError_t launch_depth_scan(int32_t* depth, int64_t n, int32_t* sums, hipStream_t stream);

@@ -402,12 +402,16 @@ hipError_t launch_groupby_init(int32_t n_slots, void* scratch, hipStream_t strea
     return hipMemsetAsync(g.head, 0, (size_t)((char*)g.misc - (char*)g.head) + 64, stream);
 }
 
-hipError_t launch_groupby(int32_t n_slots, const int32_t* n_cand_dev, const int32_t* cls, const int32_t* b1, const int32_t* b2, const int32_t* consumed,
+hipError_t launch_groupby(int32_t n_layout, int32_t n_slots, const int32_t* n_cand_dev, const int32_t* cls, const int32_t* b1, const int32_t* b2, const int32_t* consumed,
                           int32_t tie_desc, int32_t* order, int32_t* cl_key, int32_t* cl_first, int32_t* cl_count,
                           int32_t* counts, void* scratch, hipStream_t stream)
 {
     GroupScratch g; int32_t* tmp = nullptr;
-    group_carve(&g, &tmp, scratch, n_slots);       // zeroed once by launch_groupby_init; every call leaves it clean
+    // The scratch is carved for the slot count it was INITIALISED for (n_layout), whatever this call's n_slots: the table is
+    // zeroed once by launch_groupby_init and every call leaves its own entries clean, which only holds while every call
+    // sees the same arrays at the same places (a layout per call put one call's counters inside another's slot lists:
+    // phantom clusters, out-of-range representatives -- found on the 24-contig input, groups of very different sizes).
+    group_carve(&g, &tmp, scratch, n_layout);
     const int gi = grid_of(n_slots, 256, 4096);
     hipLaunchKernelGGL(group_insert_kernel, dim3(gi), dim3(256), 0, stream, n_slots, n_cand_dev, cls, b1, b2, consumed, g);
     hipLaunchKernelGGL(group_offsets_kernel, dim3(1), dim3(1024), 0, stream, g, cls, b1, b2, consumed, cl_key, cl_first, cl_count, counts);

@@ -1957,7 +1957,7 @@ typedef struct {
     /* confirmed by harvested chunks / still in flight */
     int32_t conf_cand, conf_err; int64_t conf_bytes, fly_recs, fly_seq;
     im_triage_params tp;
-    int ready;
+    int ready, own_stream;
 } ppipe;
 
 #define GPU(call) do { if ((call) != IM_OK) fatalf("%s: %s", #call, im_last_error(P->d->gpu)); } while (0)
@@ -2003,7 +2003,12 @@ static void pipe_init(ppipe* P, driver* d)
 {
     memset(P, 0, sizeof *P);
     P->d = d;
-    GPU(im_stream_create(d->gpu, &P->stream));
+    /* a stream per walker: its uploads and triage launches, and the device stage of its groups.  INDELMINER_STREAMS=shared
+     * puts every walker on the context's stream instead (the GPU then sees the run exactly as with one walker: a
+     * debugging aid -- it is how the group-by scratch bug of profiles/README.md r02 was told apart from a device race) */
+    P->own_stream = !(getenv("INDELMINER_STREAMS") && strcmp(getenv("INDELMINER_STREAMS"), "shared") == 0);
+    if (P->own_stream) GPU(im_stream_create(d->gpu, &P->stream));
+    else P->stream = im_ctx_stream(d->gpu);
     for (int i = 0; i < PIPE_NCHUNK; i++) {
         pchunk* c = &P->ck[i];
         GPU(im_host_alloc(d->gpu, PIPE_CHUNK_BYTES, (void**)&c->h_raw));
@@ -2042,7 +2047,7 @@ static void pipe_destroy(ppipe* P)
     }
     pipe_free_cands(P);
     im_dev_free(P->d->gpu, P->counters); im_dev_free(P->d->gpu, P->counts); im_dev_free(P->d->gpu, P->cut); im_dev_free(P->d->gpu, P->fdesc);
-    im_stream_destroy(P->d->gpu, P->stream);
+    if (P->own_stream) im_stream_destroy(P->d->gpu, P->stream);
     P->ready = 0;
 }
 
@@ -2062,6 +2067,7 @@ static void group_free(pgroup* G)
 }
 
 /* the chunk's triage is complete: note what it found, copy its candidates' records to the host side store */
+static int g_verify_triage;
 static void pipe_harvest(ppipe* P, pgroup* G, pchunk* c)
 {
     GPU(im_event_sync(c->done));
@@ -2092,6 +2098,30 @@ static void pipe_harvest(ppipe* P, pgroup* G, pchunk* c)
             G->craw_off = xrealloc(G->craw_off, sizeof(int64_t) * ((size_t)G->cap_cand + 1));
         }
         GPU(im_dev_download(P->d->gpu, G->cand_rec + P->conf_cand, (char*)P->cand_rec + 4 * (size_t)P->conf_cand, 4 * (size_t)fresh));
+        if (g_verify_triage) {
+            /* INDELMINER_VERIFY_TRIAGE=1: the chunk's candidates as the device placed them against the records themselves */
+            int64_t* boff = xmalloc(8 * (size_t)fresh); int32_t* len = xmalloc(4 * (size_t)fresh);
+            int32_t* tid = xmalloc(4 * (size_t)fresh); int32_t* anc = xmalloc(4 * (size_t)fresh);
+            GPU(im_dev_download(P->d->gpu, boff, (char*)P->boff + 8 * (size_t)P->conf_cand, 8 * (size_t)fresh));
+            GPU(im_dev_download(P->d->gpu, len, (char*)P->len + 4 * (size_t)P->conf_cand, 4 * (size_t)fresh));
+            GPU(im_dev_download(P->d->gpu, tid, (char*)P->tid + 4 * (size_t)P->conf_cand, 4 * (size_t)fresh));
+            GPU(im_dev_download(P->d->gpu, anc, (char*)P->anchor + 4 * (size_t)P->conf_cand, 4 * (size_t)fresh));
+            int64_t at = P->conf_bytes;
+            for (int32_t j = 0; j < fresh; j++) {
+                const int64_t li = (int64_t)G->cand_rec[P->conf_cand + j] - c->rec_base;
+                if (li < 0 || li >= c->n || (j > 0 && G->cand_rec[P->conf_cand + j] <= G->cand_rec[P->conf_cand + j - 1]))
+                    fatalf("verify: candidate %d of the chunk names record %d (chunk holds %ld..%ld)", j, G->cand_rec[P->conf_cand + j], (long)c->rec_base, (long)c->rec_base + c->n - 1);
+                bam_record b;
+                bam_record_view(c->h_raw + c->h_off[li], (int32_t)(c->h_off[li + 1] - c->h_off[li]), &b);
+                if (boff[j] != at || len[j] != b.l_seq || tid[j] != b.mtid || anc[j] != b.mpos)
+                    fatalf("verify: candidate %d (+%d) of the chunk, record %ld: device {off %ld len %d tid %d anchor %d}, record {off %ld len %d tid %d anchor %d}; "
+                           "chunk of %d records, counters before %d / %ld, after %d / %d", j, P->conf_cand, (long)li, (long)boff[j], len[j], tid[j], anc[j],
+                           (long)at, (int)b.l_seq, b.mtid, b.mpos, c->n, P->conf_cand, (long)P->conf_bytes, n_after, c->h_cnt[1]);
+                at += ((int64_t)b.l_seq + 3) & ~(int64_t)3;
+            }
+            if (at != c->h_cnt[1]) fatalf("verify: the chunk's candidates end at byte %ld, the device says %d", (long)at, c->h_cnt[1]);
+            free(boff); free(len); free(tid); free(anc);
+        }
         for (int32_t j = P->conf_cand; j < n_after; j++) {
             const int64_t li = (int64_t)G->cand_rec[j] - c->rec_base;
             forceassert(li >= 0 && li < c->n);
@@ -2482,7 +2512,12 @@ static void group_candidate_evidence(driver* d, pgroup* G, int32_t cand)
 static evidence_t* group_sr_evidence(driver* d, pgroup* G, int32_t slot)
 {
     if (!G->ev_cache[slot]) group_candidate_evidence(d, G, slot / IM_MAX_EV);
-    forceassert(G->ev_cache[slot] != NULL);
+    if (G->ev_cache[slot] == NULL) {
+        const int32_t cand = slot / IM_MAX_EV;
+        fatalf("internal: the device names evidence slot %d of candidate %d (record %d of %ld in its group, %d candidates; device class %d, "
+               "realign status %d with %d evidence) but the host finds no evidence there", slot % IM_MAX_EV, cand, G->cand_rec[cand],
+               (long)G->n_rec, G->n_cand, G->s_cls[slot], G->res[cand].status, G->res[cand].n_ev);
+    }
     return G->ev_cache[slot];
 }
 
@@ -3093,6 +3128,7 @@ static walkpool_t* walkpool_start(driver* d)
 static void run_pipeline(driver* d, walkpool_t* o)
 {
     d->pipe_mode = 1;
+    g_verify_triage = getenv("INDELMINER_VERIFY_TRIAGE") != NULL;
     gpu_wait(d);                    /* the reference is on the device */
     pipe_global_init(d);
     if (o->serial) { walker_setup(&o->w[0], d); walker_adopt_driver(&o->w[0], d); }

@@ -282,3 +282,41 @@ def test_depth_genome_wide(gpu_ctx):
         got = gpu_ctx.depth_query_tid(tid, beg, end)
         cs = np.concatenate([[0], np.cumsum(want.astype(np.int64))])
         assert np.array_equal(got.astype(np.int64), cs[np.minimum(end, 40_000)] - cs[beg])
+
+
+def test_groupby_scratch_serves_groups_of_any_size(gpu_ctx):
+    """One pipeline's buffers serve group after group of very different sizes (the product: a few contigs per group, as they
+    come).  The group-by scratch is laid out once, for its capacity: a layout per call put one call's counters inside the
+    previous call's slot lists -- phantom clusters naming empty slots, found on the 24-contig input.  Each pass is checked
+    against a plain group-by of the arrays the device itself holds."""
+    refs, rd, raw, off = _synth(seed=17, ref_len=400_000, coverage=25, big_every=6)
+    gpu_ctx.set_reference([refs[0].tobytes()])
+    gpu_ctx.set_insert_ranges(["generic"], [rd.range_max])
+    n = rd.n
+    pipe = capi.Pipeline(gpu_ctx, n, len(raw), cap_cand=n // 4)
+    sizes = [n, n // 40, n // 3, n // 200, n // 2, n // 11, n, 50, n // 5]
+    seen = 0
+    for m in sizes:
+        sub_off = off[:m + 1]
+        pipe.upload(raw[:int(sub_off[-1])], sub_off)
+        pipe.recs.n = m
+        pipe.triage()
+        pipe.fetch_counts()
+        pipe.realign()
+        nc = pipe.n_cand
+        pipe.flush(0, nc, 0, 2**31 - 1)
+        pipe.groupby()
+        pipe.sync()
+        ns = nc * capi.MAX_EV
+        cls = pipe.d_cls.download(np.int32, pipe.n_slots)[:ns]
+        b1 = pipe.d_b1.download(np.int32, pipe.n_slots)[:ns]
+        b2 = pipe.d_b2.download(np.int32, pipe.n_slots)[:ns]
+        cons = pipe.d_consumed.download(np.int32, pipe.n_slots)[:ns]
+        want = {}
+        for s in np.nonzero((cls >= 0) & (cls < 2) & (cons > 0))[0]:
+            want.setdefault((int(cons[s]), int(cls[s]), int(b1[s]), int(b2[s])), []).append(int(s))
+        key, first, count, order = pipe.clusters()
+        got = {tuple(int(x) for x in key[c]): [int(x) for x in order[first[c]:first[c] + count[c]]] for c in range(len(key))}
+        assert got == want, (m, len(got), len(want))
+        seen += len(want)
+    assert seen > 500
