@@ -332,7 +332,7 @@ template <int KT>
 __device__ __forceinline__ uint32_t vote_unit_direct(WaveLds& s, const uint32_t (&cur)[8], uint32_t (&nxt)[8],
                                                      const uint8_t* __restrict__ src_next, bool more,
                                                      uint32_t bsh, uint32_t kmask, uint32_t i0, uint32_t span,
-                                                     uint32_t obase, uint32_t off_limit, uint32_t mx)
+                                                     uint32_t obase, uint32_t off_limit, int arel, int kd, uint32_t mx)
 {
     // all eight table reads first, then the (rare) hits
     uint32_t v[8];
@@ -363,7 +363,13 @@ __device__ __forceinline__ uint32_t vote_unit_direct(WaveLds& s, const uint32_t 
         if (i <= span && off < off_limit) {
             const uint32_t bsel = (off & 3u) * 8u;
             const uint32_t old = atomicAdd(&s.diag[off >> 2], 1u << bsel);
-            mx = max(mx, ((old >> bsel) & 255u) + 1u);                   // this diagonal's count after the vote
+            // select_band's order as ONE key, largest wins: this diagonal's count after the vote, then nearest the anchor,
+            // then smallest index (kd - |anchor - off| and 2047 - off both fit 11 bits inside a chunk).  The vote that
+            // lifts a diagonal to its final count records that diagonal's key, so the largest key any lane saw names the
+            // chunk's band -- no pass over the histogram afterwards.
+            const uint32_t cnt = ((old >> bsel) & 255u) + 1u;
+            const uint32_t near = (uint32_t)(kd - abs(arel - (int)off));
+            mx = max(mx, (cnt << 22) | (near << 11) | (2047u - off));
         }
     }
     return mx;
@@ -434,14 +440,20 @@ __device__ __forceinline__ Band band_search(WaveLds& s, const uint8_t* __restric
 
         // vote: window k-mer at p and read-unique k-mer at q land on diagonal p - q + nq (102-105)
         const uint32_t obase = (uint32_t)p_lo + nq - c0 + 1u;      // off = obase + i - table value
-        uint32_t mx = 0;                                           // largest count this lane's votes produced (direct path)
+        uint32_t mx = 0;                                           // largest (count, nearness, index) key this lane's votes produced (direct path)
+        // the anchor relative to the chunk, and the smallest distance any of the chunk's diagonals has to it: distances
+        // minus that are below 1920 whatever the anchor (inside the chunk: both sides; outside: monotone in the index)
+        const int nbc = (int)(min(c0 + step, numdiag) - c0);
+        const int arel = anchor_rel - (int)c0;
+        const int dmin = arel < 0 ? -arel : (arel >= nbc ? arel - (nbc - 1) : 0);
+        const int kd = 2047 + dmin;
         if (DIRECT) {
             for (uint32_t u = 0; u < nunit; u += 2) {
                 mx = vote_unit_direct<KT>(s, wd, we, src + 128u * (u + 1u), u + 1 < nunit, bsh, kmask,
-                                          512u * u + (uint32_t)lane, span, obase, off_limit, mx);
+                                          512u * u + (uint32_t)lane, span, obase, off_limit, arel, kd, mx);
                 if (u + 1 < nunit)
                     mx = vote_unit_direct<KT>(s, we, wd, src + 128u * (u + 2u), u + 2 < nunit, bsh, kmask,
-                                              512u * (u + 1u) + (uint32_t)lane, span, obase, off_limit, mx);
+                                              512u * (u + 1u) + (uint32_t)lane, span, obase, off_limit, arel, kd, mx);
             }
         } else {
             for (uint32_t u = 0; u < nunit; u++) {
@@ -467,16 +479,22 @@ __device__ __forceinline__ Band band_search(WaveLds& s, const uint8_t* __restric
         const uint32_t iend = min(c0 + step, numdiag);
         const uint32_t nband = numdiag - g;                       // bands[i] == 0 for i >= nband (135)
         if (g == 0) {
-            // One diagonal per band.  The chunk's largest count M comes from the votes themselves (direct
-            // path: every LDS atomic returns the count it replaced) or from a pass of packed 16-bit
-            // maxima; then only the words that hold a byte equal to M are visited and the (distance,
-            // index)-least of those diagonals kept.  bc is wave-uniform; bd / bi are per lane and
-            // compared against the same bc.
+            // One diagonal per band: select_band's winner of the chunk (most votes, nearest the anchor, smallest index),
+            // merged into the running winner over the chunks.
             const uint32_t nb = iend - c0;
-            int M;
             if (DIRECT) {
-                M = wave_max((int)mx);                             // the votes reported their counts as they landed
+                // the votes reported (count, nearness, index) as they landed: one reduction names the chunk's band
+                const uint32_t K = (uint32_t)wave_max((int)mx);          // keys stay below 2^30
+                const int M = (int)(K >> 22);
+                if (M > 0 && M >= bc) {
+                    const int d = dmin + 2047 - (int)((K >> 11) & 2047u);
+                    const int i = (int)c0 + 2047 - (int)(K & 2047u);
+                    if (M > bc || d < bd || (d == bd && i < bi)) { bc = M; bd = d; bi = i; }
+                }
             } else {
+                // hash path (k > 6): the chunk's largest count from a pass of packed 16-bit maxima; then only the words that
+                // hold a byte equal to it are visited and the (distance, index)-least of those diagonals kept.  bc is
+                // wave-uniform; bd / bi are per lane here and reduced once at the end.
                 uint32_t me = 0, mo = 0;
                 for (uint32_t dw = lane; 4u * dw < nb; dw += 64) {
                     const uint32_t v = s.diag[dw];
@@ -484,21 +502,21 @@ __device__ __forceinline__ Band band_search(WaveLds& s, const uint8_t* __restric
                     mo = pk_max_u16(mo, (v >> 8) & 0x00FF00FFu);
                 }
                 const uint32_t m2 = pk_max_u16(me, mo);
-                M = wave_max((int)max(m2 & 0xFFFFu, m2 >> 16));
-            }
-            if (M > 0 && M >= bc) {
-                if (M > bc) { bc = M; bd = INT_MAX; bi = 0; }
-                const uint32_t rep = (uint32_t)M * 0x01010101u;
-                for (uint32_t dw = lane; 4u * dw < nb; dw += 64) {
-                    const uint32_t v = s.diag[dw];
-                    const uint32_t x = v ^ rep;
-                    if (((x - 0x01010101u) & ~x & 0x80808080u) == 0u) continue;      // no byte equals M
+                const int M = wave_max((int)max(m2 & 0xFFFFu, m2 >> 16));
+                if (M > 0 && M >= bc) {
+                    if (M > bc) { bc = M; bd = INT_MAX; bi = 0; }
+                    const uint32_t rep = (uint32_t)M * 0x01010101u;
+                    for (uint32_t dw = lane; 4u * dw < nb; dw += 64) {
+                        const uint32_t v = s.diag[dw];
+                        const uint32_t x = v ^ rep;
+                        if (((x - 0x01010101u) & ~x & 0x80808080u) == 0u) continue;      // no byte equals M
 #pragma unroll
-                    for (int bb = 0; bb < 4; bb++) {
-                        if (((v >> (8 * bb)) & 255u) != (uint32_t)M) continue;
-                        const int i = (int)(c0 + 4u * dw) + bb;
-                        const int d = abs(anchor_rel - i);
-                        if (d < bd || (d == bd && i < bi)) { bd = d; bi = i; }
+                        for (int bb = 0; bb < 4; bb++) {
+                            if (((v >> (8 * bb)) & 255u) != (uint32_t)M) continue;
+                            const int i = (int)(c0 + 4u * dw) + bb;
+                            const int d = abs(anchor_rel - i);
+                            if (d < bd || (d == bd && i < bi)) { bd = d; bi = i; }
+                        }
                     }
                 }
             }
@@ -527,7 +545,7 @@ __device__ __forceinline__ Band band_search(WaveLds& s, const uint8_t* __restric
         if (bc == 0) {
             // no vote anywhere: every diagonal ties at 0 and the nearest to the anchor wins
             bi = min(max(anchor_rel, 0), (int)numdiag - 1);
-        } else {
+        } else if (!DIRECT) {
             const int D = wave_min(bd);
             bi = wave_min(bd == D ? bi : INT_MAX);
         }
