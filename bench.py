@@ -282,17 +282,37 @@ class PipeStep:
         flushes, pe_b1, pe_b2 = flush_schedule(rd)
         self.flushes = flushes
         cap = max(4096, rd.n // 8)
+        ctx.depth_enable()
         self.sets = []
+        self.raw0, self.off = raw, off
+        at = (off[:-1] // 4).astype(np.int64)
         for k in range(depth):
+            # buffer set k works on contig k of the context (identical copies of the shard's contig): its own depth run,
+            # as consecutive groups of the product work on different contigs
+            rk = raw.copy()
+            r32 = rk[:len(rk) // 4 * 4].view(np.int32)
+            for word in (0, 5):                 # refID, next_refID
+                v = r32[at + word]
+                r32[at + word] = np.where(v >= 0, k, v)
             pipe = capi.Pipeline(ctx, rd.n, len(raw), cap_cand=cap, read_len_max=rd.read_len, n_pe=max(len(pe_b1), 1),
-                                 n_flushes=len(flushes), input_from=self.sets[0]["pipe"] if k else None)
-            if k == 0:
-                pipe.upload(raw, off)
+                                 n_flushes=len(flushes), want_depth=True)
+            pipe.upload(rk, off)
             pipe.set_pe(pe_b1, pe_b2)
             stream = capi.new_stream(ctx)
             self.sets.append({"pipe": pipe, "stream": stream, "done": capi.Event(ctx),
-                              "calls": pipe.bind_async(flushes, stream, grid_bound=cap), "graph": None, "tail": []})
+                              "calls": pipe.bind_async(flushes, stream, grid_bound=cap, depth_tid=k), "graph": None, "tail": []})
         self.k = 0
+
+    def depth_check(self, rd, clen, n_query=2000, seed=5):
+        """DP= range sums of every buffer set's contig against the pileup rule applied to the records on the host"""
+        from tests.support import oraclebind as ob
+        want = ob.depth_of(self.raw0, self.off, 0, clen).astype(np.int64)
+        cs = np.concatenate([[0], np.cumsum(want)])
+        rng = np.random.default_rng(seed)
+        beg = rng.integers(0, clen - 1, n_query).astype(np.int32)
+        end = np.minimum(beg + rng.integers(1, 2000, n_query), clen).astype(np.int32)
+        exp = (cs[end] - cs[beg]).astype(np.uint32)
+        return all(np.array_equal(self.ctx.depth_query_tid(k, beg, end), exp) for k in range(len(self.sets)))
 
     def capture(self):
         """One HIP graph per buffer set: the step's launches (3 fills, 4 triage kernels, realign, the flush list, 4 group-by
@@ -485,7 +505,7 @@ def shard3_measure(device, steps=24, warmup=4):
     cand = synth.candidates(rd)
     ctx = capi.Context(device)
     try:
-        ctx.set_reference([refs[0].tobytes()])
+        ctx.set_reference([refs[0].tobytes()] * PIPELINE_DEPTH)
         ctx.set_insert_ranges(["generic"], [rd.range_max])
         ps = PipeStep(ctx, rd, PIPELINE_DEPTH)
         ps.step(); ps.sync()
@@ -562,7 +582,7 @@ def main():
 
     # IM_BENCH_ONE_DEVICE=1: rehearsal of the multi-rank control flow on a one-GPU box
     ctx = capi.Context(0 if os.environ.get("IM_BENCH_ONE_DEVICE") == "1" else local_rank)
-    ctx.set_reference([refs[0].tobytes()])
+    ctx.set_reference([refs[0].tobytes()] * PIPELINE_DEPTH)        # buffer set k works on contig k (PipeStep)
     ctx.set_insert_ranges(["generic"], [rd.range_max])
     ps = PipeStep(ctx, rd, PIPELINE_DEPTH)
 
@@ -660,6 +680,10 @@ def main():
     # every buffer set must hold exactly what the pass leaves when it runs alone: the timed passes overlap on PIPELINE_DEPTH streams
     digests = [ps.digest(st_) for st_ in ps.sets[:min(len(ps.sets), args.steps + args.warmup)]]
     overlap_ok = all(dg == digest0 for dg in digests)
+    try:
+        depth_ok = bool(ps.depth_check(rd, len(refs[0]))) if args.steps + args.warmup >= len(ps.sets) else None
+    except Exception as ex:
+        depth_ok = "not checked: %s" % ex
     p0 = ps.sets[0]["pipe"]
     realign_ms = np.array([tm.elapsed_ms() for tm, at in timers if tm is not None and at == p0.realign_call_index])
     triage_ms = np.array([tm.elapsed_ms() for tm, at in timers if tm is not None and at == p0.triage_call_index])
@@ -725,11 +749,12 @@ def main():
                        "parallelism": "contig-sharded x%d" % world, "collective": collective,
                        "gathered_clusters": gathered_clusters,
                        "timed_region": "the product driver's device pass over EVERY delivered record of the shard: triage "
-                                       "(candidate rules, base decode, CIGAR evidence) -> realign -> one flush cut per READCHUNK "
-                                       "flush point -> split-read group-by; BGZF inflate and the pair table stay on the host "
+                                       "(candidate rules, base decode, CIGAR evidence, pileup depth scatter) -> depth scan of the contig -> realign -> "
+                                       "one flush cut per READCHUNK flush point -> split-read group-by; BGZF inflate and the pair table stay on the host "
                                        "(north_star) and are in end_to_end, not here",
                        "parity": parity,
                        "overlapped_passes_equal_the_pass_alone": overlap_ok,
+                       "depth_range_sums_equal_the_pileup_rule": depth_ok,
                        "pass_digest": {"candidates": digest0[0], "clusters": digest0[1], "md5": digest0[2],
                                        "of_each_buffer_set_after_the_timed_region": [dg[2] for dg in digests]}},
             "roofline": {"bound": "hbm", "kernel": "realign_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS,

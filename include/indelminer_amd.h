@@ -411,6 +411,8 @@ int im_dev_cluster_groupby_n(im_ctx* ctx, int32_t n_slots_cap, const int32_t* n_
  * have been through triage; im_depth_query_tid sums [beg,end) like im_depth_query. */
 int im_depth_enable(im_ctx* ctx);
 int im_depth_scan(im_ctx* ctx, int32_t tid, void* stream);
+/* contig tid's run back to zeros (asynchronous): a contig that is to go through triage + im_depth_scan AGAIN */
+int im_depth_reset(im_ctx* ctx, int32_t tid, void* stream);
 int im_depth_query_tid(im_ctx* ctx, int32_t tid, int32_t n, const int32_t* beg, const int32_t* end, uint32_t* sum_out);
 
 /* ---- multi-GPU: one collective ------------------------------------------------ */

@@ -191,6 +191,7 @@ def lib():
                                                C.c_void_p, C.c_size_t, C.c_void_p]
         L.im_depth_enable.argtypes = [C.c_void_p]
         L.im_depth_scan.argtypes = [C.c_void_p, C.c_int32, C.c_void_p]
+        L.im_depth_reset.argtypes = [C.c_void_p, C.c_int32, C.c_void_p]
         L.im_depth_query_tid.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]
         L.im_dev_memset.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_size_t, C.c_void_p]
         L.im_dev_copy_async.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
@@ -556,7 +557,7 @@ class Pipeline:
                                                      self.d_counts.ptr, self.d_gs.ptr, self.gs_bytes, st))
 
     # ---- the same three stages without a host round trip: the candidate count stays on the device ----
-    def bind_async(self, flushes, stream, tie_desc=0, grid_bound=None, one_launch_flushes=True):
+    def bind_async(self, flushes, stream, tie_desc=0, grid_bound=None, one_launch_flushes=True, depth_tid=None):
         """pre-binds one whole pass (triage -> realign -> flush cuts -> group-by) on `stream`; flushes =
         [(rec0, rec1, pe_hi, marker)] with record bounds.  Returns a list of (fn, args) to call in order."""
         L = lib()
@@ -565,6 +566,8 @@ class Pipeline:
         self.batch_bound = DevBatch(min(self.cap_cand, grid_bound or self.cap_cand), self.d_bases.ptr, self.d_boff.ptr, self.d_len.ptr,
                                     self.d_tid.ptr, self.d_anchor.ptr, self.d_range.ptr, self.d_res.ptr, self.d_cls.ptr, self.d_b1.ptr, self.d_b2.ptr)
         calls = [(L.im_dev_memset, (h, self.d_counters.ptr, 0, 64, stream))]
+        if depth_tid is not None:           # the contig goes through triage again: its run of the depth array starts from zeros
+            calls.append((L.im_depth_reset, (h, depth_tid, stream)))
         if not one_launch_flushes:
             calls += [(L.im_dev_memset, (h, self.d_consumed.ptr, 0, 4 * self.n_slots, stream)),
                       (L.im_dev_memset, (h, self.d_cut.ptr, 0xFF, 8 * self.n_flushes, stream))]
@@ -573,6 +576,8 @@ class Pipeline:
                   (L.im_dev_realign_n, (h, C.byref(self.P), C.byref(self.batch_bound), self.d_counters.ptr, 1, stream))]
         self.realign_call_index = len(calls) - 1
         self.triage_call_index = len(calls) - 2
+        if depth_tid is not None:           # the contig's records are all in: difference array -> depths (DP= queries of the replay)
+            calls.append((L.im_depth_scan, (h, depth_tid, stream)))
         if one_launch_flushes:
             desc = np.array([(rec0, rec1, 0, pe_hi, marker, k + 1) for k, (rec0, rec1, pe_hi, marker) in enumerate(flushes)], dtype=np.int32)
             self.d_desc = DevBuf(self.ctx, max(desc.nbytes, 24)).upload(desc)

@@ -435,6 +435,14 @@ int im_depth_scan(im_ctx* ctx, int32_t tid, void* stream)
     return IM_OK;
 }
 
+int im_depth_reset(im_ctx* ctx, int32_t tid, void* stream)
+{
+    if (!ctx || !ctx->gdepth || tid < 0 || tid >= ctx->n_contigs) return IM_E_ARG;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, hipMemsetAsync(ctx->gdepth + ctx->h_asc_off[tid], 0, ((size_t)ctx->h_len[tid] + 1) * sizeof(int32_t), (hipStream_t)stream));
+    return IM_OK;
+}
+
 int im_depth_query_tid(im_ctx* ctx, int32_t tid, int32_t n, const int32_t* beg, const int32_t* end, uint32_t* sum_out)
 {
     if (!ctx || n < 0 || !ctx->gdepth || tid < 0 || tid >= ctx->n_contigs) return IM_E_ARG;

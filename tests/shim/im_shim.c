@@ -142,6 +142,12 @@ int im_depth_scan(im_ctx* c, int32_t tid, void* stream)
     for (int64_t p = 0; p <= c->lens[tid]; p++) { run += g_gdepth[tid][p]; g_gdepth[tid][p] = run; }
     return IM_OK;
 }
+int im_depth_reset(im_ctx* c, int32_t tid, void* stream)
+{
+    (void)stream;
+    memset(g_gdepth[tid], 0, sizeof(int32_t) * ((size_t)c->lens[tid] + 1));
+    return IM_OK;
+}
 int im_depth_query_tid(im_ctx* c, int32_t tid, int32_t n, const int32_t* beg, const int32_t* end, uint32_t* sum_out)
 {
     for (int32_t q = 0; q < n; q++) {
