@@ -255,7 +255,9 @@ int im_dev_cluster_slots_max(void);
  * breakpoints and 1024 records per breakpoint per call; beyond them counts[0] = -1 and the
  * caller takes the im_dev_gather_evidence + im_dev_cluster_sr path (after a distinct-key
  * overflow the scratch must be re-initialised).  scratch: im_dev_cluster_hist_scratch_bytes(n_slots)
- * bytes, prepared ONCE with im_dev_cluster_hist_init; every call leaves it clean.  Asynchronous. */
+ * bytes, prepared ONCE with im_dev_cluster_hist_init; every call leaves it clean.  The scratch is laid out for
+ * the n_slots it was prepared with: call with THAT n_slots every time (pad the slot arrays with cls = -1), or prepare it
+ * again.  Asynchronous. */
 size_t im_dev_cluster_hist_scratch_bytes(int32_t n_slots);
 int im_dev_cluster_hist_init(im_ctx* ctx, int32_t n_slots, void* scratch, size_t scratch_bytes, void* stream);
 int im_dev_cluster_hist(im_ctx* ctx, int32_t n_slots,
