@@ -61,6 +61,14 @@ static void fatalf(const char* fmt, ...)
     va_end(ap);
     exit(EXIT_FAILURE);
 }
+/* Everything the driver prints as output goes through printf.  A replay worker (run_pipeline) points its own t_out at a
+ * memory buffer, so that several groups can be replayed at once and still come out in contig order; every other thread
+ * prints to stdout. */
+static __thread FILE* t_out;
+#define OUT (t_out ? t_out : stdout)
+#define printf(...) fprintf(OUT, __VA_ARGS__)
+static pthread_mutex_t g_query_mu = PTHREAD_MUTEX_INITIALIZER;     /* depth queries share the context's workspace and stream */
+
 #define forceassert(e) do { if (!(e)) { fprintf(stderr, "Assertion failed: %s file %s line %d\n", #e, __FILE__, __LINE__); exit(EXIT_FAILURE); } } while (0)
 
 static double now_ms(void)
@@ -855,7 +863,10 @@ static uint32_t region_depth(driver* d, int32_t tid, int32_t start, int32_t stop
         /* the device holds the contig's depth array (im_depth_build in run_contig) */
         uint32_t sum = 0;
         gpu_wait(d);
-        if ((d->pipe_mode ? im_depth_query_tid(d->gpu, tid, 1, &start, &stop, &sum) : im_depth_query(d->gpu, 1, &start, &stop, &sum)) != IM_OK)
+        pthread_mutex_lock(&g_query_mu);
+        const int qrc = d->pipe_mode ? im_depth_query_tid(d->gpu, tid, 1, &start, &stop, &sum) : im_depth_query(d->gpu, 1, &start, &stop, &sum);
+        pthread_mutex_unlock(&g_query_mu);
+        if (qrc != IM_OK)
             fatalf("im_depth_query: %s", im_last_error(d->gpu));
         return (uint32_t)floor(sum * 1.0 / (uint32_t)(stop - start));
     }
@@ -1178,7 +1189,10 @@ static void print_variants(driver* d, variant_list* vs)
         }
         if (m > 0) {
             gpu_wait(d);
-            if ((d->pipe_mode ? im_depth_query_tid(d->gpu, d->depth_tid, m, beg, end, sum) : im_depth_query(d->gpu, m, beg, end, sum)) != IM_OK)
+            pthread_mutex_lock(&g_query_mu);
+            const int qrc = d->pipe_mode ? im_depth_query_tid(d->gpu, d->depth_tid, m, beg, end, sum) : im_depth_query(d->gpu, m, beg, end, sum);
+            pthread_mutex_unlock(&g_query_mu);
+            if (qrc != IM_OK)
                 fatalf("im_depth_query: %s", im_last_error(d->gpu));
             for (int q = 0; q < m; q++) {
                 variant_t* v = out.v[who[q]];
@@ -2663,7 +2677,7 @@ static void group_replay(driver* d, pgroup* G)
                 merge_variants(&vs, d->sequences[tid], d->seqlen[tid], 0);
                 print_knownvariants(d, &g_known, &vs);
             }
-            fflush(stdout);
+            fflush(OUT);
             for (int i = 0; i < vs.n; i++) variant_free(vs.v[i]);
             free(vs.v);
             for (int64_t i = 0; i < n_used; i++) evidence_free(used[i]);
@@ -2681,7 +2695,6 @@ static void group_replay(driver* d, pgroup* G)
     }
     /* evidence objects that were built for a read but never reached a cluster (a consumed slot whose
      * cluster was dropped is freed with its flush; nothing else is ever built) */
-    phase_time("replay (variants, merge, print)");
 }
 
 /* ============================================================== multi-GPU == */
@@ -3016,12 +3029,18 @@ typedef struct {
 
 typedef struct { int first, count; walker_t* W; pgroup* G; int walked; } claim_t;
 
+/* a group whose device stage is done, on its way through a replay worker: what it prints waits in buf until every group
+ * before it has been printed */
+typedef struct { walker_t* W; pgroup* G; char* buf; size_t len; int done; } rjob_t;
+typedef struct { struct walkpool_s* pool; driver rd; pthread_t th; } replayer_t;
+
 typedef struct walkpool_s {
     driver* d;
     int32_t* order; int n_order;        /* the contigs this process handles, ascending */
     claim_t* claims; int n_claims, next_claim;
     walker_t* w; int nw;
     int serial, go;
+    rjob_t* jobs; int n_jobs, next_job, jobs_closed;    /* replay queue, in contig order */
     pthread_mutex_t mu; pthread_cond_t cv;
 } walkpool_t;
 
@@ -3074,6 +3093,31 @@ static void* walker_thread(void* arg)
         pipe_drain(&W->P, G);
         pthread_mutex_lock(&o->mu);
         c->W = W; c->G = G; c->walked = 1; W->n_started++;
+        pthread_cond_broadcast(&o->cv);
+        pthread_mutex_unlock(&o->mu);
+    }
+    return NULL;
+}
+
+static void* replay_thread(void* arg)
+{
+    replayer_t* R = arg;
+    walkpool_t* o = R->pool;
+    for (;;) {
+        pthread_mutex_lock(&o->mu);
+        while (o->next_job >= o->n_jobs && !o->jobs_closed) pthread_cond_wait(&o->cv, &o->mu);
+        const int j = o->next_job < o->n_jobs ? o->next_job++ : -1;
+        pthread_mutex_unlock(&o->mu);
+        if (j < 0) break;
+        rjob_t* J = &o->jobs[j];
+        t_out = open_memstream(&J->buf, &J->len);
+        if (!t_out) fatalf("cannot buffer the output of a group");
+        group_replay(&R->rd, J->G);
+        fclose(t_out);
+        t_out = NULL;
+        group_reset(J->G);
+        pthread_mutex_lock(&o->mu);
+        J->W->replayed++; J->done = 1;
         pthread_cond_broadcast(&o->cv);
         pthread_mutex_unlock(&o->mu);
     }
@@ -3133,6 +3177,21 @@ static void run_pipeline(driver* d, walkpool_t* o)
     pipe_global_init(d);
     if (o->serial) { walker_setup(&o->w[0], d); walker_adopt_driver(&o->w[0], d); }
     pthread_mutex_lock(&o->mu); o->go = 1; pthread_cond_broadcast(&o->cv); pthread_mutex_unlock(&o->mu);
+    /* Replay workers: the replay of a group (evidence objects, paired-read components, merge, print) is the longest serial
+     * piece of a run once the walks overlap; groups are independent of each other, so several are replayed at once, each
+     * into a buffer that is written out when every group before it has been.  The numbered blocks of -o detailed, annotate
+     * mode (one known-variant list) and the per-contig part files of a multi-GPU run keep the replay on this thread. */
+    const char* re = getenv("INDELMINER_REPLAYERS");
+    int nrep = re ? atoi(re) : 3;
+    if (o->serial || g_mg || strcmp(O.outputformat, "vcf") != 0 || nrep < 2) nrep = 0;
+    if (nrep > 8) nrep = 8;
+    replayer_t* rp = nrep ? xcalloc((size_t)nrep, sizeof(replayer_t)) : NULL;
+    if (nrep) o->jobs = xcalloc((size_t)(o->n_claims ? o->n_claims : 1), sizeof(rjob_t));
+    for (int i = 0; i < nrep; i++) {
+        rp[i].pool = o; rp[i].rd = *d; rp[i].rd.gpu_pending = 0;
+        if (pthread_create(&rp[i].th, NULL, replay_thread, &rp[i]) != 0) fatalf("cannot start a replay thread");
+    }
+    int printed = 0;
     int64_t numread = d->numread;
     int floor_ = d->marker_floor;
     for (int ci = 0; ci < o->n_claims; ci++) {
@@ -3160,9 +3219,45 @@ static void run_pipeline(driver* d, walkpool_t* o)
         group_resolve_flushes(G, &numread, &floor_);
         pipe_run_group(&W->P, G);
         pthread_mutex_lock(&o->mu); W->device_free++; pthread_cond_broadcast(&o->cv); pthread_mutex_unlock(&o->mu);
+        if (nrep) {
+            pthread_mutex_lock(&o->mu);
+            rjob_t* J = &o->jobs[o->n_jobs];
+            J->W = W; J->G = G; J->buf = NULL; J->len = 0; J->done = 0;
+            o->n_jobs++;
+            pthread_cond_broadcast(&o->cv);
+            /* whatever is complete at the head of the queue goes out now */
+            while (printed < o->n_jobs && o->jobs[printed].done) {
+                rjob_t* P = &o->jobs[printed++];
+                pthread_mutex_unlock(&o->mu);
+                if (P->len && fwrite(P->buf, 1, P->len, stdout) != P->len) fatalf("write to stdout failed");
+                free(P->buf);
+                pthread_mutex_lock(&o->mu);
+            }
+            pthread_mutex_unlock(&o->mu);
+            continue;
+        }
         group_replay(d, G);
+        phase_time("replay (variants, merge, print)");
         group_reset(G);
         pthread_mutex_lock(&o->mu); W->replayed++; pthread_cond_broadcast(&o->cv); pthread_mutex_unlock(&o->mu);
+    }
+    if (nrep) {
+        pthread_mutex_lock(&o->mu);
+        o->jobs_closed = 1;
+        pthread_cond_broadcast(&o->cv);
+        while (printed < o->n_jobs) {
+            while (!o->jobs[printed].done) pthread_cond_wait(&o->cv, &o->mu);
+            rjob_t* P = &o->jobs[printed++];
+            pthread_mutex_unlock(&o->mu);
+            if (P->len && fwrite(P->buf, 1, P->len, stdout) != P->len) fatalf("write to stdout failed");
+            free(P->buf);
+            pthread_mutex_lock(&o->mu);
+        }
+        pthread_mutex_unlock(&o->mu);
+        for (int i = 0; i < nrep; i++) pthread_join(rp[i].th, NULL);
+        fflush(stdout);
+        phase_time("replay workers drained");
+        free(rp); free(o->jobs);
     }
     d->numread = numread;
     for (int i = 0; i < o->nw && !o->serial; i++) pthread_join(o->w[i].th, NULL);

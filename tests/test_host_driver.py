@@ -198,11 +198,16 @@ def test_host_parallel_walkers_give_the_single_walk(tmp_path):
     ref_bin = os.path.join(ROOT, "oracle", "_ref", "indelminer")
     if os.path.exists(ref_bin):
         assert _run(ref_bin, [], str(tmp_path), ref="ref.fa", bam="aln.bam") == want
-    for walkers, claim in (("1", None), ("3", None), ("2", "1"), ("6", "1"), ("4", "450000")):
+    for walkers, claim, replayers in (("1", None, None), ("3", None, None), ("2", "1", "1"), ("6", "1", "4"), ("4", "450000", "2")):
         env = {"INDELMINER_WALKERS": walkers}
         if claim:
             env["INDELMINER_CLAIM_BASES"] = claim
+        if replayers:
+            env["INDELMINER_REPLAYERS"] = replayers        # groups replayed at once, printed in contig order
         assert _run(shim, [], str(tmp_path), ref="ref.fa", bam="aln.bam", env=env) == want, env
+    # -o detailed numbers its blocks across the whole run: the replay stays on one thread there
+    det = _run(shim, ["-o", "detailed"], str(tmp_path), ref="ref.fa", bam="aln.bam", env={"INDELMINER_PIPELINE": "host"})
+    assert _run(shim, ["-o", "detailed"], str(tmp_path), ref="ref.fa", bam="aln.bam", env={"INDELMINER_WALKERS": "4", "INDELMINER_CLAIM_BASES": "1"}) == det
 
 
 def _long_read_dir(tmp_path):
