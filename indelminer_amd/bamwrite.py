@@ -107,6 +107,10 @@ def write_bam(path, contigs, rd, qname_prefix="r"):
             mapq = 0 if unm else int(rd.mapq)
             mq = 0 if (flag & 0x8) else int(rd.mapq)
             tags = b"MQC" + bytes([mq])
+            if getattr(rd, "rg_names", None) is not None:      # optional read groups: rd.rg_names[rd.rg_idx[i]], "" = no RG tag
+                name = rd.rg_names[int(rd.rg_idx[i])]
+                if name:
+                    tags += b"RGZ" + name.encode() + b"\0"
             cig = b"".join(struct.pack("<I", (l << 4) | o) for l, o in ops)
             body = struct.pack("<iiBBHHHiiii", tid, pos, len(qn), mapq, b, len(ops), flag, L, tid,
                                int(rd.mpos[i]), int(rd.isize[i])) + qn + cig + packed + qual + tags

@@ -210,6 +210,58 @@ def test_host_parallel_walkers_give_the_single_walk(tmp_path):
     assert _run(shim, ["-o", "detailed"], str(tmp_path), ref="ref.fa", bam="aln.bam", env={"INDELMINER_WALKERS": "4", "INDELMINER_CLAIM_BASES": "1"}) == det
 
 
+def test_host_contigs_without_reads(tmp_path):
+    """contigs that deliver no record at all -- the first, one in the middle, the last -- between contigs that do: claims,
+    groups and flush placement must not mind (the read counter and the marker floor simply pass through them)"""
+    import numpy as np
+    from indelminer_amd import bamwrite, rawrec, synth
+    refs, rd = synth.simulate(seed=31, ref_len=150_000, coverage=30, n_contigs=5, big_every=4)
+    keep = np.isin(rd.tid, [1, 3])
+    for name, col in list(vars(rd).items()):
+        if isinstance(col, np.ndarray) and len(col) == len(keep):
+            setattr(rd, name, col[keep])
+    rd.n = int(keep.sum())
+    contigs = [("ctg%d" % i, len(r)) for i, r in enumerate(refs)]
+    bamwrite.write_fasta(str(tmp_path / "ref.fa"), contigs, refs)
+    rawrec.write_bam_fast(str(tmp_path / "aln.bam"), contigs, rd)
+    shim = _build_shim()
+    want = _run(shim, [], str(tmp_path), ref="ref.fa", bam="aln.bam", env={"INDELMINER_PIPELINE": "host"})
+    assert want.count(b"\n") > 50
+    ref_bin = os.path.join(ROOT, "oracle", "_ref", "indelminer")
+    if os.path.exists(ref_bin):
+        assert _run(ref_bin, [], str(tmp_path), ref="ref.fa", bam="aln.bam") == want
+    for env in ({}, {"INDELMINER_WALKERS": "5", "INDELMINER_CLAIM_BASES": "1"}, {"INDELMINER_WALKERS": "1"}):
+        assert _run(shim, [], str(tmp_path), ref="ref.fa", bam="aln.bam", env=env) == want, env
+
+
+def test_host_read_groups_estimated_by_several_threads(tmp_path):
+    """no config file: the insert-length table is estimated -- by several threads over different contigs -- and must list the
+    read groups in the order ONE process meets them (the table's prefix-match / last-hit look-up depends on insertion
+    order: "li" is a prefix of "lib1" is a prefix of "lib10"); records without an RG tag are "generic".  Pipeline with
+    several walkers == one-record-at-a-time host path == the reference."""
+    import numpy as np
+    from indelminer_amd import bamwrite, synth
+    refs, rd = synth.simulate(seed=41, ref_len=60_000, coverage=25, n_contigs=4, big_every=4)
+    rd.rg_names = ["lib10", "li", "", "lib1"]
+    # a pair shares its read group; the groups first appear in different contigs and in an order that is not alphabetical
+    first_tid = {0: 0, 1: 0, 2: 1, 3: 2}
+    g = (rd.pair_id % 4).astype(np.int64)
+    for k, t in first_tid.items():
+        g[(g == k) & (rd.tid < t)] = 0
+    rd.rg_idx = g
+    contigs = [("ctg%d" % i, len(r)) for i, r in enumerate(refs)]
+    bamwrite.write_fasta(str(tmp_path / "ref.fa"), contigs, refs)
+    bamwrite.write_bam(str(tmp_path / "aln.bam"), contigs, rd)
+    shim = _build_shim()
+    want = _run(shim, [], str(tmp_path), ref="ref.fa", bam="aln.bam", env={"INDELMINER_PIPELINE": "host", "INDELMINER_ESTIMATE_SERIAL": "1"})
+    assert want.count(b"\n") > 40
+    ref_bin = os.path.join(ROOT, "oracle", "_ref", "indelminer")
+    if os.path.exists(ref_bin):
+        assert _run(ref_bin, [], str(tmp_path), ref="ref.fa", bam="aln.bam") == want
+    for env in ({}, {"INDELMINER_WALKERS": "3", "INDELMINER_CLAIM_BASES": "1"}, {"INDELMINER_PIPELINE": "host"}):
+        assert _run(shim, [], str(tmp_path), ref="ref.fa", bam="aln.bam", env=env) == want, env
+
+
 def _long_read_dir(tmp_path):
     from indelminer_amd import bamwrite, synth
     refs, rd = synth.simulate(seed=5, ref_len=20_000, coverage=4, read_len=300, isize_mean=900, isize_min=700, isize_max=1100)
