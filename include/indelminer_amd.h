@@ -410,7 +410,8 @@ int im_dev_cluster_groupby_n(im_ctx* ctx, int32_t n_slots_cap, const int32_t* n_
 
 /* One int32 per reference position for ALL contigs (4 bytes per base of HBM), filled by im_dev_triage
  * (want_depth) as a difference array; im_depth_scan turns contig tid into depths once all its records
- * have been through triage; im_depth_query_tid sums [beg,end) like im_depth_query. */
+ * have been through triage (one launch: depths local to 8192-position tiles plus a tile offset each, which
+ * only im_depth_query_tid knows how to read); im_depth_query_tid sums [beg,end) like im_depth_query. */
 int im_depth_enable(im_ctx* ctx);
 int im_depth_scan(im_ctx* ctx, int32_t tid, void* stream);
 /* contig tid's run back to zeros (asynchronous): a contig that is to go through triage + im_depth_scan AGAIN */

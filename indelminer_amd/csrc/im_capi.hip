@@ -423,6 +423,7 @@ int im_depth_enable(im_ctx* ctx)
     HIP_TRY(ctx, hipMalloc((void**)&ctx->gdepth, (size_t)ctx->ref_total * sizeof(int32_t)));
     HIP_TRY(ctx, hipMalloc((void**)&ctx->gdepth_sums, (size_t)(tiles + 1) * sizeof(int32_t)));
     HIP_TRY(ctx, hipMemsetAsync(ctx->gdepth, 0, (size_t)ctx->ref_total * sizeof(int32_t), ctx->stream));
+    HIP_TRY(ctx, hipMemsetAsync(ctx->gdepth_sums, 0, (size_t)(tiles + 1) * sizeof(int32_t), ctx->stream));      // the arrival counters start at zero
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     return IM_OK;
 }
@@ -431,7 +432,8 @@ int im_depth_scan(im_ctx* ctx, int32_t tid, void* stream)
 {
     if (!ctx || !ctx->gdepth || tid < 0 || tid >= ctx->n_contigs) return IM_E_ARG;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
-    HIP_TRY(ctx, im::launch_depth_scan(ctx->gdepth + ctx->h_asc_off[tid], (int64_t)ctx->h_len[tid] + 1, ctx->gdepth_sums + ctx->h_sums_off[tid], (hipStream_t)stream));
+    // one launch: tile-local depths + exclusive tile offsets (im_depth_query_tid adds them)
+    HIP_TRY(ctx, im::launch_depth_scan_tiled(ctx->gdepth + ctx->h_asc_off[tid], (int64_t)ctx->h_len[tid] + 1, ctx->gdepth_sums + ctx->h_sums_off[tid], (hipStream_t)stream));
     return IM_OK;
 }
 
@@ -456,7 +458,7 @@ int im_depth_query_tid(im_ctx* ctx, int32_t tid, int32_t n, const int32_t* beg, 
     uint32_t* d_out = (uint32_t*)((char*)ctx->ws + 2 * sb);
     HIP_TRY(ctx, hipMemcpyAsync(d_beg, beg, sizeof(int32_t) * (size_t)n, hipMemcpyHostToDevice, ctx->stream));
     HIP_TRY(ctx, hipMemcpyAsync(d_end, end, sizeof(int32_t) * (size_t)n, hipMemcpyHostToDevice, ctx->stream));
-    HIP_TRY(ctx, im::launch_depth_query(n, d_beg, d_end, ctx->gdepth + ctx->h_asc_off[tid], ctx->h_len[tid], d_out, ctx->stream));
+    HIP_TRY(ctx, im::launch_depth_query_tiled(n, d_beg, d_end, ctx->gdepth + ctx->h_asc_off[tid], ctx->gdepth_sums + ctx->h_sums_off[tid], ctx->h_len[tid], d_out, ctx->stream));
     HIP_TRY(ctx, hipMemcpyAsync(sum_out, d_out, sizeof(uint32_t) * (size_t)n, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     return IM_OK;

@@ -55,6 +55,76 @@ __global__ __launch_bounds__(kScanBlock) void depth_scan_tiles_kernel(int32_t* _
     if (tid == kScanBlock - 1) sums[blockIdx.x] = woff + x;
 }
 
+// Genome-wide form, ONE launch per contig: the tile scan as above, and the workgroup that finishes last turns the tile totals
+// into exclusive offsets in place.  The depths are left tile-local; depth_query_tiled adds a position's tile offset when it
+// reads it -- no third pass over the contig.  Totals travel through returning agent-scope atomics (written and read back
+// on the same path, no fence: im_triage.hip uses the same hand-over); sums[tiles] is the arrival counter, zero between launches.
+__global__ __launch_bounds__(kScanBlock) void depth_scan_tiled_kernel(int32_t* __restrict__ data, int64_t n, int32_t* __restrict__ sums, int32_t tiles)
+{
+    __shared__ int32_t wsum[kScanBlock / 64];
+    __shared__ int32_t s_last, carry_s;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int64_t base = (int64_t)blockIdx.x * kScanTile + (int64_t)tid * kScanItems;
+    int32_t v[kScanItems];
+    int32_t run = 0;
+#pragma unroll
+    for (int e = 0; e < kScanItems; e++) { const int64_t i = base + e; v[e] = (i < n) ? data[i] : 0; run += v[e]; v[e] = run; }
+    int32_t x = run;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { int32_t t = __shfl_up(x, o); if (lane >= o) x += t; }
+    if (lane == 63) wsum[wave] = x;
+    __syncthreads();
+    int32_t woff = 0;
+    for (int w = 0; w < wave; w++) woff += wsum[w];
+    const int32_t excl = woff + x - run;
+#pragma unroll
+    for (int e = 0; e < kScanItems; e++) { const int64_t i = base + e; if (i < n) data[i] = v[e] + excl; }
+    if (tid == kScanBlock - 1) {
+        const int32_t seen = atomicExch(&sums[blockIdx.x], woff + x);
+        asm volatile("" :: "v"(seen));                  // the total is in before this workgroup is counted
+        s_last = atomicAdd(&sums[tiles], 1) == tiles - 1 ? 1 : 0;
+        carry_s = 0;
+    }
+    __syncthreads();
+    if (!s_last) return;
+    for (int32_t b0 = 0; b0 < tiles; b0 += kScanBlock) {
+        const int32_t j = b0 + tid;
+        const int32_t t = j < tiles ? atomicAdd(&sums[j], 0) : 0;
+        int32_t y = t;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) { int32_t u = __shfl_up(y, o); if (lane >= o) y += u; }
+        if (lane == 63) wsum[wave] = y;
+        __syncthreads();
+        int32_t wo = 0;
+        for (int w = 0; w < wave; w++) wo += wsum[w];
+        const int32_t carry = carry_s;
+        if (j < tiles) sums[j] = carry + wo + y - t;
+        __syncthreads();
+        if (tid == kScanBlock - 1) carry_s = carry + wo + y;
+        __syncthreads();
+    }
+    if (tid == 0) sums[tiles] = 0;
+}
+
+__global__ __launch_bounds__(256) void depth_query_tiled_kernel(int32_t nq, const int32_t* __restrict__ beg, const int32_t* __restrict__ end,
+                                                               const int32_t* __restrict__ depth, const int32_t* __restrict__ sums,
+                                                               int64_t clen, uint32_t* __restrict__ out)
+{
+    const int lane = threadIdx.x & 63;
+    const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int nwaves = (gridDim.x * blockDim.x) >> 6;
+    for (int q = wave; q < nq; q += nwaves) {
+        int64_t a = beg[q], b = end[q];
+        if (a < 0) a = 0;
+        if (b > clen) b = clen;
+        uint32_t s = 0;
+        for (int64_t p = a + lane; p < b; p += 64) s += (uint32_t)(depth[p] + sums[p / kScanTile]);
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) s += (uint32_t)__shfl_xor((int)s, o);
+        if (lane == 0) out[q] = s;
+    }
+}
+
 // phase 2: exclusive scan of the tile totals by one workgroup
 __global__ __launch_bounds__(kScanBlock) void depth_scan_sums_kernel(int32_t* __restrict__ sums, int64_t n)
 {
@@ -137,6 +207,25 @@ hipError_t launch_depth_scan(int32_t* depth, int64_t n, int32_t* sums, hipStream
 }
 
 int64_t depth_tiles(int64_t clen) { return (clen + 1 + kScanTile - 1) / kScanTile; }
+
+// genome-wide form: n elements, sums holds depth_tiles(n - 1) + 1 entries (the last one the arrival counter, zero between launches)
+hipError_t launch_depth_scan_tiled(int32_t* depth, int64_t n, int32_t* sums, hipStream_t stream)
+{
+    if (n <= 0) return hipSuccess;
+    const int64_t tiles = (n + kScanTile - 1) / kScanTile;
+    hipLaunchKernelGGL(depth_scan_tiled_kernel, dim3((int)tiles), dim3(kScanBlock), 0, stream, depth, n, sums, (int32_t)tiles);
+    return hipGetLastError();
+}
+
+hipError_t launch_depth_query_tiled(int32_t nq, const int32_t* beg, const int32_t* end, const int32_t* depth, const int32_t* sums,
+                                    int64_t clen, uint32_t* out, hipStream_t stream)
+{
+    if (nq <= 0) return hipSuccess;
+    int b = (nq + 3) / 4;
+    if (b > 2048) b = 2048;
+    hipLaunchKernelGGL(depth_query_tiled_kernel, dim3(b), dim3(256), 0, stream, nq, beg, end, depth, sums, clen, out);
+    return hipGetLastError();
+}
 
 hipError_t launch_depth_query(int32_t nq, const int32_t* beg, const int32_t* end, const int32_t* depth, int64_t clen,
                               uint32_t* out, hipStream_t stream)

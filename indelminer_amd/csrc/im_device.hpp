@@ -63,6 +63,9 @@ hipError_t launch_groupby(int32_t n_layout, int32_t n_slots, const int32_t* n_ca
                           int32_t tie_desc, int32_t* order, int32_t* cl_key, int32_t* cl_first, int32_t* cl_count,
                           int32_t* counts, void* scratch, hipStream_t stream);
 hipError_t launch_depth_scan(int32_t* depth, int64_t n, int32_t* sums, hipStream_t stream);
+hipError_t launch_depth_scan_tiled(int32_t* depth, int64_t n, int32_t* sums, hipStream_t stream);
+hipError_t launch_depth_query_tiled(int32_t nq, const int32_t* beg, const int32_t* end, const int32_t* depth, const int32_t* sums,
+                                    int64_t clen, uint32_t* out, hipStream_t stream);
 
 // launchers (im_realign.hip / im_cluster.hip)
 hipError_t launch_pack_reference(const uint8_t* ascii, uint64_t* pk, int64_t n_bases_padded,
