@@ -348,11 +348,11 @@ int bam_read_record(bgzf_reader* r, bam_record* b)
 int32_t bam_record_end(const bam_record* b)
 {
     /* bam_calend (bam.c:17-39): M, D, N, =, X consume the reference */
-    const uint32_t* cig = BAMR_CIGAR(b);
+    const uint8_t* cig = BAMR_CIGAR(b);
     int32_t end = b->pos;
     for (int k = 0; k < b->n_cigar; k++) {
-        const int op = (int)(cig[k] & 15u);
-        if (op == 0 || op == 2 || op == 3 || op == 7 || op == 8) end += (int32_t)(cig[k] >> 4);
+        const int op = (int)(bamr_cigar_at(cig, k) & 15u);
+        if (op == 0 || op == 2 || op == 3 || op == 7 || op == 8) end += (int32_t)(bamr_cigar_at(cig, k) >> 4);
     }
     return end;
 }

@@ -8,6 +8,7 @@
 #define IM_HOSTIO_H
 
 #include <stdint.h>
+#include <string.h>
 #include <stdio.h>
 
 /* ---- BGZF reader ---- */
@@ -35,7 +36,9 @@ typedef struct {
 } bam_record;
 
 #define BAMR_QNAME(b)  ((char*)(b)->data)
-#define BAMR_CIGAR(b)  ((uint32_t*)((b)->data + (b)->l_qname))
+/* CIGAR word k: the words follow the read name, at any byte alignment */
+static inline uint32_t bamr_cigar_at(const uint8_t* cig8, int k) { uint32_t v; memcpy(&v, cig8 + 4 * (size_t)k, 4); return v; }
+#define BAMR_CIGAR(b)  ((const uint8_t*)((b)->data + (b)->l_qname))
 #define BAMR_SEQ(b)    ((b)->data + (b)->l_qname + 4 * (b)->n_cigar)
 #define BAMR_AUX(b)    ((b)->data + (b)->l_qname + 4 * (b)->n_cigar + (((b)->l_seq + 1) >> 1) + (b)->l_seq)
 #define BAMR_SEQI(s, i) (((s)[(i) >> 1] >> ((~(i) & 1) << 2)) & 0xf)

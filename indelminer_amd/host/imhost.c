@@ -212,12 +212,12 @@ static seglist seglist_from_record(const bam_record* b)
     s.ref_start = b->pos;
     s.n = b->n_cigar;
     s.ops = xmalloc(sizeof(uint32_t) * (size_t)(b->n_cigar ? b->n_cigar : 1));
-    const uint32_t* cig = BAMR_CIGAR(b);
+    const uint8_t* cig = BAMR_CIGAR(b);
     for (int i = 0; i < b->n_cigar; i++) {
-        const int op = CIG_OP(cig[i]);
+        const int op = CIG_OP(bamr_cigar_at(cig, i));
         if (op == OP_N || op == OP_H || op == OP_P) fatalf("Implement new_readseg_bam: CIGAR op %d", op);
         if (op > OP_X) fatalf("Unhandled cigar operation");
-        s.ops[i] = cig[i];
+        s.ops[i] = bamr_cigar_at(cig, i);
     }
     s.bases = decode_bases(b);
     return s;
@@ -610,10 +610,10 @@ static void dispatch_record(driver* d, const bam_record* b)
         const char strand0 = is_rc ? '-' : '+';
         uint32_t numcdels = 0, numcins = 0, numcsclip = 0;
         int is_threeprime_clip = 0;
-        const uint32_t* cig = BAMR_CIGAR(b);
+        const uint8_t* cig = BAMR_CIGAR(b);
         const int ncig = b->n_cigar;
         for (int i = 0; i < ncig; i++) {
-            const int op = CIG_OP(cig[i]);
+            const int op = CIG_OP(bamr_cigar_at(cig, i));
             if (op == OP_N || op == OP_H || op == OP_P) fatalf("Implement new_readseg_bam: CIGAR op %d", op);
             if (op > OP_X) fatalf("Unhandled cigar operation");
             if (op == OP_D) numcdels++;
@@ -889,10 +889,10 @@ static uint32_t region_depth_from_bam(driver* d, int32_t tid, int32_t start, int
     if (h && bam_region_begin(&it, r, d->idx, tid, start, stop) == 0) {
         while (bam_region_next(&it, &b) == 1) {
             if (b.tid < 0 || (b.flag & (0x4 | 0x100 | 0x200 | 0x400))) continue;
-            const uint32_t* cig = BAMR_CIGAR(&b);
+            const uint8_t* cig = BAMR_CIGAR(&b);
             int32_t x = b.pos;
             for (int k = 0; k < b.n_cigar; k++) {
-                const int op = CIG_OP(cig[k]), len = CIG_LEN(cig[k]);
+                const int op = CIG_OP(bamr_cigar_at(cig, k)), len = CIG_LEN(bamr_cigar_at(cig, k));
                 if (op == OP_M || op == OP_EQ || op == OP_X) {
                     int32_t lo = x < start ? start : x, hi = x + len > stop ? stop : x + len;
                     for (int32_t p = lo; p < hi; p++) cov[p - start]++;
@@ -1816,10 +1816,10 @@ static void run_contig(driver* d, int32_t tid, int32_t beg, int32_t end, bgzf_re
     while (bam_region_next(&it, &b) == 1) {
         if (whole && b.tid >= 0 && !(b.flag & (0x4 | 0x100 | 0x200 | 0x400))) {
             /* what samtools' pileup would count for DP= (bam_pileup.c:171-172,238-265) */
-            const uint32_t* cig = BAMR_CIGAR(&b);
+            const uint8_t* cig = BAMR_CIGAR(&b);
             int32_t x = b.pos;
             for (int kk = 0; kk < b.n_cigar; kk++) {
-                const int op = CIG_OP(cig[kk]), len = CIG_LEN(cig[kk]);
+                const int op = CIG_OP(bamr_cigar_at(cig, kk)), len = CIG_LEN(bamr_cigar_at(cig, kk));
                 if (op == OP_M || op == OP_EQ || op == OP_X) {
                     if (d->n_seg == d->cap_seg) {
                         d->cap_seg = d->cap_seg ? d->cap_seg * 2 : (1 << 16);
