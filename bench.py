@@ -502,6 +502,73 @@ def end_to_end(refs, rd):
         return out
 
 
+def end_to_end_multi(rank, world, local_rank, dist, ref_len=500_000):
+    """The PRODUCT on all the job's GPUs: every rank starts `indelminer` as a child with its own
+    RANK / LOCAL_RANK / WORLD_SIZE on one BAM of max(world, 2) contigs -- contigs tid % world per rank, one RCCL all-gather
+    of shard summaries, rank 0 prints the VCF -- and rank 0 compares that VCF byte for byte with the single-process run.
+    Reported beside the kernel-level numbers, never `value`; a failure here never touches the line's other fields."""
+    import shutil
+    import subprocess
+    import tempfile
+    from indelminer_amd import bamwrite, build
+    if not os.path.exists(build.HOST_BIN):
+        return None
+    n_ctg = max(world, 2)
+    box = [None, 0]
+    if rank == 0:
+        box[0] = tempfile.mkdtemp(prefix="im_mgpu_")
+        refs, rd = synth.simulate(seed=11, ref_len=ref_len, coverage=30, read_len=100, n_contigs=n_ctg, big_every=7)
+        contigs = [("ctg%d" % i, len(r)) for i, r in enumerate(refs)]
+        bamwrite.write_fasta(box[0] + "/ref.fa", contigs, refs)
+        rawrec.write_bam_fast(box[0] + "/aln.bam", contigs, rd, level=6)
+        open(box[0] + "/cfg.txt", "w").write("IL generic 300 %d\n" % rd.range_max)
+        box[1] = int(rd.n)
+    if dist is not None:
+        dist.broadcast_object_list(box, src=0)
+    td, n_reads = box
+    cmd = [build.HOST_BIN, "-i", "cfg.txt", "ref.fa", "s=aln.bam"]
+    env = dict(os.environ, RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(local_rank), INDELMINER_RENDEZVOUS=td + "/rdv")
+    if world == 1:
+        env["INDELMINER_FORCE_MGPU"] = "1"
+    if os.environ.get("IM_BENCH_ONE_DEVICE") == "1":
+        env["INDELMINER_DEVICE"] = "0"
+    out = {"n_gpus": world, "contigs": n_ctg, "reads": n_reads}
+    t = time.perf_counter()
+    try:
+        p = subprocess.run(cmd, cwd=td, stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env, timeout=300)
+        rc, vcf, err = p.returncode, p.stdout, p.stderr[-400:].decode(errors="replace")
+    except Exception as ex:
+        rc, vcf, err = -1, b"", str(ex)
+    wall = time.perf_counter() - t
+    ok = rc == 0
+    if dist is not None:
+        import torch
+        w = torch.tensor([wall], dtype=torch.float64); dist.all_reduce(w, op=dist.ReduceOp.MAX); wall = float(w[0])
+        k = torch.tensor([1 if ok else 0]); dist.all_reduce(k, op=dist.ReduceOp.MIN); ok = bool(int(k[0]))
+    if rank == 0:
+        out.update(all_ranks_ok=ok, wall_s=wall, reads_per_s=n_reads / wall if ok else None,
+                   note="whole program per rank incl. process start, GPU context, the pre-walk of the rank's contigs and the RCCL "
+                        "communicator bring-up (about 2 s of the wall time on its own, measured with one rank)")
+        if not ok:
+            out["rank0_stderr_tail"] = err
+        env1 = {k_: v for k_, v in os.environ.items() if k_ not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "LOCAL_WORLD_SIZE", "GROUP_RANK")}
+        if os.environ.get("IM_BENCH_ONE_DEVICE") == "1":
+            env1["INDELMINER_DEVICE"] = "0"
+        t = time.perf_counter()
+        try:
+            q = subprocess.run(cmd, cwd=td, stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env1, timeout=300)
+            out["single_process_wall_s"] = time.perf_counter() - t
+            out["vcf_records"] = sum(1 for l in q.stdout.splitlines() if not l.startswith(b"#"))
+            out["vcf_identical_to_single_process"] = bool(ok and q.returncode == 0 and q.stdout == vcf)
+        except Exception as ex:
+            out["single_process_error"] = str(ex)
+    if dist is not None:
+        dist.barrier()
+    if rank == 0:
+        shutil.rmtree(td, ignore_errors=True)
+    return out if rank == 0 else None
+
+
 def cpu_port_baseline(ref, cand, read_len, n_reads_total, m):
     """The hoisted CPU baseline: the oracle restatement takes the contig length as an
     argument, i.e. the reference's path WITHOUT its per-candidate strlen of the contig (src/alignment.c:771).
@@ -722,6 +789,12 @@ def main():
     # triage: every record byte in, per candidate the padded read + 24 B of scalars + 48 B of slots out, 1 B class per record
     tri_bytes = ps.record_bytes + 4 * (n_reads + 1) + n_reads + n_cand * (((L + 3) // 4) * 4 + 24 + 48)
 
+    e2e_mg = None
+    if world > 1 or os.environ.get("IM_BENCH_FORCE_COMM") == "1":
+        try:
+            e2e_mg = end_to_end_multi(rank, world, local_rank, dist)
+        except Exception as ex:                 # plumbing; never hides the kernel numbers
+            e2e_mg = {"error": str(ex)}
     gathered_clusters = None
     if comm is not None and rank == 0:
         g = ps.last["gather"].download(np.int32, (gbytes // 4) * world).reshape(world, -1)
@@ -800,6 +873,7 @@ def main():
             "cpu_baseline": cpu,
             "cpu_baseline_hoisted": cpu_port,
             "end_to_end": e2e,
+            "end_to_end_multi_gpu": e2e_mg,
         }
         if world == 1 and not args.no_shard3:
             try:
