@@ -100,11 +100,12 @@ __global__ __launch_bounds__(1024) void flush_seq_kernel(const im_flush_desc* __
     __shared__ unsigned long long s_cut;
     __shared__ Ranges s_R;
     __shared__ int32_t s_lo, s_lo_rec0;           // first split-read slot of the current contig that may still be pending
+    __shared__ int32_t s_plo, s_plo_pe0, s_pfirst[16];   // the same for the contig's paired-read entries
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     // the paired-read entries are pending for the batch's first flush: their marks are cleared here (the split-read
     // marks are cleared where the candidates are written, im_dev_cands.consumed)
     for (int32_t i = t; i < pe_count; i += 1024) consumed[pe_base + i] = 0;
-    if (t == 0) { s_lo = 0; s_lo_rec0 = -1; }
+    if (t == 0) { s_lo = 0; s_lo_rec0 = -1; s_plo = 0; s_plo_pe0 = -1; }
     __syncthreads();
     __shared__ int32_t s_bound[1024];             // candidate bounds of up to 512 flushes: [2k] = first, [2k + 1] = end
     const int32_t ncand = min(*n_cand, cand_cap);
@@ -128,27 +129,63 @@ __global__ __launch_bounds__(1024) void flush_seq_kernel(const im_flush_desc* __
             if (desc[f].rec0 != s_lo_rec0) { s_lo_rec0 = desc[f].rec0; s_lo = R.a0; }
             const int32_t end = R.a0 + R.na;
             if (s_lo > R.a0) { R.a0 = s_lo < end ? s_lo : end; R.na = end - R.a0; }
+            // the paired-read entries of the contig likewise: in arrival order nearly all of a flush's are consumed by it
+            if (desc[f].pe0 != s_plo_pe0) { s_plo_pe0 = desc[f].pe0; s_plo = R.b0; }
+            const int32_t pend = R.b0 + R.nb;
+            if (s_plo > R.b0) { R.b0 = s_plo < pend ? s_plo : pend; R.nb = pend - R.b0; }
             s_R = R;
         }
         __syncthreads();
         const Ranges R = s_R;
-        const int64_t n = (int64_t)R.na + R.nb;
         const int32_t marker = desc[f].marker, id = desc[f].id;
-        // One workgroup cannot hide memory latency with occupancy, so every thread keeps kU x 4 loads in flight
-        uint64_t best = ~0ull;
-        constexpr int kU = 4;
-        for (int64_t i0 = t; i0 < n; i0 += 1024 * kU) {
-            int32_t c[kU], u[kU], v1[kU], v2[kU];
+        // The split-read part by CANDIDATE: a candidate's IM_MAX_EV = 4 slots are 16 contiguous bytes in each of the four
+        // arrays, so one thread takes whole candidates with 16-byte loads (a quarter of the load instructions, and the
+        // three empty slots of a typical candidate cost nothing more).  One workgroup cannot hide memory latency with
+        // occupancy: every thread keeps kC x 4 loads in flight, and when the flush's candidates fit one such sweep (the
+        // usual case: ~4 000 candidates per READCHUNK flush) what it loaded stays in registers for the marking pass.
+        const int32_t ca = R.a0 >> 2, cb = (R.a0 + R.na + 3) >> 2, nsr = cb - ca;
+        const int4* cls4 = reinterpret_cast<const int4*>(cls) + ca;
+        const int4* con4 = reinterpret_cast<const int4*>(consumed) + ca;
+        const int4* b14 = reinterpret_cast<const int4*>(b1) + ca;
+        const int4* b24 = reinterpret_cast<const int4*>(b2) + ca;
+        constexpr int kC = 4;
+        const bool cached = nsr <= 1024 * kC;
+        int4 kc[kC], ku[kC], k1[kC], k2[kC];
 #pragma unroll
-            for (int e = 0; e < kU; e++) {
-                const int64_t i = i0 + 1024 * e;
-                const bool in = i < n;
-                const int32_t s = in ? slot_of(R, i) : 0;
-                c[e] = in ? cls[s] : -1; u[e] = in ? consumed[s] : 1; v2[e] = in ? b2[s] : 0; v1[e] = in ? b1[s] : 0;
+        for (int e = 0; e < kC; e++) { kc[e] = make_int4(-1, -1, -1, -1); ku[e] = make_int4(1, 1, 1, 1); k1[e] = k2[e] = make_int4(0, 0, 0, 0); }
+        uint64_t best = ~0ull;
+        auto scan4 = [&](const int4& c, const int4& u, const int4& v1, const int4& v2) {
+            if (c.x >= 0 && u.x == 0 && v2.x >= marker) { const uint64_t k = cut_key(v1.x, v2.x); if (k < best) best = k; }
+            if (c.y >= 0 && u.y == 0 && v2.y >= marker) { const uint64_t k = cut_key(v1.y, v2.y); if (k < best) best = k; }
+            if (c.z >= 0 && u.z == 0 && v2.z >= marker) { const uint64_t k = cut_key(v1.z, v2.z); if (k < best) best = k; }
+            if (c.w >= 0 && u.w == 0 && v2.w >= marker) { const uint64_t k = cut_key(v1.w, v2.w); if (k < best) best = k; }
+        };
+        for (int32_t c0 = t; c0 < nsr; c0 += 1024 * kC) {
+#pragma unroll
+            for (int e = 0; e < kC; e++) {
+                const int32_t c = c0 + 1024 * e;
+                const bool in = c < nsr;
+                kc[e] = in ? cls4[c] : make_int4(-1, -1, -1, -1);
+                ku[e] = in ? con4[c] : make_int4(1, 1, 1, 1);
+                k1[e] = in ? b14[c] : make_int4(0, 0, 0, 0);
+                k2[e] = in ? b24[c] : make_int4(0, 0, 0, 0);
             }
 #pragma unroll
-            for (int e = 0; e < kU; e++)
-                if (c[e] >= 0 && u[e] == 0 && v2[e] >= marker) { const uint64_t k = cut_key(v1[e], v2[e]); if (k < best) best = k; }
+            for (int e = 0; e < kC; e++) scan4(kc[e], ku[e], k1[e], k2[e]);
+        }
+        constexpr int kP = 4;
+        for (int32_t i0 = t; i0 < R.nb; i0 += 1024 * kP) {     // the paired-read entries of the flush: independent loads, kP per array in flight
+            int32_t pc[kP], pu[kP], p1[kP], p2[kP];
+#pragma unroll
+            for (int e = 0; e < kP; e++) {
+                const int32_t i = i0 + 1024 * e;
+                const bool in = i < R.nb;
+                const int32_t sl = R.b0 + (in ? i : 0);
+                pc[e] = in ? cls[sl] : -1; pu[e] = in ? consumed[sl] : 1; p2[e] = in ? b2[sl] : 0; p1[e] = in ? b1[sl] : 0;
+            }
+#pragma unroll
+            for (int e = 0; e < kP; e++)
+                if (pc[e] >= 0 && pu[e] == 0 && p2[e] >= marker) { const uint64_t k = cut_key(p1[e], p2[e]); if (k < best) best = k; }
         }
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) {
@@ -162,22 +199,52 @@ __global__ __launch_bounds__(1024) void flush_seq_kernel(const im_flush_desc* __
         __syncthreads();
         const uint64_t X = s_cut;
         int32_t first = 0x7fffffff;                 // smallest split-read slot of the range that stays pending
-        for (int64_t i0 = t; i0 < n; i0 += 1024 * kU) {
-            int32_t c[kU], u[kU], v1[kU], v2[kU], sl[kU];
+        auto mark4 = [&](int32_t cand, const int4& c, const int4& u, const int4& v1, const int4& v2) {
+            const int32_t s0 = (ca + cand) * 4;
+            if (c.x >= 0 && u.x == 0) { if (cut_key(v1.x, v2.x) < X) consumed[s0] = id; else if (s0 < first) first = s0; }
+            if (c.y >= 0 && u.y == 0) { if (cut_key(v1.y, v2.y) < X) consumed[s0 + 1] = id; else if (s0 + 1 < first) first = s0 + 1; }
+            if (c.z >= 0 && u.z == 0) { if (cut_key(v1.z, v2.z) < X) consumed[s0 + 2] = id; else if (s0 + 2 < first) first = s0 + 2; }
+            if (c.w >= 0 && u.w == 0) { if (cut_key(v1.w, v2.w) < X) consumed[s0 + 3] = id; else if (s0 + 3 < first) first = s0 + 3; }
+        };
+        if (cached) {
 #pragma unroll
-            for (int e = 0; e < kU; e++) {
-                const int64_t i = i0 + 1024 * e;
-                const bool in = i < n;
-                sl[e] = in ? slot_of(R, i) : 0;
-                c[e] = in ? cls[sl[e]] : -1; u[e] = in ? consumed[sl[e]] : 1; v2[e] = in ? b2[sl[e]] : 0; v1[e] = in ? b1[sl[e]] : 0;
-            }
+            for (int e = 0; e < kC; e++) mark4(t + 1024 * e, kc[e], ku[e], k1[e], k2[e]);      // out-of-range candidates carry cls = -1
+        } else {
+            for (int32_t c0 = t; c0 < nsr; c0 += 1024 * kC) {
 #pragma unroll
-            for (int e = 0; e < kU; e++) {
-                if (c[e] < 0 || u[e] != 0) continue;
-                if (cut_key(v1[e], v2[e]) < X) consumed[sl[e]] = id;
-                else if (i0 + 1024 * e < R.na && sl[e] < first) first = sl[e];
+                for (int e = 0; e < kC; e++) {
+                    const int32_t c = c0 + 1024 * e;
+                    const bool in = c < nsr;
+                    kc[e] = in ? cls4[c] : make_int4(-1, -1, -1, -1);
+                    ku[e] = in ? con4[c] : make_int4(1, 1, 1, 1);
+                    k1[e] = in ? b14[c] : make_int4(0, 0, 0, 0);
+                    k2[e] = in ? b24[c] : make_int4(0, 0, 0, 0);
+                }
+#pragma unroll
+                for (int e = 0; e < kC; e++) mark4(c0 + 1024 * e, kc[e], ku[e], k1[e], k2[e]);
             }
         }
+        int32_t pfirst = 0x7fffffff;                // smallest paired-read entry of the range that stays pending
+        for (int32_t i0 = t; i0 < R.nb; i0 += 1024 * kP) {
+            int32_t pc[kP], pu[kP], p1[kP], p2[kP];
+#pragma unroll
+            for (int e = 0; e < kP; e++) {
+                const int32_t i = i0 + 1024 * e;
+                const bool in = i < R.nb;
+                const int32_t sl = R.b0 + (in ? i : 0);
+                pc[e] = in ? cls[sl] : -1; pu[e] = in ? consumed[sl] : 1; p2[e] = in ? b2[sl] : 0; p1[e] = in ? b1[sl] : 0;
+            }
+#pragma unroll
+            for (int e = 0; e < kP; e++) {
+                if (pc[e] < 0 || pu[e] != 0) continue;
+                const int32_t sl = R.b0 + i0 + 1024 * e;
+                if (cut_key(p1[e], p2[e]) < X) consumed[sl] = id;
+                else if (sl < pfirst) pfirst = sl;
+            }
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) { const int32_t of = __shfl_xor(pfirst, o); if (of < pfirst) pfirst = of; }
+        if (lane == 0) s_pfirst[wave] = pfirst;
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) { const int32_t of = __shfl_xor(first, o); if (of < first) first = of; }
         if (lane == 0) s_first[wave] = first;
@@ -186,6 +253,9 @@ __global__ __launch_bounds__(1024) void flush_seq_kernel(const im_flush_desc* __
             int32_t m = 0x7fffffff;
             for (int w = 0; w < 16; w++) if (s_first[w] < m) m = s_first[w];
             s_lo = m == 0x7fffffff ? R.a0 + R.na : m;
+            int32_t pm = 0x7fffffff;
+            for (int w = 0; w < 16; w++) if (s_pfirst[w] < pm) pm = s_pfirst[w];
+            s_plo = pm == 0x7fffffff ? R.b0 + R.nb : pm;
         }
         __syncthreads();
     }
