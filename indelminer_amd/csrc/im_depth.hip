@@ -67,8 +67,17 @@ __global__ __launch_bounds__(kScanBlock) void depth_scan_tiled_kernel(int32_t* _
     const int64_t base = (int64_t)blockIdx.x * kScanTile + (int64_t)tid * kScanItems;
     int32_t v[kScanItems];
     int32_t run = 0;
+    static_assert(kScanItems == 8, "a thread's eight items travel as two 16-byte accesses");
+    const bool whole = base + kScanItems <= n;          // the contig's run starts on a 256-byte boundary: base is 32-byte aligned
+    if (whole) {
+        const int4 a = *reinterpret_cast<const int4*>(data + base), c = *reinterpret_cast<const int4*>(data + base + 4);
+        v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = c.x; v[5] = c.y; v[6] = c.z; v[7] = c.w;
+    } else {
 #pragma unroll
-    for (int e = 0; e < kScanItems; e++) { const int64_t i = base + e; v[e] = (i < n) ? data[i] : 0; run += v[e]; v[e] = run; }
+        for (int e = 0; e < kScanItems; e++) { const int64_t i = base + e; v[e] = (i < n) ? data[i] : 0; }
+    }
+#pragma unroll
+    for (int e = 0; e < kScanItems; e++) { run += v[e]; v[e] = run; }
     int32_t x = run;
 #pragma unroll
     for (int o = 1; o < 64; o <<= 1) { int32_t t = __shfl_up(x, o); if (lane >= o) x += t; }
@@ -77,8 +86,13 @@ __global__ __launch_bounds__(kScanBlock) void depth_scan_tiled_kernel(int32_t* _
     int32_t woff = 0;
     for (int w = 0; w < wave; w++) woff += wsum[w];
     const int32_t excl = woff + x - run;
+    if (whole) {
+        *reinterpret_cast<int4*>(data + base) = make_int4(v[0] + excl, v[1] + excl, v[2] + excl, v[3] + excl);
+        *reinterpret_cast<int4*>(data + base + 4) = make_int4(v[4] + excl, v[5] + excl, v[6] + excl, v[7] + excl);
+    } else {
 #pragma unroll
-    for (int e = 0; e < kScanItems; e++) { const int64_t i = base + e; if (i < n) data[i] = v[e] + excl; }
+        for (int e = 0; e < kScanItems; e++) { const int64_t i = base + e; if (i < n) data[i] = v[e] + excl; }
+    }
     if (tid == kScanBlock - 1) {
         const int32_t seen = atomicExch(&sums[blockIdx.x], woff + x);
         asm volatile("" :: "v"(seen));                  // the total is in before this workgroup is counted
