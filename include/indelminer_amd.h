@@ -323,6 +323,8 @@ typedef struct im_triage_params {
     uint32_t ethreshold_vcfcheck;   /* -n (0 in annotate mode, src/indelminer.c:1074) */
     uint32_t maxpedelsize;          /* -p */
     int32_t  want_depth;            /* scatter the pileup match segments into the genome-wide difference array */
+    int32_t  restart;               /* 1: this call opens a new batch -- counters[0..4] count as zero whatever they hold (saves the
+                                     * caller a memset launch per batch); 0: the call appends to the running counters */
 } im_triage_params;
 
 /* Candidate batch under construction.  Candidates are APPENDED in record order: counters[0] = candidates

@@ -384,9 +384,9 @@ __global__ __launch_bounds__(kTriBlock) void triage_classify_kernel(TriageArgs A
         // Published with a RETURNING agent-scope atomic and counted only once the return is in: the count below cannot
         // overtake the totals, and no fence is needed (an agent-scope fence is a whole-L2 write-back per workgroup on
         // this chip, profiles/README.md).
-        unsigned long long seen = atomicExch(reinterpret_cast<unsigned long long*>(&A.blk[blockIdx.x]), ((unsigned long long)b << 32) | c);
-        if (k) atomicAdd(&A.out.counters[2], (int32_t)k);
-        if (e) atomicAdd(&A.out.counters[3], (int32_t)e);
+        // one word per workgroup: padded read bytes | candidates, counted records and error records (each <= 256: 9 bits)
+        unsigned long long seen = atomicExch(reinterpret_cast<unsigned long long*>(&A.blk[blockIdx.x]),
+                                             ((unsigned long long)b << 32) | c | (k << 9) | (e << 18));
         asm volatile("" :: "v"(seen));
         s_last = atomicAdd(A.blocks_done, 1u) == gridDim.x - 1u ? 1u : 0u;
     }
@@ -396,8 +396,15 @@ __global__ __launch_bounds__(kTriBlock) void triage_classify_kernel(TriageArgs A
     // appended in record order).  One launch less than a scan kernel of its own; a few thousand totals at most, read
     // back through the same atomic path they were published on.
     __shared__ uint32_t wc[kTriBlock / 64], wbb[kTriBlock / 64];
-    __shared__ uint32_t carry_c, carry_b;
-    if (t == 0) { carry_c = (uint32_t)A.out.counters[0]; carry_b = (uint32_t)A.out.counters[1]; A.chunk_base[0] = A.out.counters[0]; }
+    __shared__ uint32_t carry_c, carry_b, s_ke[2];
+    // restart: this launch opens a new batch -- the running counters count as zero whatever they hold (no memset in front)
+    const bool fresh = A.tp.restart != 0;
+    if (t == 0) {
+        carry_c = fresh ? 0u : (uint32_t)A.out.counters[0]; carry_b = fresh ? 0u : (uint32_t)A.out.counters[1];
+        A.chunk_base[0] = (int32_t)carry_c;
+        s_ke[0] = 0u; s_ke[1] = 0u;
+    }
+    uint32_t sum_k = 0, sum_e = 0;
     __syncthreads();
     const int32_t n_blocks = (int32_t)gridDim.x;
     uint2* blk = A.blk;
@@ -406,7 +413,8 @@ __global__ __launch_bounds__(kTriBlock) void triage_classify_kernel(TriageArgs A
         uint2 v = make_uint2(0u, 0u);
         if (j < n_blocks) {
             const unsigned long long pv = atomicAdd(reinterpret_cast<unsigned long long*>(&blk[j]), 0ull);
-            v.x = (uint32_t)pv; v.y = (uint32_t)(pv >> 32);
+            v.x = (uint32_t)pv & 511u; v.y = (uint32_t)(pv >> 32);
+            sum_k += ((uint32_t)pv >> 9) & 511u; sum_e += ((uint32_t)pv >> 18) & 511u;
         }
         uint32_t c = v.x, b = v.y;
 #pragma unroll
@@ -424,7 +432,17 @@ __global__ __launch_bounds__(kTriBlock) void triage_classify_kernel(TriageArgs A
         if (t == kTriBlock - 1) { carry_c = cc + oc + c; carry_b = cb + ob + b; }
         __syncthreads();
     }
-    if (t == 0) { A.out.counters[0] = (int32_t)carry_c; A.out.counters[1] = (int32_t)carry_b; *A.blocks_done = 0u; }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { sum_k += (uint32_t)__shfl_xor((int)sum_k, o); sum_e += (uint32_t)__shfl_xor((int)sum_e, o); }
+    if (lane == 0) { atomicAdd(&s_ke[0], sum_k); atomicAdd(&s_ke[1], sum_e); }
+    __syncthreads();
+    if (t == 0) {
+        A.out.counters[0] = (int32_t)carry_c; A.out.counters[1] = (int32_t)carry_b;
+        A.out.counters[2] = (fresh ? 0 : A.out.counters[2]) + (int32_t)s_ke[0];        // records counted
+        A.out.counters[3] = (fresh ? 0 : A.out.counters[3]) + (int32_t)s_ke[1];        // error records (emit / decode add theirs later)
+        if (fresh) A.out.counters[4] = 0;                                              // overflows: counted by the emit kernel
+        *A.blocks_done = 0u;
+    }
 }
 
 // 4-bit base code -> ASCII (bit2char, src/readaln.c:4-17); 0 = a code the reference exits on

@@ -195,6 +195,7 @@ int im_dev_triage(im_ctx* c, const im_triage_params* tp, const im_dev_records* r
 {
     (void)scratch; (void)scratch_bytes; (void)stream;
     int32_t* cnt = out->counters;
+    if (tp->restart) for (int k = 0; k < 5; k++) cnt[k] = 0;       /* a new batch: the running counters count as zero */
     imo_triage t;
     char* bases = malloc(1 << 20);
     for (int32_t i = 0; i < recs->n; i++) {
