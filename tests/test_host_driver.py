@@ -262,6 +262,37 @@ def test_host_read_groups_estimated_by_several_threads(tmp_path):
         assert _run(shim, [], str(tmp_path), ref="ref.fa", bam="aln.bam", env=env) == want, env
 
 
+def test_host_stale_pair_table_entries_pin_the_markers(tmp_path):
+    """first mates of discordant pairs whose second mate never comes stay in the reference's pair table for the rest of the
+    run and pin every later flush marker at their start (find_marker, src/indelminer.c:211-233) -- also in LATER contigs.
+    The walkers keep a table per contig and hand the leftovers on as a marker floor: same output as the one-record-at-a-time
+    host path and the reference, whatever the number of walkers."""
+    import numpy as np
+    from indelminer_amd import bamwrite, rawrec, synth
+    refs, rd = synth.simulate(seed=51, ref_len=250_000, coverage=30, n_contigs=4, big_every=3)
+    both = ((rd.flag & 0x4) == 0) & ((rd.flag & 0x8) == 0)
+    second_of_discordant = both & ((rd.flag & 0x2) == 0) & (rd.pos > rd.mpos)
+    drop = second_of_discordant & (rd.pair_id % 3 == 0) & np.isin(rd.tid, [0, 2])
+    assert drop.sum() > 20
+    keep = ~drop
+    for name, col in list(vars(rd).items()):
+        if isinstance(col, np.ndarray) and len(col) == len(keep):
+            setattr(rd, name, col[keep])
+    rd.n = int(keep.sum())
+    contigs = [("ctg%d" % i, len(r)) for i, r in enumerate(refs)]
+    bamwrite.write_fasta(str(tmp_path / "ref.fa"), contigs, refs)
+    rawrec.write_bam_fast(str(tmp_path / "aln.bam"), contigs, rd)
+    shim = _build_shim()
+    want = _run(shim, [], str(tmp_path), ref="ref.fa", bam="aln.bam", env={"INDELMINER_PIPELINE": "host"})
+    assert want.count(b"\n") > 100
+    ref_bin = os.path.join(ROOT, "oracle", "_ref", "indelminer")
+    if os.path.exists(ref_bin):
+        assert _run(ref_bin, [], str(tmp_path), ref="ref.fa", bam="aln.bam") == want
+    for env in ({}, {"INDELMINER_WALKERS": "4", "INDELMINER_CLAIM_BASES": "1"}, {"INDELMINER_WALKERS": "1"},
+                {"INDELMINER_WALKERS": "2", "INDELMINER_CLAIM_BASES": "1", "INDELMINER_FLUSH_MODE": "per-flush"}):
+        assert _run(shim, [], str(tmp_path), ref="ref.fa", bam="aln.bam", env=env) == want, env
+
+
 def _long_read_dir(tmp_path):
     from indelminer_amd import bamwrite, synth
     refs, rd = synth.simulate(seed=5, ref_len=20_000, coverage=4, read_len=300, isize_mean=900, isize_min=700, isize_max=1100)

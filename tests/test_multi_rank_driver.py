@@ -71,3 +71,26 @@ def test_three_ranks_two_contigs(tmp_path_factory):
     d = th._synth_dir(tmp_path_factory, "synth_2ctg_composite")
     got = _run_world(3, ["-i", "cfg.txt"], d, "ref.fa", "aln.bam")
     assert got == th._golden("synth_2ctg_composite")
+
+
+def test_two_ranks_with_stale_pair_table_entries(tmp_path):
+    """contigs 0 and 2 (rank 0's) leave first mates waiting for ever; every later flush marker -- in rank 1's contigs 1 and 3
+    too -- is pinned by them in the single run: the marker floor and the read-counter prefix both come from the ONE exchange
+    of shard summaries.  No config file, so the insert lengths travel in the same exchange."""
+    import numpy as np
+    from indelminer_amd import bamwrite, rawrec, synth
+    refs, rd = synth.simulate(seed=51, ref_len=250_000, coverage=30, n_contigs=4, big_every=3)
+    both = ((rd.flag & 0x4) == 0) & ((rd.flag & 0x8) == 0)
+    drop = both & ((rd.flag & 0x2) == 0) & (rd.pos > rd.mpos) & (rd.pair_id % 3 == 0) & np.isin(rd.tid, [0, 2])
+    keep = ~drop
+    for name, col in list(vars(rd).items()):
+        if isinstance(col, np.ndarray) and len(col) == len(keep):
+            setattr(rd, name, col[keep])
+    rd.n = int(keep.sum())
+    contigs = [("ctg%d" % i, len(r)) for i, r in enumerate(refs)]
+    bamwrite.write_fasta(str(tmp_path / "ref.fa"), contigs, refs)
+    rawrec.write_bam_fast(str(tmp_path / "aln.bam"), contigs, rd)
+    want = th._run(th._build_shim(), [], str(tmp_path), ref="ref.fa", bam="aln.bam", env={"INDELMINER_PIPELINE": "host"})
+    assert want.count(b"\n") > 100
+    for world in (2, 3):
+        assert _run_world(world, [], str(tmp_path), "ref.fa", "aln.bam") == want, world
