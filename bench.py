@@ -36,7 +36,7 @@ from indelminer_amd import capi, rawrec, shard as shardlib, synth  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0           # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 PIPELINE_DEPTH = int(os.environ.get("IM_BENCH_DEPTH", "4"))   # sets of realign output buffers in flight
-KERNEL_EVENT_STRIDE = 8         # one launch bracketed by HIP events on every 8th timed step (those steps are issued call by call, not as a graph)
+KERNEL_EVENT_STRIDE = 40        # one launch bracketed by HIP events on every 40th timed step (those steps are issued call by call, not as a graph)
 
 
 def measured_traffic():
@@ -640,8 +640,8 @@ def shard3_measure(device, steps=24, warmup=4):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=200)
-    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--steps", type=int, default=2000)       # ~150 ms of timed region at ~75 us per step
+    ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--ref-len", type=int, default=1_000_000)
     ap.add_argument("--coverage", type=float, default=30.0)
     ap.add_argument("--big-every", type=int, default=0, help="every k-th planted event a 150-900 bp deletion (config-3 style shards)")
