@@ -327,6 +327,34 @@ def test_host_rejects_oversized_known_indel_at_startup(tmp_path):
 # ---------------------------------------------------------------- product binary on the GPU
 
 @pytest.mark.gpu
+def test_product_parallel_walkers_and_replayers(tmp_path):
+    """the product on the GPU with 1 / 6 / default walkers, contigs one per claim or grouped, 1 / 4 replay workers, a stream
+    per walker or one shared stream: always the bytes of the reference's run (six contigs, flush points inside three of them,
+    groups of very different sizes through the same device buffers)"""
+    from indelminer_amd import bamwrite, rawrec, synth
+    refs, rd = synth.simulate(seed=21, ref_len=200_000, coverage=30, n_contigs=6, big_every=4)
+    lens = [200_000, 30_000, 200_000, 8_000, 120_000, 200_000]          # uneven contigs: uneven groups
+    refs = [r[:l] for r, l in zip(refs, lens)]
+    import numpy as np
+    keep = rd.pos + 400 < np.array(lens)[rd.tid]
+    keep &= rd.mpos + 400 < np.array(lens)[rd.tid]
+    for name, col in list(vars(rd).items()):
+        if isinstance(col, np.ndarray) and len(col) == len(keep):
+            setattr(rd, name, col[keep])
+    rd.n = int(keep.sum())
+    contigs = [("ctg%d" % i, len(r)) for i, r in enumerate(refs)]
+    bamwrite.write_fasta(str(tmp_path / "ref.fa"), contigs, refs)
+    rawrec.write_bam_fast(str(tmp_path / "aln.bam"), contigs, rd)
+    want = _run(_build_shim(), [], str(tmp_path), ref="ref.fa", bam="aln.bam", env={"INDELMINER_PIPELINE": "host"})
+    assert want.count(b"COMPOSITE") > 10
+    prod = _product()
+    for env in ({}, {"INDELMINER_WALKERS": "1"}, {"INDELMINER_WALKERS": "6", "INDELMINER_CLAIM_BASES": "1", "INDELMINER_REPLAYERS": "4"},
+                {"INDELMINER_WALKERS": "3", "INDELMINER_CLAIM_BASES": "1", "INDELMINER_REPLAYERS": "1", "INDELMINER_STREAMS": "shared"},
+                {"INDELMINER_WALKERS": "4", "INDELMINER_CLAIM_BASES": "250000", "INDELMINER_VERIFY_TRIAGE": "1"}):
+        assert _run(prod, [], str(tmp_path), ref="ref.fa", bam="aln.bam", env=env) == want, env
+
+
+@pytest.mark.gpu
 def test_product_rejects_long_read_library_at_startup(tmp_path):
     d = _long_read_dir(tmp_path)
     r = subprocess.run([_product(), "-i", "cfg.txt", "ref.fa", "s=aln.bam"], cwd=d, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
