@@ -323,6 +323,9 @@ typedef struct im_triage_params {
     uint32_t ethreshold_vcfcheck;   /* -n (0 in annotate mode, src/indelminer.c:1074) */
     uint32_t maxpedelsize;          /* -p */
     int32_t  want_depth;            /* scatter the pileup match segments into the genome-wide difference array */
+    int32_t  defer_ranges;          /* 1: the insert-length table is not known yet (it is being estimated in the same pass over the BAM):
+                                     * no read-group look-up, range_max[] is left 0 for the caller to fill in, and EVERY pair that passes the
+                                     * other tests of the discordant rule is labelled IM_REC_PE (the caller applies |isize| > range[1]) */
     int32_t  restart;               /* 1: this call opens a new batch -- counters[0..4] count as zero whatever they hold (saves the
                                      * caller a memset launch per batch); 0: the call appends to the running counters */
 } im_triage_params;

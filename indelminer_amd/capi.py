@@ -75,7 +75,7 @@ class DevRecords(C.Structure):
 
 class TriageParams(C.Structure):
     _fields_ = [("qthreshold", C.c_int32), ("ethreshold_vcfcheck", C.c_uint32), ("maxpedelsize", C.c_uint32),
-                ("want_depth", C.c_int32), ("restart", C.c_int32)]
+                ("want_depth", C.c_int32), ("defer_ranges", C.c_int32), ("restart", C.c_int32)]
 
 
 class DevCands(C.Structure):
@@ -500,7 +500,7 @@ class Pipeline:
         self.cands_clear = DevCands(self.batch, self.d_cand_rec.ptr, self.d_counters.ptr, self.d_class.ptr, self.cap_cand, self.cap_bases,
                                     self.d_consumed.ptr)
         self.recs = DevRecords(self.n_records, self.d_raw.ptr, self.d_off.ptr, 0)
-        self.tp = TriageParams(qthreshold, ethreshold_vcfcheck, maxpedelsize, 1 if want_depth else 0, 0)
+        self.tp = TriageParams(qthreshold, ethreshold_vcfcheck, maxpedelsize, 1 if want_depth else 0, 0, 0)
         self.P = params()
         self.n_cand = None
 
@@ -566,7 +566,7 @@ class Pipeline:
         self.batch_bound = DevBatch(min(self.cap_cand, grid_bound or self.cap_cand), self.d_bases.ptr, self.d_boff.ptr, self.d_len.ptr,
                                     self.d_tid.ptr, self.d_anchor.ptr, self.d_range.ptr, self.d_res.ptr, self.d_cls.ptr, self.d_b1.ptr, self.d_b2.ptr)
         # a pass over one resident chunk opens a new batch with its one triage call: tp.restart instead of a counters memset
-        self.tp_restart = TriageParams(self.tp.qthreshold, self.tp.ethreshold_vcfcheck, self.tp.maxpedelsize, self.tp.want_depth, 1)
+        self.tp_restart = TriageParams(self.tp.qthreshold, self.tp.ethreshold_vcfcheck, self.tp.maxpedelsize, self.tp.want_depth, 0, 1)
         calls = []
         if depth_tid is not None:           # the contig goes through triage again: its run of the depth array starts from zeros
             calls.append((L.im_depth_reset, (h, depth_tid, stream)))

@@ -198,7 +198,11 @@ __device__ __forceinline__ Verdict classify(const RecView& r, const AuxWin& w, c
 
     uint32_t o_rg, o_mq;
     find_rg_mq(r, w, o_rg, o_mq);
-    if (!o_rg) {
+    if (tp.defer_ranges) {
+        // the table is still being estimated: only what does not need it is checked (a read-group tag of a type bam_aux2Z refuses)
+        if (o_rg) { const uint32_t type = rec_byte(r, w, o_rg); if (!(type == 'Z' || type == 'H')) { v.cls = IM_REC_ERR_RG; return v; } }
+        v.range_max = 0;
+    } else if (!o_rg) {
         if (!generic_ok) { v.cls = IM_REC_ERR_RG; return v; }
         v.range_max = generic_range;
     } else {

@@ -1934,6 +1934,8 @@ typedef struct {
 } pchunk;
 
 typedef struct { int64_t rec; int32_t pe; int marker; int32_t tid; } gflush;
+typedef struct { char name[48]; int32_t min, max, first_tid, first_rec; } rgstat_t;
+static int g_onepass;               /* set before the walkers start */
 typedef struct {
     int32_t tid; int64_t rec0, rec1; int32_t pe0, pe1; int fl0, fl1;
     int64_t cn0, cn1; int32_t lm0, lm1;     /* this contig's runs in the counted-read log and the live-minimum log */
@@ -1942,7 +1944,7 @@ typedef struct {
 
 typedef struct {
     int64_t n_rec;
-    gcontig* ctg; int n_ctg, cap_ctg;
+    gcontig* ctg; int n_ctg, cap_ctg, cur_ctg;      /* cur_ctg: the contig the pair table is serving (host_discordant) */
     gflush* fl; int n_fl, cap_fl;
     evidence_t** pe; int64_t* pe_rec; int32_t n_pe, cap_pe;
     /* The walk does not know the global read counter it starts from (several contigs are walked at once), so it cannot
@@ -1951,6 +1953,12 @@ typedef struct {
      * and group_resolve_flushes places them once the contigs before this one have been counted. */
     int32_t *cn_rec, *cn_pos; int64_t n_cn, cap_cn;
     int32_t *lm_rec; int *lm_val; int32_t n_lm, cap_lm;
+    /* ONE-PASS mode (no config file: the insert lengths are estimated by the same walk, run_pipeline): per-read-group
+     * extrema as estimate_insertlengths takes them, the records of not-proper pairs kept aside (the discordant test needs
+     * range[1]), and the group's candidate arrays parked in device allocations of their own until the ranges are known */
+    rgstat_t rgs[MG_MAX_RG]; int n_rgs;
+    uint8_t* npp_raw; int64_t npp_len, npp_cap; int64_t* npp_off; int32_t* npp_rec; int32_t n_npp, cap_npp;
+    void* sv[9]; int32_t sv_n; int64_t sv_bytes; int32_t* sv_range;
     /* candidates as the device found them: record index + a host copy of the raw record */
     int32_t n_cand, cap_cand; int32_t* cand_rec; int64_t* craw_off; uint8_t* craw; int64_t craw_len, craw_cap;
     /* what came back from the run stage */
@@ -2047,6 +2055,7 @@ static void pipe_init(ppipe* P, driver* d)
     pipe_alloc_cands(P, 1 << 20, (int64_t)(1 << 20) * 160, 1 << 16);
     P->tp.qthreshold = O.qthreshold; P->tp.ethreshold_vcfcheck = O.ethreshold_vcfcheck; P->tp.maxpedelsize = O.maxpedelsize;   /* options are parsed before any thread starts */
     P->tp.want_depth = 1;
+    P->tp.defer_ranges = g_onepass;
     P->ready = 1;
 }
 
@@ -2068,6 +2077,7 @@ static void pipe_destroy(ppipe* P)
 static void group_reset(pgroup* G)
 {
     G->n_rec = 0; G->n_ctg = 0; G->n_fl = 0; G->n_pe = 0; G->n_cand = 0; G->craw_len = 0; G->n_cn = 0; G->n_lm = 0;
+    G->cur_ctg = 0; G->n_rgs = 0; G->n_npp = 0; G->npp_len = 0;
     G->n_cl = 0; G->n_nodes = 0;
 }
 
@@ -2075,6 +2085,7 @@ static void group_free(pgroup* G)
 {
     free(G->ctg); free(G->fl); free(G->pe); free(G->pe_rec); free(G->cand_rec); free(G->craw_off); free(G->craw);
     free(G->cn_rec); free(G->cn_pos); free(G->lm_rec); free(G->lm_val);
+    free(G->npp_raw); free(G->npp_off); free(G->npp_rec);
     free(G->res); free(G->s_cls); free(G->cons_sr); free(G->cons_pe);
     free(G->cl_key); free(G->cl_first); free(G->cl_count); free(G->order); free(G->cl_sorted); free(G->ev_cache);
     memset(G, 0, sizeof *G);
@@ -2211,37 +2222,82 @@ static void pipe_submit(ppipe* P, pgroup* G)
     P->ck[P->cur].rec_base = G->n_rec;
 }
 
+/* a record of a not-proper pair through the pair table (src/indelminer.c:516-615); rec = the group's record count with it */
+static void host_discordant(driver* d, pgroup* G, const bam_record* b, int64_t rec)
+{
+    evidence_t* e = discordant_pair(d, b, record_range(d, b));
+    if (e) {
+        if (G->n_pe == G->cap_pe) {
+            G->cap_pe = G->cap_pe ? G->cap_pe * 2 : 1024;
+            G->pe = xrealloc(G->pe, sizeof(evidence_t*) * (size_t)G->cap_pe);
+            G->pe_rec = xrealloc(G->pe_rec, sizeof(int64_t) * (size_t)G->cap_pe);
+        }
+        e->arrival = (rec - 1) * 8 + 7;
+        G->pe[G->n_pe] = e; G->pe_rec[G->n_pe] = rec - 1; G->n_pe++;
+    }
+    if (d->live_changed) {
+        /* find_marker (src/indelminer.c:211-233) is a function of the pair table alone: its value is logged where it moves */
+        d->live_changed = 0;
+        const int m = find_marker_live(d);
+        if (G->n_lm == G->ctg[G->cur_ctg].lm0 || G->lm_val[G->n_lm - 1] != m) {
+            if (G->n_lm == G->cap_lm) {
+                G->cap_lm = G->cap_lm ? G->cap_lm * 2 : 4096;
+                G->lm_rec = xrealloc(G->lm_rec, sizeof(int32_t) * (size_t)G->cap_lm);
+                G->lm_val = xrealloc(G->lm_val, sizeof(int) * (size_t)G->cap_lm);
+            }
+            G->lm_rec[G->n_lm] = (int32_t)rec; G->lm_val[G->n_lm] = m; G->n_lm++;
+        }
+    }
+}
+
+/* estimate_insertlengths' share of a record (src/bamoperations.c:15-86): extrema of the insert size per read group, and where
+ * the group was first seen (the table lists the groups in file order: its prefix-match look-up depends on that) */
+static void host_rg_stat(pgroup* G, const bam_record* b, int32_t rec_in_contig)
+{
+    const int flag = b->flag;
+    if (!((flag & 0x1) && !(flag & 0x4) && (flag & 0x2) && !(flag & (0x100 | 0x200 | 0x400)) &&
+          b->isize >= 0 && b->mpos - b->pos >= 0 && b->isize >= b->mpos - b->pos)) return;
+    const uint8_t* rg = bam_aux_find(b, "RG");
+    const char* rgname = "generic";
+    if (rg) { forceassert(rg[0] == 'Z'); rgname = bam_aux_str(rg); }
+    int k = G->n_rgs - 1;                           /* the last group seen first: records of one library come in runs */
+    while (k >= 0 && strcmp(G->rgs[k].name, rgname) != 0) k--;
+    if (k < 0) {
+        if (G->n_rgs == MG_MAX_RG || strlen(rgname) >= sizeof G->rgs[0].name)
+            fatalf("at most %d read groups with names under %zu bytes are supported here", MG_MAX_RG, sizeof G->rgs[0].name);
+        rgstat_t* n = &G->rgs[G->n_rgs++];
+        snprintf(n->name, sizeof n->name, "%s", rgname);
+        n->min = n->max = b->isize; n->first_tid = b->tid; n->first_rec = rec_in_contig;
+    } else {
+        if (G->rgs[k].min > b->isize) G->rgs[k].min = b->isize;
+        if (G->rgs[k].max < b->isize) G->rgs[k].max = b->isize;
+    }
+}
+
 /* the host's share of fetch_func for one record: count it, serve the pair table, log what the flush points need */
 static void pipe_host_record(driver* d, pgroup* G, const bam_record* b)
 {
     const int flag = b->flag;
+    if (g_onepass) host_rg_stat(G, b, (int32_t)(G->n_rec - 1 - G->ctg[G->cur_ctg].rec0));
     if (flag & (0x100 | 0x200 | 0x400 | 0x800)) return;
     if ((flag & 0x1) == 0) return;
     const int is_aligned = (flag & 0x4) == 0, is_mate_aligned = (flag & 0x8) == 0;
     if (is_aligned && is_mate_aligned && b->tid != b->mtid) return;
     if (is_aligned && is_mate_aligned && (flag & 0x2) == 0) {
-        evidence_t* e = discordant_pair(d, b, record_range(d, b));
-        if (e) {
-            if (G->n_pe == G->cap_pe) {
-                G->cap_pe = G->cap_pe ? G->cap_pe * 2 : 1024;
-                G->pe = xrealloc(G->pe, sizeof(evidence_t*) * (size_t)G->cap_pe);
-                G->pe_rec = xrealloc(G->pe_rec, sizeof(int64_t) * (size_t)G->cap_pe);
+        if (!g_onepass) host_discordant(d, G, b, G->n_rec);
+        else {
+            /* the pair table needs range[1]: the record waits, with its place in the group, until the walk is over */
+            const int64_t len = (int64_t)b->l_data + 32;
+            if (G->npp_len + len > G->npp_cap) { G->npp_cap = (G->npp_cap + len) * 2 + (1 << 16); G->npp_raw = xrealloc(G->npp_raw, (size_t)G->npp_cap); }
+            if (G->n_npp == G->cap_npp) {
+                G->cap_npp = G->cap_npp ? G->cap_npp * 2 : 4096;
+                G->npp_off = xrealloc(G->npp_off, sizeof(int64_t) * ((size_t)G->cap_npp + 1));
+                G->npp_rec = xrealloc(G->npp_rec, sizeof(int32_t) * (size_t)G->cap_npp);
             }
-            e->arrival = (G->n_rec - 1) * 8 + 7;
-            G->pe[G->n_pe] = e; G->pe_rec[G->n_pe] = G->n_rec - 1; G->n_pe++;
-        }
-        if (d->live_changed) {
-            /* find_marker (src/indelminer.c:211-233) is a function of the pair table alone: its value is logged where it moves */
-            d->live_changed = 0;
-            const int m = find_marker_live(d);
-            if (G->n_lm == G->ctg[G->n_ctg - 1].lm0 || G->lm_val[G->n_lm - 1] != m) {
-                if (G->n_lm == G->cap_lm) {
-                    G->cap_lm = G->cap_lm ? G->cap_lm * 2 : 4096;
-                    G->lm_rec = xrealloc(G->lm_rec, sizeof(int32_t) * (size_t)G->cap_lm);
-                    G->lm_val = xrealloc(G->lm_val, sizeof(int) * (size_t)G->cap_lm);
-                }
-                G->lm_rec[G->n_lm] = (int32_t)G->n_rec; G->lm_val[G->n_lm] = m; G->n_lm++;
-            }
+            memcpy(G->npp_raw + G->npp_len, b->data - 32, (size_t)len);
+            G->npp_off[G->n_npp] = G->npp_len; G->npp_rec[G->n_npp] = (int32_t)G->n_rec; G->n_npp++;
+            G->npp_len += len;
+            G->npp_off[G->n_npp] = G->npp_len;
         }
     }
     /* a counted read (src/indelminer.c:617): every READCHUNK-th of the whole run is a flush point */
@@ -2301,6 +2357,7 @@ static void pipe_walk_contig(ppipe* P, pgroup* G, int32_t tid, bgzf_reader* r)
     gcontig* cg = &G->ctg[G->n_ctg++];
     cg->tid = tid; cg->rec0 = G->n_rec; cg->pe0 = G->n_pe; cg->fl0 = cg->fl1 = 0;
     cg->cn0 = G->n_cn; cg->lm0 = G->n_lm;
+    G->cur_ctg = G->n_ctg - 1;
     /* the pair table starts empty: what earlier contigs left waiting reaches this one as the marker floor
      * (group_resolve_flushes), not as table entries */
     while (d->n_live > 0) {
@@ -3044,6 +3101,89 @@ typedef struct walkpool_s {
     pthread_mutex_t mu; pthread_cond_t cv;
 } walkpool_t;
 
+/* ONE-PASS mode.  A walked group's candidate arrays leave the walker's pipeline for allocations of their own (the walker goes on
+ * to its next claim; the device stage has to wait for the insert lengths), and come back into a pipeline when its turn comes. */
+static void group_park_device(ppipe* P, pgroup* G)
+{
+    im_ctx* g = P->d->gpu;
+    const size_t n = (size_t)G->n_cand, ns = n * IM_MAX_EV;
+    const size_t bytes[9] = { (size_t)P->conf_bytes, 8 * n, 4 * n, 4 * n, 4 * n, 4 * n, 4 * ns, 4 * ns, 4 * ns };
+    void* src[9] = { P->bases, P->boff, P->len, P->tid, P->anchor, P->cand_rec, P->cls, P->b1, P->b2 };
+    G->sv_n = (int32_t)n; G->sv_bytes = P->conf_bytes;
+    size_t total = 0;
+    for (int k = 0; k < 9; k++) total += (bytes[k] + 255) & ~(size_t)255;
+    char* slab = pdev_alloc(P, total);              /* one allocation per group: device allocation calls are not cheap */
+    for (int k = 0; k < 9; k++) {
+        G->sv[k] = slab;
+        if (bytes[k]) GPU(im_dev_copy_async(g, G->sv[k], src[k], bytes[k], P->stream));
+        slab += (bytes[k] + 255) & ~(size_t)255;
+    }
+    GPU(im_dev_memset(g, P->counters, 0, 64, P->stream));
+    GPU(im_stream_sync(g, P->stream));
+    P->conf_cand = 0; P->conf_err = 0; P->conf_bytes = 0;
+}
+
+static void group_unpark_device(ppipe* P, pgroup* G, const int32_t* range)
+{
+    im_ctx* g = P->d->gpu;
+    const size_t n = (size_t)G->sv_n, ns = n * IM_MAX_EV;
+    if ((int64_t)n > P->cap_cand || G->sv_bytes + 64 > P->cap_bases) {
+        int32_t nc = P->cap_cand; int64_t nb = P->cap_bases;
+        while (nc < (int64_t)n) nc *= 2;
+        while (nb < G->sv_bytes + 64) nb *= 2;
+        GPU(im_stream_sync(g, P->stream));
+        pipe_free_cands(P);
+        pipe_alloc_cands(P, nc, nb, P->cap_pe);
+    }
+    const size_t bytes[9] = { (size_t)G->sv_bytes, 8 * n, 4 * n, 4 * n, 4 * n, 4 * n, 4 * ns, 4 * ns, 4 * ns };
+    void* dst[9] = { P->bases, P->boff, P->len, P->tid, P->anchor, P->cand_rec, P->cls, P->b1, P->b2 };
+    for (int k = 0; k < 9; k++) if (bytes[k]) GPU(im_dev_copy_async(g, dst[k], G->sv[k], bytes[k], P->stream));
+    int32_t cnt[16] = { 0 };
+    cnt[0] = (int32_t)n; cnt[1] = (int32_t)G->sv_bytes;
+    GPU(im_dev_upload_async(g, P->counters, cnt, 64, P->stream));
+    if (n) GPU(im_dev_upload_async(g, P->range, range, 4 * n, P->stream));
+    GPU(im_stream_sync(g, P->stream));
+    if (getenv("INDELMINER_TIDY_EXIT")) im_dev_free(g, G->sv[0]);        /* else the slab goes with the process (a free synchronises the device) */
+    G->sv[0] = NULL;
+    P->conf_cand = (int32_t)n; P->conf_bytes = G->sv_bytes;
+}
+
+/* ONE-PASS mode, once the insert lengths are known: every candidate's range[1] from its own record, then the kept records of
+ * not-proper pairs through the pair table, contig by contig, exactly as the walk of the two-pass run would have served them */
+static int32_t* group_apply_ranges(driver* d, pgroup* G)
+{
+    int32_t* range = xmalloc(sizeof(int32_t) * (size_t)(G->n_cand ? G->n_cand : 1));
+    for (int32_t j = 0; j < G->n_cand; j++) {
+        bam_record b;
+        bam_record_view(G->craw + G->craw_off[j], (int32_t)(G->craw_off[j + 1] - G->craw_off[j]), &b);
+        range[j] = record_range(d, &b)[1];
+    }
+    int32_t k = 0;
+    for (int ci = 0; ci < G->n_ctg; ci++) {
+        gcontig* cg = &G->ctg[ci];
+        G->cur_ctg = ci;
+        while (d->n_live > 0) {                         /* a table per contig, as in pipe_walk_contig */
+            evidence_t* e = d->live[d->n_live - 1];
+            live_del(d, e);
+            qhash_remove(d->readpairs, e->qname, (int)strlen(e->qname) + 1);
+            evidence_free(e);
+        }
+        d->live_changed = 0;
+        cg->pe0 = G->n_pe; cg->lm0 = G->n_lm;
+        for (; k < G->n_npp && G->npp_rec[k] <= cg->rec1; k++) {
+            bam_record b;
+            bam_record_view(G->npp_raw + G->npp_off[k], (int32_t)(G->npp_off[k + 1] - G->npp_off[k]), &b);
+            host_discordant(d, G, &b, G->npp_rec[k]);
+        }
+        cg->pe1 = G->n_pe; cg->lm1 = G->n_lm;
+        cg->left_min = find_marker_live(d);
+    }
+    return range;
+}
+
+typedef struct { struct walkpool_s* o; int first, step; driver rd; pthread_t th; } apply_job;
+static void* apply_thread(void* arg);
+
 static void walker_adopt_driver(walker_t* W, driver* d)
 {
     W->wd = *d;                                 /* shared, read-only from here on: header, index, reference, insert lengths, GPU */
@@ -3087,14 +3227,25 @@ static void* walker_thread(void* arg)
         pthread_mutex_unlock(&o->mu);
         if (ci < 0) break;
         claim_t* c = &o->claims[ci];
-        pgroup* G = &W->G[W->n_started & 1];
+        pgroup* G = g_onepass ? xcalloc(1, sizeof(pgroup)) : &W->G[W->n_started & 1];      /* one-pass: the group outlives the walk */
         for (int k = 0; k < c->count; k++) pipe_walk_contig(&W->P, G, o->order[c->first + k], W->r);
         pipe_submit(&W->P, G);
         pipe_drain(&W->P, G);
+        if (g_onepass) group_park_device(&W->P, G);
         pthread_mutex_lock(&o->mu);
-        c->W = W; c->G = G; c->walked = 1; W->n_started++;
+        c->W = W; c->G = G; c->walked = 1; if (!g_onepass) W->n_started++;
         pthread_cond_broadcast(&o->cv);
         pthread_mutex_unlock(&o->mu);
+    }
+    return NULL;
+}
+
+static void* apply_thread(void* arg)
+{
+    apply_job* j = arg;
+    for (int ci = j->first; ci < j->o->n_claims; ci += j->step) {
+        pgroup* G = j->o->claims[ci].G;
+        G->sv_range = group_apply_ranges(&j->rd, G);
     }
     return NULL;
 }
@@ -3115,7 +3266,8 @@ static void* replay_thread(void* arg)
         group_replay(&R->rd, J->G);
         fclose(t_out);
         t_out = NULL;
-        group_reset(J->G);
+        if (g_onepass) { group_free(J->G); free(J->G); J->G = NULL; }
+        else group_reset(J->G);
         pthread_mutex_lock(&o->mu);
         J->W->replayed++; J->done = 1;
         pthread_cond_broadcast(&o->cv);
@@ -3177,12 +3329,60 @@ static void run_pipeline(driver* d, walkpool_t* o)
     pipe_global_init(d);
     if (o->serial) { walker_setup(&o->w[0], d); walker_adopt_driver(&o->w[0], d); }
     pthread_mutex_lock(&o->mu); o->go = 1; pthread_cond_broadcast(&o->cv); pthread_mutex_unlock(&o->mu);
+    if (g_onepass) {
+        /* ONE pass over the BAM: the walk above runs without insert lengths (which records are candidates does not depend on
+         * them; the triage leaves range_max open and the records of not-proper pairs wait in the group), collecting the
+         * extrema per read group as estimate_insertlengths would (src/bamoperations.c:15-86).  When every contig is in, the
+         * table is made -- read groups in the order one process meets them -- and the device stage of every group follows. */
+        pthread_mutex_lock(&o->mu);
+        for (int ci = 0; ci < o->n_claims; ci++) while (!o->claims[ci].walked) pthread_cond_wait(&o->cv, &o->mu);
+        pthread_mutex_unlock(&o->mu);
+        for (int i = 0; i < o->nw; i++) pthread_join(o->w[i].th, NULL);
+        phase_time("the walk of all contigs (inflate + count + insert-length extrema; triage on the device)");
+        mg_rg* all = xcalloc((size_t)(o->n_claims ? o->n_claims : 1) * MG_MAX_RG, sizeof(mg_rg));
+        int n_all = 0;
+        for (int ci = 0; ci < o->n_claims; ci++) {
+            const pgroup* G = o->claims[ci].G;
+            for (int k = 0; k < G->n_rgs; k++) {
+                mg_rg* m = &all[n_all++];
+                snprintf(m->name, sizeof m->name, "%s", G->rgs[k].name);
+                m->min = G->rgs[k].min; m->max = G->rgs[k].max; m->first_tid = G->rgs[k].first_tid; m->first_rec = G->rgs[k].first_rec;
+            }
+        }
+        mg_rg* merged = xcalloc((size_t)(n_all ? n_all : 1), sizeof(mg_rg));
+        const int n = merge_rgs(all, n_all, merged);
+        fprintf(stderr, "\nRead-group\tMin-value\tMax-value (estimated during the walk)\n");
+        for (int j = 0; j < n; j++) {
+            int32_t* range = xmalloc(2 * sizeof(int32_t));
+            range[0] = merged[j].min; range[1] = merged[j].max;
+            qhash_add(d->insertlengths, merged[j].name, (int)strlen(merged[j].name), range);
+            rg_order_push(merged[j].name, range);
+            fprintf(stderr, "%s\t%d\t%d\n", merged[j].name, range[0], range[1]);
+        }
+        free(all); free(merged);
+        pipe_global_init(d);
+        /* every group's ranges and pair-table replay, the groups spread over threads (each with a pair table of its own) */
+        {
+            int nt = o->nw > 1 ? o->nw : 1;
+            if (nt > o->n_claims) nt = o->n_claims ? o->n_claims : 1;
+            apply_job* aj = xcalloc((size_t)nt, sizeof(apply_job));
+            for (int i = 0; i < nt; i++) {
+                aj[i].o = o; aj[i].first = i; aj[i].step = nt; aj[i].rd = *d;
+                aj[i].rd.readpairs = qhash_new(16); aj[i].rd.live = NULL; aj[i].rd.n_live = aj[i].rd.cap_live = 0; aj[i].rd.live_changed = 0;
+                aj[i].rd.rg_last_val = NULL; aj[i].rd.rg_last_name[0] = 0; aj[i].rd.gpu_pending = 0;
+                if (pthread_create(&aj[i].th, NULL, apply_thread, &aj[i]) != 0) fatalf("cannot start a thread");
+            }
+            for (int i = 0; i < nt; i++) pthread_join(aj[i].th, NULL);
+            free(aj);
+        }
+        phase_time("insert lengths applied: candidates' ranges, pair tables");
+    }
     /* Replay workers: the replay of a group (evidence objects, paired-read components, merge, print) is the longest serial
      * piece of a run once the walks overlap; groups are independent of each other, so several are replayed at once, each
      * into a buffer that is written out when every group before it has been.  The numbered blocks of -o detailed, annotate
      * mode (one known-variant list) and the per-contig part files of a multi-GPU run keep the replay on this thread. */
     const char* re = getenv("INDELMINER_REPLAYERS");
-    int nrep = re ? atoi(re) : 3;
+    int nrep = re ? atoi(re) : (g_onepass ? 8 : 3);      /* one-pass: every replay comes after the walk, nothing else wants the cores */
     if (o->serial || g_mg || strcmp(O.outputformat, "vcf") != 0 || nrep < 2) nrep = 0;
     if (nrep > 8) nrep = 8;
     replayer_t* rp = nrep ? xcalloc((size_t)nrep, sizeof(replayer_t)) : NULL;
@@ -3216,6 +3416,12 @@ static void run_pipeline(driver* d, walkpool_t* o)
         phase_time("waited for the walk (inflate + count + pair table; triage on the device)");
         walker_t* W = c->W;
         pgroup* G = c->G;
+        if (g_onepass) {
+            /* the group's candidates come back into a pipeline (the first walker's: all walkers are done), ranges filled in */
+            W = &o->w[0];
+            group_unpark_device(&W->P, G, G->sv_range);
+            free(G->sv_range); G->sv_range = NULL;
+        }
         group_resolve_flushes(G, &numread, &floor_);
         pipe_run_group(&W->P, G);
         pthread_mutex_lock(&o->mu); W->device_free++; pthread_cond_broadcast(&o->cv); pthread_mutex_unlock(&o->mu);
@@ -3238,7 +3444,7 @@ static void run_pipeline(driver* d, walkpool_t* o)
         }
         group_replay(d, G);
         phase_time("replay (variants, merge, print)");
-        group_reset(G);
+        if (g_onepass) { group_free(G); free(G); } else group_reset(G);
         pthread_mutex_lock(&o->mu); W->replayed++; pthread_cond_broadcast(&o->cv); pthread_mutex_unlock(&o->mu);
     }
     if (nrep) {
@@ -3260,7 +3466,7 @@ static void run_pipeline(driver* d, walkpool_t* o)
         free(rp); free(o->jobs);
     }
     d->numread = numread;
-    for (int i = 0; i < o->nw && !o->serial; i++) pthread_join(o->w[i].th, NULL);
+    for (int i = 0; i < o->nw && !o->serial && !g_onepass; i++) pthread_join(o->w[i].th, NULL);
     /* the walkers' pinned rings and device arrays go with the process unless a tidy exit is asked for (leak checkers):
      * un-pinning and freeing them costs more than the whole device stage of a run */
     if (getenv("INDELMINER_TIDY_EXIT")) {
@@ -3493,10 +3699,16 @@ int main(int argc, char** argv)
     walkpool_t* pool = NULL;
     {
         const char* pl0 = getenv("INDELMINER_PIPELINE");
-        if (chromid == -1 && !(pl0 && strcmp(pl0, "host") == 0)) pool = walkpool_start(&d);
+        if (chromid == -1 && !(pl0 && strcmp(pl0, "host") == 0)) {
+            /* no config file: the insert lengths are estimated by the walk itself (run_pipeline) instead of by a pass of their own;
+             * multi-GPU runs and annotate mode keep the pre-pass (the shard summaries / the serial walk need the table up front) */
+            g_onepass = O.configfile == NULL && !g_mg && g_vcfname == NULL && getenv("INDELMINER_ONEPASS") != NULL;
+            pool = walkpool_start(&d);
+        }
     }
 
     if (O.configfile) read_configuration(O.configfile, d.insertlengths);
+    else if (g_onepass) { }
     else if (!g_mg) { if (chromid == -1 && !getenv("INDELMINER_ESTIMATE_SERIAL")) estimate_insertlengths_threads(&d); else estimate_insertlengths(&d, chromid); }
     fprintf(stderr, "\nRead-group\tMin-value\tMax-value\n----------\t---------\t---------\n");
     for (uint32_t i = 0; i <= d.insertlengths->mask; i++)

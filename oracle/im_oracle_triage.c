@@ -138,7 +138,8 @@ void imo_triage_record(const uint8_t* rec, uint32_t len,
         rglen = 0;
         while ((const uint8_t*)rgname + rglen < r.end && rgname[rglen]) rglen++;
     }
-    if (!rg_range(n_rg, rg_names, rg_range_max, rgname, rglen, &out->range_max)) { out->cls = 16; return; }
+    if (n_rg < 0) out->range_max = 0;          /* deferred ranges (im_triage_params.defer_ranges): no look-up, the caller fills the range in */
+    else if (!rg_range(n_rg, rg_names, rg_range_max, rgname, rglen, &out->range_max)) { out->cls = 16; return; }
     const uint8_t* pmmq = aux_get(&r, 'M', 'Q');
 
     char strand = rc ? '-' : '+';

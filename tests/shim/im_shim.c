@@ -201,7 +201,7 @@ int im_dev_triage(im_ctx* c, const im_triage_params* tp, const im_dev_records* r
     for (int32_t i = 0; i < recs->n; i++) {
         const uint8_t* rec = recs->raw + recs->rec_off[i];
         const uint32_t len = recs->rec_off[i + 1] - recs->rec_off[i];
-        imo_triage_record(rec, len, g_n_rg, (const char* const*)g_rg_names, g_rg_range, tp->qthreshold, tp->ethreshold_vcfcheck,
+        imo_triage_record(rec, len, tp->defer_ranges ? -1 : g_n_rg, (const char* const*)g_rg_names, g_rg_range, tp->qthreshold, tp->ethreshold_vcfcheck,
                           tp->maxpedelsize, &t, bases);
         int cls = t.cls;
         if (cls == 3 && t.n_ev > IM_MAX_EV) cls = IM_REC_ERR_LIMIT;

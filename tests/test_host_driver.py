@@ -210,6 +210,19 @@ def test_host_parallel_walkers_give_the_single_walk(tmp_path):
     assert _run(shim, ["-o", "detailed"], str(tmp_path), ref="ref.fa", bam="aln.bam", env={"INDELMINER_WALKERS": "4", "INDELMINER_CLAIM_BASES": "1"}) == det
 
 
+def test_host_one_pass_estimates_during_the_walk(synth_small, synth_1mb, tmp_path):
+    """INDELMINER_ONEPASS=1: no estimation pass of its own -- the walk collects the insert-length extrema, candidates' ranges and
+    the pair table are applied when the last contig is in -- and the bytes of the two-pass run come out (the goldens were made by
+    the reference without a config file)"""
+    shim = _build_shim()
+    for d_, golden in ((synth_small, "synth_2ctg_composite_noconfig"),):
+        for env in ({"INDELMINER_ONEPASS": "1"}, {"INDELMINER_ONEPASS": "1", "INDELMINER_WALKERS": "1"},
+                    {"INDELMINER_ONEPASS": "1", "INDELMINER_WALKERS": "3", "INDELMINER_CLAIM_BASES": "1", "INDELMINER_REPLAYERS": "1"}):
+            assert _run(shim, [], d_, ref="ref.fa", bam="aln.bam", env=env) == _golden(golden), env
+    want = _run(shim, [], synth_1mb, ref="ref.fa", bam="aln.bam")
+    assert _run(shim, [], synth_1mb, ref="ref.fa", bam="aln.bam", env={"INDELMINER_ONEPASS": "1"}) == want
+
+
 def test_host_contigs_without_reads(tmp_path):
     """contigs that deliver no record at all -- the first, one in the middle, the last -- between contigs that do: claims,
     groups and flush placement must not mind (the read counter and the marker floor simply pass through them)"""
@@ -230,7 +243,8 @@ def test_host_contigs_without_reads(tmp_path):
     ref_bin = os.path.join(ROOT, "oracle", "_ref", "indelminer")
     if os.path.exists(ref_bin):
         assert _run(ref_bin, [], str(tmp_path), ref="ref.fa", bam="aln.bam") == want
-    for env in ({}, {"INDELMINER_WALKERS": "5", "INDELMINER_CLAIM_BASES": "1"}, {"INDELMINER_WALKERS": "1"}):
+    for env in ({}, {"INDELMINER_WALKERS": "5", "INDELMINER_CLAIM_BASES": "1"}, {"INDELMINER_WALKERS": "1"},
+                {"INDELMINER_ONEPASS": "1", "INDELMINER_WALKERS": "5", "INDELMINER_CLAIM_BASES": "1"}):
         assert _run(shim, [], str(tmp_path), ref="ref.fa", bam="aln.bam", env=env) == want, env
 
 
@@ -258,7 +272,8 @@ def test_host_read_groups_estimated_by_several_threads(tmp_path):
     ref_bin = os.path.join(ROOT, "oracle", "_ref", "indelminer")
     if os.path.exists(ref_bin):
         assert _run(ref_bin, [], str(tmp_path), ref="ref.fa", bam="aln.bam") == want
-    for env in ({}, {"INDELMINER_WALKERS": "3", "INDELMINER_CLAIM_BASES": "1"}, {"INDELMINER_PIPELINE": "host"}):
+    for env in ({}, {"INDELMINER_WALKERS": "3", "INDELMINER_CLAIM_BASES": "1"}, {"INDELMINER_PIPELINE": "host"},
+                {"INDELMINER_ONEPASS": "1", "INDELMINER_WALKERS": "3", "INDELMINER_CLAIM_BASES": "1"}):
         assert _run(shim, [], str(tmp_path), ref="ref.fa", bam="aln.bam", env=env) == want, env
 
 
@@ -289,7 +304,8 @@ def test_host_stale_pair_table_entries_pin_the_markers(tmp_path):
     if os.path.exists(ref_bin):
         assert _run(ref_bin, [], str(tmp_path), ref="ref.fa", bam="aln.bam") == want
     for env in ({}, {"INDELMINER_WALKERS": "4", "INDELMINER_CLAIM_BASES": "1"}, {"INDELMINER_WALKERS": "1"},
-                {"INDELMINER_WALKERS": "2", "INDELMINER_CLAIM_BASES": "1", "INDELMINER_FLUSH_MODE": "per-flush"}):
+                {"INDELMINER_WALKERS": "2", "INDELMINER_CLAIM_BASES": "1", "INDELMINER_FLUSH_MODE": "per-flush"},
+                {"INDELMINER_ONEPASS": "1", "INDELMINER_WALKERS": "4", "INDELMINER_CLAIM_BASES": "1"}):
         assert _run(shim, [], str(tmp_path), ref="ref.fa", bam="aln.bam", env=env) == want, env
 
 
@@ -350,7 +366,8 @@ def test_product_parallel_walkers_and_replayers(tmp_path):
     prod = _product()
     for env in ({}, {"INDELMINER_WALKERS": "1"}, {"INDELMINER_WALKERS": "6", "INDELMINER_CLAIM_BASES": "1", "INDELMINER_REPLAYERS": "4"},
                 {"INDELMINER_WALKERS": "3", "INDELMINER_CLAIM_BASES": "1", "INDELMINER_REPLAYERS": "1", "INDELMINER_STREAMS": "shared"},
-                {"INDELMINER_WALKERS": "4", "INDELMINER_CLAIM_BASES": "250000", "INDELMINER_VERIFY_TRIAGE": "1"}):
+                {"INDELMINER_WALKERS": "4", "INDELMINER_CLAIM_BASES": "250000", "INDELMINER_VERIFY_TRIAGE": "1"},
+                {"INDELMINER_ONEPASS": "1"}, {"INDELMINER_ONEPASS": "1", "INDELMINER_WALKERS": "6", "INDELMINER_CLAIM_BASES": "1"}):
         assert _run(prod, [], str(tmp_path), ref="ref.fa", bam="aln.bam", env=env) == want, env
 
 
