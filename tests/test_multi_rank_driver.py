@@ -92,5 +92,5 @@ def test_two_ranks_with_stale_pair_table_entries(tmp_path):
     rawrec.write_bam_fast(str(tmp_path / "aln.bam"), contigs, rd)
     want = th._run(th._build_shim(), [], str(tmp_path), ref="ref.fa", bam="aln.bam", env={"INDELMINER_PIPELINE": "host"})
     assert want.count(b"\n") > 100
-    for world in (2, 3):
+    for world in (2, 3, 4, 5):          # 4 = one contig per rank, 5 = an idle rank
         assert _run_world(world, [], str(tmp_path), "ref.fa", "aln.bam") == want, world
