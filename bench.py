@@ -475,15 +475,22 @@ def end_to_end(refs, rd):
         open(td + "/cfg.txt", "w").write("IL generic 300 %d\n" % rd.range_max)
         cmd = ["-i", "cfg.txt", "ref.fa", "s=aln.bam"]
         out = {"reads": int(rd.n)}
-        t = time.perf_counter()
-        p = subprocess.run([prod] + cmd, cwd=td, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
-        out["product_wall_s"] = time.perf_counter() - t
+        walls = []
+        for _ in range(2):                      # the first run also pages the binary, the libraries and the inputs in
+            t = time.perf_counter()
+            p = subprocess.run([prod] + cmd, cwd=td, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+            walls.append(time.perf_counter() - t)
+        out["product_wall_s"] = min(walls)
+        out["product_wall_s_runs"] = walls
         out["product_rc"] = p.returncode
         out["vcf_records"] = sum(1 for l in p.stdout.splitlines() if not l.startswith(b"#"))
         if os.path.exists(ref_bin):
-            t = time.perf_counter()
-            q = subprocess.run([ref_bin] + cmd, cwd=td, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
-            out["reference_wall_s"] = time.perf_counter() - t
+            walls = []
+            for _ in range(2):
+                t = time.perf_counter()
+                q = subprocess.run([ref_bin] + cmd, cwd=td, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+                walls.append(time.perf_counter() - t)
+            out["reference_wall_s"] = min(walls)
             out["reference_reads_per_s"] = rd.n / out["reference_wall_s"]
             out["vcf_identical_to_reference"] = bool(q.returncode == 0 and q.stdout == p.stdout)
             # the reference's only parallel mode: one process per -c region (src/indelminer.c:536-542,711-713), 8 at a time
@@ -498,7 +505,7 @@ def end_to_end(refs, rd):
             body = lambda b: b"".join(l + b"\n" for l in b.splitlines() if not l.startswith(b"#"))
             out["reference_8proc_same_records_as_1proc"] = bool(b"".join(body(o) for o in outs) == body(q.stdout))
         out["product_reads_per_s"] = rd.n / out["product_wall_s"]
-        out["note"] = "whole programs incl. process start, BAM decode, GPU context creation and reference upload; product: 1 record-walking thread, 4 BGZF inflate workers, a GPU start-up helper thread; reference: 1 thread, and its one-process-per-region mode at 8 processes"
+        out["note"] = "whole programs incl. process start, BAM decode, GPU context creation and reference upload; product: one contig = one walker thread with 4 BGZF inflate workers, a GPU start-up helper thread (the GPU context creation, 0.1-0.25 s by run, is most of it on this input); reference: 1 thread, and its one-process-per-region mode at 8 processes; each program twice, the faster run counted"
         return out
 
 
