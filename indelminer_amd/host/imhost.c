@@ -1959,6 +1959,8 @@ typedef struct {
     rgstat_t rgs[MG_MAX_RG]; int n_rgs;
     uint8_t* npp_raw; int64_t npp_len, npp_cap; int64_t* npp_off; int32_t* npp_rec; int32_t n_npp, cap_npp;
     void* sv[9]; int32_t sv_n; int64_t sv_bytes; int32_t* sv_range;
+    int in_use;                 /* walked and not yet replayed (under the pool's mutex): replay workers finish in any order, so a
+                                 * walker waits for THIS buffer, not for a count of finished replays */
     /* candidates as the device found them: record index + a host copy of the raw record */
     int32_t n_cand, cap_cand; int32_t* cand_rec; int64_t* craw_off; uint8_t* craw; int64_t craw_len, craw_cap;
     /* what came back from the run stage */
@@ -3222,8 +3224,8 @@ static void* walker_thread(void* arg)
         pthread_mutex_lock(&o->mu);
         const int ci = o->next_claim < o->n_claims ? o->next_claim++ : -1;
         /* this walker's device arrays are free once its previous group went through the device stage, the group buffer
-         * once the group before that has been replayed */
-        while (ci >= 0 && (W->device_free < W->n_started || W->replayed < W->n_started - 1)) pthread_cond_wait(&o->cv, &o->mu);
+         * once the group that used it last has been replayed */
+        while (ci >= 0 && (W->device_free < W->n_started || (!g_onepass && W->G[W->n_started & 1].in_use))) pthread_cond_wait(&o->cv, &o->mu);
         pthread_mutex_unlock(&o->mu);
         if (ci < 0) break;
         claim_t* c = &o->claims[ci];
@@ -3233,7 +3235,7 @@ static void* walker_thread(void* arg)
         pipe_drain(&W->P, G);
         if (g_onepass) group_park_device(&W->P, G);
         pthread_mutex_lock(&o->mu);
-        c->W = W; c->G = G; c->walked = 1; if (!g_onepass) W->n_started++;
+        c->W = W; c->G = G; c->walked = 1; G->in_use = 1; if (!g_onepass) W->n_started++;
         pthread_cond_broadcast(&o->cv);
         pthread_mutex_unlock(&o->mu);
     }
@@ -3261,14 +3263,20 @@ static void* replay_thread(void* arg)
         pthread_mutex_unlock(&o->mu);
         if (j < 0) break;
         rjob_t* J = &o->jobs[j];
+        {   /* test hook: every other replay takes this much longer, so that replays finish out of order on any machine */
+            const char* dl = getenv("INDELMINER_DEBUG_REPLAY_DELAY_MS");
+            if (dl && (j & 1) == 0) { struct timespec ts = { atoi(dl) / 1000, (long)(atoi(dl) % 1000) * 1000000L }; nanosleep(&ts, NULL); }
+        }
         t_out = open_memstream(&J->buf, &J->len);
         if (!t_out) fatalf("cannot buffer the output of a group");
         group_replay(&R->rd, J->G);
         fclose(t_out);
         t_out = NULL;
-        if (g_onepass) { group_free(J->G); free(J->G); J->G = NULL; }
-        else group_reset(J->G);
+        pgroup* Gd = J->G;
+        if (g_onepass) { group_free(Gd); free(Gd); J->G = NULL; Gd = NULL; }
+        else group_reset(Gd);
         pthread_mutex_lock(&o->mu);
+        if (Gd) Gd->in_use = 0;
         J->W->replayed++; J->done = 1;
         pthread_cond_broadcast(&o->cv);
         pthread_mutex_unlock(&o->mu);
@@ -3444,8 +3452,8 @@ static void run_pipeline(driver* d, walkpool_t* o)
         }
         group_replay(d, G);
         phase_time("replay (variants, merge, print)");
-        if (g_onepass) { group_free(G); free(G); } else group_reset(G);
-        pthread_mutex_lock(&o->mu); W->replayed++; pthread_cond_broadcast(&o->cv); pthread_mutex_unlock(&o->mu);
+        if (g_onepass) { group_free(G); free(G); G = NULL; } else group_reset(G);
+        pthread_mutex_lock(&o->mu); if (G) G->in_use = 0; W->replayed++; pthread_cond_broadcast(&o->cv); pthread_mutex_unlock(&o->mu);
     }
     if (nrep) {
         pthread_mutex_lock(&o->mu);

@@ -1,0 +1,53 @@
+#!/usr/bin/env python3
+"""One-off soak on the GPU box: random synthetic inputs through the product's device pipeline (random walker / claim / replay
+settings, one-pass or two-pass) against the product's own one-record-at-a-time host path (INDELMINER_PIPELINE=host), bytes compared.
+    python profiles/pipeline_soak.py [first_seed] [n]"""
+import os, random, subprocess, sys, tempfile
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import numpy as np
+from indelminer_amd import bamwrite, build, rawrec, synth
+
+first = int(sys.argv[1]) if len(sys.argv) > 1 else 1
+n = int(sys.argv[2]) if len(sys.argv) > 2 else 10
+
+
+def run(td, flags, env):
+    p = subprocess.run([build.HOST_BIN] + flags + ["ref.fa", "s=aln.bam"], cwd=td, stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                       env=dict(os.environ, **env))
+    return p.returncode, p.stdout, p.stderr[-300:]
+
+
+for seed in range(first, first + n):
+    rng = random.Random(seed)
+    nc = rng.choice([1, 2, 3, 5, 7])
+    lens = [rng.choice([20_000, 60_000, 150_000, 400_000]) for _ in range(nc)]
+    refs, rd = synth.simulate(seed=seed, ref_lens=lens, coverage=rng.choice([8, 20, 30, 45]), big_every=rng.choice([0, 3, 7]),
+                              indel_spacing=rng.choice([1000, 2000]))
+    if rng.random() < 0.4:          # second mates of some discordant pairs never come
+        both = ((rd.flag & 0x4) == 0) & ((rd.flag & 0x8) == 0)
+        drop = both & ((rd.flag & 0x2) == 0) & (rd.pos > rd.mpos) & (rd.pair_id % 4 == 0)
+        keep = ~drop
+        for name, col in list(vars(rd).items()):
+            if isinstance(col, np.ndarray) and len(col) == len(keep):
+                setattr(rd, name, col[keep])
+        rd.n = int(keep.sum())
+    with tempfile.TemporaryDirectory() as td:
+        contigs = [("c%d" % i, len(r)) for i, r in enumerate(refs)]
+        bamwrite.write_fasta(td + "/ref.fa", contigs, refs)
+        rawrec.write_bam_fast(td + "/aln.bam", contigs, rd)
+        open(td + "/cfg.txt", "w").write("IL generic 300 %d\n" % rd.range_max)
+        flags = rng.choice([[], ["-i", "cfg.txt"], ["-e", "1"], ["-i", "cfg.txt", "-q", "0", "-a"], ["-b", "40", "-n", "15"]])
+        rc0, want, err0 = run(td, flags, {"INDELMINER_PIPELINE": "host"})
+        assert rc0 == 0, err0
+        for _ in range(3):
+            env = {"INDELMINER_WALKERS": str(rng.choice([1, 2, 4, 6])), "INDELMINER_REPLAYERS": str(rng.choice([1, 3, 6]))}
+            if rng.random() < 0.5:
+                env["INDELMINER_CLAIM_BASES"] = str(rng.choice([1, 100_000, 500_000]))
+            if rng.random() < 0.4:
+                env["INDELMINER_ONEPASS"] = "1"
+            rc, got, err = run(td, flags, env)
+            if rc != 0 or got != want:
+                print("MISMATCH seed %d flags %r env %r rc %d: %s" % (seed, flags, env, rc, err.decode(errors="replace")), flush=True)
+                sys.exit(1)
+    print("seed %d ok: %d contigs, %d reads, flags %r, %d VCF bytes" % (seed, nc, rd.n, flags, len(want)), flush=True)

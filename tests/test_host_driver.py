@@ -223,6 +223,22 @@ def test_host_one_pass_estimates_during_the_walk(synth_small, synth_1mb, tmp_pat
     assert _run(shim, [], synth_1mb, ref="ref.fa", bam="aln.bam", env={"INDELMINER_ONEPASS": "1"}) == want
 
 
+def test_host_replays_that_finish_out_of_order(tmp_path):
+    """replay workers finish in any order; a walker must wait for the very group buffer it is about to reuse, not for a count
+    of finished replays (found by profiles/pipeline_soak.py on the GPU box: one walker, three replay workers, a small group's
+    replay overtaking a large one's -- the large group's output went missing).  The delay hook makes every other replay slow."""
+    from indelminer_amd import bamwrite, rawrec, synth
+    refs, rd = synth.simulate(seed=61, ref_lens=[30_000, 30_000, 120_000, 30_000, 120_000, 30_000, 60_000], coverage=30, big_every=5)
+    contigs = [("c%d" % i, len(r)) for i, r in enumerate(refs)]
+    bamwrite.write_fasta(str(tmp_path / "ref.fa"), contigs, refs)
+    rawrec.write_bam_fast(str(tmp_path / "aln.bam"), contigs, rd)
+    shim = _build_shim()
+    want = _run(shim, [], str(tmp_path), ref="ref.fa", bam="aln.bam", env={"INDELMINER_PIPELINE": "host"})
+    for walkers in ("1", "2"):
+        env = {"INDELMINER_WALKERS": walkers, "INDELMINER_REPLAYERS": "3", "INDELMINER_CLAIM_BASES": "1", "INDELMINER_DEBUG_REPLAY_DELAY_MS": "150"}
+        assert _run(shim, [], str(tmp_path), ref="ref.fa", bam="aln.bam", env=env) == want, env
+
+
 def test_host_contigs_without_reads(tmp_path):
     """contigs that deliver no record at all -- the first, one in the middle, the last -- between contigs that do: claims,
     groups and flush placement must not mind (the read counter and the marker floor simply pass through them)"""
