@@ -37,7 +37,8 @@ for seed in range(first, first + n):
         bamwrite.write_fasta(td + "/ref.fa", contigs, refs)
         rawrec.write_bam_fast(td + "/aln.bam", contigs, rd)
         open(td + "/cfg.txt", "w").write("IL generic 300 %d\n" % rd.range_max)
-        flags = rng.choice([[], ["-i", "cfg.txt"], ["-e", "1"], ["-i", "cfg.txt", "-q", "0", "-a"], ["-b", "40", "-n", "15"]])
+        flags = rng.choice([[], ["-i", "cfg.txt"], ["-e", "1"], ["-i", "cfg.txt", "-q", "0", "-a"], ["-b", "40", "-n", "15"],
+                            ["-g", "2"], ["-k", "8"], ["-o", "detailed"], ["-s", "300"], ["-f", "2"], ["-t"], ["-i", "cfg.txt", "-g", "5", "-k", "5"]])
         rc0, want, err0 = run(td, flags, {"INDELMINER_PIPELINE": "host"})
         assert rc0 == 0, err0
         for _ in range(3):
