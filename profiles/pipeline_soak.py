@@ -32,15 +32,29 @@ for seed in range(first, first + n):
             if isinstance(col, np.ndarray) and len(col) == len(keep):
                 setattr(rd, name, col[keep])
         rd.n = int(keep.sum())
+    multi_rg = rd.n < 70_000 and rng.random() < 0.5      # several read groups (prefix-aliasing names), the slow writer: small inputs only
+    if multi_rg:
+        rd.rg_names = rng.sample(["lib10", "li", "", "lib1", "x", "lib", "other_library_with_a_long_name"], rng.choice([2, 3, 4]))
+        g = (rd.pair_id % len(rd.rg_names)).astype(np.int64)
+        g[rd.tid < rng.randrange(nc)] = 0           # the other groups first appear in a later contig
+        rd.rg_idx = g
     with tempfile.TemporaryDirectory() as td:
         contigs = [("c%d" % i, len(r)) for i, r in enumerate(refs)]
         bamwrite.write_fasta(td + "/ref.fa", contigs, refs)
-        rawrec.write_bam_fast(td + "/aln.bam", contigs, rd)
+        if multi_rg:
+            bamwrite.write_bam(td + "/aln.bam", contigs, rd)
+        else:
+            rawrec.write_bam_fast(td + "/aln.bam", contigs, rd)
         open(td + "/cfg.txt", "w").write("IL generic 300 %d\n" % rd.range_max)
-        flags = rng.choice([[], ["-i", "cfg.txt"], ["-e", "1"], ["-i", "cfg.txt", "-q", "0", "-a"], ["-b", "40", "-n", "15"],
+        flags = [] if multi_rg else rng.choice([[], ["-i", "cfg.txt"], ["-e", "1"], ["-i", "cfg.txt", "-q", "0", "-a"], ["-b", "40", "-n", "15"],
                             ["-g", "2"], ["-k", "8"], ["-o", "detailed"], ["-s", "300"], ["-f", "2"], ["-t"], ["-i", "cfg.txt", "-g", "5", "-k", "5"]])
-        rc0, want, err0 = run(td, flags, {"INDELMINER_PIPELINE": "host"})
+        rc0, want, err0 = run(td, flags, {"INDELMINER_PIPELINE": "host", "INDELMINER_ESTIMATE_SERIAL": "1"})
         assert rc0 == 0, err0
+        if seed % 10 == 0:          # the multi-GPU code path with one rank (RCCL bring-up: ~2 s)
+            rc, got, err = run(td, flags, {"INDELMINER_FORCE_MGPU": "1", "RANK": "0", "WORLD_SIZE": "1", "LOCAL_RANK": "0", "INDELMINER_RENDEZVOUS": td + "/rdv"})
+            if rc != 0 or got != want:
+                print("MISMATCH seed %d flags %r multi-GPU path rc %d: %s" % (seed, flags, rc, err.decode(errors="replace")), flush=True)
+                sys.exit(1)
         for _ in range(3):
             env = {"INDELMINER_WALKERS": str(rng.choice([1, 2, 4, 6])), "INDELMINER_REPLAYERS": str(rng.choice([1, 3, 6]))}
             if rng.random() < 0.5:
@@ -51,4 +65,4 @@ for seed in range(first, first + n):
             if rc != 0 or got != want:
                 print("MISMATCH seed %d flags %r env %r rc %d: %s" % (seed, flags, env, rc, err.decode(errors="replace")), flush=True)
                 sys.exit(1)
-    print("seed %d ok: %d contigs, %d reads, flags %r, %d VCF bytes" % (seed, nc, rd.n, flags, len(want)), flush=True)
+    print("seed %d ok: %d contigs, %d reads, flags %r, %d VCF bytes%s" % (seed, nc, rd.n, flags, len(want), ", read groups %r" % rd.rg_names if multi_rg else ""), flush=True)
