@@ -293,14 +293,10 @@ def test_host_read_groups_estimated_by_several_threads(tmp_path):
         assert _run(shim, [], str(tmp_path), ref="ref.fa", bam="aln.bam", env=env) == want, env
 
 
-def test_host_stale_pair_table_entries_pin_the_markers(tmp_path):
-    """first mates of discordant pairs whose second mate never comes stay in the reference's pair table for the rest of the
-    run and pin every later flush marker at their start (find_marker, src/indelminer.c:211-233) -- also in LATER contigs.
-    The walkers keep a table per contig and hand the leftovers on as a marker floor: same output as the one-record-at-a-time
-    host path and the reference, whatever the number of walkers."""
+def _stale_dir(tmp_path, ref_len=250_000):
     import numpy as np
     from indelminer_amd import bamwrite, rawrec, synth
-    refs, rd = synth.simulate(seed=51, ref_len=250_000, coverage=30, n_contigs=4, big_every=3)
+    refs, rd = synth.simulate(seed=51, ref_len=ref_len, coverage=30, n_contigs=4, big_every=3)
     both = ((rd.flag & 0x4) == 0) & ((rd.flag & 0x8) == 0)
     second_of_discordant = both & ((rd.flag & 0x2) == 0) & (rd.pos > rd.mpos)
     drop = second_of_discordant & (rd.pair_id % 3 == 0) & np.isin(rd.tid, [0, 2])
@@ -313,16 +309,25 @@ def test_host_stale_pair_table_entries_pin_the_markers(tmp_path):
     contigs = [("ctg%d" % i, len(r)) for i, r in enumerate(refs)]
     bamwrite.write_fasta(str(tmp_path / "ref.fa"), contigs, refs)
     rawrec.write_bam_fast(str(tmp_path / "aln.bam"), contigs, rd)
+    return str(tmp_path)
+
+
+def test_host_stale_pair_table_entries_pin_the_markers(tmp_path):
+    """first mates of discordant pairs whose second mate never comes stay in the reference's pair table for the rest of the
+    run and pin every later flush marker at their start (find_marker, src/indelminer.c:211-233) -- also in LATER contigs.
+    The walkers keep a table per contig and hand the leftovers on as a marker floor: same output as the one-record-at-a-time
+    host path and the reference, whatever the number of walkers."""
+    d = _stale_dir(tmp_path)
     shim = _build_shim()
-    want = _run(shim, [], str(tmp_path), ref="ref.fa", bam="aln.bam", env={"INDELMINER_PIPELINE": "host"})
+    want = _run(shim, [], d, ref="ref.fa", bam="aln.bam", env={"INDELMINER_PIPELINE": "host"})
     assert want.count(b"\n") > 100
     ref_bin = os.path.join(ROOT, "oracle", "_ref", "indelminer")
     if os.path.exists(ref_bin):
-        assert _run(ref_bin, [], str(tmp_path), ref="ref.fa", bam="aln.bam") == want
+        assert _run(ref_bin, [], d, ref="ref.fa", bam="aln.bam") == want
     for env in ({}, {"INDELMINER_WALKERS": "4", "INDELMINER_CLAIM_BASES": "1"}, {"INDELMINER_WALKERS": "1"},
                 {"INDELMINER_WALKERS": "2", "INDELMINER_CLAIM_BASES": "1", "INDELMINER_FLUSH_MODE": "per-flush"},
                 {"INDELMINER_ONEPASS": "1", "INDELMINER_WALKERS": "4", "INDELMINER_CLAIM_BASES": "1"}):
-        assert _run(shim, [], str(tmp_path), ref="ref.fa", bam="aln.bam", env=env) == want, env
+        assert _run(shim, [], d, ref="ref.fa", bam="aln.bam", env=env) == want, env
 
 
 def _long_read_dir(tmp_path):
@@ -385,6 +390,18 @@ def test_product_parallel_walkers_and_replayers(tmp_path):
                 {"INDELMINER_WALKERS": "4", "INDELMINER_CLAIM_BASES": "250000", "INDELMINER_VERIFY_TRIAGE": "1"},
                 {"INDELMINER_ONEPASS": "1"}, {"INDELMINER_ONEPASS": "1", "INDELMINER_WALKERS": "6", "INDELMINER_CLAIM_BASES": "1"}):
         assert _run(prod, [], str(tmp_path), ref="ref.fa", bam="aln.bam", env=env) == want, env
+
+
+@pytest.mark.gpu
+def test_product_stale_pair_table_entries(tmp_path):
+    """markers pinned low by first mates that wait for ever: pending ranges grow past what a flush keeps in registers
+    (flush_seq_kernel's re-reading path) and past the one-launch limit (per-flush launches); product vs the host path"""
+    d = _stale_dir(tmp_path, ref_len=1_200_000)
+    want = _run(_build_shim(), [], d, ref="ref.fa", bam="aln.bam", env={"INDELMINER_PIPELINE": "host"})
+    assert want.count(b"\n") > 400
+    prod = _product()
+    for env in ({}, {"INDELMINER_WALKERS": "1"}, {"INDELMINER_FLUSH_MODE": "per-flush"}, {"INDELMINER_ONEPASS": "1"}):
+        assert _run(prod, [], d, ref="ref.fa", bam="aln.bam", env=env) == want, env
 
 
 @pytest.mark.gpu
