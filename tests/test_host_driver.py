@@ -239,6 +239,30 @@ def test_host_replays_that_finish_out_of_order(tmp_path):
         assert _run(shim, [], str(tmp_path), ref="ref.fa", bam="aln.bam", env=env) == want, env
 
 
+def test_host_unknown_read_group_exits_like_the_reference(tmp_path):
+    """a read group the config file does not name: the reference exits in must_find_hashtable (src/indelminer.c:374-376); the device
+    triage flags the record, the driver replays it for the reference's own message -- same exit code, same stdout (the header)"""
+    import numpy as np
+    from indelminer_amd import bamwrite, synth
+    refs, rd = synth.simulate(seed=5, ref_len=30_000, coverage=10)
+    rd.rg_names = ["libA", "libB"]
+    rd.rg_idx = (rd.pair_id % 2).astype(np.int64)
+    contigs = [("ctg0", len(refs[0]))]
+    bamwrite.write_fasta(str(tmp_path / "ref.fa"), contigs, refs)
+    bamwrite.write_bam(str(tmp_path / "aln.bam"), contigs, rd)
+    (tmp_path / "cfg.txt").write_text("IL libA 300 700\n")
+    outs = []
+    bins = [_build_shim()]
+    ref_bin = os.path.join(ROOT, "oracle", "_ref", "indelminer")
+    if os.path.exists(ref_bin):
+        bins.append(ref_bin)
+    for b in bins:
+        r = subprocess.run([b, "-i", "cfg.txt", "ref.fa", "s=aln.bam"], cwd=str(tmp_path), stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+        outs.append((r.returncode, r.stdout, r.stderr.decode().strip().splitlines()[-1]))
+    assert outs[0][0] == 1 and outs[0][2] == "indelminer: did not find libB in the hash"
+    assert all(o == outs[0] for o in outs)
+
+
 def test_host_contigs_without_reads(tmp_path):
     """contigs that deliver no record at all -- the first, one in the middle, the last -- between contigs that do: claims,
     groups and flush placement must not mind (the read counter and the marker floor simply pass through them)"""
