@@ -37,7 +37,8 @@ with tempfile.TemporaryDirectory() as td:
             t = time.perf_counter()
             p = subprocess.run([build.HOST_BIN] + cmd, cwd=td, stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env)
             dt = time.perf_counter() - t
-            print("product run (inflate workers %s): %.2f s" % (thr or "default", dt), flush=True)
+            import hashlib
+            print("product run (inflate workers %s): %.2f s  rc %d  md5 %s" % (thr or "default", dt, p.returncode, hashlib.md5(p.stdout).hexdigest()), flush=True)
             tp = dt if tp is None else min(tp, dt)
     body = [l for l in p.stdout.splitlines() if not l.startswith(b"#")]
     print("product   rc %d  %.2f s  %d VCF records (%d COMPOSITE, %d PAIRED_READ only)" %
