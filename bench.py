@@ -3,10 +3,14 @@
 
 One "step" = one pass of the hot path over one resident batch of DELIVERED BAM RECORDS, exactly the
 sequence of C-ABI calls the product driver (indelminer_amd/host, run_pipeline) issues per batch:
-  im_dev_triage        every record: fetch_func's candidate rules, base decode + revcomp, CIGAR evidence (a1)
+  im_depth_reset       the contig's run of the depth array (the pass is repeated on the same contig; the product zeroes once)
+  im_dev_triage        every record: fetch_func's candidate rules, base decode + revcomp, CIGAR evidence, pileup depth scatter (a1, a16)
+  im_depth_scan        the contig's depths for the DP= queries (a16)
   im_dev_realign_n     every candidate: K1-K4, evidence slots (a2-a11)
-  im_dev_flush_cut_rec one per READCHUNK flush point + the end-of-contig flush (a12, node selection)
+  im_dev_flush_cuts    every READCHUNK flush point + the end-of-contig flush in one launch (a12, node selection)
   im_dev_cluster_groupby_n   the split-read clusters of all flushes (a12)
+After the timed region every buffer set is checked against the pass run alone and the depths against the pileup rule;
+at N > 1 (or IM_BENCH_FORCE_COMM=1) the product CLI is also run on all ranks (end_to_end_multi_gpu).
 Inputs (reference, the records as the BAM file holds them) are resident in HBM before the timed region
 starts; `value` counts the records the timed kernels read -- all of them.
 
