@@ -382,7 +382,9 @@ int im_dev_flush_cut_rec(im_ctx* ctx, const int32_t* cls, const int32_t* b1, con
  * record bounds [rec0, rec1) (records of its contig up to the flush point), its paired-read entries [pe0, pe1)
  * relative to slot pe_base, its marker and its id (> 0).  desc lives on the device.  A flush sees a few thousand
  * pending slots at the reference's READCHUNK, so one workgroup walks the list; callers with very long pending
- * ranges (no mid-contig flush ever consumes anything) use im_dev_flush_cut_rec per flush instead. */
+ * ranges (no mid-contig flush ever consumes anything) use im_dev_flush_cut_rec per flush instead.
+ * cls, b1, b2 and consumed are read a candidate (IM_MAX_EV slots = 16 bytes) at a time: their bases must be 16-byte aligned
+ * (any im_dev_alloc / hipMalloc pointer is). */
 typedef struct im_flush_desc { int32_t rec0, rec1, pe0, pe1, marker, id; } im_flush_desc;
 int im_dev_flush_cuts(im_ctx* ctx, const im_flush_desc* desc_dev, int32_t n_flushes,
                       const int32_t* cls, const int32_t* b1, const int32_t* b2, int32_t* consumed,

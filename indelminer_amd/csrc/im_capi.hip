@@ -356,6 +356,7 @@ int im_dev_flush_cuts(im_ctx* ctx, const im_flush_desc* desc_dev, int32_t n_flus
                       const int32_t* cand_rec, const int32_t* n_cand_dev, int32_t cand_cap, int32_t pe_base, int32_t pe_count, void* stream)
 {
     if (!ctx || n_flushes < 0 || !desc_dev || !cand_rec || !n_cand_dev || pe_count < 0) return IM_E_ARG;
+    if ((((uintptr_t)cls) | ((uintptr_t)b1) | ((uintptr_t)b2) | ((uintptr_t)consumed)) & 15u) { set_err(ctx, "im_dev_flush_cuts: the slot arrays must be 16-byte aligned"); return IM_E_ARG; }
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     HIP_TRY(ctx, im::launch_flush_seq(desc_dev, n_flushes, cls, b1, b2, consumed, cand_rec, n_cand_dev, cand_cap, pe_base, pe_count, (hipStream_t)stream));
     return IM_OK;
