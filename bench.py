@@ -424,6 +424,25 @@ def copy_peak_gbs(ctx, nbytes=1 << 30, reps=5):
     return 2.0 * nbytes / (best * 1e-3) / 1e9
 
 
+def h2d_pinned_gbs(ctx, nbytes=256 << 20, reps=4):
+    """host -> device copy rate from pinned memory (what the product's chunk uploads get): the PCIe share of a pass whose
+    records start on the host.  Reported beside `value`, which is measured with the records already resident."""
+    L_ = capi.lib()
+    hp = C.c_void_p()
+    ctx._check(L_.im_host_alloc(ctx.h, nbytes, C.byref(hp)))
+    d = capi.DevBuf(ctx, nbytes)
+    t = capi.Timer(ctx)
+    best = 1e9
+    for _ in range(reps + 1):
+        t.start(ctx.stream)
+        ctx._check(L_.im_dev_upload_async(ctx.h, d.ptr, hp, nbytes, ctx.stream))
+        t.stop(ctx.stream)
+        best = min(best, t.elapsed_ms())
+    d.free()
+    L_.im_host_free(ctx.h, hp)
+    return nbytes / (best * 1e-3) / 1e9
+
+
 def cpu_reference_baseline(ref, cand, read_len, n_reads_total, budget_s=12.0):
     """Times the REAL reference's attempt_pe_alignment (oracle/_ref, compiled in place from the
     reference sources) on a bounded sample of the same candidate batch, single thread."""
@@ -841,6 +860,10 @@ def main():
             peak_measured = copy_peak_gbs(ctx)
         except Exception:
             peak_measured = None
+        try:
+            h2d = h2d_pinned_gbs(ctx)
+        except Exception:
+            h2d = None
         line = {
             "metric": "reads/sec through split-read realign+cluster; VCF diff-clean vs reference",
             "value": value, "unit": "reads/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -851,6 +874,8 @@ def main():
                                    % (args.ref_len / 1e6, args.coverage),
                        "reads_per_step": total_reads, "candidates_per_step": total_cand,
                        "record_bytes_per_step_rank0": ps.record_bytes,
+                       "h2d_pinned_gbs": h2d,
+                       "reads_per_s_with_the_records_crossing_pcie": (n_reads / (ps.record_bytes / (h2d * 1e9) + ms_per_step * 1e-3)) if h2d else None,
                        "flushes_per_step": len(ps.flushes), "evidence_nodes_per_step_rank0": nodes, "clusters_per_step_rank0": ncl,
                        "candidates_per_s": total_cand * args.steps / elapsed,
                        "band_alignments_per_s": n_band * world * args.steps / elapsed,

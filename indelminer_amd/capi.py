@@ -190,6 +190,9 @@ def lib():
                                                C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                                C.c_void_p, C.c_size_t, C.c_void_p]
         L.im_depth_enable.argtypes = [C.c_void_p]
+        L.im_host_alloc.argtypes = [C.c_void_p, C.c_size_t, C.POINTER(C.c_void_p)]
+        L.im_host_free.argtypes = [C.c_void_p, C.c_void_p]
+        L.im_dev_upload_async.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
         L.im_depth_scan.argtypes = [C.c_void_p, C.c_int32, C.c_void_p]
         L.im_depth_reset.argtypes = [C.c_void_p, C.c_int32, C.c_void_p]
         L.im_depth_query_tid.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]
