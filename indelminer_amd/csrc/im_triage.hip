@@ -176,6 +176,106 @@ __device__ __forceinline__ bool rg_lookup(const RgView& T, NameAt name_at, uint3
     return hit;
 }
 
+// new_readaln (src/readaln.c:186-240) runs for aligned proper pairs whose mate is aligned (src/indelminer.c:425), after
+// the filters of 348-366: whether this record gets that far, from the core alone
+__device__ __forceinline__ bool reaches_new_readaln(const RecView& r)
+{
+    const uint32_t f = r.flag;
+    return r.ok && !(f & (0x100u | 0x200u | 0x400u | 0x800u)) && (f & 0x1u) && (f & 0x2u) && !(f & (0x4u | 0x8u)) && r.tid == r.mtid;
+}
+
+// How many read bases new_readaln decodes: the query bases of the CIGAR, taken where the CIGAR says -- also past l_seq --
+// but not past the record.
+__device__ __forceinline__ uint32_t bases_in_cigar_reach(const RecView& r)
+{
+    uint64_t qtot = 0;
+    for (uint32_t i = 0; i < r.n_cigar; i++) {
+        const uint32_t cw = cigar_word(r, i), op = cw & 15u;
+        if (op == 0u || op == 1u || op == 4u || op == 7u || op == 8u) qtot += cw >> 4;
+    }
+    const uint64_t avail = 2ull * (r.len - r.o_seq);
+    return (uint32_t)(qtot < avail ? qtot : avail);
+}
+
+// Of eight packed bases (one dword): bit 4 p set where nibble p holds a code bit2char takes.  A popcount per nibble (the
+// codes of A C G T have one bit, N has four), then "count is 1 or 4" on its three bits.
+__device__ __forceinline__ uint32_t good_codes(uint32_t x)
+{
+    const uint32_t c = x - ((x >> 1) & 0x77777777u) - ((x >> 2) & 0x33333333u) - ((x >> 3) & 0x11111111u);
+    return (c >> 2) | (c & ~(c >> 1));
+}
+
+// index (0..31) of the first refused code in 16 bytes of packed bases; only called when there is one
+__device__ __forceinline__ uint32_t first_refused(const uint4& x)
+{
+    const uint32_t w[4] = { x.x, x.y, x.z, x.w };
+    for (uint32_t k = 0; k < 4u; k++) {
+        const uint32_t bad = ~good_codes(w[k]) & 0x11111111u;                  // base 2 b in the high nibble of byte b
+        if (bad) return 8u * k + ((uint32_t)__builtin_ctz(((bad & 0x0F0F0F0Fu) << 4) | ((bad >> 4) & 0x0F0F0F0Fu)) >> 2);
+    }
+    return 32u;
+}
+
+__device__ __forceinline__ bool all_good(const uint4& x)
+{
+    return ((good_codes(x.x) & good_codes(x.y) & good_codes(x.z) & good_codes(x.w)) & 0x11111111u) == 0x11111111u;
+}
+
+// The first base bit2char would refuse in each of a wave's 64 records, swept by the wave together: four lanes per record
+// (eight when a read of the wave is longer than 128 bases) read its packed bases as consecutive 16-byte pieces.  A lane
+// sweeping its own record alone makes every load a 64-line gather (measured +30 % on the whole kernel); here a load
+// instruction touches 16 records.  The launch is one occupancy round -- what a wave waits for in sequence is the kernel's
+// duration -- so the sweep covers l_seq bases, known from the record's core: its loads go out with the loads of the
+// CIGAR and the aux window (issue), and are looked at when those have arrived (finish).  What the CIGAR makes of it
+// (fewer bases, or more: new_readaln reads on behind l_seq) is settled in classify.
+struct BaseSweep {
+    uint4 x[8];
+    uint32_t lm[8];
+    int shift;      // log2 of the lanes per record: 2 or 3, the same for the whole wave
+};
+
+__device__ __forceinline__ void sweep_issue(BaseSweep& S, const uint8_t* raw, uint32_t so, uint32_t lim, int lane)
+{
+    S.shift = __ballot(lim > 128u) != 0ull ? 3 : 2;
+    const uint32_t sub = (uint32_t)lane & ((1u << S.shift) - 1u);
+    const int grp = lane >> S.shift, per_pass = 64 >> S.shift;
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+        S.lm[j] = 0u; S.x[j] = make_uint4(0x11111111u, 0x11111111u, 0x11111111u, 0x11111111u);
+        if (j < (1 << S.shift)) {
+            const int src = per_pass * j + grp;
+            S.lm[j] = (uint32_t)__shfl((int)lim, src);
+            const uint32_t so_j = (uint32_t)__shfl((int)so, src);
+            // a lane with nothing to read takes the buffer's first bytes: the loads stay unconditional and go out together
+            __builtin_memcpy(&S.x[j], raw + (32u * sub < S.lm[j] ? so_j + 16u * sub : 0u), 16);
+        }
+    }
+}
+
+// s_fb: the wave's 64 entries, ~0 coming in
+__device__ __forceinline__ void sweep_finish(const BaseSweep& S, const uint8_t* raw, uint32_t so, uint32_t lim, uint32_t* s_fb, int lane)
+{
+    const uint32_t lanes = 1u << S.shift, sub = (uint32_t)lane & (lanes - 1u);
+    const int grp = lane >> S.shift, per_pass = 64 >> S.shift;
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+        if (j < (1 << S.shift) && 32u * sub < S.lm[j] && !all_good(S.x[j])) {
+            const uint32_t idx = 32u * sub + first_refused(S.x[j]);
+            if (idx < S.lm[j]) atomicMin(&s_fb[per_pass * j + grp], idx);
+        }
+    }
+    if (__ballot(lim > 256u) != 0ull) {                                         // reads longer than 256 bases: the rest, piece by piece
+        for (int j = 0; j < 8; j++) {
+            const int src = per_pass * j + grp;
+            const uint32_t lm = (uint32_t)__shfl((int)lim, src), so_j = (uint32_t)__shfl((int)so, src);
+            for (uint32_t first = 256u + 32u * sub; first < lm; first += 256u) {
+                uint4 x; __builtin_memcpy(&x, raw + so_j + (first >> 1), 16);
+                if (!all_good(x)) { const uint32_t idx = first + first_refused(x); if (idx < lm) atomicMin(&s_fb[src], idx); }
+            }
+        }
+    }
+}
+
 struct Verdict {
     uint32_t cls;           // IM_REC_*
     bool revcomp;
@@ -184,7 +284,7 @@ struct Verdict {
 
 // generic_ok / generic_range: the lookup of "generic" (records without an RG tag, src/indelminer.c:370), done once per workgroup
 __device__ __forceinline__ Verdict classify(const RecView& r, const AuxWin& w, const im_triage_params& tp, const RgView& T,
-                                            bool generic_ok, int32_t generic_range)
+                                            bool generic_ok, int32_t generic_range, uint32_t fb)
 {
     Verdict v; v.cls = IM_REC_SKIP; v.revcomp = false; v.range_max = 0;
     if (!r.ok) { v.cls = IM_REC_ERR_LIMIT; return v; }
@@ -229,13 +329,30 @@ __device__ __forceinline__ Verdict classify(const RecView& r, const AuxWin& w, c
         return v;
     }
     if (aligned && mate_aligned && proper) {                                   // 425-515
+        // new_readaln (src/readaln.c:186-240) builds the segment list of EVERY proper pair first, op by op: N / H / P and
+        // unknown ops are fatal (163-182), and so is a base code other than A C G T N in an op that carries read bases
+        // (bit2char, 4-16) -- whichever comes first along the CIGAR.  fb comes in as the first bad base among the l_seq
+        // bases of the read (the wave's cooperative sweep); only what lies inside the CIGAR's reach counts, and a CIGAR
+        // that reaches past l_seq has the bytes behind the packed bases looked at here.  Then the ops are walked: a bad op
+        // at read offset q loses to a bad base in front of it.
+        const uint32_t lim = bases_in_cigar_reach(r);
+        if (fb >= lim) {
+            fb = 0xFFFFFFFFu;
+            for (uint32_t j = (uint32_t)r.l_seq; j < lim; j++) {
+                const uint32_t code = (r.p[r.o_seq + (j >> 1)] >> ((~j & 1u) << 2)) & 15u;
+                if (!(code == 1u || code == 2u || code == 4u || code == 8u || code == 15u)) { fb = j; break; }
+            }
+        }
         uint32_t ndel = 0, nins = 0, nclip = 0; bool three = false;
+        uint64_t q = 0;
         for (uint32_t i = 0; i < r.n_cigar; i++) {
-            const uint32_t op = cigar_word(r, i) & 15u;
-            if (op == 3u || op == 5u || op == 6u || op > 8u) { v.cls = IM_REC_ERR_CIGAR; return v; }   // new_readseg_bam
+            const uint32_t cw = cigar_word(r, i), op = cw & 15u;
+            if (op == 3u || op == 5u || op == 6u || op > 8u) { v.cls = (uint64_t)fb < q ? IM_REC_ERR_BASE : IM_REC_ERR_CIGAR; return v; }   // new_readseg_bam
+            if (op == 0u || op == 1u || op == 4u || op == 7u || op == 8u) q += cw >> 4;
             ndel += op == 2u; nins += op == 1u; nclip += op == 4u;
             if (op == 4u && ((!is_rc && i == r.n_cigar - 1u) || (is_rc && i == 0u))) three = true;
         }
+        if (fb != 0xFFFFFFFFu) { v.cls = IM_REC_ERR_BASE; return v; }
         if (ndel + nins + nclip == 0u) return v;
         if ((nclip == 0u || (nclip == 1u && three)) && ndel == 0u && nins == 0u) return v;            // 457-460
         const int32_t mmq = o_mq ? aux_int(r, w, o_mq) : (int32_t)r.mapq;
@@ -283,6 +400,7 @@ __global__ __launch_bounds__(kTriBlock) void triage_classify_kernel(TriageArgs A
     // rest of the kernel).  Events outside the window or on another contig go to memory directly.
     __shared__ int32_t s_dd[kDepthWin];
     __shared__ int32_t s_wpos[kTriBlock / 64], s_wtid[kTriBlock / 64];
+    __shared__ uint32_t s_fb[kTriBlock];
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int64_t i = (int64_t)blockIdx.x * kTriBlock + t;
     if (A.depth_diff) {
@@ -291,18 +409,22 @@ __global__ __launch_bounds__(kTriBlock) void triage_classify_kernel(TriageArgs A
         for (int k = 0; k < kDepthWin / 4 / kTriBlock; k++) z[t + k * kTriBlock] = make_int4(0, 0, 0, 0);
     }
 
-    // the record: offsets, core, then CIGAR head + aux window in one round trip
-    RecView r; r.ok = false; r.l_seq = 0; r.flag = 0; r.n_cigar = 0; r.tid = -1; r.pos = 0; r.o_cigar = 0; r.p = A.recs.raw; r.len = 0; r.o_aux = 0;
-    if (i < A.recs.n) {
-        r = view_record(A.recs.raw, A.recs.rec_off[i], A.recs.rec_off[i + 1]);
-        if (r.ok) {
-            // reads past the record stay inside the chunk buffer (>= 64 spare bytes behind the last record)
+    // the record: offsets, core, then CIGAR head + aux window + the wave's sweep over the packed bases in one round trip
+    RecView r; r.ok = false; r.l_seq = 0; r.flag = 0; r.n_cigar = 0; r.tid = -1; r.pos = 0; r.o_cigar = 0; r.o_seq = 0; r.p = A.recs.raw; r.len = 0; r.o_aux = 0;
+    s_fb[t] = 0xFFFFFFFFu;
+    if (i < A.recs.n) r = view_record(A.recs.raw, A.recs.rec_off[i], A.recs.rec_off[i + 1]);
+    const uint32_t sw_lim = reaches_new_readaln(r) ? (uint32_t)r.l_seq : 0u;   // r.ok: the packed bases lie inside the record
+    const uint32_t sw_so = sw_lim ? (uint32_t)(r.p - A.recs.raw) + r.o_seq : 0u;
+    BaseSweep S;
+    sweep_issue(S, A.recs.raw, sw_so, sw_lim, lane);
+    if (r.ok) {
+        // reads past the record stay inside the chunk buffer (>= 64 spare bytes behind the last record)
 #pragma unroll
-            for (int k = 0; k < 4; k++) r.cig[k] = ld_u32(r.p + r.o_cigar + 4u * k);
+        for (int k = 0; k < 4; k++) r.cig[k] = ld_u32(r.p + r.o_cigar + 4u * k);
 #pragma unroll
-            for (int k = 0; k < kAuxWin / 4; k++) s_aux[t][k] = ld_u32(r.p + r.o_aux + 4u * k);
-        }
+        for (int k = 0; k < kAuxWin / 4; k++) s_aux[t][k] = ld_u32(r.p + r.o_aux + 4u * k);
     }
+    sweep_finish(S, A.recs.raw, sw_so, sw_lim, s_fb + 64 * wave, lane);
     // the depth window starts at the first pileup-eligible record of the workgroup (records are sorted inside a contig)
     const bool piles = A.depth_diff && r.ok && r.tid >= 0 && r.tid < A.ref.n_contigs && !(r.flag & (0x4u | 0x100u | 0x200u | 0x400u));
     if (A.depth_diff) {
@@ -333,7 +455,7 @@ __global__ __launch_bounds__(kTriBlock) void triage_classify_kernel(TriageArgs A
     bool cand = false;
     if (i < A.recs.n) {
         AuxWin w; w.lds = reinterpret_cast<const uint8_t*>(s_aux[t]); w.o0 = r.o_aux;
-        const Verdict v = classify(r, w, A.tp, T, s_generic[0] != 0, s_generic[1]);
+        const Verdict v = classify(r, w, A.tp, T, s_generic[0] != 0, s_generic[1], s_fb[t]);
         cls = v.cls;
         cand = cls == IM_REC_CAND_UNMAPPED || cls == IM_REC_CAND_PROPER;
         if (cand) bytes = padded4(r.l_seq);
@@ -541,6 +663,7 @@ __global__ __launch_bounds__(kTriBlock) void triage_emit_kernel(TriageArgs A)
         }
     }
     if (err) {
+        A.info[i] = (info & ~255u) | err;                      // the decode below leaves a record that already failed alone
         if (A.out.rec_class) A.out.rec_class[i] = (uint8_t)err;
         atomicAdd(&A.out.counters[3], 1);
     }
@@ -581,8 +704,12 @@ __global__ __launch_bounds__(256) void triage_decode_kernel(TriageArgs A)
         const uint64_t mb = __ballot(bad);
         const uint32_t half = (uint32_t)(mb >> (32 * ((threadIdx.x >> 5) & 1)));
         if (half != 0u && l32 == 0) {
-            if (A.out.rec_class) A.out.rec_class[A.out.cand_rec[ci] - A.recs.rec_base] = (uint8_t)IM_REC_ERR_BASE;
-            atomicAdd(&A.out.counters[3], 1);
+            // check_variants comes first in the reference (src/indelminer.c:470 before 484): its error stands
+            const int32_t rec = A.out.cand_rec[ci] - A.recs.rec_base;
+            if ((A.info[rec] & 255u) < IM_REC_ERR_RG) {
+                if (A.out.rec_class) A.out.rec_class[rec] = (uint8_t)IM_REC_ERR_BASE;
+                atomicAdd(&A.out.counters[3], 1);
+            }
         }
     }
 }

@@ -612,10 +612,30 @@ static void dispatch_record(driver* d, const bam_record* b)
         int is_threeprime_clip = 0;
         const uint8_t* cig = BAMR_CIGAR(b);
         const int ncig = b->n_cigar;
+        /* new_readaln (src/readaln.c:186-240) on every proper pair: op by op, N / H / P and unknown ops are fatal (163-182),
+         * and so is a base code bit2char refuses (4-16) in an op that carries read bases -- whichever comes first */
+        {
+            const uint8_t* seq = BAMR_SEQ(b);
+            const int64_t avail = 2 * (int64_t)((b->data + b->l_data) - seq);
+            int64_t q = 0;
+            for (int i = 0; i < ncig; i++) {
+                const uint32_t w = bamr_cigar_at(cig, i);
+                const int op = CIG_OP(w);
+                const int64_t l = CIG_LEN(w);
+                if (op == OP_N) fatalf("Implement new_readseg_bam:164");
+                if (op == OP_H) fatalf("Implement new_readseg_bam:176");
+                if (op == OP_P) fatalf("Implement new_readseg_bam:179");
+                if (op > OP_X) fatalf("Unhandled cigar operation");
+                if (op == OP_M || op == OP_I || op == OP_S || op == OP_EQ || op == OP_X) {
+                    for (int64_t j = q; j < q + l && j < avail; j++) {
+                        (void)bit2char((seq[j >> 1] >> ((~j & 1) << 2)) & 15);      /* exits with the reference's message on a code it refuses */
+                    }
+                    q += l;
+                }
+            }
+        }
         for (int i = 0; i < ncig; i++) {
             const int op = CIG_OP(bamr_cigar_at(cig, i));
-            if (op == OP_N || op == OP_H || op == OP_P) fatalf("Implement new_readseg_bam: CIGAR op %d", op);
-            if (op > OP_X) fatalf("Unhandled cigar operation");
             if (op == OP_D) numcdels++;
             if (op == OP_I) numcins++;
             if (op == OP_S) numcsclip++;
@@ -2111,7 +2131,6 @@ static void pipe_harvest(ppipe* P, pgroup* G, pchunk* c)
             bam_record_view(c->h_raw + c->h_off[i], (int32_t)(c->h_off[i + 1] - c->h_off[i]), &b);
             if (cls[i] == IM_REC_ERR_LIMIT)
                 fatalf("read %s: more than %d indels in its CIGAR pass the end-distance rule, or the record is malformed (kernel limit IM_MAX_EV)", BAMR_QNAME(&b), IM_MAX_EV);
-            if (cls[i] == IM_REC_ERR_BASE) { char* s = decode_bases(&b); free(s); }
             dispatch_record(P->d, &b);
             fatalf("read %s: record rejected by the device triage (class %d)", BAMR_QNAME(&b), (int)cls[i]);
         }

@@ -148,6 +148,8 @@ typedef struct {
     int32_t tid, anchor, l_seq; /* arguments of attempt_pe_alignment */
     int32_t n_ev;               /* check_variants (285-337), segment order */
     int32_t ev_cls[IMO_MAX_EV], ev_b1[IMO_MAX_EV], ev_b2[IMO_MAX_EV];
+    int32_t want;               /* 2 / 3 once the record is a candidate -- also when cls then became an error found while the candidate
+                                 * is written out (19, 20, 21); 0 when the record never got that far (new_readaln's errors included) */
 } imo_triage;
 
 void imo_triage_record(const uint8_t* rec, uint32_t len,

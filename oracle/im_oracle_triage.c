@@ -152,12 +152,32 @@ void imo_triage_record(const uint8_t* rec, uint32_t len,
             mmq = aux2i(&r, pmmq);
         }
         if (mmq < qthreshold) return;
-        want = 2; revcomp = !mate_rc; out->qual = mmq;
+        want = 2; revcomp = !mate_rc; out->qual = mmq; out->want = 2;
     } else if (aligned && mate_aligned && proper) {                            /* 425-515 */
         int ndel = 0, nins = 0, nclip = 0, three = 0;
+        /* new_readaln (src/readaln.c:186-240) builds the segment list of EVERY proper pair before anything is decided: op by op,
+         * N / H / P and unknown ops are fatal (163-182) and so is a base code other than A C G T N in an op that carries read bases
+         * (bit2char, 4-16, through 116-171) -- whichever comes first along the CIGAR.  Read bases are taken where the CIGAR says,
+         * also past l_seq (the bytes behind the packed bases); here not past the record. */
+        {
+            int64_t q = 0;
+            const int64_t avail = 2 * (int64_t)(r.end - r.seq);
+            for (int i = 0; i < r.n_cigar; i++) {
+                const uint32_t w = rd32(r.cigar + 4 * i);
+                const int op = (int)(w & 15u);
+                const int64_t l = w >> 4;
+                if (op == 3 || op == 5 || op == 6 || op > 8) { out->cls = 18; return; }
+                if (op == 0 || op == 1 || op == 4 || op == 7 || op == 8) {
+                    for (int64_t j = q; j < q + l && j < avail; j++) {
+                        const int c = (r.seq[j >> 1] >> ((~j & 1) << 2)) & 15;
+                        if (!(c == 1 || c == 2 || c == 4 || c == 8 || c == 15)) { out->cls = 20; return; }
+                    }
+                    q += l;
+                }
+            }
+        }
         for (int i = 0; i < r.n_cigar; i++) {
             const int op = (int)(rd32(r.cigar + 4 * i) & 15u);
-            if (op == 3 || op == 5 || op == 6 || op > 8) { out->cls = 18; return; }       /* new_readseg_bam, src/readaln.c:163-180 */
             if (op == 2) ndel++;
             if (op == 1) nins++;
             if (op == 4) { nclip++; if ((strand == '+' && i == r.n_cigar - 1) || (strand == '-' && i == 0)) three = 1; }
@@ -166,7 +186,7 @@ void imo_triage_record(const uint8_t* rec, uint32_t len,
         if ((nclip == 0 || (nclip == 1 && three)) && ndel == 0 && nins == 0) return;      /* 457-460 */
         const int mmq = pmmq ? aux2i(&r, pmmq) : r.mapq;
         if (mmq < qthreshold) return;
-        want = 3; revcomp = rc == mate_rc; out->qual = r.mapq;
+        want = 3; revcomp = rc == mate_rc; out->qual = r.mapq; out->want = 3;
         /* check_variants (285-337) */
         uint32_t tpos = 0, rpos = 0;
         for (int i = 0; i < r.n_cigar; i++) {

@@ -95,7 +95,7 @@ def realign(P, contig_bytes, contig_len, anchor, range_max, read):
 class Triage(C.Structure):
     _fields_ = [("cls", C.c_int32), ("revcomp", C.c_int32), ("range_max", C.c_int32), ("qual", C.c_int32),
                 ("strand", C.c_int32), ("tid", C.c_int32), ("anchor", C.c_int32), ("l_seq", C.c_int32),
-                ("n_ev", C.c_int32), ("ev_cls", C.c_int32 * MAX_EV), ("ev_b1", C.c_int32 * MAX_EV), ("ev_b2", C.c_int32 * MAX_EV)]
+                ("n_ev", C.c_int32), ("ev_cls", C.c_int32 * MAX_EV), ("ev_b1", C.c_int32 * MAX_EV), ("ev_b2", C.c_int32 * MAX_EV), ("want", C.c_int32)]
 
 
 def triage_records(raw, rec_off, rg_names, rg_range_max, qthreshold=10, eth_vcf=10, maxpedelsize=1000000):

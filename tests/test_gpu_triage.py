@@ -26,9 +26,10 @@ def _compare_triage(pipe, raw, rec_off, rg_names, rg_range, tri=None, **kw):
     o_cls = np.array([21 if (t.cls == 3 and t.n_ev > capi.MAX_EV) else t.cls for t, _ in tri], dtype=np.uint8)
     h_cls = pipe.d_class.download(np.uint8, n)
     assert np.array_equal(h_cls, o_cls), np.nonzero(h_cls != o_cls)[0][:10]
-    # a bad base code (20), a soft clip inside the CIGAR (19) or the evidence limit are found while the candidate is
-    # being written: it keeps its place in the batch
-    cand = [i for i in range(n) if tri[i][0].cls in (2, 3, 19, 20)]
+    # a soft clip inside the CIGAR (19), a bad base code outside the CIGAR's reach or in an unaligned read (20) and the evidence
+    # limit are found while the candidate is being written: it keeps its place in the batch.  What new_readaln refuses in a
+    # proper pair (18, 20) is found before the record becomes a candidate.
+    cand = [i for i in range(n) if tri[i][0].want]
     assert c[0] == len(cand)
     assert c[2] == int((o_cls != 0).sum()) and c[3] == int((o_cls >= 16).sum()) and c[4] == 0
     m = len(cand)
@@ -46,7 +47,7 @@ def _compare_triage(pipe, raw, rec_off, rg_names, rg_range, tri=None, **kw):
     for j, i in enumerate(cand):
         t, b = tri[i]
         assert boff[j] == pos and boff[j] % 4 == 0
-        if t.cls in (19, 20):
+        if t.cls in (18, 19, 20):
             pos += (int(blen[j]) + 3) // 4 * 4
             continue
         assert blen[j] == t.l_seq
@@ -95,10 +96,11 @@ def test_triage_matches_oracle_test_data(gpu_ctx, golden_dir):
         assert len(cand) == (697 if q == 10 else 703)
 
 
-def _rec(flag, tid=0, pos=100, mtid=0, mpos=300, isize=300, mapq=60, cigar=((100, 0),), seq=None, tags=b"", qname=b"q\0", l_seq=100, pad=b"\0\0\0"):
+def _rec(flag, tid=0, pos=100, mtid=0, mpos=300, isize=300, mapq=60, cigar=((100, 0),), seq=None, tags=b"", qname=b"q\0", l_seq=100, pad=b"\0\0\0", qual=None):
     seq = seq if seq is not None else bytes([0x12] * ((l_seq + 1) // 2))
+    qual = qual if qual is not None else b"\x28" * l_seq
     cig = b"".join(struct.pack("<I", (l << 4) | o) for l, o in cigar)
-    body = struct.pack("<iiBBHHHiiii", tid, pos, len(qname), mapq, 0, len(cigar), flag, l_seq, mtid, mpos, isize) + qname + cig + seq + b"\x28" * l_seq + tags
+    body = struct.pack("<iiBBHHHiiii", tid, pos, len(qname), mapq, 0, len(cigar), flag, l_seq, mtid, mpos, isize) + qname + cig + seq + qual + tags
     return body + pad[:(-len(body)) % 4]
 
 
@@ -127,6 +129,14 @@ def test_triage_edge_records(gpu_ctx):
         _rec(P, cigar=((20, 4), (13, 0)), l_seq=33, seq=bytes([0x48] * 17)), _rec(P | 0x10 | 0x20, cigar=((20, 4), (13, 0)), l_seq=33, seq=bytes([0x84, 0x21] * 8 + [0xf0])),
         _rec(P, cigar=S)[:60],                                                                                     # truncated record
         _rec(P, cigar=S, qname=b"qq\0", tags=b"MQC\x0a", pad=b"RGZ"), _rec(P, cigar=S, qname=b"qqq\0", pad=b"MQ"),   # alignment padding is no aux field
+        # new_readaln decodes EVERY proper pair op by op: a bad base code in a plain 100M read, behind / in front of a bad op,
+        # in a clipped part, past the CIGAR's coverage (not read), and a CIGAR that runs past l_seq into the qualities
+        _rec(P, seq=bytes([0x12] * 20 + [0x13] + [0x12] * 29)), _rec(P, cigar=((50, 0), (50, 3)), seq=bytes([0x12] * 10 + [0x31] + [0x12] * 39)),
+        _rec(P, cigar=((10, 0), (5, 3), (85, 0)), seq=bytes([0x12] * 30 + [0x50] + [0x12] * 19)), _rec(P, cigar=((20, 4), (80, 0)), seq=bytes([0x02] + [0x12] * 49)),
+        _rec(P, cigar=((60, 0),), seq=bytes([0x12] * 40 + [0x77] * 10)), _rec(P, cigar=((120, 0),)), _rec(P, cigar=((50, 0), (50, 9)), seq=bytes([0x12] * 49 + [0x10])),
+        _rec(P, cigar=((120, 0),), qual=b"\x28" * 5 + b"\x30" + b"\x28" * 94), _rec(P, cigar=((106, 0),), qual=b"\x28" * 5 + b"\x30" + b"\x28" * 94),   # the bytes behind the bases, read as bases
+        _rec(P, cigar=((300, 0),), l_seq=300, seq=bytes([0x12] * 145 + [0x13] + [0x12] * 4)), _rec(P, cigar=((200, 0),), l_seq=200, seq=bytes([0x12] * 90 + [0x31] + [0x12] * 9)),
+        _rec(P, cigar=((290, 0), (10, 4)), l_seq=300, seq=bytes([0x12] * 150)), _rec(P, cigar=((129, 0),), l_seq=129, seq=bytes([0x12] * 64 + [0x70])),
     ]
     raw = np.frombuffer(b"".join(recs), dtype=np.uint8).copy()
     off = np.zeros(len(recs) + 1, dtype=np.uint32)

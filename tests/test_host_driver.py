@@ -263,6 +263,37 @@ def test_host_unknown_read_group_exits_like_the_reference(tmp_path):
     assert all(o == outs[0] for o in outs)
 
 
+def test_host_iupac_base_in_a_plain_proper_pair_exits_like_the_reference(tmp_path):
+    """the reference builds the segment list of EVERY proper pair (new_readaln, src/readaln.c:186-240) and bit2char exits on a base
+    code other than A C G T N -- also in a read that is no candidate at all (100M).  Same exit code, same message, same stdout."""
+    import numpy as np
+    from indelminer_amd import bamwrite, synth
+    refs, rd = synth.simulate(seed=5, ref_len=30_000, coverage=10)
+    idx = [i for i in range(rd.n) if (rd.flag[i] & 0x3) == 0x3 and rd.ncig[i] == 1][50]
+    rd.seq = rd.seq.copy()
+    rd.seq[idx, 10] = ord("M")
+    contigs = [("ctg0", len(refs[0]))]
+    bamwrite.write_fasta(str(tmp_path / "ref.fa"), contigs, refs)
+    code = bamwrite._SEQ_CODE.copy()
+    try:
+        bamwrite._SEQ_CODE[ord("M")] = 3            # IUPAC M
+        bamwrite.write_bam(str(tmp_path / "aln.bam"), contigs, rd)
+    finally:
+        bamwrite._SEQ_CODE[:] = code
+    (tmp_path / "cfg.txt").write_text("IL generic 300 700\n")
+    outs = []
+    bins = [(_build_shim(), {}), (_build_shim(), {"INDELMINER_WALKERS": "1", "INDELMINER_REPLAYERS": "1"})]
+    ref_bin = os.path.join(ROOT, "oracle", "_ref", "indelminer")
+    if os.path.exists(ref_bin):
+        bins.append((ref_bin, {}))
+    for b, env in bins:
+        r = subprocess.run([b, "-i", "cfg.txt", "ref.fa", "s=aln.bam"], cwd=str(tmp_path), stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                           env=dict(os.environ, **env))
+        outs.append((r.returncode, r.stdout, r.stderr.decode().strip().splitlines()[-1]))
+    assert outs[0][0] == 1 and outs[0][2] == "indelminer: Unhandled base encoding : 3:3"
+    assert all(o == outs[0] for o in outs)
+
+
 def test_host_contigs_without_reads(tmp_path):
     """contigs that deliver no record at all -- the first, one in the middle, the last -- between contigs that do: claims,
     groups and flush placement must not mind (the read counter and the marker floor simply pass through them)"""
