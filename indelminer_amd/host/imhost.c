@@ -187,6 +187,42 @@ static char bit2char(int enc)
     return 'X';
 }
 
+/* What new_readaln refuses (src/readaln.c:186-240), in its order: op by op, N / H / P and unknown ops are fatal (163-182) and so
+ * is a base code bit2char refuses (4-16) under an op that carries read bases -- whichever comes first along the CIGAR.  Bases are
+ * taken where the CIGAR says (also behind l_seq; here not past the record); bases the CIGAR does not reach are never looked at. */
+static void check_like_new_readaln(const bam_record* b)
+{
+    const uint8_t* cig = BAMR_CIGAR(b);
+    const uint8_t* seq = BAMR_SEQ(b);
+    const int64_t avail = 2 * (int64_t)((b->data + b->l_data) - seq);
+    int64_t q = 0;
+    for (int i = 0; i < b->n_cigar; i++) {
+        const uint32_t w = bamr_cigar_at(cig, i);
+        const int op = CIG_OP(w);
+        const int64_t l = CIG_LEN(w);
+        if (op == OP_N) fatalf("Implement new_readseg_bam:164");
+        if (op == OP_H) fatalf("Implement new_readseg_bam:176");
+        if (op == OP_P) fatalf("Implement new_readseg_bam:179");
+        if (op > OP_X) fatalf("Unhandled cigar operation");
+        if (op == OP_M || op == OP_I || op == OP_S || op == OP_EQ || op == OP_X) {
+            for (int64_t j = q; j < q + l && j < avail; j++)
+                (void)bit2char((seq[j >> 1] >> ((~j & 1) << 2)) & 15);      /* exits with the reference's message on a code it refuses */
+            q += l;
+        }
+    }
+}
+
+/* the l_seq bases of a record new_readaln has accepted: a code outside the CIGAR's reach is never decoded there, '?' here */
+static char* decode_bases_checked(const bam_record* b)
+{
+    static const char dec[16] = { '?', 'A', 'C', '?', 'G', '?', '?', '?', 'T', '?', '?', '?', '?', '?', '?', 'N' };
+    char* s = xmalloc((size_t)b->l_seq + 1);
+    const uint8_t* q = BAMR_SEQ(b);
+    for (int i = 0; i < b->l_seq; i++) s[i] = dec[BAMR_SEQI(q, i) & 15];
+    s[b->l_seq] = 0;
+    return s;
+}
+
 static char* decode_bases(const bam_record* b)
 {
     char* s = xmalloc((size_t)b->l_seq + 1);
@@ -213,13 +249,9 @@ static seglist seglist_from_record(const bam_record* b)
     s.n = b->n_cigar;
     s.ops = xmalloc(sizeof(uint32_t) * (size_t)(b->n_cigar ? b->n_cigar : 1));
     const uint8_t* cig = BAMR_CIGAR(b);
-    for (int i = 0; i < b->n_cigar; i++) {
-        const int op = CIG_OP(bamr_cigar_at(cig, i));
-        if (op == OP_N || op == OP_H || op == OP_P) fatalf("Implement new_readseg_bam: CIGAR op %d", op);
-        if (op > OP_X) fatalf("Unhandled cigar operation");
-        s.ops[i] = bamr_cigar_at(cig, i);
-    }
-    s.bases = decode_bases(b);
+    check_like_new_readaln(b);
+    for (int i = 0; i < b->n_cigar; i++) s.ops[i] = bamr_cigar_at(cig, i);
+    s.bases = decode_bases_checked(b);
     return s;
 }
 
@@ -612,28 +644,7 @@ static void dispatch_record(driver* d, const bam_record* b)
         int is_threeprime_clip = 0;
         const uint8_t* cig = BAMR_CIGAR(b);
         const int ncig = b->n_cigar;
-        /* new_readaln (src/readaln.c:186-240) on every proper pair: op by op, N / H / P and unknown ops are fatal (163-182),
-         * and so is a base code bit2char refuses (4-16) in an op that carries read bases -- whichever comes first */
-        {
-            const uint8_t* seq = BAMR_SEQ(b);
-            const int64_t avail = 2 * (int64_t)((b->data + b->l_data) - seq);
-            int64_t q = 0;
-            for (int i = 0; i < ncig; i++) {
-                const uint32_t w = bamr_cigar_at(cig, i);
-                const int op = CIG_OP(w);
-                const int64_t l = CIG_LEN(w);
-                if (op == OP_N) fatalf("Implement new_readseg_bam:164");
-                if (op == OP_H) fatalf("Implement new_readseg_bam:176");
-                if (op == OP_P) fatalf("Implement new_readseg_bam:179");
-                if (op > OP_X) fatalf("Unhandled cigar operation");
-                if (op == OP_M || op == OP_I || op == OP_S || op == OP_EQ || op == OP_X) {
-                    for (int64_t j = q; j < q + l && j < avail; j++) {
-                        (void)bit2char((seq[j >> 1] >> ((~j & 1) << 2)) & 15);      /* exits with the reference's message on a code it refuses */
-                    }
-                    q += l;
-                }
-            }
-        }
+        check_like_new_readaln(b);
         for (int i = 0; i < ncig; i++) {
             const int op = CIG_OP(bamr_cigar_at(cig, i));
             if (op == OP_D) numcdels++;
