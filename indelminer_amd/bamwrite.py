@@ -111,8 +111,14 @@ def write_bam(path, contigs, rd, qname_prefix="r"):
                 name = rd.rg_names[int(rd.rg_idx[i])]
                 if name:
                     tags += b"RGZ" + name.encode() + b"\0"
+            mtid = tid
+            ov = getattr(rd, "overrides", None)                # optional per-record overrides for fuzzing: {i: {field: value}}
+            if ov is not None and i in ov:
+                o = ov[i]
+                tags = o.get("tags", tags); mtid = o.get("mtid", mtid); mapq = o.get("mapq", mapq)
+                ops = o.get("ops", ops); packed = o.get("packed", packed)
             cig = b"".join(struct.pack("<I", (l << 4) | o) for l, o in ops)
-            body = struct.pack("<iiBBHHHiiii", tid, pos, len(qn), mapq, b, len(ops), flag, L, tid,
+            body = struct.pack("<iiBBHHHiiii", tid, pos, len(qn), mapq, b, len(ops), flag, L, mtid,
                                int(rd.mpos[i]), int(rd.isize[i])) + qn + cig + packed + qual + tags
             rec = struct.pack("<i", len(body)) + body
             if len(z.buf) + len(rec) > 0xFF00:

@@ -3792,6 +3792,9 @@ int main(int argc, char** argv)
     }
     if (use_pipeline) run_pipeline(&d, pool);
     if (g_mg) mg_finish(&mg, &d);
+    /* the reference prints its header before it reads the first record (src/indelminer.c:745-754 in front of 756-): a run it
+     * aborts on some record has the header on stdout.  Here the header waits for the GPU context (gpu_wait). */
+    if (!use_pipeline) gpu_wait(&d);
     for (int32_t i = 0; i < d.hdr->n_targets && !use_pipeline; i++) {
         if (chromid != -1 && i != chromid) continue;
         if (g_vcfname != NULL) {

@@ -1,0 +1,143 @@
+#!/usr/bin/env python3
+"""CPU soak in the build container: the whole program against the COMPILED REFERENCE (oracle/_ref/indelminer) on small synthetic
+inputs whose records are then made odd -- flag bits, strands, insert sizes, mate contigs, =/X ops, N / H / P ops, clips inside the
+CIGAR, base codes, MQ / RG tags of right and wrong types, mapping qualities.  The product runs through the CPU shim (the device
+entry points answered by the oracle) in pipeline mode and record-at-a-time; exit code and stdout must be the reference's.
+    python profiles/ref_diff_fuzz.py [first_seed] [n_inputs] [workers]"""
+import hashlib, os, random, shutil, subprocess, sys, tempfile
+from concurrent.futures import ProcessPoolExecutor
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+REF = os.path.join(ROOT, "oracle", "_ref", "indelminer")
+
+
+def mutate(rng, rd, fatal_ok, cigar_ok=True):
+    import numpy as np
+    ov = {}
+    flag = rd.flag.copy(); isize = rd.isize.copy(); mpos = rd.mpos.copy()
+    for _ in range(rng.choice([0, 1, 3, 10, 30, 100])):
+        i = rng.randrange(rd.n)
+        o = ov.setdefault(i, {})
+        kind = rng.choice(["flag", "flag", "isize", "mtid", "eqx", "tags", "mapq", "strand", "unmate"] + ((["nhp", "clip"] if cigar_ok else []) + ["base", "badtag"] if fatal_ok else []))
+        f = int(flag[i])
+        ops = [(int(rd.cig_len[i, j]), int(rd.cig_op[i, j])) for j in range(int(rd.ncig[i]))] if not (f & 0x4) else []
+        if kind == "flag":
+            flag[i] = f ^ rng.choice([0x2, 0x100, 0x200, 0x400, 0x800, 0x1, 0x40 | 0x80])
+        elif kind == "strand":
+            flag[i] = f ^ rng.choice([0x10, 0x20, 0x30])
+        elif kind == "unmate":
+            flag[i] = f | 0x8
+        elif kind == "isize":
+            isize[i] = rng.choice([0, 1, -1, 100000, -100000, 2000000, -2000000, 701, -701, 999999, 1000000, rng.randrange(-5000, 5000)])
+            if rng.random() < 0.5: flag[i] = f & ~0x2
+        elif kind == "mtid":
+            o["mtid"] = rng.choice([1, 5, -1])
+        elif kind == "eqx" and ops:
+            new = []
+            for l, op in ops:
+                if op == 0 and l > 4 and rng.random() < 0.7:
+                    a = rng.randrange(1, l); new += [(a, rng.choice([7, 8, 0])), (l - a, rng.choice([7, 8]))]
+                else:
+                    new.append((l, op))
+            o["ops"] = new
+        elif kind == "tags":
+            t = rng.choice("CcSsIi"); v = rng.choice([0, 5, 9, 10, 11, 60, 255])
+            import struct
+            val = {"C": struct.pack("<B", v), "c": struct.pack("<b", min(v, 127)), "S": struct.pack("<H", v), "s": struct.pack("<h", v),
+                   "I": struct.pack("<I", v), "i": struct.pack("<i", v)}[t]
+            o["tags"] = rng.choice([b"", b"XYZab\0", b"NMi\1\0\0\0"]) + b"MQ" + t.encode() + val + rng.choice([b"", b"ASC\x10"])
+            if rng.random() < 0.2: o["tags"] = b""
+        elif kind == "mapq":
+            o["mapq"] = rng.choice([0, 1, 9, 10, 11, 255])
+        elif kind == "nhp" and ops:
+            k = rng.randrange(len(ops) + 1)
+            o["ops"] = ops[:k] + [(rng.randrange(1, 50), rng.choice([3, 5, 6, 9, 15]))] + ops[k:]
+        elif kind == "clip" and ops and ops[0][0] > 10:
+            l, op = ops[0]
+            a = rng.randrange(1, l - 4); b = rng.randrange(1, l - a)
+            o["ops"] = [(a, op), (b, 4), (l - a - b, op)] + ops[1:]
+        elif kind == "base":
+            from indelminer_amd import bamwrite
+            codes = bamwrite._SEQ_CODE[rd.seq[i]].copy()
+            codes[rng.randrange(len(codes))] = rng.choice([0, 3, 5, 6, 7, 9, 14])
+            if len(codes) & 1: codes = np.concatenate([codes, [0]])
+            o["packed"] = ((codes[0::2] << 4) | codes[1::2]).astype(np.uint8).tobytes()
+        elif kind == "badtag":
+            o["tags"] = rng.choice([b"MQf\0\0\x80\x3f", b"MQZ12\0", b"MQA5", b"RGZnope\0MQC\x3c", b"RGAx", b"RGZgen\0", b"RGZgenericx\0"])
+    rd.flag = flag; rd.isize = isize; rd.mpos = mpos
+    rd.overrides = ov
+
+
+def one(seed):
+    from indelminer_amd import bamwrite, synth
+    from tests.test_host_driver import _build_shim
+    rng = random.Random(seed)
+    d = tempfile.mkdtemp(prefix="rdf%d_" % seed, dir="/tmp")
+    try:
+        nct = rng.choice([1, 1, 2, 3])
+        refs, rd = synth.simulate(seed=seed, ref_len=rng.choice([8000, 15000, 30000]), coverage=rng.choice([6, 10, 16]), n_contigs=nct,
+                                  big_every=rng.choice([0, 3, 7]), indel_spacing=rng.choice([700, 2000]))
+        fatal_ok = rng.random() < 0.3
+        with_config = rng.random() < 0.7
+        # without -i the reference's coverage pass piles up every record first, and samtools' pileup asserts on the odd CIGARs
+        # (bam_pileup.c:112) before indelMINER's own code sees them: those only with a configuration file
+        mutate(rng, rd, fatal_ok, cigar_ok=with_config)
+        contigs = [("ctg%d" % t, len(refs[t])) for t in range(nct)]
+        bamwrite.write_fasta(os.path.join(d, "ref.fa"), contigs, refs)
+        bamwrite.write_bam(os.path.join(d, "aln.bam"), contigs, rd)
+        args = []
+        if with_config:
+            open(os.path.join(d, "cfg.txt"), "w").write("IL generic 300 %d\n" % rd.range_max)
+            args += ["-i", "cfg.txt"]
+        for fl in (["-o", "detailed"], ["-q", str(rng.choice([0, 5, 11, 30]))], ["-n", str(rng.choice([1, 5, 50]))], ["-s", str(rng.choice([300, 2000]))],
+                   ["-g", str(rng.choice([1, 5]))], ["-t"], ["-f", str(rng.choice([2, 10]))], ["-a"], ["-e", str(rng.choice([1, 3]))], ["-b", str(rng.choice([10, 45]))],
+                   ["-p", str(rng.choice([2000, 100000]))], ["-k", str(rng.choice([4, 8, 11]))], ["-c", "ctg0"]):
+            if rng.random() < 0.15: args += fl
+        cmd = args + ["ref.fa", "s=aln.bam"]
+        outs = []
+        shim = _build_shim()
+        for b, env in ((REF, {}), (shim, {}), (shim, {"INDELMINER_PIPELINE": "host"}), (shim, {"INDELMINER_WALKERS": "1", "INDELMINER_REPLAYERS": "1"})):
+            try:
+                r = subprocess.run([b] + cmd, cwd=d, stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=dict(os.environ, **env), timeout=600)
+                err = r.stderr.decode(errors="replace").strip().splitlines()
+                outs.append((r.returncode, hashlib.md5(r.stdout).hexdigest(), len(r.stdout), err[-1][:100] if err else ""))
+            except subprocess.TimeoutExpired:
+                outs.append(("timeout", "", 0, ""))
+        signalled = isinstance(outs[0][0], int) and outs[0][0] < 0
+        if signalled:
+            # the reference died of a signal (strlen(NULL) on a read-group tag of another type, an assert inside samtools): the product
+            # exits with status 1 and a message there
+            outs[0] = (1,) + outs[0][1:]
+        same = all((o[0], o[1]) == (outs[0][0], outs[0][1]) for o in outs[1:])
+        # A run the reference aborts: same exit status everywhere.  Its stdout up to there (the header, the variants of the flushes
+        # in front of the fatal record) is what the record-at-a-time mode prints too; the device pipeline finds the record during the
+        # walk, before any flush is replayed, and has printed the header only.  A reference that died of a
+        # signal lost its buffered stdout.
+        if not same and outs[0][0] != 0:
+            same = all(o[0] == outs[0][0] for o in outs[1:]) and (signalled or outs[2][1] == outs[0][1])
+        if not same:
+            keep = "/tmp/rdf_fail_%d" % seed
+            shutil.rmtree(keep, ignore_errors=True); shutil.copytree(d, keep)
+        return seed, same, fatal_ok, " ".join(cmd), outs
+    finally:
+        shutil.rmtree(d, ignore_errors=True)
+
+
+if __name__ == "__main__":
+    first = int(sys.argv[1]) if len(sys.argv) > 1 else 1
+    n = int(sys.argv[2]) if len(sys.argv) > 2 else 20
+    workers = int(sys.argv[3]) if len(sys.argv) > 3 else 6
+    assert os.path.exists(REF), "needs the compiled reference (oracle/Makefile, target ref)"
+    from tests.test_host_driver import _build_shim
+    _build_shim()
+    bad = 0; failed_runs = 0
+    with ProcessPoolExecutor(workers) as ex:
+        for seed, same, fatal_ok, cmd, outs in ex.map(one, range(first, first + n)):
+            failed_runs += outs[0][0] != 0
+            if not same:
+                bad += 1
+                print("DIFF seed %d (%s): %s" % (seed, cmd, outs), flush=True)
+            elif seed % 10 == 0:
+                print("seed %d ok (rc %s, %d bytes) %s" % (seed, outs[0][0], outs[0][2], outs[0][3][:60]), flush=True)
+    print("%d inputs, %d differ, %d where the reference exits with an error" % (n, bad, failed_runs))
+    sys.exit(1 if bad else 0)
