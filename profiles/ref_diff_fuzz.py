@@ -84,10 +84,20 @@ def one(seed):
         mutate(rng, rd, fatal_ok, cigar_ok=with_config)
         contigs = [("ctg%d" % t, len(refs[t])) for t in range(nct)]
         bamwrite.write_fasta(os.path.join(d, "ref.fa"), contigs, refs)
+        # read groups: names that are prefixes of one another (the table's strncmp / last-hit rule), some records without a tag
+        groups = [("generic", rd.range_max)]
+        if rng.random() < 0.4:
+            import numpy as np
+            names = rng.sample(["lib", "lib1", "lib10", "l", "libA", "x" * 30], rng.choice([1, 2, 4]))
+            groups += [(nm, rng.choice([500, 650, 700, 900])) for nm in names]
+            rd.rg_names = [""] + names
+            per_pair = {}
+            rd.rg_idx = np.array([per_pair.setdefault(int(pid), rng.randrange(len(rd.rg_names))) for pid in rd.pair_id], dtype=np.int32)
         bamwrite.write_bam(os.path.join(d, "aln.bam"), contigs, rd)
         args = []
         if with_config:
-            open(os.path.join(d, "cfg.txt"), "w").write("IL generic 300 %d\n" % rd.range_max)
+            rng.shuffle(groups)
+            open(os.path.join(d, "cfg.txt"), "w").write("".join("IL %s 300 %d\n" % g for g in groups))
             args += ["-i", "cfg.txt"]
         for fl in (["-o", "detailed"], ["-q", str(rng.choice([0, 5, 11, 30]))], ["-n", str(rng.choice([1, 5, 50]))], ["-s", str(rng.choice([300, 2000]))],
                    ["-g", str(rng.choice([1, 5]))], ["-t"], ["-f", str(rng.choice([2, 10]))], ["-a"], ["-e", str(rng.choice([1, 3]))], ["-b", str(rng.choice([10, 45]))],
@@ -115,6 +125,25 @@ def one(seed):
         # signal lost its buffered stdout.
         if not same and outs[0][0] != 0:
             same = all(o[0] == outs[0][0] for o in outs[1:]) and (signalled or outs[2][1] == outs[0][1])
+        if same and outs[0][0] == 0 and "-o" not in args and rng.random() < 0.5:
+            # annotate mode (README.md:116 of the reference): the calls of this sample tagged against a second one (other reads of
+            # the same genome, made odd the same way)
+            r0 = subprocess.run([REF] + cmd, cwd=d, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+            open(os.path.join(d, "calls.vcf"), "wb").write(r0.stdout)
+            refs2, rd2 = synth.simulate(seed=seed, ref_len=len(refs[0]), coverage=rng.choice([6, 12]), n_contigs=nct, read_seed=seed + 31,
+                                        big_every=0, indel_spacing=rng.choice([700, 2000]), somatic_spacing=0)
+            mutate(rng, rd2, False)
+            bamwrite.write_bam(os.path.join(d, "other.bam"), contigs, rd2)
+            acmd = [a for a in args if a != "-c" and a != "ctg0"] + ["ref.fa", "calls.vcf", "other=other.bam"]
+            aouts = []
+            for b, env in ((REF, {}), (shim, {}), (shim, {"INDELMINER_PIPELINE": "host"})):
+                r = subprocess.run([b] + acmd, cwd=d, stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=dict(os.environ, **env), timeout=600)
+                err = r.stderr.decode(errors="replace").strip().splitlines()
+                aouts.append((r.returncode if r.returncode >= 0 else 1, hashlib.md5(r.stdout).hexdigest(), len(r.stdout), err[-1][:100] if err else ""))
+            if not all((o[0], o[1]) == (aouts[0][0], aouts[0][1]) for o in aouts[1:]):
+                same = False
+                outs = outs + [("annotate",) + o for o in aouts]
+                cmd = cmd + ["|"] + acmd
         if not same:
             keep = "/tmp/rdf_fail_%d" % seed
             shutil.rmtree(keep, ignore_errors=True); shutil.copytree(d, keep)
