@@ -633,24 +633,26 @@ __global__ __launch_bounds__(kTriBlock) void triage_emit_kernel(TriageArgs A)
             if (op == 7u || op == 8u || op == 0u || op == 1u) tpos += w >> 4;
         }
         int32_t refpos = r.pos;
+        bool over = false;      // more evidence than the slots hold: the kernel's own limit, behind anything the reference refuses further on
         for (uint32_t k = 0; k < r.n_cigar && !err; k++) {
             const uint32_t w = cigar_word(r, k), op = w & 15u, len = w >> 4;
             if (op == 2u || op == 1u) {
                 if (rpos > A.tp.ethreshold_vcfcheck && (tpos - rpos) > A.tp.ethreshold_vcfcheck) {
-                    if (ne >= IM_MAX_EV) { err = IM_REC_ERR_LIMIT; break; }
                     const int32_t c = op == 2u ? IM_CLS_DELETION : IM_CLS_INSERTION, x1 = refpos, x2 = op == 2u ? refpos + (int32_t)len : refpos;
                     // static slot selection keeps the three small arrays in registers
                     if (ne == 0) { e_cls[0] = c; e_b1[0] = x1; e_b2[0] = x2; }
                     else if (ne == 1) { e_cls[1] = c; e_b1[1] = x1; e_b2[1] = x2; }
                     else if (ne == 2) { e_cls[2] = c; e_b1[2] = x1; e_b2[2] = x2; }
-                    else { e_cls[3] = c; e_b1[3] = x1; e_b2[3] = x2; }
-                    ne++;
+                    else if (ne == 3) { e_cls[3] = c; e_b1[3] = x1; e_b2[3] = x2; }
+                    else over = true;
+                    ne += ne < IM_MAX_EV ? 1 : 0;
                 }
             } else if (op == 0u || op == 7u || op == 8u) rpos += len;
             else if (op == 4u) { if (!(k == 0u || k == r.n_cigar - 1u)) err = IM_REC_ERR_CLIP; }
             else err = IM_REC_ERR_CIGAR;
             if (op == 0u || op == 7u || op == 8u || op == 2u) refpos += (int32_t)len;
         }
+        if (!err && over) err = IM_REC_ERR_LIMIT;
     }
     if (B.ev_cls) {
 #pragma unroll
