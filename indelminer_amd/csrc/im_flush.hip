@@ -98,7 +98,6 @@ __global__ __launch_bounds__(1024) void flush_seq_kernel(const im_flush_desc* __
     __shared__ unsigned long long s_best[16];
     __shared__ int32_t s_first[16];
     __shared__ unsigned long long s_cut;
-    __shared__ Ranges s_R;
     __shared__ int32_t s_lo, s_lo_rec0;           // first split-read slot of the current contig that may still be pending
     __shared__ int32_t s_plo, s_plo_pe0, s_pfirst[16];   // the same for the contig's paired-read entries
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
@@ -108,6 +107,7 @@ __global__ __launch_bounds__(1024) void flush_seq_kernel(const im_flush_desc* __
     if (t == 0) { s_lo = 0; s_lo_rec0 = -1; s_plo = 0; s_plo_pe0 = -1; }
     __syncthreads();
     __shared__ int32_t s_bound[1024];             // candidate bounds of up to 512 flushes: [2k] = first, [2k + 1] = end
+    __shared__ im_flush_desc s_desc[512];         // ... and their descriptors: a flush starts without a trip to memory
     const int32_t ncand = min(*n_cand, cand_cap);
     for (int32_t f = 0; f < n_fl; f++) {
         if ((f & 511) == 0) {
@@ -116,28 +116,28 @@ __global__ __launch_bounds__(1024) void flush_seq_kernel(const im_flush_desc* __
             __syncthreads();
             const int32_t ff = f + (t >> 1);
             if (ff < n_fl) s_bound[t] = lower_bound_dev(cand_rec, ncand, (t & 1) ? desc[ff].rec1 : desc[ff].rec0);
+            if (t < 512 && f + t < n_fl) s_desc[t] = desc[f + t];
             __syncthreads();
         }
-        if (t == 0) {
-            Ranges R;
+        const im_flush_desc D = s_desc[f & 511];
+        // every thread works the flush's ranges out for itself from what the last flush left in LDS (no hand-over, no barrier)
+        Ranges R;
+        {
             const int32_t lo = s_bound[2 * (f & 511)], hi = max(lo, s_bound[2 * (f & 511) + 1]);
-            R.a0 = lo * IM_MAX_EV; R.na = (hi - lo) * IM_MAX_EV; R.b0 = pe_base + desc[f].pe0; R.nb = desc[f].pe1 - desc[f].pe0;
+            R.a0 = lo * IM_MAX_EV; R.na = (hi - lo) * IM_MAX_EV; R.b0 = pe_base + D.pe0; R.nb = D.pe1 - D.pe0;
             R.cand_rec = nullptr; R.n_cand = nullptr; R.cand_cap = 0;
             if (R.nb < 0) R.nb = 0;
             // Everything in front of s_lo was consumed by earlier flushes of this contig (a flush consumes a prefix of
             // what is pending, in slot order nearly all of it): start there, not at the contig's first slot.
-            if (desc[f].rec0 != s_lo_rec0) { s_lo_rec0 = desc[f].rec0; s_lo = R.a0; }
+            const int32_t cur_lo = D.rec0 != s_lo_rec0 ? R.a0 : s_lo;
             const int32_t end = R.a0 + R.na;
-            if (s_lo > R.a0) { R.a0 = s_lo < end ? s_lo : end; R.na = end - R.a0; }
+            if (cur_lo > R.a0) { R.a0 = cur_lo < end ? cur_lo : end; R.na = end - R.a0; }
             // the paired-read entries of the contig likewise: in arrival order nearly all of a flush's are consumed by it
-            if (desc[f].pe0 != s_plo_pe0) { s_plo_pe0 = desc[f].pe0; s_plo = R.b0; }
+            const int32_t cur_plo = D.pe0 != s_plo_pe0 ? R.b0 : s_plo;
             const int32_t pend = R.b0 + R.nb;
-            if (s_plo > R.b0) { R.b0 = s_plo < pend ? s_plo : pend; R.nb = pend - R.b0; }
-            s_R = R;
+            if (cur_plo > R.b0) { R.b0 = cur_plo < pend ? cur_plo : pend; R.nb = pend - R.b0; }
         }
-        __syncthreads();
-        const Ranges R = s_R;
-        const int32_t marker = desc[f].marker, id = desc[f].id;
+        const int32_t marker = D.marker, id = D.id;
         // The split-read part by CANDIDATE: a candidate's IM_MAX_EV = 4 slots are 16 contiguous bytes in each of the four
         // arrays, so one thread takes whole candidates with 16-byte loads (a quarter of the load instructions, and the
         // three empty slots of a typical candidate cost nothing more).  One workgroup cannot hide memory latency with
@@ -252,10 +252,10 @@ __global__ __launch_bounds__(1024) void flush_seq_kernel(const im_flush_desc* __
         if (t == 0) {
             int32_t m = 0x7fffffff;
             for (int w = 0; w < 16; w++) if (s_first[w] < m) m = s_first[w];
-            s_lo = m == 0x7fffffff ? R.a0 + R.na : m;
+            s_lo = m == 0x7fffffff ? R.a0 + R.na : m; s_lo_rec0 = D.rec0;
             int32_t pm = 0x7fffffff;
             for (int w = 0; w < 16; w++) if (s_pfirst[w] < pm) pm = s_pfirst[w];
-            s_plo = pm == 0x7fffffff ? R.b0 + R.nb : pm;
+            s_plo = pm == 0x7fffffff ? R.b0 + R.nb : pm; s_plo_pe0 = D.pe0;
         }
         __syncthreads();
     }
