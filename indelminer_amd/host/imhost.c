@@ -552,6 +552,7 @@ static evidence_t* discordant_pair(driver* d, const bam_record* b, const int32_t
             qbin* hb = qhash_lookup(d->readpairs, qname, b->l_qname);
             evidence_t* e = hb ? hb->val : NULL;
             int skip = 0;
+            evidence_t* dropped = NULL;         /* completed, but neither mate passes -q: freed once it has left the table */
             if (!e) {
                 seglist m; char mstrand = '+';
                 const char want = (flag & 0x40) ? '2' : '1';
@@ -580,9 +581,10 @@ static evidence_t* discordant_pair(driver* d, const bam_record* b, const int32_t
                     seg_reduce(&e->aln, 0, e->aln.n, r, &e->lflank, &e->nd_print, &e->nd_filter);
                     seg_reduce(&e->aln3, 0, e->aln3.n, r, &e->rflank, &e->nd_print, &e->nd_filter);
                     done = e;
-                } else evidence_free(e);
+                } else dropped = e;
             }
             live_del(d, qhash_remove(d->readpairs, qname, b->l_qname));
+            if (dropped) evidence_free(dropped);
         }
     }
     return done;
@@ -1714,9 +1716,13 @@ static void rg_order_push(const char* name, int32_t* range)
     g_rg_name[g_rg_n] = xstrdup(name); g_rg_range[g_rg_n] = range; g_rg_n++;
 }
 
-static void read_configuration(const char* filename, qhash* insertlengths)
+static void read_configuration(const char* filename, qhash* insertlengths, const bam_header* hdr)
 {
-    /* src/shared.c:5-44 */
+    /* src/shared.c:5-44.  An RC line's contig goes through must_find_hashtable_int on a 32-bin table of the BAM header's names
+     * (src/indelminer.c:700-706) -- a name the header does not know ends the run there; the coverage itself is only ever
+     * printed on stderr (src/indelminer.c:731). */
+    qhash* id2chroms = qhash_new(5);
+    for (int32_t i = 0; i < hdr->n_targets; i++) qhash_add(id2chroms, hdr->target_name[i], (int)strlen(hdr->target_name[i]), NULL);
     size_t cap = 2;
     char* line = xmalloc(cap);
     FILE* fp = fopen(filename, "r");
@@ -1731,10 +1737,12 @@ static void read_configuration(const char* filename, qhash* insertlengths)
             rg_order_push(name, range);
         } else if (strncmp(line, "RC", 2) == 0) {
             if (sscanf(line, "RC %127s %u\n", name, &a) != 2) fatalf("error in reading the mean coverage: %s", line);
+            if (!qhash_lookup(id2chroms, name, (int)strlen(name))) fatalf("did not find %s in the hash", name);
         } else fatalf("unknown tag in configuration: %s", line);
     }
     free(line);
     fclose(fp);
+    qhash_free(id2chroms, NULL);
 }
 
 static void estimate_insertlengths(driver* d, int chromid)
@@ -3745,7 +3753,7 @@ int main(int argc, char** argv)
         }
     }
 
-    if (O.configfile) read_configuration(O.configfile, d.insertlengths);
+    if (O.configfile) read_configuration(O.configfile, d.insertlengths, d.hdr);
     else if (g_onepass) { }
     else if (!g_mg) { if (chromid == -1 && !getenv("INDELMINER_ESTIMATE_SERIAL")) estimate_insertlengths_threads(&d); else estimate_insertlengths(&d, chromid); }
     fprintf(stderr, "\nRead-group\tMin-value\tMax-value\n----------\t---------\t---------\n");

@@ -99,18 +99,19 @@ def one(seed):
             rng.shuffle(groups)
             open(os.path.join(d, "cfg.txt"), "w").write("".join("IL %s 300 %d\n" % g for g in groups))
             args += ["-i", "cfg.txt"]
-        for fl in (["-o", "detailed"], ["-q", str(rng.choice([0, 5, 11, 30]))], ["-n", str(rng.choice([1, 5, 50]))], ["-s", str(rng.choice([300, 2000]))],
+        for fl in (["-o", "detailed"], ["-q", str(rng.choice([0, 5, 11, 30, 61, 255]))], ["-n", str(rng.choice([1, 5, 50]))], ["-s", str(rng.choice([300, 2000]))],
                    ["-g", str(rng.choice([1, 5]))], ["-t"], ["-f", str(rng.choice([2, 10]))], ["-a"], ["-e", str(rng.choice([1, 3]))], ["-b", str(rng.choice([10, 45]))],
                    ["-p", str(rng.choice([2000, 100000]))], ["-k", str(rng.choice([4, 8, 11]))], ["-c", "ctg0"]):
             if rng.random() < 0.15: args += fl
         cmd = args + ["ref.fa", "s=aln.bam"]
         outs = []
-        shim = _build_shim()
+        shim = os.environ.get("RDF_SHIM") or _build_shim()      # RDF_SHIM: a sanitizer build of the same sources
         for b, env in ((REF, {}), (shim, {}), (shim, {"INDELMINER_PIPELINE": "host"}), (shim, {"INDELMINER_WALKERS": "1", "INDELMINER_REPLAYERS": "1"})):
             try:
                 r = subprocess.run([b] + cmd, cwd=d, stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=dict(os.environ, **env), timeout=600)
                 err = r.stderr.decode(errors="replace").strip().splitlines()
-                outs.append((r.returncode, hashlib.md5(r.stdout).hexdigest(), len(r.stdout), err[-1][:100] if err else ""))
+                rc = "sanitizer" if b"Sanitizer" in r.stderr else r.returncode
+                outs.append((rc, hashlib.md5(r.stdout).hexdigest(), len(r.stdout), err[-1][:100] if err else ""))
             except subprocess.TimeoutExpired:
                 outs.append(("timeout", "", 0, ""))
         signalled = isinstance(outs[0][0], int) and outs[0][0] < 0
