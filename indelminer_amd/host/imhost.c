@@ -2983,10 +2983,29 @@ static int merge_rgs(mg_rg* all, int n_all, mg_rg* out)
     return n;
 }
 
+/* The merged list (exact names, first-met order) into the insert-length table the way ONE sequential pass builds it
+ * (src/bamoperations.c:48-57): a name is looked up before it is added, and the table's look-up takes an OLDER entry of the same
+ * bin whose name merely starts with it (src/hashtable.c:62-81) -- "lib1" met after "lib10" never gets an entry, its sizes widen
+ * lib10's range.  Which entry a name goes to is settled when it is first met (entries are never removed, the oldest match wins),
+ * so replaying the names in first-met order gives the sequential table exactly.  Returns the entry's range. */
+static int32_t* rg_table_enter(driver* d, const mg_rg* g)
+{
+    qbin* hit = qhash_lookup(d->insertlengths, g->name, (int)strlen(g->name));
+    if (hit) {
+        int32_t* range = hit->val;
+        if (g->min < range[0]) range[0] = g->min;
+        if (g->max > range[1]) range[1] = g->max;
+        return range;
+    }
+    int32_t* range = xmalloc(2 * sizeof(int32_t));
+    range[0] = g->min; range[1] = g->max;
+    qhash_add(d->insertlengths, g->name, (int)strlen(g->name), range);
+    rg_order_push(g->name, range);
+    return range;
+}
+
 /* estimate_insertlengths (src/bamoperations.c:15-86) with the contigs spread over threads: the pass is pure decode + a
- * min / max per read group, so contigs are independent and the per-thread tables merge exactly (read groups enter the table
- * in the order of their first record in the file, as in a single pass; names that are prefixes of one another and share a
- * hash bin would alias in the reference's lookup -- not reproduced across threads) */
+ * min / max per read group, so contigs are independent and the per-thread lists merge exactly (rg_table_enter) */
 typedef struct { const driver* d; int t0, step; mg_rg rgs[MG_MAX_RG]; int n_rg; } est_job;
 static void* est_thread(void* arg)
 {
@@ -3013,12 +3032,7 @@ static void estimate_insertlengths_threads(driver* d)
     for (int i = 0; i < nt; i++) { pthread_join(th[i], NULL); for (int k = 0; k < jobs[i].n_rg; k++) all[n_all++] = jobs[i].rgs[k]; }
     mg_rg* merged = xcalloc((size_t)(n_all ? n_all : 1), sizeof(mg_rg));
     const int n = merge_rgs(all, n_all, merged);
-    for (int j = 0; j < n; j++) {
-        int32_t* range = xmalloc(2 * sizeof(int32_t));
-        range[0] = merged[j].min; range[1] = merged[j].max;
-        qhash_add(d->insertlengths, merged[j].name, (int)strlen(merged[j].name), range);
-        rg_order_push(merged[j].name, range);
-    }
+    for (int j = 0; j < n; j++) rg_table_enter(d, &merged[j]);
     free(all); free(merged); free(jobs); free(th);
 }
 
@@ -3048,12 +3062,7 @@ static void mg_exchange(mgpu* m, driver* d, int estimate)
         mg_rg* rgs = xcalloc((size_t)(n_got ? n_got : 1), sizeof(mg_rg));
         const int n = merge_rgs(got, n_got, rgs);          /* the order in which one process would have met them */
         free(got);
-        for (int j = 0; j < n; j++) {
-            int32_t* range = xmalloc(2 * sizeof(int32_t));
-            range[0] = rgs[j].min; range[1] = rgs[j].max;
-            qhash_add(d->insertlengths, rgs[j].name, (int)strlen(rgs[j].name), range);
-            rg_order_push(rgs[j].name, range);
-        }
+        for (int j = 0; j < n; j++) rg_table_enter(d, &rgs[j]);
         free(rgs);
     }
     m->prefix = xcalloc((size_t)nt + 1, sizeof(int64_t));
@@ -3398,13 +3407,8 @@ static void run_pipeline(driver* d, walkpool_t* o)
         mg_rg* merged = xcalloc((size_t)(n_all ? n_all : 1), sizeof(mg_rg));
         const int n = merge_rgs(all, n_all, merged);
         fprintf(stderr, "\nRead-group\tMin-value\tMax-value (estimated during the walk)\n");
-        for (int j = 0; j < n; j++) {
-            int32_t* range = xmalloc(2 * sizeof(int32_t));
-            range[0] = merged[j].min; range[1] = merged[j].max;
-            qhash_add(d->insertlengths, merged[j].name, (int)strlen(merged[j].name), range);
-            rg_order_push(merged[j].name, range);
-            fprintf(stderr, "%s\t%d\t%d\n", merged[j].name, range[0], range[1]);
-        }
+        for (int j = 0; j < n; j++) rg_table_enter(d, &merged[j]);
+        for (int j = 0; j < g_rg_n; j++) fprintf(stderr, "%s\t%d\t%d\n", g_rg_name[j], g_rg_range[j][0], g_rg_range[j][1]);
         free(all); free(merged);
         pipe_global_init(d);
         /* every group's ranges and pair-table replay, the groups spread over threads (each with a pair table of its own) */
@@ -3602,7 +3606,7 @@ static void check_read_lengths(const char* bam_name)
 static void check_known_variants(const char* vcfname)
 {
     FILE* fp = fopen(vcfname, "r");
-    if (!fp) fatalf("error in opening the file %s", vcfname);
+    if (!fp) return;            /* the reference finds that out when it reads the first contig's variants, its header already printed: so here */
     size_t cap = 2;
     char* line = xmalloc(cap);
     while (im_getline(&line, &cap, fp) != -1) {

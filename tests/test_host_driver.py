@@ -347,6 +347,28 @@ def test_host_read_groups_estimated_by_several_threads(tmp_path):
                 {"INDELMINER_ONEPASS": "1", "INDELMINER_WALKERS": "3", "INDELMINER_CLAIM_BASES": "1"}):
         assert _run(shim, [], str(tmp_path), ref="ref.fa", bam="aln.bam", env=env) == want, env
 
+    # The table itself (stderr): "lib1" is first met after "lib10", shares its hash bin and is a prefix of it -- the sequential
+    # look-up never gives it an entry, its sizes widen lib10's range (src/bamoperations.c:48-57, src/hashtable.c:62-81).
+    def table(binary, env):
+        r = subprocess.run([binary, "ref.fa", "sample=aln.bam"], cwd=str(tmp_path), stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=dict(os.environ, **env))
+        assert r.returncode == 0
+        lines = r.stderr.decode().splitlines()
+        at = next(i for i, l in enumerate(lines) if l.startswith("Read-group"))
+        rows = []
+        for l in lines[at + 1:]:
+            f = l.split("\t")
+            if len(f) == 3 and f[1].lstrip("-").isdigit():
+                rows.append(tuple(f))
+            elif rows:
+                break
+        return sorted(rows)
+    serial = table(shim, {"INDELMINER_PIPELINE": "host", "INDELMINER_ESTIMATE_SERIAL": "1"})
+    assert [r[0] for r in serial] == ["generic", "li", "lib10"]
+    if os.path.exists(ref_bin):
+        assert table(ref_bin, {}) == serial
+    for env in ({}, {"INDELMINER_WALKERS": "3"}, {"INDELMINER_ONEPASS": "1"}):
+        assert table(shim, env) == serial, env
+
 
 def _stale_dir(tmp_path, ref_len=250_000):
     import numpy as np
