@@ -420,6 +420,7 @@ typedef struct {
 static void gpu_wait(driver* d);
 static void print_vcf_preamble(void);
 static int g_mg_rank = 0, g_mg_local = -1;
+static int g_mg_parts = 0;              /* a multi-GPU run: output goes to per-contig parts that rank 0 puts together */
 static char g_mg_header_path[512] = "";
 
 static void cb_push(cand_batch* cb, const char* bases, int32_t tid, int32_t anchor, int32_t range_max,
@@ -1154,7 +1155,10 @@ static void print_det_output(driver* d, const variant_t* v)
 {
     static int indel_index = 1;
     printf("###########################################################\n");
-    printf("%d\t%s\t%d\t%d\t%s\t%d\t%d\t%d\n", indel_index++, d->hdr->target_name[v->tid], (int)v->start, (int)v->stop,
+    /* the blocks are numbered across the run: a rank of a multi-GPU run does not know how many the contigs in front of its own
+     * print, so it leaves a mark where the number goes and rank 0 counts while it puts the parts together (mg_finish) */
+    if (g_mg_parts) printf("\001"); else printf("%d", indel_index++);
+    printf("\t%s\t%d\t%d\t%s\t%d\t%d\t%d\n", d->hdr->target_name[v->tid], (int)v->start, (int)v->stop,
            v->type == CLS_DELETION ? "Deletion" : "Insertion", (int)v->start, (int)(v->stop + v->rw + 1), (int)v->support);
     if (v->type == CLS_DELETION) print_deletion_output(d, v);
     else if (v->type == CLS_INSERTION) print_insertion_output(d, v);
@@ -3094,6 +3098,7 @@ static void mg_finish(mgpu* m, driver* d)
     free(all);
     if (m->rank == 0) {
         char path[512], buf[1 << 16];
+        int det_blocks = 0;
         for (int32_t t = -1; t < d->hdr->n_targets; t++) {
             if (t < 0) snprintf(path, sizeof path, "%s", g_mg_header_path); else mg_path(m, path, sizeof path, "part", t);
             FILE* fp = fopen(path, "rb");
@@ -3101,7 +3106,18 @@ static void mg_finish(mgpu* m, driver* d)
             size_t got;
             while ((got = fread(buf, 1, sizeof buf, fp)) > 0) {
                 size_t off = 0;
-                while (off < got) { const ssize_t w = write(m->out_fd, buf + off, got - off); if (w <= 0) fatalf("write to stdout failed"); off += (size_t)w; }
+                while (off < got) {
+                    /* -o detailed: a 0x01 byte stands where a block's number goes (print_det_output) */
+                    const char* mark = memchr(buf + off, 1, got - off);
+                    const size_t upto = mark ? (size_t)(mark - buf) : got;
+                    while (off < upto) { const ssize_t w = write(m->out_fd, buf + off, upto - off); if (w <= 0) fatalf("write to stdout failed"); off += (size_t)w; }
+                    if (mark) {
+                        char num[16];
+                        const int nl = snprintf(num, sizeof num, "%d", ++det_blocks);
+                        if (write(m->out_fd, num, (size_t)nl) != nl) fatalf("write to stdout failed");
+                        off++;
+                    }
+                }
             }
             fclose(fp);
         }
@@ -3729,7 +3745,7 @@ int main(int argc, char** argv)
             mg.rank = getenv("RANK") ? atoi(getenv("RANK")) : 0;
             mg.local_rank = getenv("LOCAL_RANK") ? atoi(getenv("LOCAL_RANK")) : mg.rank;
             forceassert(mg.rank >= 0 && mg.rank < mg.world);
-            g_mg = &mg; g_mg_rank = mg.rank; g_mg_local = mg.local_rank;
+            g_mg = &mg; g_mg_rank = mg.rank; g_mg_local = mg.local_rank; g_mg_parts = 1;
             /* librccl prints a banner on descriptor 1: the VCF goes through part files and the saved descriptor, and
              * descriptor 1 points at stderr for the whole run */
             fflush(stdout);

@@ -126,6 +126,22 @@ def one(seed):
         # signal lost its buffered stdout.
         if not same and outs[0][0] != 0:
             same = all(o[0] == outs[0][0] for o in outs[1:]) and (signalled or outs[2][1] == outs[0][1])
+        if same and outs[0][0] == 0 and "-c" not in args and rng.random() < 0.4:
+            # the multi-GPU mode of the CLI (one process per rank, contigs tid % world, one exchange of summaries), ranks as plain
+            # processes on the shim: rank 0's stdout must be the single-process VCF
+            world = rng.choice([2, 3])
+            rdv = os.path.join(d, "rdv")
+            procs = []
+            for rank in range(world):
+                env = dict(os.environ, RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(20000 + seed % 20000),
+                           INDELMINER_RENDEZVOUS=rdv)
+                procs.append(subprocess.Popen([shim] + cmd, cwd=d, stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env))
+            res = [p.communicate(timeout=600) for p in procs]
+            rcs = [p.returncode for p in procs]
+            mg = (max(rcs) if min(rcs) >= 0 else min(rcs), hashlib.md5(res[0][0]).hexdigest(), len(res[0][0]), "world %d" % world)
+            if (mg[0], mg[1]) != (outs[0][0], outs[0][1]):
+                same = False
+                outs = outs + [("multi-rank",) + mg + (res[0][1].decode(errors="replace").strip().splitlines()[-1:],)]
         if same and outs[0][0] == 0 and "-o" not in args and rng.random() < 0.5:
             # annotate mode (README.md:116 of the reference): the calls of this sample tagged against a second one (other reads of
             # the same genome, made odd the same way)

@@ -66,6 +66,15 @@ def test_two_ranks_print_the_single_run(tmp_path_factory, flags, golden):
     assert got == want
 
 
+def test_two_ranks_number_the_detailed_blocks_across_the_run(tmp_path_factory):
+    """-o detailed numbers its blocks across the contigs (src/variant.c print_det_output's static counter): a rank does not know how
+    many blocks the contigs in front of its own print, rank 0 fills the numbers in while it puts the parts together"""
+    d = th._synth_dir(tmp_path_factory, "synth_2ctg_composite")
+    want = th._run(th._build_shim(), ["-i", "cfg.txt", "-o", "detailed"], d, ref="ref.fa", bam="aln.bam", env={"INDELMINER_PIPELINE": "host"})
+    assert want.count(b"#####") > 20 and b"\x01" not in want
+    assert _run_world(2, ["-i", "cfg.txt", "-o", "detailed"], d, "ref.fa", "aln.bam") == want
+
+
 def test_three_ranks_two_contigs(tmp_path_factory):
     """more ranks than contigs: the idle rank still takes part in the collectives"""
     d = th._synth_dir(tmp_path_factory, "synth_2ctg_composite")
