@@ -536,3 +536,40 @@ def test_product_multi_gpu_path_one_rank(synth_small, tmp_path):
                    env={"INDELMINER_FORCE_MGPU": "1", "RANK": "0", "WORLD_SIZE": "1", "LOCAL_RANK": "0",
                         "INDELMINER_RENDEZVOUS": str(tmp_path / "rdv")})
         assert out == _golden(gold)
+
+
+def _odd_inputs(binary, tmp_path, envs, seeds=None):
+    """the inputs of tests/golden/odd_inputs.py regenerated from their seeds; what the compiled reference did with each is in
+    tests/golden/odd_inputs.json (make_golden_odd.py): same exit status; same stdout where the reference completes"""
+    import hashlib, json, shutil
+    from tests.golden.odd_inputs import make_input
+    want = json.load(open(os.path.join(ROOT, "tests", "golden", "odd_inputs.json")))
+    n_ok = 0
+    for seed in sorted(want, key=int):
+        if seeds is not None and int(seed) not in seeds:
+            continue
+        w = want[seed]
+        d = str(tmp_path / ("odd" + seed))
+        os.makedirs(d)
+        cmd, _ = make_input(int(seed), d)
+        assert cmd == w["cmd"], seed
+        for env in envs:
+            r = subprocess.run([binary] + cmd, cwd=d, stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=dict(os.environ, **env))
+            assert r.returncode == w["rc"], (seed, env, r.returncode, r.stderr.decode(errors="replace")[-400:])
+            if w["rc"] == 0:
+                assert hashlib.md5(r.stdout).hexdigest() == w["md5"], (seed, env, len(r.stdout), w["bytes"])
+                n_ok += 1
+        shutil.rmtree(d)
+    return n_ok
+
+
+def test_host_odd_inputs_match_the_reference(tmp_path):
+    """host logic on the CPU shim; a third of the list here, the whole list on the GPU below"""
+    assert _odd_inputs(_build_shim(), tmp_path, [{}, {"INDELMINER_PIPELINE": "host"}], seeds=set(range(20000, 20070, 3))) > 20
+
+
+@pytest.mark.gpu
+def test_product_odd_inputs_match_the_reference(tmp_path):
+    """the product with its real kernels: records made odd in every way the reference has an opinion on, random flags, read
+    groups, with and without a configuration file -- exit status and stdout as the compiled reference gave them"""
+    assert _odd_inputs(_product(), tmp_path, [{}, {"INDELMINER_WALKERS": "1", "INDELMINER_REPLAYERS": "1"}]) > 90
