@@ -72,7 +72,8 @@ def make_input(seed, d):
     if True:
         nct = rng.choice([1, 1, 2, 3])
         refs, rd = synth.simulate(seed=seed, ref_len=rng.choice([8000, 15000, 30000]), coverage=rng.choice([6, 10, 16]), n_contigs=nct,
-                                  big_every=rng.choice([0, 3, 7]), indel_spacing=rng.choice([700, 2000]))
+                                  big_every=rng.choice([0, 3, 7]), indel_spacing=rng.choice([700, 2000]),
+                                  read_len=rng.choice([100, 100, 100, 51, 76, 150, 250]))
         fatal_ok = rng.random() < 0.3
         with_config = rng.random() < 0.7
         # without -i the reference's coverage pass piles up every record first, and samtools' pileup asserts on the odd CIGARs
