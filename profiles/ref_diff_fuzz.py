@@ -71,8 +71,9 @@ def one(seed):
             for b, env in ((REF, {}), (shim, {}), (shim, {"INDELMINER_PIPELINE": "host"})):
                 r = subprocess.run([b] + acmd, cwd=d, stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=dict(os.environ, **env), timeout=600)
                 err = r.stderr.decode(errors="replace").strip().splitlines()
-                aouts.append((r.returncode if r.returncode >= 0 else 1, hashlib.md5(r.stdout).hexdigest(), len(r.stdout), err[-1][:100] if err else ""))
-            if not all((o[0], o[1]) == (aouts[0][0], aouts[0][1]) for o in aouts[1:]):
+                aouts.append((r.returncode if r.returncode >= 0 else 1, hashlib.md5(r.stdout).hexdigest(), len(r.stdout), err[-1][:100] if err else "", r.returncode < 0))
+            # completed: same bytes; aborted: same status (a reference that died of a signal -- its asserts -- lost its buffered stdout)
+            if not all(o[0] == aouts[0][0] and (o[1] == aouts[0][1] or aouts[0][4]) for o in aouts[1:]):
                 same = False
                 outs = outs + [("annotate",) + o for o in aouts]
                 cmd = cmd + ["|"] + acmd

@@ -11,11 +11,12 @@ import random
 def mutate(rng, rd, fatal_ok, cigar_ok=True):
     import numpy as np
     ov = {}
+    mates = None
     flag = rd.flag.copy(); isize = rd.isize.copy(); mpos = rd.mpos.copy()
     for _ in range(rng.choice([0, 1, 3, 10, 30, 100])):
         i = rng.randrange(rd.n)
         o = ov.setdefault(i, {})
-        kind = rng.choice(["flag", "flag", "isize", "mtid", "eqx", "tags", "mapq", "strand", "unmate"] + ((["nhp", "clip"] if cigar_ok else []) + ["base", "badtag"] if fatal_ok else []))
+        kind = rng.choice(["flag", "flag", "isize", "mtid", "eqx", "tags", "mapq", "strand", "unmate", "unmap", "unmap", "unmap"] + ((["nhp", "clip"] if cigar_ok else []) + ["base", "badtag"] if fatal_ok else []))
         f = int(flag[i])
         ops = [(int(rd.cig_len[i, j]), int(rd.cig_op[i, j])) for j in range(int(rd.ncig[i]))] if not (f & 0x4) else []
         if kind == "flag":
@@ -24,6 +25,17 @@ def mutate(rng, rd, fatal_ok, cigar_ok=True):
             flag[i] = f ^ rng.choice([0x10, 0x20, 0x30])
         elif kind == "unmate":
             flag[i] = f | 0x8
+        elif kind == "unmap":
+            # the read did not align, its mate did (src/indelminer.c:386-424): the aligner leaves it where it was sorted, without a
+            # CIGAR, stored as sequenced; the mate learns that its mate is unmapped
+            if mates is None:
+                mates = {}
+                for j in range(rd.n): mates.setdefault(int(rd.pair_id[j]), []).append(j)
+            pair = [j for j in mates[int(rd.pair_id[i])] if j != i]
+            if len(pair) == 1 and not (f & 0x4) and not (int(flag[pair[0]]) & 0x4):
+                flag[i] = (f | 0x4) & ~0x2 & ~0x10
+                flag[pair[0]] = (int(flag[pair[0]]) | 0x8) & ~0x2
+                if rng.random() < 0.3: flag[i] = int(flag[i]) ^ 0x20
         elif kind == "isize":
             isize[i] = rng.choice([0, 1, -1, 100000, -100000, 2000000, -2000000, 701, -701, 999999, 1000000, rng.randrange(-5000, 5000)])
             if rng.random() < 0.5: flag[i] = f & ~0x2
