@@ -12,11 +12,11 @@ def mutate(rng, rd, fatal_ok, cigar_ok=True):
     import numpy as np
     ov = {}
     mates = None
-    flag = rd.flag.copy(); isize = rd.isize.copy(); mpos = rd.mpos.copy()
+    flag = rd.flag.copy(); isize = rd.isize.copy(); mpos = rd.mpos.copy(); pair_id = rd.pair_id.copy()
     for _ in range(rng.choice([0, 1, 3, 10, 30, 100])):
         i = rng.randrange(rd.n)
         o = ov.setdefault(i, {})
-        kind = rng.choice(["flag", "flag", "isize", "mtid", "eqx", "tags", "mapq", "strand", "unmate", "unmap", "unmap", "unmap"] + ((["nhp", "clip"] if cigar_ok else []) + ["base", "badtag"] if fatal_ok else []))
+        kind = rng.choice(["flag", "flag", "isize", "mtid", "eqx", "tags", "mapq", "strand", "unmate", "unmap", "unmap", "unmap", "mpos", "mpos", "dupname"] + ((["nhp", "clip"] if cigar_ok else []) + ["base", "badtag"] if fatal_ok else []))
         f = int(flag[i])
         ops = [(int(rd.cig_len[i, j]), int(rd.cig_op[i, j])) for j in range(int(rd.ncig[i]))] if not (f & 0x4) else []
         if kind == "flag":
@@ -25,6 +25,14 @@ def mutate(rng, rd, fatal_ok, cigar_ok=True):
             flag[i] = f ^ rng.choice([0x10, 0x20, 0x30])
         elif kind == "unmate":
             flag[i] = f | 0x8
+        elif kind == "mpos":
+            # the mate's claimed position: which mate of a discordant pair comes first, the anchor of an unaligned read's window
+            clen = int(rd.pos.max()) + 200
+            mpos[i] = rng.choice([0, 1, -1, clen - 150, clen - 50, clen + 500, int(rd.pos[i]), int(rd.pos[i]) + rng.randrange(-400, 400), rng.randrange(0, clen)])
+        elif kind == "dupname":
+            # two pairs with one name: the pair table and the mate look-up go by name
+            j = rng.randrange(rd.n)
+            pair_id[i] = pair_id[j]
         elif kind == "unmap":
             # the read did not align, its mate did (src/indelminer.c:386-424): the aligner leaves it where it was sorted, without a
             # CIGAR, stored as sequenced; the mate learns that its mate is unmapped
@@ -73,7 +81,7 @@ def mutate(rng, rd, fatal_ok, cigar_ok=True):
             o["packed"] = ((codes[0::2] << 4) | codes[1::2]).astype(np.uint8).tobytes()
         elif kind == "badtag":
             o["tags"] = rng.choice([b"MQf\0\0\x80\x3f", b"MQZ12\0", b"MQA5", b"RGZnope\0MQC\x3c", b"RGAx", b"RGZgen\0", b"RGZgenericx\0"])
-    rd.flag = flag; rd.isize = isize; rd.mpos = mpos
+    rd.flag = flag; rd.isize = isize; rd.mpos = mpos; rd.pair_id = pair_id
     rd.overrides = ov
 
 
