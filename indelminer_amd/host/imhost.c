@@ -16,6 +16,7 @@
  *   pass B  replay: evidence enters the pending list in arrival order; at every flush
  *           point process_evidence -> sort -> merge -> print exactly as the reference
  */
+#define _GNU_SOURCE            /* fopencookie */
 #define _POSIX_C_SOURCE 200809L
 #include "imhost.h"
 
@@ -31,6 +32,9 @@
 #include <unistd.h>
 #include <errno.h>
 #include <sys/stat.h>
+#include <sys/wait.h>
+#include <setjmp.h>
+#include <spawn.h>
 
 #define INDELMINER_VERSION 0.2          /* src/indelminer.c:26 */
 
@@ -49,11 +53,13 @@
 static im_options O;
 static time_t t0;
 
+static void out_flush_on_exit(void);
 static void fatalf(const char* fmt, ...)
 {
     /* src/errors.c:15-27: message on stderr, exit(1) */
     va_list ap;
     va_start(ap, fmt);
+    out_flush_on_exit();
     fflush(stdout);
     fprintf(stderr, "indelminer: ");
     vfprintf(stderr, fmt, ap);
@@ -69,7 +75,57 @@ static __thread FILE* t_out;
 #define printf(...) fprintf(OUT, __VA_ARGS__)
 static pthread_mutex_t g_query_mu = PTHREAD_MUTEX_INITIALIZER;     /* depth queries share the context's workspace and stream */
 
-#define forceassert(e) do { if (!(e)) { fprintf(stderr, "Assertion failed: %s file %s line %d\n", #e, __FILE__, __LINE__); exit(EXIT_FAILURE); } } while (0)
+/* Runs the reference aborts.  The device pipeline finds the record the reference would die on during the walk (or in the device
+ * stage), when only the groups in front of it have been printed; the reference has by then also printed the flushes of that
+ * group in front of the record.  Rather than unpick a half-walked group, the pipeline hands the run over: it lets the groups in
+ * front go out, counts the bytes it has printed (the main thread prints through a counting stream), and starts this program
+ * again as a child in its record-at-a-time mode, told to drop that many bytes of its output.  The child prints the rest exactly
+ * as the reference does and dies at the record with the reference's message and status; the parent exits with its status. */
+static int64_t g_out_bytes = 0;             /* parent: bytes the main thread has written to stdout */
+static int64_t g_out_skip = 0;              /* child: bytes of its output still to drop */
+static int g_real_stderr = -1;              /* child: stderr is silent until it has something new to say */
+static char** g_argv = NULL;
+static __thread int t_is_main = 0;
+static __thread jmp_buf* t_abort_jmp = NULL;    /* a walker thread's way out of a walk that met such a record */
+static ssize_t out_cookie_write(void* c, const char* buf, size_t n)
+{
+    (void)c;
+    size_t at = 0;
+    if (g_out_skip > 0) { at = (size_t)g_out_skip < n ? (size_t)g_out_skip : n; g_out_skip -= (int64_t)at; }
+    while (at < n) { const ssize_t w = write(STDOUT_FILENO, buf + at, n - at); if (w <= 0) return 0; at += (size_t)w; g_out_bytes += w; }
+    return (ssize_t)n;
+}
+static FILE* out_cookie_open(void)
+{
+    cookie_io_functions_t io = { NULL, out_cookie_write, NULL, NULL };
+    FILE* f = fopencookie(NULL, "w", io);
+    if (f) setvbuf(f, NULL, _IOFBF, 1 << 16);
+    return f;
+}
+static void out_flush_on_exit(void)
+{
+    if (t_out) fflush(t_out);
+    if (g_real_stderr >= 0) { fflush(stderr); dup2(g_real_stderr, STDERR_FILENO); g_real_stderr = -1; }
+}
+extern char** environ;
+static void handoff_to_host_child(void)
+{
+    if (t_out) fflush(t_out);
+    fflush(stdout);
+    char skip[32];
+    snprintf(skip, sizeof skip, "%lld", (long long)g_out_bytes);
+    setenv("INDELMINER_PIPELINE", "host", 1);
+    setenv("INDELMINER_SKIP_STDOUT", skip, 1);
+    pid_t pid;
+    if (getenv("INDELMINER_DEBUG_HANDOFF")) fprintf(stderr, "[handoff] %lld bytes printed, starting the child\n", (long long)g_out_bytes);
+    if (posix_spawn(&pid, "/proc/self/exe", NULL, NULL, g_argv, environ) != 0) { fprintf(stderr, "indelminer: cannot start the record-at-a-time run\n"); _exit(EXIT_FAILURE); }
+    int status = 0;
+    while (waitpid(pid, &status, 0) < 0 && errno == EINTR) { }
+    if (getenv("INDELMINER_DEBUG_HANDOFF")) fprintf(stderr, "[handoff] child status 0x%x\n", status);
+    _exit(WIFEXITED(status) ? WEXITSTATUS(status) : EXIT_FAILURE);
+}
+
+#define forceassert(e) do { if (!(e)) { out_flush_on_exit(); fprintf(stderr, "Assertion failed: %s file %s line %d\n", #e, __FILE__, __LINE__); exit(EXIT_FAILURE); } } while (0)
 
 static double now_ms(void)
 {
@@ -2028,6 +2084,9 @@ typedef struct {
 } ppipe;
 
 #define GPU(call) do { if ((call) != IM_OK) fatalf("%s: %s", #call, im_last_error(P->d->gpu)); } while (0)
+struct walkpool_s;
+static struct walkpool_s* g_handoff_pool = NULL;       /* set while run_pipeline can hand a run the reference aborts to a child */
+static void pipeline_handoff(void);
 
 static void* pdev_alloc(ppipe* P, size_t bytes) { void* p = NULL; GPU(im_dev_alloc(P->d->gpu, bytes ? bytes : 256, &p)); return p; }
 
@@ -2154,6 +2213,8 @@ static void pipe_harvest(ppipe* P, pgroup* G, pchunk* c)
             bam_record_view(c->h_raw + c->h_off[i], (int32_t)(c->h_off[i + 1] - c->h_off[i]), &b);
             if (cls[i] == IM_REC_ERR_LIMIT)
                 fatalf("read %s: more than %d indels in its CIGAR pass the end-distance rule, or the record is malformed (kernel limit IM_MAX_EV)", BAMR_QNAME(&b), IM_MAX_EV);
+            if (t_abort_jmp) { free(cls); longjmp(*t_abort_jmp, 1); }      /* the main thread hands the run over when it gets to this group */
+            if (g_handoff_pool && t_is_main) pipeline_handoff();            /* annotate mode: the walk is on the main thread */
             dispatch_record(P->d, &b);
             fatalf("read %s: record rejected by the device triage (class %d)", BAMR_QNAME(&b), (int)cls[i]);
         }
@@ -2567,6 +2628,7 @@ static void pipe_run_group(ppipe* P, pgroup* G)
     memset(G->ev_cache, 0, sizeof(evidence_t*) * (size_t)(nc ? nc : 1) * IM_MAX_EV);
     for (int32_t i = 0; i < nc; i++) {
         const int st = G->res[i].status;
+        if (st == IM_ST_ABORT && g_handoff_pool) pipeline_handoff();
         if (st == IM_ST_ABORT) fatalf("im_dev_realign: read %d: the reference would abort on this input", i);
         if (st == IM_ST_OVERFLOW) fatalf("im_dev_realign: read %d: segment list longer than IM_MAX_OPS", i);
         if (st == IM_ST_UNSUPPORTED) fatalf("im_dev_realign: read %d: longer than IM_MAX_READ=%d", i, IM_MAX_READ);
@@ -3139,6 +3201,7 @@ static void mg_finish(mgpu* m, driver* d)
  * walker holds two groups' worth of host state, so it walks its next claim while its previous one is replayed.  Order of
  * output is the order of the contigs. */
 struct walkpool_s;
+typedef struct claim_s claim_t;
 typedef struct {
     struct walkpool_s* pool;
     driver wd;                          /* private: pair table, read-group cache */
@@ -3146,10 +3209,11 @@ typedef struct {
     bgzf_reader* r; bam_header* hdr;
     pgroup G[2];
     int n_started, device_free, replayed;
+    claim_t* cur_claim; jmp_buf abort_jmp;  /* the claim being walked; where a walk that met a record the reference dies on ends up */
     pthread_t th;
 } walker_t;
 
-typedef struct { int first, count; walker_t* W; pgroup* G; int walked; } claim_t;
+struct claim_s { int first, count; walker_t* W; pgroup* G; int walked, aborted; };
 
 /* a group whose device stage is done, on its way through a replay worker: what it prints waits in buf until every group
  * before it has been printed */
@@ -3163,6 +3227,7 @@ typedef struct walkpool_s {
     walker_t* w; int nw;
     int serial, go;
     rjob_t* jobs; int n_jobs, next_job, jobs_closed;    /* replay queue, in contig order */
+    int printed;                                        /* jobs whose output has been written */
     pthread_mutex_t mu; pthread_cond_t cv;
 } walkpool_t;
 
@@ -3293,6 +3358,18 @@ static void* walker_thread(void* arg)
         if (ci < 0) break;
         claim_t* c = &o->claims[ci];
         pgroup* G = g_onepass ? xcalloc(1, sizeof(pgroup)) : &W->G[W->n_started & 1];      /* one-pass: the group outlives the walk */
+        if (g_handoff_pool && !g_onepass) {
+            /* a record the reference dies on ends this walker: the claim is published as it is, marked */
+            W->cur_claim = c;
+            if (setjmp(W->abort_jmp)) {
+                pthread_mutex_lock(&o->mu);
+                W->cur_claim->W = W; W->cur_claim->G = NULL; W->cur_claim->aborted = 1; W->cur_claim->walked = 1;
+                pthread_cond_broadcast(&o->cv);
+                pthread_mutex_unlock(&o->mu);
+                return NULL;
+            }
+            t_abort_jmp = &W->abort_jmp;
+        }
         for (int k = 0; k < c->count; k++) pipe_walk_contig(&W->P, G, o->order[c->first + k], W->r);
         pipe_submit(&W->P, G);
         pipe_drain(&W->P, G);
@@ -3396,6 +3473,11 @@ static void run_pipeline(driver* d, walkpool_t* o)
 {
     d->pipe_mode = 1;
     g_verify_triage = getenv("INDELMINER_VERIFY_TRIAGE") != NULL;
+    if (!g_mg && !getenv("INDELMINER_NO_HANDOFF")) {
+        /* from here on this thread prints through the counting stream (see handoff_to_host_child) */
+        t_out = out_cookie_open();
+        if (t_out) g_handoff_pool = o;
+    }
     gpu_wait(d);                    /* the reference is on the device */
     pipe_global_init(d);
     if (o->serial) { walker_setup(&o->w[0], d); walker_adopt_driver(&o->w[0], d); }
@@ -3457,7 +3539,7 @@ static void run_pipeline(driver* d, walkpool_t* o)
         rp[i].pool = o; rp[i].rd = *d; rp[i].rd.gpu_pending = 0;
         if (pthread_create(&rp[i].th, NULL, replay_thread, &rp[i]) != 0) fatalf("cannot start a replay thread");
     }
-    int printed = 0;
+    o->printed = 0;
     int64_t numread = d->numread;
     int floor_ = d->marker_floor;
     for (int ci = 0; ci < o->n_claims; ci++) {
@@ -3478,6 +3560,7 @@ static void run_pipeline(driver* d, walkpool_t* o)
             pthread_mutex_lock(&o->mu);
             while (!c->walked) pthread_cond_wait(&o->cv, &o->mu);
             pthread_mutex_unlock(&o->mu);
+            if (c->aborted) pipeline_handoff();
         }
         phase_time("waited for the walk (inflate + count + pair table; triage on the device)");
         walker_t* W = c->W;
@@ -3498,10 +3581,10 @@ static void run_pipeline(driver* d, walkpool_t* o)
             o->n_jobs++;
             pthread_cond_broadcast(&o->cv);
             /* whatever is complete at the head of the queue goes out now */
-            while (printed < o->n_jobs && o->jobs[printed].done) {
-                rjob_t* P = &o->jobs[printed++];
+            while (o->printed < o->n_jobs && o->jobs[o->printed].done) {
+                rjob_t* P = &o->jobs[o->printed++];
                 pthread_mutex_unlock(&o->mu);
-                if (P->len && fwrite(P->buf, 1, P->len, stdout) != P->len) fatalf("write to stdout failed");
+                if (P->len && fwrite(P->buf, 1, P->len, OUT) != P->len) fatalf("write to stdout failed");
                 free(P->buf);
                 pthread_mutex_lock(&o->mu);
             }
@@ -3517,21 +3600,23 @@ static void run_pipeline(driver* d, walkpool_t* o)
         pthread_mutex_lock(&o->mu);
         o->jobs_closed = 1;
         pthread_cond_broadcast(&o->cv);
-        while (printed < o->n_jobs) {
-            while (!o->jobs[printed].done) pthread_cond_wait(&o->cv, &o->mu);
-            rjob_t* P = &o->jobs[printed++];
+        while (o->printed < o->n_jobs) {
+            while (!o->jobs[o->printed].done) pthread_cond_wait(&o->cv, &o->mu);
+            rjob_t* P = &o->jobs[o->printed++];
             pthread_mutex_unlock(&o->mu);
-            if (P->len && fwrite(P->buf, 1, P->len, stdout) != P->len) fatalf("write to stdout failed");
+            if (P->len && fwrite(P->buf, 1, P->len, OUT) != P->len) fatalf("write to stdout failed");
             free(P->buf);
             pthread_mutex_lock(&o->mu);
         }
         pthread_mutex_unlock(&o->mu);
         for (int i = 0; i < nrep; i++) pthread_join(rp[i].th, NULL);
+        fflush(OUT);
         fflush(stdout);
         phase_time("replay workers drained");
         free(rp); free(o->jobs);
     }
     d->numread = numread;
+    if (g_handoff_pool) { g_handoff_pool = NULL; fflush(t_out); fclose(t_out); t_out = NULL; }
     for (int i = 0; i < o->nw && !o->serial && !g_onepass; i++) pthread_join(o->w[i].th, NULL);
     /* the walkers' pinned rings and device arrays go with the process unless a tidy exit is asked for (leak checkers):
      * un-pinning and freeing them costs more than the whole device stage of a run */
@@ -3549,6 +3634,24 @@ static void run_pipeline(driver* d, walkpool_t* o)
         free(o->w); free(o->claims); free(o->order);
         free(o);
     }
+}
+
+/* main thread, at the first group the reference does not survive: the groups in front go out, then the child takes over */
+static void pipeline_handoff(void)
+{
+    walkpool_t* o = g_handoff_pool;
+    if (o->jobs) {
+        pthread_mutex_lock(&o->mu);
+        while (o->printed < o->n_jobs) {
+            while (!o->jobs[o->printed].done) pthread_cond_wait(&o->cv, &o->mu);
+            rjob_t* P = &o->jobs[o->printed++];
+            pthread_mutex_unlock(&o->mu);
+            if (P->len && fwrite(P->buf, 1, P->len, OUT) != P->len) fatalf("write to stdout failed");
+            pthread_mutex_lock(&o->mu);
+        }
+        pthread_mutex_unlock(&o->mu);
+    }
+    handoff_to_host_child();
 }
 
 /* -------------------------------------------------------------------- main -- */
@@ -3651,6 +3754,23 @@ static void check_known_variants(const char* vcfname)
 
 int main(int argc, char** argv)
 {
+    t_is_main = 1;
+    g_argv = xcalloc((size_t)argc + 1, sizeof(char*));          /* as given: the parsing below cuts the sample argument in two */
+    for (int i = 0; i < argc; i++) g_argv[i] = xstrdup(argv[i]);
+    {
+        /* the record-at-a-time child of a pipeline run the reference aborts: its first bytes are on stdout already, and so is
+         * everything it has to say on stderr until something goes wrong */
+        const char* sk = getenv("INDELMINER_SKIP_STDOUT");
+        if (sk) {
+            g_out_skip = atoll(sk);
+            unsetenv("INDELMINER_SKIP_STDOUT");
+            t_out = out_cookie_open();
+            if (!getenv("INDELMINER_DEBUG_HANDOFF")) {
+                g_real_stderr = dup(STDERR_FILENO);
+                if (!freopen("/dev/null", "w", stderr)) { }
+            }
+        }
+    }
     O.maxdelsize = 1000; O.maxpedelsize = 1000000; O.minsupport = 2; O.klength = 6; O.numgaps = 0;
     O.outputformat = "vcf"; O.qthreshold = 10; O.ethreshold = 10; O.ethreshold_vcfcheck = 10;
     O.call_all_indels = 0; O.maxdiffsallowed = 6; O.minbalance = 30;
@@ -3835,6 +3955,7 @@ int main(int argc, char** argv)
     }
 
     gpu_wait(&d);
+    if (t_out) fflush(t_out);
     if (!getenv("INDELMINER_TIDY_EXIT")) {
         /* everything is printed: the GPU context, the pinned rings and the device arrays go with the process -- tearing the
          * HIP runtime down in order costs about as long as the whole device work of a small run (leak checkers: INDELMINER_TIDY_EXIT=1) */

@@ -35,12 +35,11 @@ def one(seed):
             # exits with status 1 and a message there
             outs[0] = (1,) + outs[0][1:]
         same = all((o[0], o[1]) == (outs[0][0], outs[0][1]) for o in outs[1:])
-        # A run the reference aborts: same exit status everywhere.  Its stdout up to there (the header, the variants of the flushes
-        # in front of the fatal record) is what the record-at-a-time mode prints too; the device pipeline finds the record during the
-        # walk, before any flush is replayed, and has printed the header only.  A reference that died of a
-        # signal lost its buffered stdout.
+        # A run the reference aborts: same exit status, and the same stdout in front of the abort (the header, the variants of the
+        # flushes in front of the fatal record) in every mode -- the device pipeline hands such a run over to a record-at-a-time
+        # child.  A reference that died of a signal lost its buffered stdout.
         if not same and outs[0][0] != 0:
-            same = all(o[0] == outs[0][0] for o in outs[1:]) and (signalled or outs[2][1] == outs[0][1])
+            same = all(o[0] == outs[0][0] for o in outs[1:]) and (signalled or all(o[1] == outs[0][1] for o in outs[1:]))
         if same and outs[0][0] == 0 and "-c" not in args and rng.random() < 0.4:
             # the multi-GPU mode of the CLI (one process per rank, contigs tid % world, one exchange of summaries), ranks as plain
             # processes on the shim: rank 0's stdout must be the single-process VCF

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Writes tests/golden/odd_inputs.json: for a fixed list of seeds of tests/golden/odd_inputs.py, what the COMPILED REFERENCE
-(oracle/_ref/indelminer, built from /root/reference by oracle/Makefile) does with the input -- exit status, and the md5 of its
-stdout where it completes.  Run in the build container; the -m gpu test regenerates the inputs from the seeds on the GPU box
+(oracle/_ref/indelminer, built from /root/reference by oracle/Makefile) does with the input -- exit status and the md5 of its
+stdout (also of what it printed in front of an abort; not where it died of a signal, its buffered output is lost then).  Run in the build container; the -m gpu test regenerates the inputs from the seeds on the GPU box
 and holds the product (real kernels) to these results.
     python tests/golden/make_golden_odd.py"""
 import hashlib, json, os, shutil, subprocess, sys, tempfile
@@ -20,7 +20,7 @@ for seed in SEEDS:
         r = subprocess.run([REF] + cmd, cwd=d, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900)
         err = r.stderr.decode(errors="replace").strip().splitlines()
         out[str(seed)] = {"cmd": cmd, "rc": r.returncode if r.returncode >= 0 else 1, "signal": r.returncode < 0,
-                          "md5": hashlib.md5(r.stdout).hexdigest() if r.returncode == 0 else None, "bytes": len(r.stdout),
+                          "md5": hashlib.md5(r.stdout).hexdigest() if r.returncode >= 0 else None, "bytes": len(r.stdout),
                           "last_stderr_line": err[-1][:80] if r.returncode != 0 and err else ""}
         print(seed, out[str(seed)]["rc"], out[str(seed)]["bytes"], " ".join(cmd), flush=True)
     finally:

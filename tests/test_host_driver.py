@@ -556,9 +556,9 @@ def _odd_inputs(binary, tmp_path, envs, seeds=None):
         for env in envs:
             r = subprocess.run([binary] + cmd, cwd=d, stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=dict(os.environ, **env))
             assert r.returncode == w["rc"], (seed, env, r.returncode, r.stderr.decode(errors="replace")[-400:])
-            if w["rc"] == 0:
-                assert hashlib.md5(r.stdout).hexdigest() == w["md5"], (seed, env, len(r.stdout), w["bytes"])
-                n_ok += 1
+            if w["md5"] is not None:        # also what the reference printed in front of an abort (not where a signal took its buffer)
+                assert hashlib.md5(r.stdout).hexdigest() == w["md5"], (seed, env, len(r.stdout), w["bytes"], r.stderr.decode(errors="replace")[-300:])
+            n_ok += w["rc"] == 0
         shutil.rmtree(d)
     return n_ok
 
