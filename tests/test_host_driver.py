@@ -294,6 +294,52 @@ def test_host_iupac_base_in_a_plain_proper_pair_exits_like_the_reference(tmp_pat
     assert all(o == outs[0] for o in outs)
 
 
+def _abort_in_a_later_group(binary, tmp_path):
+    """a base code the reference refuses, in a plain proper pair of the THIRD contig, every contig a claim of its own and three
+    walkers: the groups in front go out, then the run is handed to a record-at-a-time child that drops the bytes already printed
+    (DESIGN.md section 4b).  Same stdout, exit status and message as the record-at-a-time run and as the reference."""
+    import numpy as np
+    from indelminer_amd import bamwrite, synth
+    refs, rd = synth.simulate(seed=9, ref_len=40_000, coverage=12, n_contigs=4, big_every=5)
+    idx = [i for i in range(rd.n) if rd.tid[i] == 2 and (rd.flag[i] & 0x3) == 0x3 and rd.ncig[i] == 1]
+    idx = idx[len(idx) // 2]
+    rd.seq = rd.seq.copy()
+    rd.seq[idx, 10] = ord("M")
+    contigs = [("ctg%d" % i, len(r)) for i, r in enumerate(refs)]
+    bamwrite.write_fasta(str(tmp_path / "ref.fa"), contigs, refs)
+    code = bamwrite._SEQ_CODE.copy()
+    try:
+        bamwrite._SEQ_CODE[ord("M")] = 3
+        bamwrite.write_bam(str(tmp_path / "aln.bam"), contigs, rd)
+    finally:
+        bamwrite._SEQ_CODE[:] = code
+    (tmp_path / "cfg.txt").write_text("IL generic 300 700\n")
+    shim = binary
+    runs = [(shim, {"INDELMINER_PIPELINE": "host"}), (shim, {"INDELMINER_CLAIM_BASES": "1", "INDELMINER_WALKERS": "3"}),
+            (shim, {"INDELMINER_CLAIM_BASES": "1", "INDELMINER_WALKERS": "2", "INDELMINER_REPLAYERS": "1"}), (shim, {})]
+    ref_bin = os.path.join(ROOT, "oracle", "_ref", "indelminer")
+    if os.path.exists(ref_bin):
+        runs.append((ref_bin, {}))
+    outs = []
+    for b, env in runs:
+        r = subprocess.run([b, "-i", "cfg.txt", "ref.fa", "s=aln.bam"], cwd=str(tmp_path), stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                           env=dict(os.environ, **env))
+        outs.append((r.returncode, r.stdout, r.stderr.decode().strip().splitlines()[-1]))
+    assert outs[0][0] == 1 and outs[0][2] == "indelminer: Unhandled base encoding : 3:3"
+    body = [l for l in outs[0][1].splitlines() if not l.startswith(b"#")]
+    assert len(body) > 20 and {l.split(b"\t")[0] for l in body} >= {b"ctg0", b"ctg1"}      # two whole contigs and a part of the third
+    assert all(o == outs[0] for o in outs)
+
+
+def test_host_abort_in_a_later_group_prints_what_the_reference_has_printed(tmp_path):
+    _abort_in_a_later_group(_build_shim(), tmp_path)
+
+
+@pytest.mark.gpu
+def test_product_abort_in_a_later_group_prints_what_the_reference_has_printed(tmp_path):
+    _abort_in_a_later_group(_product(), tmp_path)
+
+
 def test_host_contigs_without_reads(tmp_path):
     """contigs that deliver no record at all -- the first, one in the middle, the last -- between contigs that do: claims,
     groups and flush placement must not mind (the read counter and the marker floor simply pass through them)"""
