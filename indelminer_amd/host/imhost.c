@@ -54,10 +54,12 @@ static im_options O;
 static time_t t0;
 
 static void out_flush_on_exit(void);
+static void walker_bails_out(void);
 static void fatalf(const char* fmt, ...)
 {
     /* src/errors.c:15-27: message on stderr, exit(1) */
     va_list ap;
+    walker_bails_out();         /* a walker thread of the pipeline does not come back from this (see handoff_to_host_child) */
     va_start(ap, fmt);
     out_flush_on_exit();
     fflush(stdout);
@@ -102,6 +104,13 @@ static FILE* out_cookie_open(void)
     if (f) setvbuf(f, NULL, _IOFBF, 1 << 16);
     return f;
 }
+/* Whatever ends the run inside a walker's walk -- the triage's error classes at harvest, the host's own checks on discordant
+ * mates and read groups as the records go by -- may not be the FIRST thing the reference dies of (errors are found chunk by
+ * chunk, contigs in parallel): the walker leaves the walk, and the record-at-a-time child finds the first in record order. */
+static void walker_bails_out(void)
+{
+    if (t_abort_jmp) { jmp_buf* j = t_abort_jmp; t_abort_jmp = NULL; longjmp(*j, 1); }
+}
 static void out_flush_on_exit(void)
 {
     if (t_out) fflush(t_out);
@@ -125,7 +134,7 @@ static void handoff_to_host_child(void)
     _exit(WIFEXITED(status) ? WEXITSTATUS(status) : EXIT_FAILURE);
 }
 
-#define forceassert(e) do { if (!(e)) { out_flush_on_exit(); fprintf(stderr, "Assertion failed: %s file %s line %d\n", #e, __FILE__, __LINE__); exit(EXIT_FAILURE); } } while (0)
+#define forceassert(e) do { if (!(e)) { walker_bails_out(); out_flush_on_exit(); fprintf(stderr, "Assertion failed: %s file %s line %d\n", #e, __FILE__, __LINE__); exit(EXIT_FAILURE); } } while (0)
 
 static double now_ms(void)
 {
@@ -2213,7 +2222,7 @@ static void pipe_harvest(ppipe* P, pgroup* G, pchunk* c)
             bam_record_view(c->h_raw + c->h_off[i], (int32_t)(c->h_off[i + 1] - c->h_off[i]), &b);
             if (cls[i] == IM_REC_ERR_LIMIT)
                 fatalf("read %s: more than %d indels in its CIGAR pass the end-distance rule, or the record is malformed (kernel limit IM_MAX_EV)", BAMR_QNAME(&b), IM_MAX_EV);
-            if (t_abort_jmp) { free(cls); longjmp(*t_abort_jmp, 1); }      /* the main thread hands the run over when it gets to this group */
+            if (t_abort_jmp) { free(cls); walker_bails_out(); }            /* the main thread hands the run over when it gets to this group */
             if (g_handoff_pool && t_is_main) pipeline_handoff();            /* annotate mode: the walk is on the main thread */
             dispatch_record(P->d, &b);
             fatalf("read %s: record rejected by the device triage (class %d)", BAMR_QNAME(&b), (int)cls[i]);
@@ -3373,6 +3382,7 @@ static void* walker_thread(void* arg)
         for (int k = 0; k < c->count; k++) pipe_walk_contig(&W->P, G, o->order[c->first + k], W->r);
         pipe_submit(&W->P, G);
         pipe_drain(&W->P, G);
+        t_abort_jmp = NULL;
         if (g_onepass) group_park_device(&W->P, G);
         pthread_mutex_lock(&o->mu);
         c->W = W; c->G = G; c->walked = 1; G->in_use = 1; if (!g_onepass) W->n_started++;
