@@ -21,7 +21,8 @@ def one(seed):
         rng, refs, contigs, nct, args = info["rng"], info["refs"], info["contigs"], info["nct"], info["args"]
         outs = []
         shim = os.environ.get("RDF_SHIM") or _build_shim()      # RDF_SHIM: a sanitizer build of the same sources
-        for b, env in ((REF, {}), (shim, {}), (shim, {"INDELMINER_PIPELINE": "host"}), (shim, {"INDELMINER_WALKERS": "1", "INDELMINER_REPLAYERS": "1"})):
+        for b, env in ((REF, {}), (shim, {}), (shim, {"INDELMINER_PIPELINE": "host"}), (shim, {"INDELMINER_WALKERS": "1", "INDELMINER_REPLAYERS": "1"} if seed & 1 else
+                             {"INDELMINER_CLAIM_BASES": "1", "INDELMINER_WALKERS": "3", "INDELMINER_REPLAYERS": "2"})):     # every contig a group of its own
             try:
                 r = subprocess.run([b] + cmd, cwd=d, stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=dict(os.environ, **env), timeout=600)
                 err = r.stderr.decode(errors="replace").strip().splitlines()
