@@ -107,9 +107,12 @@ static FILE* out_cookie_open(void)
 /* Whatever ends the run inside a walker's walk -- the triage's error classes at harvest, the host's own checks on discordant
  * mates and read groups as the records go by -- may not be the FIRST thing the reference dies of (errors are found chunk by
  * chunk, contigs in parallel): the walker leaves the walk, and the record-at-a-time child finds the first in record order. */
+static int g_main_in_walk = 0;              /* annotate mode walks on the main thread: the same, without the jump */
+static void pipeline_handoff(void);
 static void walker_bails_out(void)
 {
     if (t_abort_jmp) { jmp_buf* j = t_abort_jmp; t_abort_jmp = NULL; longjmp(*j, 1); }
+    if (t_is_main && g_main_in_walk) { g_main_in_walk = 0; pipeline_handoff(); }
 }
 static void out_flush_on_exit(void)
 {
@@ -2222,8 +2225,7 @@ static void pipe_harvest(ppipe* P, pgroup* G, pchunk* c)
             bam_record_view(c->h_raw + c->h_off[i], (int32_t)(c->h_off[i + 1] - c->h_off[i]), &b);
             if (cls[i] == IM_REC_ERR_LIMIT)
                 fatalf("read %s: more than %d indels in its CIGAR pass the end-distance rule, or the record is malformed (kernel limit IM_MAX_EV)", BAMR_QNAME(&b), IM_MAX_EV);
-            if (t_abort_jmp) { free(cls); walker_bails_out(); }            /* the main thread hands the run over when it gets to this group */
-            if (g_handoff_pool && t_is_main) pipeline_handoff();            /* annotate mode: the walk is on the main thread */
+            if (t_abort_jmp || g_main_in_walk) { free(cls); walker_bails_out(); }     /* the main thread hands the run over when it gets to this group */
             dispatch_record(P->d, &b);
             fatalf("read %s: record rejected by the device triage (class %d)", BAMR_QNAME(&b), (int)cls[i]);
         }
@@ -3562,9 +3564,11 @@ static void run_pipeline(driver* d, walkpool_t* o)
             if (g_known.n == 0) continue;           /* src/indelminer.c:788 */
             walker_t* W = &o->w[0];
             pgroup* G = &W->G[0];
+            g_main_in_walk = g_handoff_pool != NULL;
             pipe_walk_contig(&W->P, G, tid, W->r);
             pipe_submit(&W->P, G);
             pipe_drain(&W->P, G);
+            g_main_in_walk = 0;
             c->W = W; c->G = G; c->walked = 1;
         } else {
             pthread_mutex_lock(&o->mu);
