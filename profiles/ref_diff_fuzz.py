@@ -64,7 +64,7 @@ def one(seed):
             open(os.path.join(d, "calls.vcf"), "wb").write(r0.stdout)
             refs2, rd2 = synth.simulate(seed=seed, ref_len=len(refs[0]), coverage=rng.choice([6, 12]), n_contigs=nct, read_seed=seed + 31,
                                         big_every=0, indel_spacing=rng.choice([700, 2000]), somatic_spacing=0)
-            mutate(rng, rd2, False)
+            mutate(rng, rd2, rng.random() < 0.3)        # some second samples with records the reference dies on
             bamwrite.write_bam(os.path.join(d, "other.bam"), contigs, rd2)
             acmd = [a for a in args if a != "-c" and a != "ctg0"] + ["ref.fa", "calls.vcf", "other=other.bam"]
             aouts = []
