@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define IM_ABI_VERSION 1
+#define IM_ABI_VERSION 2
 
 /* ---- return codes ------------------------------------------------------ */
 #define IM_OK             0
@@ -385,11 +385,44 @@ int im_dev_flush_cut_rec(im_ctx* ctx, const int32_t* cls, const int32_t* b1, con
  * ranges (no mid-contig flush ever consumes anything) use im_dev_flush_cut_rec per flush instead.
  * cls, b1, b2 and consumed are read a candidate (IM_MAX_EV slots = 16 bytes) at a time: their bases must be 16-byte aligned
  * (any im_dev_alloc / hipMalloc pointer is). */
-typedef struct im_flush_desc { int32_t rec0, rec1, pe0, pe1, marker, id; } im_flush_desc;
+typedef struct im_flush_desc {
+    int32_t rec0, rec1, pe0, pe1, marker, id;
+    int32_t last;               /* index (in the list) of the LAST flush of the same contig; read by im_dev_flush_groupby only */
+    int32_t reserved;
+} im_flush_desc;
 int im_dev_flush_cuts(im_ctx* ctx, const im_flush_desc* desc_dev, int32_t n_flushes,
                       const int32_t* cls, const int32_t* b1, const int32_t* b2, int32_t* consumed,
                       const int32_t* cand_rec, const int32_t* n_cand_dev, int32_t cand_cap,
                       int32_t pe_base, int32_t pe_count /* their marks are cleared first */, void* stream);
+
+/* The flush list AND the split-read group-by of a group of contigs in three chip-wide launches (the product's device
+ * stage; im_dev_flush_cuts + im_dev_cluster_groupby are the sequential form of the same thing).
+ *
+ * Why no history is needed: find_marker (src/indelminer.c:211-233) is a minimum over the pair table, whose entries only
+ * leave it or enter it at the current read position of a coordinate-sorted walk, and the marker of a flush is
+ * min(that, current position) (622-623) -- so WITHIN A CONTIG THE MARKERS NEVER DECREASE (the end-of-contig flush has
+ * INT_MAX, 806).  An entry a flush f' consumed sorted in front of f' s cutting entry, hence had b2 < marker(f') <=
+ * marker(f) for every later flush f of the contig: it could not be f's cutting entry even if it were still pending.
+ * So the cut of flush f is simply  cut(f) = min{ (b1,b2) of e : e arrived before f's bounds, b2(e) >= marker(f) }  over
+ * ALL entries of the contig, and  consumed(e) = the first flush f at or after e's arrival with (b1,b2)(e) < cut(f).
+ * Launch 1 gives every entry's key to the cuts of the (contiguous, usually empty) run of flushes it is a candidate
+ * for; launch 2 marks every entry and enters the consumed split-read slots into the cluster table; launch 3 writes
+ * each cluster's record and its members in arrival order.
+ *
+ * THE CALLER GUARANTEES: desc[] lists the flushes in file order, rec1 and pe1 never decrease along the list, the flushes
+ * of one contig are consecutive, carry the index of the contig's last flush in `last`, and their markers never
+ * decrease (true for every coordinate-sorted BAM; a caller that finds otherwise uses im_dev_flush_cuts).  Entries
+ * that no flush of their contig consumes keep consumed = 0.  Outputs as im_dev_cluster_groupby; counts must be 8-byte
+ * aligned; the slot arrays 16-byte aligned.  The scratch is prepared once (im_dev_flushgroup_scratch_init) for a slot
+ * and a flush capacity and every call leaves it ready for the next one. */
+size_t im_dev_flushgroup_scratch_bytes(int32_t n_slots_cap, int32_t n_flushes_cap);
+int im_dev_flushgroup_scratch_init(im_ctx* ctx, int32_t n_slots_cap, int32_t n_flushes_cap, void* scratch, size_t scratch_bytes, void* stream);
+int im_dev_flush_groupby(im_ctx* ctx, const im_flush_desc* desc_dev, int32_t n_flushes,
+                         const int32_t* cls, const int32_t* b1, const int32_t* b2, int32_t* consumed,
+                         const int32_t* cand_rec, const int32_t* n_cand_dev, int32_t cand_cap /* also the launch bound */,
+                         int32_t pe_base, int32_t pe_count, int32_t tie_desc,
+                         int32_t* order, int32_t* cl_key, int32_t* cl_first, int32_t* cl_count, int32_t* counts,
+                         void* scratch, size_t scratch_bytes, void* stream);
 
 /* The split-read rule of add_node (src/graph.c:122-127) over every consumed slot of [0, n_slots):
  * one cluster per distinct (consumed flush, class, b1, b2).  Output: cl_key[4 * c] = {flush_id, cls, b1,

@@ -184,6 +184,12 @@ def lib():
                                            C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]
         L.im_dev_flush_cuts.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                         C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]
+        L.im_dev_flushgroup_scratch_bytes.restype = C.c_size_t
+        L.im_dev_flushgroup_scratch_bytes.argtypes = [C.c_int32, C.c_int32]
+        L.im_dev_flushgroup_scratch_init.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_size_t, C.c_void_p]
+        L.im_dev_flush_groupby.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                           C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
+                                           C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
         L.im_dev_triage_scratch_init.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_size_t, C.c_void_p]
         L.im_dev_groupby_scratch_init.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_size_t, C.c_void_p]
         L.im_dev_cluster_groupby_n.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32,
@@ -495,6 +501,10 @@ class Pipeline:
         self.gs_bytes = L.im_dev_groupby_scratch_bytes(self.n_slots)
         self.d_gs = DevBuf(ctx, self.gs_bytes)
         ctx._check(L.im_dev_groupby_scratch_init(ctx.h, self.n_slots, self.d_gs.ptr, self.gs_bytes, ctx.stream))
+        # the chip-wide form (im_dev_flush_groupby): its own table + the range-minimum tree over the flush list
+        self.fg_bytes = L.im_dev_flushgroup_scratch_bytes(self.cap_cand * MAX_EV, max(n_flushes, 1))
+        self.d_fg = DevBuf(ctx, self.fg_bytes)
+        ctx._check(L.im_dev_flushgroup_scratch_init(ctx.h, self.cap_cand * MAX_EV, max(n_flushes, 1), self.d_fg.ptr, self.fg_bytes, ctx.stream))
         ctx._check(L.im_stream_sync(ctx.h, ctx.stream))
         self.batch = DevBatch(0, self.d_bases.ptr, self.d_boff.ptr, self.d_len.ptr, self.d_tid.ptr, self.d_anchor.ptr,
                               self.d_range.ptr, self.d_res.ptr, self.d_cls.ptr, self.d_b1.ptr, self.d_b2.ptr)
@@ -560,9 +570,37 @@ class Pipeline:
                                                      self.d_counts.ptr, self.d_gs.ptr, self.gs_bytes, st))
 
     # ---- the same three stages without a host round trip: the candidate count stays on the device ----
-    def bind_async(self, flushes, stream, tie_desc=0, grid_bound=None, one_launch_flushes=True, depth_tid=None):
+    @staticmethod
+    def flush_descs(flushes):
+        """im_flush_desc[] for [(rec0, rec1, pe_hi, marker)]: a change of rec0 opens a new contig; `last` = the contig's last flush"""
+        n = len(flushes)
+        desc = np.zeros((max(n, 1), 8), dtype=np.int32)
+        for k, (rec0, rec1, pe_hi, marker) in enumerate(flushes):
+            desc[k, :6] = (rec0, rec1, 0, pe_hi, marker, k + 1)
+        k = 0
+        while k < n:
+            e = k
+            while e + 1 < n and flushes[e + 1][0] == flushes[k][0]:
+                e += 1
+            desc[k:e + 1, 6] = e
+            k = e + 1
+        return desc[:n] if n else desc[:0]
+
+    def flush_groupby(self, flushes, tie_desc=0, stream=None, cand_bound=None):
+        """the flush list and the group-by chip-wide (im_dev_flush_groupby): three launches, no history"""
+        st = self.ctx.stream if stream is None else stream
+        desc = self.flush_descs(flushes)
+        self.d_desc = DevBuf(self.ctx, max(desc.nbytes, 32)).upload(desc)
+        self.ctx._check(lib().im_dev_flush_groupby(
+            self.ctx.h, self.d_desc.ptr, len(flushes), self.d_cls.ptr, self.d_b1.ptr, self.d_b2.ptr, self.d_consumed.ptr,
+            self.d_cand_rec.ptr, self.d_counters.ptr, self.cap_cand if cand_bound is None else cand_bound, self.cap_cand * MAX_EV, self.n_pe, tie_desc,
+            self.d_order.ptr, self.d_clkey.ptr, self.d_clfirst.ptr, self.d_clcount.ptr, self.d_counts.ptr, self.d_fg.ptr, self.fg_bytes, st))
+
+    def bind_async(self, flushes, stream, tie_desc=0, grid_bound=None, one_launch_flushes=True, depth_tid=None, wide=False):
         """pre-binds one whole pass (triage -> realign -> flush cuts -> group-by) on `stream`; flushes =
-        [(rec0, rec1, pe_hi, marker)] with record bounds.  Returns a list of (fn, args) to call in order."""
+        [(rec0, rec1, pe_hi, marker)] with record bounds.  Returns a list of (fn, args) to call in order.
+        wide: the flush list + group-by as im_dev_flush_groupby (three chip-wide launches) instead of the
+        one-workgroup flush list + the four group-by launches."""
         L = lib()
         h = self.ctx.h
         base = self.cap_cand * MAX_EV
@@ -573,19 +611,27 @@ class Pipeline:
         calls = []
         if depth_tid is not None:           # the contig goes through triage again: its run of the depth array starts from zeros
             calls.append((L.im_depth_reset, (h, depth_tid, stream)))
-        if not one_launch_flushes:
+        if not one_launch_flushes and not wide:
             calls += [(L.im_dev_memset, (h, self.d_consumed.ptr, 0, 4 * self.n_slots, stream)),
                       (L.im_dev_memset, (h, self.d_cut.ptr, 0xFF, 8 * self.n_flushes, stream))]
-        calls += [(L.im_dev_triage, (h, C.byref(self.tp_restart), C.byref(self.recs), C.byref(self.cands_clear if one_launch_flushes else self.cands),
+        calls += [(L.im_dev_triage, (h, C.byref(self.tp_restart), C.byref(self.recs), C.byref(self.cands_clear if (one_launch_flushes and not wide) else self.cands),
                                      self.d_ts.ptr, self.ts_bytes, stream)),
                   (L.im_dev_realign_n, (h, C.byref(self.P), C.byref(self.batch_bound), self.d_counters.ptr, 1, stream))]
         self.realign_call_index = len(calls) - 1
         self.triage_call_index = len(calls) - 2
         if depth_tid is not None:           # the contig's records are all in: difference array -> depths (DP= queries of the replay)
             calls.append((L.im_depth_scan, (h, depth_tid, stream)))
+        if wide:
+            desc = self.flush_descs(flushes)
+            self.d_desc = DevBuf(self.ctx, max(desc.nbytes, 32)).upload(desc)
+            calls.append((L.im_dev_flush_groupby, (h, self.d_desc.ptr, len(flushes), self.d_cls.ptr, self.d_b1.ptr, self.d_b2.ptr, self.d_consumed.ptr,
+                                                   self.d_cand_rec.ptr, self.d_counters.ptr, self.batch_bound.n, base, self.n_pe, tie_desc,
+                                                   self.d_order.ptr, self.d_clkey.ptr, self.d_clfirst.ptr, self.d_clcount.ptr, self.d_counts.ptr,
+                                                   self.d_fg.ptr, self.fg_bytes, stream)))
+            return calls
         if one_launch_flushes:
-            desc = np.array([(rec0, rec1, 0, pe_hi, marker, k + 1) for k, (rec0, rec1, pe_hi, marker) in enumerate(flushes)], dtype=np.int32)
-            self.d_desc = DevBuf(self.ctx, max(desc.nbytes, 24)).upload(desc)
+            desc = self.flush_descs(flushes)
+            self.d_desc = DevBuf(self.ctx, max(desc.nbytes, 32)).upload(desc)
             calls.append((L.im_dev_flush_cuts, (h, self.d_desc.ptr, len(flushes), self.d_cls.ptr, self.d_b1.ptr, self.d_b2.ptr, self.d_consumed.ptr,
                                                 self.d_cand_rec.ptr, self.d_counters.ptr, self.cap_cand, base, self.n_pe, stream)))
         else:

@@ -45,6 +45,7 @@ struct im_ctx {
     int32_t* gdepth_sums = nullptr;
     std::mutex gb_mu;
     std::unordered_map<void*, int32_t> gb_layout;   // group-by scratch -> the slot count it was initialised (and is carved) for
+    std::unordered_map<void*, std::pair<int32_t, int32_t>> fg_layout;   // flush + group-by scratch -> (slots, flushes) it is carved for
     std::vector<int64_t> h_sums_off;    // each contig's own run of tile sums: scans of different contigs may be in flight on different streams
     // read-group -> range[1] table (im_set_insert_ranges), flattened hashtable chains
     void* rg_blob = nullptr;
@@ -359,6 +360,43 @@ int im_dev_flush_cuts(im_ctx* ctx, const im_flush_desc* desc_dev, int32_t n_flus
     if ((((uintptr_t)cls) | ((uintptr_t)b1) | ((uintptr_t)b2) | ((uintptr_t)consumed)) & 15u) { set_err(ctx, "im_dev_flush_cuts: the slot arrays must be 16-byte aligned"); return IM_E_ARG; }
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     HIP_TRY(ctx, im::launch_flush_seq(desc_dev, n_flushes, cls, b1, b2, consumed, cand_rec, n_cand_dev, cand_cap, pe_base, pe_count, (hipStream_t)stream));
+    return IM_OK;
+}
+
+size_t im_dev_flushgroup_scratch_bytes(int32_t n_slots_cap, int32_t n_flushes_cap) { return im::flushgroup_scratch_bytes(n_slots_cap, n_flushes_cap); }
+
+int im_dev_flushgroup_scratch_init(im_ctx* ctx, int32_t n_slots_cap, int32_t n_flushes_cap, void* scratch, size_t scratch_bytes, void* stream)
+{
+    if (!ctx || !scratch || n_slots_cap < 0 || n_flushes_cap < 0 || scratch_bytes < im::flushgroup_scratch_bytes(n_slots_cap, n_flushes_cap)) return IM_E_ARG;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, im::launch_flushgroup_init(n_slots_cap, n_flushes_cap, scratch, (hipStream_t)stream));
+    { std::lock_guard<std::mutex> lk(ctx->gb_mu); ctx->fg_layout[scratch] = std::make_pair(n_slots_cap, n_flushes_cap); }
+    return IM_OK;
+}
+
+int im_dev_flush_groupby(im_ctx* ctx, const im_flush_desc* desc_dev, int32_t n_flushes,
+                         const int32_t* cls, const int32_t* b1, const int32_t* b2, int32_t* consumed,
+                         const int32_t* cand_rec, const int32_t* n_cand_dev, int32_t cand_cap, int32_t pe_base, int32_t pe_count, int32_t tie_desc,
+                         int32_t* order, int32_t* cl_key, int32_t* cl_first, int32_t* cl_count, int32_t* counts,
+                         void* scratch, size_t scratch_bytes, void* stream)
+{
+    if (!ctx || n_flushes < 0 || !desc_dev || !cand_rec || !n_cand_dev || cand_cap < 0 || pe_count < 0 || !counts || !scratch) return IM_E_ARG;
+    if (((((uintptr_t)cls) | ((uintptr_t)b1) | ((uintptr_t)b2) | ((uintptr_t)consumed) | ((uintptr_t)desc_dev) | ((uintptr_t)cl_key)) & 15u) || (((uintptr_t)counts) & 7u)) {
+        set_err(ctx, "im_dev_flush_groupby: the slot arrays, desc and cl_key must be 16-byte aligned, counts 8-byte aligned"); return IM_E_ARG;
+    }
+    std::pair<int32_t, int32_t> lay(-1, -1);
+    {
+        std::lock_guard<std::mutex> lk(ctx->gb_mu);
+        auto it = ctx->fg_layout.find(scratch);
+        if (it != ctx->fg_layout.end()) lay = it->second;
+    }
+    if (lay.first < 0) { set_err(ctx, "flush + group-by scratch was not initialised (im_dev_flushgroup_scratch_init)"); return IM_E_ARG; }
+    if ((int64_t)cand_cap * IM_MAX_EV > lay.first || n_flushes > lay.second || scratch_bytes < im::flushgroup_scratch_bytes(lay.first, lay.second)) {
+        set_err(ctx, "flush + group-by scratch too small"); return IM_E_ARG;
+    }
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, im::launch_flush_groupby(lay.first, lay.second, desc_dev, n_flushes, cls, b1, b2, consumed, cand_rec, n_cand_dev, cand_cap, pe_base, pe_count,
+                                          tie_desc, order, cl_key, cl_first, cl_count, counts, scratch, (hipStream_t)stream));
     return IM_OK;
 }
 
@@ -798,7 +836,7 @@ int im_dev_free(im_ctx* ctx, void* p)
 {
     if (!ctx) return IM_E_ARG;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
-    { std::lock_guard<std::mutex> lk(ctx->gb_mu); ctx->gb_layout.erase(p); }     // a group-by scratch: its address may come back as something else
+    { std::lock_guard<std::mutex> lk(ctx->gb_mu); ctx->gb_layout.erase(p); ctx->fg_layout.erase(p); }     // a group-by scratch: its address may come back as something else
     HIP_TRY(ctx, hipFree(p));
     return IM_OK;
 }

@@ -22,6 +22,8 @@
 
 #include "im_device.hpp"
 
+#include <mutex>
+
 namespace im {
 namespace {
 
@@ -798,13 +800,18 @@ hipError_t launch_cluster_small(int32_t n_slots, const int32_t* n_slots_dev,
                                 int32_t* order, int32_t* cl_first, int32_t* cl_count,
                                 uint8_t* used, int32_t* out_counts, hipStream_t stream)
 {
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(cluster_small_kernel),
+    // the attribute belongs to the (kernel, device) pair: set once per device, whichever thread / context gets there first
+    static std::once_flag once[64];
+    static hipError_t once_rc[64];
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    dev &= 63;
+    std::call_once(once[dev], [dev] {
+        once_rc[dev] = hipFuncSetAttribute(reinterpret_cast<const void*>(cluster_small_kernel),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(SmallLds));
-        if (e != hipSuccess) return e;
-        attr_set = true;
-    }
+    });
+    if (once_rc[dev] != hipSuccess) return once_rc[dev];
     hipLaunchKernelGGL(cluster_small_kernel, dim3(1), dim3(kSmallThreads), sizeof(SmallLds), stream,
                        n_slots, n_slots_dev, cls, b1, b2, marker, tie_desc, order, cl_first, cl_count, used, out_counts);
     return hipGetLastError();

@@ -62,6 +62,14 @@ hipError_t launch_groupby_init(int32_t n_slots, void* scratch, hipStream_t strea
 hipError_t launch_groupby(int32_t n_layout, int32_t n_slots, const int32_t* n_cand_dev, const int32_t* cls, const int32_t* b1, const int32_t* b2, const int32_t* consumed,
                           int32_t tie_desc, int32_t* order, int32_t* cl_key, int32_t* cl_first, int32_t* cl_count,
                           int32_t* counts, void* scratch, hipStream_t stream);
+// im_flushwide.hip: the flush list and the group-by chip-wide (three launches)
+size_t flushgroup_scratch_bytes(int32_t n_slots, int32_t n_fl_cap);
+hipError_t launch_flushgroup_init(int32_t n_slots, int32_t n_fl_cap, void* scratch, hipStream_t stream);
+hipError_t launch_flush_groupby(int32_t n_slots_layout, int32_t n_fl_layout, const im_flush_desc* desc, int32_t n_fl,
+                                const int32_t* cls, const int32_t* b1, const int32_t* b2, int32_t* consumed,
+                                const int32_t* cand_rec, const int32_t* n_cand_dev, int32_t cand_cap, int32_t pe_base, int32_t pe_count,
+                                int32_t tie_desc, int32_t* order, int32_t* cl_key, int32_t* cl_first, int32_t* cl_count, int32_t* counts,
+                                void* scratch, hipStream_t stream);
 hipError_t launch_depth_scan(int32_t* depth, int64_t n, int32_t* sums, hipStream_t stream);
 hipError_t launch_depth_scan_tiled(int32_t* depth, int64_t n, int32_t* sums, hipStream_t stream);
 hipError_t launch_depth_query_tiled(int32_t nq, const int32_t* beg, const int32_t* end, const int32_t* depth, const int32_t* sums,

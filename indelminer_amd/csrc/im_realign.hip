@@ -1466,56 +1466,60 @@ __device__ BandAln band_alignment(BandLds& G, const uint8_t* contig, const uint8
     return a;
 }
 
-// count_matches (src/alignment.c:219-303) for one candidate split i: '=' and 'X' bases of piece 1 over read[0, i)
-// plus piece 2 over read[i, q4).  Every lane runs it for its own candidate; the op words come from LDS.
-__device__ __forceinline__ int band_split_score(const uint32_t* c1, int n1, int q2, const uint32_t* c2, int n2, int q4, int* pmm)
+// The '=' / 'X' read bases of a band alignment as bits, four read positions per lane in READ coordinates (position
+// 4 * lane + j: bit j = '=', bit 4 + j = 'X'), taken from the per-position form while it is still in LDS (the second
+// band search overwrites piece 1's).  Piece position p is read position p0 + p.
+__device__ __forceinline__ uint32_t band_piece_bits(const BandLds& G, int which, int p0, int M, int lane)
 {
-    const int q3 = q2;
-    int i, j, matches = 0, mm = 0;
-    for (i = 0, j = 0; i < n1; i++) {
-        const int len = (int)(c1[i] >> 4), op = (int)(c1[i] & 15u);
-        if (op != IM_OP_D) j += len;
-        if (j < q2) { if (op == IM_OP_EQ) matches += len; else if (op == IM_OP_X) mm += len; }
-        if (j >= q2) { if (op == IM_OP_EQ) matches += q2 - (j - len); else if (op == IM_OP_X) mm += q2 - (j - len); break; }
+    uint32_t v = 0;
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        const int p = 4 * lane + j - p0;
+        if (p >= 0 && p < M) {
+            const uint32_t kd = G.kind[which][p];
+            v |= (kd == kPosEq ? 1u : 0u) << j;
+            v |= (kd == kPosX ? 1u : 0u) << (4 + j);
+        }
     }
-    for (i = 0, j = 0; i < n2; i++) {
-        const int len = (int)(c2[i] >> 4), op = (int)(c2[i] & 15u);
-        if (op != IM_OP_D) j += len;
-        if (j >= q3) { if (op == IM_OP_EQ) matches += j - q3; else if (op == IM_OP_X) mm += j - q3; i += 1; break; }
-    }
-    for (; i < n2; i++) {
-        const int len = (int)(c2[i] >> 4), op = (int)(c2[i] & 15u);
-        if (op != IM_OP_D) j += len;
-        if (j < q4) { if (op == IM_OP_EQ) matches += len; else if (op == IM_OP_X) mm += len; }
-        if (j >= q4) { if (op == IM_OP_EQ) matches += q4 - (j - len); else if (op == IM_OP_X) mm += q4 - (j - len); break; }
-    }
-    *pmm = mm;
-    return matches;
+    return v;
 }
 
-// find_best_del_candidate (src/alignment.c:306-339): lane = candidate split (i = q3 + lane, + 64, ...); most matches,
-// then fewest mismatches, then the first; candidates behind the first perfect one are never looked at by the reference
-__device__ __forceinline__ int band_best_split(BandLds& G, int q1, int q2, const uint32_t* c1, int n1, int q3, int q4, const uint32_t* c2, int n2,
-                                               int L, int lane, int* pindex)
+// find_best_del_candidate (src/alignment.c:306-339) over the per-position form.  A = the piece that starts at read
+// offset 0 and ends at qa2, B = the piece on [qb1, L).  For the split i the reference counts the '=' and 'X' bases of
+// A over read[0, i) and of B over read[i, L) (count_matches, 219-303): with E / X the running counts of the bits
+// above that is EA(i) + EB(L) - EB(i), likewise for X -- two prefix counts per piece, every candidate of [qb1, qa2] at
+// once (lane l holds i = 4l .. 4l + 3).  "Most matches, then fewest mismatches, then the first" is one packed
+// maximum; the reference's early exit at a perfect candidate picks the same index (nothing in front of the first
+// perfect candidate ties with it).
+__device__ __forceinline__ int band_best_split(BandLds& G, uint32_t bitsA, int qa2, uint32_t bitsB, int qb1, int L, int lane, int* pindex)
 {
-    if (q1 != 0 || q3 > q2) { BFAIL(G, 8); return IM_ST_ABORT; }
-    int bm = -1, bmm = INT_MAX, bi = INT_MAX, perfect = INT_MAX, over = INT_MAX;
-    for (int i = q3 + lane; i <= q2; i += 64) {
-        int mm;
-        const int matches = band_split_score(c1, n1, i, c2, n2, q4, &mm);
-        if (matches > L) over = min(over, i);
-        if (matches == L && mm == 0) perfect = min(perfect, i);
-        if (matches > bm || (matches == bm && mm < bmm)) { bm = matches; bmm = mm; bi = i; }      // ascending i per lane: first wins
+    if (qb1 > qa2 || qa2 > L) { BFAIL(G, 8); return IM_ST_ABORT; }
+    const int x0 = 4 * lane;
+    uint32_t ea = 0, xa = 0, eb = 0, xb = 0;        // A only counts in front of qa2, B only from qb1 on
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        const bool inA = x0 + j < qa2, inB = x0 + j >= qb1 && x0 + j < L;
+        ea |= inA ? (bitsA & (1u << j)) : 0u;       xa |= inA ? ((bitsA >> 4) & (1u << j)) : 0u;
+        eb |= inB ? (bitsB & (1u << j)) : 0u;       xb |= inB ? ((bitsB >> 4) & (1u << j)) : 0u;
     }
-    perfect = wave_min(perfect);
-    over = wave_min(over);
-    if (over != INT_MAX && over <= perfect) { BFAIL(G, 9); return IM_ST_ABORT; }                     // forceassert(matches <= readlength)
-    if (perfect != INT_MAX) { *pindex = perfect; return 0; }     // nothing in front of it can be better, nothing behind it is seen
-    const int M = wave_max(bm);
-    const int MM = wave_min(bm == M ? bmm : INT_MAX);
-    const int idx = wave_min((bm == M && bmm == MM) ? bi : INT_MAX);
-    if (idx == INT_MAX) { BFAIL(G, 10); return IM_ST_ABORT; }
-    *pindex = idx;
+    // one scan carries the four counts (each <= 255)
+    const int mine = __popc(ea) | (__popc(xa) << 8) | (__popc(eb) << 16) | (__popc(xb) << 24);
+    const int incl = wave_scan_add(mine, lane);
+    const int tot = lane_get(incl, 63), excl = incl - mine;
+    const int totEB = (tot >> 16) & 255, totXB = (tot >> 24) & 255;
+    int best = -1;
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        const int i = x0 + j;
+        const uint32_t below = (1u << j) - 1u;
+        const int EA = (excl & 255) + __popc(ea & below), XA = ((excl >> 8) & 255) + __popc(xa & below);
+        const int EB = ((excl >> 16) & 255) + __popc(eb & below), XB = ((excl >> 24) & 255) + __popc(xb & below);
+        const int matches = EA + totEB - EB, mm = XA + totXB - XB;
+        if (i >= qb1 && i <= qa2) best = max(best, (matches << 16) | ((255 - mm) << 8) | (255 - i));
+    }
+    best = wave_max(best);
+    if (best < 0) { BFAIL(G, 10); return IM_ST_ABORT; }          // forceassert(index != -1)
+    *pindex = 255 - (best & 255);
     return 0;
 }
 
@@ -1678,6 +1682,7 @@ __global__ __launch_bounds__(64, 4) void realign_band_kernel(RealignArgs A)
         if (lane < n1) c1_keep[lane] = G.ops[0][lane];
         wave_lds_sync();
         const uint32_t* c1 = c1_keep;
+        const uint32_t bits1 = band_piece_bits(G, 0, 0, L, lane);
         if (q1 == 0 && q2 == L) {       // whole read aligned: evidence only from I/D ops inside the CIGAR (575-582)
             const int rs = band_build_result(out, G, r1, c1, n1, L, 0, -1, c1, 0, lane, A, c);
             finish(out, rs, 1, lane);
@@ -1760,11 +1765,14 @@ __global__ __launch_bounds__(64, 4) void realign_band_kernel(RealignArgs A)
                 if (!(q1 < q2 && q3 < q4)) { BFAIL(G, 103); st = IM_ST_ABORT; }
                 else {
                     int index = -1;
+                    const uint32_t bits2 = band_piece_bits(G, 1, (int)p0, (int)(p1 - p0), lane);
+                    // find_best_del_candidate asserts that its first piece starts at read offset 0 (314-315); its second piece
+                    // ends at L by the accept conditions above
                     if (q1 > q3 && q1 <= q4) {
-                        st = band_best_split(G, q3, q4, c2, n2, q1, q2, c1, n1, L, lane, &index);
+                        st = (q3 != 0 || q2 != L) ? IM_ST_ABORT : band_best_split(G, bits2, q4, bits1, q1, L, lane, &index);
                         if (st == 0) st = band_build_result(out, G, r3, c2, n2, index, q1, r1, c1, n1, lane, A, c);
                     } else if (q3 > q1 && q3 <= q2) {
-                        st = band_best_split(G, q1, q2, c1, n1, q3, q4, c2, n2, L, lane, &index);
+                        st = (q1 != 0 || q4 != L) ? IM_ST_ABORT : band_best_split(G, bits1, q2, bits2, q3, L, lane, &index);
                         if (st == 0) st = band_build_result(out, G, r1, c1, n1, index, q3, r3, c2, n2, lane, A, c);
                     } else if (q1 > q4 && r1 == r4) st = band_build_result(out, G, r3, c2, n2, q4, q1, r1, c1, n1, lane, A, c);
                     else if (q3 > q2 && r2 == r3) st = band_build_result(out, G, r1, c1, n1, q2, q3, r3, c2, n2, lane, A, c);

@@ -2088,7 +2088,7 @@ typedef struct {
     /* device arrays of the group (growable) */
     int32_t cap_cand; int64_t cap_bases; int32_t cap_pe, cap_fl;
     void *bases, *boff, *len, *tid, *anchor, *range, *res, *cls, *b1, *b2, *consumed, *cand_rec, *counters, *cut;
-    void *order, *clkey, *clfirst, *clcount, *counts, *gscratch, *fdesc; size_t gscratch_bytes;
+    void *order, *clkey, *clfirst, *clcount, *counts, *gscratch, *fdesc, *fgscratch; size_t gscratch_bytes, fgscratch_bytes;
     /* confirmed by harvested chunks / still in flight */
     int32_t conf_cand, conf_err; int64_t conf_bytes, fly_recs, fly_seq;
     im_triage_params tp;
@@ -2115,13 +2115,17 @@ static void pipe_alloc_cands(ppipe* P, int32_t cap_cand, int64_t cap_bases, int3
     P->gscratch_bytes = im_dev_groupby_scratch_bytes((int32_t)nsl);
     P->gscratch = pdev_alloc(P, P->gscratch_bytes);
     GPU(im_dev_groupby_scratch_init(P->d->gpu, (int32_t)nsl, P->gscratch, P->gscratch_bytes, P->stream));
+    /* the chip-wide flush list + group-by (im_dev_flush_groupby): its table and the range-minimum tree over the flush list */
+    P->fgscratch_bytes = im_dev_flushgroup_scratch_bytes(cap_cand * IM_MAX_EV, P->cap_fl);
+    P->fgscratch = pdev_alloc(P, P->fgscratch_bytes);
+    GPU(im_dev_flushgroup_scratch_init(P->d->gpu, cap_cand * IM_MAX_EV, P->cap_fl, P->fgscratch, P->fgscratch_bytes, P->stream));
     P->cap_cand = cap_cand; P->cap_bases = cap_bases; P->cap_pe = cap_pe;
 }
 
 static void pipe_free_cands(ppipe* P)
 {
     void* all[] = { P->bases, P->boff, P->len, P->tid, P->anchor, P->range, P->cand_rec, P->res, P->cls, P->b1, P->b2, P->consumed,
-                    P->order, P->clkey, P->clfirst, P->clcount, P->gscratch };
+                    P->order, P->clkey, P->clfirst, P->clcount, P->gscratch, P->fgscratch };
     for (size_t i = 0; i < sizeof all / sizeof all[0]; i++) if (all[i]) im_dev_free(P->d->gpu, all[i]);
 }
 
@@ -2537,7 +2541,13 @@ static void pipe_run_group(ppipe* P, pgroup* G)
     if (G->n_pe > P->cap_pe || G->n_fl > P->cap_fl) {
         /* rare: more discordant pairs / flushes than the arrays were sized for */
         GPU(im_stream_sync(g, P->stream));
-        if (G->n_fl > P->cap_fl) { im_dev_free(g, P->cut); while (P->cap_fl < G->n_fl) P->cap_fl *= 2; P->cut = pdev_alloc(P, 8 * (size_t)P->cap_fl); im_dev_free(g, P->fdesc); P->fdesc = pdev_alloc(P, sizeof(im_flush_desc) * (size_t)P->cap_fl); }
+        if (G->n_fl > P->cap_fl) {
+            im_dev_free(g, P->cut); while (P->cap_fl < G->n_fl) P->cap_fl *= 2; P->cut = pdev_alloc(P, 8 * (size_t)P->cap_fl); im_dev_free(g, P->fdesc); P->fdesc = pdev_alloc(P, sizeof(im_flush_desc) * (size_t)P->cap_fl);
+            im_dev_free(g, P->fgscratch);
+            P->fgscratch_bytes = im_dev_flushgroup_scratch_bytes(P->cap_cand * IM_MAX_EV, P->cap_fl);
+            P->fgscratch = pdev_alloc(P, P->fgscratch_bytes);
+            GPU(im_dev_flushgroup_scratch_init(g, P->cap_cand * IM_MAX_EV, P->cap_fl, P->fgscratch, P->fgscratch_bytes, P->stream));
+        }
         if (G->n_pe > P->cap_pe) {
             ppipe old = *P;
             int32_t np = P->cap_pe; while (np < G->n_pe) np *= 2;
@@ -2562,8 +2572,33 @@ static void pipe_run_group(ppipe* P, pgroup* G)
         GPU(im_dev_upload(g, (char*)P->b2 + 4 * pe_base, t + 2 * (size_t)G->n_pe, 4 * (size_t)G->n_pe));
         free(t);
     }
-    GPU(im_dev_memset(g, P->consumed, 0, 4 * (pe_base + (size_t)G->n_pe), P->stream));
-    GPU(im_dev_memset(g, P->cut, 0xFF, 8 * (size_t)G->n_fl, P->stream));
+    /* The flush list of the group, in file order, and the split-read group-by.  Within a contig the markers never decrease
+     * (find_marker is a minimum over pair-table entries that leave the table or enter it at the current position of a
+     * coordinate-sorted walk), so which flush consumes an entry needs no history: three chip-wide launches do the whole
+     * list and the group-by (im_dev_flush_groupby).  A BAM whose positions run backwards inside a contig can break that;
+     * such a group takes the sequential forms: one workgroup walking the list, or one launch pair per flush when no
+     * mid-contig flush consumes anything and the pending ranges grow long. */
+    im_flush_desc* fd = xcalloc((size_t)(G->n_fl ? G->n_fl : 1), sizeof(im_flush_desc));
+    int64_t longest = 0;
+    int monotone = 1;
+    for (int ci = 0; ci < G->n_ctg; ci++) {
+        const gcontig* cg = &G->ctg[ci];
+        for (int f = cg->fl0; f < cg->fl1; f++) {
+            const gflush* fl = &G->fl[f];
+            fd[f].rec0 = (int32_t)cg->rec0; fd[f].rec1 = (int32_t)fl->rec; fd[f].pe0 = cg->pe0; fd[f].pe1 = fl->pe;
+            fd[f].marker = fl->marker; fd[f].id = f + 1; fd[f].last = cg->fl1 - 1;
+            if (fl->rec - cg->rec0 > longest) longest = fl->rec - cg->rec0;
+            if (f > cg->fl0 && (fl->marker < G->fl[f - 1].marker || fl->rec < G->fl[f - 1].rec || fl->pe < G->fl[f - 1].pe)) monotone = 0;
+        }
+    }
+    const char* fm = getenv("INDELMINER_FLUSH_MODE");
+    const int wide = fm ? strcmp(fm, "wide") == 0 : monotone;
+    if (wide && !monotone) fatalf("INDELMINER_FLUSH_MODE=wide: the flush markers of a contig decrease (is %s coordinate-sorted?)", d->bam_name);
+    const int per_flush = !wide && (fm && strcmp(fm, "seq") != 0 ? strcmp(fm, "per-flush") == 0 : (longest > 16 * (int64_t)READCHUNK && G->n_fl > 64));
+    if (!wide) {
+        GPU(im_dev_memset(g, P->consumed, 0, 4 * (pe_base + (size_t)G->n_pe), P->stream));
+        if (per_flush) GPU(im_dev_memset(g, P->cut, 0xFF, 8 * (size_t)G->n_fl, P->stream));
+    }
     im_params prm = { O.klength, O.numgaps, O.maxdelsize, O.ethreshold };
     if (nc > 0) {
         im_dev_batch bt;
@@ -2572,26 +2607,13 @@ static void pipe_run_group(ppipe* P, pgroup* G)
         bt.range_max = P->range; bt.out = P->res; bt.ev_cls = P->cls; bt.ev_b1 = P->b1; bt.ev_b2 = P->b2;
         GPU(im_dev_realign_keep(g, &prm, &bt, P->stream));
     }
-    {
-        /* the flush list of the group, in file order.  One launch walks it when every flush sees a short pending
-         * range (the usual case: a flush consumes nearly everything that arrived since the previous one); a group
-         * whose pending ranges grow long (markers pinned low by stale pair-table entries) takes one launch pair per
-         * flush, which spreads each range over the whole chip */
-        im_flush_desc* fd = xmalloc(sizeof(im_flush_desc) * (size_t)(G->n_fl ? G->n_fl : 1));
-        int64_t longest = 0;
-        for (int ci = 0; ci < G->n_ctg; ci++) {
-            const gcontig* cg = &G->ctg[ci];
-            for (int f = cg->fl0; f < cg->fl1; f++) {
-                const gflush* fl = &G->fl[f];
-                fd[f].rec0 = (int32_t)cg->rec0; fd[f].rec1 = (int32_t)fl->rec; fd[f].pe0 = cg->pe0; fd[f].pe1 = fl->pe;
-                fd[f].marker = fl->marker; fd[f].id = f + 1;
-                if (fl->rec - cg->rec0 > longest) longest = fl->rec - cg->rec0;
-            }
-        }
-        const char* fm = getenv("INDELMINER_FLUSH_MODE");
-        const int per_flush = fm ? strcmp(fm, "per-flush") == 0 : (longest > 16 * (int64_t)READCHUNK && G->n_fl > 64);
+    if (!per_flush) GPU(im_dev_upload(g, P->fdesc, fd, sizeof(im_flush_desc) * (size_t)G->n_fl));    /* synchronous: complete before the launches below */
+    if (wide) {
+        GPU(im_dev_flush_groupby(g, (const im_flush_desc*)P->fdesc, G->n_fl, P->cls, P->b1, P->b2, P->consumed, P->cand_rec, P->counters, nc,
+                                 (int32_t)pe_base, G->n_pe, O.tie_desc, P->order, P->clkey, P->clfirst, P->clcount, P->counts,
+                                 P->fgscratch, P->fgscratch_bytes, P->stream));
+    } else {
         if (!per_flush) {
-            GPU(im_dev_upload(g, P->fdesc, fd, sizeof(im_flush_desc) * (size_t)G->n_fl));    /* synchronous: complete before the launch below */
             GPU(im_dev_flush_cuts(g, (const im_flush_desc*)P->fdesc, G->n_fl, P->cls, P->b1, P->b2, P->consumed,
                                   P->cand_rec, P->counters, P->cap_cand, (int32_t)pe_base, G->n_pe, P->stream));
         } else {
@@ -2600,10 +2622,10 @@ static void pipe_run_group(ppipe* P, pgroup* G)
                                          (int32_t)pe_base + fd[f].pe0, (int32_t)pe_base + fd[f].pe1, fd[f].marker, fd[f].id,
                                          (uint64_t*)P->cut + f, P->stream));
         }
-        free(fd);
+        GPU(im_dev_cluster_groupby(g, nc * IM_MAX_EV, P->cls, P->b1, P->b2, P->consumed, O.tie_desc,
+                                   P->order, P->clkey, P->clfirst, P->clcount, P->counts, P->gscratch, P->gscratch_bytes, P->stream));
     }
-    GPU(im_dev_cluster_groupby(g, nc * IM_MAX_EV, P->cls, P->b1, P->b2, P->consumed, O.tie_desc,
-                               P->order, P->clkey, P->clfirst, P->clcount, P->counts, P->gscratch, P->gscratch_bytes, P->stream));
+    free(fd);
     GPU(im_stream_sync(g, P->stream));
     phase_time("device: realign + flush cuts + group-by");
 

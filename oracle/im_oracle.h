@@ -159,6 +159,8 @@ void imo_triage_record(const uint8_t* rec, uint32_t len,
 void imo_depth_add(const uint8_t* rec, uint32_t len, int32_t tid, int32_t* depth, int64_t clen);
 int32_t imo_flush_cut(int32_t n, const int32_t* cls, const int32_t* b1, const int32_t* b2, int32_t* consumed,
                       int32_t marker, int32_t flush_id);
+int32_t imo_flush_nohistory(int32_t n_fl, const int32_t* marker, const int32_t* id, const int32_t* last,
+                            int32_t n, const int32_t* cls, const int32_t* b1, const int32_t* b2, const int32_t* arr, int32_t* consumed);
 
 #ifdef __cplusplus
 }

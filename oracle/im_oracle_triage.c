@@ -282,3 +282,40 @@ int32_t imo_flush_cut(int32_t n, const int32_t* cls, const int32_t* b1, const in
     free(k);
     return taken;
 }
+
+/* The flush list WITHOUT history -- the formulation im_dev_flush_groupby computes (include/indelminer_amd.h), restated
+ * sequentially so that it can be held against the step-by-step imo_flush_cut above.
+ *
+ * find_marker (src/indelminer.c:211-233) is a minimum over pair-table entries that only leave the table or enter it at
+ * the current position of a coordinate-sorted walk, and a flush's marker is min(that, current position) (622-623):
+ * within a contig the markers never decrease.  What process_evidence (123-146) consumed at flush f' sorted in front of
+ * the first entry with b2 >= marker(f'), so it had b2 < marker(f') <= marker(f) for every later f and could not be f's
+ * cutting entry.  Hence   cut(f) = min{(b1,b2)(e) : arr(e) <= f, b2(e) >= marker(f)}   over ALL entries of the contig,
+ * and   consumed(e) = id of the first f >= arr(e) with (b1,b2)(e) < cut(f).
+ *
+ * Flush f: marker[f], id[f] (> 0), last[f] = index of the last flush of f's contig.  Entry i: arr[i] = the first flush
+ * whose bounds cover it (n_fl: none; it then stays pending).  Returns 0, or -1 if the markers of some contig decrease
+ * (the formulation does not apply; consumed[] is untouched). */
+int32_t imo_flush_nohistory(int32_t n_fl, const int32_t* marker, const int32_t* id, const int32_t* last,
+                            int32_t n, const int32_t* cls, const int32_t* b1, const int32_t* b2, const int32_t* arr, int32_t* consumed)
+{
+    for (int32_t f = 0; f + 1 < n_fl; f++)
+        if (last[f] > f && marker[f + 1] < marker[f]) return -1;
+    uint64_t* cut = malloc(sizeof(uint64_t) * (size_t)(n_fl > 0 ? n_fl : 1));
+    for (int32_t f = 0; f < n_fl; f++) cut[f] = ~(uint64_t)0;
+    for (int32_t i = 0; i < n; i++) {
+        if (cls[i] < 0 || arr[i] >= n_fl) continue;
+        const uint64_t key = ((uint64_t)(uint32_t)b1[i] << 32) | (uint32_t)b2[i];
+        for (int32_t f = arr[i]; f <= last[arr[i]] && marker[f] <= b2[i]; f++)
+            if (key < cut[f]) cut[f] = key;
+    }
+    for (int32_t i = 0; i < n; i++) {
+        consumed[i] = 0;
+        if (cls[i] < 0 || arr[i] >= n_fl) continue;
+        const uint64_t key = ((uint64_t)(uint32_t)b1[i] << 32) | (uint32_t)b2[i];
+        for (int32_t f = arr[i]; f <= last[arr[i]]; f++)
+            if (key < cut[f]) { consumed[i] = id[f]; break; }
+    }
+    free(cut);
+    return 0;
+}

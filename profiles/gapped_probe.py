@@ -11,7 +11,9 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import numpy as np  # noqa: E402
 from indelminer_amd import capi, synth  # noqa: E402
-import bench  # noqa: E402
+import bench  # noqa: E402,F401
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import legacy_shard  # noqa: E402
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 24464
 GS = [int(a) for a in sys.argv[2:]] or [0, 1, 2, 5, 12]
@@ -23,7 +25,7 @@ n_all = len(cand["index"])
 L = capi.lib()
 reps = (n + n_all - 1) // n_all
 sub = {k: (np.concatenate([v] * reps)[:n] if isinstance(v, np.ndarray) and v.shape[:1] == (n_all,) else v) for k, v in cand.items()}
-sh = bench.Shard(ctx, refs[0], sub, 100)
+sh = legacy_shard.Shard(ctx, refs[0], sub, 100)
 for g in GS:
     P = capi.params(numgaps=g)
     t = capi.Timer(ctx)

@@ -7,7 +7,9 @@ import time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from indelminer_amd import capi, synth  # noqa: E402
-import bench  # noqa: E402
+import bench  # noqa: E402,F401
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import legacy_shard  # noqa: E402
 
 refs, rd = synth.simulate(seed=1, ref_len=1_000_000, coverage=30)
 cand = synth.candidates(rd)
@@ -17,7 +19,7 @@ if len(sys.argv) > 1:                       # fewer reads per step: is the loop 
     cand = {k: (v[:n_sub] if isinstance(v, np.ndarray) and v.shape[:1] == (n_all,) else v) for k, v in cand.items()}
 ctx = capi.Context(0)
 ctx.set_reference([refs[0].tobytes()])
-sh = bench.Shard(ctx, refs[0], cand, 100)
+sh = legacy_shard.Shard(ctx, refs[0], cand, 100)
 for _ in range(5):
     sh.step()
 sh.sync()

@@ -10,7 +10,9 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import numpy as np  # noqa: E402
 from indelminer_amd import capi, synth  # noqa: E402
-import bench  # noqa: E402
+import bench  # noqa: E402,F401
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import legacy_shard  # noqa: E402
 
 NAMES = {0: "setup (loads, staging, geometry)", 1: "p1 table build", 2: "p1 histogram clear", 3: "p1 vote",
          4: "p1 evaluate", 5: "p1 argmax reduce", 6: "p1 diagonal scan", 7: "case selection",
@@ -21,7 +23,7 @@ refs, rd = synth.simulate(seed=1, ref_len=1_000_000, coverage=30)
 cand = synth.candidates(rd)
 ctx = capi.Context(0)
 ctx.set_reference([refs[0].tobytes()])
-sh = bench.Shard(ctx, refs[0], cand, 100)
+sh = legacy_shard.Shard(ctx, refs[0], cand, 100)
 L = capi.lib()
 acc = (C.c_ulonglong * 32)()
 sh.step(); sh.sync()

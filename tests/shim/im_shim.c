@@ -362,6 +362,47 @@ int im_dev_cluster_groupby(im_ctx* c, int32_t n_slots, const int32_t* cls, const
     return IM_OK;
 }
 
+/* The chip-wide form: flush marks without history (imo_flush_nohistory restates what the kernels compute), then the group-by. */
+size_t im_dev_flushgroup_scratch_bytes(int32_t n_slots_cap, int32_t n_flushes_cap) { (void)n_slots_cap; (void)n_flushes_cap; return 256; }
+int im_dev_flushgroup_scratch_init(im_ctx* c, int32_t n_slots_cap, int32_t n_flushes_cap, void* scratch, size_t scratch_bytes, void* stream)
+{
+    (void)c; (void)n_slots_cap; (void)n_flushes_cap; (void)scratch; (void)scratch_bytes; (void)stream;
+    return IM_OK;
+}
+int im_dev_flush_groupby(im_ctx* c, const im_flush_desc* desc, int32_t n_flushes,
+                         const int32_t* cls, const int32_t* b1, const int32_t* b2, int32_t* consumed,
+                         const int32_t* cand_rec, const int32_t* n_cand_dev, int32_t cand_cap, int32_t pe_base, int32_t pe_count, int32_t tie_desc,
+                         int32_t* order, int32_t* cl_key, int32_t* cl_first, int32_t* cl_count, int32_t* counts,
+                         void* scratch, size_t scratch_bytes, void* stream)
+{
+    const int32_t nc = *n_cand_dev < cand_cap ? *n_cand_dev : cand_cap;
+    const int32_t ns = nc * IM_MAX_EV, n = ns + pe_count;
+    int32_t *mk = malloc(4 * (size_t)(n_flushes + 1)), *id = malloc(4 * (size_t)(n_flushes + 1)), *last = malloc(4 * (size_t)(n_flushes + 1));
+    for (int32_t f = 0; f < n_flushes; f++) {
+        mk[f] = desc[f].marker; id[f] = desc[f].id;
+        last[f] = desc[f].last < f ? f : (desc[f].last >= n_flushes ? n_flushes - 1 : desc[f].last);
+    }
+    int32_t *tc = malloc(4 * (size_t)(n + 1)), *t1 = malloc(4 * (size_t)(n + 1)), *t2 = malloc(4 * (size_t)(n + 1)), *ta = malloc(4 * (size_t)(n + 1)), *tu = malloc(4 * (size_t)(n + 1));
+    int32_t f = 0;
+    for (int32_t k = 0; k < nc; k++) {
+        while (f < n_flushes && desc[f].rec1 <= cand_rec[k]) f++;       /* cand_rec ascends */
+        for (int j = 0; j < IM_MAX_EV; j++) { const int32_t s = k * IM_MAX_EV + j; tc[s] = cls[s]; t1[s] = b1[s]; t2[s] = b2[s]; ta[s] = f; }
+    }
+    f = 0;
+    for (int32_t i = 0; i < pe_count; i++) {
+        while (f < n_flushes && desc[f].pe1 <= i) f++;
+        const int32_t s = pe_base + i; tc[ns + i] = cls[s]; t1[ns + i] = b1[s]; t2[ns + i] = b2[s]; ta[ns + i] = f;
+    }
+    const int rc = imo_flush_nohistory(n_flushes, mk, id, last, n, tc, t1, t2, ta, tu);
+    if (rc == 0) {
+        for (int32_t s = 0; s < ns; s++) consumed[s] = tu[s];
+        for (int32_t i = 0; i < pe_count; i++) consumed[pe_base + i] = tu[ns + i];
+    }
+    free(mk); free(id); free(last); free(tc); free(t1); free(t2); free(ta); free(tu);
+    if (rc != 0) { snprintf(c->err, sizeof c->err, "im_dev_flush_groupby: the markers of a contig decrease"); return IM_E_ARG; }
+    return im_dev_cluster_groupby(c, ns, cls, b1, b2, consumed, tie_desc, order, cl_key, cl_first, cl_count, counts, scratch, scratch_bytes, stream);
+}
+
 /* ---- the collective, CPU edition: an all-gather through files in a directory named by the unique id ---- */
 #include <time.h>
 #include <unistd.h>

@@ -142,3 +142,16 @@ def flush_cut(cls, b1, b2, consumed, marker, flush_id):
     cls = np.ascontiguousarray(cls, np.int32); b1 = np.ascontiguousarray(b1, np.int32); b2 = np.ascontiguousarray(b2, np.int32)
     assert consumed.dtype == np.int32 and consumed.flags.c_contiguous
     return L.imo_flush_cut(len(cls), cls.ctypes.data, b1.ctypes.data, b2.ctypes.data, consumed.ctypes.data, marker, flush_id)
+
+
+def flush_nohistory(marker, ids, last, cls, b1, b2, arr):
+    """imo_flush_nohistory: consumed[] for the whole flush list at once, or None when a contig's markers decrease"""
+    import numpy as np
+    L = lib()
+    L.imo_flush_nohistory.restype = C.c_int32
+    L.imo_flush_nohistory.argtypes = [C.c_int32] + [C.c_void_p] * 3 + [C.c_int32] + [C.c_void_p] * 5
+    a = [np.ascontiguousarray(x, np.int32) for x in (marker, ids, last, cls, b1, b2, arr)]
+    consumed = np.full(len(a[3]), -7, np.int32)
+    rc = L.imo_flush_nohistory(len(a[0]), a[0].ctypes.data, a[1].ctypes.data, a[2].ctypes.data, len(a[3]),
+                               a[3].ctypes.data, a[4].ctypes.data, a[5].ctypes.data, a[6].ctypes.data, consumed.ctypes.data)
+    return consumed if rc == 0 else None

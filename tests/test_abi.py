@@ -23,7 +23,8 @@ def test_library_exports_every_declared_symbol():
     assert len(syms) >= 20
     for s in syms:
         assert hasattr(L, s), "missing export: " + s
-    assert L.im_abi_version() == 1
+    version = int(re.search(r"#define IM_ABI_VERSION (\d+)", open(os.path.join(ROOT, "include", "indelminer_amd.h")).read()).group(1))
+    assert L.im_abi_version() == version == 2
 
 
 def test_result_record_layout():

@@ -212,10 +212,11 @@ def test_realign_keep_flush_groupby(gpu_ctx):
     assert got == {k: v[::-1] for k, v in want.items()}
 
 
-@pytest.mark.parametrize("one_launch", [True, False])
-def test_async_pass_matches_stepwise(gpu_ctx, one_launch):
+@pytest.mark.parametrize("mode", ["wide", "seq", "per-flush"])
+def test_async_pass_matches_stepwise(gpu_ctx, mode):
     """the whole pass bound on one stream without host round trips (device-resident candidate count, record bounds,
-    all flushes in one launch) gives the stepwise results"""
+    the flush list chip-wide without history / walked by one workgroup / one launch pair per flush) gives the stepwise results"""
+    one_launch = mode != "per-flush"
     refs, rd, raw, off = _synth(seed=13, ref_len=150_000, coverage=25, big_every=5)
     contig = refs[0].tobytes()
     gpu_ctx.set_reference([contig])
@@ -240,12 +241,14 @@ def test_async_pass_matches_stepwise(gpu_ctx, one_launch):
     pipe = capi.Pipeline(gpu_ctx, rd.n, len(raw), cap_cand=rd.n // 4, n_pe=max(len(pe_b1), 1), n_flushes=len(flushes), input_from=ref_pipe)
     pipe.set_pe(pe_b1, pe_b2)
     st = capi.new_stream(gpu_ctx)
-    for fn, args in pipe.bind_async(flushes, st, grid_bound=rd.n // 8, one_launch_flushes=one_launch):
+    for fn, args in pipe.bind_async(flushes, st, grid_bound=rd.n // 8, one_launch_flushes=one_launch, wide=mode == "wide"):
         gpu_ctx._check(fn(*args))
     pipe.sync(st)
     pipe.fetch_counts()
     assert pipe.n_cand == ref_pipe.n_cand
-    assert np.array_equal(pipe.d_consumed.download(np.int32, pipe.n_slots), want_cons)
+    got_cons = pipe.d_consumed.download(np.int32, pipe.n_slots)
+    live, base = pipe.n_cand * capi.MAX_EV, pipe.cap_cand * capi.MAX_EV        # the marks of unused slots are nobody's business
+    assert np.array_equal(got_cons[:live], want_cons[:live]) and np.array_equal(got_cons[base:], want_cons[base:])
     key, first, count, order = pipe.clusters()
     got = {tuple(int(x) for x in key[c]): list(order[first[c]:first[c] + count[c]]) for c in range(len(key))}
     assert got == want
@@ -330,3 +333,90 @@ def test_groupby_scratch_serves_groups_of_any_size(gpu_ctx):
         assert got == want, (m, len(got), len(want))
         seen += len(want)
     assert seen > 500
+
+
+def _wide_case(rng, n_cand, n_ctg, n_pe, pinned, dense):
+    """slot arrays, candidate records, paired-read entries and a flush list of n_ctg contigs the way the product builds
+    them: records ascend, a contig's flushes share rec0, markers never decrease inside a contig, INT_MAX at its end"""
+    E = capi.MAX_EV
+    rec = np.cumsum(rng.integers(1, 40, n_cand)).astype(np.int32)
+    n_rec = int(rec[-1]) + 1
+    ctg_of_rec = np.sort(rng.integers(0, n_ctg, n_rec))                  # records -> contigs, in order
+    ctg_start = [int(np.searchsorted(ctg_of_rec, c)) for c in range(n_ctg)] + [n_rec]
+    pos_of_rec = np.zeros(n_rec, np.int64)
+    for c in range(n_ctg):
+        a, b = ctg_start[c], ctg_start[c + 1]
+        pos_of_rec[a:b] = np.sort(rng.integers(0, 2_000_000, b - a))
+    cls = np.full(n_cand * E, -1, np.int32); b1 = np.zeros(n_cand * E, np.int32); b2 = np.zeros(n_cand * E, np.int32)
+    pool = rng.integers(-600, 600, 64)                                   # few distinct offsets: clusters with several members
+    for j in range(E):
+        live = rng.random(n_cand) < (0.9 if j == 0 else 0.15)
+        s = pos_of_rec[rec] // 200 * 200 + pool[rng.integers(0, 64, n_cand)]
+        s = np.maximum(s, 0)
+        cls[j::E] = np.where(live, rng.integers(0, 2, n_cand), -1)
+        b1[j::E] = s
+        b2[j::E] = s + np.where(rng.random(n_cand) < 0.6, rng.integers(1, 900, n_cand) // 50 * 50, 0)
+    pe_rec = np.sort(rng.integers(0, n_rec, n_pe))
+    pe_b1 = np.maximum(pos_of_rec[pe_rec] + rng.integers(-500, 500, n_pe), 0).astype(np.int32)
+    pe_b2 = (pe_b1 + rng.integers(100, 5000, n_pe)).astype(np.int32)
+    flushes = []
+    for c in range(n_ctg):
+        a, b = ctg_start[c], ctg_start[c + 1]
+        nf = int(rng.integers(0, 40 if dense else 6))
+        cuts = np.sort(rng.integers(a, b + 1, nf)) if b > a else []
+        floor = int(rng.integers(0, 100_000)) if pinned else 2**31 - 1
+        mk = -1
+        for r1 in cuts:
+            here = int(pos_of_rec[r1 - 1]) if r1 > a else 0
+            mk = max(mk, min(floor, here - int(rng.integers(0, 3000))))
+            flushes.append((a, int(r1), int(np.searchsorted(pe_rec, r1)), mk))
+        flushes.append((a, b, int(np.searchsorted(pe_rec, b)), 2**31 - 1))
+    return rec, cls, b1, b2, pe_b1, pe_b2, flushes
+
+
+def test_flush_groupby_wide_against_the_stepwise_oracle(gpu_ctx):
+    """im_dev_flush_groupby (three chip-wide launches, no history) on ONE pipeline's buffers, group after group: several
+    contigs, dense and sparse flush lists, markers pinned low (every entry a cutting candidate up to its contig's end), paired-read
+    entries in the cuts, both member orders -- against imo_flush_cut flush by flush and a plain group-by"""
+    E = capi.MAX_EV
+    cap, cap_pe = 60_000, 3000
+    pipe = capi.Pipeline(gpu_ctx, 1, 64, cap_cand=cap, n_pe=cap_pe, n_flushes=400)
+    rng = np.random.default_rng(77)
+    cases = [(50_000, 3, 2500, False, False), (700, 1, 0, False, True), (20_000, 5, 900, True, True), (1, 1, 1, False, False),
+             (33_333, 2, 3000, True, False), (5000, 8, 100, False, True), (60_000, 1, 10, False, False)]
+    total = 0
+    for ci, (n_cand, n_ctg, n_pe, pinned, dense) in enumerate(cases):
+        rec, cls, b1, b2, pe_b1, pe_b2, flushes = _wide_case(rng, n_cand, n_ctg, n_pe, pinned, dense)
+        assert len(flushes) <= 400
+        pipe.d_cls.upload(cls); pipe.d_b1.upload(b1); pipe.d_b2.upload(b2)
+        pipe.n_pe = n_pe
+        pipe.set_pe(pe_b1, pe_b2)
+        pipe.d_cand_rec.upload(rec)
+        cnt = np.zeros(8, np.int32); cnt[0] = n_cand
+        pipe.d_counters.upload(cnt)
+        tie = ci & 1
+        pipe.flush_groupby(flushes, tie_desc=tie, cand_bound=max(n_cand, 1) if ci % 3 else cap)
+        pipe.sync()
+        ns = n_cand * E
+        a_cls = np.concatenate([cls, np.full(n_pe, 2, np.int32)]); a_b1 = np.concatenate([b1, pe_b1]); a_b2 = np.concatenate([b2, pe_b2])
+        want = np.zeros(ns + n_pe, np.int32)
+        for k, (r0, r1, pe_hi, marker) in enumerate(flushes):
+            lo, hi = int(np.searchsorted(rec, r0)), int(np.searchsorted(rec, r1))
+            vis = np.full(ns + n_pe, -1, np.int32)
+            vis[lo * E:hi * E] = cls[lo * E:hi * E]; vis[ns:ns + pe_hi] = 2
+            ob.flush_cut(vis, a_b1, a_b2, want, marker, k + 1)
+        got = pipe.d_consumed.download(np.int32, pipe.n_slots)
+        base = cap * E
+        assert np.array_equal(got[:ns], want[:ns]), (ci, int((got[:ns] != want[:ns]).sum()))
+        assert np.array_equal(got[base:base + n_pe], want[ns:]), ci
+        groups = {}
+        for s in np.nonzero((cls >= 0) & (cls < 2) & (want[:ns] > 0))[0]:
+            groups.setdefault((int(want[s]), int(cls[s]), int(b1[s]), int(b2[s])), []).append(int(s))
+        key, first, count, order = pipe.clusters()
+        assert int(count.sum()) == len(order) == sum(len(v) for v in groups.values())
+        seen = {tuple(int(x) for x in key[c]): [int(x) for x in order[first[c]:first[c] + count[c]]] for c in range(len(key))}
+        assert seen == ({k: v[::-1] for k, v in groups.items()} if tie else groups), ci
+        total += len(groups)
+        if not pinned and n_cand >= 5000 and len(flushes) > 2 * n_ctg:
+            assert len({k[0] for k in groups}) > n_ctg            # mid-contig flushes did consume
+    assert total > 20_000
