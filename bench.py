@@ -402,7 +402,7 @@ def end_to_end_multi(rank, world, local_rank, dist, ref_len=500_000):
         dist.broadcast_object_list(box, src=0)
     td, n_reads = box
     cmd = [build.HOST_BIN, "-i", "cfg.txt", "ref.fa", "s=aln.bam"]
-    env = dict(os.environ, RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(local_rank), INDELMINER_RENDEZVOUS=td + "/rdv")
+    env = dict(os.environ, RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(local_rank), INDELMINER_RENDEZVOUS=td + "/rdv", INDELMINER_RUN_TOKEN=td)
     if world == 1:
         env["INDELMINER_FORCE_MGPU"] = "1"
     if os.environ.get("IM_BENCH_ONE_DEVICE") == "1":

@@ -415,6 +415,7 @@ typedef struct {
     int32_t   n_intv;
     uint64_t* ioffset;
     uint64_t  first_chunk;      /* smallest chunk start of any real bin, 0 if none */
+    uint64_t  last_chunk;       /* largest chunk end of any real bin */
 } bai_ref;
 
 struct bai_index {
@@ -446,7 +447,7 @@ bai_index* bai_load(const char* bam_path)
     for (int32_t i = 0; i < n_ref; i++) {
         int32_t n_bin;
         if (frd(fp, &n_bin, 4)) goto fail;
-        uint64_t first = 0;
+        uint64_t first = 0, last = 0;
         for (int32_t j = 0; j < n_bin; j++) {
             uint32_t bin; int32_t n_chunk;
             if (frd(fp, &bin, 4) || frd(fp, &n_chunk, 4)) goto fail;
@@ -454,9 +455,10 @@ bai_index* bai_load(const char* bam_path)
                 uint64_t uv[2];
                 if (frd(fp, uv, 16)) goto fail;
                 if (bin != 37450 && (first == 0 || uv[0] < first)) first = uv[0];
+                if (bin != 37450 && uv[1] > last) last = uv[1];
             }
         }
-        idx->ref[i].first_chunk = first;
+        idx->ref[i].first_chunk = first; idx->ref[i].last_chunk = last;
         if (frd(fp, &idx->ref[i].n_intv, 4)) goto fail;
         idx->ref[i].ioffset = calloc((size_t)(idx->ref[i].n_intv > 0 ? idx->ref[i].n_intv : 1), 8);
         if (idx->ref[i].n_intv > 0 && frd(fp, idx->ref[i].ioffset, 8 * (size_t)idx->ref[i].n_intv)) goto fail;
@@ -467,6 +469,14 @@ fail:
     fclose(fp);
     bai_free(idx);
     return NULL;
+}
+
+/* compressed bytes of the file that hold contig tid's records (0: none): what reading the contig costs */
+int64_t bai_contig_bytes(const bai_index* idx, int32_t tid)
+{
+    if (!idx || tid < 0 || tid >= idx->n_ref || idx->ref[tid].first_chunk == 0) return 0;
+    const int64_t a = (int64_t)(idx->ref[tid].first_chunk >> 16), b = (int64_t)(idx->ref[tid].last_chunk >> 16);
+    return b > a ? b - a : 1;
 }
 
 void bai_free(bai_index* idx)

@@ -55,6 +55,7 @@ const char* bam_aux_str(const uint8_t* s);              /* after a 'Z' type byte
 typedef struct bai_index bai_index;
 bai_index* bai_load(const char* bam_path);              /* <bam>.bai ; NULL if missing */
 void bai_free(bai_index* idx);
+int64_t bai_contig_bytes(const bai_index* idx, int32_t tid);   /* compressed bytes holding the contig's records, 0 if none */
 
 /* region iterator with bam_fetch's semantics (bam_index.c:571-576,715-726): every record of
  * tid with rend > beg && rbeg < end, in file order; rend = pos+1 for records without CIGAR */

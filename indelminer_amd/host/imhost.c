@@ -32,6 +32,7 @@
 #include <unistd.h>
 #include <errno.h>
 #include <sys/stat.h>
+#include <dirent.h>
 #include <sys/wait.h>
 #include <setjmp.h>
 #include <spawn.h>
@@ -55,11 +56,13 @@ static time_t t0;
 
 static void out_flush_on_exit(void);
 static void walker_bails_out(void);
+static void mg_rank_failed(void);
 static void fatalf(const char* fmt, ...)
 {
     /* src/errors.c:15-27: message on stderr, exit(1) */
     va_list ap;
     walker_bails_out();         /* a walker thread of the pipeline does not come back from this (see handoff_to_host_child) */
+    mg_rank_failed();           /* multi-GPU: rank 0 stops waiting for this rank's output */
     va_start(ap, fmt);
     out_flush_on_exit();
     fflush(stdout);
@@ -1993,21 +1996,25 @@ static void run_contig(driver* d, int32_t tid, int32_t beg, int32_t end, bgzf_re
 
 /* multi-GPU state (the section further down): declared here because the replay writes one part per contig */
 #define MG_MAX_RG    64
-#define MG_RG_WORDS  16         /* name[48] + min + max + first_tid + first_rec */
-#define MG_MAX_LEFT  32
-#define MG_CTG_WORDS (4 + 3 * MG_MAX_LEFT)
+#define MG_RG_WORDS  17         /* name[48] + min + max + first_tid + first_rec + seen on a proper pair */
 
 typedef struct {
     int rank, world, local_rank;
     im_comm* comm;
     char dir[400];
+    int32_t* owner;             /* [n_targets] the rank that walks the contig (mg_plan) */
     int64_t* prefix;            /* [n_targets] counted reads of all earlier contigs */
     int*     floor;             /* [n_targets] smallest start of a stale pair-table entry of an earlier contig */
     int      out_fd;            /* rank 0: the real stdout */
     uint8_t* skip;              /* [n_targets] annotate mode: contigs without known variants are not walked at all */
+    int      abort_tid;         /* -1, or the first contig of this rank that holds a record the reference dies on */
+    int      cross;             /* the exchanged pair-table logs show entries of one contig meeting records of another */
 } mgpu;
 
 static mgpu* g_mg = NULL;
+static driver* g_mg_driver = NULL;
+static void mg_finish(mgpu* m, driver* d);
+static int g_mg_cur_tid = -1;          /* the first contig of the claim the main thread is working on */
 
 static void mg_path(const mgpu* m, char* out, size_t cap, const char* what, int idx) { snprintf(out, cap, "%s/%s.%d", m->dir, what, idx); }
 
@@ -2051,6 +2058,7 @@ typedef struct {
     int32_t tid; int64_t rec0, rec1; int32_t pe0, pe1; int fl0, fl1;
     int64_t cn0, cn1; int32_t lm0, lm1;     /* this contig's runs in the counted-read log and the live-minimum log */
     int left_min;                           /* smallest start among the pair-table entries still waiting at the contig's end */
+    int64_t dn0, dn1, sn0, sn1;             /* this contig's runs in the group's name logs (pair-table records; entries left waiting) */
 } gcontig;
 
 typedef struct {
@@ -2064,6 +2072,11 @@ typedef struct {
      * and group_resolve_flushes places them once the contigs before this one have been counted. */
     int32_t *cn_rec, *cn_pos; int64_t n_cn, cap_cn;
     int32_t *lm_rec; int *lm_val; int32_t n_lm, cap_lm;
+    /* The reference keeps ONE pair table for the run (readpairs is never reset): a first mate left waiting in one contig is found
+     * by a record of the same name in a later contig.  Contigs are walked independently here, each with a table of its own, so the
+     * names are logged -- of every record that goes through the table (dn) and of the entries a contig leaves waiting (sn) -- and
+     * the main thread, taking the groups in contig order, hands the run to the record-at-a-time path if they ever meet. */
+    char *dn, *sn; int64_t dn_len, dn_cap, sn_len, sn_cap;
     /* ONE-PASS mode (no config file: the insert lengths are estimated by the same walk, run_pipeline): per-read-group
      * extrema as estimate_insertlengths takes them, the records of not-proper pairs kept aside (the discordant test needs
      * range[1]), and the group's candidate arrays parked in device allocations of their own until the ranges are known */
@@ -2198,14 +2211,14 @@ static void group_reset(pgroup* G)
 {
     G->n_rec = 0; G->n_ctg = 0; G->n_fl = 0; G->n_pe = 0; G->n_cand = 0; G->craw_len = 0; G->n_cn = 0; G->n_lm = 0;
     G->cur_ctg = 0; G->n_rgs = 0; G->n_npp = 0; G->npp_len = 0;
-    G->n_cl = 0; G->n_nodes = 0;
+    G->n_cl = 0; G->n_nodes = 0; G->dn_len = 0; G->sn_len = 0;
 }
 
 static void group_free(pgroup* G)
 {
     free(G->ctg); free(G->fl); free(G->pe); free(G->pe_rec); free(G->cand_rec); free(G->craw_off); free(G->craw);
     free(G->cn_rec); free(G->cn_pos); free(G->lm_rec); free(G->lm_val);
-    free(G->npp_raw); free(G->npp_off); free(G->npp_rec);
+    free(G->npp_raw); free(G->npp_off); free(G->npp_rec); free(G->dn); free(G->sn);
     free(G->res); free(G->s_cls); free(G->cons_sr); free(G->cons_pe);
     free(G->cl_key); free(G->cl_first); free(G->cl_count); free(G->order); free(G->cl_sorted); free(G->ev_cache);
     memset(G, 0, sizeof *G);
@@ -2227,9 +2240,12 @@ static void pipe_harvest(ppipe* P, pgroup* G, pchunk* c)
             if (cls[i] < IM_REC_ERR_RG) continue;
             bam_record b;
             bam_record_view(c->h_raw + c->h_off[i], (int32_t)(c->h_off[i + 1] - c->h_off[i]), &b);
+            /* a record the reference exits on, or one beyond a kernel limit (more than IM_MAX_EV indels of one CIGAR pass the
+             * end-distance rule: check_variants has no such bound, src/indelminer.c:285-337): the record-at-a-time run, whose
+             * CIGAR-derived evidence is made on the host, takes over when the main thread gets to this group */
+            if (t_abort_jmp || g_main_in_walk) { free(cls); walker_bails_out(); }
             if (cls[i] == IM_REC_ERR_LIMIT)
                 fatalf("read %s: more than %d indels in its CIGAR pass the end-distance rule, or the record is malformed (kernel limit IM_MAX_EV)", BAMR_QNAME(&b), IM_MAX_EV);
-            if (t_abort_jmp || g_main_in_walk) { free(cls); walker_bails_out(); }     /* the main thread hands the run over when it gets to this group */
             dispatch_record(P->d, &b);
             fatalf("read %s: record rejected by the device triage (class %d)", BAMR_QNAME(&b), (int)cls[i]);
         }
@@ -2342,10 +2358,29 @@ static void pipe_submit(ppipe* P, pgroup* G)
     P->ck[P->cur].rec_base = G->n_rec;
 }
 
+static void name_log(char** buf, int64_t* len, int64_t* cap, const char* name)
+{
+    const int64_t l = (int64_t)strlen(name) + 1;
+    if (*len + l > *cap) { *cap = (*cap + l) * 2 + 4096; *buf = xrealloc(*buf, (size_t)*cap); }
+    memcpy(*buf + *len, name, (size_t)l);
+    *len += l;
+}
+
+/* the entries a contig leaves waiting in its pair table, by name */
+static void group_log_waiting(const driver* d, pgroup* G, gcontig* cg)
+{
+    cg->sn0 = G->sn_len;
+    for (int32_t i = 0; i < d->n_live; i++) name_log(&G->sn, &G->sn_len, &G->sn_cap, d->live[i]->qname);
+    cg->sn1 = G->sn_len;
+}
+
 /* a record of a not-proper pair through the pair table (src/indelminer.c:516-615); rec = the group's record count with it */
 static void host_discordant(driver* d, pgroup* G, const bam_record* b, int64_t rec)
 {
-    evidence_t* e = discordant_pair(d, b, record_range(d, b));
+    const int32_t* range = record_range(d, b);
+    if (abs(b->isize) > range[1] && (uint32_t)abs(b->isize) < O.maxpedelsize && ((b->flag & 0x10) != 0) != ((b->flag & 0x20) != 0))
+        name_log(&G->dn, &G->dn_len, &G->dn_cap, BAMR_QNAME(b));            /* it is entered in, or looked up in, the table */
+    evidence_t* e = discordant_pair(d, b, range);
     if (e) {
         if (G->n_pe == G->cap_pe) {
             G->cap_pe = G->cap_pe ? G->cap_pe * 2 : 1024;
@@ -2470,13 +2505,30 @@ static void group_resolve_flushes(pgroup* G, int64_t* numread, int* floor)
     }
 }
 
+/* Main thread, groups in contig order: does a record of this group go through the pair table under the name of an entry an
+ * EARLIER contig left waiting?  Then the reference's one table pairs them (or hands the old entry to the new pair's second mate:
+ * its look-up takes the oldest entry of a name, src/hashtable.c:62-81) and the contigs are not independent.  Returns 1 if so. */
+static qhash* g_run_waiting = NULL;
+static int group_meets_earlier_contigs(const pgroup* G)
+{
+    if (!g_run_waiting) g_run_waiting = qhash_new(12);
+    for (int ci = 0; ci < G->n_ctg; ci++) {
+        const gcontig* cg = &G->ctg[ci];
+        for (int64_t at = cg->dn0; at < cg->dn1; at += (int64_t)strlen(G->dn + at) + 1)
+            if (qhash_lookup(g_run_waiting, G->dn + at, (int)strlen(G->dn + at) + 1)) return 1;
+        for (int64_t at = cg->sn0; at < cg->sn1; at += (int64_t)strlen(G->sn + at) + 1)
+            qhash_add(g_run_waiting, G->sn + at, (int)strlen(G->sn + at) + 1, NULL);
+    }
+    return 0;
+}
+
 static void pipe_walk_contig(ppipe* P, pgroup* G, int32_t tid, bgzf_reader* r)
 {
     driver* d = P->d;
     if (G->n_ctg == G->cap_ctg) { G->cap_ctg = G->cap_ctg ? G->cap_ctg * 2 : 32; G->ctg = xrealloc(G->ctg, sizeof(gcontig) * (size_t)G->cap_ctg); }
     gcontig* cg = &G->ctg[G->n_ctg++];
     cg->tid = tid; cg->rec0 = G->n_rec; cg->pe0 = G->n_pe; cg->fl0 = cg->fl1 = 0;
-    cg->cn0 = G->n_cn; cg->lm0 = G->n_lm;
+    cg->cn0 = G->n_cn; cg->lm0 = G->n_lm; cg->dn0 = cg->dn1 = G->dn_len; cg->sn0 = cg->sn1 = G->sn_len;
     G->cur_ctg = G->n_ctg - 1;
     /* the pair table starts empty: what earlier contigs left waiting reaches this one as the marker floor
      * (group_resolve_flushes), not as table entries */
@@ -2512,8 +2564,9 @@ static void pipe_walk_contig(ppipe* P, pgroup* G, int32_t tid, bgzf_reader* r)
         pipe_host_record(d, G, &b);
     }
     cg = &G->ctg[G->n_ctg - 1];
-    cg->rec1 = G->n_rec; cg->pe1 = G->n_pe; cg->cn1 = G->n_cn; cg->lm1 = G->n_lm;
+    cg->rec1 = G->n_rec; cg->pe1 = G->n_pe; cg->cn1 = G->n_cn; cg->lm1 = G->n_lm; cg->dn1 = G->dn_len;
     cg->left_min = find_marker_live(d);
+    group_log_waiting(d, G, cg);
     /* the contig's last records go out now, so that its depth array can be finished behind them */
     pipe_submit(P, G);
     GPU(im_depth_scan(d->gpu, tid, P->stream));
@@ -2661,7 +2714,7 @@ static void pipe_run_group(ppipe* P, pgroup* G)
     memset(G->ev_cache, 0, sizeof(evidence_t*) * (size_t)(nc ? nc : 1) * IM_MAX_EV);
     for (int32_t i = 0; i < nc; i++) {
         const int st = G->res[i].status;
-        if (st == IM_ST_ABORT && g_handoff_pool) pipeline_handoff();
+        if ((st == IM_ST_ABORT || st == IM_ST_OVERFLOW || st == IM_ST_UNSUPPORTED) && g_handoff_pool) pipeline_handoff();
         if (st == IM_ST_ABORT) fatalf("im_dev_realign: read %d: the reference would abort on this input", i);
         if (st == IM_ST_OVERFLOW) fatalf("im_dev_realign: read %d: segment list longer than IM_MAX_OPS", i);
         if (st == IM_ST_UNSUPPORTED) fatalf("im_dev_realign: read %d: longer than IM_MAX_READ=%d", i, IM_MAX_READ);
@@ -2895,83 +2948,209 @@ static void group_replay(driver* d, pgroup* G)
 
 /* ============================================================== multi-GPU == */
 /*
- * One process per GPU (RANK / WORLD_SIZE / LOCAL_RANK in the environment, as torch.distributed.run sets
- * them), contigs sharded tid % world.  Contigs are independent in the reference except for three things that
- * are carried from one contig to the next, and those are what the ranks exchange -- in ONE all-gather (RCCL
- * over xGMI) of fixed-size per-shard summaries, before any rank starts its main pass:
+ * One process per GPU (RANK / WORLD_SIZE / LOCAL_RANK in the environment, as torch.distributed.run sets them).  Contigs
+ * are independent in the reference except for three things that are carried from one contig to the next, and those are
+ * what the ranks exchange -- in ONE all-gather (RCCL over xGMI) of per-rank logs, before any rank starts its main pass:
  *   the global read counter that places the READCHUNK flushes (numread is never reset, src/indelminer.c:617,764)
  *       -> counted reads per contig, so that a rank starts contig c at the single run's count;
- *   the pair table, whose stale entries (first mates whose second mate never comes) lower every later marker
- *       (find_marker, 211-233)  -> the unpaired first mates of every contig (start, |isize|, read group);
+ *   the pair table (516-615), whose stale entries (first mates whose second mate never comes) lower every later marker
+ *       (find_marker, 211-233)  -> EVERY record that may go through the pair table, as an event (position, |isize|, read
+ *       group, first or second mate, name): each rank replays all contigs' events through the table with the final
+ *       insert lengths -- the same adds, look-ups and removals as the walk, exactly, whatever the names and sizes are;
  *   the insert-length table when no config file is given (estimate_insertlengths, src/bamoperations.c:15-86)
  *       -> per read group min / max and where it was first seen, merged in file order.
- * Each rank gets them from ONE pre-walk over its own contigs (the estimation pass the reference runs anyway).
- * Then every rank runs the device pipeline over its contigs, writes one VCF part per contig, and rank 0
+ * Each rank gets them from ONE pre-walk over its own contigs (the estimation pass the reference runs anyway).  Contigs go
+ * to ranks by size (longest first onto the least loaded rank, sizes = compressed bytes from the index).  Then every rank
+ * runs the device pipeline over its contigs, writes one VCF part per contig and a flag file when it is done; rank 0
  * concatenates the parts in contig order behind the header: the single run's bytes.
  */
 
+typedef struct { uint8_t* p; size_t n, cap; } mgbuf;
+static void* mgbuf_take(mgbuf* b, size_t bytes)
+{
+    if (b->n + bytes > b->cap) { b->cap = (b->cap + bytes) * 2 + 4096; b->p = xrealloc(b->p, b->cap); }
+    void* at = b->p + b->n;
+    memset(at, 0, bytes);
+    b->n += bytes;
+    return at;
+}
+
+/* a run that hangs in a collective (a rank died, a stale rendezvous) ends here, not never */
+static volatile double g_mg_deadline = 0;
+static const char* volatile g_mg_waiting_for = "";
+static void* mg_watchdog(void* arg)
+{
+    (void)arg;
+    for (;;) {
+        struct timespec ts = { 0, 200 * 1000 * 1000 };
+        nanosleep(&ts, NULL);
+        const double dl = g_mg_deadline;
+        if (dl > 0 && now_ms() > dl) {
+            fprintf(stderr, "indelminer: rank %d gave up waiting for the other ranks (%s)\n", g_mg_rank, g_mg_waiting_for);
+            _exit(3);
+        }
+    }
+    return NULL;
+}
+static double mg_timeout_ms(void) { const char* e = getenv("INDELMINER_MG_TIMEOUT"); return (e ? atof(e) : 600.0) * 1e3; }
+static void mg_arm(const char* what) { g_mg_waiting_for = what; g_mg_deadline = now_ms() + mg_timeout_ms(); }
+static void mg_disarm(void) { g_mg_deadline = 0; }
+
+/* contigs to ranks: longest first onto the least loaded rank (every rank computes the same plan from the same index) */
+static void mg_plan(mgpu* m, const driver* d)
+{
+    const int32_t nt = d->hdr->n_targets;
+    m->owner = xmalloc(sizeof(int32_t) * (size_t)(nt ? nt : 1));
+    int64_t* w = xmalloc(sizeof(int64_t) * (size_t)(nt ? nt : 1));
+    int32_t* by = xmalloc(sizeof(int32_t) * (size_t)(nt ? nt : 1));
+    for (int32_t t = 0; t < nt; t++) { w[t] = (m->skip && m->skip[t]) ? 0 : bai_contig_bytes(d->idx, t); by[t] = t; }
+    for (int32_t i = 1; i < nt; i++) {                  /* by weight, heaviest first; equal weights in contig order */
+        const int32_t t = by[i]; int32_t j = i - 1;
+        while (j >= 0 && w[by[j]] < w[t]) { by[j + 1] = by[j]; j--; }
+        by[j + 1] = t;
+    }
+    int64_t* load = xcalloc((size_t)m->world, sizeof(int64_t));
+    const char* pl = getenv("INDELMINER_MG_PLAN");
+    for (int32_t i = 0; i < nt; i++) {
+        const int32_t t = by[i];
+        int best = 0;
+        for (int r = 1; r < m->world; r++) if (load[r] < load[best]) best = r;
+        if (pl && strcmp(pl, "modulo") == 0) best = t % m->world;
+        m->owner[t] = best;
+        load[best] += w[t] + 1;                          /* + 1: empty contigs spread out too */
+    }
+    free(w); free(by); free(load);
+}
+
+static void mg_write_flag(const mgpu* m, const char* text);
+static void mg_rank_failed(void)
+{
+    static int once = 0;
+    if (!g_mg || g_mg->dir[0] == 0 || __sync_lock_test_and_set(&once, 1)) return;
+    mg_write_flag(g_mg, "-2\n");
+}
+
+static void mg_write_flag(const mgpu* m, const char* text)
+{
+    char path[512], tmp[520];
+    mg_path(m, path, sizeof path, "done", m->rank);
+    snprintf(tmp, sizeof tmp, "%s.tmp", path);
+    FILE* fp = fopen(tmp, "w");
+    if (!fp) return;
+    fputs(text, fp);
+    fclose(fp);
+    rename(tmp, path);
+}
+
 static void mg_rendezvous(mgpu* m, driver* d)
 {
-    /* the RCCL unique id travels through a file in a directory every rank can see (one node) */
+    /* The RCCL unique id travels through a file in a directory every rank can see (one node).  The directory is this run's
+     * alone: named after the launcher's process (the ranks of one run share a parent) unless the caller names one, emptied
+     * by rank 0 before the id is published, and an id file is believed only if it carries this run's token. */
     const char* dir = getenv("INDELMINER_RENDEZVOUS");
     if (dir) snprintf(m->dir, sizeof m->dir, "%s", dir);
-    else snprintf(m->dir, sizeof m->dir, "/tmp/indelminer_mgpu_%s", getenv("MASTER_PORT") ? getenv("MASTER_PORT") : "0");
+    else snprintf(m->dir, sizeof m->dir, "/tmp/indelminer_mgpu_%s_%ld", getenv("MASTER_PORT") ? getenv("MASTER_PORT") : "0", (long)getppid());
+    pthread_t wd;
+    if (pthread_create(&wd, NULL, mg_watchdog, NULL) == 0) pthread_detach(wd);
     char path[512], tmp[520];
     snprintf(path, sizeof path, "%s/rccl_id", m->dir);
     uint8_t id[IM_COMM_ID_BYTES];
+    /* what the ranks of ONE run share and no other run has: the launcher's run id, port and process (or what the caller says) */
+    char token[96];
+    memset(token, 0, sizeof token);
+    if (getenv("INDELMINER_RUN_TOKEN")) snprintf(token, sizeof token, "%s", getenv("INDELMINER_RUN_TOKEN"));
+    else snprintf(token, sizeof token, "%s:%s:%ld", getenv("TORCHELASTIC_RUN_ID") ? getenv("TORCHELASTIC_RUN_ID") : "", getenv("MASTER_PORT") ? getenv("MASTER_PORT") : "0", (long)getppid());
     if (m->rank == 0) {
         /* no fork() here: the GPU helper thread is inside the HIP runtime's start-up */
         if (mkdir(m->dir, 0700) != 0 && errno != EEXIST) fatalf("cannot create the rendezvous directory %s", m->dir);
         unlink(path);
+        {   /* whatever an earlier run left behind: parts, flags, logs */
+            DIR* dp = opendir(m->dir);
+            if (dp) {
+                struct dirent* de;
+                while ((de = readdir(dp)) != NULL) {
+                    if (strncmp(de->d_name, "part.", 5) != 0 && strncmp(de->d_name, "done.", 5) != 0 && strncmp(de->d_name, "rccl_id", 7) != 0) continue;
+                    char victim[800];
+                    snprintf(victim, sizeof victim, "%s/%s", m->dir, de->d_name);
+                    unlink(victim);
+                }
+                closedir(dp);
+            }
+        }
         snprintf(g_mg_header_path, sizeof g_mg_header_path, "%s/part.header", m->dir);
         gpu_wait(d);                                    /* the HIP runtime is up before librccl is asked for anything */
         if (im_comm_unique_id(id) != IM_OK) fatalf("im_comm_unique_id: %s", im_comm_last_error());
         snprintf(tmp, sizeof tmp, "%s.tmp", path);
         FILE* fp = fopen(tmp, "wb");
-        if (!fp || fwrite(id, 1, sizeof id, fp) != sizeof id) fatalf("cannot write %s", tmp);
+        if (!fp || fwrite(id, 1, sizeof id, fp) != sizeof id || fwrite(token, 1, sizeof token, fp) != sizeof token) fatalf("cannot write %s", tmp);
         fclose(fp);
         if (rename(tmp, path) != 0) fatalf("cannot publish %s", path);
     } else {
         const double t_end = now_ms() + 120e3;
         for (;;) {
+            /* an id file that does not carry this run's token is somebody else's (an earlier run in a re-used directory) */
+            char seen[sizeof token];
             FILE* fp = fopen(path, "rb");
-            if (fp) { const size_t got = fread(id, 1, sizeof id, fp); fclose(fp); if (got == sizeof id) break; }
-            if (now_ms() > t_end) fatalf("rank %d: no RCCL id at %s after 120 s", m->rank, path);
+            if (fp) {
+                const size_t got = fread(id, 1, sizeof id, fp), got2 = fread(seen, 1, sizeof seen, fp);
+                fclose(fp);
+                if (got == sizeof id && got2 == sizeof seen && memcmp(seen, token, sizeof token) == 0) break;
+            }
+            if (now_ms() > t_end) fatalf("rank %d: no RCCL id of this run at %s after 120 s", m->rank, path);
             struct timespec ts = { 0, 20 * 1000 * 1000 };
             nanosleep(&ts, NULL);
         }
     }
     gpu_wait(d);
+    mg_arm("communicator bring-up");
     if (im_comm_init(d->gpu, id, m->rank, m->world, &m->comm) != IM_OK) fatalf("im_comm_init: %s", im_comm_last_error());
+    mg_disarm();
 }
 
-/* every rank contributes `words` int32; all[] receives world * words */
-static void mg_allgather(mgpu* m, driver* d, const int32_t* mine, int32_t* all, size_t words)
+/* every rank contributes `bytes` bytes (a multiple of 4); all[] receives world * bytes */
+static void mg_allgather(mgpu* m, driver* d, const void* mine, void* all, size_t bytes)
 {
     void *ds = NULL, *dr = NULL;
-    if (im_dev_alloc(d->gpu, 4 * words, &ds) != IM_OK || im_dev_alloc(d->gpu, 4 * words * (size_t)m->world, &dr) != IM_OK) fatalf("im_dev_alloc: %s", im_last_error(d->gpu));
-    if (im_dev_upload(d->gpu, ds, mine, 4 * words) != IM_OK) fatalf("im_dev_upload: %s", im_last_error(d->gpu));
+    if (im_dev_alloc(d->gpu, bytes, &ds) != IM_OK || im_dev_alloc(d->gpu, bytes * (size_t)m->world, &dr) != IM_OK) fatalf("im_dev_alloc: %s", im_last_error(d->gpu));
+    if (im_dev_upload(d->gpu, ds, mine, bytes) != IM_OK) fatalf("im_dev_upload: %s", im_last_error(d->gpu));
     void* st = im_ctx_stream(d->gpu);
-    if (im_comm_allgather(m->comm, ds, dr, 4 * words, st) != IM_OK) fatalf("im_comm_allgather: %s", im_comm_last_error());
+    mg_arm("the all-gather of the shard logs");
+    if (im_comm_allgather(m->comm, ds, dr, bytes, st) != IM_OK) fatalf("im_comm_allgather: %s", im_comm_last_error());
     if (im_stream_sync(d->gpu, st) != IM_OK) fatalf("im_stream_sync: %s", im_last_error(d->gpu));
-    if (im_dev_download(d->gpu, all, dr, 4 * words * (size_t)m->world) != IM_OK) fatalf("im_dev_download: %s", im_last_error(d->gpu));
+    mg_disarm();
+    if (im_dev_download(d->gpu, all, dr, bytes * (size_t)m->world) != IM_OK) fatalf("im_dev_download: %s", im_last_error(d->gpu));
     im_dev_free(d->gpu, ds); im_dev_free(d->gpu, dr);
 }
 
-typedef struct { char name[48]; int32_t min, max, first_tid, first_rec; int seen; } mg_rg;
+typedef struct { char name[48]; int32_t min, max, first_tid, first_rec; int32_t seen; } mg_rg;
+
+static int mg_rg_index(mg_rg* rgs, int* pn, const char* rgname)
+{
+    int k = *pn - 1;                                    /* the last one first: records of a library come in runs */
+    while (k >= 0 && strcmp(rgs[k].name, rgname) != 0) k--;
+    if (k >= 0) return k;
+    if (*pn == MG_MAX_RG || strlen(rgname) >= sizeof rgs[0].name) fatalf("at most %d read groups with names under %zu bytes are supported here", MG_MAX_RG, sizeof rgs[0].name);
+    k = (*pn)++;
+    memset(&rgs[k], 0, sizeof rgs[k]);
+    snprintf(rgs[k].name, sizeof rgs[k].name, "%s", rgname);
+    return k;
+}
 
 /* One contig of the pre-walk: insert-length statistics per read group (estimate_insertlengths, src/bamoperations.c:15-86),
- * counted reads, and the first mates left waiting in the pair table.  cw = the contig's MG_CTG_WORDS of an exchange buffer
- * (NULL: statistics only).  Thread-safe: everything it touches is the caller's. */
-static void prewalk_contig(const driver* d, bgzf_reader* r, const bam_header* h, int32_t t, int estimate, mg_rg* rgs, int* pn_rg, int32_t* cw)
+ * counted reads, and the log of the records that may go through the pair table.  out = the rank's exchange buffer (NULL:
+ * statistics only).  Thread-safe: everything it touches is the caller's.
+ * The contig's block: { tid, counted (2 words), events, bytes of events }, then per event { pos, |isize|, record index,
+ * first-mate flag | read group << 8 | name length << 16 } and the name with its NUL, padded to a word. */
+static void prewalk_contig(const driver* d, bgzf_reader* r, const bam_header* h, int32_t t, int estimate, mg_rg* rgs, int* pn_rg, mgbuf* out)
 {
-    int n_rg = *pn_rg;
     bam_region_iter it;
+    size_t head_at = 0;
+    if (out) { head_at = out->n; int32_t* hd = mgbuf_take(out, 20); hd[0] = t; }
     if (bam_region_begin(&it, r, d->idx, t, 0, h->target_len[t]) != 0) return;
-    qhash* waiting = cw ? qhash_new(16) : NULL;         /* unpaired first mates of this contig: name -> {start, |isize|, rg} */
     bam_record b; memset(&b, 0, sizeof b);
     int64_t counted = 0;
-    int32_t rec = 0;
+    int32_t rec = 0, n_ev = 0;
+    const size_t ev_at = out ? out->n : 0;
     while (bam_region_next(&it, &b) == 1) {
         const int flag = b.flag;
         const int32_t this_rec = rec++;
@@ -2980,78 +3159,61 @@ static void prewalk_contig(const driver* d, bgzf_reader* r, const bam_header* h,
             const uint8_t* rg = bam_aux_find(&b, "RG");
             const char* rgname = "generic";
             if (rg) { forceassert(rg[0] == 'Z'); rgname = bam_aux_str(rg); }
-            int k = 0;
-            while (k < n_rg && strcmp(rgs[k].name, rgname) != 0) k++;
-            if (k == n_rg) {
-                if (n_rg == MG_MAX_RG || strlen(rgname) >= sizeof rgs[0].name) fatalf("at most %d read groups with names under %zu bytes are supported here", MG_MAX_RG, sizeof rgs[0].name);
-                snprintf(rgs[k].name, sizeof rgs[k].name, "%s", rgname);
-                rgs[k].min = rgs[k].max = b.isize; rgs[k].first_tid = t; rgs[k].first_rec = this_rec;
-                n_rg++;
-            } else {
-                if (rgs[k].min > b.isize) rgs[k].min = b.isize;
-                if (rgs[k].max < b.isize) rgs[k].max = b.isize;
-            }
+            mg_rg* g = &rgs[mg_rg_index(rgs, pn_rg, rgname)];
+            if (!g->seen) { g->seen = 1; g->min = g->max = b.isize; g->first_tid = t; g->first_rec = this_rec; }
+            else { if (g->min > b.isize) g->min = b.isize; if (g->max < b.isize) g->max = b.isize; }
         }
-        if (!cw) continue;
+        if (!out) continue;
         if (flag & (0x100 | 0x200 | 0x400 | 0x800)) continue;
         if (!(flag & 0x1)) continue;
         const int aligned = !(flag & 0x4), mate_aligned = !(flag & 0x8);
         if (aligned && mate_aligned && b.tid != b.mtid) continue;
         counted++;
-        /* the pair table's bookkeeping, independent of range[1]: both mates of a pair carry the same |isize|, so the
-         * threshold |isize| > range[1] (src/indelminer.c:519) keeps or drops them together -- applied after the exchange */
+        /* what src/indelminer.c:516-522 asks of a record apart from |isize| > range[1], which waits for the final table */
         if (aligned && mate_aligned && !(flag & 0x2) && ((flag & 0x10) != 0) != ((flag & 0x20) != 0) &&
             (uint32_t)abs(b.isize) < O.maxpedelsize) {
-            const char* qname = BAMR_QNAME(&b);
-            if (b.pos < b.mpos) {
-                int32_t* v = xmalloc(3 * sizeof(int32_t));
-                const uint8_t* rg = bam_aux_find(&b, "RG");
-                const char* rgname = rg ? bam_aux_str(rg) : "generic";
-                v[0] = b.pos; v[1] = abs(b.isize);
-                v[2] = (int32_t)djb2_rev(rgname, (int)strlen(rgname));
-                qhash_add(waiting, qname, b.l_qname, v);
-            } else free(qhash_remove(waiting, qname, b.l_qname));
+            const uint8_t* rg = bam_aux_find(&b, "RG");
+            const int gi = mg_rg_index(rgs, pn_rg, rg ? bam_aux_str(rg) : "generic");
+            const size_t nl = (size_t)b.l_qname;
+            int32_t* ev = mgbuf_take(out, 16 + ((nl + 3) & ~(size_t)3));
+            ev[0] = b.pos; ev[1] = abs(b.isize); ev[2] = this_rec;
+            ev[3] = (b.pos < b.mpos ? 1 : 0) | (gi << 8) | ((int32_t)nl << 16);
+            memcpy(ev + 4, BAMR_QNAME(&b), nl);
+            n_ev++;
         }
     }
     free(b.data);
-    *pn_rg = n_rg;
-    if (!cw) return;
-    cw[0] = (int32_t)(counted & 0xffffffff); cw[1] = (int32_t)(counted >> 32);
-    int n_left = 0;
-    for (uint32_t i = 0; i <= waiting->mask; i++)
-        for (qbin* q = waiting->bins[i]; q; q = q->next) {
-            const int32_t* v = q->val;
-            /* keep the MG_MAX_LEFT smallest starts */
-            int pos = n_left < MG_MAX_LEFT ? n_left++ : -1;
-            if (pos < 0) { int worst = 0; for (int k = 1; k < MG_MAX_LEFT; k++) if (cw[4 + 3 * k] > cw[4 + 3 * worst]) worst = k; if (v[0] < cw[4 + 3 * worst]) pos = worst; }
-            if (pos >= 0) { cw[4 + 3 * pos] = v[0]; cw[5 + 3 * pos] = v[1]; cw[6 + 3 * pos] = v[2]; }
-        }
-    cw[2] = n_left;
-    qhash_free(waiting, free);
+    if (!out) return;
+    int32_t* hd = (int32_t*)(out->p + head_at);
+    hd[1] = (int32_t)(counted & 0xffffffff); hd[2] = (int32_t)(counted >> 32); hd[3] = n_ev; hd[4] = (int32_t)(out->n - ev_at);
 }
 
-/* The pre-walk over this rank's contigs.  Fills this rank's words of the exchange buffer. */
-static void mg_prewalk(mgpu* m, driver* d, int estimate, int32_t* mine, size_t words)
+#define MG_MAGIC 0x4d473033
+#define MG_HEAD_WORDS 8         /* magic, read groups, contigs, bytes used (2 words), 3 spare */
+
+/* The pre-walk over this rank's contigs: the rank's log, ready for the exchange. */
+static void mg_prewalk(mgpu* m, driver* d, int estimate, mgbuf* out)
 {
-    memset(mine, 0, 4 * words);
     mg_rg* rgs = xcalloc(MG_MAX_RG, sizeof(mg_rg));
-    int n_rg = 0;
+    int n_rg = 0, n_ctg = 0;
     bgzf_reader* r = bgzf_open(d->bam_name);
     if (!r) fatalf("error in opening the file %s", d->bam_name);
     bam_header* h = bam_header_load(r);
-    for (int32_t t = m->rank; t < h->n_targets; t += m->world) {
-        int32_t* cw = mine + 2 + MG_MAX_RG * MG_RG_WORDS + (size_t)t * MG_CTG_WORDS;
-        cw[3] = 1;                                      /* walked by this rank */
-        if (m->skip && m->skip[t]) continue;
-        prewalk_contig(d, r, h, t, estimate, rgs, &n_rg, cw);
+    mgbuf_take(out, 4 * (MG_HEAD_WORDS + (size_t)MG_MAX_RG * MG_RG_WORDS));
+    for (int32_t t = 0; t < h->n_targets; t++) {
+        if (m->owner[t] != m->rank) continue;
+        n_ctg++;
+        if (m->skip && m->skip[t]) { int32_t* hd = mgbuf_take(out, 20); hd[0] = t; continue; }
+        prewalk_contig(d, r, h, t, estimate, rgs, &n_rg, out);
     }
     bam_header_free(h);
     bgzf_close(r);
-    mine[0] = 0x4d47; mine[1] = n_rg;
+    int32_t* w = (int32_t*)out->p;
+    w[0] = MG_MAGIC; w[1] = n_rg; w[2] = n_ctg; w[3] = (int32_t)(out->n & 0xffffffff); w[4] = (int32_t)((uint64_t)out->n >> 32);
     for (int k = 0; k < n_rg; k++) {
-        int32_t* w = mine + 2 + (size_t)k * MG_RG_WORDS;
-        memcpy(w, rgs[k].name, 48);
-        w[12] = rgs[k].min; w[13] = rgs[k].max; w[14] = rgs[k].first_tid; w[15] = rgs[k].first_rec;
+        int32_t* g = w + MG_HEAD_WORDS + (size_t)k * MG_RG_WORDS;
+        memcpy(g, rgs[k].name, 48);
+        g[12] = rgs[k].min; g[13] = rgs[k].max; g[14] = rgs[k].first_tid; g[15] = rgs[k].first_rec; g[16] = rgs[k].seen;
     }
     free(rgs);
 }
@@ -3128,34 +3290,68 @@ static void estimate_insertlengths_threads(driver* d)
     for (int i = 0; i < nt; i++) { jobs[i].d = d; jobs[i].t0 = i; jobs[i].step = nt; if (pthread_create(&th[i], NULL, est_thread, &jobs[i]) != 0) fatalf("cannot start an estimation thread"); }
     mg_rg* all = xcalloc((size_t)nt * MG_MAX_RG, sizeof(mg_rg));
     int n_all = 0;
-    for (int i = 0; i < nt; i++) { pthread_join(th[i], NULL); for (int k = 0; k < jobs[i].n_rg; k++) all[n_all++] = jobs[i].rgs[k]; }
+    for (int i = 0; i < nt; i++) { pthread_join(th[i], NULL); for (int k = 0; k < jobs[i].n_rg; k++) if (jobs[i].rgs[k].seen) all[n_all++] = jobs[i].rgs[k]; }
     mg_rg* merged = xcalloc((size_t)(n_all ? n_all : 1), sizeof(mg_rg));
     const int n = merge_rgs(all, n_all, merged);
     for (int j = 0; j < n; j++) rg_table_enter(d, &merged[j]);
     free(all); free(merged); free(jobs); free(th);
 }
 
+/* the pair table of the replay: name -> the waiting first mate's start and contig; the entries that wait, for the floor */
+typedef struct { int32_t start, tid, slot; } mg_wait;
+
 /* exchange + merge: the insert-length table (when estimated), the counter prefix and the marker floor of every contig */
 static void mg_exchange(mgpu* m, driver* d, int estimate)
 {
     const int32_t nt = d->hdr->n_targets;
-    const size_t words = 2 + (size_t)MG_MAX_RG * MG_RG_WORDS + (size_t)nt * MG_CTG_WORDS;
-    int32_t* mine = xmalloc(4 * words);
-    int32_t* all = xmalloc(4 * words * (size_t)m->world);
-    mg_prewalk(m, d, estimate, mine, words);
-    phase_time("pre-walk of this rank's contigs (count, unpaired mates, insert lengths)");
-    mg_allgather(m, d, mine, all, words);
+    mgbuf mine = { NULL, 0, 0 };
+    mg_prewalk(m, d, estimate, &mine);
+    phase_time("pre-walk of this rank's contigs (count, pair-table events, insert lengths)");
+    /* ONE all-gather of fixed-size buffers.  Every rank derives the same size from the same file: pair-table events are a few
+     * per thousand records, so a 64th of the file holds them many times over; a rank whose log does not fit says so in its
+     * header and the exchange is repeated once with the size that does (all ranks see all headers: all agree). */
+    size_t cap;
+    {
+        struct stat sb;
+        const int64_t fsize = stat(d->bam_name, &sb) == 0 ? (int64_t)sb.st_size : 0;
+        const char* e = getenv("INDELMINER_MG_LOG_BYTES");
+        int64_t c = e ? atoll(e) : fsize / 64;
+        const int64_t least = 4 * (MG_HEAD_WORDS + (int64_t)MG_MAX_RG * MG_RG_WORDS) + 20 * ((int64_t)nt + 1);
+        if (c < least) c = least;
+        if (!e && c < (4 << 20)) c = 4 << 20;
+        cap = ((size_t)c + 255) & ~(size_t)255;
+    }
+    uint8_t* all = NULL;
+    for (int round = 0; round < 2; round++) {
+        uint8_t* send = xcalloc(cap, 1);
+        memcpy(send, mine.p, mine.n < cap ? mine.n : 4 * (size_t)MG_HEAD_WORDS);     /* too long: the header alone, it says how long */
+        all = xmalloc(cap * (size_t)m->world);
+        mg_allgather(m, d, send, all, cap);
+        free(send);
+        size_t need = 0;
+        for (int rk = 0; rk < m->world; rk++) {
+            const int32_t* a = (const int32_t*)(all + (size_t)rk * cap);
+            forceassert(a[0] == MG_MAGIC);
+            const size_t used = (size_t)(uint32_t)a[3] | ((size_t)(uint32_t)a[4] << 32);
+            if (used > need) need = used;
+        }
+        if (need <= cap) break;
+        if (round == 1) fatalf("internal: the shard logs did not fit the second exchange either");
+        free(all); all = NULL;
+        cap = (need + 255) & ~(size_t)255;
+    }
+    free(mine.p);
     if (estimate) {
         mg_rg* got = xcalloc((size_t)MG_MAX_RG * (size_t)m->world, sizeof(mg_rg));
         int n_got = 0;
         for (int rk = 0; rk < m->world; rk++) {
-            const int32_t* a = all + (size_t)rk * words;
-            forceassert(a[0] == 0x4d47);
+            const int32_t* a = (const int32_t*)(all + (size_t)rk * cap);
             for (int k = 0; k < a[1]; k++) {
-                const int32_t* w = a + 2 + (size_t)k * MG_RG_WORDS;
+                const int32_t* w = a + MG_HEAD_WORDS + (size_t)k * MG_RG_WORDS;
+                if (!w[16]) continue;                   /* met on pair-table records only: not part of the estimate */
                 mg_rg* g = &got[n_got++];
                 memcpy(g->name, w, 48); g->name[47] = 0;
-                g->min = w[12]; g->max = w[13]; g->first_tid = w[14]; g->first_rec = w[15];
+                g->min = w[12]; g->max = w[13]; g->first_tid = w[14]; g->first_rec = w[15]; g->seen = 1;
             }
         }
         mg_rg* rgs = xcalloc((size_t)(n_got ? n_got : 1), sizeof(mg_rg));
@@ -3164,22 +3360,81 @@ static void mg_exchange(mgpu* m, driver* d, int estimate)
         for (int j = 0; j < n; j++) rg_table_enter(d, &rgs[j]);
         free(rgs);
     }
-    m->prefix = xcalloc((size_t)nt + 1, sizeof(int64_t));
-    m->floor = xmalloc(sizeof(int) * ((size_t)nt + 1));
-    int64_t run = 0; int fl = INT_MAX;
-    for (int32_t t = 0; t < nt; t++) {
-        m->prefix[t] = run; m->floor[t] = fl;
-        const int32_t* cw = all + (size_t)(t % m->world) * words + 2 + (size_t)MG_MAX_RG * MG_RG_WORDS + (size_t)t * MG_CTG_WORDS;
-        forceassert(cw[3] == 1);
-        run += (int64_t)(uint32_t)cw[0] | ((int64_t)cw[1] << 32);
-        for (int k = 0; k < cw[2]; k++) {
-            /* stale iff the pair passes src/indelminer.c:519 with its read group's range[1] */
-            int32_t rmax = -1;
-            for (int j = 0; j < g_rg_n; j++) if ((int32_t)djb2_rev(g_rg_name[j], (int)strlen(g_rg_name[j])) == cw[6 + 3 * k]) rmax = g_rg_range[j][1];
-            if (rmax >= 0 && cw[5 + 3 * k] > rmax && cw[4 + 3 * k] < fl) fl = cw[4 + 3 * k];
+    /* where each contig's block lies, and range[1] of every (rank, read group) through the table's own look-up */
+    const int32_t** block = xcalloc((size_t)nt + 1, sizeof(int32_t*));
+    int32_t* rmax = xmalloc(sizeof(int32_t) * (size_t)m->world * MG_MAX_RG);
+    for (int rk = 0; rk < m->world; rk++) {
+        const int32_t* a = (const int32_t*)(all + (size_t)rk * cap);
+        for (int k = 0; k < MG_MAX_RG; k++) rmax[rk * MG_MAX_RG + k] = -1;
+        for (int k = 0; k < a[1]; k++) {
+            char name[48];
+            memcpy(name, a + MG_HEAD_WORDS + (size_t)k * MG_RG_WORDS, 48); name[47] = 0;
+            qbin* hit = qhash_lookup(d->insertlengths, name, (int)strlen(name));
+            if (hit) rmax[rk * MG_MAX_RG + k] = ((int32_t*)hit->val)[1];    /* no entry: the walk stops at that record (must_find_hashtable) */
+        }
+        const int32_t* at = a + MG_HEAD_WORDS + (size_t)MG_MAX_RG * MG_RG_WORDS;
+        for (int c = 0; c < a[2]; c++) {
+            forceassert(at[0] >= 0 && at[0] < nt && m->owner[at[0]] == rk && block[at[0]] == NULL);
+            block[at[0]] = at;
+            at += 5 + at[4] / 4;
         }
     }
-    free(mine); free(all);
+    /* the replay: every contig's events through ONE pair table, in file order, as the single run serves it */
+    m->prefix = xcalloc((size_t)nt + 1, sizeof(int64_t));
+    m->floor = xmalloc(sizeof(int) * ((size_t)nt + 1));
+    qhash* table = qhash_new(16);
+    mg_wait** live = NULL; int32_t n_live = 0, cap_live = 0;
+    int64_t run = 0;
+    for (int32_t t = 0; t < nt; t++) {
+        m->prefix[t] = run;
+        int fl = INT_MAX;
+        for (int32_t i = 0; i < n_live; i++) if (live[i]->start < fl) fl = live[i]->start;
+        m->floor[t] = fl;
+        const int32_t* hd = block[t];
+        forceassert(hd != NULL);
+        run += (int64_t)(uint32_t)hd[1] | ((int64_t)hd[2] << 32);
+        const int32_t* ev = hd + 5;
+        for (int32_t k = 0; k < hd[3]; k++) {
+            const int32_t pos = ev[0], aisize = ev[1], word = ev[3];
+            const int first = word & 1, gi = (word >> 8) & 0xff, nl = (word >> 16) & 0xffff;
+            const char* name = (const char*)(ev + 4);
+            ev += 4 + (nl + 3) / 4;
+            const int32_t r1 = rmax[m->owner[t] * MG_MAX_RG + gi];
+            if (r1 < 0 || aisize <= r1) continue;                                   /* src/indelminer.c:519 */
+            qbin* hb = qhash_lookup(table, name, nl);
+            if (hb && ((mg_wait*)hb->val)->tid != t) m->cross = 1;                  /* an entry of an earlier contig under this name */
+            if (first) {
+                mg_wait* w = xmalloc(sizeof *w);
+                w->start = pos; w->tid = t; w->slot = n_live;
+                qhash_add(table, name, nl, w);
+                if (n_live == cap_live) { cap_live = cap_live ? cap_live * 2 : 256; live = xrealloc(live, sizeof(mg_wait*) * (size_t)cap_live); }
+                live[n_live++] = w;
+            } else {
+                /* not in the table: the mate is fetched from the file, entered and removed at once (537-575, 610-612); in it: removed */
+                mg_wait* w = qhash_remove(table, name, nl);
+                if (w) { live[w->slot] = live[--n_live]; live[w->slot]->slot = w->slot; free(w); }
+            }
+        }
+    }
+    qhash_free(table, free);
+    free(live); free(block); free(rmax); free(all);
+}
+
+static void mg_restore_stdout(mgpu* m) { fflush(stdout); if (m->out_fd >= 0) dup2(m->out_fd, STDOUT_FILENO); }
+
+static void mg_discard_dir(mgpu* m)
+{
+    DIR* dp = opendir(m->dir);
+    if (!dp) return;
+    struct dirent* de;
+    while ((de = readdir(dp)) != NULL) {
+        if (strncmp(de->d_name, "part.", 5) != 0 && strncmp(de->d_name, "done.", 5) != 0 && strncmp(de->d_name, "rccl_id", 7) != 0) continue;
+        char victim[800];
+        snprintf(victim, sizeof victim, "%s/%s", m->dir, de->d_name);
+        unlink(victim);
+    }
+    closedir(dp);
+    rmdir(m->dir);
 }
 
 /* rank 0, at the very end: the parts in contig order behind the header that is already on the real stdout */
@@ -3187,14 +3442,35 @@ static void mg_finish(mgpu* m, driver* d)
 {
     fflush(stdout);
     if (!freopen("/dev/null", "w", stdout)) { }        /* the last part is closed */
-    int32_t one = 1;
-    int32_t* all = xmalloc(4 * (size_t)m->world);
-    mg_allgather(m, d, &one, all, 1);                   /* every rank has closed its parts */
-    free(all);
+    {
+        char text[64];
+        snprintf(text, sizeof text, "%d\n", m->abort_tid);
+        mg_write_flag(m, text);                         /* every part of this rank is complete (up to the contig it names) */
+    }
     if (m->rank == 0) {
+        /* the other ranks' flags: no collective at the end, a rank that is done is done */
+        int first_abort = m->abort_tid >= 0 ? m->abort_tid : INT_MAX;
+        mg_arm("the other ranks' output");
+        for (int rk = 1; rk < m->world; rk++) {
+            char path[512];
+            snprintf(path, sizeof path, "%s/done.%d", m->dir, rk);
+            for (;;) {
+                FILE* fp = fopen(path, "r");
+                int v = 0, got = 0;
+                if (fp) { got = fscanf(fp, "%d", &v) == 1; fclose(fp); }
+                if (got) {
+                    if (v == -2) { fprintf(stderr, "indelminer: rank %d failed\n", rk); _exit(EXIT_FAILURE); }
+                    if (v >= 0 && v < first_abort) first_abort = v;
+                    break;
+                }
+                struct timespec ts = { 0, 5 * 1000 * 1000 };
+                nanosleep(&ts, NULL);
+            }
+        }
+        mg_disarm();
         char path[512], buf[1 << 16];
         int det_blocks = 0;
-        for (int32_t t = -1; t < d->hdr->n_targets; t++) {
+        for (int32_t t = -1; t < d->hdr->n_targets && t < first_abort; t++) {
             if (t < 0) snprintf(path, sizeof path, "%s", g_mg_header_path); else mg_path(m, path, sizeof path, "part", t);
             FILE* fp = fopen(path, "rb");
             if (!fp) continue;                          /* a contig nobody printed for */
@@ -3205,11 +3481,12 @@ static void mg_finish(mgpu* m, driver* d)
                     /* -o detailed: a 0x01 byte stands where a block's number goes (print_det_output) */
                     const char* mark = memchr(buf + off, 1, got - off);
                     const size_t upto = mark ? (size_t)(mark - buf) : got;
-                    while (off < upto) { const ssize_t w = write(m->out_fd, buf + off, upto - off); if (w <= 0) fatalf("write to stdout failed"); off += (size_t)w; }
+                    while (off < upto) { const ssize_t w = write(m->out_fd, buf + off, upto - off); if (w <= 0) fatalf("write to stdout failed"); off += (size_t)w; g_out_bytes += w; }
                     if (mark) {
                         char num[16];
                         const int nl = snprintf(num, sizeof num, "%d", ++det_blocks);
                         if (write(m->out_fd, num, (size_t)nl) != nl) fatalf("write to stdout failed");
+                        g_out_bytes += nl;
                         off++;
                     }
                 }
@@ -3220,9 +3497,16 @@ static void mg_finish(mgpu* m, driver* d)
             if (t < 0) snprintf(path, sizeof path, "%s", g_mg_header_path); else mg_path(m, path, sizeof path, "part", t);
             unlink(path);
         }
+        for (int rk = 0; rk < m->world; rk++) { snprintf(path, sizeof path, "%s/done.%d", m->dir, rk); unlink(path); }
         snprintf(path, sizeof path, "%s/rccl_id", m->dir);
         unlink(path);
         rmdir(m->dir);
+        if (first_abort != INT_MAX) {
+            /* a record the reference dies on, in contig first_abort: what is in front of that contig is out; the
+             * record-at-a-time child prints the rest and dies as the reference does (handoff_to_host_child) */
+            mg_restore_stdout(m);
+            handoff_to_host_child();
+        }
     }
     im_comm_destroy(m->comm);
 }
@@ -3332,14 +3616,15 @@ static int32_t* group_apply_ranges(driver* d, pgroup* G)
             evidence_free(e);
         }
         d->live_changed = 0;
-        cg->pe0 = G->n_pe; cg->lm0 = G->n_lm;
+        cg->pe0 = G->n_pe; cg->lm0 = G->n_lm; cg->dn0 = G->dn_len;
         for (; k < G->n_npp && G->npp_rec[k] <= cg->rec1; k++) {
             bam_record b;
             bam_record_view(G->npp_raw + G->npp_off[k], (int32_t)(G->npp_off[k + 1] - G->npp_off[k]), &b);
             host_discordant(d, G, &b, G->npp_rec[k]);
         }
-        cg->pe1 = G->n_pe; cg->lm1 = G->n_lm;
+        cg->pe1 = G->n_pe; cg->lm1 = G->n_lm; cg->dn1 = G->dn_len;
         cg->left_min = find_marker_live(d);
+        group_log_waiting(d, G, cg);
     }
     return range;
 }
@@ -3469,7 +3754,7 @@ static walkpool_t* walkpool_start(driver* d)
     o->order = xmalloc(sizeof(int32_t) * (size_t)(nt ? nt : 1));
     int64_t total_len = 0;
     for (int32_t i = 0; i < nt; i++) {
-        if (g_mg && i % g_mg->world != g_mg->rank) continue;        /* another rank's contig */
+        if (g_mg && g_mg->owner[i] != g_mg->rank) continue;         /* another rank's contig */
         o->order[o->n_order++] = i;
         total_len += d->hdr->target_len[i];
     }
@@ -3511,6 +3796,10 @@ static void run_pipeline(driver* d, walkpool_t* o)
         /* from here on this thread prints through the counting stream (see handoff_to_host_child) */
         t_out = out_cookie_open();
         if (t_out) g_handoff_pool = o;
+    } else if (g_mg && !getenv("INDELMINER_NO_HANDOFF")) {
+        /* multi-GPU: the parts in front of the contig are complete, rank 0 prints them and starts the child (mg_finish) */
+        g_handoff_pool = o;
+        g_mg_driver = d;
     }
     gpu_wait(d);                    /* the reference is on the device */
     pipe_global_init(d);
@@ -3578,6 +3867,7 @@ static void run_pipeline(driver* d, walkpool_t* o)
     int floor_ = d->marker_floor;
     for (int ci = 0; ci < o->n_claims; ci++) {
         claim_t* c = &o->claims[ci];
+        g_mg_cur_tid = o->order[c->first];
         if (o->serial) {
             /* walked here, after the replay of the previous contig let go of the known-variant list */
             const int32_t tid = o->order[c->first];
@@ -3606,6 +3896,10 @@ static void run_pipeline(driver* d, walkpool_t* o)
             W = &o->w[0];
             group_unpark_device(&W->P, G, G->sv_range);
             free(G->sv_range); G->sv_range = NULL;
+        }
+        if (!g_mg && group_meets_earlier_contigs(G)) {
+            if (g_handoff_pool) pipeline_handoff();
+            fatalf("read names are shared between contigs (the reference pairs them across contigs in its one pair table): run with INDELMINER_PIPELINE=host");
         }
         group_resolve_flushes(G, &numread, &floor_);
         pipe_run_group(&W->P, G);
@@ -3652,7 +3946,7 @@ static void run_pipeline(driver* d, walkpool_t* o)
         free(rp); free(o->jobs);
     }
     d->numread = numread;
-    if (g_handoff_pool) { g_handoff_pool = NULL; fflush(t_out); fclose(t_out); t_out = NULL; }
+    if (g_handoff_pool) { g_handoff_pool = NULL; if (t_out) { fflush(t_out); fclose(t_out); t_out = NULL; } }
     for (int i = 0; i < o->nw && !o->serial && !g_onepass; i++) pthread_join(o->w[i].th, NULL);
     /* the walkers' pinned rings and device arrays go with the process unless a tidy exit is asked for (leak checkers):
      * un-pinning and freeing them costs more than the whole device stage of a run */
@@ -3676,6 +3970,14 @@ static void run_pipeline(driver* d, walkpool_t* o)
 static void pipeline_handoff(void)
 {
     walkpool_t* o = g_handoff_pool;
+    if (g_mg) {
+        /* this rank's parts in front of the claim it is working on are complete; the flag names the claim's first contig and
+         * rank 0, once every rank has reported, prints what lies in front of the smallest such contig and hands over */
+        g_mg->abort_tid = g_mg_cur_tid;
+        mg_finish(g_mg, g_mg_driver);           /* rank 0 does not come back from this */
+        fflush(stderr);
+        _exit(EXIT_SUCCESS);
+    }
     if (o->jobs) {
         pthread_mutex_lock(&o->mu);
         while (o->printed < o->n_jobs) {
@@ -3907,6 +4209,17 @@ int main(int argc, char** argv)
             fflush(stdout);
             mg.out_fd = dup(1);
             if (mg.out_fd < 0 || dup2(2, 1) < 0) fatalf("cannot redirect stdout");
+            mg.abort_tid = -1;
+            if (g_vcfname != NULL) {
+                /* annotate mode walks only the contigs the variant file names (src/indelminer.c:788) */
+                mg.skip = xcalloc((size_t)d.hdr->n_targets, 1);
+                for (int32_t i = 0; i < d.hdr->n_targets; i++) {
+                    known_free(&g_known);
+                    read_variants(g_vcfname, i, d.hdr->target_name[i], &g_known);
+                    mg.skip[i] = g_known.n == 0;
+                }
+            }
+            mg_plan(&mg, &d);                   /* before the walkers are planned: they take this rank's contigs */
         }
     }
     d.marker_floor = INT_MAX;
@@ -3958,17 +4271,19 @@ int main(int argc, char** argv)
     const char* pl = getenv("INDELMINER_PIPELINE");
     const int use_pipeline = chromid == -1 && !(pl && strcmp(pl, "host") == 0);
     if (g_mg) {
-        if (g_vcfname != NULL) {
-            /* annotate mode walks only the contigs the variant file names (src/indelminer.c:788) */
-            mg.skip = xcalloc((size_t)d.hdr->n_targets, 1);
-            for (int32_t i = 0; i < d.hdr->n_targets; i++) {
-                known_free(&g_known);
-                read_variants(g_vcfname, i, d.hdr->target_name[i], &g_known);
-                mg.skip[i] = g_known.n == 0;
-            }
-        }
         mg_rendezvous(&mg, &d);
         mg_exchange(&mg, &d, O.configfile == NULL);
+        if (mg.cross) {
+            /* A first mate left waiting in one contig meets a record of the same name in a later one: the reference's one
+             * pair table pairs them across contigs (readpairs is never reset, src/indelminer.c), so the contigs of this
+             * input are not independent.  Every rank sees that in the exchanged logs; the run goes to ONE process that
+             * serves one table record by record, the other ranks have nothing to add. */
+            if (mg.rank != 0) { im_comm_destroy(mg.comm); fflush(stderr); _exit(EXIT_SUCCESS); }
+            fprintf(stderr, "indelminer: read names are shared between contigs (pairs across contigs in the one pair table): one process takes the run\n");
+            mg_discard_dir(&mg);
+            mg_restore_stdout(&mg);
+            handoff_to_host_child();
+        }
         if (O.configfile == NULL && mg.rank == 0) {
             fprintf(stderr, "\nRead-group\tMin-value\tMax-value (estimated over all ranks' contigs)\n");
             for (int j = 0; j < g_rg_n; j++) fprintf(stderr, "%s\t%d\t%d\n", g_rg_name[j], g_rg_range[j][0], g_rg_range[j][1]);

@@ -435,6 +435,80 @@ def _stale_dir(tmp_path, ref_len=250_000):
     return str(tmp_path)
 
 
+def _apply_keep(rd, keep):
+    import numpy as np
+    for name, col in list(vars(rd).items()):
+        if isinstance(col, np.ndarray) and len(col) == len(keep):
+            setattr(rd, name, col[keep])
+    rd.n = int(keep.sum())
+
+
+def _many_waiting_dir(tmp_path, ref_len=250_000):
+    """contig 0 leaves more than forty first mates waiting in the pair table's bookkeeping whose |isize| does NOT pass
+    src/indelminer.c:519 (ordinary pairs made 'not proper', second mate removed), all in front of the few that do pass
+    and really pin the later markers: a summary that keeps 'the 32 smallest starts' loses the real ones"""
+    import numpy as np
+    from indelminer_amd import bamwrite, rawrec, synth
+    refs, rd = synth.simulate(seed=52, ref_len=ref_len, coverage=30, n_contigs=4, big_every=3)
+    both = ((rd.flag & 0x4) == 0) & ((rd.flag & 0x8) == 0)
+    proper_first = both & ((rd.flag & 0x2) != 0) & (rd.tid == 0) & (rd.pos < rd.mpos) & (rd.pos < 30_000) & (((rd.flag & 0x10) != 0) != ((rd.flag & 0x20) != 0))
+    pick = np.nonzero(proper_first)[0][::7][:60]
+    assert len(pick) >= 45
+    ids = set(rd.pair_id[pick].tolist())
+    in_pick = np.isin(rd.pair_id, list(ids)) & (rd.tid == 0)
+    rd.flag = np.where(in_pick, rd.flag & ~0x2, rd.flag).astype(rd.flag.dtype)
+    drop = in_pick & (rd.pos > rd.mpos)
+    real = both & ((rd.flag & 0x2) == 0) & ~in_pick & (rd.pos > rd.mpos) & (rd.pair_id % 2 == 0) & np.isin(rd.tid, [0, 1]) & (rd.mpos > 40_000)
+    assert real.sum() >= 5
+    _apply_keep(rd, ~(drop | real))
+    contigs = [("ctg%d" % i, len(r)) for i, r in enumerate(refs)]
+    bamwrite.write_fasta(str(tmp_path / "ref.fa"), contigs, refs)
+    rawrec.write_bam_fast(str(tmp_path / "aln.bam"), contigs, rd)
+    open(str(tmp_path / "cfg.txt"), "w").write("IL generic 300 %d\n" % rd.range_max)
+    return str(tmp_path)
+
+
+def _shared_names_dir(tmp_path, ref_len=200_000):
+    """a first mate left waiting in contig 0 and a complete discordant pair under the SAME name in contig 2: the reference's
+    one pair table (readpairs is never reset) hands the old entry to the new pair's second mate"""
+    import numpy as np
+    from indelminer_amd import bamwrite, rawrec, synth
+    refs, rd = synth.simulate(seed=53, ref_len=ref_len, coverage=30, n_contigs=3, big_every=3)
+    both = ((rd.flag & 0x4) == 0) & ((rd.flag & 0x8) == 0)
+    disc = both & ((rd.flag & 0x2) == 0) & (((rd.flag & 0x10) != 0) != ((rd.flag & 0x20) != 0)) & (np.abs(rd.isize) > rd.range_max)
+    a = np.nonzero(disc & (rd.tid == 0) & (rd.pos < rd.mpos))[0]
+    c = np.nonzero(disc & (rd.tid == 2) & (rd.pos < rd.mpos))[0]
+    assert len(a) >= 3 and len(c) >= 3
+    lost, twin = int(rd.pair_id[a[1]]), int(rd.pair_id[c[1]])
+    drop = (rd.pair_id == lost) & (rd.tid == 0) & (rd.pos > rd.mpos)        # contig 0: the second mate never comes
+    rd.pair_id = np.where((rd.pair_id == twin) & (rd.tid == 2), lost, rd.pair_id).astype(rd.pair_id.dtype)     # contig 2: same name
+    _apply_keep(rd, ~drop)
+    contigs = [("ctg%d" % i, len(r)) for i, r in enumerate(refs)]
+    bamwrite.write_fasta(str(tmp_path / "ref.fa"), contigs, refs)
+    rawrec.write_bam_fast(str(tmp_path / "aln.bam"), contigs, rd)
+    return str(tmp_path)
+
+
+def test_host_names_shared_between_contigs_go_to_the_one_table(tmp_path):
+    """the pipeline walks contigs independently; when a record goes through the pair table under the name of an entry an
+    earlier contig left waiting, the run is handed to the record-at-a-time path, which keeps the reference's one table"""
+    d = _shared_names_dir(tmp_path)
+    shim = _build_shim()
+    want = _run(shim, [], d, ref="ref.fa", bam="aln.bam", env={"INDELMINER_PIPELINE": "host"})
+    ref_bin = os.path.join(ROOT, "oracle", "_ref", "indelminer")
+    if os.path.exists(ref_bin):
+        # the compiled reference pairs them too -- and on this input dies of SIGSEGV while it prints the evidence it made of reads
+        # of two contigs; where it survives, its bytes are the record-at-a-time path's
+        r = subprocess.run([ref_bin, "ref.fa", "sample=aln.bam"], cwd=d, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+        assert r.returncode < 0 or r.stdout == want
+    for env in ({}, {"INDELMINER_WALKERS": "3", "INDELMINER_CLAIM_BASES": "1"}, {"INDELMINER_ONEPASS": "1"}):
+        assert _run(shim, [], d, ref="ref.fa", bam="aln.bam", env=env) == want, env
+    # and without the hand-over the run says why it stops instead of printing something else
+    e = dict(os.environ, INDELMINER_NO_HANDOFF="1")
+    r = subprocess.run([shim, "ref.fa", "s=aln.bam"], cwd=d, stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=e)
+    assert r.returncode != 0 and b"shared between contigs" in r.stderr
+
+
 def test_host_stale_pair_table_entries_pin_the_markers(tmp_path):
     """first mates of discordant pairs whose second mate never comes stay in the reference's pair table for the rest of the
     run and pin every later flush marker at their start (find_marker, src/indelminer.c:211-233) -- also in LATER contigs.
