@@ -1,0 +1,185 @@
+#!/usr/bin/env python3
+"""BASELINE configs[3] on ONE MI355X: a 3 Gb reference in 24 contigs with the human length spread, 100 bp pairs at the stated
+coverage, generated on the box by tests/support/simgen.c (nothing of that size travels), through the product CLI.
+
+    python3 profiles/wgs_run.py [--total 3000000000] [--coverage 30] [--dir /tmp/wgs] [--variants ...] [--cpu-contig 20]
+
+Reports (one JSON object, also written to gpurun_out/<tag>.json):
+  * generation: records, BAM bytes, seconds
+  * per product run (config file / estimated insert lengths / one-pass / walker counts): wall seconds, delivered reads per second,
+    peak resident memory of the process, the [timing] phases the driver prints, md5 of the VCF, number of records
+  * properties: the md5 is the same in every mode; recall of the planted events in the VCF
+  * the CPU side on the same box: tests/shim/indelminer_shim (the host driver over the CPU oracle, i.e. the reference's path
+    without its per-candidate strlen of the contig) on ONE contig with -c, one process, and eight processes on eight contigs
+    at once (the reference's only parallel mode, src/indelminer.c:536-542), in delivered reads per second
+  * one whole contig of the product's VCF against that shim run (same bytes, when the contig's flush points coincide: -c runs
+    start the read counter at zero, so the comparison is made on the contig that the whole run also starts at zero: contig 0
+    when --cpu-contig 0, otherwise on the set of records)
+"""
+import argparse
+import bisect
+import hashlib
+import json
+import os
+import re
+import resource
+import subprocess
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def build_simgen():
+    out = os.path.join(ROOT, "tests", "support", "simgen")
+    src = out + ".c"
+    if not os.path.exists(out) or os.path.getmtime(out) < os.path.getmtime(src):
+        subprocess.check_call(["gcc", "-O2", "-std=gnu11", "-pthread", "-o", out, src, "-lz", "-lm"])
+    return out
+
+
+def run_timed(cmd, cwd, env=None, stdout_path=None):
+    e = dict(os.environ)
+    e.update(env or {})
+    t = time.perf_counter()
+    with open(stdout_path, "wb") if stdout_path else open(os.devnull, "wb") as fo:
+        p = subprocess.Popen(cmd, cwd=cwd, stdout=fo, stderr=subprocess.PIPE, env=e)
+        _, err = p.communicate()
+        ru = resource.getrusage(resource.RUSAGE_CHILDREN)
+    return p.returncode, time.perf_counter() - t, err.decode(errors="replace"), ru
+
+
+def md5_of(path):
+    h = hashlib.md5()
+    n = 0
+    with open(path, "rb") as fh:
+        for block in iter(lambda: fh.read(1 << 22), b""):
+            h.update(block)
+    with open(path, "rb") as fh:
+        for line in fh:
+            n += not line.startswith(b"#")
+    return h.hexdigest(), n
+
+
+def recall(truth_path, vcf_path, tol=60):
+    by = {}
+    with open(vcf_path) as fh:
+        for line in fh:
+            if line.startswith("#"):
+                continue
+            c = line.split("\t", 3)
+            by.setdefault(c[0], []).append(int(c[1]))
+    for v in by.values():
+        v.sort()
+    hit = tot = 0
+    with open(truth_path) as fh:
+        for line in fh:
+            t, pos, size, kind = line.split()
+            a = by.get("ctg" + t, [])
+            i = bisect.bisect_left(a, int(pos) - tol)
+            hit += i < len(a) and a[i] <= int(pos) + tol
+            tot += 1
+    return hit, tot
+
+
+def phases(err):
+    out = []
+    for m in re.finditer(r"\[timing\] (.*?)\s+([0-9.]+) ms", err):
+        out.append((m.group(1).strip(), float(m.group(2))))
+    agg = {}
+    for k, v in out:
+        agg[k] = agg.get(k, 0.0) + v
+    return {k: round(v, 1) for k, v in agg.items()}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--total", type=int, default=3_000_000_000)
+    ap.add_argument("--coverage", type=float, default=30.0)
+    ap.add_argument("--dir", default="/tmp/wgs")
+    ap.add_argument("--threads", type=int, default=16)
+    ap.add_argument("--tag", default="r03_wgs")
+    ap.add_argument("--variants", default="config,estimate", help="comma list of: config, estimate, onepass, walkers8, walkers1")
+    ap.add_argument("--cpu-contig", type=int, default=20, help="contig for the CPU shim baseline (-1: skip)")
+    ap.add_argument("--keep", action="store_true")
+    args = ap.parse_args()
+    from indelminer_amd import build
+    build.build(); prod = os.environ.get("IM_WGS_PRODUCT") or build.build_host()
+    os.makedirs(args.dir, exist_ok=True)
+    out = {"workload": "BASELINE configs[3]: %.2f Gb in 24 contigs (human length spread), 100 bp PE at %gx, seeded 1-50 bp indels every ~2 kb"
+                       % (args.total / 1e9, args.coverage)}
+    gen = build_simgen()
+    t = time.perf_counter()
+    g = subprocess.run([gen, "--prefix", os.path.join(args.dir, "w"), "--human", str(args.total), "--coverage", str(args.coverage),
+                        "--threads", str(args.threads), "--seed", "3"], stdout=subprocess.PIPE, check=True)
+    out["generation"] = json.loads(g.stdout.decode())
+    out["generation"]["wall_s"] = round(time.perf_counter() - t, 2)
+    n_reads = out["generation"]["records"]
+    print("generated", out["generation"], file=sys.stderr, flush=True)
+    variants = {
+        "config": (["-i", "w.cfg"], {}),
+        "estimate": ([], {}),
+        "onepass": ([], {"INDELMINER_ONEPASS": "1"}),
+        "walkers8": (["-i", "w.cfg"], {"INDELMINER_WALKERS": "8"}),
+        "walkers1": (["-i", "w.cfg"], {"INDELMINER_WALKERS": "1"}),
+        "threads2": (["-i", "w.cfg"], {"INDELMINER_WALKERS": "8", "INDELMINER_THREADS": "2"}),
+    }
+    runs = {}
+    for name in [v for v in args.variants.split(",") if v]:
+        flags, env = variants[name]
+        vcf = os.path.join(args.dir, "out_%s.vcf" % name)
+        env = dict(env, INDELMINER_TIMING="1")
+        rc, wall, err, ru = run_timed([prod] + flags + ["w.fa", "s=w.bam"], args.dir, env, vcf)
+        md5, nrec = md5_of(vcf) if rc == 0 else (None, 0)
+        runs[name] = {"rc": rc, "wall_s": round(wall, 2), "reads_per_s": n_reads / wall if rc == 0 else None, "vcf_md5": md5, "vcf_records": nrec,
+                      "max_rss_gb_of_any_child_so_far": round(ru.ru_maxrss / 1e6, 2), "phases_ms": phases(err), "stderr_tail": err[-600:] if rc else ""}
+        print(name, runs[name], file=sys.stderr, flush=True)
+    out["product"] = runs
+    md5s = {r["vcf_md5"] for r in runs.values() if r["rc"] == 0}
+    out["same_vcf_in_every_mode"] = len(md5s) == 1 and all(r["rc"] == 0 for r in runs.values())
+    first = next((n for n, r in runs.items() if r["rc"] == 0), None)
+    if first:
+        hit, tot = recall(os.path.join(args.dir, "w.truth.tsv"), os.path.join(args.dir, "out_%s.vcf" % first))
+        out["recall_of_planted_events"] = {"found": hit, "planted": tot, "fraction": hit / max(tot, 1)}
+    if args.cpu_contig >= 0:
+        import tests.test_host_driver as th
+        shim = th._build_shim()
+        lens = out["generation"]["lens"]
+        frac = [x / sum(lens) for x in lens]
+        c = args.cpu_contig
+        vcf = os.path.join(args.dir, "cpu_one.vcf")
+        rc, wall, err, ru = run_timed([shim, "-i", "w.cfg", "-c", "ctg%d" % c, "w.fa", "s=w.bam"], args.dir, {"INDELMINER_PIPELINE": "host"}, vcf)
+        reads_c = n_reads * frac[c]
+        # the FASTA of the whole genome is read by every process (the reference does the same): reported with and without it
+        out["cpu_baseline_shim"] = {"what": "tests/shim/indelminer_shim (host driver over oracle/, no contig strlen) -c ctg%d, 1 process" % c,
+                                    "rc": rc, "wall_s": round(wall, 2), "reads": int(reads_c), "reads_per_s": reads_c / wall}
+        procs, t0 = [], time.perf_counter()
+        pick = sorted(range(len(lens)), key=lambda i: lens[i])[:8]
+        for i in pick:
+            procs.append(subprocess.Popen([shim, "-i", "w.cfg", "-c", "ctg%d" % i, "w.fa", "s=w.bam"], cwd=args.dir, stdout=subprocess.DEVNULL,
+                                          stderr=subprocess.DEVNULL, env=dict(os.environ, INDELMINER_PIPELINE="host")))
+        for p in procs:
+            p.wait()
+        wall8 = time.perf_counter() - t0
+        reads8 = n_reads * sum(frac[i] for i in pick)
+        out["cpu_baseline_shim_8_processes"] = {"contigs": pick, "wall_s": round(wall8, 2), "reads": int(reads8), "reads_per_s": reads8 / wall8}
+        if first:
+            body = lambda path, name: sorted(l for l in open(path) if l.startswith(name + "\t"))
+            a = body(os.path.join(args.dir, "out_%s.vcf" % first), "ctg%d" % c)
+            b = body(vcf, "ctg%d" % c)
+            out["contig_%d_product_vs_cpu_shim" % c] = {"records_product": len(a), "records_cpu": len(b), "same_set_of_records": a == b}
+        if first:
+            out["ratio_product_over_cpu_1_process"] = runs[first]["reads_per_s"] / out["cpu_baseline_shim"]["reads_per_s"]
+            out["ratio_product_over_cpu_8_processes"] = runs[first]["reads_per_s"] / out["cpu_baseline_shim_8_processes"]["reads_per_s"]
+    os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+    with open(os.path.join(ROOT, "gpurun_out", args.tag + ".json"), "w") as fh:
+        json.dump(out, fh, indent=1)
+    print(json.dumps(out))
+    if not args.keep:
+        for f in os.listdir(args.dir):
+            os.unlink(os.path.join(args.dir, f))
+
+
+if __name__ == "__main__":
+    main()
