@@ -12,6 +12,8 @@
 #include <string.h>
 #include <zlib.h>
 
+#include "iminflate.h"
+
 /* ------------------------------------------------------------------ BGZF -- */
 /*
  * Sequential reads run through a read-ahead ring: the reading thread fetches the compressed blocks
@@ -30,7 +32,7 @@ enum { SLOT_FREE = 0, SLOT_LOADED, SLOT_BUSY, SLOT_DONE, SLOT_BAD };
 
 typedef struct {
     uint8_t  cbuf[BGZF_MAX_BLOCK + 64];
-    uint8_t  ubuf[BGZF_MAX_BLOCK];
+    uint8_t  ubuf[BGZF_MAX_BLOCK + IM_INFLATE_SLACK];
     int64_t  coff;
     int32_t  total, hdr, ulen;
     int      state;
@@ -39,7 +41,7 @@ typedef struct {
 struct bgzf_reader {
     FILE*    fp;
     uint8_t  cbuf[BGZF_MAX_BLOCK + 64];
-    uint8_t  ubuf[BGZF_MAX_BLOCK];
+    uint8_t  ubuf[BGZF_MAX_BLOCK + IM_INFLATE_SLACK];
     int32_t  ulen, upos;
     int64_t  block_coff;        /* file offset of the block in ubuf */
     int64_t  next_coff;         /* file offset of the next block */
@@ -101,10 +103,21 @@ static int bgzf_fetch(FILE* fp, int64_t coff, uint8_t* h, int* phdr)
     return total;
 }
 
-/* raw-deflate payload of a fetched block -> ubuf; returns the inflated size or -1 */
+/* raw-deflate payload of a fetched block -> ubuf (BGZF_MAX_BLOCK + IM_INFLATE_SLACK bytes); returns the inflated size or -1.
+ * The driver's own decoder (iminflate.c); INDELMINER_INFLATE=zlib takes zlib's instead (a cross-check). */
+static int g_use_zlib = -1;
 static int bgzf_inflate(const uint8_t* h, int total, int hdr, uint8_t* ubuf)
 {
     const int clen = total - hdr - 8;
+    if (g_use_zlib < 0) { const char* e = getenv("INDELMINER_INFLATE"); g_use_zlib = e && strcmp(e, "zlib") == 0; }
+    if (!g_use_zlib) {
+        /* the block's trailer (CRC32, ISIZE) and the buffer's spare bytes follow the payload: the decoder's look-ahead stays inside */
+        const uint8_t* tr = h + total - 8;
+        const uint32_t isize = (uint32_t)tr[4] | ((uint32_t)tr[5] << 8) | ((uint32_t)tr[6] << 16) | ((uint32_t)tr[7] << 24);
+        if (isize > BGZF_MAX_BLOCK) return -1;
+        const int64_t got = im_inflate(h + hdr, (size_t)clen, ubuf, BGZF_MAX_BLOCK);
+        return got == (int64_t)isize ? (int)got : -1;
+    }
     z_stream zs;
     memset(&zs, 0, sizeof zs);
     if (inflateInit2(&zs, -15) != Z_OK) return -1;

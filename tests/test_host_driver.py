@@ -35,6 +35,7 @@ FLAG_MATRIX = {
 
 def _build_shim():
     srcs = [os.path.join(ROOT, "indelminer_amd", "host", "imhost.c"), os.path.join(ROOT, "indelminer_amd", "host", "hostio.c"),
+            os.path.join(ROOT, "indelminer_amd", "host", "iminflate.c"),
             os.path.join(ROOT, "tests", "shim", "im_shim.c"), os.path.join(ROOT, "oracle", "im_oracle.c"),
             os.path.join(ROOT, "oracle", "im_oracle_triage.c")]
     if os.path.exists(SHIM) and all(os.path.getmtime(s) <= os.path.getmtime(SHIM) for s in srcs):
