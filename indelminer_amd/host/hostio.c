@@ -522,6 +522,31 @@ int bam_region_begin(bam_region_iter* it, bgzf_reader* r, const bai_index* idx, 
     return 0;
 }
 
+int bam_piece_begin(bam_region_iter* it, bgzf_reader* r, const bai_index* idx, int32_t tid, int32_t beg, int32_t end)
+{
+    const int rc = bam_region_begin(it, r, idx, tid, beg, end);
+    it->by_start = 1;
+    return rc;
+}
+
+int bai_split_points(const bai_index* idx, int32_t tid, int32_t length, int64_t target_bytes, int32_t* out, int cap)
+{
+    if (!idx || tid < 0 || tid >= idx->n_ref || target_bytes <= 0) return 0;
+    const bai_ref* br = &idx->ref[tid];
+    if (br->first_chunk == 0 || br->n_intv < 2) return 0;
+    const int64_t first = (int64_t)(br->first_chunk >> 16);
+    int n = 0;
+    int64_t next = target_bytes;
+    for (int32_t w = 1; w < br->n_intv && n < cap; w++) {
+        if (br->ioffset[w] == 0) continue;
+        const int64_t at = (int64_t)(br->ioffset[w] >> 16) - first;
+        const int64_t pos = (int64_t)w << 14;
+        if (pos >= length) break;
+        if (at >= next) { out[n++] = (int32_t)pos; next = at + target_bytes; }
+    }
+    return n;
+}
+
 int bam_region_next(bam_region_iter* it, bam_record* b)
 {
     while (!it->done) {
@@ -530,7 +555,7 @@ int bam_region_next(bam_region_iter* it, bam_record* b)
         if (b->tid != it->tid || b->pos >= it->end) { it->done = 1; return 0; }   /* bam_index.c:704-707 */
         const uint32_t rbeg = (uint32_t)b->pos;
         const uint32_t rend = b->n_cigar ? (uint32_t)bam_record_end(b) : (uint32_t)b->pos + 1u;   /* bam_index.c:571-576 */
-        if (rend > (uint32_t)it->beg && rbeg < (uint32_t)it->end) return 1;
+        if (it->by_start ? (rbeg >= (uint32_t)it->beg && rbeg < (uint32_t)it->end) : (rend > (uint32_t)it->beg && rbeg < (uint32_t)it->end)) return 1;
     }
     return 0;
 }
@@ -574,7 +599,7 @@ int bam_region_next_raw(bam_region_iter* it, uint8_t* dst, int64_t cap, int32_t*
         if (32 + (int64_t)view->l_qname + 4 * (int64_t)view->n_cigar > bs) { it->done = 1; return -1; }
         const uint32_t rbeg = (uint32_t)view->pos;
         const uint32_t rend = view->n_cigar ? (uint32_t)bam_record_end(view) : (uint32_t)view->pos + 1u;
-        if (rend > (uint32_t)it->beg && rbeg < (uint32_t)it->end) { *len_out = bs; return 1; }
+        if (it->by_start ? (rbeg >= (uint32_t)it->beg && rbeg < (uint32_t)it->end) : (rend > (uint32_t)it->beg && rbeg < (uint32_t)it->end)) { *len_out = bs; return 1; }
     }
     return 0;
 }

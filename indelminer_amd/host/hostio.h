@@ -64,9 +64,16 @@ typedef struct {
     int32_t tid, beg, end;
     int done;
     int32_t pending_size;   /* block_size of a record whose body has not been read yet (bam_region_next_raw) */
+    int by_start;           /* 1: the records that START in [beg, end) (bam_piece_begin), not the ones that overlap it */
 } bam_region_iter;
 int bam_region_begin(bam_region_iter* it, bgzf_reader* r, const bai_index* idx, int32_t tid, int32_t beg, int32_t end);
 int bam_region_next(bam_region_iter* it, bam_record* b);   /* 1 = record, 0 = done, -1 = error */
+/* A PIECE of a contig: every record of tid whose position lies in [beg, end), in file order -- consecutive pieces
+ * [0, a), [a, b), ..., [z, length) deliver exactly the records, in the order, that bam_region_begin(tid, 0, length) does */
+int bam_piece_begin(bam_region_iter* it, bgzf_reader* r, const bai_index* idx, int32_t tid, int32_t beg, int32_t end);
+/* split points for pieces of about equal file size: positions (multiples of 16 kb) where the contig's compressed bytes
+ * cross k * target; out[] receives up to cap of them, ascending, each in (0, length).  Returns how many. */
+int bai_split_points(const bai_index* idx, int32_t tid, int32_t length, int64_t target_bytes, int32_t* out, int cap);
 /* The same iteration, but the record's bytes (32-byte core + variable part, as in the file, without the
  * block_size word) land in the caller's buffer dst[0..cap) -- the host driver points it into a pinned chunk
  * that goes to the GPU as it is.  view receives the decoded core and view->data = dst + 32 (not owned).

@@ -438,6 +438,7 @@ static int check_variants(const seglist* rln, char strand, uint8_t qual, const c
 /* ------------------------------------------------------------------ pass A -- */
 
 enum { ITEM_CAND = 1, ITEM_PE = 2 };
+#define EV_PHANTOM (-1)         /* a paired-read entry of a stage that stands for the entries waiting for the contig's end (stage_leftovers) */
 
 typedef struct {
     int kind;
@@ -2052,45 +2053,71 @@ typedef struct {
 } pchunk;
 
 typedef struct { int64_t rec; int32_t pe; int marker; int32_t tid; } gflush;
-typedef struct { char name[48]; int32_t min, max, first_tid, first_rec; } rgstat_t;
+typedef struct { char name[48]; int32_t min, max, first_tid; int64_t first_rec; } rgstat_t;    /* first_rec: position << 32 | record index in its piece */
 static int g_onepass;               /* set before the walkers start */
-typedef struct {
-    int32_t tid; int64_t rec0, rec1; int32_t pe0, pe1; int fl0, fl1;
-    int64_t cn0, cn1; int32_t lm0, lm1;     /* this contig's runs in the counted-read log and the live-minimum log */
-    int left_min;                           /* smallest start among the pair-table entries still waiting at the contig's end */
-    int64_t dn0, dn1, sn0, sn1;             /* this contig's runs in the group's name logs (pair-table records; entries left waiting) */
-} gcontig;
+
+/* A PIECE of a contig: the records that start in [beg, end).  Whole small contigs are pieces too (first and last at once).
+ * Pieces are what the walkers claim: a contig of any size spreads over all of them. */
+typedef struct { int32_t tid, beg, end; int first, last; int64_t weight; } piece_t;
 
 typedef struct {
+    int32_t tid; int64_t rec0, rec1; int32_t pe0, pe1; int fl0, fl1;
+    int64_t cn0, cn1; int32_t lm0, lm1;     /* this piece's runs in the counted-read log and the live-minimum log */
+    int left_min;                           /* smallest start among the pair-table entries still waiting at the piece's end */
+    int64_t dn0, dn1, sn0, sn1;             /* this piece's runs in the group's name logs (pair-table records; entries left waiting) */
+    int32_t beg, end; int first, last;      /* the piece */
+    int lm_init;                            /* find_marker's value when the piece begins (entries earlier pieces left in the table) */
+} gcontig;
+
+struct pgroup_s;
+/* What a piece leaves for the next piece of its contig: evidence no flush has consumed yet.  Split-read evidence travels as the
+ * candidate it came from (its pending slots; the origin group keeps the realigned record and the BAM record), paired-read evidence
+ * as the object.  `when` = piece sequence number << 32 | record index in that piece: the order of arrival over the whole contig. */
+typedef struct {
+    int64_t when;
+    struct pgroup_s* g; int32_t cand;       /* split-read: origin group and candidate index there; g == NULL: paired-read */
+    evidence_t* pe;
+    int32_t cls[IM_MAX_EV], b1[IM_MAX_EV], b2[IM_MAX_EV];   /* split-read: the pending slots, -1 = consumed or empty */
+} carry_item;
+typedef struct { carry_item* v; int32_t n, cap; } carry_list;
+
+typedef struct pgroup_s {
     int64_t n_rec;
-    gcontig* ctg; int n_ctg, cap_ctg, cur_ctg;      /* cur_ctg: the contig the pair table is serving (host_discordant) */
+    gcontig* ctg; int n_ctg, cap_ctg, cur_ctg;      /* cur_ctg: the piece the pair table is serving (host_discordant) */
     gflush* fl; int n_fl, cap_fl;
     evidence_t** pe; int64_t* pe_rec; int32_t n_pe, cap_pe;
-    /* The walk does not know the global read counter it starts from (several contigs are walked at once), so it cannot
+    /* The walk does not know the global read counter it starts from (several pieces are walked at once), so it cannot
      * place the READCHUNK flush points itself (src/indelminer.c:617-670).  It logs what placing them needs -- for every
-     * counted read its record bound and position, and the pair table's smallest waiting start whenever that moves --
-     * and group_resolve_flushes places them once the contigs before this one have been counted. */
+     * counted read its record bound and position -- and group_resolve_flushes places them once the pieces before this one
+     * have been counted; the pair table's smallest waiting start is logged whenever it moves (group_pair_table). */
     int32_t *cn_rec, *cn_pos; int64_t n_cn, cap_cn;
     int32_t *lm_rec; int *lm_val; int32_t n_lm, cap_lm;
     /* The reference keeps ONE pair table for the run (readpairs is never reset): a first mate left waiting in one contig is found
-     * by a record of the same name in a later contig.  Contigs are walked independently here, each with a table of its own, so the
+     * by a record of the same name in a later contig.  Contigs are worked on independently here, each with a table of its own, so the
      * names are logged -- of every record that goes through the table (dn) and of the entries a contig leaves waiting (sn) -- and
      * the main thread, taking the groups in contig order, hands the run to the record-at-a-time path if they ever meet. */
     char *dn, *sn; int64_t dn_len, dn_cap, sn_len, sn_cap;
-    /* ONE-PASS mode (no config file: the insert lengths are estimated by the same walk, run_pipeline): per-read-group
-     * extrema as estimate_insertlengths takes them, the records of not-proper pairs kept aside (the discordant test needs
-     * range[1]), and the group's candidate arrays parked in device allocations of their own until the ranges are known */
+    /* per-read-group insert-size extrema as estimate_insertlengths takes them (one-pass mode: no config file, the table is made
+     * by the walk), the records of not-proper pairs kept aside for the pair table (served on the main thread, piece after piece of
+     * a contig: the walkers run ahead of one another), and the group's candidate arrays parked in a device allocation of their
+     * own until the main thread stages them */
     rgstat_t rgs[MG_MAX_RG]; int n_rgs;
     uint8_t* npp_raw; int64_t npp_len, npp_cap; int64_t* npp_off; int32_t* npp_rec; int32_t n_npp, cap_npp;
-    void* sv[9]; int32_t sv_n; int64_t sv_bytes; int32_t* sv_range;
-    int in_use;                 /* walked and not yet replayed (under the pool's mutex): replay workers finish in any order, so a
-                                 * walker waits for THIS buffer, not for a count of finished replays */
+    void* sv[10]; int32_t sv_n; int64_t sv_bytes; int32_t* sv_range;
     /* candidates as the device found them: record index + a host copy of the raw record */
     int32_t n_cand, cap_cand; int32_t* cand_rec; int64_t* craw_off; uint8_t* craw; int64_t craw_len, craw_cap;
-    /* what came back from the run stage */
-    im_read_result* res; int32_t *s_cls, *cons_sr, *cons_pe;
+    /* The stage: in front of the group's own candidates sit the ones earlier pieces of the contig left pending (front[], in order
+     * of arrival), in front of its paired-read entries the pending ones; n_virt = how many such items there are in all -- the
+     * group's own records count on from there, so that record numbers order the whole stage by arrival. */
+    carry_item* front; int32_t n_front; int32_t* front_virt;
+    int32_t n_pe_front, n_virt; int phantom;
+    int seq;                                /* position of the group in the run (the `when` of what it leaves pending) */
+    /* what came back from the stage */
+    im_read_result* res; int32_t *s_cls, *s_b1, *s_b2, *cons_sr, *cons_pe;
     int32_t n_cl, n_nodes; int32_t *cl_key, *cl_first, *cl_count, *order, *cl_sorted;
     evidence_t** ev_cache;
+    /* groups of one contig are freed together, when the last of them has been replayed (pending evidence points back at them) */
+    struct pgroup_s* next_of_contig;
 } pgroup;
 
 typedef struct {
@@ -2109,8 +2136,10 @@ typedef struct {
 } ppipe;
 
 #define GPU(call) do { if ((call) != IM_OK) fatalf("%s: %s", #call, im_last_error(P->d->gpu)); } while (0)
+#define GPU2(drv, call) do { if ((call) != IM_OK) fatalf("%s: %s", #call, im_last_error((drv)->gpu)); } while (0)
 struct walkpool_s;
 static struct walkpool_s* g_handoff_pool = NULL;       /* set while run_pipeline can hand a run the reference aborts to a child */
+static int g_free_slabs = 1;                            /* parked groups' device slabs are freed once staged */
 static void pipeline_handoff(void);
 
 static void* pdev_alloc(ppipe* P, size_t bytes) { void* p = NULL; GPU(im_dev_alloc(P->d->gpu, bytes ? bytes : 256, &p)); return p; }
@@ -2153,8 +2182,9 @@ static void pipe_global_init(driver* d)
     if (im_depth_enable(d->gpu) != IM_OK) fatalf("im_depth_enable: %s", im_last_error(d->gpu));
 }
 
-/* one walker's buffers: needs the GPU context (d->gpu), nothing else of the driver yet */
-static void pipe_init(ppipe* P, driver* d)
+/* one walker's buffers (with_chunks: the pinned chunk ring a walk delivers records through; the main thread's stage pipeline
+ * has none): needs the GPU context (d->gpu), nothing else of the driver yet */
+static void pipe_init(ppipe* P, driver* d, int with_chunks)
 {
     memset(P, 0, sizeof *P);
     P->d = d;
@@ -2164,7 +2194,7 @@ static void pipe_init(ppipe* P, driver* d)
     P->own_stream = !(getenv("INDELMINER_STREAMS") && strcmp(getenv("INDELMINER_STREAMS"), "shared") == 0);
     if (P->own_stream) GPU(im_stream_create(d->gpu, &P->stream));
     else P->stream = im_ctx_stream(d->gpu);
-    for (int i = 0; i < PIPE_NCHUNK; i++) {
+    for (int i = 0; i < PIPE_NCHUNK && with_chunks; i++) {
         pchunk* c = &P->ck[i];
         GPU(im_host_alloc(d->gpu, PIPE_CHUNK_BYTES, (void**)&c->h_raw));
         GPU(im_host_alloc(d->gpu, 4 * ((size_t)PIPE_CHUNK_RECS + 1), (void**)&c->h_off));
@@ -2195,7 +2225,7 @@ static void pipe_init(ppipe* P, driver* d)
 static void pipe_destroy(ppipe* P)
 {
     if (!P->ready) return;
-    for (int i = 0; i < PIPE_NCHUNK; i++) {
+    for (int i = 0; i < PIPE_NCHUNK && P->ck[i].h_raw; i++) {
         pchunk* c = &P->ck[i];
         im_host_free(P->d->gpu, c->h_raw); im_host_free(P->d->gpu, c->h_off); im_host_free(P->d->gpu, c->h_cnt);
         im_dev_free(P->d->gpu, c->d_raw); im_dev_free(P->d->gpu, c->d_off); im_dev_free(P->d->gpu, c->d_class); im_dev_free(P->d->gpu, c->d_scratch);
@@ -2207,19 +2237,13 @@ static void pipe_destroy(ppipe* P)
     P->ready = 0;
 }
 
-static void group_reset(pgroup* G)
-{
-    G->n_rec = 0; G->n_ctg = 0; G->n_fl = 0; G->n_pe = 0; G->n_cand = 0; G->craw_len = 0; G->n_cn = 0; G->n_lm = 0;
-    G->cur_ctg = 0; G->n_rgs = 0; G->n_npp = 0; G->npp_len = 0;
-    G->n_cl = 0; G->n_nodes = 0; G->dn_len = 0; G->sn_len = 0;
-}
-
 static void group_free(pgroup* G)
 {
+    if (G->phantom && G->pe && G->n_pe_front > 0 && G->pe[G->n_pe_front - 1] && G->pe[G->n_pe_front - 1]->type == EV_PHANTOM) evidence_free(G->pe[G->n_pe_front - 1]);
     free(G->ctg); free(G->fl); free(G->pe); free(G->pe_rec); free(G->cand_rec); free(G->craw_off); free(G->craw);
     free(G->cn_rec); free(G->cn_pos); free(G->lm_rec); free(G->lm_val);
     free(G->npp_raw); free(G->npp_off); free(G->npp_rec); free(G->dn); free(G->sn);
-    free(G->res); free(G->s_cls); free(G->cons_sr); free(G->cons_pe);
+    free(G->res); free(G->s_cls); free(G->s_b1); free(G->s_b2); free(G->cons_sr); free(G->cons_pe); free(G->front); free(G->front_virt);
     free(G->cl_key); free(G->cl_first); free(G->cl_count); free(G->order); free(G->cl_sorted); free(G->ev_cache);
     memset(G, 0, sizeof *G);
 }
@@ -2387,7 +2411,8 @@ static void host_discordant(driver* d, pgroup* G, const bam_record* b, int64_t r
             G->pe = xrealloc(G->pe, sizeof(evidence_t*) * (size_t)G->cap_pe);
             G->pe_rec = xrealloc(G->pe_rec, sizeof(int64_t) * (size_t)G->cap_pe);
         }
-        e->arrival = (rec - 1) * 8 + 7;
+        e->arrival = ((int64_t)G->n_virt + rec - 1) * 8 + 7;
+        e->when = ((int64_t)G->seq << 32) | (rec - 1);
         G->pe[G->n_pe] = e; G->pe_rec[G->n_pe] = rec - 1; G->n_pe++;
     }
     if (d->live_changed) {
@@ -2407,7 +2432,7 @@ static void host_discordant(driver* d, pgroup* G, const bam_record* b, int64_t r
 
 /* estimate_insertlengths' share of a record (src/bamoperations.c:15-86): extrema of the insert size per read group, and where
  * the group was first seen (the table lists the groups in file order: its prefix-match look-up depends on that) */
-static void host_rg_stat(pgroup* G, const bam_record* b, int32_t rec_in_contig)
+static void host_rg_stat(pgroup* G, const bam_record* b, int64_t rec_in_contig)
 {
     const int flag = b->flag;
     if (!((flag & 0x1) && !(flag & 0x4) && (flag & 0x2) && !(flag & (0x100 | 0x200 | 0x400)) &&
@@ -2433,27 +2458,26 @@ static void host_rg_stat(pgroup* G, const bam_record* b, int32_t rec_in_contig)
 static void pipe_host_record(driver* d, pgroup* G, const bam_record* b)
 {
     const int flag = b->flag;
-    if (g_onepass) host_rg_stat(G, b, (int32_t)(G->n_rec - 1 - G->ctg[G->cur_ctg].rec0));
+    if (g_onepass) host_rg_stat(G, b, ((int64_t)(b->pos < 0 ? 0 : b->pos) << 32) | (G->n_rec - 1 - G->ctg[G->cur_ctg].rec0));
     if (flag & (0x100 | 0x200 | 0x400 | 0x800)) return;
     if ((flag & 0x1) == 0) return;
     const int is_aligned = (flag & 0x4) == 0, is_mate_aligned = (flag & 0x8) == 0;
     if (is_aligned && is_mate_aligned && b->tid != b->mtid) return;
     if (is_aligned && is_mate_aligned && (flag & 0x2) == 0) {
-        if (!g_onepass) host_discordant(d, G, b, G->n_rec);
-        else {
-            /* the pair table needs range[1]: the record waits, with its place in the group, until the walk is over */
-            const int64_t len = (int64_t)b->l_data + 32;
-            if (G->npp_len + len > G->npp_cap) { G->npp_cap = (G->npp_cap + len) * 2 + (1 << 16); G->npp_raw = xrealloc(G->npp_raw, (size_t)G->npp_cap); }
-            if (G->n_npp == G->cap_npp) {
-                G->cap_npp = G->cap_npp ? G->cap_npp * 2 : 4096;
-                G->npp_off = xrealloc(G->npp_off, sizeof(int64_t) * ((size_t)G->cap_npp + 1));
-                G->npp_rec = xrealloc(G->npp_rec, sizeof(int32_t) * (size_t)G->cap_npp);
-            }
-            memcpy(G->npp_raw + G->npp_len, b->data - 32, (size_t)len);
-            G->npp_off[G->n_npp] = G->npp_len; G->npp_rec[G->n_npp] = (int32_t)G->n_rec; G->n_npp++;
-            G->npp_len += len;
-            G->npp_off[G->n_npp] = G->npp_len;
+        /* the pair table (src/indelminer.c:516-615) carries entries from one piece of a contig into the next, and pieces are
+         * walked at the same time: the record waits, with its place in the group, for the main thread (group_pair_table) */
+        (void)d;
+        const int64_t len = (int64_t)b->l_data + 32;
+        if (G->npp_len + len > G->npp_cap) { G->npp_cap = (G->npp_cap + len) * 2 + (1 << 16); G->npp_raw = xrealloc(G->npp_raw, (size_t)G->npp_cap); }
+        if (G->n_npp == G->cap_npp) {
+            G->cap_npp = G->cap_npp ? G->cap_npp * 2 : 4096;
+            G->npp_off = xrealloc(G->npp_off, sizeof(int64_t) * ((size_t)G->cap_npp + 1));
+            G->npp_rec = xrealloc(G->npp_rec, sizeof(int32_t) * (size_t)G->cap_npp);
         }
+        memcpy(G->npp_raw + G->npp_len, b->data - 32, (size_t)len);
+        G->npp_off[G->n_npp] = G->npp_len; G->npp_rec[G->n_npp] = (int32_t)G->n_rec; G->n_npp++;
+        G->npp_len += len;
+        G->npp_off[G->n_npp] = G->npp_len;
     }
     /* a counted read (src/indelminer.c:617): every READCHUNK-th of the whole run is a flush point */
     if (G->n_cn == G->cap_cn) {
@@ -2471,21 +2495,21 @@ static void group_push_flush(pgroup* G, int64_t rec, int32_t pe, int marker, int
     f->rec = rec; f->pe = pe; f->marker = marker; f->tid = tid;
 }
 
-/* Places the flush points of a walked group (src/indelminer.c:617-670, 806-823), contig by contig, from the logs of the
- * walk: *numread is the run's read counter in front of the group's first contig, *floor the smallest start among the
- * pair-table entries that contigs before it left waiting (the reference never removes those, so find_marker keeps seeing
- * them).  Both are advanced past the group.  In a multi-GPU run they come per contig from the exchanged summaries. */
+/* Places the flush points of a walked group (src/indelminer.c:617-670, 806-823), piece by piece, from the logs of the
+ * walk and of the pair table: *numread is the run's read counter in front of the group's first piece, *floor the smallest
+ * start among the pair-table entries that CONTIGS before it left waiting (the reference never removes those, so find_marker
+ * keeps seeing them).  Both are advanced past the group.  In a multi-GPU run they come per contig from the exchanged logs. */
 static void group_resolve_flushes(pgroup* G, int64_t* numread, int* floor)
 {
     G->n_fl = 0;
     for (int ci = 0; ci < G->n_ctg; ci++) {
         gcontig* cg = &G->ctg[ci];
-        if (g_mg) { *numread = g_mg->prefix[cg->tid]; *floor = g_mg->floor[cg->tid]; }
+        if (g_mg && cg->first) { *numread = g_mg->prefix[cg->tid]; *floor = g_mg->floor[cg->tid]; }
         cg->fl0 = G->n_fl;
         int32_t lm = cg->lm0, pe = cg->pe0;
-        int live_min = INT_MAX;
+        int live_min = cg->lm_init;
         const int64_t ncount = cg->cn1 - cg->cn0;
-        /* the k-th counted read of the contig (k from 0) is read number *numread + k + 1 of the run */
+        /* the k-th counted read of the piece (k from 0) is read number *numread + k + 1 of the run */
         int64_t k = (READCHUNK - 1 - (*numread % READCHUNK)) % READCHUNK;
         for (; k < ncount; k += READCHUNK) {
             const int64_t rec = G->cn_rec[cg->cn0 + k];
@@ -2498,10 +2522,10 @@ static void group_resolve_flushes(pgroup* G, int64_t* numread, int* floor)
             group_push_flush(G, rec, pe, marker, cg->tid);
         }
         /* end of contig (src/indelminer.c:806-823): everything still pending is consumed */
-        group_push_flush(G, cg->rec1, cg->pe1, INT_MAX, cg->tid);
+        if (cg->last) group_push_flush(G, cg->rec1, cg->pe1, INT_MAX, cg->tid);
         cg->fl1 = G->n_fl;
         *numread += ncount;
-        if (cg->left_min < *floor) *floor = cg->left_min;
+        if (cg->last && cg->left_min < *floor) *floor = cg->left_min;
     }
 }
 
@@ -2522,25 +2546,19 @@ static int group_meets_earlier_contigs(const pgroup* G)
     return 0;
 }
 
-static void pipe_walk_contig(ppipe* P, pgroup* G, int32_t tid, bgzf_reader* r)
+static void pipe_walk_piece(ppipe* P, pgroup* G, const piece_t* pc, bgzf_reader* r)
 {
     driver* d = P->d;
+    const int32_t tid = pc->tid;
     if (G->n_ctg == G->cap_ctg) { G->cap_ctg = G->cap_ctg ? G->cap_ctg * 2 : 32; G->ctg = xrealloc(G->ctg, sizeof(gcontig) * (size_t)G->cap_ctg); }
     gcontig* cg = &G->ctg[G->n_ctg++];
+    memset(cg, 0, sizeof *cg);
     cg->tid = tid; cg->rec0 = G->n_rec; cg->pe0 = G->n_pe; cg->fl0 = cg->fl1 = 0;
-    cg->cn0 = G->n_cn; cg->lm0 = G->n_lm; cg->dn0 = cg->dn1 = G->dn_len; cg->sn0 = cg->sn1 = G->sn_len;
+    cg->cn0 = G->n_cn; cg->lm0 = cg->lm1 = G->n_lm; cg->dn0 = cg->dn1 = G->dn_len; cg->sn0 = cg->sn1 = G->sn_len;
+    cg->beg = pc->beg; cg->end = pc->end; cg->first = pc->first; cg->last = pc->last; cg->lm_init = INT_MAX; cg->left_min = INT_MAX;
     G->cur_ctg = G->n_ctg - 1;
-    /* the pair table starts empty: what earlier contigs left waiting reaches this one as the marker floor
-     * (group_resolve_flushes), not as table entries */
-    while (d->n_live > 0) {
-        evidence_t* e = d->live[d->n_live - 1];
-        live_del(d, e);
-        qhash_remove(d->readpairs, e->qname, (int)strlen(e->qname) + 1);
-        evidence_free(e);
-    }
-    d->live_changed = 0;
     bam_region_iter it;
-    if (bam_region_begin(&it, r, d->idx, tid, 0, d->hdr->target_len[tid]) != 0) fatalf("cannot seek in %s", d->bam_name);
+    if (bam_piece_begin(&it, r, d->idx, tid, pc->beg, pc->end) != 0) fatalf("cannot seek in %s", d->bam_name);
     bam_record b; memset(&b, 0, sizeof b);
     for (;;) {
         pchunk* c = &P->ck[P->cur];
@@ -2560,16 +2578,13 @@ static void pipe_walk_contig(ppipe* P, pgroup* G, int32_t tid, bgzf_reader* r)
         c->bytes += ((uint32_t)len + 3u) & ~3u;
         c->seq_bytes += ((int64_t)b.l_seq + 3) & ~(int64_t)3;
         G->n_rec++;
-        if (G->n_rec >= 0x7fffffff) fatalf("more than 2^31 records in one group of contigs");
+        if (G->n_rec >= 0x7fffffff) fatalf("more than 2^31 records in one group of pieces");
         pipe_host_record(d, G, &b);
     }
     cg = &G->ctg[G->n_ctg - 1];
-    cg->rec1 = G->n_rec; cg->pe1 = G->n_pe; cg->cn1 = G->n_cn; cg->lm1 = G->n_lm; cg->dn1 = G->dn_len;
-    cg->left_min = find_marker_live(d);
-    group_log_waiting(d, G, cg);
-    /* the contig's last records go out now, so that its depth array can be finished behind them */
+    cg->rec1 = G->n_rec; cg->pe1 = G->n_pe; cg->cn1 = G->n_cn;
+    /* the piece's last records go out now */
     pipe_submit(P, G);
-    GPU(im_depth_scan(d->gpu, tid, P->stream));
 }
 
 static int g_tie_for_sort;
@@ -2585,39 +2600,67 @@ static int cmp_cluster_idx(const void* x, const void* y)
     return 0;
 }
 
-/* realign + flush cuts + group-by for the whole group, results to the host */
-static void pipe_run_group(ppipe* P, pgroup* G)
+/* THE STAGE of a walked group, on the main thread's pipeline S: in front the candidates earlier pieces of the contig left pending
+ * (their slots as they were left), behind them the group's own candidates out of their parked arrays; realign of the own
+ * candidates, the flush list and the group-by over all of them, results to the host.  Record numbers of the stage: the
+ * front items 0 .. n_virt - 1 in order of arrival, the group's own records from n_virt on. */
+static void stage_run_group(ppipe* P, pgroup* G)
 {
     driver* d = P->d;
     im_ctx* g = d->gpu;
-    const int32_t nc = G->n_cand;
-    if (G->n_pe > P->cap_pe || G->n_fl > P->cap_fl) {
-        /* rare: more discordant pairs / flushes than the arrays were sized for */
-        GPU(im_stream_sync(g, P->stream));
+    const int32_t K = G->n_front, n_own = G->sv_n, nc = K + n_own;
+    /* room: candidates, read bytes, paired-read entries, flushes */
+    {
+        int32_t need_c = nc > P->cap_cand ? nc : P->cap_cand; int64_t need_b = G->sv_bytes + 64 > P->cap_bases ? G->sv_bytes + 64 : P->cap_bases;
+        int32_t need_pe = G->n_pe > P->cap_pe ? G->n_pe : P->cap_pe;
+        int grow = 0;
         if (G->n_fl > P->cap_fl) {
-            im_dev_free(g, P->cut); while (P->cap_fl < G->n_fl) P->cap_fl *= 2; P->cut = pdev_alloc(P, 8 * (size_t)P->cap_fl); im_dev_free(g, P->fdesc); P->fdesc = pdev_alloc(P, sizeof(im_flush_desc) * (size_t)P->cap_fl);
-            im_dev_free(g, P->fgscratch);
-            P->fgscratch_bytes = im_dev_flushgroup_scratch_bytes(P->cap_cand * IM_MAX_EV, P->cap_fl);
-            P->fgscratch = pdev_alloc(P, P->fgscratch_bytes);
-            GPU(im_dev_flushgroup_scratch_init(g, P->cap_cand * IM_MAX_EV, P->cap_fl, P->fgscratch, P->fgscratch_bytes, P->stream));
-        }
-        if (G->n_pe > P->cap_pe) {
-            ppipe old = *P;
-            int32_t np = P->cap_pe; while (np < G->n_pe) np *= 2;
-            pipe_alloc_cands(P, old.cap_cand, old.cap_bases, np);
-            const size_t n = (size_t)nc;
-            GPU(im_dev_copy_async(g, P->bases, old.bases, (size_t)P->conf_bytes, P->stream));
-            GPU(im_dev_copy_async(g, P->boff, old.boff, 8 * n, P->stream)); GPU(im_dev_copy_async(g, P->len, old.len, 4 * n, P->stream));
-            GPU(im_dev_copy_async(g, P->tid, old.tid, 4 * n, P->stream)); GPU(im_dev_copy_async(g, P->anchor, old.anchor, 4 * n, P->stream));
-            GPU(im_dev_copy_async(g, P->range, old.range, 4 * n, P->stream)); GPU(im_dev_copy_async(g, P->cand_rec, old.cand_rec, 4 * n, P->stream));
-            GPU(im_dev_copy_async(g, P->cls, old.cls, 4 * n * IM_MAX_EV, P->stream)); GPU(im_dev_copy_async(g, P->b1, old.b1, 4 * n * IM_MAX_EV, P->stream));
-            GPU(im_dev_copy_async(g, P->b2, old.b2, 4 * n * IM_MAX_EV, P->stream));
             GPU(im_stream_sync(g, P->stream));
-            pipe_free_cands(&old);
+            im_dev_free(g, P->cut); im_dev_free(g, P->fdesc);
+            while (P->cap_fl < G->n_fl) P->cap_fl *= 2;
+            P->cut = pdev_alloc(P, 8 * (size_t)P->cap_fl); P->fdesc = pdev_alloc(P, sizeof(im_flush_desc) * (size_t)P->cap_fl);
+            grow = 1;
+        }
+        if (need_c > P->cap_cand || need_b > P->cap_bases || need_pe > P->cap_pe || grow) {
+            int32_t c2 = P->cap_cand, p2 = P->cap_pe; int64_t b2 = P->cap_bases;
+            while (c2 < need_c) c2 *= 2;
+            while (b2 < need_b) b2 *= 2;
+            while (p2 < need_pe) p2 *= 2;
+            GPU(im_stream_sync(g, P->stream));
+            pipe_free_cands(P);
+            pipe_alloc_cands(P, c2, b2, p2);
         }
     }
     const size_t pe_base = (size_t)P->cap_cand * IM_MAX_EV;
+    const size_t nK = (size_t)K, nO = (size_t)n_own;
+    /* the group's own arrays, behind the front */
+    {
+        const size_t bytes[10] = { (size_t)G->sv_bytes, 8 * nO, 4 * nO, 4 * nO, 4 * nO, 4 * nO, 4 * nO * IM_MAX_EV, 4 * nO * IM_MAX_EV, 4 * nO * IM_MAX_EV, 4 * nO };
+        void* dst[10] = { P->bases, (char*)P->boff + 8 * nK, (char*)P->len + 4 * nK, (char*)P->tid + 4 * nK, (char*)P->anchor + 4 * nK, NULL,
+                          (char*)P->cls + 16 * nK, (char*)P->b1 + 16 * nK, (char*)P->b2 + 16 * nK, (char*)P->range + 4 * nK };
+        for (int k = 0; k < 10; k++) if (dst[k] && bytes[k] && G->sv[k]) GPU(im_dev_copy_async(g, dst[k], G->sv[k], bytes[k], P->stream));
+        if (G->sv_range && n_own) GPU(im_dev_upload_async(g, (char*)P->range + 4 * nK, G->sv_range, 4 * nO, P->stream));    /* one-pass: known only now */
+    }
+    /* record numbers: the front's, then the own ones counted on from n_virt; the front's slots */
+    {
+        int32_t* t = xmalloc(4 * ((size_t)nc + 1) + 12 * nK * IM_MAX_EV + 64);
+        for (int32_t q = 0; q < K; q++) t[q] = G->front_virt[q];
+        for (int32_t i = 0; i < n_own; i++) t[K + i] = G->cand_rec[i] + G->n_virt;
+        if (nc) GPU(im_dev_upload(g, P->cand_rec, t, 4 * (size_t)nc));
+        if (K) {
+            int32_t *c = t + nc + 1, *x1 = c + nK * IM_MAX_EV, *x2 = x1 + nK * IM_MAX_EV;
+            for (int32_t q = 0; q < K; q++)
+                for (int k = 0; k < IM_MAX_EV; k++) { c[q * IM_MAX_EV + k] = G->front[q].cls[k]; x1[q * IM_MAX_EV + k] = G->front[q].b1[k]; x2[q * IM_MAX_EV + k] = G->front[q].b2[k]; }
+            GPU(im_dev_upload(g, P->cls, c, 16 * nK)); GPU(im_dev_upload(g, P->b1, x1, 16 * nK)); GPU(im_dev_upload(g, P->b2, x2, 16 * nK));
+        }
+        free(t);
+        int32_t cnt[16] = { 0 };
+        cnt[0] = nc;
+        GPU(im_dev_upload(g, P->counters, cnt, 64));
+    }
     if (G->n_pe > 0) {
+        /* paired-read entries (class 2) behind the split-read slots: pending ones of earlier pieces first; an entry without an
+         * evidence object stands for the entries that wait for the contig's end (stage_leftovers) and carries their smallest key */
         int32_t* t = xmalloc(sizeof(int32_t) * 3 * (size_t)G->n_pe);
         for (int32_t i = 0; i < G->n_pe; i++) { t[i] = 2; t[G->n_pe + i] = G->pe[i]->b1; t[2 * (size_t)G->n_pe + i] = G->pe[i]->b2; }
         GPU(im_dev_upload(g, (char*)P->cls + 4 * pe_base, t, 4 * (size_t)G->n_pe));
@@ -2638,7 +2681,8 @@ static void pipe_run_group(ppipe* P, pgroup* G)
         const gcontig* cg = &G->ctg[ci];
         for (int f = cg->fl0; f < cg->fl1; f++) {
             const gflush* fl = &G->fl[f];
-            fd[f].rec0 = (int32_t)cg->rec0; fd[f].rec1 = (int32_t)fl->rec; fd[f].pe0 = cg->pe0; fd[f].pe1 = fl->pe;
+            /* a piece that continues a contig is the only one of its group: its flushes see the front from record 0 on */
+            fd[f].rec0 = G->n_virt ? 0 : (int32_t)cg->rec0; fd[f].rec1 = (int32_t)fl->rec + G->n_virt; fd[f].pe0 = cg->pe0; fd[f].pe1 = fl->pe;
             fd[f].marker = fl->marker; fd[f].id = f + 1; fd[f].last = cg->fl1 - 1;
             if (fl->rec - cg->rec0 > longest) longest = fl->rec - cg->rec0;
             if (f > cg->fl0 && (fl->marker < G->fl[f - 1].marker || fl->rec < G->fl[f - 1].rec || fl->pe < G->fl[f - 1].pe)) monotone = 0;
@@ -2653,14 +2697,15 @@ static void pipe_run_group(ppipe* P, pgroup* G)
         if (per_flush) GPU(im_dev_memset(g, P->cut, 0xFF, 8 * (size_t)G->n_fl, P->stream));
     }
     im_params prm = { O.klength, O.numgaps, O.maxdelsize, O.ethreshold };
-    if (nc > 0) {
+    if (n_own > 0) {
         im_dev_batch bt;
         memset(&bt, 0, sizeof bt);
-        bt.n = nc; bt.bases = P->bases; bt.base_off = P->boff; bt.read_len = P->len; bt.tid = P->tid; bt.anchor = P->anchor;
-        bt.range_max = P->range; bt.out = P->res; bt.ev_cls = P->cls; bt.ev_b1 = P->b1; bt.ev_b2 = P->b2;
+        bt.n = n_own; bt.bases = P->bases; bt.base_off = (const int64_t*)P->boff + nK; bt.read_len = (const int32_t*)P->len + nK; bt.tid = (const int32_t*)P->tid + nK;
+        bt.anchor = (const int32_t*)P->anchor + nK; bt.range_max = (const int32_t*)P->range + nK; bt.out = (im_read_result*)P->res + nK;
+        bt.ev_cls = (int32_t*)P->cls + nK * IM_MAX_EV; bt.ev_b1 = (int32_t*)P->b1 + nK * IM_MAX_EV; bt.ev_b2 = (int32_t*)P->b2 + nK * IM_MAX_EV;
         GPU(im_dev_realign_keep(g, &prm, &bt, P->stream));
     }
-    if (!per_flush) GPU(im_dev_upload(g, P->fdesc, fd, sizeof(im_flush_desc) * (size_t)G->n_fl));    /* synchronous: complete before the launches below */
+    if (!per_flush && G->n_fl) GPU(im_dev_upload(g, P->fdesc, fd, sizeof(im_flush_desc) * (size_t)G->n_fl));    /* synchronous: complete before the launches below */
     if (wide) {
         GPU(im_dev_flush_groupby(g, (const im_flush_desc*)P->fdesc, G->n_fl, P->cls, P->b1, P->b2, P->consumed, P->cand_rec, P->counters, nc,
                                  (int32_t)pe_base, G->n_pe, O.tie_desc, P->order, P->clkey, P->clfirst, P->clcount, P->counts,
@@ -2682,14 +2727,17 @@ static void pipe_run_group(ppipe* P, pgroup* G)
     GPU(im_stream_sync(g, P->stream));
     phase_time("device: realign + flush cuts + group-by");
 
-    G->res = xrealloc(G->res, sizeof(im_read_result) * (size_t)(nc ? nc : 1));
-    G->s_cls = xrealloc(G->s_cls, 4 * (size_t)(nc ? nc : 1) * IM_MAX_EV);
-    G->cons_sr = xrealloc(G->cons_sr, 4 * (size_t)(nc ? nc : 1) * IM_MAX_EV);
+    const size_t nn = (size_t)(nc ? nc : 1);
+    G->res = xrealloc(G->res, sizeof(im_read_result) * (size_t)(n_own ? n_own : 1));
+    G->s_cls = xrealloc(G->s_cls, 4 * nn * IM_MAX_EV); G->s_b1 = xrealloc(G->s_b1, 4 * nn * IM_MAX_EV); G->s_b2 = xrealloc(G->s_b2, 4 * nn * IM_MAX_EV);
+    G->cons_sr = xrealloc(G->cons_sr, 4 * nn * IM_MAX_EV);
     G->cons_pe = xrealloc(G->cons_pe, 4 * (size_t)(G->n_pe ? G->n_pe : 1));
     int32_t counts[2] = { 0, 0 };
+    if (n_own > 0) GPU(im_dev_download(g, G->res, (char*)P->res + sizeof(im_read_result) * nK, sizeof(im_read_result) * nO));
     if (nc > 0) {
-        GPU(im_dev_download(g, G->res, P->res, sizeof(im_read_result) * (size_t)nc));
         GPU(im_dev_download(g, G->s_cls, P->cls, 4 * (size_t)nc * IM_MAX_EV));
+        GPU(im_dev_download(g, G->s_b1, P->b1, 4 * (size_t)nc * IM_MAX_EV));
+        GPU(im_dev_download(g, G->s_b2, P->b2, 4 * (size_t)nc * IM_MAX_EV));
         GPU(im_dev_download(g, G->cons_sr, P->consumed, 4 * (size_t)nc * IM_MAX_EV));
     }
     if (G->n_pe > 0) GPU(im_dev_download(g, G->cons_pe, (char*)P->consumed + 4 * pe_base, 4 * (size_t)G->n_pe));
@@ -2710,32 +2758,30 @@ static void pipe_run_group(ppipe* P, pgroup* G)
     for (int32_t i = 0; i < G->n_cl; i++) G->cl_sorted[i] = i;
     g_key_for_sort = G->cl_key;
     qsort(G->cl_sorted, (size_t)G->n_cl, sizeof(int32_t), cmp_cluster_idx);
-    G->ev_cache = xrealloc(G->ev_cache, sizeof(evidence_t*) * (size_t)(nc ? nc : 1) * IM_MAX_EV);
-    memset(G->ev_cache, 0, sizeof(evidence_t*) * (size_t)(nc ? nc : 1) * IM_MAX_EV);
-    for (int32_t i = 0; i < nc; i++) {
+    G->ev_cache = xrealloc(G->ev_cache, sizeof(evidence_t*) * nn * IM_MAX_EV);
+    memset(G->ev_cache, 0, sizeof(evidence_t*) * nn * IM_MAX_EV);
+    for (int32_t i = 0; i < n_own; i++) {
         const int st = G->res[i].status;
         if ((st == IM_ST_ABORT || st == IM_ST_OVERFLOW || st == IM_ST_UNSUPPORTED) && g_handoff_pool) pipeline_handoff();
         if (st == IM_ST_ABORT) fatalf("im_dev_realign: read %d: the reference would abort on this input", i);
         if (st == IM_ST_OVERFLOW) fatalf("im_dev_realign: read %d: segment list longer than IM_MAX_OPS", i);
         if (st == IM_ST_UNSUPPORTED) fatalf("im_dev_realign: read %d: longer than IM_MAX_READ=%d", i, IM_MAX_READ);
     }
-    P->conf_cand = 0; P->conf_err = 0; P->conf_bytes = 0;
-    GPU(im_dev_memset(g, P->counters, 0, 64, P->stream));
+    if (G->sv[0]) { if (getenv("INDELMINER_TIDY_EXIT") || g_free_slabs) im_dev_free(g, G->sv[0]); G->sv[0] = NULL; }
     phase_time("results to the host");
 }
 
-/* the evidence objects of candidate `cand`: the realigned segments when the device found any (they
- * replace the CIGAR-derived ones, src/indelminer.c:494-502), else the CIGAR-derived */
-static void group_candidate_evidence(driver* d, pgroup* G, int32_t cand)
+/* the evidence objects of candidate `cand` of group S (its realigned record, its BAM record) into slot[0 .. IM_MAX_EV): the realigned
+ * segments when the device found any (they replace the CIGAR-derived ones, src/indelminer.c:494-502), else the CIGAR-derived.
+ * arrival0 = the candidate's place in the order of arrival of the stage that asks. */
+static void candidate_evidence(driver* d, const pgroup* S, int32_t cand, int64_t arrival0, evidence_t** slot)
 {
     bam_record b;
-    bam_record_view(G->craw + G->craw_off[cand], (int32_t)(G->craw_off[cand + 1] - G->craw_off[cand]), &b);
+    bam_record_view(S->craw + S->craw_off[cand], (int32_t)(S->craw_off[cand + 1] - S->craw_off[cand]), &b);
     const int flag = b.flag;
     const int is_aligned = (flag & 0x4) == 0, is_rc = (flag & 0x10) != 0, is_mate_rc = (flag & 0x20) != 0;
     const char* qname = BAMR_QNAME(&b);
-    const im_read_result* r = &G->res[cand];
-    evidence_t** slot = &G->ev_cache[(size_t)cand * IM_MAX_EV];
-    const int64_t arrival0 = (int64_t)G->cand_rec[cand] * 8;
+    const im_read_result* r = &S->res[cand];
     if (r->status == IM_ST_EVIDENCE && r->n_ev > 0) {
         char* bases = decode_bases(&b);
         char strand = is_rc ? '-' : '+';
@@ -2772,14 +2818,27 @@ static void group_candidate_evidence(driver* d, pgroup* G, int32_t cand)
     }
 }
 
+/* stage candidate q of group G: one of the front (the candidate of an earlier piece; only its pending slots count) or an own one */
+static void group_candidate_evidence(driver* d, pgroup* G, int32_t q)
+{
+    evidence_t** slot = &G->ev_cache[(size_t)q * IM_MAX_EV];
+    if (q < G->n_front) {
+        const carry_item* it = &G->front[q];
+        candidate_evidence(d, it->g, it->cand, (int64_t)G->front_virt[q] * 8, slot);
+        for (int k = 0; k < IM_MAX_EV; k++) if (slot[k] && it->cls[k] < 0) { evidence_free(slot[k]); slot[k] = NULL; }      /* consumed by an earlier piece's flush */
+    } else {
+        const int32_t cand = q - G->n_front;
+        candidate_evidence(d, G, cand, ((int64_t)G->cand_rec[cand] + G->n_virt) * 8, slot);
+    }
+}
+
 static evidence_t* group_sr_evidence(driver* d, pgroup* G, int32_t slot)
 {
     if (!G->ev_cache[slot]) group_candidate_evidence(d, G, slot / IM_MAX_EV);
     if (G->ev_cache[slot] == NULL) {
-        const int32_t cand = slot / IM_MAX_EV;
-        fatalf("internal: the device names evidence slot %d of candidate %d (record %d of %ld in its group, %d candidates; device class %d, "
-               "realign status %d with %d evidence) but the host finds no evidence there", slot % IM_MAX_EV, cand, G->cand_rec[cand],
-               (long)G->n_rec, G->n_cand, G->s_cls[slot], G->res[cand].status, G->res[cand].n_ev);
+        const int32_t q = slot / IM_MAX_EV;
+        fatalf("internal: the device names evidence slot %d of stage candidate %d (%d in front, %d own, %ld records; device class %d) "
+               "but the host finds no evidence there", slot % IM_MAX_EV, q, G->n_front, G->n_cand, (long)G->n_rec, G->s_cls[slot]);
     }
     return G->ev_cache[slot];
 }
@@ -2825,6 +2884,7 @@ static void group_process_flush(driver* d, pgroup* G, const gcontig* cg, int f, 
         int64_t rep = -1;
         for (int32_t k = 0; k < cnt; k++) {
             evidence_t* e = group_sr_evidence(d, G, G->order[first + k]);
+            G->ev_cache[G->order[first + k]] = NULL;        /* the flush owns it now (freed with the flush's evidence) */
             v->evidence[k] = e;
             USED_PUSH(e);
             /* the member with the largest sorted position: oldest arrival, newest with tie_desc */
@@ -2835,11 +2895,11 @@ static void group_process_flush(driver* d, pgroup* G, const gcontig* cg, int f, 
     }
     /* paired-read nodes of this flush, in sorted order */
     int npe = 0;
-    for (int32_t i = cg->pe0; i < G->fl[f].pe; i++) if (G->cons_pe[i] == id) npe++;
+    for (int32_t i = cg->pe0; i < G->fl[f].pe; i++) if (G->cons_pe[i] == id && G->pe[i]->type != EV_PHANTOM) npe++;
     if (npe > 0) {
         evidence_t** pe = xmalloc(sizeof(evidence_t*) * (size_t)npe);
         int m = 0;
-        for (int32_t i = cg->pe0; i < G->fl[f].pe; i++) if (G->cons_pe[i] == id) { pe[m++] = G->pe[i]; USED_PUSH(G->pe[i]); }
+        for (int32_t i = cg->pe0; i < G->fl[f].pe; i++) if (G->cons_pe[i] == id && G->pe[i]->type != EV_PHANTOM) { pe[m++] = G->pe[i]; USED_PUSH(G->pe[i]); }
         g_tie_for_sort = O.tie_desc;
         qsort(pe, (size_t)npe, sizeof(evidence_t*), cmp_pe_sorted);
         int* parent = xmalloc(sizeof(int) * (size_t)npe);
@@ -2913,7 +2973,7 @@ static void group_replay(driver* d, pgroup* G)
             char path[512];
             mg_path(g_mg, path, sizeof path, "part", tid);
             fflush(stdout);
-            if (!freopen(path, "w", stdout)) fatalf("cannot write %s", path);
+            if (!freopen(path, cg->first ? "w" : "a", stdout)) fatalf("cannot write %s", path);
         }
         for (int f = cg->fl0; f < cg->fl1; f++) {
             variant_list vs = {0};
@@ -2932,7 +2992,7 @@ static void group_replay(driver* d, pgroup* G)
             for (int64_t i = 0; i < n_used; i++) evidence_free(used[i]);
             free(used);
         }
-        if (g_vcfname != NULL) {
+        if (g_vcfname != NULL && cg->last) {
             for (int ki = g_known.next; ki < g_known.n; ki++) {
                 knownvariant_t* k = g_known.v[ki];
                 print_vcf_line(d, k);
@@ -2942,8 +3002,10 @@ static void group_replay(driver* d, pgroup* G)
             g_known.next = g_known.n;
         }
     }
-    /* evidence objects that were built for a read but never reached a cluster (a consumed slot whose
-     * cluster was dropped is freed with its flush; nothing else is ever built) */
+    /* evidence objects that were built with their candidate but belong to slots no flush of this group consumed (they are still
+     * pending: a later piece builds them again from the candidate) */
+    const size_t ns = (size_t)(G->n_front + G->sv_n) * IM_MAX_EV;
+    for (size_t i = 0; i < ns; i++) if (G->ev_cache[i]) { evidence_free(G->ev_cache[i]); G->ev_cache[i] = NULL; }
 }
 
 /* ============================================================== multi-GPU == */
@@ -3122,7 +3184,7 @@ static void mg_allgather(mgpu* m, driver* d, const void* mine, void* all, size_t
     im_dev_free(d->gpu, ds); im_dev_free(d->gpu, dr);
 }
 
-typedef struct { char name[48]; int32_t min, max, first_tid, first_rec; int32_t seen; } mg_rg;
+typedef struct { char name[48]; int32_t min, max, first_tid; int64_t first_rec; int32_t seen; } mg_rg;
 
 static int mg_rg_index(mg_rg* rgs, int* pn, const char* rgname)
 {
@@ -3213,7 +3275,7 @@ static void mg_prewalk(mgpu* m, driver* d, int estimate, mgbuf* out)
     for (int k = 0; k < n_rg; k++) {
         int32_t* g = w + MG_HEAD_WORDS + (size_t)k * MG_RG_WORDS;
         memcpy(g, rgs[k].name, 48);
-        g[12] = rgs[k].min; g[13] = rgs[k].max; g[14] = rgs[k].first_tid; g[15] = rgs[k].first_rec; g[16] = rgs[k].seen;
+        g[12] = rgs[k].min; g[13] = rgs[k].max; g[14] = rgs[k].first_tid; g[15] = (int32_t)rgs[k].first_rec; g[16] = rgs[k].seen;
     }
     free(rgs);
 }
@@ -3511,56 +3573,57 @@ static void mg_finish(mgpu* m, driver* d)
     im_comm_destroy(m->comm);
 }
 
-/* Several contigs are walked at once (inflate, count, pair table, triage launches: one thread's worth of host work per
- * walker), each walker with its own BAM reader, pinned chunk ring, device arrays and stream; the main thread takes the
- * walked groups in contig order, places their flush points (group_resolve_flushes: the only step that needs the contigs
- * before it), runs the device stage and replays.  A claim is a run of consecutive contigs that goes into one group; a
- * walker holds two groups' worth of host state, so it walks its next claim while its previous one is replayed.  Order of
- * output is the order of the contigs. */
+/* PIECES of contigs are walked at once (inflate, count, triage launches: one thread's worth of host work per walker), each
+ * walker with its own BAM reader, pinned chunk ring, device arrays and stream.  A claim is a run of consecutive pieces that
+ * goes into one group: a piece of a large contig on its own, or several whole small contigs.  A walked group's candidate
+ * arrays are parked in a device allocation of their own and the walker goes on to its next claim.  The main thread takes the
+ * walked groups in file order: it serves the pair table (entries carry over from one piece of a contig to the next), places
+ * the flush points (group_resolve_flushes: the read counter carries over too), runs the stage (stage_run_group: in front of
+ * the group's own candidates the evidence earlier pieces left pending) and hands the group to a replay worker once the
+ * contig's depth array is complete.  Order of output is the order of the file. */
 struct walkpool_s;
 typedef struct claim_s claim_t;
 typedef struct {
     struct walkpool_s* pool;
-    driver wd;                          /* private: pair table, read-group cache */
+    driver wd;                          /* private: read-group cache */
     ppipe P;
     bgzf_reader* r; bam_header* hdr;
-    pgroup G[2];
-    int n_started, device_free, replayed;
     claim_t* cur_claim; jmp_buf abort_jmp;  /* the claim being walked; where a walk that met a record the reference dies on ends up */
     pthread_t th;
 } walker_t;
 
-struct claim_s { int first, count; walker_t* W; pgroup* G; int walked, aborted; };
+struct claim_s { int first, count; pgroup* G; int walked, aborted; };
 
-/* a group whose device stage is done, on its way through a replay worker: what it prints waits in buf until every group
+/* a group whose stage is done, on its way through a replay worker: what it prints waits in buf until every group
  * before it has been printed */
-typedef struct { walker_t* W; pgroup* G; char* buf; size_t len; int done; } rjob_t;
+typedef struct { pgroup* G; char* buf; size_t len; int done; int last_of_contig; } rjob_t;
 typedef struct { struct walkpool_s* pool; driver rd; pthread_t th; } replayer_t;
 
 typedef struct walkpool_s {
     driver* d;
-    int32_t* order; int n_order;        /* the contigs this process handles, ascending */
+    piece_t* pieces; int n_pieces;      /* this process's share of the file, in file order */
     claim_t* claims; int n_claims, next_claim;
+    int staged;                         /* claims the main thread is through with: walkers stay a bounded number of claims ahead */
     walker_t* w; int nw;
     int serial, go;
-    rjob_t* jobs; int n_jobs, next_job, jobs_closed;    /* replay queue, in contig order */
+    rjob_t* jobs; int n_jobs, next_job, jobs_closed;    /* replay queue, in file order */
     int printed;                                        /* jobs whose output has been written */
     pthread_mutex_t mu; pthread_cond_t cv;
 } walkpool_t;
 
-/* ONE-PASS mode.  A walked group's candidate arrays leave the walker's pipeline for allocations of their own (the walker goes on
- * to its next claim; the device stage has to wait for the insert lengths), and come back into a pipeline when its turn comes. */
+/* A walked group's candidate arrays leave the walker's pipeline for an allocation of their own (the walker goes on to its next
+ * claim) and come into the main thread's pipeline when the group's turn comes (stage_run_group). */
 static void group_park_device(ppipe* P, pgroup* G)
 {
     im_ctx* g = P->d->gpu;
     const size_t n = (size_t)G->n_cand, ns = n * IM_MAX_EV;
-    const size_t bytes[9] = { (size_t)P->conf_bytes, 8 * n, 4 * n, 4 * n, 4 * n, 4 * n, 4 * ns, 4 * ns, 4 * ns };
-    void* src[9] = { P->bases, P->boff, P->len, P->tid, P->anchor, P->cand_rec, P->cls, P->b1, P->b2 };
+    const size_t bytes[10] = { (size_t)P->conf_bytes, 8 * n, 4 * n, 4 * n, 4 * n, 4 * n, 4 * ns, 4 * ns, 4 * ns, 4 * n };
+    void* src[10] = { P->bases, P->boff, P->len, P->tid, P->anchor, P->cand_rec, P->cls, P->b1, P->b2, P->range };
     G->sv_n = (int32_t)n; G->sv_bytes = P->conf_bytes;
     size_t total = 0;
-    for (int k = 0; k < 9; k++) total += (bytes[k] + 255) & ~(size_t)255;
+    for (int k = 0; k < 10; k++) total += (bytes[k] + 255) & ~(size_t)255;
     char* slab = pdev_alloc(P, total);              /* one allocation per group: device allocation calls are not cheap */
-    for (int k = 0; k < 9; k++) {
+    for (int k = 0; k < 10; k++) {
         G->sv[k] = slab;
         if (bytes[k]) GPU(im_dev_copy_async(g, G->sv[k], src[k], bytes[k], P->stream));
         slab += (bytes[k] + 255) & ~(size_t)255;
@@ -3570,34 +3633,8 @@ static void group_park_device(ppipe* P, pgroup* G)
     P->conf_cand = 0; P->conf_err = 0; P->conf_bytes = 0;
 }
 
-static void group_unpark_device(ppipe* P, pgroup* G, const int32_t* range)
-{
-    im_ctx* g = P->d->gpu;
-    const size_t n = (size_t)G->sv_n, ns = n * IM_MAX_EV;
-    if ((int64_t)n > P->cap_cand || G->sv_bytes + 64 > P->cap_bases) {
-        int32_t nc = P->cap_cand; int64_t nb = P->cap_bases;
-        while (nc < (int64_t)n) nc *= 2;
-        while (nb < G->sv_bytes + 64) nb *= 2;
-        GPU(im_stream_sync(g, P->stream));
-        pipe_free_cands(P);
-        pipe_alloc_cands(P, nc, nb, P->cap_pe);
-    }
-    const size_t bytes[9] = { (size_t)G->sv_bytes, 8 * n, 4 * n, 4 * n, 4 * n, 4 * n, 4 * ns, 4 * ns, 4 * ns };
-    void* dst[9] = { P->bases, P->boff, P->len, P->tid, P->anchor, P->cand_rec, P->cls, P->b1, P->b2 };
-    for (int k = 0; k < 9; k++) if (bytes[k]) GPU(im_dev_copy_async(g, dst[k], G->sv[k], bytes[k], P->stream));
-    int32_t cnt[16] = { 0 };
-    cnt[0] = (int32_t)n; cnt[1] = (int32_t)G->sv_bytes;
-    GPU(im_dev_upload_async(g, P->counters, cnt, 64, P->stream));
-    if (n) GPU(im_dev_upload_async(g, P->range, range, 4 * n, P->stream));
-    GPU(im_stream_sync(g, P->stream));
-    if (getenv("INDELMINER_TIDY_EXIT")) im_dev_free(g, G->sv[0]);        /* else the slab goes with the process (a free synchronises the device) */
-    G->sv[0] = NULL;
-    P->conf_cand = (int32_t)n; P->conf_bytes = G->sv_bytes;
-}
-
-/* ONE-PASS mode, once the insert lengths are known: every candidate's range[1] from its own record, then the kept records of
- * not-proper pairs through the pair table, contig by contig, exactly as the walk of the two-pass run would have served them */
-static int32_t* group_apply_ranges(driver* d, pgroup* G)
+/* ONE-PASS mode, once the insert lengths are known: every candidate's range[1] from its own record */
+static int32_t* group_ranges(driver* d, pgroup* G)
 {
     int32_t* range = xmalloc(sizeof(int32_t) * (size_t)(G->n_cand ? G->n_cand : 1));
     for (int32_t j = 0; j < G->n_cand; j++) {
@@ -3605,18 +3642,35 @@ static int32_t* group_apply_ranges(driver* d, pgroup* G)
         bam_record_view(G->craw + G->craw_off[j], (int32_t)(G->craw_off[j + 1] - G->craw_off[j]), &b);
         range[j] = record_range(d, &b)[1];
     }
+    return range;
+}
+
+/* the driver's pair table, emptied (a contig begins: what earlier contigs left waiting reaches it as the marker floor, not as entries) */
+static void pair_table_clear(driver* d)
+{
+    while (d->n_live > 0) {
+        evidence_t* e = d->live[d->n_live - 1];
+        live_del(d, e);
+        qhash_remove(d->readpairs, e->qname, (int)strlen(e->qname) + 1);
+        evidence_free(e);
+    }
+    d->live_changed = 0;
+}
+
+/* The kept records of not-proper pairs through the pair table (src/indelminer.c:516-615), piece by piece, on the main thread:
+ * the table's entries carry over from one piece of a contig to the next.  Completed pairs join the group's paired-read entries
+ * (behind the pending ones of earlier pieces, which stage_take_front put there), the table's smallest waiting start is logged
+ * where it moves (find_marker, 211-233). */
+static void group_pair_table(driver* d, pgroup* G)
+{
     int32_t k = 0;
     for (int ci = 0; ci < G->n_ctg; ci++) {
         gcontig* cg = &G->ctg[ci];
         G->cur_ctg = ci;
-        while (d->n_live > 0) {                         /* a table per contig, as in pipe_walk_contig */
-            evidence_t* e = d->live[d->n_live - 1];
-            live_del(d, e);
-            qhash_remove(d->readpairs, e->qname, (int)strlen(e->qname) + 1);
-            evidence_free(e);
-        }
+        if (cg->first) pair_table_clear(d);
         d->live_changed = 0;
-        cg->pe0 = G->n_pe; cg->lm0 = G->n_lm; cg->dn0 = G->dn_len;
+        cg->lm_init = find_marker_live(d);
+        cg->pe0 = ci == 0 ? 0 : G->n_pe; cg->lm0 = G->n_lm; cg->dn0 = G->dn_len;
         for (; k < G->n_npp && G->npp_rec[k] <= cg->rec1; k++) {
             bam_record b;
             bam_record_view(G->npp_raw + G->npp_off[k], (int32_t)(G->npp_off[k + 1] - G->npp_off[k]), &b);
@@ -3624,18 +3678,145 @@ static int32_t* group_apply_ranges(driver* d, pgroup* G)
         }
         cg->pe1 = G->n_pe; cg->lm1 = G->n_lm; cg->dn1 = G->dn_len;
         cg->left_min = find_marker_live(d);
-        group_log_waiting(d, G, cg);
+        cg->sn0 = cg->sn1 = G->sn_len;
+        if (cg->last) group_log_waiting(d, G, cg);
     }
-    return range;
 }
 
-typedef struct { struct walkpool_s* o; int first, step; driver rd; pthread_t th; } apply_job;
-static void* apply_thread(void* arg);
+/* ---- evidence that crosses piece boundaries ---- */
+
+typedef struct {
+    carry_list live;            /* pending: takes part in the next piece's flushes */
+    carry_list frozen;          /* pending with b2 >= the contig's marker floor: no flush before the contig's last can consume it
+                                 * (every marker is <= the floor, so it is a cutting candidate of every flush that sees it); it
+                                 * waits for the last piece, and a single entry carries the smallest (b1,b2) among them so far */
+    uint64_t frozen_min;
+    int tid;
+} carry_t;
+
+static void carry_push(carry_list* l, const carry_item* it)
+{
+    if (l->n == l->cap) { l->cap = l->cap ? l->cap * 2 : 256; l->v = xrealloc(l->v, sizeof(carry_item) * (size_t)l->cap); }
+    l->v[l->n++] = *it;
+}
+
+static evidence_t* phantom_entry(uint64_t key)
+{
+    evidence_t* e = xcalloc(1, sizeof *e);
+    e->type = EV_PHANTOM; e->cls = CLS_DELETION;
+    e->b1 = (int32_t)(key >> 32); e->b2 = (int32_t)(uint32_t)key;
+    e->live_slot = -1;
+    return e;
+}
+
+/* Before a group's pair table and stage: what the earlier pieces of its contig left pending goes in front -- split-read candidates
+ * into front[], paired-read entries to the head of pe[] -- numbered 0 .. n_virt - 1 in order of arrival.  The last piece of a
+ * contig takes the frozen entries too; any other piece takes one entry that stands for them. */
+static void stage_take_front(pgroup* G, carry_t* C)
+{
+    const gcontig* cg = &G->ctg[0];
+    G->n_front = 0; G->n_pe_front = 0; G->n_virt = 0; G->phantom = 0;
+    if (cg->first) { C->live.n = 0; C->frozen.n = 0; C->frozen_min = ~0ull; C->tid = cg->tid; return; }
+    forceassert(G->n_ctg == 1 && C->tid == cg->tid && G->n_pe == 0);
+    const int take_frozen = cg->last;
+    const int32_t n_all = C->live.n + (take_frozen ? C->frozen.n : 0);
+    G->front = xrealloc(G->front, sizeof(carry_item) * (size_t)(n_all ? n_all : 1));
+    G->front_virt = xrealloc(G->front_virt, sizeof(int32_t) * (size_t)(n_all ? n_all : 1));
+    if (n_all + 1 > G->cap_pe) {
+        G->cap_pe = n_all + 1024;
+        G->pe = xrealloc(G->pe, sizeof(evidence_t*) * (size_t)G->cap_pe);
+        G->pe_rec = xrealloc(G->pe_rec, sizeof(int64_t) * (size_t)G->cap_pe);
+    }
+    /* both lists are in order of arrival: merge */
+    int32_t a = 0, b = 0, v = 0;
+    const int32_t nb = take_frozen ? C->frozen.n : 0;
+    while (a < C->live.n || b < nb) {
+        const carry_item* it = (b >= nb || (a < C->live.n && C->live.v[a].when <= C->frozen.v[b].when)) ? &C->live.v[a++] : &C->frozen.v[b++];
+        if (it->g) { G->front[G->n_front] = *it; G->front_virt[G->n_front] = v; G->n_front++; }
+        else {
+            it->pe->arrival = (int64_t)v * 8 + 7;
+            G->pe[G->n_pe] = it->pe; G->pe_rec[G->n_pe] = -1; G->n_pe++;
+        }
+        v++;
+    }
+    if (!take_frozen && C->frozen_min != ~0ull) {
+        G->pe[G->n_pe] = phantom_entry(C->frozen_min); G->pe_rec[G->n_pe] = -1; G->n_pe++;
+        G->phantom = 1;
+    }
+    G->n_pe_front = G->n_pe;
+    G->n_virt = v;
+    C->live.n = 0;
+    if (take_frozen) { C->frozen.n = 0; C->frozen_min = ~0ull; }
+}
+
+/* After a group's stage: what no flush of it has consumed.  Nothing is left behind the last piece of a contig (its last flush takes
+ * everything).  floor = the marker floor of the contig (group_resolve_flushes): an entry with b2 >= floor is frozen. */
+static void stage_leftovers(pgroup* G, carry_t* C, int floor)
+{
+    const gcontig* cg = &G->ctg[G->n_ctg - 1];
+    if (cg->last) return;
+    forceassert(G->n_ctg == 1);
+    const int32_t nc = G->n_front + G->sv_n;
+    const int32_t frozen0 = C->frozen.n;
+    for (int32_t q = 0; q < nc; q++) {
+        carry_item live, froz;
+        int nl = 0, nf = 0;
+        for (int k = 0; k < IM_MAX_EV; k++) {
+            const size_t sl = (size_t)q * IM_MAX_EV + (size_t)k;
+            live.cls[k] = froz.cls[k] = -1; live.b1[k] = froz.b1[k] = 0; live.b2[k] = froz.b2[k] = 0;
+            if (G->s_cls[sl] < 0 || G->cons_sr[sl] != 0) continue;
+            carry_item* to = G->s_b2[sl] >= floor ? &froz : &live;
+            to->cls[k] = G->s_cls[sl]; to->b1[k] = G->s_b1[sl]; to->b2[k] = G->s_b2[sl];
+            if (to == &froz) {
+                nf++;
+                const uint64_t key = ((uint64_t)(uint32_t)G->s_b1[sl] << 32) | (uint32_t)G->s_b2[sl];
+                if (key < C->frozen_min) C->frozen_min = key;
+            } else nl++;
+        }
+        if (!nl && !nf) continue;
+        carry_item base;
+        if (q < G->n_front) base = G->front[q];
+        else { base.g = G; base.cand = q - G->n_front; base.pe = NULL; base.when = ((int64_t)G->seq << 32) | (uint32_t)G->cand_rec[q - G->n_front]; }
+        if (nl) { live.when = base.when; live.g = base.g; live.cand = base.cand; live.pe = NULL; carry_push(&C->live, &live); }
+        if (nf) { froz.when = base.when; froz.g = base.g; froz.cand = base.cand; froz.pe = NULL; carry_push(&C->frozen, &froz); }
+    }
+    /* the same for the paired-read entries; then each kind's pending items, both in order of arrival, merged into the lists */
+    carry_list pl = { NULL, 0, 0 }, pf = { NULL, 0, 0 };
+    for (int32_t i = 0; i < G->n_pe; i++) {
+        evidence_t* e = G->pe[i];
+        if (e->type == EV_PHANTOM || G->cons_pe[i] != 0) continue;
+        carry_item it;
+        memset(&it, 0, sizeof it);
+        it.g = NULL; it.pe = e; it.when = e->when;
+        for (int k = 0; k < IM_MAX_EV; k++) it.cls[k] = -1;
+        if (e->b2 >= floor) {
+            const uint64_t key = ((uint64_t)(uint32_t)e->b1 << 32) | (uint32_t)e->b2;
+            if (key < C->frozen_min) C->frozen_min = key;
+            carry_push(&pf, &it);
+        } else carry_push(&pl, &it);
+    }
+    /* C->live / C->frozen hold this stage's split-read leftovers from index n0 on (stage_take_front emptied live; frozen keeps
+     * what earlier pieces froze, all of which arrived before anything of this piece: front items are never frozen-kind) */
+    for (int pass = 0; pass < 2; pass++) {
+        carry_list* l = pass ? &C->frozen : &C->live;
+        const carry_list* pe = pass ? &pf : &pl;
+        const int32_t n0 = pass ? frozen0 : 0;
+        if (pe->n == 0) continue;
+        const int32_t nsr = l->n - n0;
+        carry_item* m = xmalloc(sizeof(carry_item) * (size_t)(nsr + pe->n));
+        int32_t a = 0, b = 0, w = 0;
+        while (a < nsr || b < pe->n) m[w++] = (b >= pe->n || (a < nsr && l->v[n0 + a].when <= pe->v[b].when)) ? l->v[n0 + a++] : pe->v[b++];
+        l->n = n0;
+        for (int32_t i = 0; i < w; i++) carry_push(l, &m[i]);
+        free(m);
+    }
+    free(pl.v); free(pf.v);
+}
 
 static void walker_adopt_driver(walker_t* W, driver* d)
 {
     W->wd = *d;                                 /* shared, read-only from here on: header, index, reference, insert lengths, GPU */
-    W->wd.readpairs = qhash_new(16);
+    W->wd.readpairs = qhash_new(4);             /* the pair table is the main thread's (group_pair_table) */
     W->wd.live = NULL; W->wd.n_live = W->wd.cap_live = 0; W->wd.live_changed = 0;
     W->wd.rg_last_val = NULL; W->wd.rg_last_name[0] = 0;
     W->wd.gpu_pending = 0;
@@ -3644,11 +3825,22 @@ static void walker_adopt_driver(walker_t* W, driver* d)
 static void walker_setup(walker_t* W, driver* d)
 {
     W->wd.gpu = d->gpu;
-    pipe_init(&W->P, &W->wd);
+    pipe_init(&W->P, &W->wd, 1);
     W->r = bgzf_open(d->bam_name);
     if (!W->r) fatalf("error in opening the file %s", d->bam_name);
     W->hdr = bam_header_load(W->r);
     if (!W->hdr) fatalf("%s is not a BAM file", d->bam_name);
+}
+
+/* one claim: its pieces through the walker's pipeline into a new group, the group's device arrays parked */
+static pgroup* walk_claim(walker_t* W, walkpool_t* o, const claim_t* c)
+{
+    pgroup* G = xcalloc(1, sizeof(pgroup));
+    for (int k = 0; k < c->count; k++) pipe_walk_piece(&W->P, G, &o->pieces[c->first + k], W->r);
+    pipe_submit(&W->P, G);
+    pipe_drain(&W->P, G);
+    group_park_device(&W->P, G);
+    return G;
 }
 
 static void* walker_thread(void* arg)
@@ -3668,47 +3860,49 @@ static void* walker_thread(void* arg)
     walker_adopt_driver(W, d);
     for (;;) {
         pthread_mutex_lock(&o->mu);
+        /* walked groups wait for the main thread with their logs and parked arrays: stay a bounded number of claims ahead of it */
+        while (!g_onepass && o->next_claim < o->n_claims && o->next_claim >= o->staged + 2 * o->nw + 4) pthread_cond_wait(&o->cv, &o->mu);
         const int ci = o->next_claim < o->n_claims ? o->next_claim++ : -1;
-        /* this walker's device arrays are free once its previous group went through the device stage, the group buffer
-         * once the group that used it last has been replayed */
-        while (ci >= 0 && (W->device_free < W->n_started || (!g_onepass && W->G[W->n_started & 1].in_use))) pthread_cond_wait(&o->cv, &o->mu);
         pthread_mutex_unlock(&o->mu);
         if (ci < 0) break;
         claim_t* c = &o->claims[ci];
-        pgroup* G = g_onepass ? xcalloc(1, sizeof(pgroup)) : &W->G[W->n_started & 1];      /* one-pass: the group outlives the walk */
-        if (g_handoff_pool && !g_onepass) {
+        if (g_handoff_pool) {
             /* a record the reference dies on ends this walker: the claim is published as it is, marked */
             W->cur_claim = c;
             if (setjmp(W->abort_jmp)) {
                 pthread_mutex_lock(&o->mu);
-                W->cur_claim->W = W; W->cur_claim->G = NULL; W->cur_claim->aborted = 1; W->cur_claim->walked = 1;
+                W->cur_claim->G = NULL; W->cur_claim->aborted = 1; W->cur_claim->walked = 1;
                 pthread_cond_broadcast(&o->cv);
                 pthread_mutex_unlock(&o->mu);
                 return NULL;
             }
             t_abort_jmp = &W->abort_jmp;
         }
-        for (int k = 0; k < c->count; k++) pipe_walk_contig(&W->P, G, o->order[c->first + k], W->r);
-        pipe_submit(&W->P, G);
-        pipe_drain(&W->P, G);
+        pgroup* G = walk_claim(W, o, c);
         t_abort_jmp = NULL;
-        if (g_onepass) group_park_device(&W->P, G);
         pthread_mutex_lock(&o->mu);
-        c->W = W; c->G = G; c->walked = 1; G->in_use = 1; if (!g_onepass) W->n_started++;
+        c->G = G; c->walked = 1;
         pthread_cond_broadcast(&o->cv);
         pthread_mutex_unlock(&o->mu);
     }
     return NULL;
 }
 
+typedef struct { struct walkpool_s* o; int first, step; driver rd; pthread_t th; } apply_job;
 static void* apply_thread(void* arg)
 {
     apply_job* j = arg;
     for (int ci = j->first; ci < j->o->n_claims; ci += j->step) {
         pgroup* G = j->o->claims[ci].G;
-        G->sv_range = group_apply_ranges(&j->rd, G);
+        G->sv_range = group_ranges(&j->rd, G);
     }
     return NULL;
+}
+
+/* groups of a contig are freed together: pending evidence points back at the groups it came from */
+static void groups_free_chain(pgroup* G)
+{
+    while (G) { pgroup* n = G->next_of_contig; group_free(G); free(G); G = n; }
 }
 
 static void* replay_thread(void* arg)
@@ -3731,51 +3925,74 @@ static void* replay_thread(void* arg)
         group_replay(&R->rd, J->G);
         fclose(t_out);
         t_out = NULL;
-        pgroup* Gd = J->G;
-        if (g_onepass) { group_free(Gd); free(Gd); J->G = NULL; Gd = NULL; }
-        else group_reset(Gd);
         pthread_mutex_lock(&o->mu);
-        if (Gd) Gd->in_use = 0;
-        J->W->replayed++; J->done = 1;
+        J->done = 1;
         pthread_cond_broadcast(&o->cv);
         pthread_mutex_unlock(&o->mu);
     }
     return NULL;
 }
 
-/* Called as soon as the BAM header is known: plans the claims and starts the walkers, which set their buffers up in the
- * background and then wait for run_pipeline's go. */
+/* Called as soon as the BAM header and index are known: cuts this process's share of the file into pieces, plans the claims and
+ * starts the walkers, which set their buffers up in the background and then wait for run_pipeline's go. */
 static walkpool_t* walkpool_start(driver* d)
 {
     walkpool_t* o = xcalloc(1, sizeof *o);
     o->d = d;
     pthread_mutex_init(&o->mu, NULL); pthread_cond_init(&o->cv, NULL);
     const int32_t nt = d->hdr->n_targets;
-    o->order = xmalloc(sizeof(int32_t) * (size_t)(nt ? nt : 1));
-    int64_t total_len = 0;
-    for (int32_t i = 0; i < nt; i++) {
-        if (g_mg && g_mg->owner[i] != g_mg->rank) continue;         /* another rank's contig */
-        o->order[o->n_order++] = i;
-        total_len += d->hdr->target_len[i];
-    }
-    /* annotate mode shares the known-variant list with the replay and skips contigs without variants: one walker, one contig
-     * per claim, walked by the main thread only after the previous one has been replayed */
+    /* annotate mode shares the known-variant list with the replay and skips contigs without variants: one walker, one whole
+     * contig per claim, walked by the main thread only after the previous one has been replayed */
     o->serial = g_vcfname != NULL;
     const char* e = getenv("INDELMINER_WALKERS");
-    int nw = e ? atoi(e) : 4;
+    long ncpu = sysconf(_SC_NPROCESSORS_ONLN);
+    {   /* the cores this process may use, not the machine's (a container's CPU quota) */
+        FILE* fp = fopen("/sys/fs/cgroup/cpu.max", "r");
+        long quota = 0, period = 0;
+        if (fp) { if (fscanf(fp, "%ld %ld", &quota, &period) == 2 && quota > 0 && period > 0 && quota / period < ncpu) ncpu = quota / period; fclose(fp); }
+        if (ncpu < 1) ncpu = 1;
+    }
+    int nw = e ? atoi(e) : (ncpu >= 12 ? 8 : 4);
     if (o->serial || nw < 1) nw = 1;
-    if (nw > 16) nw = 16;
-    /* claims: consecutive contigs up to about 1/(4 walkers) of the reference each, so that small contigs share a group
-     * (the device stage and the replay have fixed costs per group) and large ones spread over the walkers */
+    if (nw > 32) nw = 32;
+    int64_t total_bytes = 0, total_len = 0;
+    for (int32_t i = 0; i < nt; i++) {
+        if (g_mg && g_mg->owner[i] != g_mg->rank) continue;
+        total_bytes += bai_contig_bytes(d->idx, i); total_len += d->hdr->target_len[i];
+    }
+    /* pieces: a contig is cut where its compressed bytes cross multiples of the piece size -- about 1/(8 walkers) of the file, at
+     * least 8 MB of it (a stage and a replay have fixed costs per group), so that large contigs spread over all walkers */
+    int64_t piece_bytes = total_bytes / (8 * (int64_t)nw);
+    if (piece_bytes < (8 << 20)) piece_bytes = 8 << 20;
+    if (getenv("INDELMINER_PIECE_BYTES")) piece_bytes = atoll(getenv("INDELMINER_PIECE_BYTES"));
+    if (o->serial) piece_bytes = 0;
+    int cap = 0;
+    for (int32_t i = 0; i < nt; i++) {
+        if (g_mg && g_mg->owner[i] != g_mg->rank) continue;         /* another rank's contig */
+        int32_t cuts[4096];
+        const int nc = piece_bytes > 0 ? bai_split_points(d->idx, i, d->hdr->target_len[i], piece_bytes, cuts, 4096) : 0;
+        if (o->n_pieces + nc + 1 > cap) { cap = (cap + nc + 1) * 2; o->pieces = xrealloc(o->pieces, sizeof(piece_t) * (size_t)cap); }
+        const int64_t w = bai_contig_bytes(d->idx, i);
+        for (int k = 0; k <= nc; k++) {
+            piece_t* pc = &o->pieces[o->n_pieces++];
+            pc->tid = i; pc->beg = k ? cuts[k - 1] : 0; pc->end = k < nc ? cuts[k] : d->hdr->target_len[i];
+            pc->first = k == 0; pc->last = k == nc; pc->weight = w / (nc + 1);
+        }
+    }
+    /* claims: a piece of a cut contig on its own; whole small contigs together up to about a piece's worth (the stage and the
+     * replay have fixed costs per group) */
     int64_t claim_len = total_len / (4 * (int64_t)nw);
     if (claim_len < 2000000) claim_len = 2000000;
     if (getenv("INDELMINER_CLAIM_BASES")) claim_len = atoll(getenv("INDELMINER_CLAIM_BASES"));
-    o->claims = xcalloc((size_t)(o->n_order ? o->n_order : 1), sizeof(claim_t));
-    for (int k = 0; k < o->n_order;) {
+    o->claims = xcalloc((size_t)(o->n_pieces ? o->n_pieces : 1), sizeof(claim_t));
+    for (int k = 0; k < o->n_pieces;) {
         claim_t* c = &o->claims[o->n_claims++];
         c->first = k;
+        const piece_t* p0 = &o->pieces[k];
         int64_t len = 0;
-        do { len += d->hdr->target_len[o->order[k]]; k++; } while (!o->serial && k < o->n_order && len + d->hdr->target_len[o->order[k]] <= claim_len);
+        if (!(p0->first && p0->last)) { k++; c->count = 1; continue; }
+        do { len += d->hdr->target_len[o->pieces[k].tid]; k++; }
+        while (!o->serial && k < o->n_pieces && o->pieces[k].first && o->pieces[k].last && len + d->hdr->target_len[o->pieces[k].tid] <= claim_len);
         c->count = k - c->first;
     }
     if (nw > o->n_claims) nw = o->n_claims ? o->n_claims : 1;
@@ -3805,48 +4022,54 @@ static void run_pipeline(driver* d, walkpool_t* o)
     pipe_global_init(d);
     if (o->serial) { walker_setup(&o->w[0], d); walker_adopt_driver(&o->w[0], d); }
     pthread_mutex_lock(&o->mu); o->go = 1; pthread_cond_broadcast(&o->cv); pthread_mutex_unlock(&o->mu);
+    /* the main thread's own pipeline: the stage of every group */
+    driver sd = *d;
+    ppipe S;
+    pipe_init(&S, &sd, 0);
     if (g_onepass) {
         /* ONE pass over the BAM: the walk above runs without insert lengths (which records are candidates does not depend on
-         * them; the triage leaves range_max open and the records of not-proper pairs wait in the group), collecting the
-         * extrema per read group as estimate_insertlengths would (src/bamoperations.c:15-86).  When every contig is in, the
-         * table is made -- read groups in the order one process meets them -- and the device stage of every group follows. */
+         * them; the triage leaves range_max open), collecting the extrema per read group as estimate_insertlengths would
+         * (src/bamoperations.c:15-86).  When every piece is in, the table is made -- read groups in the order one process
+         * meets them -- and the stage of every group follows. */
         pthread_mutex_lock(&o->mu);
         for (int ci = 0; ci < o->n_claims; ci++) while (!o->claims[ci].walked) pthread_cond_wait(&o->cv, &o->mu);
         pthread_mutex_unlock(&o->mu);
         for (int i = 0; i < o->nw; i++) pthread_join(o->w[i].th, NULL);
-        phase_time("the walk of all contigs (inflate + count + insert-length extrema; triage on the device)");
-        mg_rg* all = xcalloc((size_t)(o->n_claims ? o->n_claims : 1) * MG_MAX_RG, sizeof(mg_rg));
-        int n_all = 0;
-        for (int ci = 0; ci < o->n_claims; ci++) {
-            const pgroup* G = o->claims[ci].G;
-            for (int k = 0; k < G->n_rgs; k++) {
-                mg_rg* m = &all[n_all++];
-                snprintf(m->name, sizeof m->name, "%s", G->rgs[k].name);
-                m->min = G->rgs[k].min; m->max = G->rgs[k].max; m->first_tid = G->rgs[k].first_tid; m->first_rec = G->rgs[k].first_rec;
+        phase_time("the walk of all pieces (inflate + count + insert-length extrema; triage on the device)");
+        int aborted = 0;
+        for (int ci = 0; ci < o->n_claims; ci++) aborted |= o->claims[ci].aborted;
+        if (aborted && g_handoff_pool) pipeline_handoff();      /* nothing is out yet: the record-at-a-time run prints it all */
+        if (!aborted) {
+            mg_rg* all = xcalloc((size_t)(o->n_claims ? o->n_claims : 1) * MG_MAX_RG, sizeof(mg_rg));
+            int n_all = 0;
+            for (int ci = 0; ci < o->n_claims; ci++) {
+                const pgroup* G = o->claims[ci].G;
+                for (int k = 0; k < G->n_rgs; k++) {
+                    mg_rg* m = &all[n_all++];
+                    snprintf(m->name, sizeof m->name, "%s", G->rgs[k].name);
+                    m->min = G->rgs[k].min; m->max = G->rgs[k].max; m->first_tid = G->rgs[k].first_tid; m->first_rec = G->rgs[k].first_rec; m->seen = 1;
+                }
             }
-        }
-        mg_rg* merged = xcalloc((size_t)(n_all ? n_all : 1), sizeof(mg_rg));
-        const int n = merge_rgs(all, n_all, merged);
-        fprintf(stderr, "\nRead-group\tMin-value\tMax-value (estimated during the walk)\n");
-        for (int j = 0; j < n; j++) rg_table_enter(d, &merged[j]);
-        for (int j = 0; j < g_rg_n; j++) fprintf(stderr, "%s\t%d\t%d\n", g_rg_name[j], g_rg_range[j][0], g_rg_range[j][1]);
-        free(all); free(merged);
-        pipe_global_init(d);
-        /* every group's ranges and pair-table replay, the groups spread over threads (each with a pair table of its own) */
-        {
+            mg_rg* merged = xcalloc((size_t)(n_all ? n_all : 1), sizeof(mg_rg));
+            const int n = merge_rgs(all, n_all, merged);
+            fprintf(stderr, "\nRead-group\tMin-value\tMax-value (estimated during the walk)\n");
+            for (int j = 0; j < n; j++) rg_table_enter(d, &merged[j]);
+            for (int j = 0; j < g_rg_n; j++) fprintf(stderr, "%s\t%d\t%d\n", g_rg_name[j], g_rg_range[j][0], g_rg_range[j][1]);
+            free(all); free(merged);
+            pipe_global_init(d);
+            /* every group's candidates get their range[1], the groups spread over threads */
             int nt = o->nw > 1 ? o->nw : 1;
             if (nt > o->n_claims) nt = o->n_claims ? o->n_claims : 1;
             apply_job* aj = xcalloc((size_t)nt, sizeof(apply_job));
             for (int i = 0; i < nt; i++) {
                 aj[i].o = o; aj[i].first = i; aj[i].step = nt; aj[i].rd = *d;
-                aj[i].rd.readpairs = qhash_new(16); aj[i].rd.live = NULL; aj[i].rd.n_live = aj[i].rd.cap_live = 0; aj[i].rd.live_changed = 0;
                 aj[i].rd.rg_last_val = NULL; aj[i].rd.rg_last_name[0] = 0; aj[i].rd.gpu_pending = 0;
                 if (pthread_create(&aj[i].th, NULL, apply_thread, &aj[i]) != 0) fatalf("cannot start a thread");
             }
             for (int i = 0; i < nt; i++) pthread_join(aj[i].th, NULL);
             free(aj);
+            phase_time("insert lengths applied: candidates' ranges");
         }
-        phase_time("insert lengths applied: candidates' ranges, pair tables");
     }
     /* Replay workers: the replay of a group (evidence objects, paired-read components, merge, print) is the longest serial
      * piece of a run once the walks overlap; groups are independent of each other, so several are replayed at once, each
@@ -3857,7 +4080,7 @@ static void run_pipeline(driver* d, walkpool_t* o)
     if (o->serial || g_mg || strcmp(O.outputformat, "vcf") != 0 || nrep < 2) nrep = 0;
     if (nrep > 8) nrep = 8;
     replayer_t* rp = nrep ? xcalloc((size_t)nrep, sizeof(replayer_t)) : NULL;
-    if (nrep) o->jobs = xcalloc((size_t)(o->n_claims ? o->n_claims : 1), sizeof(rjob_t));
+    o->jobs = xcalloc((size_t)(o->n_claims ? o->n_claims : 1), sizeof(rjob_t));
     for (int i = 0; i < nrep; i++) {
         rp[i].pool = o; rp[i].rd = *d; rp[i].rd.gpu_pending = 0;
         if (pthread_create(&rp[i].th, NULL, replay_thread, &rp[i]) != 0) fatalf("cannot start a replay thread");
@@ -3865,50 +4088,69 @@ static void run_pipeline(driver* d, walkpool_t* o)
     o->printed = 0;
     int64_t numread = d->numread;
     int floor_ = d->marker_floor;
+    carry_t C;
+    memset(&C, 0, sizeof C);
+    C.frozen_min = ~0ull; C.tid = -1;
+    /* groups of the contig being worked on: their replays start when the contig's depth array is complete (its last piece is in) */
+    pgroup** held = xcalloc((size_t)(o->n_claims ? o->n_claims : 1), sizeof(pgroup*));
+    int n_held = 0;
+    pgroup* chain = NULL;                   /* the same groups, for freeing them together */
+    int n_freeable = 0;
+    struct { pgroup* chain; int last_job; } *dead = xcalloc((size_t)(o->n_claims ? o->n_claims : 1), sizeof *dead);
     for (int ci = 0; ci < o->n_claims; ci++) {
         claim_t* c = &o->claims[ci];
-        g_mg_cur_tid = o->order[c->first];
+        g_mg_cur_tid = o->pieces[c->first].tid;
         if (o->serial) {
             /* walked here, after the replay of the previous contig let go of the known-variant list */
-            const int32_t tid = o->order[c->first];
+            const int32_t tid = o->pieces[c->first].tid;
             known_free(&g_known);
             read_variants(g_vcfname, tid, d->hdr->target_name[tid], &g_known);
-            if (g_known.n == 0) continue;           /* src/indelminer.c:788 */
-            walker_t* W = &o->w[0];
-            pgroup* G = &W->G[0];
+            if (g_known.n == 0) { pthread_mutex_lock(&o->mu); o->staged = ci + 1; pthread_mutex_unlock(&o->mu); continue; }   /* src/indelminer.c:788 */
             g_main_in_walk = g_handoff_pool != NULL;
-            pipe_walk_contig(&W->P, G, tid, W->r);
-            pipe_submit(&W->P, G);
-            pipe_drain(&W->P, G);
+            c->G = walk_claim(&o->w[0], o, c);
             g_main_in_walk = 0;
-            c->W = W; c->G = G; c->walked = 1;
+            c->walked = 1;
         } else {
             pthread_mutex_lock(&o->mu);
             while (!c->walked) pthread_cond_wait(&o->cv, &o->mu);
             pthread_mutex_unlock(&o->mu);
             if (c->aborted) pipeline_handoff();
         }
-        phase_time("waited for the walk (inflate + count + pair table; triage on the device)");
-        walker_t* W = c->W;
+        phase_time("waited for the walk (inflate + count; triage on the device)");
         pgroup* G = c->G;
-        if (g_onepass) {
-            /* the group's candidates come back into a pipeline (the first walker's: all walkers are done), ranges filled in */
-            W = &o->w[0];
-            group_unpark_device(&W->P, G, G->sv_range);
-            free(G->sv_range); G->sv_range = NULL;
-        }
+        G->seq = ci;
+        const int first_of_contig = G->ctg[0].first, last_of_contig = G->ctg[G->n_ctg - 1].last;
+        const int floor_of_contig = (g_mg && first_of_contig) ? g_mg->floor[G->ctg[0].tid] : floor_;
+        static int contig_floor;            /* the floor all pieces of the contig in hand are measured against */
+        if (first_of_contig) contig_floor = floor_of_contig;
+        stage_take_front(G, &C);
+        g_main_in_walk = g_handoff_pool != NULL;        /* a record the reference dies on inside the pair table: hand the run over */
+        group_pair_table(d, G);
+        g_main_in_walk = 0;
         if (!g_mg && group_meets_earlier_contigs(G)) {
             if (g_handoff_pool) pipeline_handoff();
             fatalf("read names are shared between contigs (the reference pairs them across contigs in its one pair table): run with INDELMINER_PIPELINE=host");
         }
         group_resolve_flushes(G, &numread, &floor_);
-        pipe_run_group(&W->P, G);
-        pthread_mutex_lock(&o->mu); W->device_free++; pthread_cond_broadcast(&o->cv); pthread_mutex_unlock(&o->mu);
+        stage_run_group(&S, G);
+        stage_leftovers(G, &C, contig_floor);
+        pthread_mutex_lock(&o->mu); o->staged = ci + 1; pthread_cond_broadcast(&o->cv); pthread_mutex_unlock(&o->mu);
+        G->next_of_contig = chain; chain = G;
+        held[n_held++] = G;
+        if (!last_of_contig) continue;
+        /* the contig (or the run of small contigs) is complete: its depth array, then its groups' replays */
+        for (int k = 0; k < n_held; k++)
+            for (int cj = 0; cj < held[k]->n_ctg; cj++)
+                if (held[k]->ctg[cj].last) GPU2(d, im_depth_scan(d->gpu, held[k]->ctg[cj].tid, S.stream));
+        GPU2(d, im_stream_sync(d->gpu, S.stream));
         if (nrep) {
             pthread_mutex_lock(&o->mu);
-            rjob_t* J = &o->jobs[o->n_jobs];
-            J->W = W; J->G = G; J->buf = NULL; J->len = 0; J->done = 0;
-            o->n_jobs++;
+            for (int k = 0; k < n_held; k++) {
+                rjob_t* J = &o->jobs[o->n_jobs];
+                J->G = held[k]; J->buf = NULL; J->len = 0; J->done = 0; J->last_of_contig = k == n_held - 1;
+                o->n_jobs++;
+            }
+            dead[n_freeable].chain = chain; dead[n_freeable].last_job = o->n_jobs - 1; n_freeable++;
             pthread_cond_broadcast(&o->cv);
             /* whatever is complete at the head of the queue goes out now */
             while (o->printed < o->n_jobs && o->jobs[o->printed].done) {
@@ -3918,13 +4160,20 @@ static void run_pipeline(driver* d, walkpool_t* o)
                 free(P->buf);
                 pthread_mutex_lock(&o->mu);
             }
+            /* contigs whose every replay is done: their groups go */
+            for (int k = 0; k < n_freeable; k++) {
+                if (!dead[k].chain) continue;
+                int all = 1;
+                for (int j = k ? dead[k - 1].last_job + 1 : 0; j <= dead[k].last_job; j++) all &= o->jobs[j].done;
+                if (all) { pgroup* ch = dead[k].chain; dead[k].chain = NULL; pthread_mutex_unlock(&o->mu); groups_free_chain(ch); pthread_mutex_lock(&o->mu); }
+            }
             pthread_mutex_unlock(&o->mu);
-            continue;
+        } else {
+            for (int k = 0; k < n_held; k++) group_replay(d, held[k]);
+            phase_time("replay (variants, merge, print)");
+            groups_free_chain(chain);
         }
-        group_replay(d, G);
-        phase_time("replay (variants, merge, print)");
-        if (g_onepass) { group_free(G); free(G); G = NULL; } else group_reset(G);
-        pthread_mutex_lock(&o->mu); if (G) G->in_use = 0; W->replayed++; pthread_cond_broadcast(&o->cv); pthread_mutex_unlock(&o->mu);
+        n_held = 0; chain = NULL;
     }
     if (nrep) {
         pthread_mutex_lock(&o->mu);
@@ -3943,8 +4192,10 @@ static void run_pipeline(driver* d, walkpool_t* o)
         fflush(OUT);
         fflush(stdout);
         phase_time("replay workers drained");
-        free(rp); free(o->jobs);
+        if (getenv("INDELMINER_TIDY_EXIT")) for (int k = 0; k < n_freeable; k++) if (dead[k].chain) groups_free_chain(dead[k].chain);
+        free(rp);
     }
+    free(o->jobs); o->jobs = NULL; free(held); free(dead);
     d->numread = numread;
     if (g_handoff_pool) { g_handoff_pool = NULL; if (t_out) { fflush(t_out); fclose(t_out); t_out = NULL; } }
     for (int i = 0; i < o->nw && !o->serial && !g_onepass; i++) pthread_join(o->w[i].th, NULL);
@@ -3954,14 +4205,13 @@ static void run_pipeline(driver* d, walkpool_t* o)
         for (int i = 0; i < o->nw; i++) {
             walker_t* W = &o->w[i];
             pipe_destroy(&W->P);
-            group_free(&W->G[0]); group_free(&W->G[1]);
             bam_header_free(W->hdr);
             bgzf_close(W->r);
-            while (W->wd.n_live > 0) { evidence_t* ev = W->wd.live[W->wd.n_live - 1]; live_del(&W->wd, ev); evidence_free(ev); }
-            free(W->wd.live);
-            qhash_free(W->wd.readpairs, NULL);
         }
-        free(o->w); free(o->claims); free(o->order);
+        pipe_destroy(&S);
+        pair_table_clear(d);
+        free(C.live.v); free(C.frozen.v);
+        free(o->w); free(o->claims); free(o->pieces);
         free(o);
     }
 }

@@ -56,6 +56,7 @@ typedef struct {
     int      used;
     int64_t  arrival;               /* position in arrival order */
     int32_t  live_slot;             /* paired-read evidence waiting for its second mate: index in the driver's live list */
+    int64_t  when;                  /* paired-read evidence: where in the contig it was completed (piece << 32 | record), see carry_item */
 } evidence_t;
 
 typedef struct {

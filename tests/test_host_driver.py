@@ -490,6 +490,44 @@ def _shared_names_dir(tmp_path, ref_len=200_000):
     return str(tmp_path)
 
 
+PIECE_ENVS = [{"INDELMINER_PIECE_BYTES": "150000"}, {"INDELMINER_PIECE_BYTES": "1000000", "INDELMINER_WALKERS": "3"},
+              {"INDELMINER_PIECE_BYTES": "40000", "INDELMINER_WALKERS": "6", "INDELMINER_REPLAYERS": "4"},
+              {"INDELMINER_PIECE_BYTES": "300000", "INDELMINER_ONEPASS": "1"}, {"INDELMINER_PIECE_BYTES": "300000", "INDELMINER_FLUSH_MODE": "seq"},
+              {"INDELMINER_PIECE_BYTES": "500000", "INDELMINER_WALKERS": "1", "INDELMINER_THREADS": "0"}]
+
+
+def test_host_contigs_walked_in_pieces(synth_small, synth_1mb):
+    """A contig is cut into pieces (records by start position) that walkers take at the same time; the pair table, the read
+    counter and the evidence no flush has consumed yet carry over from piece to piece on the main thread: the bytes of the whole-contig
+    run whatever the piece size -- pieces of a few hundred reads up to a third of the contig, READCHUNK flushes inside and across
+    them, COMPOSITE calls whose mates lie in different pieces; also with the insert lengths estimated by the same pass"""
+    shim = _build_shim()
+    for d, golden, flags in ((synth_1mb, "synth_1mb_30x", ["-i", "cfg.txt"]), (synth_1mb, "synth_1mb_30x_noconfig", []),
+                             (synth_small, "synth_2ctg_composite", ["-i", "cfg.txt"]), (synth_small, "synth_2ctg_composite_noconfig", [])):
+        want = _golden(golden)
+        for env in PIECE_ENVS:
+            if flags and "INDELMINER_ONEPASS" in env:
+                continue
+            assert _run(shim, flags, d, ref="ref.fa", bam="aln.bam", env=env) == want, (golden, env)
+
+
+def test_host_pieces_with_markers_pinned_low(tmp_path):
+    """first mates that wait for ever pin every later marker (also of later contigs): nearly all evidence then waits for its contig's
+    last flush -- the frozen entries skip the piece-to-piece chain and one entry carries their smallest key for the cuts in between;
+    and a detailed run (blocks numbered across the run, replay on the main thread)"""
+    d = _stale_dir(tmp_path, ref_len=400_000)
+    shim = _build_shim()
+    want = _run(shim, [], d, ref="ref.fa", bam="aln.bam", env={"INDELMINER_PIPELINE": "host"})
+    det = _run(shim, ["-o", "detailed"], d, ref="ref.fa", bam="aln.bam", env={"INDELMINER_PIPELINE": "host"})
+    for env in PIECE_ENVS:
+        assert _run(shim, [], d, ref="ref.fa", bam="aln.bam", env=env) == want, env
+    assert _run(shim, ["-o", "detailed"], d, ref="ref.fa", bam="aln.bam", env=PIECE_ENVS[0]) == det
+    d2 = _many_waiting_dir(tmp_path / "w" if (tmp_path / "w").mkdir() is None else tmp_path)
+    want2 = _run(shim, ["-i", "cfg.txt"], d2, ref="ref.fa", bam="aln.bam", env={"INDELMINER_PIPELINE": "host"})
+    for env in PIECE_ENVS[:3]:
+        assert _run(shim, ["-i", "cfg.txt"], d2, ref="ref.fa", bam="aln.bam", env=env) == want2, env
+
+
 def test_host_names_shared_between_contigs_go_to_the_one_table(tmp_path):
     """the pipeline walks contigs independently; when a record goes through the pair table under the name of an entry an
     earlier contig left waiting, the run is handed to the record-at-a-time path, which keeps the reference's one table"""
