@@ -2058,7 +2058,8 @@ static int g_onepass;               /* set before the walkers start */
 
 /* A PIECE of a contig: the records that start in [beg, end).  Whole small contigs are pieces too (first and last at once).
  * Pieces are what the walkers claim: a contig of any size spreads over all of them. */
-typedef struct { int32_t tid, beg, end; int first, last; int64_t weight; } piece_t;
+typedef struct { int32_t tid, beg, end; int first, last; int64_t weight; int overlap; } piece_t;   /* overlap: a -c region's first piece also takes the records that begin in front of it and reach into it (bam_fetch) */
+static int g_region_tid = -1, g_region_beg = 0, g_region_end = 0;      /* -c: the one stretch this run works on */
 
 typedef struct {
     int32_t tid; int64_t rec0, rec1; int32_t pe0, pe1; int fl0, fl1;
@@ -2217,7 +2218,7 @@ static void pipe_init(ppipe* P, driver* d, int with_chunks)
     P->fdesc = pdev_alloc(P, sizeof(im_flush_desc) * (size_t)P->cap_fl);
     pipe_alloc_cands(P, 1 << 20, (int64_t)(1 << 20) * 160, 1 << 16);
     P->tp.qthreshold = O.qthreshold; P->tp.ethreshold_vcfcheck = O.ethreshold_vcfcheck; P->tp.maxpedelsize = O.maxpedelsize;   /* options are parsed before any thread starts */
-    P->tp.want_depth = 1;
+    P->tp.want_depth = g_region_tid < 0;        /* -c: DP= comes from the file around each variant, like the reference's (region_depth) */
     P->tp.defer_ranges = g_onepass;
     P->ready = 1;
 }
@@ -2558,7 +2559,7 @@ static void pipe_walk_piece(ppipe* P, pgroup* G, const piece_t* pc, bgzf_reader*
     cg->beg = pc->beg; cg->end = pc->end; cg->first = pc->first; cg->last = pc->last; cg->lm_init = INT_MAX; cg->left_min = INT_MAX;
     G->cur_ctg = G->n_ctg - 1;
     bam_region_iter it;
-    if (bam_piece_begin(&it, r, d->idx, tid, pc->beg, pc->end) != 0) fatalf("cannot seek in %s", d->bam_name);
+    if ((pc->overlap ? bam_region_begin(&it, r, d->idx, tid, pc->beg, pc->end) : bam_piece_begin(&it, r, d->idx, tid, pc->beg, pc->end)) != 0) fatalf("cannot seek in %s", d->bam_name);
     bam_record b; memset(&b, 0, sizeof b);
     for (;;) {
         pchunk* c = &P->ck[P->cur];
@@ -2968,7 +2969,7 @@ static void group_replay(driver* d, pgroup* G)
     for (int ci = 0; ci < G->n_ctg; ci++) {
         const gcontig* cg = &G->ctg[ci];
         const int32_t tid = cg->tid;
-        d->depth_tid = tid;
+        d->depth_tid = g_region_tid < 0 ? tid : -1;     /* -c: the depth of a variant is taken from the file (it reaches outside the stretch) */
         if (g_mg) {                                     /* one VCF part per contig, concatenated by rank 0 in contig order */
             char path[512];
             mg_path(g_mg, path, sizeof path, "part", tid);
@@ -3958,6 +3959,7 @@ static walkpool_t* walkpool_start(driver* d)
     int64_t total_bytes = 0, total_len = 0;
     for (int32_t i = 0; i < nt; i++) {
         if (g_mg && g_mg->owner[i] != g_mg->rank) continue;
+        if (g_region_tid >= 0 && i != g_region_tid) continue;
         total_bytes += bai_contig_bytes(d->idx, i); total_len += d->hdr->target_len[i];
     }
     /* pieces: a contig is cut where its compressed bytes cross multiples of the piece size -- about 1/(8 walkers) of the file, at
@@ -3969,14 +3971,24 @@ static walkpool_t* walkpool_start(driver* d)
     int cap = 0;
     for (int32_t i = 0; i < nt; i++) {
         if (g_mg && g_mg->owner[i] != g_mg->rank) continue;         /* another rank's contig */
+        if (g_region_tid >= 0 && i != g_region_tid) continue;
         int32_t cuts[4096];
-        const int nc = piece_bytes > 0 ? bai_split_points(d->idx, i, d->hdr->target_len[i], piece_bytes, cuts, 4096) : 0;
+        int nc = piece_bytes > 0 ? bai_split_points(d->idx, i, d->hdr->target_len[i], piece_bytes, cuts, 4096) : 0;
+        int32_t lo = 0, hi = d->hdr->target_len[i];
+        if (g_region_tid >= 0) {
+            /* -c: the stretch [beg, end) only; cuts outside it go */
+            lo = g_region_beg < 0 ? 0 : g_region_beg; hi = g_region_end;
+            int m = 0;
+            for (int k = 0; k < nc; k++) if (cuts[k] > lo && cuts[k] < hi) cuts[m++] = cuts[k];
+            nc = m;
+        }
         if (o->n_pieces + nc + 1 > cap) { cap = (cap + nc + 1) * 2; o->pieces = xrealloc(o->pieces, sizeof(piece_t) * (size_t)cap); }
         const int64_t w = bai_contig_bytes(d->idx, i);
         for (int k = 0; k <= nc; k++) {
             piece_t* pc = &o->pieces[o->n_pieces++];
-            pc->tid = i; pc->beg = k ? cuts[k - 1] : 0; pc->end = k < nc ? cuts[k] : d->hdr->target_len[i];
+            pc->tid = i; pc->beg = k ? cuts[k - 1] : lo; pc->end = k < nc ? cuts[k] : hi;
             pc->first = k == 0; pc->last = k == nc; pc->weight = w / (nc + 1);
+            pc->overlap = g_region_tid >= 0 && k == 0;
         }
     }
     /* claims: a piece of a cut contig on its own; whole small contigs together up to about a piece's worth (the stage and the
@@ -4141,7 +4153,7 @@ static void run_pipeline(driver* d, walkpool_t* o)
         /* the contig (or the run of small contigs) is complete: its depth array, then its groups' replays */
         for (int k = 0; k < n_held; k++)
             for (int cj = 0; cj < held[k]->n_ctg; cj++)
-                if (held[k]->ctg[cj].last) GPU2(d, im_depth_scan(d->gpu, held[k]->ctg[cj].tid, S.stream));
+                if (held[k]->ctg[cj].last && g_region_tid < 0) GPU2(d, im_depth_scan(d->gpu, held[k]->ctg[cj].tid, S.stream));
         GPU2(d, im_stream_sync(d->gpu, S.stream));
         if (nrep) {
             pthread_mutex_lock(&o->mu);
@@ -4479,15 +4491,22 @@ int main(int argc, char** argv)
     pthread_mutex_init(&d.gpu_mu, NULL); pthread_cond_init(&d.gpu_cv, NULL);
     d.gpu_pending = 1;
     if (pthread_create(&d.gpu_thread, NULL, gpu_open_thread, &d) != 0) fatalf("cannot start the GPU helper thread");
-    /* whole-contig runs take the device pipeline (region runs, -c, keep the per-contig host path, whose mate look-ups and
-     * depth queries go to the BAM file like the reference's): its walkers set their buffers up from now on */
+    /* the device pipeline: its walkers set their buffers up from now on.  A region run (-c) is the same pipeline over the pieces of
+     * one stretch of one contig (its first piece also takes the records that reach into it from the front, as bam_fetch does;
+     * mates outside the stretch and the depth around a variant are looked up in the file, like the reference does).
+     * INDELMINER_PIPELINE=host is the record-at-a-time path, kept for runs the reference aborts (handoff_to_host_child). */
     walkpool_t* pool = NULL;
     {
         const char* pl0 = getenv("INDELMINER_PIPELINE");
-        if (chromid == -1 && !(pl0 && strcmp(pl0, "host") == 0)) {
+        if (!(pl0 && strcmp(pl0, "host") == 0)) {
+            if (chromid != -1) {
+                g_region_tid = chromid; g_region_beg = chromstart; g_region_end = chromstop;
+                if (g_region_end > d.hdr->target_len[chromid]) g_region_end = d.hdr->target_len[chromid];
+                if (g_region_end < g_region_beg) g_region_end = g_region_beg;
+            }
             /* no config file: the insert lengths are estimated by the walk itself (run_pipeline) instead of by a pass of their own;
              * multi-GPU runs and annotate mode keep the pre-pass (the shard summaries / the serial walk need the table up front) */
-            g_onepass = O.configfile == NULL && !g_mg && g_vcfname == NULL && getenv("INDELMINER_ONEPASS") != NULL;
+            g_onepass = O.configfile == NULL && !g_mg && g_vcfname == NULL && chromid == -1 && getenv("INDELMINER_ONEPASS") != NULL;
             pool = walkpool_start(&d);
         }
     }
@@ -4516,10 +4535,8 @@ int main(int argc, char** argv)
     pthread_mutex_unlock(&d.gpu_mu);
 
 
-    /* whole-contig runs take the device pipeline; region runs (-c) keep the per-contig host path, whose
-     * mate look-ups and depth queries go to the BAM file like the reference's */
     const char* pl = getenv("INDELMINER_PIPELINE");
-    const int use_pipeline = chromid == -1 && !(pl && strcmp(pl, "host") == 0);
+    const int use_pipeline = !(pl && strcmp(pl, "host") == 0);
     if (g_mg) {
         mg_rendezvous(&mg, &d);
         mg_exchange(&mg, &d, O.configfile == NULL);

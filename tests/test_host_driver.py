@@ -511,6 +511,23 @@ def test_host_contigs_walked_in_pieces(synth_small, synth_1mb):
             assert _run(shim, flags, d, ref="ref.fa", bam="aln.bam", env=env) == want, (golden, env)
 
 
+def test_host_region_runs_take_the_pipeline(synth_1mb, synth_small):
+    """-c: the pipeline over the pieces of one stretch -- its first piece takes the reads that reach into it from the front (bam_fetch),
+    mates outside the stretch are looked up in the file (find_mate_rln), DP= comes from the file around each variant -- against the
+    record-at-a-time path and, where it is present, the compiled reference"""
+    shim = _build_shim()
+    ref_bin = os.path.join(ROOT, "oracle", "_ref", "indelminer")
+    cases = [(synth_1mb, "ctg0:200,001-640,000"), (synth_1mb, "ctg0:1-90000"), (synth_1mb, "ctg0:777000"), (synth_small, "ctg1:50000-250000"), (synth_small, "ctg0")]
+    for d, region in cases:
+        for flags in (["-i", "cfg.txt", "-c", region], ["-c", region]):
+            want = _run(shim, flags, d, ref="ref.fa", bam="aln.bam", env={"INDELMINER_PIPELINE": "host"})
+            assert want.count(b"\n") > 40
+            if os.path.exists(ref_bin) and flags[0] == "-i":
+                assert _run(ref_bin, flags, d, ref="ref.fa", bam="aln.bam") == want, region
+            for env in ({}, {"INDELMINER_PIECE_BYTES": "120000", "INDELMINER_WALKERS": "3"}, {"INDELMINER_PIECE_BYTES": "40000"}):
+                assert _run(shim, flags, d, ref="ref.fa", bam="aln.bam", env=env) == want, (region, flags, env)
+
+
 def test_host_pieces_with_markers_pinned_low(tmp_path):
     """first mates that wait for ever pin every later marker (also of later contigs): nearly all evidence then waits for its contig's
     last flush -- the frozen entries skip the piece-to-piece chain and one entry carries their smallest key for the cuts in between;
@@ -624,7 +641,9 @@ def test_product_parallel_walkers_and_replayers(tmp_path):
     for env in ({}, {"INDELMINER_WALKERS": "1"}, {"INDELMINER_WALKERS": "6", "INDELMINER_CLAIM_BASES": "1", "INDELMINER_REPLAYERS": "4"},
                 {"INDELMINER_WALKERS": "3", "INDELMINER_CLAIM_BASES": "1", "INDELMINER_REPLAYERS": "1", "INDELMINER_STREAMS": "shared"},
                 {"INDELMINER_WALKERS": "4", "INDELMINER_CLAIM_BASES": "250000", "INDELMINER_VERIFY_TRIAGE": "1"},
-                {"INDELMINER_ONEPASS": "1"}, {"INDELMINER_ONEPASS": "1", "INDELMINER_WALKERS": "6", "INDELMINER_CLAIM_BASES": "1"}):
+                {"INDELMINER_ONEPASS": "1"}, {"INDELMINER_ONEPASS": "1", "INDELMINER_WALKERS": "6", "INDELMINER_CLAIM_BASES": "1"},
+                {"INDELMINER_PIECE_BYTES": "200000", "INDELMINER_WALKERS": "5"}, {"INDELMINER_PIECE_BYTES": "60000", "INDELMINER_ONEPASS": "1"},
+                {"INDELMINER_PIECE_BYTES": "100000", "INDELMINER_FLUSH_MODE": "seq", "INDELMINER_THREADS": "0"}):
         assert _run(prod, [], str(tmp_path), ref="ref.fa", bam="aln.bam", env=env) == want, env
 
 
@@ -636,8 +655,27 @@ def test_product_stale_pair_table_entries(tmp_path):
     want = _run(_build_shim(), [], d, ref="ref.fa", bam="aln.bam", env={"INDELMINER_PIPELINE": "host"})
     assert want.count(b"\n") > 400
     prod = _product()
-    for env in ({}, {"INDELMINER_WALKERS": "1"}, {"INDELMINER_FLUSH_MODE": "per-flush"}, {"INDELMINER_ONEPASS": "1"}):
+    for env in ({}, {"INDELMINER_WALKERS": "1"}, {"INDELMINER_FLUSH_MODE": "per-flush"}, {"INDELMINER_ONEPASS": "1"},
+                {"INDELMINER_PIECE_BYTES": "500000"}, {"INDELMINER_PIECE_BYTES": "150000", "INDELMINER_WALKERS": "6"}):
         assert _run(prod, [], d, ref="ref.fa", bam="aln.bam", env=env) == want, env
+
+
+@pytest.mark.gpu
+def test_product_contigs_walked_in_pieces_and_region_runs(synth_small, synth_1mb):
+    """the product on the GPU: contigs cut into pieces of many sizes (evidence, pair table and read counter carried from piece to
+    piece), and -c stretches through the same pipeline"""
+    prod = _product()
+    for d, golden, flags in ((synth_1mb, "synth_1mb_30x", ["-i", "cfg.txt"]), (synth_1mb, "synth_1mb_30x_noconfig", []),
+                             (synth_small, "synth_2ctg_composite", ["-i", "cfg.txt"])):
+        for env in PIECE_ENVS:
+            if flags and "INDELMINER_ONEPASS" in env:
+                continue
+            assert _run(prod, flags, d, ref="ref.fa", bam="aln.bam", env=env) == _golden(golden), (golden, env)
+    shim = _build_shim()
+    for d, region in ((synth_1mb, "ctg0:200,001-640,000"), (synth_small, "ctg1:50000-250000")):
+        want = _run(shim, ["-i", "cfg.txt", "-c", region], d, ref="ref.fa", bam="aln.bam", env={"INDELMINER_PIPELINE": "host"})
+        for env in ({}, {"INDELMINER_PIECE_BYTES": "120000", "INDELMINER_WALKERS": "3"}):
+            assert _run(prod, ["-i", "cfg.txt", "-c", region], d, ref="ref.fa", bam="aln.bam", env=env) == want, (region, env)
 
 
 @pytest.mark.gpu
