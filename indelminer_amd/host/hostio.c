@@ -7,6 +7,10 @@
 #include "hostio.h"
 
 #include <ctype.h>
+#include <fcntl.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
 #include <pthread.h>
 #include <stdlib.h>
 #include <string.h>
@@ -68,6 +72,13 @@ bgzf_reader* bgzf_open(const char* path)
     if (r->nworkers < 0) r->nworkers = 0;
     if (r->nworkers > 16) r->nworkers = 16;
     return r;
+}
+
+/* the number of inflate workers of a reader that has not started its pool yet (the walkers of the driver share the cores out) */
+void bgzf_set_workers(bgzf_reader* r, int n)
+{
+    if (!r || r->started) return;
+    r->nworkers = n < 0 ? 0 : (n > 16 ? 16 : n);
 }
 
 /* reads the compressed block at coff into cbuf; returns total size, 0 at EOF, -1 on error; *phdr = header size */
@@ -665,7 +676,8 @@ static int fasta_keep(int ch)
     }
 }
 
-int fasta_load(const char* path, int32_t n_expected, char*** seqs_out, int64_t** lens_out, int only_index)
+/* the serial reader: block by block through stdio */
+static int fasta_load_serial(const char* path, int32_t n_expected, char*** seqs_out, int64_t** lens_out, int only_index)
 {
     /* Same grammar as the reference's reader (src/sequences.c:63-120): blanks, then '>' header lines, every byte
      * up to the next '>' is sequence data filtered by fasta_keep and upper-cased -- read in blocks instead of
@@ -706,6 +718,97 @@ int fasta_load(const char* path, int32_t n_expected, char*** seqs_out, int64_t**
     fclose(fp);
     *seqs_out = seqs; *lens_out = lens;
     return indx;        /* caller checks indx == n_targets (forceassert, src/shared.c:77) */
+}
+
+/* The same grammar over a memory map of the file, in parallel: a 3 Gb reference is the longest serial stretch of a run otherwise.
+ * The contigs' data ranges are found first (every '>' that does not lie inside a header line begins a header that ends at the next
+ * newline); then each range is cut into slices, every slice's kept bytes are counted and, once the counts give the offsets,
+ * written in place by the same threads. */
+typedef struct { const uint8_t* base; size_t lo, hi; const uint8_t* tab; size_t kept; char* dst; int write; } fa_slice;
+static void* fa_slice_run(void* arg)
+{
+    fa_slice* s = arg;
+    const uint8_t* p = s->base + s->lo; const uint8_t* e = s->base + s->hi;
+    if (!s->write) { size_t n = 0; for (; p < e; p++) n += s->tab[*p] != 0; s->kept = n; }
+    else { char* d = s->dst; for (; p < e; p++) { const uint8_t u = s->tab[*p]; *d = (char)u; d += u != 0; } }
+    return NULL;
+}
+typedef struct { fa_slice* v; int lo, hi; } fa_batch;
+static void* fa_batch_run(void* arg) { fa_batch* b = arg; for (int i = b->lo; i < b->hi; i++) fa_slice_run(&b->v[i]); return NULL; }
+
+int fasta_load(const char* path, int32_t n_expected, char*** seqs_out, int64_t** lens_out, int only_index)
+{
+    const char* e = getenv("INDELMINER_FASTA_THREADS");
+    int nt = e ? atoi(e) : 8;
+    int fd = nt > 1 ? open(path, O_RDONLY) : -1;
+    struct stat sb;
+    const char* mn = getenv("INDELMINER_FASTA_PARALLEL_FROM");     /* bytes; smaller files take the serial reader (tests set 0) */
+    if (fd < 0 || fstat(fd, &sb) != 0 || sb.st_size < (mn ? atoll(mn) : (8 << 20)) || sb.st_size == 0) { if (fd >= 0) close(fd); return fasta_load_serial(path, n_expected, seqs_out, lens_out, only_index); }
+    const size_t size = (size_t)sb.st_size;
+    const uint8_t* m = mmap(NULL, size, PROT_READ, MAP_PRIVATE, fd, 0);
+    close(fd);
+    if (m == MAP_FAILED) return fasta_load_serial(path, n_expected, seqs_out, lens_out, only_index);
+    if (nt > 32) nt = 32;
+    uint8_t tab[256];
+    for (int c = 0; c < 256; c++) tab[c] = fasta_keep(c) ? (uint8_t)toupper(c) : 0;
+    /* data ranges, in file order (the headers are few: found by this thread with memchr) */
+    size_t cap_r = 64, n_r = 0;
+    size_t (*rng)[2] = malloc(sizeof(size_t[2]) * cap_r);
+    size_t at = 0;
+    while (at < size && (m[at] == ' ' || m[at] == '\t')) at++;
+    while (at < size && m[at] == '>') {
+        const uint8_t* nl = memchr(m + at, '\n', size - at);
+        const size_t d0 = nl ? (size_t)(nl - m) + 1 : size;
+        const uint8_t* nx = d0 < size ? memchr(m + d0, '>', size - d0) : NULL;
+        const size_t d1 = nx ? (size_t)(nx - m) : size;
+        if (n_r == cap_r) { cap_r *= 2; rng = realloc(rng, sizeof(size_t[2]) * cap_r); }
+        rng[n_r][0] = d0; rng[n_r][1] = d1; n_r++;
+        at = d1;
+    }
+    char** seqs = calloc((size_t)(n_expected > 0 ? n_expected : 1), sizeof(char*));
+    int64_t* lens = calloc((size_t)(n_expected > 0 ? n_expected : 1), sizeof(int64_t));
+    /* slices of the ranges that are kept */
+    const size_t SL = 4 << 20;
+    size_t n_sl = 0;
+    for (size_t r = 0; r < n_r; r++) if ((only_index < 0 || only_index == (int)r) && (int32_t)r < n_expected) n_sl += (rng[r][1] - rng[r][0]) / SL + 1;
+    fa_slice* sl = calloc(n_sl ? n_sl : 1, sizeof(fa_slice));
+    size_t* first_of = calloc(n_r + 1, sizeof(size_t));
+    size_t k = 0;
+    for (size_t r = 0; r < n_r; r++) {
+        first_of[r] = k;
+        if (!((only_index < 0 || only_index == (int)r) && (int32_t)r < n_expected)) continue;
+        for (size_t lo = rng[r][0]; lo < rng[r][1] || lo == rng[r][0]; lo += SL) {
+            sl[k].base = m; sl[k].lo = lo; sl[k].hi = lo + SL < rng[r][1] ? lo + SL : rng[r][1]; sl[k].tab = tab; k++;
+            if (rng[r][1] == rng[r][0]) break;
+        }
+    }
+    first_of[n_r] = k;
+    n_sl = k;
+    for (int pass = 0; pass < 2; pass++) {
+        if (pass == 1) {
+            for (size_t r = 0; r < n_r; r++) {
+                if (first_of[r] == first_of[r + 1]) continue;
+                size_t tot = 0;
+                for (size_t i = first_of[r]; i < first_of[r + 1]; i++) tot += sl[i].kept;
+                char* buf = malloc(tot + 2);
+                size_t off = 0;
+                for (size_t i = first_of[r]; i < first_of[r + 1]; i++) { sl[i].dst = buf + off; off += sl[i].kept; sl[i].write = 1; }
+                buf[tot] = 0;
+                seqs[r] = buf; lens[r] = (int64_t)tot;
+            }
+        }
+        pthread_t th[32]; fa_batch bt[32];
+        int started = 0;
+        for (int t = 0; t < nt; t++) {
+            bt[t].v = sl; bt[t].lo = (int)(n_sl * (size_t)t / (size_t)nt); bt[t].hi = (int)(n_sl * (size_t)(t + 1) / (size_t)nt);
+            if (pthread_create(&th[t], NULL, fa_batch_run, &bt[t]) != 0) { fa_batch_run(&bt[t]); th[t] = 0; } else started |= 1 << t;
+        }
+        for (int t = 0; t < nt; t++) if (started & (1 << t)) pthread_join(th[t], NULL);
+    }
+    free(sl); free(first_of); free(rng);
+    munmap((void*)m, size);
+    *seqs_out = seqs; *lens_out = lens;
+    return (int)n_r;    /* caller checks it against n_targets (forceassert, src/shared.c:77) */
 }
 
 /* ------------------------------------------------------------- getline -- */

@@ -15,6 +15,7 @@
 typedef struct bgzf_reader bgzf_reader;
 bgzf_reader* bgzf_open(const char* path);
 void    bgzf_close(bgzf_reader* r);
+void    bgzf_set_workers(bgzf_reader* r, int n);             /* inflate workers of this reader (before it has read far); default INDELMINER_THREADS or 4 */
 int64_t bgzf_read(bgzf_reader* r, void* buf, int64_t n);    /* bytes read, < n at EOF, -1 on error */
 int64_t bgzf_tell(const bgzf_reader* r);                     /* virtual offset */
 int     bgzf_seek(bgzf_reader* r, int64_t voffset);

@@ -1997,7 +1997,7 @@ static void run_contig(driver* d, int32_t tid, int32_t beg, int32_t end, bgzf_re
 
 /* multi-GPU state (the section further down): declared here because the replay writes one part per contig */
 #define MG_MAX_RG    64
-#define MG_RG_WORDS  17         /* name[48] + min + max + first_tid + first_rec + seen on a proper pair */
+#define MG_RG_WORDS  18         /* name[48] + min + max + first_tid + first position + seen on a proper pair + first record */
 
 typedef struct {
     int rank, world, local_rank;
@@ -3204,12 +3204,12 @@ static int mg_rg_index(mg_rg* rgs, int* pn, const char* rgname)
  * statistics only).  Thread-safe: everything it touches is the caller's.
  * The contig's block: { tid, counted (2 words), events, bytes of events }, then per event { pos, |isize|, record index,
  * first-mate flag | read group << 8 | name length << 16 } and the name with its NUL, padded to a word. */
-static void prewalk_contig(const driver* d, bgzf_reader* r, const bam_header* h, int32_t t, int estimate, mg_rg* rgs, int* pn_rg, mgbuf* out)
+static void prewalk_piece(const driver* d, bgzf_reader* r, int32_t t, int32_t beg, int32_t end, int estimate, mg_rg* rgs, int* pn_rg, mgbuf* out)
 {
     bam_region_iter it;
     size_t head_at = 0;
     if (out) { head_at = out->n; int32_t* hd = mgbuf_take(out, 20); hd[0] = t; }
-    if (bam_region_begin(&it, r, d->idx, t, 0, h->target_len[t]) != 0) return;
+    if (bam_piece_begin(&it, r, d->idx, t, beg, end) != 0) return;
     bam_record b; memset(&b, 0, sizeof b);
     int64_t counted = 0;
     int32_t rec = 0, n_ev = 0;
@@ -3223,7 +3223,7 @@ static void prewalk_contig(const driver* d, bgzf_reader* r, const bam_header* h,
             const char* rgname = "generic";
             if (rg) { forceassert(rg[0] == 'Z'); rgname = bam_aux_str(rg); }
             mg_rg* g = &rgs[mg_rg_index(rgs, pn_rg, rgname)];
-            if (!g->seen) { g->seen = 1; g->min = g->max = b.isize; g->first_tid = t; g->first_rec = this_rec; }
+            if (!g->seen) { g->seen = 1; g->min = g->max = b.isize; g->first_tid = t; g->first_rec = ((int64_t)(b.pos < 0 ? 0 : b.pos) << 32) | (uint32_t)this_rec; }
             else { if (g->min > b.isize) g->min = b.isize; if (g->max < b.isize) g->max = b.isize; }
         }
         if (!out) continue;
@@ -3267,7 +3267,7 @@ static void mg_prewalk(mgpu* m, driver* d, int estimate, mgbuf* out)
         if (m->owner[t] != m->rank) continue;
         n_ctg++;
         if (m->skip && m->skip[t]) { int32_t* hd = mgbuf_take(out, 20); hd[0] = t; continue; }
-        prewalk_contig(d, r, h, t, estimate, rgs, &n_rg, out);
+        prewalk_piece(d, r, t, 0, h->target_len[t], estimate, rgs, &n_rg, out);
     }
     bam_header_free(h);
     bgzf_close(r);
@@ -3276,7 +3276,8 @@ static void mg_prewalk(mgpu* m, driver* d, int estimate, mgbuf* out)
     for (int k = 0; k < n_rg; k++) {
         int32_t* g = w + MG_HEAD_WORDS + (size_t)k * MG_RG_WORDS;
         memcpy(g, rgs[k].name, 48);
-        g[12] = rgs[k].min; g[13] = rgs[k].max; g[14] = rgs[k].first_tid; g[15] = (int32_t)rgs[k].first_rec; g[16] = rgs[k].seen;
+        /* whole contigs per rank: the position of the first sighting orders the read groups inside a contig */
+        g[12] = rgs[k].min; g[13] = rgs[k].max; g[14] = rgs[k].first_tid; g[15] = (int32_t)(rgs[k].first_rec >> 32); g[16] = rgs[k].seen; g[17] = (int32_t)(uint32_t)rgs[k].first_rec;
     }
     free(rgs);
 }
@@ -3330,27 +3331,39 @@ static int32_t* rg_table_enter(driver* d, const mg_rg* g)
 
 /* estimate_insertlengths (src/bamoperations.c:15-86) with the contigs spread over threads: the pass is pure decode + a
  * min / max per read group, so contigs are independent and the per-thread lists merge exactly (rg_table_enter) */
-typedef struct { const driver* d; int t0, step; mg_rg rgs[MG_MAX_RG]; int n_rg; } est_job;
+typedef struct { const driver* d; const piece_t* pieces; int n_pieces, t0, step; mg_rg rgs[MG_MAX_RG]; int n_rg; } est_job;
 static void* est_thread(void* arg)
 {
     est_job* j = arg;
     bgzf_reader* r = bgzf_open(j->d->bam_name);
     if (!r) fatalf("error in opening the file %s", j->d->bam_name);
+    bgzf_set_workers(r, 0);
     bam_header* h = bam_header_load(r);
-    for (int32_t t = j->t0; t < h->n_targets; t += j->step) prewalk_contig(j->d, r, h, t, 1, j->rgs, &j->n_rg, NULL);
+    for (int i = j->t0; i < j->n_pieces; i += j->step) prewalk_piece(j->d, r, j->pieces[i].tid, j->pieces[i].beg, j->pieces[i].end, 1, j->rgs, &j->n_rg, NULL);
     bam_header_free(h);
     bgzf_close(r);
     return NULL;
 }
-static void estimate_insertlengths_threads(driver* d)
+/* pieces / n_pieces: how the file is cut for the walkers (walkpool_start); the pre-pass takes the same pieces, one thread per core */
+static void estimate_insertlengths_threads(driver* d, const piece_t* pieces, int n_pieces)
 {
     const char* e = getenv("INDELMINER_WALKERS");
-    int nt = e ? atoi(e) : 8;
-    if (nt > d->hdr->n_targets) nt = d->hdr->n_targets;
+    long ncpu = sysconf(_SC_NPROCESSORS_ONLN);
+    {
+        FILE* fp = fopen("/sys/fs/cgroup/cpu.max", "r");
+        long quota = 0, period = 0;
+        if (fp) { if (fscanf(fp, "%ld %ld", &quota, &period) == 2 && quota > 0 && period > 0 && quota / period < ncpu) ncpu = quota / period; fclose(fp); }
+    }
+    int nt = e ? atoi(e) : (int)(ncpu > 16 ? 16 : ncpu);
+    if (nt > n_pieces) nt = n_pieces;
     if (nt < 1) nt = 1;
+    if (nt > 32) nt = 32;
     est_job* jobs = xcalloc((size_t)nt, sizeof(est_job));
     pthread_t* th = xmalloc(sizeof(pthread_t) * (size_t)nt);
-    for (int i = 0; i < nt; i++) { jobs[i].d = d; jobs[i].t0 = i; jobs[i].step = nt; if (pthread_create(&th[i], NULL, est_thread, &jobs[i]) != 0) fatalf("cannot start an estimation thread"); }
+    for (int i = 0; i < nt; i++) {
+        jobs[i].d = d; jobs[i].pieces = pieces; jobs[i].n_pieces = n_pieces; jobs[i].t0 = i; jobs[i].step = nt;
+        if (pthread_create(&th[i], NULL, est_thread, &jobs[i]) != 0) fatalf("cannot start an estimation thread");
+    }
     mg_rg* all = xcalloc((size_t)nt * MG_MAX_RG, sizeof(mg_rg));
     int n_all = 0;
     for (int i = 0; i < nt; i++) { pthread_join(th[i], NULL); for (int k = 0; k < jobs[i].n_rg; k++) if (jobs[i].rgs[k].seen) all[n_all++] = jobs[i].rgs[k]; }
@@ -3414,7 +3427,7 @@ static void mg_exchange(mgpu* m, driver* d, int estimate)
                 if (!w[16]) continue;                   /* met on pair-table records only: not part of the estimate */
                 mg_rg* g = &got[n_got++];
                 memcpy(g->name, w, 48); g->name[47] = 0;
-                g->min = w[12]; g->max = w[13]; g->first_tid = w[14]; g->first_rec = w[15]; g->seen = 1;
+                g->min = w[12]; g->max = w[13]; g->first_tid = w[14]; g->first_rec = ((int64_t)w[15] << 32) | (uint32_t)w[17]; g->seen = 1;
             }
         }
         mg_rg* rgs = xcalloc((size_t)(n_got ? n_got : 1), sizeof(mg_rg));
@@ -3607,6 +3620,7 @@ typedef struct walkpool_s {
     int staged;                         /* claims the main thread is through with: walkers stay a bounded number of claims ahead */
     walker_t* w; int nw;
     int serial, go;
+    int inflate_workers;                /* per reader; -1: as INDELMINER_THREADS says */
     rjob_t* jobs; int n_jobs, next_job, jobs_closed;    /* replay queue, in file order */
     int printed;                                        /* jobs whose output has been written */
     pthread_mutex_t mu; pthread_cond_t cv;
@@ -3829,6 +3843,7 @@ static void walker_setup(walker_t* W, driver* d)
     pipe_init(&W->P, &W->wd, 1);
     W->r = bgzf_open(d->bam_name);
     if (!W->r) fatalf("error in opening the file %s", d->bam_name);
+    if (W->pool->inflate_workers >= 0) bgzf_set_workers(W->r, W->pool->inflate_workers);
     W->hdr = bam_header_load(W->r);
     if (!W->hdr) fatalf("%s is not a BAM file", d->bam_name);
 }
@@ -3953,7 +3968,9 @@ static walkpool_t* walkpool_start(driver* d)
         if (fp) { if (fscanf(fp, "%ld %ld", &quota, &period) == 2 && quota > 0 && period > 0 && quota / period < ncpu) ncpu = quota / period; fclose(fp); }
         if (ncpu < 1) ncpu = 1;
     }
-    int nw = e ? atoi(e) : (ncpu >= 12 ? 8 : 4);
+    /* one walker per core when there are pieces enough to go round (each then inflates its own blocks: no hand-over between
+     * threads); with few pieces, few walkers and the other cores as inflate workers of their readers (set below) */
+    int nw = e ? atoi(e) : (int)(ncpu > 16 ? 16 : ncpu);
     if (o->serial || nw < 1) nw = 1;
     if (nw > 32) nw = 32;
     int64_t total_bytes = 0, total_len = 0;
@@ -4009,6 +4026,9 @@ static walkpool_t* walkpool_start(driver* d)
     }
     if (nw > o->n_claims) nw = o->n_claims ? o->n_claims : 1;
     o->nw = nw;
+    o->inflate_workers = getenv("INDELMINER_THREADS") ? -1 : (o->n_claims >= 2 * nw && nw >= ncpu - 1 ? 0 : (int)((ncpu - nw + nw - 1) / nw));
+    if (o->inflate_workers > 4) o->inflate_workers = 4;
+    if (!getenv("INDELMINER_THREADS") && o->inflate_workers < 1 && nw < ncpu - 1) o->inflate_workers = 1;
     o->w = xcalloc((size_t)nw, sizeof(walker_t));
     for (int i = 0; i < nw; i++) o->w[i].pool = o;
     if (!o->serial)
@@ -4513,7 +4533,7 @@ int main(int argc, char** argv)
 
     if (O.configfile) read_configuration(O.configfile, d.insertlengths, d.hdr);
     else if (g_onepass) { }
-    else if (!g_mg) { if (chromid == -1 && !getenv("INDELMINER_ESTIMATE_SERIAL")) estimate_insertlengths_threads(&d); else estimate_insertlengths(&d, chromid); }
+    else if (!g_mg) { if (chromid == -1 && pool && !getenv("INDELMINER_ESTIMATE_SERIAL")) estimate_insertlengths_threads(&d, pool->pieces, pool->n_pieces); else estimate_insertlengths(&d, chromid); }
     fprintf(stderr, "\nRead-group\tMin-value\tMax-value\n----------\t---------\t---------\n");
     for (uint32_t i = 0; i <= d.insertlengths->mask; i++)
         for (qbin* it = d.insertlengths->bins[i]; it; it = it->next)

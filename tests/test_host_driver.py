@@ -496,6 +496,33 @@ PIECE_ENVS = [{"INDELMINER_PIECE_BYTES": "150000"}, {"INDELMINER_PIECE_BYTES": "
               {"INDELMINER_PIECE_BYTES": "500000", "INDELMINER_WALKERS": "1", "INDELMINER_THREADS": "0"}]
 
 
+def test_host_fasta_read_in_parallel(synth_small, tmp_path):
+    """the memory-mapped parallel FASTA reader (large references) against the serial one: same run, byte for byte -- also with
+    lower-case bases, IUPAC codes, characters the reference's reader drops, a '>' inside a header line and blank lines"""
+    shim = _build_shim()
+    want = _golden("synth_2ctg_composite")
+    for nt in ("2", "5", "13"):
+        env = {"INDELMINER_FASTA_PARALLEL_FROM": "0", "INDELMINER_FASTA_THREADS": nt}
+        assert _run(shim, ["-i", "cfg.txt"], synth_small, ref="ref.fa", bam="aln.bam", env=env) == want
+    # an untidy copy of the same reference
+    import shutil
+    for f in ("aln.bam", "aln.bam.bai", "cfg.txt"):
+        shutil.copy(os.path.join(synth_small, f), str(tmp_path / f))
+    lines = open(os.path.join(synth_small, "ref.fa")).read().split("\n")
+    out = []
+    for i, ln in enumerate(lines):
+        if ln.startswith(">"):
+            out.append(ln + " some > text")
+        else:
+            out.append((ln.lower() if i % 3 == 0 else ln) + ("" if i % 5 else " \t") )
+            if i % 7 == 0:
+                out.append("")
+    open(str(tmp_path / "ref.fa"), "w").write("\n".join(out))
+    serial = _run(shim, ["-i", "cfg.txt"], str(tmp_path), ref="ref.fa", bam="aln.bam", env={"INDELMINER_FASTA_THREADS": "1"})
+    assert serial == want
+    assert _run(shim, ["-i", "cfg.txt"], str(tmp_path), ref="ref.fa", bam="aln.bam", env={"INDELMINER_FASTA_PARALLEL_FROM": "0", "INDELMINER_FASTA_THREADS": "6"}) == want
+
+
 def test_host_contigs_walked_in_pieces(synth_small, synth_1mb):
     """A contig is cut into pieces (records by start position) that walkers take at the same time; the pair table, the read
     counter and the evidence no flush has consumed yet carry over from piece to piece on the main thread: the bytes of the whole-contig
