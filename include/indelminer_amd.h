@@ -61,6 +61,7 @@ extern "C" {
 #define IM_CLS_DELETION  1
 
 typedef struct im_ctx im_ctx;
+typedef struct im_comm im_comm;         /* an RCCL communicator (multi-GPU section below) */
 
 /* The globals the reference path reads (src/alignment.c:3-9), set from the CLI
  * (src/indelminer.c:930-944): -k, -g, -s, -n. */
@@ -457,6 +458,10 @@ int im_depth_scan(im_ctx* ctx, int32_t tid, void* stream);
 /* contig tid's run back to zeros (asynchronous): a contig that is to go through triage + im_depth_scan AGAIN */
 int im_depth_reset(im_ctx* ctx, int32_t tid, void* stream);
 int im_depth_query_tid(im_ctx* ctx, int32_t tid, int32_t n, const int32_t* beg, const int32_t* end, uint32_t* sum_out);
+/* Multi-GPU, pieces of one contig walked by several ranks: every rank's difference array holds the +-1 of the records IT
+ * delivered; their sum (one RCCL all-reduce over the whole array, before any im_depth_scan) is the single run's array.  The
+ * reference has no counterpart (calculate_cov_params re-reads the file per variant, src/shared.c:178-212).  Synchronous. */
+int im_depth_allreduce(im_ctx* ctx, im_comm* comm);
 
 /* ---- multi-GPU: one collective ------------------------------------------------ */
 
@@ -466,11 +471,12 @@ int im_depth_query_tid(im_ctx* ctx, int32_t tid, int32_t n, const int32_t* beg, 
  * Rendezvous: rank 0 calls im_comm_unique_id and ships the IM_COMM_ID_BYTES to the
  * other ranks by any side channel (bench.py: torch.distributed/gloo broadcast). */
 #define IM_COMM_ID_BYTES 128
-typedef struct im_comm im_comm;
 int  im_comm_unique_id(void* id_bytes);
 int  im_comm_init(im_ctx* ctx, const void* id_bytes, int rank, int world, im_comm** out);
 /* every rank contributes bytes_per_rank bytes; recv_dev holds world * bytes_per_rank.  Asynchronous. */
 int  im_comm_allgather(im_comm* comm, const void* send_dev, void* recv_dev, size_t bytes_per_rank, void* stream);
+/* in place: buf[i] = sum over ranks of buf[i].  Asynchronous. */
+int  im_comm_allreduce_sum_i32(im_comm* comm, int32_t* buf_dev, size_t count, void* stream);
 void im_comm_destroy(im_comm* comm);
 const char* im_comm_last_error(void);
 

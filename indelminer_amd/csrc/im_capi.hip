@@ -484,6 +484,21 @@ int im_depth_reset(im_ctx* ctx, int32_t tid, void* stream)
     return IM_OK;
 }
 
+int im_depth_allreduce(im_ctx* ctx, im_comm* comm)
+{
+    if (!ctx || !comm) return IM_E_ARG;
+    if (!ctx->gdepth) { set_err(ctx, "im_depth_enable has not been called"); return IM_E_ARG; }
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    const size_t total = (size_t)ctx->ref_total, step = (size_t)1 << 28;           // 1 GiB of int32 per call
+    for (size_t at = 0; at < total; at += step) {
+        const size_t n = total - at < step ? total - at : step;
+        if (im_comm_allreduce_sum_i32(comm, ctx->gdepth + at, n, ctx->stream) != IM_OK) { set_err(ctx, "%s", im_comm_last_error()); return IM_E_HIP; }
+    }
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return IM_OK;
+}
+
 int im_depth_query_tid(im_ctx* ctx, int32_t tid, int32_t n, const int32_t* beg, const int32_t* end, uint32_t* sum_out)
 {
     if (!ctx || n < 0 || !ctx->gdepth || tid < 0 || tid >= ctx->n_contigs) return IM_E_ARG;

@@ -1,5 +1,6 @@
-// im_comm.hip -- the one data-path collective of the multi-GPU design: an RCCL
-// all-gather of per-shard cluster lists over xGMI.
+// im_comm.hip -- the collectives of the multi-GPU design over RCCL / xGMI: the all-gather of the
+// per-rank logs, and -- only when pieces of one contig were walked by several ranks -- the sum of the ranks' shares of the
+// depth array.
 //
 // The reference has no communication at all (its only parallel mode is running
 // several processes with -c regions, src/indelminer.c:536-542,711-713); contigs are
@@ -28,6 +29,7 @@ struct RcclApi {
     ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
     ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
     ncclResult_t (*AllGather)(const void*, void*, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*AllReduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
     ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
     const char* (*GetErrorString)(ncclResult_t) = nullptr;
     char err[256] = {0};
@@ -65,6 +67,7 @@ bool load_rccl()
     LOAD(GetUniqueId, "ncclGetUniqueId")
     LOAD(CommInitRank, "ncclCommInitRank")
     LOAD(AllGather, "ncclAllGather")
+    LOAD(AllReduce, "ncclAllReduce")
     LOAD(CommDestroy, "ncclCommDestroy")
     LOAD(GetErrorString, "ncclGetErrorString")
 #undef LOAD
@@ -116,6 +119,17 @@ int im_comm_allgather(im_comm* c, const void* send_dev, void* recv_dev, size_t b
     ncclResult_t r = g_rccl.AllGather(send_dev, recv_dev, bytes_per_rank, ncclInt8, c->comm, (hipStream_t)stream);
     if (r != ncclSuccess) {
         snprintf(g_rccl.err, sizeof g_rccl.err, "ncclAllGather: %s", g_rccl.GetErrorString(r));
+        return IM_E_HIP;
+    }
+    return IM_OK;
+}
+
+int im_comm_allreduce_sum_i32(im_comm* c, int32_t* buf_dev, size_t count, void* stream)
+{
+    if (!c || !buf_dev) return IM_E_ARG;
+    ncclResult_t r = g_rccl.AllReduce(buf_dev, buf_dev, count, ncclInt32, ncclSum, c->comm, (hipStream_t)stream);
+    if (r != ncclSuccess) {
+        snprintf(g_rccl.err, sizeof g_rccl.err, "ncclAllReduce: %s", g_rccl.GetErrorString(r));
         return IM_E_HIP;
     }
     return IM_OK;

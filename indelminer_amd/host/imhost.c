@@ -2004,7 +2004,11 @@ typedef struct {
     im_comm* comm;
     char dir[400];
     int32_t* owner;             /* [n_targets] the rank that walks the contig (mg_plan) */
-    int64_t* prefix;            /* [n_targets] counted reads of all earlier contigs */
+    int64_t* piece_prefix;      /* [pieces] counted reads of the run in front of each piece */
+    int32_t* claim_walker;      /* [claims] the rank that walks the claim (reads the file, runs the triage) */
+    int32_t* piece_walker;      /* [pieces] the same per piece */
+    int32_t* claim_owner;       /* [claims] the rank that stages and replays it: the owner of its contig */
+    int      split;             /* some claim is walked by a rank that does not own it (pieces of a contig over several GPUs) */
     int*     floor;             /* [n_targets] smallest start of a stale pair-table entry of an earlier contig */
     int      out_fd;            /* rank 0: the real stdout */
     uint8_t* skip;              /* [n_targets] annotate mode: contigs without known variants are not walked at all */
@@ -2058,7 +2062,7 @@ static int g_onepass;               /* set before the walkers start */
 
 /* A PIECE of a contig: the records that start in [beg, end).  Whole small contigs are pieces too (first and last at once).
  * Pieces are what the walkers claim: a contig of any size spreads over all of them. */
-typedef struct { int32_t tid, beg, end; int first, last; int64_t weight; int overlap; } piece_t;   /* overlap: a -c region's first piece also takes the records that begin in front of it and reach into it (bam_fetch) */
+typedef struct { int32_t tid, beg, end; int first, last; int64_t weight; int overlap; int32_t index; } piece_t;   /* overlap: a -c region's first piece also takes the records that begin in front of it and reach into it (bam_fetch) */
 static int g_region_tid = -1, g_region_beg = 0, g_region_end = 0;      /* -c: the one stretch this run works on */
 
 typedef struct {
@@ -2068,7 +2072,11 @@ typedef struct {
     int64_t dn0, dn1, sn0, sn1;             /* this piece's runs in the group's name logs (pair-table records; entries left waiting) */
     int32_t beg, end; int first, last;      /* the piece */
     int lm_init;                            /* find_marker's value when the piece begins (entries earlier pieces left in the table) */
+    int64_t n_counted;                      /* counted reads of the piece (src/indelminer.c:617) */
+    int32_t fp0, fp1;                       /* this piece's run of the group's flush points */
+    int32_t piece;                          /* index of the piece in the run's plan */
 } gcontig;
+typedef struct { int64_t rec; int32_t pos; } gfpoint;     /* a READCHUNK flush point: the record bound and the position of the counted read */
 
 struct pgroup_s;
 /* What a piece leaves for the next piece of its contig: evidence no flush has consumed yet.  Split-read evidence travels as the
@@ -2086,6 +2094,7 @@ typedef struct pgroup_s {
     int64_t n_rec;
     gcontig* ctg; int n_ctg, cap_ctg, cur_ctg;      /* cur_ctg: the piece the pair table is serving (host_discordant) */
     gflush* fl; int n_fl, cap_fl;
+    gfpoint* fp; int32_t n_fp, cap_fp;
     evidence_t** pe; int64_t* pe_rec; int32_t n_pe, cap_pe;
     /* The walk does not know the global read counter it starts from (several pieces are walked at once), so it cannot
      * place the READCHUNK flush points itself (src/indelminer.c:617-670).  It logs what placing them needs -- for every
@@ -2113,6 +2122,7 @@ typedef struct pgroup_s {
     carry_item* front; int32_t n_front; int32_t* front_virt;
     int32_t n_pe_front, n_virt; int phantom;
     int seq;                                /* position of the group in the run (the `when` of what it leaves pending) */
+    int from_package;                       /* multi-GPU: walked by another rank (its flush points came with it) */
     /* what came back from the stage */
     im_read_result* res; int32_t *s_cls, *s_b1, *s_b2, *cons_sr, *cons_pe;
     int32_t n_cl, n_nodes; int32_t *cl_key, *cl_first, *cl_count, *order, *cl_sorted;
@@ -2241,7 +2251,7 @@ static void pipe_destroy(ppipe* P)
 static void group_free(pgroup* G)
 {
     if (G->phantom && G->pe && G->n_pe_front > 0 && G->pe[G->n_pe_front - 1] && G->pe[G->n_pe_front - 1]->type == EV_PHANTOM) evidence_free(G->pe[G->n_pe_front - 1]);
-    free(G->ctg); free(G->fl); free(G->pe); free(G->pe_rec); free(G->cand_rec); free(G->craw_off); free(G->craw);
+    free(G->ctg); free(G->fl); free(G->fp); free(G->pe); free(G->pe_rec); free(G->cand_rec); free(G->craw_off); free(G->craw);
     free(G->cn_rec); free(G->cn_pos); free(G->lm_rec); free(G->lm_val);
     free(G->npp_raw); free(G->npp_off); free(G->npp_rec); free(G->dn); free(G->sn);
     free(G->res); free(G->s_cls); free(G->s_b1); free(G->s_b2); free(G->cons_sr); free(G->cons_pe); free(G->front); free(G->front_virt);
@@ -2496,36 +2506,55 @@ static void group_push_flush(pgroup* G, int64_t rec, int32_t pe, int marker, int
     f->rec = rec; f->pe = pe; f->marker = marker; f->tid = tid;
 }
 
-/* Places the flush points of a walked group (src/indelminer.c:617-670, 806-823), piece by piece, from the logs of the
- * walk and of the pair table: *numread is the run's read counter in front of the group's first piece, *floor the smallest
- * start among the pair-table entries that CONTIGS before it left waiting (the reference never removes those, so find_marker
- * keeps seeing them).  Both are advanced past the group.  In a multi-GPU run they come per contig from the exchanged logs. */
-static void group_resolve_flushes(pgroup* G, int64_t* numread, int* floor)
+/* Where the READCHUNK flushes of a walked group fall (src/indelminer.c:617): every READCHUNK-th counted read of the RUN, found from
+ * the walk's log of counted reads once the run's read counter in front of the group is known -- *numread, advanced past the
+ * group.  (A multi-GPU run knows the counter in front of every piece from the exchanged logs: there the rank that walked the
+ * piece does this and only the points travel.) */
+static void group_flush_points(pgroup* G, int64_t* numread)
+{
+    G->n_fp = 0;
+    for (int ci = 0; ci < G->n_ctg; ci++) {
+        gcontig* cg = &G->ctg[ci];
+        if (g_mg) *numread = g_mg->piece_prefix[cg->piece];
+        cg->fp0 = G->n_fp;
+        const int64_t ncount = cg->cn1 - cg->cn0;
+        cg->n_counted = ncount;
+        /* the k-th counted read of the piece (k from 0) is read number *numread + k + 1 of the run */
+        for (int64_t k = (READCHUNK - 1 - (*numread % READCHUNK)) % READCHUNK; k < ncount; k += READCHUNK) {
+            if (G->n_fp == G->cap_fp) { G->cap_fp = G->cap_fp ? G->cap_fp * 2 : 64; G->fp = xrealloc(G->fp, sizeof(gfpoint) * (size_t)G->cap_fp); }
+            G->fp[G->n_fp].rec = G->cn_rec[cg->cn0 + k]; G->fp[G->n_fp].pos = G->cn_pos[cg->cn0 + k]; G->n_fp++;
+            timestamp("Read %ld reads", (long)(*numread + k + 1));
+        }
+        cg->fp1 = G->n_fp;
+        *numread += ncount;
+    }
+}
+
+/* The flushes themselves (src/indelminer.c:617-670, 806-823), piece by piece, from the flush points and the pair table's log:
+ * *floor = the smallest start among the pair-table entries that CONTIGS before this one left waiting (the reference never
+ * removes those, so find_marker keeps seeing them), advanced past the group.  In a multi-GPU run it comes per contig from the
+ * exchanged logs. */
+static void group_resolve_flushes(pgroup* G, int* floor)
 {
     G->n_fl = 0;
     for (int ci = 0; ci < G->n_ctg; ci++) {
         gcontig* cg = &G->ctg[ci];
-        if (g_mg && cg->first) { *numread = g_mg->prefix[cg->tid]; *floor = g_mg->floor[cg->tid]; }
+        if (g_mg && cg->first) *floor = g_mg->floor[cg->tid];
         cg->fl0 = G->n_fl;
         int32_t lm = cg->lm0, pe = cg->pe0;
         int live_min = cg->lm_init;
-        const int64_t ncount = cg->cn1 - cg->cn0;
-        /* the k-th counted read of the piece (k from 0) is read number *numread + k + 1 of the run */
-        int64_t k = (READCHUNK - 1 - (*numread % READCHUNK)) % READCHUNK;
-        for (; k < ncount; k += READCHUNK) {
-            const int64_t rec = G->cn_rec[cg->cn0 + k];
+        for (int32_t k = cg->fp0; k < cg->fp1; k++) {
+            const int64_t rec = G->fp[k].rec;
             while (lm < cg->lm1 && G->lm_rec[lm] <= rec) live_min = G->lm_val[lm++];
             while (pe < cg->pe1 && G->pe_rec[pe] < rec) pe++;
-            timestamp("Read %ld reads", (long)(*numread + k + 1));
             int marker = live_min;
             if (*floor < marker) marker = *floor;
-            if (G->cn_pos[cg->cn0 + k] < marker) marker = G->cn_pos[cg->cn0 + k];
+            if (G->fp[k].pos < marker) marker = G->fp[k].pos;
             group_push_flush(G, rec, pe, marker, cg->tid);
         }
         /* end of contig (src/indelminer.c:806-823): everything still pending is consumed */
         if (cg->last) group_push_flush(G, cg->rec1, cg->pe1, INT_MAX, cg->tid);
         cg->fl1 = G->n_fl;
-        *numread += ncount;
         if (cg->last && cg->left_min < *floor) *floor = cg->left_min;
     }
 }
@@ -2557,6 +2586,7 @@ static void pipe_walk_piece(ppipe* P, pgroup* G, const piece_t* pc, bgzf_reader*
     cg->tid = tid; cg->rec0 = G->n_rec; cg->pe0 = G->n_pe; cg->fl0 = cg->fl1 = 0;
     cg->cn0 = G->n_cn; cg->lm0 = cg->lm1 = G->n_lm; cg->dn0 = cg->dn1 = G->dn_len; cg->sn0 = cg->sn1 = G->sn_len;
     cg->beg = pc->beg; cg->end = pc->end; cg->first = pc->first; cg->last = pc->last; cg->lm_init = INT_MAX; cg->left_min = INT_MAX;
+    cg->piece = pc->index;
     G->cur_ctg = G->n_ctg - 1;
     bam_region_iter it;
     if ((pc->overlap ? bam_region_begin(&it, r, d->idx, tid, pc->beg, pc->end) : bam_piece_begin(&it, r, d->idx, tid, pc->beg, pc->end)) != 0) fatalf("cannot seek in %s", d->bam_name);
@@ -3132,7 +3162,7 @@ static void mg_rendezvous(mgpu* m, driver* d)
             if (dp) {
                 struct dirent* de;
                 while ((de = readdir(dp)) != NULL) {
-                    if (strncmp(de->d_name, "part.", 5) != 0 && strncmp(de->d_name, "done.", 5) != 0 && strncmp(de->d_name, "rccl_id", 7) != 0) continue;
+                    if (strncmp(de->d_name, "part.", 5) != 0 && strncmp(de->d_name, "done.", 5) != 0 && strncmp(de->d_name, "pkg.", 4) != 0 && strncmp(de->d_name, "rccl_id", 7) != 0) continue;
                     char victim[800];
                     snprintf(victim, sizeof victim, "%s/%s", m->dir, de->d_name);
                     unlink(victim);
@@ -3254,32 +3284,92 @@ static void prewalk_piece(const driver* d, bgzf_reader* r, int32_t t, int32_t be
 #define MG_MAGIC 0x4d473033
 #define MG_HEAD_WORDS 8         /* magic, read groups, contigs, bytes used (2 words), 3 spare */
 
-/* The pre-walk over this rank's contigs: the rank's log, ready for the exchange. */
-static void mg_prewalk(mgpu* m, driver* d, int estimate, mgbuf* out)
+/* The pre-walk over the pieces this rank walks (mg_plan_walks), spread over threads: the rank's log, ready for the exchange --
+ * header, read groups, then one block per piece in file order. */
+typedef struct { const driver* d; const piece_t* pieces; const int32_t* mine; int n_mine, t0, step, estimate; mg_rg rgs[MG_MAX_RG]; int n_rg; mgbuf* out; } prewalk_job;
+static void* prewalk_thread(void* arg)
 {
-    mg_rg* rgs = xcalloc(MG_MAX_RG, sizeof(mg_rg));
-    int n_rg = 0, n_ctg = 0;
-    bgzf_reader* r = bgzf_open(d->bam_name);
-    if (!r) fatalf("error in opening the file %s", d->bam_name);
+    prewalk_job* j = arg;
+    bgzf_reader* r = bgzf_open(j->d->bam_name);
+    if (!r) fatalf("error in opening the file %s", j->d->bam_name);
+    bgzf_set_workers(r, 0);
     bam_header* h = bam_header_load(r);
-    mgbuf_take(out, 4 * (MG_HEAD_WORDS + (size_t)MG_MAX_RG * MG_RG_WORDS));
-    for (int32_t t = 0; t < h->n_targets; t++) {
-        if (m->owner[t] != m->rank) continue;
-        n_ctg++;
-        if (m->skip && m->skip[t]) { int32_t* hd = mgbuf_take(out, 20); hd[0] = t; continue; }
-        prewalk_piece(d, r, t, 0, h->target_len[t], estimate, rgs, &n_rg, out);
+    for (int k = j->t0; k < j->n_mine; k += j->step) {
+        const piece_t* pc = &j->pieces[j->mine[k]];
+        const size_t at = j->out[k].n;
+        prewalk_piece(j->d, r, pc->tid, pc->beg, pc->end, j->estimate, j->rgs, &j->n_rg, &j->out[k]);
+        ((int32_t*)(j->out[k].p + at))[0] = pc->index;
+        /* the read-group indices of the events are this thread's: the main thread maps them onto the rank's list (mg_prewalk) */
     }
     bam_header_free(h);
     bgzf_close(r);
+    return NULL;
+}
+
+static void mg_prewalk(mgpu* m, driver* d, int estimate, mgbuf* out, const piece_t* pieces, int n_pieces, const int32_t* piece_walker)
+{
+    int32_t* mine = xmalloc(sizeof(int32_t) * (size_t)(n_pieces ? n_pieces : 1));
+    int n_mine = 0;
+    for (int i = 0; i < n_pieces; i++) if (piece_walker[i] == m->rank) mine[n_mine++] = i;
+    long ncpu = sysconf(_SC_NPROCESSORS_ONLN);
+    {
+        FILE* fp = fopen("/sys/fs/cgroup/cpu.max", "r");
+        long quota = 0, period = 0;
+        if (fp) { if (fscanf(fp, "%ld %ld", &quota, &period) == 2 && quota > 0 && period > 0 && quota / period < ncpu) ncpu = quota / period; fclose(fp); }
+    }
+    int nt = getenv("INDELMINER_WALKERS") ? atoi(getenv("INDELMINER_WALKERS")) : (int)(ncpu > 16 ? 16 : ncpu);
+    if (nt > n_mine) nt = n_mine;
+    if (nt < 1) nt = 1;
+    if (nt > 32) nt = 32;
+    mgbuf* pieces_out = xcalloc((size_t)(n_mine ? n_mine : 1), sizeof(mgbuf));
+    prewalk_job* jobs = xcalloc((size_t)nt, sizeof(prewalk_job));
+    pthread_t* th = xmalloc(sizeof(pthread_t) * (size_t)nt);
+    for (int i = 0; i < nt; i++) {
+        jobs[i].d = d; jobs[i].pieces = pieces; jobs[i].mine = mine; jobs[i].n_mine = n_mine; jobs[i].t0 = i; jobs[i].step = nt;
+        jobs[i].estimate = estimate; jobs[i].out = pieces_out;
+        if (pthread_create(&th[i], NULL, prewalk_thread, &jobs[i]) != 0) fatalf("cannot start a pre-walk thread");
+    }
+    for (int i = 0; i < nt; i++) pthread_join(th[i], NULL);
+    /* one read-group list for the rank: each thread's list onto it (names; extrema and first sightings merged) */
+    mg_rg* rgs = xcalloc(MG_MAX_RG, sizeof(mg_rg));
+    int n_rg = 0;
+    int (*remap)[MG_MAX_RG] = xcalloc((size_t)nt, sizeof *remap);
+    for (int i = 0; i < nt; i++)
+        for (int k = 0; k < jobs[i].n_rg; k++) {
+            const mg_rg* g = &jobs[i].rgs[k];
+            const int at = mg_rg_index(rgs, &n_rg, g->name);
+            remap[i][k] = at;
+            if (!g->seen) continue;
+            mg_rg* t = &rgs[at];
+            if (!t->seen) { const int32_t keep = 1; *t = *g; t->seen = keep; }
+            else {
+                if (g->min < t->min) t->min = g->min;
+                if (g->max > t->max) t->max = g->max;
+                if (g->first_tid < t->first_tid || (g->first_tid == t->first_tid && g->first_rec < t->first_rec)) { t->first_tid = g->first_tid; t->first_rec = g->first_rec; }
+            }
+        }
+    mgbuf_take(out, 4 * (MG_HEAD_WORDS + (size_t)MG_MAX_RG * MG_RG_WORDS));
+    for (int k = 0; k < n_mine; k++) {
+        /* the piece's block, its events' read groups in the rank's numbering */
+        int32_t* hd = (int32_t*)pieces_out[k].p;
+        int32_t* ev = hd + 5;
+        const int who = k % nt;
+        for (int32_t e = 0; e < hd[3]; e++) {
+            const int gi = (ev[3] >> 8) & 0xff, nl = (ev[3] >> 16) & 0xffff;
+            ev[3] = (ev[3] & ~0xff00) | (remap[who][gi] << 8);
+            ev += 4 + (nl + 3) / 4;
+        }
+        memcpy(mgbuf_take(out, pieces_out[k].n), pieces_out[k].p, pieces_out[k].n);
+        free(pieces_out[k].p);
+    }
     int32_t* w = (int32_t*)out->p;
-    w[0] = MG_MAGIC; w[1] = n_rg; w[2] = n_ctg; w[3] = (int32_t)(out->n & 0xffffffff); w[4] = (int32_t)((uint64_t)out->n >> 32);
+    w[0] = MG_MAGIC; w[1] = n_rg; w[2] = n_mine; w[3] = (int32_t)(out->n & 0xffffffff); w[4] = (int32_t)((uint64_t)out->n >> 32);
     for (int k = 0; k < n_rg; k++) {
         int32_t* g = w + MG_HEAD_WORDS + (size_t)k * MG_RG_WORDS;
         memcpy(g, rgs[k].name, 48);
-        /* whole contigs per rank: the position of the first sighting orders the read groups inside a contig */
         g[12] = rgs[k].min; g[13] = rgs[k].max; g[14] = rgs[k].first_tid; g[15] = (int32_t)(rgs[k].first_rec >> 32); g[16] = rgs[k].seen; g[17] = (int32_t)(uint32_t)rgs[k].first_rec;
     }
-    free(rgs);
+    free(rgs); free(remap); free(pieces_out); free(jobs); free(th); free(mine);
 }
 
 static int cmp_mg_rg(const void* x, const void* y)
@@ -3377,11 +3467,11 @@ static void estimate_insertlengths_threads(driver* d, const piece_t* pieces, int
 typedef struct { int32_t start, tid, slot; } mg_wait;
 
 /* exchange + merge: the insert-length table (when estimated), the counter prefix and the marker floor of every contig */
-static void mg_exchange(mgpu* m, driver* d, int estimate)
+static void mg_exchange(mgpu* m, driver* d, int estimate, const piece_t* pieces, int n_pieces, const int32_t* piece_walker)
 {
     const int32_t nt = d->hdr->n_targets;
     mgbuf mine = { NULL, 0, 0 };
-    mg_prewalk(m, d, estimate, &mine);
+    mg_prewalk(m, d, estimate, &mine, pieces, n_pieces, piece_walker);
     phase_time("pre-walk of this rank's contigs (count, pair-table events, insert lengths)");
     /* ONE all-gather of fixed-size buffers.  Every rank derives the same size from the same file: pair-table events are a few
      * per thousand records, so a 64th of the file holds them many times over; a rank whose log does not fit says so in its
@@ -3392,7 +3482,7 @@ static void mg_exchange(mgpu* m, driver* d, int estimate)
         const int64_t fsize = stat(d->bam_name, &sb) == 0 ? (int64_t)sb.st_size : 0;
         const char* e = getenv("INDELMINER_MG_LOG_BYTES");
         int64_t c = e ? atoll(e) : fsize / 64;
-        const int64_t least = 4 * (MG_HEAD_WORDS + (int64_t)MG_MAX_RG * MG_RG_WORDS) + 20 * ((int64_t)nt + 1);
+        const int64_t least = 4 * (MG_HEAD_WORDS + (int64_t)MG_MAX_RG * MG_RG_WORDS) + 20 * ((int64_t)n_pieces + 1);
         if (c < least) c = least;
         if (!e && c < (4 << 20)) c = 4 << 20;
         cap = ((size_t)c + 255) & ~(size_t)255;
@@ -3436,8 +3526,8 @@ static void mg_exchange(mgpu* m, driver* d, int estimate)
         for (int j = 0; j < n; j++) rg_table_enter(d, &rgs[j]);
         free(rgs);
     }
-    /* where each contig's block lies, and range[1] of every (rank, read group) through the table's own look-up */
-    const int32_t** block = xcalloc((size_t)nt + 1, sizeof(int32_t*));
+    /* where each piece's block lies, and range[1] of every (rank, read group) through the table's own look-up */
+    const int32_t** block = xcalloc((size_t)n_pieces + 1, sizeof(int32_t*));
     int32_t* rmax = xmalloc(sizeof(int32_t) * (size_t)m->world * MG_MAX_RG);
     for (int rk = 0; rk < m->world; rk++) {
         const int32_t* a = (const int32_t*)(all + (size_t)rk * cap);
@@ -3450,23 +3540,27 @@ static void mg_exchange(mgpu* m, driver* d, int estimate)
         }
         const int32_t* at = a + MG_HEAD_WORDS + (size_t)MG_MAX_RG * MG_RG_WORDS;
         for (int c = 0; c < a[2]; c++) {
-            forceassert(at[0] >= 0 && at[0] < nt && m->owner[at[0]] == rk && block[at[0]] == NULL);
+            forceassert(at[0] >= 0 && at[0] < n_pieces && piece_walker[at[0]] == rk && block[at[0]] == NULL);
             block[at[0]] = at;
             at += 5 + at[4] / 4;
         }
     }
-    /* the replay: every contig's events through ONE pair table, in file order, as the single run serves it */
-    m->prefix = xcalloc((size_t)nt + 1, sizeof(int64_t));
+    /* the replay: every piece's events through ONE pair table, in file order, as the single run serves it */
+    m->piece_prefix = xcalloc((size_t)n_pieces + 1, sizeof(int64_t));
     m->floor = xmalloc(sizeof(int) * ((size_t)nt + 1));
+    for (int32_t t = 0; t <= nt; t++) m->floor[t] = INT_MAX;
     qhash* table = qhash_new(16);
     mg_wait** live = NULL; int32_t n_live = 0, cap_live = 0;
     int64_t run = 0;
-    for (int32_t t = 0; t < nt; t++) {
-        m->prefix[t] = run;
-        int fl = INT_MAX;
-        for (int32_t i = 0; i < n_live; i++) if (live[i]->start < fl) fl = live[i]->start;
-        m->floor[t] = fl;
-        const int32_t* hd = block[t];
+    for (int pi = 0; pi < n_pieces; pi++) {
+        const int32_t t = pieces[pi].tid;
+        m->piece_prefix[pi] = run;
+        if (pieces[pi].first) {
+            int fl = INT_MAX;
+            for (int32_t i = 0; i < n_live; i++) if (live[i]->start < fl) fl = live[i]->start;
+            m->floor[t] = fl;
+        }
+        const int32_t* hd = block[pi];
         forceassert(hd != NULL);
         run += (int64_t)(uint32_t)hd[1] | ((int64_t)hd[2] << 32);
         const int32_t* ev = hd + 5;
@@ -3475,7 +3569,7 @@ static void mg_exchange(mgpu* m, driver* d, int estimate)
             const int first = word & 1, gi = (word >> 8) & 0xff, nl = (word >> 16) & 0xffff;
             const char* name = (const char*)(ev + 4);
             ev += 4 + (nl + 3) / 4;
-            const int32_t r1 = rmax[m->owner[t] * MG_MAX_RG + gi];
+            const int32_t r1 = rmax[piece_walker[pi] * MG_MAX_RG + gi];
             if (r1 < 0 || aisize <= r1) continue;                                   /* src/indelminer.c:519 */
             qbin* hb = qhash_lookup(table, name, nl);
             if (hb && ((mg_wait*)hb->val)->tid != t) m->cross = 1;                  /* an entry of an earlier contig under this name */
@@ -3504,7 +3598,7 @@ static void mg_discard_dir(mgpu* m)
     if (!dp) return;
     struct dirent* de;
     while ((de = readdir(dp)) != NULL) {
-        if (strncmp(de->d_name, "part.", 5) != 0 && strncmp(de->d_name, "done.", 5) != 0 && strncmp(de->d_name, "rccl_id", 7) != 0) continue;
+        if (strncmp(de->d_name, "part.", 5) != 0 && strncmp(de->d_name, "done.", 5) != 0 && strncmp(de->d_name, "pkg.", 4) != 0 && strncmp(de->d_name, "rccl_id", 7) != 0) continue;
         char victim[800];
         snprintf(victim, sizeof victim, "%s/%s", m->dir, de->d_name);
         unlink(victim);
@@ -3646,6 +3740,98 @@ static void group_park_device(ppipe* P, pgroup* G)
     GPU(im_dev_memset(g, P->counters, 0, 64, P->stream));
     GPU(im_stream_sync(g, P->stream));
     P->conf_cand = 0; P->conf_err = 0; P->conf_bytes = 0;
+}
+
+/* ---- multi-GPU: a group walked by one rank, staged and replayed by another ---- */
+/* What the owner of the contig needs of a walked group: the pieces' bounds and counted reads, the flush points (placed by the
+ * walking rank, which knows the read counter in front of its pieces from the exchange), the kept records of not-proper pairs,
+ * the candidates' record numbers and BAM records, and the parked device arrays.  One file per claim in the rendezvous directory,
+ * written under another name and renamed when complete; `aborted` = the walk met a record the reference dies on. */
+#define PKG_MAGIC 0x504b4733
+typedef struct { int32_t magic, aborted, n_ctg, n_fp, n_npp, n_cand, sv_n; int64_t n_rec, npp_len, craw_len, sv_bytes; } pkg_head;
+
+static void pkg_put(FILE* fp, const void* p, size_t bytes, const char* path) { if (bytes && fwrite(p, 1, bytes, fp) != bytes) fatalf("cannot write %s", path); }
+static void pkg_get(FILE* fp, void* p, size_t bytes, const char* path) { if (bytes && fread(p, 1, bytes, fp) != bytes) fatalf("%s is cut short", path); }
+
+static void package_write(const mgpu* m, int ci, ppipe* P, pgroup* G, int aborted)
+{
+    char path[512], tmp[520];
+    mg_path(m, path, sizeof path, "pkg", ci);
+    snprintf(tmp, sizeof tmp, "%s.tmp", path);
+    FILE* fp = fopen(tmp, "wb");
+    if (!fp) fatalf("cannot write %s", tmp);
+    pkg_head h;
+    memset(&h, 0, sizeof h);
+    h.magic = PKG_MAGIC; h.aborted = aborted;
+    if (!aborted) {
+        h.n_ctg = G->n_ctg; h.n_fp = G->n_fp; h.n_npp = G->n_npp; h.n_cand = G->n_cand; h.sv_n = G->sv_n;
+        h.n_rec = G->n_rec; h.npp_len = G->npp_len; h.craw_len = G->craw_len; h.sv_bytes = G->sv_bytes;
+    }
+    pkg_put(fp, &h, sizeof h, tmp);
+    if (!aborted) {
+        pkg_put(fp, G->ctg, sizeof(gcontig) * (size_t)G->n_ctg, tmp);
+        pkg_put(fp, G->fp, sizeof(gfpoint) * (size_t)G->n_fp, tmp);
+        pkg_put(fp, G->npp_off, sizeof(int64_t) * ((size_t)G->n_npp + (G->n_npp ? 1 : 0)), tmp);
+        pkg_put(fp, G->npp_rec, sizeof(int32_t) * (size_t)G->n_npp, tmp);
+        pkg_put(fp, G->npp_raw, (size_t)G->npp_len, tmp);
+        pkg_put(fp, G->cand_rec, sizeof(int32_t) * (size_t)G->n_cand, tmp);
+        pkg_put(fp, G->craw_off, sizeof(int64_t) * ((size_t)G->n_cand + (G->n_cand ? 1 : 0)), tmp);
+        pkg_put(fp, G->craw, (size_t)G->craw_len, tmp);
+        const size_t n = (size_t)G->sv_n, ns = n * IM_MAX_EV;
+        const size_t bytes[10] = { (size_t)G->sv_bytes, 8 * n, 4 * n, 4 * n, 4 * n, 4 * n, 4 * ns, 4 * ns, 4 * ns, 4 * n };
+        size_t most = 0;
+        for (int k = 0; k < 10; k++) if (bytes[k] > most) most = bytes[k];
+        uint8_t* t = xmalloc(most + 8);
+        for (int k = 0; k < 10; k++) {
+            if (!bytes[k]) continue;
+            GPU(im_dev_download(P->d->gpu, t, G->sv[k], bytes[k]));
+            pkg_put(fp, t, bytes[k], tmp);
+        }
+        free(t);
+    }
+    if (fclose(fp) != 0 || rename(tmp, path) != 0) fatalf("cannot publish %s", path);
+}
+
+/* the owner's side: waits for the file, rebuilds the group, parks its arrays on this rank's device; NULL = the walk was aborted */
+static pgroup* package_read(const mgpu* m, int ci, ppipe* P)
+{
+    char path[512];
+    mg_path(m, path, sizeof path, "pkg", ci);
+    FILE* fp = NULL;
+    mg_arm("a piece another rank walks");
+    while (!(fp = fopen(path, "rb"))) { struct timespec ts = { 0, 2 * 1000 * 1000 }; nanosleep(&ts, NULL); }
+    mg_disarm();
+    pkg_head h;
+    pkg_get(fp, &h, sizeof h, path);
+    if (h.magic != PKG_MAGIC) fatalf("%s is not a group of this run", path);
+    if (h.aborted) { fclose(fp); unlink(path); return NULL; }
+    pgroup* G = xcalloc(1, sizeof(pgroup));
+    G->from_package = 1;
+    G->n_ctg = G->cap_ctg = h.n_ctg; G->n_fp = G->cap_fp = h.n_fp; G->n_npp = G->cap_npp = h.n_npp; G->n_cand = G->cap_cand = h.n_cand; G->sv_n = h.sv_n;
+    G->n_rec = h.n_rec; G->npp_len = G->npp_cap = h.npp_len; G->craw_len = G->craw_cap = h.craw_len; G->sv_bytes = h.sv_bytes;
+    G->ctg = xmalloc(sizeof(gcontig) * (size_t)(h.n_ctg ? h.n_ctg : 1)); pkg_get(fp, G->ctg, sizeof(gcontig) * (size_t)h.n_ctg, path);
+    G->fp = xmalloc(sizeof(gfpoint) * (size_t)(h.n_fp ? h.n_fp : 1)); pkg_get(fp, G->fp, sizeof(gfpoint) * (size_t)h.n_fp, path);
+    G->npp_off = xmalloc(sizeof(int64_t) * ((size_t)h.n_npp + 1)); pkg_get(fp, G->npp_off, sizeof(int64_t) * ((size_t)h.n_npp + (h.n_npp ? 1 : 0)), path);
+    G->npp_rec = xmalloc(sizeof(int32_t) * (size_t)(h.n_npp ? h.n_npp : 1)); pkg_get(fp, G->npp_rec, sizeof(int32_t) * (size_t)h.n_npp, path);
+    G->npp_raw = xmalloc((size_t)h.npp_len + 1); pkg_get(fp, G->npp_raw, (size_t)h.npp_len, path);
+    G->cand_rec = xmalloc(sizeof(int32_t) * (size_t)(h.n_cand ? h.n_cand : 1)); pkg_get(fp, G->cand_rec, sizeof(int32_t) * (size_t)h.n_cand, path);
+    G->craw_off = xmalloc(sizeof(int64_t) * ((size_t)h.n_cand + 1)); pkg_get(fp, G->craw_off, sizeof(int64_t) * ((size_t)h.n_cand + (h.n_cand ? 1 : 0)), path);
+    G->craw = xmalloc((size_t)h.craw_len + 1); pkg_get(fp, G->craw, (size_t)h.craw_len, path);
+    const size_t n = (size_t)G->sv_n, ns = n * IM_MAX_EV;
+    const size_t bytes[10] = { (size_t)G->sv_bytes, 8 * n, 4 * n, 4 * n, 4 * n, 4 * n, 4 * ns, 4 * ns, 4 * ns, 4 * n };
+    size_t total = 0, most = 0;
+    for (int k = 0; k < 10; k++) { total += (bytes[k] + 255) & ~(size_t)255; if (bytes[k] > most) most = bytes[k]; }
+    char* slab = pdev_alloc(P, total);
+    uint8_t* t = xmalloc(most + 8);
+    for (int k = 0; k < 10; k++) {
+        G->sv[k] = slab;
+        if (bytes[k]) { pkg_get(fp, t, bytes[k], path); GPU(im_dev_upload(P->d->gpu, G->sv[k], t, bytes[k])); }
+        slab += (bytes[k] + 255) & ~(size_t)255;
+    }
+    free(t);
+    fclose(fp);
+    unlink(path);
+    return G;
 }
 
 /* ONE-PASS mode, once the insert lengths are known: every candidate's range[1] from its own record */
@@ -3877,15 +4063,19 @@ static void* walker_thread(void* arg)
     for (;;) {
         pthread_mutex_lock(&o->mu);
         /* walked groups wait for the main thread with their logs and parked arrays: stay a bounded number of claims ahead of it */
-        while (!g_onepass && o->next_claim < o->n_claims && o->next_claim >= o->staged + 2 * o->nw + 4) pthread_cond_wait(&o->cv, &o->mu);
+        while (!g_onepass && !g_mg && o->next_claim < o->n_claims && o->next_claim >= o->staged + 2 * o->nw + 4) pthread_cond_wait(&o->cv, &o->mu);
+        while (g_mg && o->next_claim < o->n_claims && g_mg->claim_walker[o->next_claim] != g_mg->rank) o->next_claim++;      /* another rank walks it */
         const int ci = o->next_claim < o->n_claims ? o->next_claim++ : -1;
         pthread_mutex_unlock(&o->mu);
         if (ci < 0) break;
         claim_t* c = &o->claims[ci];
+        const int ship = g_mg && g_mg->claim_owner[ci] != g_mg->rank;
         if (g_handoff_pool) {
             /* a record the reference dies on ends this walker: the claim is published as it is, marked */
             W->cur_claim = c;
             if (setjmp(W->abort_jmp)) {
+                const int cj = (int)(W->cur_claim - o->claims);
+                if (g_mg && g_mg->claim_owner[cj] != g_mg->rank) package_write(g_mg, cj, &W->P, NULL, 1);      /* its owner hands the run over */
                 pthread_mutex_lock(&o->mu);
                 W->cur_claim->G = NULL; W->cur_claim->aborted = 1; W->cur_claim->walked = 1;
                 pthread_cond_broadcast(&o->cv);
@@ -3896,6 +4086,13 @@ static void* walker_thread(void* arg)
         }
         pgroup* G = walk_claim(W, o, c);
         t_abort_jmp = NULL;
+        if (g_mg) { int64_t nr = 0; group_flush_points(G, &nr); G->from_package = 1; }      /* the counter in front of every piece is known (mg_exchange) */
+        if (ship) {
+            package_write(g_mg, ci, &W->P, G, 0);
+            im_dev_free(W->P.d->gpu, G->sv[0]);
+            group_free(G); free(G);
+            G = NULL;
+        }
         pthread_mutex_lock(&o->mu);
         c->G = G; c->walked = 1;
         pthread_cond_broadcast(&o->cv);
@@ -3975,10 +4172,11 @@ static walkpool_t* walkpool_start(driver* d)
     if (nw > 32) nw = 32;
     int64_t total_bytes = 0, total_len = 0;
     for (int32_t i = 0; i < nt; i++) {
-        if (g_mg && g_mg->owner[i] != g_mg->rank) continue;
+        if (g_mg && g_mg->skip && g_mg->skip[i]) continue;
         if (g_region_tid >= 0 && i != g_region_tid) continue;
         total_bytes += bai_contig_bytes(d->idx, i); total_len += d->hdr->target_len[i];
     }
+    if (g_mg) { total_bytes /= g_mg->world; total_len /= g_mg->world; }      /* a rank's share: the plan below is the whole run's, the same on every rank */
     /* pieces: a contig is cut where its compressed bytes cross multiples of the piece size -- about 1/(8 walkers) of the file, at
      * least 8 MB of it (a stage and a replay have fixed costs per group), so that large contigs spread over all walkers */
     int64_t piece_bytes = total_bytes / (8 * (int64_t)nw);
@@ -3987,7 +4185,7 @@ static walkpool_t* walkpool_start(driver* d)
     if (o->serial) piece_bytes = 0;
     int cap = 0;
     for (int32_t i = 0; i < nt; i++) {
-        if (g_mg && g_mg->owner[i] != g_mg->rank) continue;         /* another rank's contig */
+        if (g_mg && g_mg->skip && g_mg->skip[i]) continue;          /* annotate mode: no known variant on it, nobody walks it */
         if (g_region_tid >= 0 && i != g_region_tid) continue;
         int32_t cuts[4096];
         int nc = piece_bytes > 0 ? bai_split_points(d->idx, i, d->hdr->target_len[i], piece_bytes, cuts, 4096) : 0;
@@ -4006,6 +4204,7 @@ static walkpool_t* walkpool_start(driver* d)
             pc->tid = i; pc->beg = k ? cuts[k - 1] : lo; pc->end = k < nc ? cuts[k] : hi;
             pc->first = k == 0; pc->last = k == nc; pc->weight = w / (nc + 1);
             pc->overlap = g_region_tid >= 0 && k == 0;
+            pc->index = o->n_pieces - 1;
         }
     }
     /* claims: a piece of a cut contig on its own; whole small contigs together up to about a piece's worth (the stage and the
@@ -4021,8 +4220,34 @@ static walkpool_t* walkpool_start(driver* d)
         int64_t len = 0;
         if (!(p0->first && p0->last)) { k++; c->count = 1; continue; }
         do { len += d->hdr->target_len[o->pieces[k].tid]; k++; }
-        while (!o->serial && k < o->n_pieces && o->pieces[k].first && o->pieces[k].last && len + d->hdr->target_len[o->pieces[k].tid] <= claim_len);
+        while (!o->serial && k < o->n_pieces && o->pieces[k].first && o->pieces[k].last && len + d->hdr->target_len[o->pieces[k].tid] <= claim_len &&
+               (!g_mg || g_mg->owner[o->pieces[k].tid] == g_mg->owner[p0->tid]));
         c->count = k - c->first;
+    }
+    if (g_mg) {
+        /* Who walks what.  A contig's stage and replay are its owner's (mg_plan: contigs to ranks by size); its pieces are WALKED --
+         * read, inflated, triaged -- by whichever rank has done the least so far, so that one large contig, or fewer contigs than
+         * GPUs, still keeps every rank's cores and GPU busy.  The walked group then travels to the owner (package_write). */
+        mgpu* m = g_mg;
+        m->claim_owner = xmalloc(sizeof(int32_t) * (size_t)(o->n_claims ? o->n_claims : 1));
+        m->claim_walker = xmalloc(sizeof(int32_t) * (size_t)(o->n_claims ? o->n_claims : 1));
+        m->piece_walker = xmalloc(sizeof(int32_t) * (size_t)(o->n_pieces ? o->n_pieces : 1));
+        int64_t* load = xcalloc((size_t)m->world, sizeof(int64_t));
+        const char* how = getenv("INDELMINER_MG_WALK");
+        for (int ci = 0; ci < o->n_claims; ci++) {
+            const claim_t* c = &o->claims[ci];
+            int64_t w = 1;
+            for (int k = 0; k < c->count; k++) w += o->pieces[c->first + k].weight;
+            const int own = m->owner[o->pieces[c->first].tid];
+            int best = own;
+            for (int r = 0; r < m->world; r++) if (load[r] + w / 8 < load[best]) best = r;      /* the owner unless somebody is clearly idler */
+            if (o->serial || (how && strcmp(how, "owner") == 0)) best = own;
+            m->claim_owner[ci] = own; m->claim_walker[ci] = best;
+            load[best] += w;
+            for (int k = 0; k < c->count; k++) m->piece_walker[c->first + k] = best;
+            if (best != own) m->split = 1;
+        }
+        free(load);
     }
     if (nw > o->n_claims) nw = o->n_claims ? o->n_claims : 1;
     o->nw = nw;
@@ -4129,10 +4354,19 @@ static void run_pipeline(driver* d, walkpool_t* o)
     pgroup* chain = NULL;                   /* the same groups, for freeing them together */
     int n_freeable = 0;
     struct { pgroup* chain; int last_job; } *dead = xcalloc((size_t)(o->n_claims ? o->n_claims : 1), sizeof *dead);
+    /* multi-GPU with pieces of a contig walked by several ranks: no rank's depth array is complete before all ranks have walked
+     * all their pieces -- the contigs' replays wait for the sum (im_depth_allreduce) */
+    struct { pgroup** held; int n_held; pgroup* chain; } *late = (g_mg && g_mg->split) ? xcalloc((size_t)(o->n_claims ? o->n_claims : 1), sizeof *late) : NULL;
+    int n_late = 0;
     for (int ci = 0; ci < o->n_claims; ci++) {
         claim_t* c = &o->claims[ci];
+        if (g_mg && g_mg->claim_owner[ci] != g_mg->rank) continue;        /* another rank's contig */
         g_mg_cur_tid = o->pieces[c->first].tid;
-        if (o->serial) {
+        if (g_mg && g_mg->claim_walker[ci] != g_mg->rank) {
+            c->G = package_read(g_mg, ci, &S);
+            c->walked = 1; c->aborted = c->G == NULL;
+            if (c->aborted) pipeline_handoff();
+        } else if (o->serial) {
             /* walked here, after the replay of the previous contig let go of the known-variant list */
             const int32_t tid = o->pieces[c->first].tid;
             known_free(&g_known);
@@ -4163,13 +4397,21 @@ static void run_pipeline(driver* d, walkpool_t* o)
             if (g_handoff_pool) pipeline_handoff();
             fatalf("read names are shared between contigs (the reference pairs them across contigs in its one pair table): run with INDELMINER_PIPELINE=host");
         }
-        group_resolve_flushes(G, &numread, &floor_);
+        if (!G->from_package) group_flush_points(G, &numread);
+        group_resolve_flushes(G, &floor_);
         stage_run_group(&S, G);
         stage_leftovers(G, &C, contig_floor);
         pthread_mutex_lock(&o->mu); o->staged = ci + 1; pthread_cond_broadcast(&o->cv); pthread_mutex_unlock(&o->mu);
         G->next_of_contig = chain; chain = G;
         held[n_held++] = G;
         if (!last_of_contig) continue;
+        if (late) {
+            late[n_late].held = xmalloc(sizeof(pgroup*) * (size_t)n_held);
+            memcpy(late[n_late].held, held, sizeof(pgroup*) * (size_t)n_held);
+            late[n_late].n_held = n_held; late[n_late].chain = chain; n_late++;
+            n_held = 0; chain = NULL;
+            continue;
+        }
         /* the contig (or the run of small contigs) is complete: its depth array, then its groups' replays */
         for (int k = 0; k < n_held; k++)
             for (int cj = 0; cj < held[k]->n_ctg; cj++)
@@ -4207,6 +4449,25 @@ static void run_pipeline(driver* d, walkpool_t* o)
         }
         n_held = 0; chain = NULL;
     }
+    if (late) {
+        /* every rank has walked what it walks (its walkers are done: the packages are out) and staged what it owns */
+        for (int i = 0; i < o->nw && !o->serial; i++) pthread_join(o->w[i].th, NULL);
+        mg_arm("the sum of the depth arrays");
+        GPU2(d, im_depth_allreduce(d->gpu, g_mg->comm));
+        mg_disarm();
+        phase_time("depth arrays summed over the ranks");
+        for (int k = 0; k < n_late; k++) {
+            for (int j = 0; j < late[k].n_held; j++)
+                for (int cj = 0; cj < late[k].held[j]->n_ctg; cj++)
+                    if (late[k].held[j]->ctg[cj].last) GPU2(d, im_depth_scan(d->gpu, late[k].held[j]->ctg[cj].tid, S.stream));
+            GPU2(d, im_stream_sync(d->gpu, S.stream));
+            for (int j = 0; j < late[k].n_held; j++) group_replay(d, late[k].held[j]);
+            groups_free_chain(late[k].chain);
+            free(late[k].held);
+        }
+        free(late);
+        phase_time("replay (variants, merge, print)");
+    }
     if (nrep) {
         pthread_mutex_lock(&o->mu);
         o->jobs_closed = 1;
@@ -4230,7 +4491,7 @@ static void run_pipeline(driver* d, walkpool_t* o)
     free(o->jobs); o->jobs = NULL; free(held); free(dead);
     d->numread = numread;
     if (g_handoff_pool) { g_handoff_pool = NULL; if (t_out) { fflush(t_out); fclose(t_out); t_out = NULL; } }
-    for (int i = 0; i < o->nw && !o->serial && !g_onepass; i++) pthread_join(o->w[i].th, NULL);
+    for (int i = 0; i < o->nw && !o->serial && !g_onepass && !(g_mg && g_mg->split); i++) pthread_join(o->w[i].th, NULL);
     /* the walkers' pinned rings and device arrays go with the process unless a tidy exit is asked for (leak checkers):
      * un-pinning and freeing them costs more than the whole device stage of a run */
     if (getenv("INDELMINER_TIDY_EXIT")) {
@@ -4559,7 +4820,7 @@ int main(int argc, char** argv)
     const int use_pipeline = !(pl && strcmp(pl, "host") == 0);
     if (g_mg) {
         mg_rendezvous(&mg, &d);
-        mg_exchange(&mg, &d, O.configfile == NULL);
+        mg_exchange(&mg, &d, O.configfile == NULL, pool->pieces, pool->n_pieces, mg.piece_walker);
         if (mg.cross) {
             /* A first mate left waiting in one contig meets a record of the same name in a later one: the reference's one
              * pair table pairs them across contigs (readpairs is never reset, src/indelminer.c), so the contigs of this

@@ -455,6 +455,25 @@ int im_comm_allgather(im_comm* m, const void* send, void* recv, size_t bytes, vo
     m->seq++;
     return IM_OK;
 }
+int im_comm_allreduce_sum_i32(im_comm* m, int32_t* buf, size_t count, void* stream)
+{
+    int32_t* all = malloc(4 * count * (size_t)m->world);
+    const int rc = im_comm_allgather(m, buf, all, 4 * count, stream);
+    if (rc == IM_OK)
+        for (size_t i = 0; i < count; i++) { int32_t s = 0; for (int r = 0; r < m->world; r++) s += all[(size_t)r * count + i]; buf[i] = s; }
+    free(all);
+    return rc;
+}
+int im_depth_allreduce(im_ctx* c, im_comm* m)
+{
+    if (!g_gdepth) return IM_E_ARG;
+    for (int i = 0; i < c->n; i++) {
+        const int rc = im_comm_allreduce_sum_i32(m, g_gdepth[i], (size_t)c->lens[i] + 1, NULL);
+        if (rc != IM_OK) return rc;
+    }
+    return IM_OK;
+}
+
 void im_comm_destroy(im_comm* m)
 {
     if (!m) return;

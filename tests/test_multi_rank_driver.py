@@ -176,3 +176,40 @@ def test_ranks_hand_a_run_the_reference_aborts_to_one_process(tmp_path):
             assert _run_world(world, [], str(tmp_path), "ref.fa", "s=aln.bam".split("=")[1]) == one.stdout, world
     finally:
         del os.environ["IM_TEST_RC0"]
+
+
+def _with_env(env, fn):
+    old = {k: os.environ.get(k) for k in env}
+    os.environ.update(env)
+    try:
+        return fn()
+    finally:
+        for k, v in old.items():
+            if v is None:
+                del os.environ[k]
+            else:
+                os.environ[k] = v
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_one_contig_over_several_ranks(tmp_path_factory, world):
+    """ONE contig, several ranks: its pieces are walked (read, inflated, triaged) by all of them, the walked groups travel to the
+    contig's owner, which serves the pair table, places the markers, runs the stage and replays -- with the depth arrays of the
+    ranks summed in one all-reduce first.  The bytes of the single-process run, with and without a config file."""
+    d = th._synth_dir(tmp_path_factory, "synth_1mb_30x")
+    for flags, golden in ((["-i", "cfg.txt"], "synth_1mb_30x"), ([], "synth_1mb_30x_noconfig")):
+        for pb in ("400000", "90000"):
+            got = _with_env({"INDELMINER_PIECE_BYTES": pb}, lambda: _run_world(world, flags, d, "ref.fa", "aln.bam"))
+            assert got == th._golden(golden), (flags, pb)
+
+
+def test_contigs_in_pieces_over_ranks_with_markers_pinned_low(tmp_path):
+    """four contigs, first mates that wait for ever in two of them (every later marker pinned, also in later contigs), pieces of
+    every contig on every rank: counter prefixes per piece, marker floors per contig, frozen evidence waiting for its contig's end"""
+    d = th._stale_dir(tmp_path)
+    want = th._run(th._build_shim(), [], d, ref="ref.fa", bam="aln.bam", env={"INDELMINER_PIPELINE": "host"})
+    for world in (2, 3):
+        got = _with_env({"INDELMINER_PIECE_BYTES": "120000"}, lambda: _run_world(world, [], d, "ref.fa", "aln.bam"))
+        assert got == want, world
+    det = th._run(th._build_shim(), ["-o", "detailed"], d, ref="ref.fa", bam="aln.bam", env={"INDELMINER_PIPELINE": "host"})
+    assert _with_env({"INDELMINER_PIECE_BYTES": "200000"}, lambda: _run_world(2, ["-o", "detailed"], d, "ref.fa", "aln.bam")) == det
