@@ -125,7 +125,7 @@ class PipeStep:
 
     def __init__(self, ctx, rd, depth):
         self.ctx = ctx
-        raw, off = rawrec.records(rd)
+        raw, off = rawrec.records(rd, qual=os.environ.get("IM_BENCH_KEEP_QUAL") == "1")     # as the product's walkers deliver them: without base qualities
         self.n_records = rd.n
         self.record_bytes = int(len(raw))
         flushes, pe_b1, pe_b2 = flush_schedule(rd)

@@ -309,7 +309,10 @@ int im_set_insert_ranges(im_ctx* ctx, int32_t n, const char* const* names, const
 
 /* A chunk of delivered records on the device: each record is the 32-byte BAM core followed by its
  * variable part (qname, cigar, seq, qual, aux) exactly as in the file, WITHOUT the block_size word,
- * starting at a 4-byte aligned offset.  rec_off has n + 1 entries; record i spans rec_off[i]..rec_off[i+1], which may
+ * starting at a 4-byte aligned offset.  A record whose core carries bin = 0xFFFF (no bin of any record: bins end at 37449)
+ * comes WITHOUT its l_seq quality bytes -- (qname, cigar, seq, aux): nothing on the path reads qualities, and they are half
+ * of every record's bytes over PCIe and out of HBM.  The deliverer may only leave them out when the CIGAR's read bases do not
+ * exceed l_seq (the reference reads on behind the packed bases otherwise, src/readaln.c:186-240).  rec_off has n + 1 entries; record i spans rec_off[i]..rec_off[i+1], which may
  * include up to three bytes of alignment padding behind the aux area: the tag walk treats a tail shorter than the
  * smallest possible field (tag, type, one value byte = 4 bytes) as the end of the record. */
 typedef struct im_dev_records {

@@ -62,7 +62,9 @@ __device__ __forceinline__ RecView view_record(const uint8_t* raw, uint32_t off,
     if (r.l_seq < 0) return r;
     r.o_cigar = 32u + r.l_qname;
     r.o_seq = r.o_cigar + 4u * r.n_cigar;
-    const uint64_t o_aux = (uint64_t)r.o_seq + (((uint64_t)r.l_seq + 1u) >> 1) + (uint64_t)r.l_seq;
+    // a record delivered without its base qualities says so in its bin field (include/indelminer_amd.h, im_dev_records)
+    const bool no_qual = (w2 >> 16) == 0xFFFFu;
+    const uint64_t o_aux = (uint64_t)r.o_seq + (((uint64_t)r.l_seq + 1u) >> 1) + (no_qual ? 0ull : (uint64_t)r.l_seq);
     if (o_aux > r.len) return r;
     r.o_aux = (uint32_t)o_aux;
     r.ok = true;

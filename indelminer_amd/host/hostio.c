@@ -579,6 +579,7 @@ static void core_view(const uint8_t* c, bam_record* b)
     b->n_cigar = (uint16_t)(c[12] | (c[13] << 8)); b->flag = (uint16_t)(c[14] | (c[15] << 8));
     b->l_seq = (int32_t)U32(16); b->mtid = (int32_t)U32(20); b->mpos = (int32_t)U32(24); b->isize = (int32_t)U32(28);
 #undef U32
+    b->no_qual = b->bin == BAM_BIN_NO_QUAL;
 }
 
 void bam_record_view(const uint8_t* rec, int32_t len, bam_record* view)
@@ -602,9 +603,43 @@ int bam_region_next_raw(bam_region_iter* it, uint8_t* dst, int64_t cap, int32_t*
             it->pending_size = bs;
         }
         if ((int64_t)it->pending_size > cap) return -2;
-        const int32_t bs = it->pending_size;
+        int32_t bs = it->pending_size;
         it->pending_size = 0;
-        if (bgzf_read(it->r, dst, bs) != bs) { it->done = 1; return -1; }
+        if (!it->drop_qual) {
+            if (bgzf_read(it->r, dst, bs) != bs) { it->done = 1; return -1; }
+            if (dst[10] == 0xFF && dst[11] == 0xFF) dst[10] = 0xFE;        /* not a bin of any record: it must not read as the marker */
+        } else {
+            /* core, name and CIGAR first: they say where the qualities lie and whether the CIGAR stays inside l_seq */
+            if (bgzf_read(it->r, dst, 32) != 32) { it->done = 1; return -1; }
+            const int32_t l_qname = dst[8], n_cigar = dst[12] | (dst[13] << 8);
+            const int32_t l_seq = (int32_t)((uint32_t)dst[16] | ((uint32_t)dst[17] << 8) | ((uint32_t)dst[18] << 16) | ((uint32_t)dst[19] << 24));
+            const int64_t head = 32 + (int64_t)l_qname + 4 * (int64_t)n_cigar;
+            if (l_seq < 0 || head + (((int64_t)l_seq + 1) >> 1) + l_seq > bs) {
+                /* a record that is not what it says: as it is (the triage calls it malformed) */
+                if (bgzf_read(it->r, dst + 32, bs - 32) != bs - 32) { it->done = 1; return -1; }
+                if (dst[10] == 0xFF && dst[11] == 0xFF) dst[10] = 0xFE;
+            } else {
+                if (bgzf_read(it->r, dst + 32, head - 32) != head - 32) { it->done = 1; return -1; }
+                int64_t q = 0;
+                for (int32_t k = 0; k < n_cigar; k++) {
+                    const uint32_t cw = bamr_cigar_at(dst + 32 + l_qname, k), op = cw & 15u;
+                    if (op == 0 || op == 1 || op == 4 || op == 7 || op == 8) q += cw >> 4;
+                }
+                const int64_t packed = ((int64_t)l_seq + 1) >> 1;
+                if (q > l_seq) {
+                    if (bgzf_read(it->r, dst + head, bs - head) != bs - head) { it->done = 1; return -1; }
+                    if (dst[10] == 0xFF && dst[11] == 0xFF) dst[10] = 0xFE;
+                } else {
+                    if (bgzf_read(it->r, dst + head, packed) != packed) { it->done = 1; return -1; }
+                    uint8_t skip[512];
+                    for (int64_t left = l_seq; left > 0;) { const int64_t n = left < (int64_t)sizeof skip ? left : (int64_t)sizeof skip; if (bgzf_read(it->r, skip, n) != n) { it->done = 1; return -1; } left -= n; }
+                    const int64_t aux = bs - head - packed - l_seq;
+                    if (bgzf_read(it->r, dst + head + packed, aux) != aux) { it->done = 1; return -1; }
+                    dst[10] = 0xFF; dst[11] = 0xFF;
+                    bs -= l_seq;
+                }
+            }
+        }
         bam_record_view(dst, bs, view);
         if (view->tid != it->tid || view->pos >= it->end) { it->done = 1; return 0; }    /* bam_index.c:704-707 */
         if (32 + (int64_t)view->l_qname + 4 * (int64_t)view->n_cigar > bs) { it->done = 1; return -1; }

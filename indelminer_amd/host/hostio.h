@@ -34,14 +34,18 @@ typedef struct {
     int32_t  l_seq, mtid, mpos, isize;
     uint8_t* data;          /* qname, cigar, seq, qual, aux */
     int32_t  l_data, m_data;
+    int      no_qual;       /* a delivered record whose base qualities were left out (bin == BAM_BIN_NO_QUAL): aux follows the packed bases */
 } bam_record;
+/* The device pipeline's records travel without their base qualities (half of every record; nothing on the path reads them):
+ * such a record says so in its bin field, which no part of the path uses.  See bam_region_next_raw. */
+#define BAM_BIN_NO_QUAL 0xFFFFu
 
 #define BAMR_QNAME(b)  ((char*)(b)->data)
 /* CIGAR word k: the words follow the read name, at any byte alignment */
 static inline uint32_t bamr_cigar_at(const uint8_t* cig8, int k) { uint32_t v; memcpy(&v, cig8 + 4 * (size_t)k, 4); return v; }
 #define BAMR_CIGAR(b)  ((const uint8_t*)((b)->data + (b)->l_qname))
 #define BAMR_SEQ(b)    ((b)->data + (b)->l_qname + 4 * (b)->n_cigar)
-#define BAMR_AUX(b)    ((b)->data + (b)->l_qname + 4 * (b)->n_cigar + (((b)->l_seq + 1) >> 1) + (b)->l_seq)
+#define BAMR_AUX(b)    ((b)->data + (b)->l_qname + 4 * (b)->n_cigar + (((b)->l_seq + 1) >> 1) + ((b)->no_qual ? 0 : (b)->l_seq))
 #define BAMR_SEQI(s, i) (((s)[(i) >> 1] >> ((~(i) & 1) << 2)) & 0xf)
 
 bam_header* bam_header_load(bgzf_reader* r);
@@ -66,6 +70,7 @@ typedef struct {
     int done;
     int32_t pending_size;   /* block_size of a record whose body has not been read yet (bam_region_next_raw) */
     int by_start;           /* 1: the records that START in [beg, end) (bam_piece_begin), not the ones that overlap it */
+    int drop_qual;          /* bam_region_next_raw leaves the base qualities out (set by the caller after *_begin) */
 } bam_region_iter;
 int bam_region_begin(bam_region_iter* it, bgzf_reader* r, const bai_index* idx, int32_t tid, int32_t beg, int32_t end);
 int bam_region_next(bam_region_iter* it, bam_record* b);   /* 1 = record, 0 = done, -1 = error */
@@ -79,7 +84,10 @@ int bai_split_points(const bai_index* idx, int32_t tid, int32_t length, int64_t 
  * block_size word) land in the caller's buffer dst[0..cap) -- the host driver points it into a pinned chunk
  * that goes to the GPU as it is.  view receives the decoded core and view->data = dst + 32 (not owned).
  * Returns 1 = record (*len_out bytes written), 0 = done, -1 = error, -2 = the next record needs more than
- * cap bytes (nothing consumed: call again with a bigger / fresh buffer). */
+ * cap bytes (nothing consumed: call again with a bigger / fresh buffer).
+ * With it->drop_qual the l_seq quality bytes are not copied and the record's bin field reads BAM_BIN_NO_QUAL -- unless the CIGAR
+ * asks for more read bases than l_seq: the reference then reads on into the bytes behind the packed bases (new_readaln,
+ * src/readaln.c:186-240), so such a record keeps them. */
 void bam_record_view(const uint8_t* rec, int32_t len, bam_record* view);   /* decode a raw record in place (view->data not owned) */
 int bam_region_next_raw(bam_region_iter* it, uint8_t* dst, int64_t cap, int32_t* len_out, bam_record* view);
 

@@ -2590,6 +2590,8 @@ static void pipe_walk_piece(ppipe* P, pgroup* G, const piece_t* pc, bgzf_reader*
     G->cur_ctg = G->n_ctg - 1;
     bam_region_iter it;
     if ((pc->overlap ? bam_region_begin(&it, r, d->idx, tid, pc->beg, pc->end) : bam_piece_begin(&it, r, d->idx, tid, pc->beg, pc->end)) != 0) fatalf("cannot seek in %s", d->bam_name);
+    /* the records travel without their base qualities (half their bytes; nothing on the path reads them): INDELMINER_KEEP_QUAL=1 keeps them */
+    it.drop_qual = !getenv("INDELMINER_KEEP_QUAL");
     bam_record b; memset(&b, 0, sizeof b);
     for (;;) {
         pchunk* c = &P->ck[P->cur];

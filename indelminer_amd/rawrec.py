@@ -119,11 +119,60 @@ def build(rd, lo=0, hi=None, qname_prefix="r", align=4, block_size_word=False, r
     return raw, off, dict(pos=pos, end=end, bin=core["bin"].astype(np.int64), tid=rd.tid[sl].astype(np.int64))
 
 
-def records(rd, lo=0, hi=None, qname_prefix="r", rg=None):
-    """Device layout: (raw uint8, rec_off uint32[n + 1])."""
+def records(rd, lo=0, hi=None, qname_prefix="r", rg=None, qual=True):
+    """Device layout: (raw uint8, rec_off uint32[n + 1]).  qual=False: without base qualities, as the product delivers records."""
     raw, off, _ = build(rd, lo, hi, qname_prefix, align=4, block_size_word=False, rg=rg)
     assert off[-1] < 2**32
+    if not qual:
+        return strip_quals(raw, off)
     return raw, off.astype(np.uint32)
+
+
+def strip_quals(raw, off):
+    """The device layout WITHOUT base qualities, as the product's walkers deliver records (include/indelminer_amd.h, im_dev_records):
+    (qname, cigar, seq, aux) behind the core, bin = 0xFFFF -- except records whose CIGAR asks for more read bases than l_seq, which
+    stay as they are.  Returns (raw, rec_off uint32[n + 1])."""
+    raw = np.ascontiguousarray(raw, dtype=np.uint8)
+    off = np.asarray(off, dtype=np.int64)
+    n = len(off) - 1
+    if n == 0:
+        return raw.copy(), off.astype(np.uint32)
+    start, end = off[:-1], off[1:]
+    ok = end - start >= 32
+    base = np.where(ok, start, 0)
+    u8 = lambda o: raw[base + o].astype(np.int64)
+    l_qname = u8(8)
+    n_cigar = u8(12) | (u8(13) << 8)
+    l_seq = (u8(16) | (u8(17) << 8) | (u8(18) << 16) | (u8(19) << 24)).astype(np.int64)
+    l_seq = np.where(l_seq >= 1 << 31, l_seq - (1 << 32), l_seq)
+    head = 32 + l_qname + 4 * n_cigar
+    packed = (np.maximum(l_seq, 0) + 1) >> 1
+    fits = ok & (l_seq >= 0) & (head + packed + l_seq <= end - start)
+    qlen = np.zeros(n, np.int64)
+    for k in range(int(n_cigar[fits].max()) if fits.any() else 0):
+        has = fits & (n_cigar > k)
+        o = np.where(has, base + 32 + l_qname + 4 * k, 0)
+        cw = raw[o].astype(np.int64) | (raw[o + 1].astype(np.int64) << 8) | (raw[o + 2].astype(np.int64) << 16) | (raw[o + 3].astype(np.int64) << 24)
+        op = cw & 15
+        qlen += np.where(has & np.isin(op, (0, 1, 4, 7, 8)), cw >> 4, 0)
+    drop = fits & (qlen <= l_seq)
+    cut = np.where(drop, l_seq, 0)
+    # real length of each record without its alignment padding is unknown here: keep the bytes behind the qualities as they are
+    new_len = (end - start) - cut
+    new_step = (new_len + 3) // 4 * 4
+    new_off = np.zeros(n + 1, np.int64)
+    np.cumsum(new_step, out=new_off[1:])
+    out = np.zeros(int(new_off[-1]) + 64, np.uint8)
+    first = np.where(drop, head + packed, end - start)          # bytes in front of the qualities
+    _scatter(out, new_off[:-1], first, raw[np.repeat(start - (np.cumsum(first) - first), first) + np.arange(int(first.sum()), dtype=np.int64)])
+    rest = (end - start) - first - cut
+    src0 = start + first + cut
+    _scatter(out, new_off[:-1] + first, rest, raw[np.repeat(src0 - (np.cumsum(rest) - rest), rest) + np.arange(int(rest.sum()), dtype=np.int64)])
+    dropped = np.nonzero(drop)[0]
+    out[new_off[dropped] + 10] = 0xFF; out[new_off[dropped] + 11] = 0xFF
+    kept_marker = np.nonzero(~drop & ok & (raw[base + 10] == 0xFF) & (raw[base + 11] == 0xFF))[0]
+    out[new_off[kept_marker] + 10] = 0xFE
+    return out[:int(new_off[-1])].copy(), new_off.astype(np.uint32)
 
 
 def records_from_bam(path):

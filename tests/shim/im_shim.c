@@ -198,9 +198,22 @@ int im_dev_triage(im_ctx* c, const im_triage_params* tp, const im_dev_records* r
     if (tp->restart) for (int k = 0; k < 5; k++) cnt[k] = 0;       /* a new batch: the running counters count as zero */
     imo_triage t;
     char* bases = malloc(1 << 20);
+    uint8_t* whole = NULL; size_t whole_cap = 0;
     for (int32_t i = 0; i < recs->n; i++) {
         const uint8_t* rec = recs->raw + recs->rec_off[i];
-        const uint32_t len = recs->rec_off[i + 1] - recs->rec_off[i];
+        uint32_t len = recs->rec_off[i + 1] - recs->rec_off[i];
+        if (len >= 32 && rec[10] == 0xFF && rec[11] == 0xFF) {
+            /* delivered without its base qualities (bin = 0xFFFF): the oracle takes records as the file has them -- put l_seq bytes back */
+            const uint32_t l_qname = rec[8], n_cigar = rec[12] | (rec[13] << 8);
+            const uint32_t l_seq = (uint32_t)rec[16] | ((uint32_t)rec[17] << 8) | ((uint32_t)rec[18] << 16) | ((uint32_t)rec[19] << 24);
+            const uint32_t head = 32 + l_qname + 4 * n_cigar + ((l_seq + 1) >> 1);
+            if ((size_t)len + l_seq + 8 > whole_cap) { whole_cap = ((size_t)len + l_seq + 8) * 2; whole = realloc(whole, whole_cap); }
+            memcpy(whole, rec, head);
+            memset(whole + head, 0xFF, l_seq);
+            memcpy(whole + head + l_seq, rec + head, len - head);
+            whole[10] = 0; whole[11] = 0;
+            rec = whole; len += l_seq;
+        }
         imo_triage_record(rec, len, tp->defer_ranges ? -1 : g_n_rg, (const char* const*)g_rg_names, g_rg_range, tp->qthreshold, tp->ethreshold_vcfcheck,
                           tp->maxpedelsize, &t, bases);
         int cls = t.cls;
@@ -246,7 +259,7 @@ int im_dev_triage(im_ctx* c, const im_triage_params* tp, const im_dev_records* r
         }
         cnt[0]++; cnt[1] += padded;
     }
-    free(bases);
+    free(bases); free(whole);
     return IM_OK;
 }
 

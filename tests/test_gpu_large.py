@@ -43,6 +43,28 @@ def test_large_config_matches_reference_digest(tmp_path, name):
         assert got[k] == want[k], (k, got[k], want[k])
 
 
+def test_wgs_scale_reference_at_1x(tmp_path):
+    """BASELINE configs[3]'s reference -- 3.0e9 bases in 24 contigs with the human length spread -- at 1x (3.0e7 reads), generated on
+    the box by tests/support/simgen.c, through the product: the VCF's digest is the CPU shim's (the record-at-a-time path over the
+    oracle, tests/golden/large_wgs1x.json); the same bytes with the insert lengths estimated in the same pass and with the contigs
+    cut into many more pieces.  (At 30x this input is profiles/wgs_run.py: minutes of GPU-box time, not a test.)"""
+    import hashlib
+    from indelminer_amd import build
+    want = json.load(open(os.path.join(GOLD, "large_wgs1x.json")))
+    gen = os.path.join(ROOT, "tests", "support", "simgen")
+    subprocess.check_call(["gcc", "-O2", "-std=gnu11", "-pthread", "-o", gen, gen + ".c", "-lz", "-lm"])
+    out = subprocess.run([gen, "--prefix", str(tmp_path / "w"), "--threads", "16"] + want["simgen"], stdout=subprocess.PIPE, check=True)
+    info = json.loads(out.stdout.decode())
+    assert info["records"] == want["records_in_bam"] and info["bam_bytes"] == want["bam_bytes"]
+    build.build()
+    prod = build.build_host()
+    for flags, env in ((["-i", "w.cfg"], {}), ([], {"INDELMINER_ONEPASS": "1"}), (["-i", "w.cfg"], {"INDELMINER_PIECE_BYTES": "3000000", "INDELMINER_WALKERS": "12"})):
+        p = subprocess.run([prod] + flags + ["w.fa", "s=w.bam"], cwd=str(tmp_path), stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=dict(os.environ, **env))
+        assert p.returncode == 0, p.stderr.decode()[-2000:]
+        assert hashlib.md5(p.stdout).hexdigest() == want["md5"], (flags, env)
+        assert sum(1 for l in p.stdout.splitlines() if not l.startswith(b"#")) == want["vcf_records"]
+
+
 def test_config4like_candidates_match_oracle_record_by_record(gpu_ctx):
     """the 24-contig, 2.28e9-byte reference resident in HBM at once (contig offsets beyond 2^31, the longest contig beyond
     2^27 bases): device triage of every delivered record, then the realign kernel on every candidate of every contig,

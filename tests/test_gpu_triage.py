@@ -61,6 +61,22 @@ def _compare_triage(pipe, raw, rec_off, rg_names, rg_range, tri=None, **kw):
                 assert (s_cls[sl], s_b1[sl], s_b2[sl]) == (t.ev_cls[k], t.ev_b1[k], t.ev_b2[k])
             else:
                 assert s_cls[sl] == -1
+    # the same records the way the product's walkers deliver them -- without their base qualities (bin = 0xFFFF; records whose CIGAR
+    # reaches past l_seq keep them): every output must be what it was
+    raw2, off2 = rawrec.strip_quals(raw, rec_off)
+    assert len(raw2) < len(raw) or n == 0 or not any(t.cls in (1, 3) for t, _ in tri)
+    pipe.upload(raw2, off2)
+    pipe.triage()
+    c2 = pipe.fetch_counts()
+    assert np.array_equal(c2[:5], c[:5])
+    assert np.array_equal(pipe.d_class.download(np.uint8, n), h_cls)
+    assert np.array_equal(pipe.d_cand_rec.download(np.int32, max(m, 1))[:m], np.array(cand, np.int32))
+    assert np.array_equal(pipe.d_boff.download(np.int64, max(m, 1))[:m], boff) and np.array_equal(pipe.d_len.download(np.int32, max(m, 1))[:m], blen)
+    assert np.array_equal(pipe.d_bases.download(np.uint8, pipe.cap_bases)[:pos], bases[:pos])
+    assert np.array_equal(pipe.d_anchor.download(np.int32, max(m, 1))[:m], anchor) and np.array_equal(pipe.d_range.download(np.int32, max(m, 1))[:m], rng)
+    assert np.array_equal(pipe.d_cls.download(np.int32, pipe.n_slots).reshape(-1)[:m * capi.MAX_EV], s_cls[:m * capi.MAX_EV])
+    assert np.array_equal(pipe.d_b1.download(np.int32, pipe.n_slots)[:m * capi.MAX_EV], s_b1[:m * capi.MAX_EV])
+    assert np.array_equal(pipe.d_b2.download(np.int32, pipe.n_slots)[:m * capi.MAX_EV], s_b2[:m * capi.MAX_EV])
     return tri, cand
 
 
