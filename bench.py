@@ -20,7 +20,7 @@ starts; `value` counts the records the timed kernels read -- all of them.
 Workload (BASELINE.json configs[1]): synthetic 1 Mb contig, 100 bp PE reads at
 30x with seeded 1-50 bp indels, per GPU (weak scaling: every rank owns one such
 contig, seeded by its rank; the path shards by contig with no data-path
-collective except the gather of per-shard cluster lists).
+collective in the timed step).
 
 Prints ONE JSON line on rank 0.
 """
@@ -148,7 +148,7 @@ class PipeStep:
             pipe.upload(rk, off)
             pipe.set_pe(pe_b1, pe_b2)
             stream = capi.new_stream(ctx)
-            self.sets.append({"pipe": pipe, "stream": stream, "done": capi.Event(ctx),
+            self.sets.append({"pipe": pipe, "stream": stream, "done": capi.Event(ctx), "raw_host": rk,
                               "calls": pipe.bind_async(flushes, stream, grid_bound=cap, depth_tid=k, wide=FLUSH_WIDE), "graph": None, "tail": []})
         self.k = 0
 
@@ -206,6 +206,46 @@ class PipeStep:
     def sync(self):
         for st_ in self.sets:
             self.ctx._check(capi.lib().im_stream_sync(self.ctx.h, st_["stream"]))
+
+    def measure_with_uploads(self, steps):
+        """The same overlapped passes with the step's records CROSSING PCIe first: every step uploads its chunk (records + offsets)
+        from pinned host memory on its stream, then runs the pass -- what the product's walkers do.  Returns seconds per step."""
+        L_ = capi.lib()
+        import ctypes
+        pinned = []
+        for cur in self.sets:
+            p = cur["pipe"]
+            hr, ho = ctypes.c_void_p(), ctypes.c_void_p()
+            self.ctx._check(L_.im_host_alloc(self.ctx.h, len(self.raw0) + 64, ctypes.byref(hr)))
+            self.ctx._check(L_.im_host_alloc(self.ctx.h, 4 * len(self.off), ctypes.byref(ho)))
+            ctypes.memmove(hr.value, np.ascontiguousarray(cur["raw_host"]).ctypes.data, len(self.raw0))
+            ctypes.memmove(ho.value, np.ascontiguousarray(self.off).ctypes.data, 4 * len(self.off))
+            pinned.append((hr, ho))
+            cur["upload"] = [(L_.im_dev_upload_async, (self.ctx.h, p.d_raw.ptr, hr.value, len(self.raw0), cur["stream"])),
+                             (L_.im_dev_upload_async, (self.ctx.h, p.d_off.ptr, ho.value, 4 * len(self.off), cur["stream"]))]
+        self.sync()
+        t = time.perf_counter()
+        for _ in range(steps):
+            cur = self.sets[self.k % len(self.sets)]
+            if self.k >= len(self.sets):
+                cur["done"].sync()
+            rc = 0
+            for fn, args in cur["upload"]:
+                rc = rc or fn(*args)
+            rc = rc or (L_.im_graph_launch(cur["graph"], cur["stream"]) if cur["graph"] is not None else 0)
+            if cur["graph"] is None:
+                for fn, args in cur["calls"]:
+                    rc = rc or fn(*args)
+            if rc:
+                self.ctx._check(rc)
+            cur["done"].record(cur["stream"])
+            self.last = cur
+            self.k += 1
+        self.sync()
+        dt = (time.perf_counter() - t) / steps
+        for hr, ho in pinned:
+            L_.im_host_free(self.ctx.h, hr); L_.im_host_free(self.ctx.h, ho)
+        return dt
 
     def quiet_launch_times(self, n=12):
         """HIP events around the realign launch and around the triage launches with NOTHING else on the device: the pass
@@ -377,7 +417,7 @@ def end_to_end(refs, rd):
         return out
 
 
-def end_to_end_multi(rank, world, local_rank, dist, ref_len=500_000):
+def end_to_end_multi(rank, world, local_rank, dist, ref_len=2_000_000):
     """The PRODUCT on all the job's GPUs: every rank starts `indelminer` as a child with its own
     RANK / LOCAL_RANK / WORLD_SIZE on one BAM of max(world, 2) contigs -- contigs tid % world per rank, one RCCL all-gather
     of shard summaries, rank 0 prints the VCF -- and rank 0 compares that VCF byte for byte with the single-process run.
@@ -388,8 +428,8 @@ def end_to_end_multi(rank, world, local_rank, dist, ref_len=500_000):
     from indelminer_amd import bamwrite, build
     if not os.path.exists(build.HOST_BIN):
         return None
-    n_ctg = max(world, 2)
-    box = [None, 0]
+    n_ctg = 2                     # fewer contigs than GPUs from 3 ranks on: their pieces are walked by every rank
+    box = [None, 0, 0]
     if rank == 0:
         box[0] = tempfile.mkdtemp(prefix="im_mgpu_")
         refs, rd = synth.simulate(seed=11, ref_len=ref_len, coverage=30, read_len=100, n_contigs=n_ctg, big_every=7)
@@ -398,16 +438,20 @@ def end_to_end_multi(rank, world, local_rank, dist, ref_len=500_000):
         rawrec.write_bam_fast(box[0] + "/aln.bam", contigs, rd, level=6)
         open(box[0] + "/cfg.txt", "w").write("IL generic 300 %d\n" % rd.range_max)
         box[1] = int(rd.n)
+        box[2] = os.path.getsize(box[0] + "/aln.bam")
     if dist is not None:
         dist.broadcast_object_list(box, src=0)
-    td, n_reads = box
+    td, n_reads, bam_bytes = box
     cmd = [build.HOST_BIN, "-i", "cfg.txt", "ref.fa", "s=aln.bam"]
-    env = dict(os.environ, RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(local_rank), INDELMINER_RENDEZVOUS=td + "/rdv", INDELMINER_RUN_TOKEN=td)
+    # pieces small enough that every rank gets several (the default piece size is for files of gigabytes)
+    env = dict(os.environ, RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(local_rank), INDELMINER_RENDEZVOUS=td + "/rdv", INDELMINER_RUN_TOKEN=td,
+               INDELMINER_PIECE_BYTES=str(max(bam_bytes // (3 * max(world, 1)), 200000)))
     if world == 1:
         env["INDELMINER_FORCE_MGPU"] = "1"
     if os.environ.get("IM_BENCH_ONE_DEVICE") == "1":
         env["INDELMINER_DEVICE"] = "0"
-    out = {"n_gpus": world, "contigs": n_ctg, "reads": n_reads}
+    out = {"n_gpus": world, "contigs": n_ctg, "reads": n_reads, "what": "the product CLI, one process per GPU: %d contigs cut into pieces that all ranks walk, "
+           "walked groups shipped to the contig's owner, one all-gather of the ranks' logs + one sum of the depth arrays" % n_ctg}
     t = time.perf_counter()
     try:
         p = subprocess.run(cmd, cwd=td, stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env, timeout=300)
@@ -553,58 +597,14 @@ def main():
     ctx.set_insert_ranges(["generic"], [rd.range_max])
     ps = PipeStep(ctx, rd, PIPELINE_DEPTH)
 
-    # ---- the one collective: all-gather of the per-shard cluster lists (fixed capacity, sized from a first pass) ----
+    # ---- no data-path collective in the timed step: contigs (and pieces of contigs) are independent on the device; the product's
+    # exchanges -- one all-gather of the ranks' logs before the walk, one sum of the depth arrays when pieces of a contig were
+    # walked by several ranks -- happen once per RUN and are measured where they happen, in end_to_end_multi_gpu ----
     ps.step(); ps.sync()
     c0, res0, counts0 = ps.results()
     assert int(c0[0]) == n_cand and int(c0[3]) == 0 and int(c0[4]) == 0, (c0, n_cand)
     digest0 = ps.digest(ps.last)           # the pass on its own, nothing else on the device
-    comm = None
-    collective = None
-    if world > 1 or os.environ.get("IM_BENCH_FORCE_COMM") == "1":
-        # every bring-up stage is agreed on by ALL ranks over gloo before the next one starts: either every rank
-        # attaches the communicator or the job stops (a rank-local failure must not leave the others in a collective)
-        def agree(ok):
-            if dist is None:
-                return ok
-            t = torch.tensor([1 if ok else 0], dtype=torch.int64)
-            dist.all_reduce(t, op=dist.ReduceOp.MIN)
-            return bool(int(t[0]))
-        ncl = int(counts0[0])
-        if dist is not None:
-            t = torch.tensor([ncl], dtype=torch.int64)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            ncl = int(t[0])
-        rec_cap = 1024
-        while rec_cap < 2 * ncl:
-            rec_cap *= 2
-        ids = [None]
-        err = None
-        try:
-            if rank == 0:
-                ids = [capi.comm_unique_id()]
-        except Exception as e:
-            err = e
-        ok = agree(err is None)
-        if ok and dist is not None:
-            dist.broadcast_object_list(ids, src=0)
-        if ok:
-            try:
-                comm = capi.Comm(ctx, ids[0], rank, world)
-            except Exception as e:
-                err = e
-            ok = agree(err is None and comm is not None)
-        if ok:
-            gbytes = 16 + 16 * rec_cap
-            for st_ in ps.sets:
-                st_["gather"] = capi.DevBuf(ctx, gbytes * world)
-                st_["tail"].append((capi.lib().im_comm_allgather, (comm.h, st_["pipe"].d_clbuf.ptr, st_["gather"].ptr, gbytes, st_["stream"])))
-            collective = "rccl all-gather of per-shard cluster lists, %d B per rank per step" % gbytes
-        else:
-            # agreed by ALL ranks: nobody attaches a communicator, the shards run independently and the line says so
-            if comm is not None:
-                comm.close()
-                comm = None
-            collective = "NONE (RCCL bring-up failed on at least one rank%s); shards ran independently" % (": %s" % err if err else "")
+    collective = "none in the timed step (shards are independent); the product's per-run exchanges are in end_to_end_multi_gpu"
 
     def barrier():
         ps.sync()
@@ -670,10 +670,6 @@ def main():
             e2e_mg = end_to_end_multi(rank, world, local_rank, dist)
         except Exception as ex:                 # plumbing; never hides the kernel numbers
             e2e_mg = {"error": str(ex)}
-    gathered_clusters = None
-    if comm is not None and rank == 0:
-        g = ps.last["gather"].download(np.int32, (gbytes // 4) * world).reshape(world, -1)
-        gathered_clusters = int(sum(int(g[r, 0]) for r in range(world)))
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
         value = total_reads * args.steps / elapsed
@@ -709,6 +705,11 @@ def main():
             h2d = h2d_pinned_gbs(ctx)
         except Exception:
             h2d = None
+        try:
+            s_pcie = ps.measure_with_uploads(min(max(args.steps, 50), 400))
+        except Exception as ex:
+            s_pcie = None
+            sys.stderr.write("measure_with_uploads: %s\n" % ex)
         line = {
             "metric": "reads/sec through split-read realign+cluster; VCF diff-clean vs reference",
             "value": value, "unit": "reads/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -720,14 +721,16 @@ def main():
                        "reads_per_step": total_reads, "candidates_per_step": total_cand,
                        "record_bytes_per_step_rank0": ps.record_bytes,
                        "h2d_pinned_gbs": h2d,
-                       "reads_per_s_with_the_records_crossing_pcie": (n_reads / (ps.record_bytes / (h2d * 1e9) + ms_per_step * 1e-3)) if h2d else None,
+                       "reads_per_s_with_the_records_crossing_pcie": (n_reads / s_pcie) if s_pcie else None,
+                       "reads_per_s_with_the_records_crossing_pcie_note": "MEASURED: every step uploads its records from pinned host memory on its stream, "
+                                                                          "then runs the pass; 4 streams overlap copies and kernels as the product's walkers do",
+                       "ms_per_step_with_the_records_crossing_pcie": s_pcie * 1e3 if s_pcie else None,
                        "flushes_per_step": len(ps.flushes), "evidence_nodes_per_step_rank0": nodes, "clusters_per_step_rank0": ncl,
                        "candidates_per_s": total_cand * args.steps / elapsed,
                        "band_alignments_per_s": n_band * world * args.steps / elapsed,
                        "gcups": 2.0 * L * n_band * world * args.steps / elapsed / 1e9,
                        "pipeline_depth": PIPELINE_DEPTH, "hip_graph": os.environ.get("IM_BENCH_GRAPH", "1") == "1",
                        "parallelism": "contig-sharded x%d" % world, "collective": collective,
-                       "gathered_clusters": gathered_clusters,
                        "timed_region": "the product driver's device pass over EVERY delivered record of the shard: triage "
                                        "(candidate rules, base decode, CIGAR evidence, pileup depth scatter) -> depth scan of the contig -> realign -> "
                                        "one flush cut per READCHUNK flush point -> split-read group-by; BGZF inflate and the pair table stay on the host "
@@ -739,6 +742,7 @@ def main():
                                        "of_each_buffer_set_after_the_timed_region": [dg[2] for dg in digests]}},
             "roofline": {"bound": "hbm", "kernel": "realign_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": measured_traffic()[0],
+                         "longest_stage_of_the_step": "realign_kernel" if q_realign >= q_triage else "triage (classify + emit + decode, three launches)",
                          "traffic_source": "%s: PMC passes of an EARLIER run of this command (FETCH_SIZE x 2 + WRITE_SIZE per launch), not measured in this run" % measured_traffic()[1],
                          "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": q_realign,
                          "avg_launch_ms_note": "HIP events around the realign launch on its stream with nothing else on the device (the kernel's own "
@@ -763,9 +767,6 @@ def main():
                 line["shard_config3"] = {"error": str(ex)}
         sys.stdout.flush()
         os.write(real_stdout, (json.dumps(line) + "\n").encode())
-    if comm is not None:
-        ps.sync()
-        comm.close()
     if dist is not None:
         dist.destroy_process_group()
     ctx.close()
