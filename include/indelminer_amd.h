@@ -42,7 +42,7 @@ extern "C" {
 #define IM_ST_EVIDENCE    1     /* segment list + n_ev >= 1 evidence records valid   */
 #define IM_ST_ABORT      -1     /* the reference would have exited on this read      */
 #define IM_ST_OVERFLOW   -2
-#define IM_ST_UNSUPPORTED -3    /* e.g. read longer than IM_MAX_READ                 */
+#define IM_ST_UNSUPPORTED -3    /* e.g. read longer than IM_MAX_READ, or than 255 bases without im_expect_read_length */
 
 /* CIGAR op codes in packed words (len<<4|op): samtools bam.h + src/readaln.h:10-11 */
 #define IM_OP_M  0
@@ -52,7 +52,8 @@ extern "C" {
 #define IM_OP_EQ 7
 #define IM_OP_X  8
 
-#define IM_MAX_READ  255        /* longest read the kernels take                     */
+#define IM_MAX_READ  1020       /* longest read the realign kernels take (numgaps == 0; 255 with numgaps > 0);
+                                   reads beyond 255 bases run in a second kernel, see im_expect_read_length */
 #define IM_MAX_SW_TARGET 4095   /* longest annotate-mode window (reference span + variant) im_support_batch takes */
 #define IM_MAX_OPS   64         /* packed segment words per realigned read           */
 #define IM_MAX_EV    4          /* indel segments (= evidence) per realigned read    */
@@ -220,6 +221,15 @@ typedef struct im_dev_batch {
  * Asynchronous: returns after the launch. */
 int im_dev_realign(im_ctx* ctx, const im_params* params,
                    const im_dev_batch* batch, void* stream);
+
+/* The reference realigns reads of any length (src/readaln.c:242-267).  Here reads of up to 255 bases run in the
+ * kernel laid out for them (four read positions per lane); reads of 256 .. IM_MAX_READ bases (2 x 300 chemistry)
+ * take a second launch with sixteen positions per lane, which every im_dev_realign* call issues behind the first
+ * once the context has been told that such reads occur: max_len = the longest read seen so far (the value only
+ * ever grows; callable from any thread).  im_realign (host buffers) calls it by itself.  Without the call such a
+ * read comes back IM_ST_UNSUPPORTED, as does any read beyond 255 bases when numgaps > 0.
+ * Returns IM_E_UNSUPPORTED for max_len > IM_MAX_READ. */
+int im_expect_read_length(im_ctx* ctx, int32_t max_len);
 
 /* Bytes of device scratch im_dev_cluster_sr needs for n evidence records. */
 size_t im_dev_cluster_scratch_bytes(int32_t n);

@@ -14,7 +14,8 @@ from . import build as _build
 
 MAX_OPS = 64
 MAX_EV = 4
-MAX_READ = 255
+MAX_READ = 1020
+SHORT_READ = 255        # reads beyond it take the second realign launch (Context.expect_read_length)
 
 IM_OK = 0
 E_ARG, E_NOGPU, E_HIP, E_UNSUPPORTED, E_ABORT, E_OVERFLOW = -1, -2, -3, -4, -5, -6
@@ -117,6 +118,7 @@ def lib():
         L.im_cluster_sr.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32,
                                     C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_int32)]
         L.im_dev_realign.argtypes = [C.c_void_p, C.POINTER(Params), C.POINTER(DevBatch), C.c_void_p]
+        L.im_expect_read_length.argtypes = [C.c_void_p, C.c_int32]
         L.im_dev_cluster_scratch_bytes.restype = C.c_size_t
         L.im_dev_cluster_scratch_bytes.argtypes = [C.c_int32]
         L.im_dev_gather_scratch_bytes.restype = C.c_size_t
@@ -378,6 +380,10 @@ class Context:
         lens = (C.c_int64 * n)(*[len(c) for c in contigs])
         self._check(lib().im_set_reference(self.h, n, arr, lens))
         self.contig_len = [len(c) for c in contigs]
+
+    def expect_read_length(self, max_len):
+        """reads of 256 .. MAX_READ bases occur: every realign launch is followed by the long-read kernel"""
+        self._check(lib().im_expect_read_length(self.h, int(max_len)))
 
     def realign_batch(self, params, reads, tid, anchor, range_max, allow=()):
         """reads: list of bytes.  Returns (rc, numpy structured array of RESULT_DTYPE)."""

@@ -11,10 +11,12 @@
 #include <vector>
 #include <unordered_map>
 #include <mutex>
+#include <atomic>
 
 struct im_ctx {
     int device = -1;
     int n_cu = 0;
+    std::atomic<int> expect_len{0};     // im_expect_read_length: beyond kShortRead the long-read pass follows every realign launch
     hipStream_t stream = nullptr;
     char err[512] = {0};
     // reference
@@ -251,6 +253,17 @@ static int dev_realign(im_ctx* ctx, const im_params* params, const im_dev_batch*
     a.keep_slots = keep;
     a.n_dev = n_dev;
     HIP_TRY(ctx, im::launch_realign(a, ctx->n_cu, (hipStream_t)stream));
+    if (ctx->expect_len.load(std::memory_order_relaxed) > im::kShortRead && params->numgaps == 0)
+        HIP_TRY(ctx, im::launch_realign_long(a, ctx->n_cu, (hipStream_t)stream));
+    return IM_OK;
+}
+
+int im_expect_read_length(im_ctx* ctx, int32_t max_len)
+{
+    if (!ctx) return IM_E_ARG;
+    if (max_len > IM_MAX_READ) { set_err(ctx, "reads of %d bases: this build realigns reads of up to IM_MAX_READ=%d bases", max_len, IM_MAX_READ); return IM_E_UNSUPPORTED; }
+    int cur = ctx->expect_len.load(std::memory_order_relaxed);
+    while (max_len > cur && !ctx->expect_len.compare_exchange_weak(cur, max_len)) {}
     return IM_OK;
 }
 
@@ -587,10 +600,11 @@ int im_realign_batch(im_ctx* ctx, const im_params* params, const im_read_batch* 
         int32_t* h_anchor = (int32_t*)(hp + bases_bytes + off_bytes + 2 * i32_bytes);
         int32_t* h_range = (int32_t*)(hp + bases_bytes + off_bytes + 3 * i32_bytes);
         // re-pack the reads at 4-byte aligned offsets (device layout requirement), straight into pinned memory
-        int64_t pos = 0;
+        int64_t pos = 0, longest = 0;
         for (int32_t i = 0; i < m; i++) {
             const int64_t l = batch->base_off[c0 + i + 1] - batch->base_off[c0 + i];
             h_off[i] = pos; h_len[i] = (int32_t)l;
+            if (l > longest) longest = l;
             memcpy(h_bases + pos, batch->bases + batch->base_off[c0 + i], (size_t)l);
             const int64_t padded = (l + 3) & ~(int64_t)3;
             memset(h_bases + pos + l, 0, (size_t)(padded - l));
@@ -600,6 +614,7 @@ int im_realign_batch(im_ctx* ctx, const im_params* params, const im_read_batch* 
         memcpy(h_tid, batch->tid + c0, sizeof(int32_t) * (size_t)m);
         memcpy(h_anchor, batch->anchor + c0, sizeof(int32_t) * (size_t)m);
         memcpy(h_range, batch->range_max + c0, sizeof(int32_t) * (size_t)m);
+        if (longest > im::kShortRead && longest <= IM_MAX_READ) im_expect_read_length(ctx, (int32_t)longest);
         HIP_TRY(ctx, hipMemcpyAsync(dp, hp, in_bytes, hipMemcpyHostToDevice, ctx->copy_stream));
         HIP_TRY(ctx, hipEventRecord(ctx->ev_in[sl], ctx->copy_stream));
         HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_in[sl], 0));
@@ -625,7 +640,7 @@ int im_realign_batch(im_ctx* ctx, const im_params* params, const im_read_batch* 
         const int st = out[i].status;
         if (st == IM_ST_ABORT && worst == IM_OK) { worst = IM_E_ABORT; set_err(ctx, "read %d: the reference would abort on this input", i); }
         else if (st == IM_ST_OVERFLOW && worst == IM_OK) { worst = IM_E_OVERFLOW; set_err(ctx, "read %d: segment list longer than IM_MAX_OPS", i); }
-        else if (st == IM_ST_UNSUPPORTED && worst == IM_OK) { worst = IM_E_UNSUPPORTED; set_err(ctx, "read %d: longer than IM_MAX_READ=%d", i, IM_MAX_READ); }
+        else if (st == IM_ST_UNSUPPORTED && worst == IM_OK) { worst = IM_E_UNSUPPORTED; set_err(ctx, "read %d: longer than IM_MAX_READ=%d%s", i, IM_MAX_READ, params->numgaps ? ", or than 255 with numgaps > 0" : ""); }
     }
     return worst;
 }

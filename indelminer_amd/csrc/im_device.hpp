@@ -29,6 +29,8 @@ struct RefDev {
     int32_t         n_contigs;
 };
 
+constexpr int kShortRead = 255;      // longest read of the four-positions-per-lane kernels (im_realign.hip)
+
 struct RealignArgs {
     RefDev      ref;
     im_dev_batch batch;
@@ -79,6 +81,8 @@ hipError_t launch_depth_query_tiled(int32_t nq, const int32_t* beg, const int32_
 hipError_t launch_pack_reference(const uint8_t* ascii, uint64_t* pk, int64_t n_bases_padded,
                                  hipStream_t stream);
 hipError_t launch_realign(const RealignArgs& a, int n_cu, hipStream_t stream);
+// im_realign_long.hip: the reads of kShortRead + 1 .. IM_MAX_READ bases of the same batch (numgaps == 0)
+hipError_t launch_realign_long(const RealignArgs& a, int n_cu, hipStream_t stream);
 
 size_t cluster_scratch_bytes(int32_t n);
 hipError_t launch_cluster_sr(int32_t n_cap, const int32_t* n_dev,

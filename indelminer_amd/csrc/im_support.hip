@@ -51,8 +51,11 @@ inline size_t sw_lds_bytes(int cap) { return (size_t)cap * 13; }
 __device__ __forceinline__ int sw_shr1(int old, int v) { return __builtin_amdgcn_update_dpp(old, v, kDppWaveShr1S, 0xf, 0xf, false); }
 __device__ __forceinline__ uint32_t up8(uint32_t c) { return (c >= 'a' && c <= 'z') ? c - 32u : c; }
 
-// packed path statistics: aligned [0,12) | indels [12,24) | substitutions [24,32)
-constexpr uint32_t kStAligned = 1u, kStIndel = 1u << 12, kStSub = 1u << 24;
+// packed path statistics: aligned [0,10) | indels [10,21) | substitutions [21,32).  Statistics only run along cells of
+// positive score: with m matches (+2 each, m <= IM_MAX_READ = 1020) the substitutions and gap bases of such a path stay
+// below 2m <= 2040 < 2^11, and "aligned" counts read bases (<= 1020 < 2^10).
+constexpr uint32_t kStAligned = 1u, kStIndel = 1u << 10, kStSub = 1u << 21;
+static_assert(IM_MAX_READ <= 1023, "the packed statistics are sized for reads of up to 1023 bases");
 
 __global__ __launch_bounds__(64) void support_kernel(int32_t n_tasks,
                                                     const uint8_t* __restrict__ targets, const int64_t* __restrict__ t_off,
@@ -135,9 +138,9 @@ __global__ __launch_bounds__(64) void support_kernel(int32_t n_tasks,
             __syncthreads();
         }
         if (lane == 0) {
-            out[4 * task]     = (int32_t)(g_stats >> 24);
-            out[4 * task + 1] = (int32_t)((g_stats >> 12) & 0xFFFu);
-            out[4 * task + 2] = (int32_t)(g_stats & 0xFFFu) + 1;   // the NUL position is counted too (1392-1404)
+            out[4 * task]     = (int32_t)(g_stats >> 21);
+            out[4 * task + 1] = (int32_t)((g_stats >> 10) & 0x7FFu);
+            out[4 * task + 2] = (int32_t)(g_stats & 0x3FFu) + 1;   // the NUL position is counted too (1392-1404)
             out[4 * task + 3] = IM_ST_EVIDENCE;
         }
         __syncthreads();

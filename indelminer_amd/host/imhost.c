@@ -2466,12 +2466,24 @@ static void host_rg_stat(pgroup* G, const bam_record* b, int64_t rec_in_contig)
 }
 
 /* the host's share of fetch_func for one record: count it, serve the pair table, log what the flush points need */
+/* Reads beyond 255 bases take the realign kernels' second launch (im_expect_read_length, include/indelminer_amd.h): the context
+ * hears of the longest read so far the moment a walker meets it, i.e. before the group that holds it is launched. */
+static volatile int g_longest_read = 255;
+static void note_long_read(driver* d, int l_seq)
+{
+    if (l_seq > IM_MAX_READ || O.numgaps != 0) return;                 /* the kernel reports such a candidate, the run stops with its name */
+    if (im_expect_read_length(d->gpu, l_seq) != IM_OK) fatalf("im_expect_read_length: %s", im_last_error(d->gpu));
+    int cur = __atomic_load_n(&g_longest_read, __ATOMIC_RELAXED);
+    while (l_seq > cur && !__atomic_compare_exchange_n(&g_longest_read, &cur, l_seq, 1, __ATOMIC_RELAXED, __ATOMIC_RELAXED)) {}
+}
+
 static void pipe_host_record(driver* d, pgroup* G, const bam_record* b)
 {
     const int flag = b->flag;
     if (g_onepass) host_rg_stat(G, b, ((int64_t)(b->pos < 0 ? 0 : b->pos) << 32) | (G->n_rec - 1 - G->ctg[G->cur_ctg].rec0));
     if (flag & (0x100 | 0x200 | 0x400 | 0x800)) return;
     if ((flag & 0x1) == 0) return;
+    if (b->l_seq > g_longest_read) note_long_read(d, b->l_seq);
     const int is_aligned = (flag & 0x4) == 0, is_mate_aligned = (flag & 0x8) == 0;
     if (is_aligned && is_mate_aligned && b->tid != b->mtid) return;
     if (is_aligned && is_mate_aligned && (flag & 0x2) == 0) {
@@ -2798,7 +2810,7 @@ static void stage_run_group(ppipe* P, pgroup* G)
         if ((st == IM_ST_ABORT || st == IM_ST_OVERFLOW || st == IM_ST_UNSUPPORTED) && g_handoff_pool) pipeline_handoff();
         if (st == IM_ST_ABORT) fatalf("im_dev_realign: read %d: the reference would abort on this input", i);
         if (st == IM_ST_OVERFLOW) fatalf("im_dev_realign: read %d: segment list longer than IM_MAX_OPS", i);
-        if (st == IM_ST_UNSUPPORTED) fatalf("im_dev_realign: read %d: longer than IM_MAX_READ=%d", i, IM_MAX_READ);
+        if (st == IM_ST_UNSUPPORTED) fatalf("im_dev_realign: read %d: longer than IM_MAX_READ=%d", i, O.numgaps ? 255 : IM_MAX_READ);
     }
     if (G->sv[0]) { if (getenv("INDELMINER_TIDY_EXIT") || g_free_slabs) im_dev_free(g, G->sv[0]); G->sv[0] = NULL; }
     phase_time("results to the host");
@@ -4582,8 +4594,8 @@ static void print_help(FILE* file)
 
 static void free_range(void* p) { free(p); }
 
-/* The realignment kernels take reads of up to IM_MAX_READ bases (include/indelminer_amd.h; the reference has no such
- * bound, src/readaln.c:242-267).  A library of longer reads is turned away here, before any work, rather than at its
+/* The realignment kernels take reads of up to IM_MAX_READ bases, 255 with -g > 0 (include/indelminer_amd.h; the reference has
+ * no such bound, src/readaln.c:242-267).  A library of longer reads is turned away here, before any work, rather than at its
  * first long candidate somewhere inside a contig; a stray long read later on still stops the run with its name. */
 static void check_read_lengths(const char* bam_name)
 {
@@ -4593,9 +4605,10 @@ static void check_read_lengths(const char* bam_name)
     if (h) {
         bam_record b; memset(&b, 0, sizeof b);
         for (int i = 0; i < 20000 && bam_read_record(r, &b) == 1; i++)
-            if (b.l_seq > IM_MAX_READ && (b.flag & (0x100 | 0x800)) == 0)
+            if (b.l_seq > (O.numgaps ? 255 : IM_MAX_READ) && (b.flag & (0x100 | 0x800)) == 0)
                 fatalf("%s holds reads of %d bases (%s): this build realigns reads of up to %d bases (IM_MAX_READ, "
-                       "include/indelminer_amd.h)", bam_name, (int)b.l_seq, BAMR_QNAME(&b), IM_MAX_READ);
+                       "include/indelminer_amd.h)%s", bam_name, (int)b.l_seq, BAMR_QNAME(&b), O.numgaps ? 255 : IM_MAX_READ,
+                       O.numgaps ? " when -g is not 0" : "");
         free(b.data);
         bam_header_free(h);
     }

@@ -181,10 +181,12 @@ def test_support_sw_matches_oracle(gpu_ctx):
     L = ob.lib()
     rng = np.random.default_rng(5)
     targets, queries = [], []
-    for it in range(400):
+    for it in range(460):
         len1 = int(rng.choice([40, 120, 200, 260, 700, 1500]))
-        t = rng.choice(list(b"ACGT"), size=len1).astype(np.uint8)
         len2 = int(rng.choice([20, 64, 65, 100, 100, 128, 150, 255]))
+        if it >= 400:                  # reads of up to IM_MAX_READ bases: the packed path statistics (11 + 11 + 10 bits) at their widest
+            len1, len2 = int(rng.choice([1200, 2500, 4000])), int(rng.choice([256, 300, 600, 1020, 1020]))
+        t = rng.choice(list(b"ACGT"), size=len1).astype(np.uint8)
         p = int(rng.integers(0, max(1, len1 - len2 // 2)))
         q = t[p:p + len2].copy()
         if len(q) < len2:
@@ -198,7 +200,7 @@ def test_support_sw_matches_oracle(gpu_ctx):
             q = np.concatenate([q[:cut], rng.choice(list(b"ACGT"), size=d).astype(np.uint8), q[cut:]])[:len2]
         elif typ < 0.8:
             q = rng.choice(list(b"ACGT"), size=len2).astype(np.uint8)
-        sub = rng.random(len(q)) < rng.choice([0, 0.02, 0.1])
+        sub = rng.random(len(q)) < rng.choice([0, 0.02, 0.1, 0.3] if it >= 400 else [0, 0.02, 0.1])
         q[sub] = rng.choice(list(b"ACGT"), size=int(sub.sum())).astype(np.uint8)
         if it % 17 == 0:
             q[len(q) // 2] = ord("N")

@@ -59,7 +59,7 @@ def test_hip_matches_oracle_on_synthetic_golden_groups(gpu_ctx):
     for gi, grp in enumerate(groups):
         contig = grp["contig"].encode()
         gpu_ctx.set_reference([contig])
-        cases = [c for c in grp["cases"] if len(c["read"]) <= capi.MAX_READ]
+        cases = [c for c in grp["cases"] if len(c["read"]) <= (capi.MAX_READ if grp["params"].get("numgaps", 0) == 0 else capi.SHORT_READ)]
         out, bad = _run_cases(gpu_ctx, capi, capi.params(**grp["params"]), ob.params(**grp["params"]), contig, cases,
                               dump="gpurun_out/mismatch_synth_%d.txt" % gi)
         assert not bad, "%r: %d of %d differ, first: %r" % (grp["params"], len(bad), len(cases), bad[0][:2])
@@ -109,6 +109,61 @@ def test_hip_matches_oracle_on_wide_windows(gpu_ctx, k, g, Rm, maxdel):
     assert not bad, "%d of %d differ, first: %r" % (len(bad), len(cases), bad[0][:2])
     assert int((out["status"] == 1).sum()) > 300
     assert int(out["band"]["win_bytes"].max()) > 1920
+
+
+@pytest.mark.parametrize("k,L,Rm,maxdel", [(6, 300, 900, 1000), (6, 256, 700, 1000), (6, 1020, 2500, 3000), (5, 511, 1500, 6000), (9, 300, 900, 1000),
+                                           (13, 750, 2000, 1000), (6, 301, 5000, 9000)])
+def test_hip_long_reads_match_oracle(gpu_ctx, k, L, Rm, maxdel):
+    """Reads of 256 .. IM_MAX_READ bases: the second kernel (sixteen read positions per lane, 16-bit table offsets and vote
+    counters; indelminer_amd/csrc/im_realign_long.hip), mixed into one batch with reads of 100 bases that the first
+    kernel takes.  Windows of one to several histogram passes, k = 6 / 5 (direct table), 9 / 13 (hash)."""
+    from indelminer_amd import capi
+    contig, long_cases = _synthetic_batch(4000 + k + L, 500, clen=150000, L=L, Rm=Rm)
+    contig_again, short_cases = _synthetic_batch(4000 + k + L, 300, clen=150000, L=100, Rm=Rm)      # same seed, same contig
+    assert contig_again == contig
+    cases = long_cases + short_cases
+    random.Random(L).shuffle(cases)
+    gpu_ctx.set_reference([contig])
+    kw = dict(klength=k, numgaps=0, maxdelsize=maxdel)
+    out, bad = _run_cases(gpu_ctx, capi, capi.params(**kw), ob.params(**kw), contig, cases,
+                          dump="gpurun_out/mismatch_long_k%d_L%d.txt" % (k, L))
+    assert not bad, "%d of %d differ, first: %r" % (len(bad), len(cases), bad[0][:2])
+    is_long = np.array([len(c["read"]) > capi.SHORT_READ for c in cases])
+    assert int((out["status"][is_long] == 1).sum()) > 50 and int((out["status"][~is_long] == 1).sum()) > 50
+
+
+def test_hip_long_reads_fuzzed(gpu_ctx):
+    """lengths around the two kernels' border and the upper bound, short contigs (windows clipped at both ends), every k"""
+    from indelminer_amd import capi
+    rng = random.Random(31)
+    for trial in range(30):
+        k = rng.choice([2, 3, 4, 5, 6, 6, 7, 8, 10, 12, 15])
+        kw = dict(klength=k, numgaps=0, maxdelsize=rng.choice([50, 300, 1000, 2500]), ethreshold=rng.choice([1, 5, 10, 25]))
+        clen = rng.choice([1100, 2500, 20000])
+        contig = "".join(rng.choice("ACGT") for _ in range(clen))
+        cases = []
+        for _ in range(60):
+            L = min(rng.choice([100, 255, 256, 257, 300, 400, 512, 777, 1019, 1020]), clen - 10)
+            Rm = rng.choice([200, 705, 1500, 3000])
+            anchor = rng.choice([0, clen - 1, rng.randint(0, clen - 1)])
+            p = max(0, min(clen - L, anchor + rng.randint(-Rm, Rm)))
+            cut = rng.randint(1, max(1, L - 1))
+            d = rng.randint(1, 60)
+            typ = rng.random()
+            if typ < 0.45:
+                read = (contig[p:p + cut] + contig[p + cut + d:p + cut + d + (L - cut)])
+            elif typ < 0.8:
+                read = (contig[p:p + cut] + "".join(rng.choice("ACGT") for _ in range(d)) + contig[p + cut:p + L])[:L]
+            else:
+                read = contig[p:p + L]
+            read = "".join((rng.choice("ACGT") if rng.random() < 0.004 else ch) for ch in read)
+            if len(read) < 4:
+                read = contig[:4]
+            cases.append(dict(anchor=anchor, range_max=Rm, read=read))
+        gpu_ctx.set_reference([contig.encode()])
+        out, bad = _run_cases(gpu_ctx, capi, capi.params(**kw), ob.params(**kw), contig.encode(), cases,
+                              dump="gpurun_out/mismatch_longfuzz_%d.txt" % trial)
+        assert not bad, "%r: %d of %d differ, first: %r" % (kw, len(bad), len(cases), bad[0][:2])
 
 
 @pytest.mark.parametrize("seed", [11, 12, 13])
@@ -361,5 +416,9 @@ def test_unsupported_is_loud(gpu_ctx):
     with pytest.raises(capi.IMError) as ei:
         gpu_ctx.realign_batch(capi.params(numgaps=200), [b"ACGTACGTACGTACGTACGT"], [0], [100], [300])
     assert ei.value.code == capi.E_UNSUPPORTED
-    rc, out = gpu_ctx.realign_batch(capi.params(), [b"A" * 300], [0], [100], [300], allow=(capi.E_UNSUPPORTED,))
+    rc, out = gpu_ctx.realign_batch(capi.params(), [b"A" * (capi.MAX_READ + 1)], [0], [100], [300], allow=(capi.E_UNSUPPORTED,))
     assert rc == capi.E_UNSUPPORTED and out[0]["status"] == capi.ST_UNSUPPORTED
+    rc, out = gpu_ctx.realign_batch(capi.params(numgaps=2), [b"A" * 300], [0], [100], [300], allow=(capi.E_UNSUPPORTED,))
+    assert rc == capi.E_UNSUPPORTED and out[0]["status"] == capi.ST_UNSUPPORTED
+    with pytest.raises(capi.IMError):
+        gpu_ctx.expect_read_length(capi.MAX_READ + 1)

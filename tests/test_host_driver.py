@@ -610,23 +610,50 @@ def test_host_stale_pair_table_entries_pin_the_markers(tmp_path):
         assert _run(shim, [], d, ref="ref.fa", bam="aln.bam", env=env) == want, env
 
 
-def _long_read_dir(tmp_path):
+def _long_read_dir(tmp_path, read_len=300, ref_len=20_000, coverage=4, seed=5):
     from indelminer_amd import bamwrite, synth
-    refs, rd = synth.simulate(seed=5, ref_len=20_000, coverage=4, read_len=300, isize_mean=900, isize_min=700, isize_max=1100)
+    isz = 3 * read_len
+    refs, rd = synth.simulate(seed=seed, ref_len=ref_len, coverage=coverage, read_len=read_len, isize_mean=isz, isize_min=isz - 200, isize_max=isz + 200)
     contigs = [("ctg0", len(refs[0]))]
     bamwrite.write_fasta(str(tmp_path / "ref.fa"), contigs, refs)
     bamwrite.write_bam(str(tmp_path / "aln.bam"), contigs, rd)
-    (tmp_path / "cfg.txt").write_text("IL generic 700 1100\n")
+    (tmp_path / "cfg.txt").write_text("IL generic %d %d\n" % (isz - 200, isz + 200))
     return str(tmp_path)
 
 
+def _long_read_library(binary, tmp_path, envs=({},)):
+    """2 x 300 reads (the realign kernels' second lane layout, include/indelminer_amd.h im_expect_read_length): the reference has
+    no bound on the read length (src/readaln.c:242-267), the run must print what it prints"""
+    d = _long_read_dir(tmp_path, ref_len=150_000, coverage=20, seed=6)
+    want = _run(_build_shim(), ["-i", "cfg.txt"], d, ref="ref.fa", bam="aln.bam", env={"INDELMINER_PIPELINE": "host"})
+    assert want.count(b"SPLIT_READ") > 30
+    ref_bin = os.path.join(ROOT, "oracle", "_ref", "indelminer")
+    if os.path.exists(ref_bin):
+        assert _run(ref_bin, ["-i", "cfg.txt"], d, ref="ref.fa", bam="aln.bam") == want
+    for env in envs:
+        assert _run(binary, ["-i", "cfg.txt"], d, ref="ref.fa", bam="aln.bam", env=env) == want, env
+        assert _run(binary, ["-i", "cfg.txt", "-k", "9"], d, ref="ref.fa", bam="aln.bam", env=env) == \
+            _run(_build_shim(), ["-i", "cfg.txt", "-k", "9"], d, ref="ref.fa", bam="aln.bam", env={"INDELMINER_PIPELINE": "host"}), env
+
+
+def test_host_takes_a_2x300_library(tmp_path):
+    _long_read_library(_build_shim(), tmp_path, envs=({}, {"INDELMINER_PIECE_BYTES": "150000", "INDELMINER_WALKERS": "3"}))
+
+
+def _rejects_long_reads(binary, tmp_path):
+    """reads beyond IM_MAX_READ (1020; 255 with -g > 0): the reference has no bound (src/readaln.c:242-267), the kernels do --
+    the driver says so before any work instead of dying at the first long candidate inside a contig"""
+    (tmp_path / "a").mkdir(); (tmp_path / "b").mkdir()
+    d = _long_read_dir(tmp_path / "a", read_len=1100)
+    r = subprocess.run([binary, "-i", "cfg.txt", "ref.fa", "s=aln.bam"], cwd=d, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    assert r.returncode != 0 and b"IM_MAX_READ" in r.stderr and b"1100 bases" in r.stderr and r.stdout == b""
+    d = _long_read_dir(tmp_path / "b", read_len=300)
+    r = subprocess.run([binary, "-i", "cfg.txt", "-g", "2", "ref.fa", "s=aln.bam"], cwd=d, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    assert r.returncode != 0 and b"IM_MAX_READ" in r.stderr and b"300 bases" in r.stderr and b"-g is not 0" in r.stderr and r.stdout == b""
+
+
 def test_host_rejects_long_read_library_at_startup(tmp_path):
-    """reads beyond IM_MAX_READ (255): the reference has no bound (src/readaln.c:242-267), the kernels do -- the driver
-    says so before any work instead of dying at the first long candidate inside a contig"""
-    d = _long_read_dir(tmp_path)
-    r = subprocess.run([_build_shim(), "-i", "cfg.txt", "ref.fa", "s=aln.bam"], cwd=d, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
-    assert r.returncode != 0 and b"IM_MAX_READ" in r.stderr and b"300 bases" in r.stderr
-    assert r.stdout == b""
+    _rejects_long_reads(_build_shim(), tmp_path)
 
 
 def test_host_rejects_oversized_known_indel_at_startup(tmp_path):
@@ -707,9 +734,12 @@ def test_product_contigs_walked_in_pieces_and_region_runs(synth_small, synth_1mb
 
 @pytest.mark.gpu
 def test_product_rejects_long_read_library_at_startup(tmp_path):
-    d = _long_read_dir(tmp_path)
-    r = subprocess.run([_product(), "-i", "cfg.txt", "ref.fa", "s=aln.bam"], cwd=d, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
-    assert r.returncode != 0 and b"IM_MAX_READ" in r.stderr and r.stdout == b""
+    _rejects_long_reads(_product(), tmp_path)
+
+
+@pytest.mark.gpu
+def test_product_takes_a_2x300_library(tmp_path):
+    _long_read_library(_product(), tmp_path, envs=({}, {"INDELMINER_PIECE_BYTES": "150000", "INDELMINER_WALKERS": "3"}, {"INDELMINER_PIPELINE": "host"}))
 
 
 @pytest.mark.gpu
