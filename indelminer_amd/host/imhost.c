@@ -1792,13 +1792,16 @@ static void rg_order_push(const char* name, int32_t* range)
     g_rg_name[g_rg_n] = xstrdup(name); g_rg_range[g_rg_n] = range; g_rg_n++;
 }
 
+static uint32_t* g_meancov;         /* [n_targets] mean coverage: the RC lines of a config file, or observed (cov_means) */
+
 static void read_configuration(const char* filename, qhash* insertlengths, const bam_header* hdr)
 {
     /* src/shared.c:5-44.  An RC line's contig goes through must_find_hashtable_int on a 32-bin table of the BAM header's names
      * (src/indelminer.c:700-706) -- a name the header does not know ends the run there; the coverage itself is only ever
      * printed on stderr (src/indelminer.c:731). */
     qhash* id2chroms = qhash_new(5);
-    for (int32_t i = 0; i < hdr->n_targets; i++) qhash_add(id2chroms, hdr->target_name[i], (int)strlen(hdr->target_name[i]), NULL);
+    for (int32_t i = 0; i < hdr->n_targets; i++) qhash_add(id2chroms, hdr->target_name[i], (int)strlen(hdr->target_name[i]), (void*)(intptr_t)(i + 1));
+    if (!g_meancov) g_meancov = xcalloc((size_t)(hdr->n_targets > 0 ? hdr->n_targets : 1), sizeof(uint32_t));
     size_t cap = 2;
     char* line = xmalloc(cap);
     FILE* fp = fopen(filename, "r");
@@ -1813,12 +1816,90 @@ static void read_configuration(const char* filename, qhash* insertlengths, const
             rg_order_push(name, range);
         } else if (strncmp(line, "RC", 2) == 0) {
             if (sscanf(line, "RC %127s %u\n", name, &a) != 2) fatalf("error in reading the mean coverage: %s", line);
-            if (!qhash_lookup(id2chroms, name, (int)strlen(name))) fatalf("did not find %s in the hash", name);
+            qbin* hit = qhash_lookup(id2chroms, name, (int)strlen(name));
+            if (!hit) fatalf("did not find %s in the hash", name);
+            g_meancov[(intptr_t)hit->val - 1] = a;
         } else fatalf("unknown tag in configuration: %s", line);
     }
     free(line);
     fclose(fp);
     qhash_free(id2chroms, NULL);
+}
+
+/* ---- observed coverage per contig (estimate_average_coverage, src/bamoperations.c:88-147) ---------------------------
+ * The reference pileups every contig once more and prints floor(sum of the pileup's n / positions with n > 0) on stderr
+ * (src/indelminer.c:728-733); nothing else reads the number.  The pileup's n at a position is the number of records -- not
+ * unmapped, secondary, QC-fail or duplicate (BAM_DEF_MASK) -- whose reference span [pos, bam_calend) holds the position,
+ * deletions and skips included: the sum is the sum of the spans, the covered positions are the union of the spans.  Both
+ * come out of any walk of the records in file order: a running segment per walker, closed where the next record starts
+ * behind its end; the few segments of all walkers are merged at the end.  (Not kept: the pileup buffer's cap of 8000
+ * records starting at one position, bam_pileup.c.) */
+typedef struct { int32_t tid, beg, end; } covseg;
+typedef struct { int32_t nt; uint64_t* sum; covseg* seg; int64_t n, cap; int open; covseg cur; } covlist;
+static uint32_t* g_meancov;         /* [n_targets]: from the RC lines of a config file, or observed */
+
+static void cov_init(covlist* c, int32_t nt) { memset(c, 0, sizeof *c); c->nt = nt; c->sum = xcalloc((size_t)(nt > 0 ? nt : 1), sizeof(uint64_t)); }
+static void cov_push(covlist* c, covseg sg)
+{
+    if (c->n == c->cap) { c->cap = c->cap ? c->cap * 2 : 64; c->seg = xrealloc(c->seg, sizeof(covseg) * (size_t)c->cap); }
+    c->seg[c->n++] = sg;
+}
+static void cov_close(covlist* c) { if (c->open) { cov_push(c, c->cur); c->open = 0; } }
+static void cov_free(covlist* c) { free(c->sum); free(c->seg); memset(c, 0, sizeof *c); }
+static inline void cov_record(covlist* c, const bam_record* b)
+{
+    if (b->flag & (0x4 | 0x100 | 0x200 | 0x400)) return;
+    if (b->tid < 0 || b->tid >= c->nt || b->pos < 0) return;
+    const int32_t end = bam_record_end(b);
+    if (end <= b->pos) return;                                  /* no reference base: the pileup drops it unseen */
+    c->sum[b->tid] += (uint64_t)(end - b->pos);
+    if (c->open && c->cur.tid == b->tid && b->pos >= c->cur.beg && b->pos <= c->cur.end) { if (end > c->cur.end) c->cur.end = end; return; }
+    cov_close(c);
+    c->cur.tid = b->tid; c->cur.beg = b->pos; c->cur.end = end; c->open = 1;
+}
+static int cmp_covseg(const void* x, const void* y)
+{
+    const covseg* a = x; const covseg* b = y;
+    if (a->tid != b->tid) return a->tid < b->tid ? -1 : 1;
+    if (a->beg != b->beg) return a->beg < b->beg ? -1 : 1;
+    return 0;
+}
+/* sums[nt] and the segments of every walker -> g_meancov */
+static void cov_means(int32_t nt, const uint64_t* sums, covseg* seg, int64_t n)
+{
+    if (!g_meancov) g_meancov = xcalloc((size_t)(nt > 0 ? nt : 1), sizeof(uint32_t));
+    uint64_t* covered = xcalloc((size_t)(nt > 0 ? nt : 1), sizeof(uint64_t));
+    qsort(seg, (size_t)n, sizeof(covseg), cmp_covseg);
+    for (int64_t i = 0; i < n; ) {
+        const int32_t t = seg[i].tid;
+        int32_t beg = seg[i].beg, end = seg[i].end;
+        for (i++; i < n && seg[i].tid == t && seg[i].beg <= end; i++) if (seg[i].end > end) end = seg[i].end;
+        covered[t] += (uint64_t)(end - beg);
+    }
+    for (int32_t t = 0; t < nt; t++) if (covered[t]) g_meancov[t] = (uint32_t)floor((double)sums[t] * 1.0 / (double)covered[t]);
+    free(covered);
+}
+static void cov_means_of_lists(int32_t nt, covlist* const* ls, int n_lists)
+{
+    uint64_t* sums = xcalloc((size_t)(nt > 0 ? nt : 1), sizeof(uint64_t));
+    int64_t n = 0;
+    for (int i = 0; i < n_lists; i++) { cov_close(ls[i]); n += ls[i]->n; }
+    covseg* seg = xmalloc(sizeof(covseg) * (size_t)(n ? n : 1));
+    n = 0;
+    for (int i = 0; i < n_lists; i++) {
+        for (int32_t t = 0; t < nt; t++) sums[t] += ls[i]->sum[t];
+        if (ls[i]->n) memcpy(seg + n, ls[i]->seg, sizeof(covseg) * (size_t)ls[i]->n);
+        n += ls[i]->n;
+    }
+    cov_means(nt, sums, seg, n);
+    free(sums); free(seg);
+}
+static void cov_print_table(const bam_header* hdr)
+{
+    /* src/indelminer.c:728-733 */
+    fprintf(stderr, "\nChromosomeID\tMean-coverage\n-------------\t-----------\n");
+    for (int32_t i = 0; i < hdr->n_targets; i++) fprintf(stderr, "%d\t%u\n", i, g_meancov ? g_meancov[i] : 0u);
+    fprintf(stderr, "-------------\t-----------\n\n");
 }
 
 static void estimate_insertlengths(driver* d, int chromid)
@@ -1828,11 +1909,14 @@ static void estimate_insertlengths(driver* d, int chromid)
     if (!r) fatalf("error in opening the file %s", d->bam_name);
     bam_header* h = bam_header_load(r);
     bam_record b; memset(&b, 0, sizeof b);
+    covlist cov;
+    cov_init(&cov, h->n_targets);
     for (int32_t t = 0; t < h->n_targets; t++) {
         if (chromid != -1 && t != chromid) continue;
         bam_region_iter it;
         if (bam_region_begin(&it, r, d->idx, t, 0, h->target_len[t]) != 0) continue;
         while (bam_region_next(&it, &b) == 1) {
+            cov_record(&cov, &b);
             if ((b.flag & 0x1) == 0 || (b.flag & 0x4) || (b.flag & 0x2) == 0) continue;
             if (b.flag & (0x100 | 0x200 | 0x400)) continue;
             if (b.isize < 0) continue;
@@ -1856,6 +1940,7 @@ static void estimate_insertlengths(driver* d, int chromid)
         }
     }
     free(b.data);
+    { covlist* one = &cov; cov_means_of_lists(h->n_targets, &one, 1); cov_free(&cov); }
     bam_header_free(h);
     bgzf_close(r);
 }
@@ -2112,6 +2197,7 @@ typedef struct pgroup_s {
      * a contig: the walkers run ahead of one another), and the group's candidate arrays parked in a device allocation of their
      * own until the main thread stages them */
     rgstat_t rgs[MG_MAX_RG]; int n_rgs;
+    covlist cov;                        /* one-pass mode: the group's share of the observed coverage */
     uint8_t* npp_raw; int64_t npp_len, npp_cap; int64_t* npp_off; int32_t* npp_rec; int32_t n_npp, cap_npp;
     void* sv[10]; int32_t sv_n; int64_t sv_bytes; int32_t* sv_range;
     /* candidates as the device found them: record index + a host copy of the raw record */
@@ -2256,6 +2342,7 @@ static void group_free(pgroup* G)
     free(G->npp_raw); free(G->npp_off); free(G->npp_rec); free(G->dn); free(G->sn);
     free(G->res); free(G->s_cls); free(G->s_b1); free(G->s_b2); free(G->cons_sr); free(G->cons_pe); free(G->front); free(G->front_virt);
     free(G->cl_key); free(G->cl_first); free(G->cl_count); free(G->order); free(G->cl_sorted); free(G->ev_cache);
+    free(G->cov.sum); free(G->cov.seg);
     memset(G, 0, sizeof *G);
 }
 
@@ -2480,7 +2567,11 @@ static void note_long_read(driver* d, int l_seq)
 static void pipe_host_record(driver* d, pgroup* G, const bam_record* b)
 {
     const int flag = b->flag;
-    if (g_onepass) host_rg_stat(G, b, ((int64_t)(b->pos < 0 ? 0 : b->pos) << 32) | (G->n_rec - 1 - G->ctg[G->cur_ctg].rec0));
+    if (g_onepass) {
+        host_rg_stat(G, b, ((int64_t)(b->pos < 0 ? 0 : b->pos) << 32) | (G->n_rec - 1 - G->ctg[G->cur_ctg].rec0));
+        if (!G->cov.sum) cov_init(&G->cov, d->hdr->n_targets);
+        cov_record(&G->cov, b);
+    }
     if (flag & (0x100 | 0x200 | 0x400 | 0x800)) return;
     if ((flag & 0x1) == 0) return;
     if (b->l_seq > g_longest_read) note_long_read(d, b->l_seq);
@@ -3247,8 +3338,9 @@ static int mg_rg_index(mg_rg* rgs, int* pn, const char* rgname)
  * counted reads, and the log of the records that may go through the pair table.  out = the rank's exchange buffer (NULL:
  * statistics only).  Thread-safe: everything it touches is the caller's.
  * The contig's block: { tid, counted (2 words), events, bytes of events }, then per event { pos, |isize|, record index,
- * first-mate flag | read group << 8 | name length << 16 } and the name with its NUL, padded to a word. */
-static void prewalk_piece(const driver* d, bgzf_reader* r, int32_t t, int32_t beg, int32_t end, int estimate, mg_rg* rgs, int* pn_rg, mgbuf* out)
+ * first-mate flag | read group << 8 | name length << 16 } and the name with its NUL, padded to a word.
+ * cov (NULL: not wanted): the piece's share of the observed coverage (estimate_average_coverage). */
+static void prewalk_piece(const driver* d, bgzf_reader* r, int32_t t, int32_t beg, int32_t end, int estimate, mg_rg* rgs, int* pn_rg, mgbuf* out, covlist* cov)
 {
     bam_region_iter it;
     size_t head_at = 0;
@@ -3261,6 +3353,7 @@ static void prewalk_piece(const driver* d, bgzf_reader* r, int32_t t, int32_t be
     while (bam_region_next(&it, &b) == 1) {
         const int flag = b.flag;
         const int32_t this_rec = rec++;
+        if (cov) cov_record(cov, &b);
         if (estimate && (flag & 0x1) && !(flag & 0x4) && (flag & 0x2) && !(flag & (0x100 | 0x200 | 0x400)) &&
             b.isize >= 0 && b.mpos - b.pos >= 0 && b.isize >= b.mpos - b.pos) {
             const uint8_t* rg = bam_aux_find(&b, "RG");
@@ -3300,7 +3393,7 @@ static void prewalk_piece(const driver* d, bgzf_reader* r, int32_t t, int32_t be
 
 /* The pre-walk over the pieces this rank walks (mg_plan_walks), spread over threads: the rank's log, ready for the exchange --
  * header, read groups, then one block per piece in file order. */
-typedef struct { const driver* d; const piece_t* pieces; const int32_t* mine; int n_mine, t0, step, estimate; mg_rg rgs[MG_MAX_RG]; int n_rg; mgbuf* out; } prewalk_job;
+typedef struct { const driver* d; const piece_t* pieces; const int32_t* mine; int n_mine, t0, step, estimate; mg_rg rgs[MG_MAX_RG]; int n_rg; mgbuf* out; covlist cov; } prewalk_job;
 static void* prewalk_thread(void* arg)
 {
     prewalk_job* j = arg;
@@ -3311,7 +3404,7 @@ static void* prewalk_thread(void* arg)
     for (int k = j->t0; k < j->n_mine; k += j->step) {
         const piece_t* pc = &j->pieces[j->mine[k]];
         const size_t at = j->out[k].n;
-        prewalk_piece(j->d, r, pc->tid, pc->beg, pc->end, j->estimate, j->rgs, &j->n_rg, &j->out[k]);
+        prewalk_piece(j->d, r, pc->tid, pc->beg, pc->end, j->estimate, j->rgs, &j->n_rg, &j->out[k], j->estimate ? &j->cov : NULL);
         ((int32_t*)(j->out[k].p + at))[0] = pc->index;
         /* the read-group indices of the events are this thread's: the main thread maps them onto the rank's list (mg_prewalk) */
     }
@@ -3341,6 +3434,7 @@ static void mg_prewalk(mgpu* m, driver* d, int estimate, mgbuf* out, const piece
     for (int i = 0; i < nt; i++) {
         jobs[i].d = d; jobs[i].pieces = pieces; jobs[i].mine = mine; jobs[i].n_mine = n_mine; jobs[i].t0 = i; jobs[i].step = nt;
         jobs[i].estimate = estimate; jobs[i].out = pieces_out;
+        cov_init(&jobs[i].cov, d->hdr->n_targets);
         if (pthread_create(&th[i], NULL, prewalk_thread, &jobs[i]) != 0) fatalf("cannot start a pre-walk thread");
     }
     for (int i = 0; i < nt; i++) pthread_join(th[i], NULL);
@@ -3375,6 +3469,24 @@ static void mg_prewalk(mgpu* m, driver* d, int estimate, mgbuf* out, const piece
         }
         memcpy(mgbuf_take(out, pieces_out[k].n), pieces_out[k].p, pieces_out[k].n);
         free(pieces_out[k].p);
+    }
+    {
+        /* the rank's share of the observed coverage (no config file): { segments, per contig the span sum (2 words) }, the segments */
+        const int32_t ntg = d->hdr->n_targets;
+        int64_t nseg = 0;
+        for (int i = 0; i < nt; i++) { cov_close(&jobs[i].cov); nseg += jobs[i].cov.n; }
+        int32_t* cw = mgbuf_take(out, 4 * (1 + 2 * (size_t)ntg + 3 * (size_t)nseg));
+        cw[0] = (int32_t)nseg;
+        for (int32_t t = 0; t < ntg; t++) {
+            uint64_t sm = 0;
+            for (int i = 0; i < nt; i++) sm += jobs[i].cov.sum[t];
+            cw[1 + 2 * t] = (int32_t)(uint32_t)sm; cw[2 + 2 * t] = (int32_t)(uint32_t)(sm >> 32);
+        }
+        int32_t* sg = cw + 1 + 2 * (size_t)ntg;
+        for (int i = 0; i < nt; i++) {
+            for (int64_t k = 0; k < jobs[i].cov.n; k++) { *sg++ = jobs[i].cov.seg[k].tid; *sg++ = jobs[i].cov.seg[k].beg; *sg++ = jobs[i].cov.seg[k].end; }
+            cov_free(&jobs[i].cov);
+        }
     }
     int32_t* w = (int32_t*)out->p;
     w[0] = MG_MAGIC; w[1] = n_rg; w[2] = n_mine; w[3] = (int32_t)(out->n & 0xffffffff); w[4] = (int32_t)((uint64_t)out->n >> 32);
@@ -3435,7 +3547,7 @@ static int32_t* rg_table_enter(driver* d, const mg_rg* g)
 
 /* estimate_insertlengths (src/bamoperations.c:15-86) with the contigs spread over threads: the pass is pure decode + a
  * min / max per read group, so contigs are independent and the per-thread lists merge exactly (rg_table_enter) */
-typedef struct { const driver* d; const piece_t* pieces; int n_pieces, t0, step; mg_rg rgs[MG_MAX_RG]; int n_rg; } est_job;
+typedef struct { const driver* d; const piece_t* pieces; int n_pieces, t0, step; mg_rg rgs[MG_MAX_RG]; int n_rg; covlist cov; } est_job;
 static void* est_thread(void* arg)
 {
     est_job* j = arg;
@@ -3443,7 +3555,7 @@ static void* est_thread(void* arg)
     if (!r) fatalf("error in opening the file %s", j->d->bam_name);
     bgzf_set_workers(r, 0);
     bam_header* h = bam_header_load(r);
-    for (int i = j->t0; i < j->n_pieces; i += j->step) prewalk_piece(j->d, r, j->pieces[i].tid, j->pieces[i].beg, j->pieces[i].end, 1, j->rgs, &j->n_rg, NULL);
+    for (int i = j->t0; i < j->n_pieces; i += j->step) prewalk_piece(j->d, r, j->pieces[i].tid, j->pieces[i].beg, j->pieces[i].end, 1, j->rgs, &j->n_rg, NULL, &j->cov);
     bam_header_free(h);
     bgzf_close(r);
     return NULL;
@@ -3466,6 +3578,7 @@ static void estimate_insertlengths_threads(driver* d, const piece_t* pieces, int
     pthread_t* th = xmalloc(sizeof(pthread_t) * (size_t)nt);
     for (int i = 0; i < nt; i++) {
         jobs[i].d = d; jobs[i].pieces = pieces; jobs[i].n_pieces = n_pieces; jobs[i].t0 = i; jobs[i].step = nt;
+        cov_init(&jobs[i].cov, d->hdr->n_targets);
         if (pthread_create(&th[i], NULL, est_thread, &jobs[i]) != 0) fatalf("cannot start an estimation thread");
     }
     mg_rg* all = xcalloc((size_t)nt * MG_MAX_RG, sizeof(mg_rg));
@@ -3474,6 +3587,13 @@ static void estimate_insertlengths_threads(driver* d, const piece_t* pieces, int
     mg_rg* merged = xcalloc((size_t)(n_all ? n_all : 1), sizeof(mg_rg));
     const int n = merge_rgs(all, n_all, merged);
     for (int j = 0; j < n; j++) rg_table_enter(d, &merged[j]);
+    {
+        covlist** ls = xmalloc(sizeof(covlist*) * (size_t)nt);
+        for (int i = 0; i < nt; i++) ls[i] = &jobs[i].cov;
+        cov_means_of_lists(d->hdr->n_targets, ls, nt);
+        for (int i = 0; i < nt; i++) cov_free(&jobs[i].cov);
+        free(ls);
+    }
     free(all); free(merged); free(jobs); free(th);
 }
 
@@ -3496,7 +3616,7 @@ static void mg_exchange(mgpu* m, driver* d, int estimate, const piece_t* pieces,
         const int64_t fsize = stat(d->bam_name, &sb) == 0 ? (int64_t)sb.st_size : 0;
         const char* e = getenv("INDELMINER_MG_LOG_BYTES");
         int64_t c = e ? atoll(e) : fsize / 64;
-        const int64_t least = 4 * (MG_HEAD_WORDS + (int64_t)MG_MAX_RG * MG_RG_WORDS) + 20 * ((int64_t)n_pieces + 1);
+        const int64_t least = 4 * (MG_HEAD_WORDS + (int64_t)MG_MAX_RG * MG_RG_WORDS) + 20 * ((int64_t)n_pieces + 1) + 4 * (1 + 2 * (int64_t)nt);
         if (c < least) c = least;
         if (!e && c < (4 << 20)) c = 4 << 20;
         cap = ((size_t)c + 255) & ~(size_t)255;
@@ -3542,6 +3662,7 @@ static void mg_exchange(mgpu* m, driver* d, int estimate, const piece_t* pieces,
     }
     /* where each piece's block lies, and range[1] of every (rank, read group) through the table's own look-up */
     const int32_t** block = xcalloc((size_t)n_pieces + 1, sizeof(int32_t*));
+    const int32_t** cov_at = xcalloc((size_t)m->world, sizeof(int32_t*));
     int32_t* rmax = xmalloc(sizeof(int32_t) * (size_t)m->world * MG_MAX_RG);
     for (int rk = 0; rk < m->world; rk++) {
         const int32_t* a = (const int32_t*)(all + (size_t)rk * cap);
@@ -3558,7 +3679,25 @@ static void mg_exchange(mgpu* m, driver* d, int estimate, const piece_t* pieces,
             block[at[0]] = at;
             at += 5 + at[4] / 4;
         }
+        cov_at[rk] = at;
     }
+    if (estimate) {
+        /* every rank's span sums and covered segments -> the coverage table, the same on all ranks (rank 0 prints it) */
+        uint64_t* sums = xcalloc((size_t)nt + 1, sizeof(uint64_t));
+        int64_t nseg = 0;
+        for (int rk = 0; rk < m->world; rk++) nseg += cov_at[rk][0];
+        covseg* seg = xmalloc(sizeof(covseg) * (size_t)(nseg ? nseg : 1));
+        nseg = 0;
+        for (int rk = 0; rk < m->world; rk++) {
+            const int32_t* cw = cov_at[rk];
+            for (int32_t t = 0; t < nt; t++) sums[t] += (uint64_t)(uint32_t)cw[1 + 2 * t] | ((uint64_t)(uint32_t)cw[2 + 2 * t] << 32);
+            const int32_t* sg = cw + 1 + 2 * (size_t)nt;
+            for (int32_t k = 0; k < cw[0]; k++, sg += 3) { seg[nseg].tid = sg[0]; seg[nseg].beg = sg[1]; seg[nseg].end = sg[2]; nseg++; }
+        }
+        cov_means(nt, sums, seg, nseg);
+        free(sums); free(seg);
+    }
+    free(cov_at);
     /* the replay: every piece's events through ONE pair table, in file order, as the single run serves it */
     m->piece_prefix = xcalloc((size_t)n_pieces + 1, sizeof(int64_t));
     m->floor = xmalloc(sizeof(int) * ((size_t)nt + 1));
@@ -4327,6 +4466,14 @@ static void run_pipeline(driver* d, walkpool_t* o)
             for (int j = 0; j < n; j++) rg_table_enter(d, &merged[j]);
             for (int j = 0; j < g_rg_n; j++) fprintf(stderr, "%s\t%d\t%d\n", g_rg_name[j], g_rg_range[j][0], g_rg_range[j][1]);
             free(all); free(merged);
+            {
+                covlist** ls = xmalloc(sizeof(covlist*) * (size_t)(o->n_claims ? o->n_claims : 1));
+                int nl = 0;
+                for (int ci = 0; ci < o->n_claims; ci++) if (o->claims[ci].G->cov.sum) ls[nl++] = &o->claims[ci].G->cov;
+                cov_means_of_lists(d->hdr->n_targets, ls, nl);
+                free(ls);
+                cov_print_table(d->hdr);
+            }
             pipe_global_init(d);
             /* every group's candidates get their range[1], the groups spread over threads */
             int nt = o->nw > 1 ? o->nw : 1;
@@ -4815,6 +4962,7 @@ int main(int argc, char** argv)
         for (qbin* it = d.insertlengths->bins[i]; it; it = it->next)
             fprintf(stderr, "%s\t%d\t%d\n", it->name, ((int32_t*)it->val)[0], ((int32_t*)it->val)[1]);
     fprintf(stderr, "----------\t---------\t---------\n\n");
+    if (!g_onepass && !(g_mg && O.configfile == NULL)) cov_print_table(d.hdr);      /* one-pass and multi-rank estimates: printed when every record has been seen */
     timestamp("Read insertlengths for the BAM file");
     phase_time("open BAM, index, insert lengths");
 
@@ -4850,6 +4998,7 @@ int main(int argc, char** argv)
         if (O.configfile == NULL && mg.rank == 0) {
             fprintf(stderr, "\nRead-group\tMin-value\tMax-value (estimated over all ranks' contigs)\n");
             for (int j = 0; j < g_rg_n; j++) fprintf(stderr, "%s\t%d\t%d\n", g_rg_name[j], g_rg_range[j][0], g_rg_range[j][1]);
+            cov_print_table(d.hdr);
         }
     }
     if (use_pipeline) run_pipeline(&d, pool);

@@ -656,6 +656,58 @@ def test_host_rejects_long_read_library_at_startup(tmp_path):
     _rejects_long_reads(_build_shim(), tmp_path)
 
 
+def _coverage_dir(tmp_path):
+    """uneven coverage: a stretch of contig 0 without reads, contig 2 thinned to a third, contig 3 empty"""
+    import numpy as np
+    from indelminer_amd import bamwrite, rawrec, synth
+    refs, rd = synth.simulate(seed=23, ref_len=120_000, coverage=14, n_contigs=4, big_every=4)
+    rng = np.random.default_rng(3)
+    drop = ((rd.tid == 0) & (rd.pos >= 40_000) & (rd.pos < 60_000)) | ((rd.tid == 2) & (rng.random(rd.n) < 0.67)) | (rd.tid == 3)
+    _apply_keep(rd, ~drop)
+    contigs = [("ctg%d" % i, len(r)) for i, r in enumerate(refs)]
+    bamwrite.write_fasta(str(tmp_path / "ref.fa"), contigs, refs)
+    rawrec.write_bam_fast(str(tmp_path / "aln.bam"), contigs, rd)
+    return str(tmp_path)
+
+
+def _coverage_table(stderr):
+    import re
+    m = re.search(rb"ChromosomeID\tMean-coverage\n-+\t-+\n((?:\d+\t\d+\n)*)-+\t-+\n", stderr)
+    return m.group(1) if m else None
+
+
+def _stderr_of(binary, flags, cwd, env=None):
+    e = dict(os.environ)
+    e.update(env or {})
+    r = subprocess.run([binary] + flags + ["ref.fa", "s=aln.bam"], cwd=cwd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=e)
+    assert r.returncode == 0, r.stderr.decode()[-2000:]
+    return r.stderr
+
+
+def _coverage_tables(binary, tmp_path, envs):
+    """the mean-coverage table the reference prints on stderr when it has no config file (estimate_average_coverage,
+    src/bamoperations.c:88-147: a pileup of every contig): here the sum of the records' reference spans over the length of their
+    union, collected by whichever pass sees every record -- the table must be the reference's in every mode"""
+    d = _coverage_dir(tmp_path)
+    ref_bin = os.path.join(ROOT, "oracle", "_ref", "indelminer")
+    want = _coverage_table(_stderr_of(ref_bin if os.path.exists(ref_bin) else _build_shim(), [], d, env={"INDELMINER_PIPELINE": "host"}))
+    rows = [int(l.split(b"\t")[1]) for l in want.splitlines()]
+    assert len(rows) == 4 and rows[3] == 0 and 0 < rows[2] < rows[1] and rows[0] > 0, rows
+    for env in envs:
+        assert _coverage_table(_stderr_of(binary, [], d, env=env)) == want, env
+    if os.path.exists(ref_bin):
+        assert _coverage_table(_stderr_of(binary, ["-c", "ctg2"], d)) == _coverage_table(_stderr_of(ref_bin, ["-c", "ctg2"], d))
+    (tmp_path / "cfg.txt").write_text("IL generic 300 700\nRC ctg2 41\nRC ctg0 7\n")
+    assert _coverage_table(_stderr_of(binary, ["-i", "cfg.txt"], d)) == b"0\t7\n1\t0\n2\t41\n3\t0\n"
+    return d, want
+
+
+def test_host_coverage_table(tmp_path):
+    _coverage_tables(_build_shim(), tmp_path, ({}, {"INDELMINER_ESTIMATE_SERIAL": "1"}, {"INDELMINER_ONEPASS": "1"}, {"INDELMINER_PIPELINE": "host"},
+                                              {"INDELMINER_PIECE_BYTES": "60000", "INDELMINER_WALKERS": "3"},
+                                              {"INDELMINER_PIECE_BYTES": "60000", "INDELMINER_WALKERS": "3", "INDELMINER_ONEPASS": "1"}))
+
+
 def test_host_rejects_oversized_known_indel_at_startup(tmp_path):
     """annotate mode realigns reads against windows of up to IM_MAX_SW_TARGET bytes: a split-read deletion of 2500 bases in
     the variant file is named at startup (the reference's own line buffers are sized by -s, src/variant.c:853-856)"""
@@ -735,6 +787,11 @@ def test_product_contigs_walked_in_pieces_and_region_runs(synth_small, synth_1mb
 @pytest.mark.gpu
 def test_product_rejects_long_read_library_at_startup(tmp_path):
     _rejects_long_reads(_product(), tmp_path)
+
+
+@pytest.mark.gpu
+def test_product_coverage_table(tmp_path):
+    _coverage_tables(_product(), tmp_path, ({}, {"INDELMINER_ONEPASS": "1"}, {"INDELMINER_PIECE_BYTES": "60000", "INDELMINER_WALKERS": "3"}))
 
 
 @pytest.mark.gpu

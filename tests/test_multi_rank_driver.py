@@ -45,7 +45,7 @@ def _rank(rank, world, port, binary, flags, cwd, ref, bam, q):
     dist.destroy_process_group()
 
 
-def _run_world(world, flags, cwd, ref, bam):
+def _run_world(world, flags, cwd, ref, bam, with_stderr=False):
     binary = th._build_shim()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
@@ -57,7 +57,7 @@ def _run_world(world, flags, cwd, ref, bam):
     for p in procs:
         p.join(timeout=60)
     assert ok == 1, err.decode()
-    return out
+    return (out, err) if with_stderr else out
 
 
 @pytest.mark.parametrize("flags,golden", [(["-i", "cfg.txt"], "synth_2ctg_composite"), ([], "synth_2ctg_composite_noconfig")])
@@ -213,3 +213,11 @@ def test_contigs_in_pieces_over_ranks_with_markers_pinned_low(tmp_path):
         assert got == want, world
     det = th._run(th._build_shim(), ["-o", "detailed"], d, ref="ref.fa", bam="aln.bam", env={"INDELMINER_PIPELINE": "host"})
     assert _with_env({"INDELMINER_PIECE_BYTES": "200000"}, lambda: _run_world(2, ["-o", "detailed"], d, "ref.fa", "aln.bam")) == det
+
+
+def test_ranks_coverage_table(tmp_path):
+    """no config file: every rank's span sums and covered segments ride in the one all-gather; rank 0 prints the reference's table"""
+    d, want = th._coverage_tables(th._build_shim(), tmp_path, ())
+    for world, env in ((2, {}), (3, {"INDELMINER_PIECE_BYTES": "60000"})):
+        out, err = _with_env(env, lambda: _run_world(world, [], d, "ref.fa", "aln.bam", with_stderr=True))
+        assert th._coverage_table(err) == want, (world, err[-800:])
