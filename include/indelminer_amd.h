@@ -231,6 +231,14 @@ int im_dev_realign(im_ctx* ctx, const im_params* params,
  * Returns IM_E_UNSUPPORTED for max_len > IM_MAX_READ. */
 int im_expect_read_length(im_ctx* ctx, int32_t max_len);
 
+/* The results' trip to the host.  attempt_pe_alignment returns NULL for most candidates (src/alignment.c:764-799), and the
+ * caller reads a candidate's 512-byte record only when it holds realigned evidence (src/indelminer.c:494-502): this packs the
+ * records with status == IM_ST_EVIDENCE and n_ev > 0 into compact[] (capacity n records, order unspecified) and leaves per
+ * read its status in status[i] and its place in compact[] -- or -1 -- in slot[i]; *count (a device int32, set by the call)
+ * receives the number of packed records.  n_dev: device-resident batch size (NULL: n).  Asynchronous. */
+int im_dev_compact_results(im_ctx* ctx, const im_read_result* res, int32_t n, const int32_t* n_dev,
+                           int32_t* status, int32_t* slot, im_read_result* compact, int32_t* count, void* stream);
+
 /* Bytes of device scratch im_dev_cluster_sr needs for n evidence records. */
 size_t im_dev_cluster_scratch_bytes(int32_t n);
 

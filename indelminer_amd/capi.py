@@ -119,6 +119,7 @@ def lib():
                                     C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_int32)]
         L.im_dev_realign.argtypes = [C.c_void_p, C.POINTER(Params), C.POINTER(DevBatch), C.c_void_p]
         L.im_expect_read_length.argtypes = [C.c_void_p, C.c_int32]
+        L.im_dev_compact_results.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         L.im_dev_cluster_scratch_bytes.restype = C.c_size_t
         L.im_dev_cluster_scratch_bytes.argtypes = [C.c_int32]
         L.im_dev_gather_scratch_bytes.restype = C.c_size_t

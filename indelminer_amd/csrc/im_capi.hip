@@ -258,6 +258,15 @@ static int dev_realign(im_ctx* ctx, const im_params* params, const im_dev_batch*
     return IM_OK;
 }
 
+int im_dev_compact_results(im_ctx* ctx, const im_read_result* res, int32_t n, const int32_t* n_dev,
+                           int32_t* status, int32_t* slot, im_read_result* compact, int32_t* count, void* stream)
+{
+    if (!ctx || n < 0 || !count || (n > 0 && (!res || !status || !slot || !compact))) return IM_E_ARG;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, im::launch_compact_results(res, n, n_dev, status, slot, compact, count, ctx->n_cu, (hipStream_t)stream));
+    return IM_OK;
+}
+
 int im_expect_read_length(im_ctx* ctx, int32_t max_len)
 {
     if (!ctx) return IM_E_ARG;

@@ -84,6 +84,10 @@ hipError_t launch_realign(const RealignArgs& a, int n_cu, hipStream_t stream);
 // im_realign_long.hip: the reads of kShortRead + 1 .. IM_MAX_READ bases of the same batch (numgaps == 0)
 hipError_t launch_realign_long(const RealignArgs& a, int n_cu, hipStream_t stream);
 
+// im_results.hip
+hipError_t launch_compact_results(const im_read_result* res, int32_t n_cap, const int32_t* n_dev, int32_t* status, int32_t* slot,
+                                  im_read_result* compact, int32_t* count, int n_cu, hipStream_t stream);
+
 size_t cluster_scratch_bytes(int32_t n);
 hipError_t launch_cluster_sr(int32_t n_cap, const int32_t* n_dev,
                              const int32_t* cls, const int32_t* b1, const int32_t* b2,

@@ -590,9 +590,69 @@ void bam_record_view(const uint8_t* rec, int32_t len, bam_record* view)
     view->m_data = 0;
 }
 
+/* A record that lies whole in the inflated block at hand (all but the one or two that straddle a block's end) is taken
+ * from the block's buffer in place: no call per field.  Returns the delivered size, 0 when the slow path has to take it,
+ * -2 when it does not fit cap (nothing consumed). */
+static inline int32_t record_from_block(bam_region_iter* it, uint8_t* dst, int64_t cap)
+{
+    bgzf_reader* r = it->r;
+    const int32_t avail = r->ulen - r->upos;
+    if (avail < 36) return 0;
+    const uint8_t* p = r->ubuf + r->upos;
+    const int32_t bs = (int32_t)((uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16) | ((uint32_t)p[3] << 24));
+    if (bs < 32 || bs > avail - 4) return 0;
+    if ((int64_t)bs > cap) return -2;
+    p += 4;
+    int32_t out = bs;
+    if (it->drop_qual) {
+        const int32_t l_qname = p[8], n_cigar = p[12] | (p[13] << 8);
+        const int32_t l_seq = (int32_t)((uint32_t)p[16] | ((uint32_t)p[17] << 8) | ((uint32_t)p[18] << 16) | ((uint32_t)p[19] << 24));
+        const int64_t head = 32 + (int64_t)l_qname + 4 * (int64_t)n_cigar;
+        const int64_t packed = ((int64_t)l_seq + 1) >> 1;
+        int strip = l_seq >= 0 && head + packed + l_seq <= bs;
+        if (strip) {
+            int64_t q = 0;
+            const uint8_t* cig = p + 32 + l_qname;
+            for (int32_t k = 0; k < n_cigar; k++) {
+                const uint32_t cw = bamr_cigar_at(cig, k), op = cw & 15u;
+                if (op == 0 || op == 1 || op == 4 || op == 7 || op == 8) q += cw >> 4;
+            }
+            strip = q <= l_seq;             /* a CIGAR that reaches past l_seq has the bytes behind the bases looked at (new_readaln) */
+        }
+        if (strip) {
+            memcpy(dst, p, (size_t)(head + packed));
+            memcpy(dst + head + packed, p + head + packed + l_seq, (size_t)(bs - head - packed - l_seq));
+            dst[10] = 0xFF; dst[11] = 0xFF;
+            out = bs - l_seq;
+        } else {
+            memcpy(dst, p, (size_t)bs);
+            if (dst[10] == 0xFF && dst[11] == 0xFF) dst[10] = 0xFE;
+        }
+    } else {
+        memcpy(dst, p, (size_t)bs);
+        if (dst[10] == 0xFF && dst[11] == 0xFF) dst[10] = 0xFE;        /* not a bin of any record: it must not read as the marker */
+    }
+    r->upos += 4 + bs;
+    return out;
+}
+
 int bam_region_next_raw(bam_region_iter* it, uint8_t* dst, int64_t cap, int32_t* len_out, bam_record* view)
 {
     while (!it->done) {
+        if (it->pending_size == 0) {
+            const int32_t fast = record_from_block(it, dst, cap);
+            if (fast == -2) return -2;
+            if (fast > 0) {
+                bam_record_view(dst, fast, view);
+                if (view->tid != it->tid || view->pos >= it->end) { it->done = 1; return 0; }
+                if (32 + (int64_t)view->l_qname + 4 * (int64_t)view->n_cigar > fast) { it->done = 1; return -1; }
+                const uint32_t rbeg = (uint32_t)view->pos;
+                if (it->by_start) { if (rbeg >= (uint32_t)it->beg && rbeg < (uint32_t)it->end) { *len_out = fast; return 1; } continue; }
+                const uint32_t rend = view->n_cigar ? (uint32_t)bam_record_end(view) : (uint32_t)view->pos + 1u;
+                if (rend > (uint32_t)it->beg && rbeg < (uint32_t)it->end) { *len_out = fast; return 1; }
+                continue;
+            }
+        }
         if (it->pending_size == 0) {
             uint8_t c[4];
             const int64_t got = bgzf_read(it->r, c, 4);

@@ -2210,7 +2210,8 @@ typedef struct pgroup_s {
     int seq;                                /* position of the group in the run (the `when` of what it leaves pending) */
     int from_package;                       /* multi-GPU: walked by another rank (its flush points came with it) */
     /* what came back from the stage */
-    im_read_result* res; int32_t *s_cls, *s_b1, *s_b2, *cons_sr, *cons_pe;
+    im_read_result* res; int32_t* res_slot;     /* the realigned records that hold evidence, packed; per own candidate its place there or -1 */
+    int32_t *s_cls, *s_b1, *s_b2, *cons_sr, *cons_pe;
     int32_t n_cl, n_nodes; int32_t *cl_key, *cl_first, *cl_count, *order, *cl_sorted;
     evidence_t** ev_cache;
     /* groups of one contig are freed together, when the last of them has been replayed (pending evidence points back at them) */
@@ -2225,6 +2226,7 @@ typedef struct {
     /* device arrays of the group (growable) */
     int32_t cap_cand; int64_t cap_bases; int32_t cap_pe, cap_fl;
     void *bases, *boff, *len, *tid, *anchor, *range, *res, *cls, *b1, *b2, *consumed, *cand_rec, *counters, *cut;
+    void *rstat, *rslot, *rcompact, *rcount; int32_t cap_rc;    /* im_dev_compact_results of the stage pipeline */
     void *order, *clkey, *clfirst, *clcount, *counts, *gscratch, *fdesc, *fgscratch; size_t gscratch_bytes, fgscratch_bytes;
     /* confirmed by harvested chunks / still in flight */
     int32_t conf_cand, conf_err; int64_t conf_bytes, fly_recs, fly_seq;
@@ -2329,6 +2331,8 @@ static void pipe_destroy(ppipe* P)
         im_event_destroy(c->done);
     }
     pipe_free_cands(P);
+    if (P->rstat) { im_dev_free(P->d->gpu, P->rstat); im_dev_free(P->d->gpu, P->rslot); im_dev_free(P->d->gpu, P->rcompact); }
+    if (P->rcount) im_dev_free(P->d->gpu, P->rcount);
     im_dev_free(P->d->gpu, P->counters); im_dev_free(P->d->gpu, P->counts); im_dev_free(P->d->gpu, P->cut); im_dev_free(P->d->gpu, P->fdesc);
     if (P->own_stream) im_stream_destroy(P->d->gpu, P->stream);
     P->ready = 0;
@@ -2340,7 +2344,7 @@ static void group_free(pgroup* G)
     free(G->ctg); free(G->fl); free(G->fp); free(G->pe); free(G->pe_rec); free(G->cand_rec); free(G->craw_off); free(G->craw);
     free(G->cn_rec); free(G->cn_pos); free(G->lm_rec); free(G->lm_val);
     free(G->npp_raw); free(G->npp_off); free(G->npp_rec); free(G->dn); free(G->sn);
-    free(G->res); free(G->s_cls); free(G->s_b1); free(G->s_b2); free(G->cons_sr); free(G->cons_pe); free(G->front); free(G->front_virt);
+    free(G->res); free(G->res_slot); free(G->s_cls); free(G->s_b1); free(G->s_b2); free(G->cons_sr); free(G->cons_pe); free(G->front); free(G->front_virt);
     free(G->cl_key); free(G->cl_first); free(G->cl_count); free(G->order); free(G->cl_sorted); free(G->ev_cache);
     free(G->cov.sum); free(G->cov.seg);
     memset(G, 0, sizeof *G);
@@ -2860,16 +2864,36 @@ static void stage_run_group(ppipe* P, pgroup* G)
                                    P->order, P->clkey, P->clfirst, P->clcount, P->counts, P->gscratch, P->gscratch_bytes, P->stream));
     }
     free(fd);
+    if (n_own > 0) {
+        /* only the realigned records that hold evidence travel whole (im_dev_compact_results) */
+        if (n_own > P->cap_rc) {
+            GPU(im_stream_sync(g, P->stream));
+            if (P->rstat) { im_dev_free(g, P->rstat); im_dev_free(g, P->rslot); im_dev_free(g, P->rcompact); }
+            if (!P->rcount) P->rcount = pdev_alloc(P, 256);
+            P->cap_rc = P->cap_cand > n_own ? P->cap_cand : n_own;
+            P->rstat = pdev_alloc(P, 4 * (size_t)P->cap_rc); P->rslot = pdev_alloc(P, 4 * (size_t)P->cap_rc);
+            P->rcompact = pdev_alloc(P, sizeof(im_read_result) * (size_t)P->cap_rc);
+        }
+        GPU(im_dev_compact_results(g, (const im_read_result*)P->res + nK, n_own, NULL, P->rstat, P->rslot, P->rcompact, P->rcount, P->stream));
+    }
     GPU(im_stream_sync(g, P->stream));
     phase_time("device: realign + flush cuts + group-by");
 
     const size_t nn = (size_t)(nc ? nc : 1);
-    G->res = xrealloc(G->res, sizeof(im_read_result) * (size_t)(n_own ? n_own : 1));
+    int32_t n_evd = 0;
+    int32_t* rstat = xmalloc(4 * (size_t)(n_own ? n_own : 1));
+    if (n_own > 0) GPU(im_dev_download(g, &n_evd, P->rcount, 4));
+    G->res = xrealloc(G->res, sizeof(im_read_result) * (size_t)(n_evd ? n_evd : 1));
+    G->res_slot = xrealloc(G->res_slot, 4 * (size_t)(n_own ? n_own : 1));
     G->s_cls = xrealloc(G->s_cls, 4 * nn * IM_MAX_EV); G->s_b1 = xrealloc(G->s_b1, 4 * nn * IM_MAX_EV); G->s_b2 = xrealloc(G->s_b2, 4 * nn * IM_MAX_EV);
     G->cons_sr = xrealloc(G->cons_sr, 4 * nn * IM_MAX_EV);
     G->cons_pe = xrealloc(G->cons_pe, 4 * (size_t)(G->n_pe ? G->n_pe : 1));
     int32_t counts[2] = { 0, 0 };
-    if (n_own > 0) GPU(im_dev_download(g, G->res, (char*)P->res + sizeof(im_read_result) * nK, sizeof(im_read_result) * nO));
+    if (n_own > 0) {
+        GPU(im_dev_download(g, rstat, P->rstat, 4 * nO));
+        GPU(im_dev_download(g, G->res_slot, P->rslot, 4 * nO));
+        if (n_evd > 0) GPU(im_dev_download(g, G->res, P->rcompact, sizeof(im_read_result) * (size_t)n_evd));
+    }
     if (nc > 0) {
         GPU(im_dev_download(g, G->s_cls, P->cls, 4 * (size_t)nc * IM_MAX_EV));
         GPU(im_dev_download(g, G->s_b1, P->b1, 4 * (size_t)nc * IM_MAX_EV));
@@ -2897,12 +2921,14 @@ static void stage_run_group(ppipe* P, pgroup* G)
     G->ev_cache = xrealloc(G->ev_cache, sizeof(evidence_t*) * nn * IM_MAX_EV);
     memset(G->ev_cache, 0, sizeof(evidence_t*) * nn * IM_MAX_EV);
     for (int32_t i = 0; i < n_own; i++) {
-        const int st = G->res[i].status;
+        const int st = rstat[i];
+        if (st >= 0) continue;
         if ((st == IM_ST_ABORT || st == IM_ST_OVERFLOW || st == IM_ST_UNSUPPORTED) && g_handoff_pool) pipeline_handoff();
         if (st == IM_ST_ABORT) fatalf("im_dev_realign: read %d: the reference would abort on this input", i);
         if (st == IM_ST_OVERFLOW) fatalf("im_dev_realign: read %d: segment list longer than IM_MAX_OPS", i);
         if (st == IM_ST_UNSUPPORTED) fatalf("im_dev_realign: read %d: longer than IM_MAX_READ=%d", i, O.numgaps ? 255 : IM_MAX_READ);
     }
+    free(rstat);
     if (G->sv[0]) { if (getenv("INDELMINER_TIDY_EXIT") || g_free_slabs) im_dev_free(g, G->sv[0]); G->sv[0] = NULL; }
     phase_time("results to the host");
 }
@@ -2917,8 +2943,8 @@ static void candidate_evidence(driver* d, const pgroup* S, int32_t cand, int64_t
     const int flag = b.flag;
     const int is_aligned = (flag & 0x4) == 0, is_rc = (flag & 0x10) != 0, is_mate_rc = (flag & 0x20) != 0;
     const char* qname = BAMR_QNAME(&b);
-    const im_read_result* r = &S->res[cand];
-    if (r->status == IM_ST_EVIDENCE && r->n_ev > 0) {
+    const im_read_result* r = S->res_slot[cand] >= 0 ? &S->res[S->res_slot[cand]] : NULL;
+    if (r) {                                        /* status == IM_ST_EVIDENCE, n_ev > 0 */
         char* bases = decode_bases(&b);
         char strand = is_rc ? '-' : '+';
         uint8_t qual;
@@ -4949,7 +4975,10 @@ int main(int argc, char** argv)
             }
             /* no config file: the insert lengths are estimated by the walk itself (run_pipeline) instead of by a pass of their own;
              * multi-GPU runs and annotate mode keep the pre-pass (the shard summaries / the serial walk need the table up front) */
-            g_onepass = O.configfile == NULL && !g_mg && g_vcfname == NULL && chromid == -1 && getenv("INDELMINER_ONEPASS") != NULL;
+            {
+                const char* op = getenv("INDELMINER_ONEPASS");          /* INDELMINER_ONEPASS=0: the pre-pass of the reference's layout */
+                g_onepass = O.configfile == NULL && !g_mg && g_vcfname == NULL && chromid == -1 && !(op && strcmp(op, "0") == 0);
+            }
             pool = walkpool_start(&d);
         }
     }

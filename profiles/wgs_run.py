@@ -119,8 +119,8 @@ def main():
     print("generated", out["generation"], file=sys.stderr, flush=True)
     variants = {
         "config": (["-i", "w.cfg"], {}),
-        "estimate": ([], {}),
-        "onepass": ([], {"INDELMINER_ONEPASS": "1"}),
+        "estimate": ([], {"INDELMINER_ONEPASS": "0"}),
+        "onepass": ([], {}),
         "walkers8": (["-i", "w.cfg"], {"INDELMINER_WALKERS": "8"}),
         "walkers1": (["-i", "w.cfg"], {"INDELMINER_WALKERS": "1"}),
         "threads2": (["-i", "w.cfg"], {"INDELMINER_WALKERS": "8", "INDELMINER_THREADS": "2"}),
@@ -128,7 +128,7 @@ def main():
         "w14t0": (["-i", "w.cfg"], {"INDELMINER_WALKERS": "14", "INDELMINER_THREADS": "0"}),
         "w12t1": (["-i", "w.cfg"], {"INDELMINER_WALKERS": "12", "INDELMINER_THREADS": "1"}),
         "w16t1": (["-i", "w.cfg"], {"INDELMINER_WALKERS": "16", "INDELMINER_THREADS": "1"}),
-        "onepass16": ([], {"INDELMINER_ONEPASS": "1", "INDELMINER_WALKERS": "16", "INDELMINER_THREADS": "0"}),
+        "onepass16": ([], {"INDELMINER_WALKERS": "16", "INDELMINER_THREADS": "0"}),
     }
     runs = {}
     for name in [v for v in args.variants.split(",") if v]:

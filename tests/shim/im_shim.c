@@ -31,6 +31,21 @@ int im_set_reference(im_ctx* c, int32_t n, const char* const* seqs, const int64_
     return IM_OK;
 }
 
+int im_dev_compact_results(im_ctx* c, const im_read_result* res, int32_t n, const int32_t* n_dev,
+                           int32_t* status, int32_t* slot, im_read_result* compact, int32_t* count, void* stream)
+{
+    (void)c; (void)stream;
+    if (n_dev && *n_dev < n) n = *n_dev;
+    int32_t k = 0;
+    /* the device leaves the packed records in no particular order: here from the back, so that nothing grows to rely on one */
+    for (int32_t i = n - 1; i >= 0; i--) {
+        status[i] = res[i].status;
+        if (res[i].status == IM_ST_EVIDENCE && res[i].n_ev > 0) { compact[k] = res[i]; slot[i] = k++; } else slot[i] = -1;
+    }
+    *count = k;
+    return IM_OK;
+}
+
 int im_expect_read_length(im_ctx* c, int32_t max_len) { (void)c; return max_len > IM_MAX_READ ? IM_E_UNSUPPORTED : IM_OK; }   /* the oracle has one path for every length */
 
 int im_realign_batch(im_ctx* c, const im_params* p, const im_read_batch* b, im_read_result* out)

@@ -244,3 +244,36 @@ def test_support_kernel_matches_reference_realign_with_indel(gpu_ctx):
     got = gpu_ctx.support_batch(targets, queries)
     for k, c in enumerate(cases):
         assert [int(x) for x in got[k][:3]] == c["expect"], (k, c["expect"], tuple(got[k]))
+
+
+@pytest.mark.parametrize("n", [0, 1, 63, 64, 65, 1000, 50001])
+def test_compact_results_packs_exactly_the_records_with_evidence(gpu_ctx, n):
+    """im_dev_compact_results: status and place of every read, the records with status == IM_ST_EVIDENCE and n_ev > 0 packed whole
+    (any order), nothing else; also with the batch size read from device memory"""
+    import ctypes as C
+    from indelminer_amd import capi
+    L = capi.lib()
+    rng = np.random.default_rng(n)
+    res = np.frombuffer(rng.integers(0, 256, size=512 * max(n, 1), dtype=np.uint8).tobytes(), dtype=capi.RESULT_DTYPE).copy()
+    res["status"] = rng.choice([0, 1, 1, -1, -2, -3], size=len(res))
+    res["n_ev"] = rng.choice([0, 1, 2, 4], size=len(res))
+    for n_live in ([n] if n < 100 else [n, n - 37]):
+        d_res = capi.DevBuf(gpu_ctx, 512 * max(n, 1)).upload(res)
+        d_stat, d_slot = capi.DevBuf(gpu_ctx, 4 * max(n, 1)), capi.DevBuf(gpu_ctx, 4 * max(n, 1))
+        d_comp, d_cnt = capi.DevBuf(gpu_ctx, 512 * max(n, 1)), capi.DevBuf(gpu_ctx, 256)
+        d_n = capi.DevBuf(gpu_ctx, 256).upload(np.array([n_live], np.int32))
+        gpu_ctx._check(L.im_dev_compact_results(gpu_ctx.h, d_res.ptr, n, d_n.ptr if n_live != n else None, d_stat.ptr, d_slot.ptr, d_comp.ptr, d_cnt.ptr, gpu_ctx.stream))
+        gpu_ctx._check(L.im_stream_sync(gpu_ctx.h, gpu_ctx.stream))
+        cnt = int(d_cnt.download(np.int32, 1)[0])
+        want = (res["status"][:n_live] == 1) & (res["n_ev"][:n_live] > 0)
+        assert cnt == int(want.sum())
+        if n_live:
+            stat, slot = d_stat.download(np.int32, n_live), d_slot.download(np.int32, n_live)
+            assert np.array_equal(stat, res["status"][:n_live])
+            assert np.array_equal(slot >= 0, want)
+            assert sorted(slot[want].tolist()) == list(range(cnt))
+            if cnt:
+                comp = d_comp.download(capi.RESULT_DTYPE, cnt)
+                assert comp[slot[want]].tobytes() == res[:n_live][want].tobytes()
+        for b in (d_res, d_stat, d_slot, d_comp, d_cnt, d_n):
+            b.free()

@@ -58,7 +58,7 @@ def test_wgs_scale_reference_at_1x(tmp_path):
     assert info["records"] == want["records_in_bam"] and info["bam_bytes"] == want["bam_bytes"]
     build.build()
     prod = build.build_host()
-    for flags, env in ((["-i", "w.cfg"], {}), ([], {"INDELMINER_ONEPASS": "1"}), (["-i", "w.cfg"], {"INDELMINER_PIECE_BYTES": "3000000", "INDELMINER_WALKERS": "12"})):
+    for flags, env in ((["-i", "w.cfg"], {}), ([], {}), ([], {"INDELMINER_ONEPASS": "0"}), (["-i", "w.cfg"], {"INDELMINER_PIECE_BYTES": "3000000", "INDELMINER_WALKERS": "12"})):
         p = subprocess.run([prod] + flags + ["w.fa", "s=w.bam"], cwd=str(tmp_path), stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=dict(os.environ, **env))
         assert p.returncode == 0, p.stderr.decode()[-2000:]
         assert hashlib.md5(p.stdout).hexdigest() == want["md5"], (flags, env)

@@ -212,16 +212,16 @@ def test_host_parallel_walkers_give_the_single_walk(tmp_path):
 
 
 def test_host_one_pass_estimates_during_the_walk(synth_small, synth_1mb, tmp_path):
-    """INDELMINER_ONEPASS=1: no estimation pass of its own -- the walk collects the insert-length extrema, candidates' ranges and
+    """no config file (the default; INDELMINER_ONEPASS=0 is the pre-pass of the reference's layout): no estimation pass of its own -- the walk collects the insert-length extrema, candidates' ranges and
     the pair table are applied when the last contig is in -- and the bytes of the two-pass run come out (the goldens were made by
     the reference without a config file)"""
     shim = _build_shim()
     for d_, golden in ((synth_small, "synth_2ctg_composite_noconfig"),):
-        for env in ({"INDELMINER_ONEPASS": "1"}, {"INDELMINER_ONEPASS": "1", "INDELMINER_WALKERS": "1"},
+        for env in ({"INDELMINER_ONEPASS": "0"}, {"INDELMINER_ONEPASS": "1", "INDELMINER_WALKERS": "1"},
                     {"INDELMINER_ONEPASS": "1", "INDELMINER_WALKERS": "3", "INDELMINER_CLAIM_BASES": "1", "INDELMINER_REPLAYERS": "1"}):
             assert _run(shim, [], d_, ref="ref.fa", bam="aln.bam", env=env) == _golden(golden), env
     want = _run(shim, [], synth_1mb, ref="ref.fa", bam="aln.bam")
-    assert _run(shim, [], synth_1mb, ref="ref.fa", bam="aln.bam", env={"INDELMINER_ONEPASS": "1"}) == want
+    assert _run(shim, [], synth_1mb, ref="ref.fa", bam="aln.bam", env={"INDELMINER_ONEPASS": "0"}) == want
 
 
 def test_host_replays_that_finish_out_of_order(tmp_path):
@@ -413,7 +413,7 @@ def test_host_read_groups_estimated_by_several_threads(tmp_path):
     assert [r[0] for r in serial] == ["generic", "li", "lib10"]
     if os.path.exists(ref_bin):
         assert table(ref_bin, {}) == serial
-    for env in ({}, {"INDELMINER_WALKERS": "3"}, {"INDELMINER_ONEPASS": "1"}):
+    for env in ({}, {"INDELMINER_WALKERS": "3"}, {"INDELMINER_ONEPASS": "0"}):
         assert table(shim, env) == serial, env
 
 
@@ -584,7 +584,7 @@ def test_host_names_shared_between_contigs_go_to_the_one_table(tmp_path):
         # of two contigs; where it survives, its bytes are the record-at-a-time path's
         r = subprocess.run([ref_bin, "ref.fa", "sample=aln.bam"], cwd=d, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
         assert r.returncode < 0 or r.stdout == want
-    for env in ({}, {"INDELMINER_WALKERS": "3", "INDELMINER_CLAIM_BASES": "1"}, {"INDELMINER_ONEPASS": "1"}):
+    for env in ({}, {"INDELMINER_WALKERS": "3", "INDELMINER_CLAIM_BASES": "1"}, {"INDELMINER_ONEPASS": "0"}):
         assert _run(shim, [], d, ref="ref.fa", bam="aln.bam", env=env) == want, env
     # and without the hand-over the run says why it stops instead of printing something else
     e = dict(os.environ, INDELMINER_NO_HANDOFF="1")
@@ -703,7 +703,7 @@ def _coverage_tables(binary, tmp_path, envs):
 
 
 def test_host_coverage_table(tmp_path):
-    _coverage_tables(_build_shim(), tmp_path, ({}, {"INDELMINER_ESTIMATE_SERIAL": "1"}, {"INDELMINER_ONEPASS": "1"}, {"INDELMINER_PIPELINE": "host"},
+    _coverage_tables(_build_shim(), tmp_path, ({}, {"INDELMINER_ESTIMATE_SERIAL": "1"}, {"INDELMINER_ONEPASS": "0"}, {"INDELMINER_PIPELINE": "host"},
                                               {"INDELMINER_PIECE_BYTES": "60000", "INDELMINER_WALKERS": "3"},
                                               {"INDELMINER_PIECE_BYTES": "60000", "INDELMINER_WALKERS": "3", "INDELMINER_ONEPASS": "1"}))
 
@@ -747,7 +747,7 @@ def test_product_parallel_walkers_and_replayers(tmp_path):
     for env in ({}, {"INDELMINER_WALKERS": "1"}, {"INDELMINER_WALKERS": "6", "INDELMINER_CLAIM_BASES": "1", "INDELMINER_REPLAYERS": "4"},
                 {"INDELMINER_WALKERS": "3", "INDELMINER_CLAIM_BASES": "1", "INDELMINER_REPLAYERS": "1", "INDELMINER_STREAMS": "shared"},
                 {"INDELMINER_WALKERS": "4", "INDELMINER_CLAIM_BASES": "250000", "INDELMINER_VERIFY_TRIAGE": "1"},
-                {"INDELMINER_ONEPASS": "1"}, {"INDELMINER_ONEPASS": "1", "INDELMINER_WALKERS": "6", "INDELMINER_CLAIM_BASES": "1"},
+                {"INDELMINER_ONEPASS": "0"}, {"INDELMINER_ONEPASS": "1", "INDELMINER_WALKERS": "6", "INDELMINER_CLAIM_BASES": "1"},
                 {"INDELMINER_PIECE_BYTES": "200000", "INDELMINER_WALKERS": "5"}, {"INDELMINER_PIECE_BYTES": "60000", "INDELMINER_ONEPASS": "1"},
                 {"INDELMINER_PIECE_BYTES": "100000", "INDELMINER_FLUSH_MODE": "seq", "INDELMINER_THREADS": "0"}):
         assert _run(prod, [], str(tmp_path), ref="ref.fa", bam="aln.bam", env=env) == want, env
@@ -761,7 +761,7 @@ def test_product_stale_pair_table_entries(tmp_path):
     want = _run(_build_shim(), [], d, ref="ref.fa", bam="aln.bam", env={"INDELMINER_PIPELINE": "host"})
     assert want.count(b"\n") > 400
     prod = _product()
-    for env in ({}, {"INDELMINER_WALKERS": "1"}, {"INDELMINER_FLUSH_MODE": "per-flush"}, {"INDELMINER_ONEPASS": "1"},
+    for env in ({}, {"INDELMINER_WALKERS": "1"}, {"INDELMINER_FLUSH_MODE": "per-flush"}, {"INDELMINER_ONEPASS": "0"},
                 {"INDELMINER_PIECE_BYTES": "500000"}, {"INDELMINER_PIECE_BYTES": "150000", "INDELMINER_WALKERS": "6"}):
         assert _run(prod, [], d, ref="ref.fa", bam="aln.bam", env=env) == want, env
 
@@ -791,7 +791,7 @@ def test_product_rejects_long_read_library_at_startup(tmp_path):
 
 @pytest.mark.gpu
 def test_product_coverage_table(tmp_path):
-    _coverage_tables(_product(), tmp_path, ({}, {"INDELMINER_ONEPASS": "1"}, {"INDELMINER_PIECE_BYTES": "60000", "INDELMINER_WALKERS": "3"}))
+    _coverage_tables(_product(), tmp_path, ({}, {"INDELMINER_ONEPASS": "0"}, {"INDELMINER_PIECE_BYTES": "60000", "INDELMINER_WALKERS": "3"}))
 
 
 @pytest.mark.gpu
