@@ -1,0 +1,662 @@
+/* host_walk.c -- part of the indelminer host driver (one translation unit: imhost.c includes the parts in order, so that the
+ * reference-shaped helpers can stay static).  Here: evidence that crosses piece boundaries, the walker pool (pieces, claims), run_pipeline (the main thread's loop over the
+ * groups in file order, replay workers). */
+
+/* ---- evidence that crosses piece boundaries ---- */
+
+typedef struct {
+    carry_list live;            /* pending: takes part in the next piece's flushes */
+    carry_list frozen;          /* pending with b2 >= the contig's marker floor: no flush before the contig's last can consume it
+                                 * (every marker is <= the floor, so it is a cutting candidate of every flush that sees it); it
+                                 * waits for the last piece, and a single entry carries the smallest (b1,b2) among them so far */
+    uint64_t frozen_min;
+    int tid;
+} carry_t;
+
+static void carry_push(carry_list* l, const carry_item* it)
+{
+    if (l->n == l->cap) { l->cap = l->cap ? l->cap * 2 : 256; l->v = xrealloc(l->v, sizeof(carry_item) * (size_t)l->cap); }
+    l->v[l->n++] = *it;
+}
+
+static evidence_t* phantom_entry(uint64_t key)
+{
+    evidence_t* e = xcalloc(1, sizeof *e);
+    e->type = EV_PHANTOM; e->cls = CLS_DELETION;
+    e->b1 = (int32_t)(key >> 32); e->b2 = (int32_t)(uint32_t)key;
+    e->live_slot = -1;
+    return e;
+}
+
+/* Before a group's pair table and stage: what the earlier pieces of its contig left pending goes in front -- split-read candidates
+ * into front[], paired-read entries to the head of pe[] -- numbered 0 .. n_virt - 1 in order of arrival.  The last piece of a
+ * contig takes the frozen entries too; any other piece takes one entry that stands for them. */
+static void stage_take_front(pgroup* G, carry_t* C)
+{
+    const gcontig* cg = &G->ctg[0];
+    G->n_front = 0; G->n_pe_front = 0; G->n_virt = 0; G->phantom = 0;
+    if (cg->first) { C->live.n = 0; C->frozen.n = 0; C->frozen_min = ~0ull; C->tid = cg->tid; return; }
+    forceassert(G->n_ctg == 1 && C->tid == cg->tid && G->n_pe == 0);
+    const int take_frozen = cg->last;
+    const int32_t n_all = C->live.n + (take_frozen ? C->frozen.n : 0);
+    G->front = xrealloc(G->front, sizeof(carry_item) * (size_t)(n_all ? n_all : 1));
+    G->front_virt = xrealloc(G->front_virt, sizeof(int32_t) * (size_t)(n_all ? n_all : 1));
+    if (n_all + 1 > G->cap_pe) {
+        G->cap_pe = n_all + 1024;
+        G->pe = xrealloc(G->pe, sizeof(evidence_t*) * (size_t)G->cap_pe);
+        G->pe_rec = xrealloc(G->pe_rec, sizeof(int64_t) * (size_t)G->cap_pe);
+    }
+    /* both lists are in order of arrival: merge */
+    int32_t a = 0, b = 0, v = 0;
+    const int32_t nb = take_frozen ? C->frozen.n : 0;
+    while (a < C->live.n || b < nb) {
+        const carry_item* it = (b >= nb || (a < C->live.n && C->live.v[a].when <= C->frozen.v[b].when)) ? &C->live.v[a++] : &C->frozen.v[b++];
+        if (it->g) { G->front[G->n_front] = *it; G->front_virt[G->n_front] = v; G->n_front++; }
+        else {
+            it->pe->arrival = (int64_t)v * 8 + 7;
+            G->pe[G->n_pe] = it->pe; G->pe_rec[G->n_pe] = -1; G->n_pe++;
+        }
+        v++;
+    }
+    if (!take_frozen && C->frozen_min != ~0ull) {
+        G->pe[G->n_pe] = phantom_entry(C->frozen_min); G->pe_rec[G->n_pe] = -1; G->n_pe++;
+        G->phantom = 1;
+    }
+    G->n_pe_front = G->n_pe;
+    G->n_virt = v;
+    C->live.n = 0;
+    if (take_frozen) { C->frozen.n = 0; C->frozen_min = ~0ull; }
+}
+
+/* After a group's stage: what no flush of it has consumed.  Nothing is left behind the last piece of a contig (its last flush takes
+ * everything).  floor = the marker floor of the contig (group_resolve_flushes): an entry with b2 >= floor is frozen. */
+static void stage_leftovers(pgroup* G, carry_t* C, int floor)
+{
+    const gcontig* cg = &G->ctg[G->n_ctg - 1];
+    if (cg->last) return;
+    forceassert(G->n_ctg == 1);
+    const int32_t nc = G->n_front + G->sv_n;
+    const int32_t frozen0 = C->frozen.n;
+    for (int32_t q = 0; q < nc; q++) {
+        carry_item live, froz;
+        int nl = 0, nf = 0;
+        for (int k = 0; k < IM_MAX_EV; k++) {
+            const size_t sl = (size_t)q * IM_MAX_EV + (size_t)k;
+            live.cls[k] = froz.cls[k] = -1; live.b1[k] = froz.b1[k] = 0; live.b2[k] = froz.b2[k] = 0;
+            if (G->s_cls[sl] < 0 || G->cons_sr[sl] != 0) continue;
+            carry_item* to = G->s_b2[sl] >= floor ? &froz : &live;
+            to->cls[k] = G->s_cls[sl]; to->b1[k] = G->s_b1[sl]; to->b2[k] = G->s_b2[sl];
+            if (to == &froz) {
+                nf++;
+                const uint64_t key = ((uint64_t)(uint32_t)G->s_b1[sl] << 32) | (uint32_t)G->s_b2[sl];
+                if (key < C->frozen_min) C->frozen_min = key;
+            } else nl++;
+        }
+        if (!nl && !nf) continue;
+        carry_item base;
+        if (q < G->n_front) base = G->front[q];
+        else { base.g = G; base.cand = q - G->n_front; base.pe = NULL; base.when = ((int64_t)G->seq << 32) | (uint32_t)G->cand_rec[q - G->n_front]; }
+        if (nl) { live.when = base.when; live.g = base.g; live.cand = base.cand; live.pe = NULL; carry_push(&C->live, &live); }
+        if (nf) { froz.when = base.when; froz.g = base.g; froz.cand = base.cand; froz.pe = NULL; carry_push(&C->frozen, &froz); }
+    }
+    /* the same for the paired-read entries; then each kind's pending items, both in order of arrival, merged into the lists */
+    carry_list pl = { NULL, 0, 0 }, pf = { NULL, 0, 0 };
+    for (int32_t i = 0; i < G->n_pe; i++) {
+        evidence_t* e = G->pe[i];
+        if (e->type == EV_PHANTOM || G->cons_pe[i] != 0) continue;
+        carry_item it;
+        memset(&it, 0, sizeof it);
+        it.g = NULL; it.pe = e; it.when = e->when;
+        for (int k = 0; k < IM_MAX_EV; k++) it.cls[k] = -1;
+        if (e->b2 >= floor) {
+            const uint64_t key = ((uint64_t)(uint32_t)e->b1 << 32) | (uint32_t)e->b2;
+            if (key < C->frozen_min) C->frozen_min = key;
+            carry_push(&pf, &it);
+        } else carry_push(&pl, &it);
+    }
+    /* C->live / C->frozen hold this stage's split-read leftovers from index n0 on (stage_take_front emptied live; frozen keeps
+     * what earlier pieces froze, all of which arrived before anything of this piece: front items are never frozen-kind) */
+    for (int pass = 0; pass < 2; pass++) {
+        carry_list* l = pass ? &C->frozen : &C->live;
+        const carry_list* pe = pass ? &pf : &pl;
+        const int32_t n0 = pass ? frozen0 : 0;
+        if (pe->n == 0) continue;
+        const int32_t nsr = l->n - n0;
+        carry_item* m = xmalloc(sizeof(carry_item) * (size_t)(nsr + pe->n));
+        int32_t a = 0, b = 0, w = 0;
+        while (a < nsr || b < pe->n) m[w++] = (b >= pe->n || (a < nsr && l->v[n0 + a].when <= pe->v[b].when)) ? l->v[n0 + a++] : pe->v[b++];
+        l->n = n0;
+        for (int32_t i = 0; i < w; i++) carry_push(l, &m[i]);
+        free(m);
+    }
+    free(pl.v); free(pf.v);
+}
+
+static void walker_adopt_driver(walker_t* W, driver* d)
+{
+    W->wd = *d;                                 /* shared, read-only from here on: header, index, reference, insert lengths, GPU */
+    W->wd.readpairs = qhash_new(4);             /* the pair table is the main thread's (group_pair_table) */
+    W->wd.live = NULL; W->wd.n_live = W->wd.cap_live = 0; W->wd.live_changed = 0;
+    W->wd.rg_last_val = NULL; W->wd.rg_last_name[0] = 0;
+    W->wd.gpu_pending = 0;
+}
+
+static void walker_setup(walker_t* W, driver* d)
+{
+    W->wd.gpu = d->gpu;
+    pipe_init(&W->P, &W->wd, 1);
+    W->r = bgzf_open(d->bam_name);
+    if (!W->r) fatalf("error in opening the file %s", d->bam_name);
+    if (W->pool->inflate_workers >= 0) bgzf_set_workers(W->r, W->pool->inflate_workers);
+    W->hdr = bam_header_load(W->r);
+    if (!W->hdr) fatalf("%s is not a BAM file", d->bam_name);
+}
+
+/* one claim: its pieces through the walker's pipeline into a new group, the group's device arrays parked */
+static pgroup* walk_claim(walker_t* W, walkpool_t* o, const claim_t* c)
+{
+    pgroup* G = xcalloc(1, sizeof(pgroup));
+    for (int k = 0; k < c->count; k++) pipe_walk_piece(&W->P, G, &o->pieces[c->first + k], W->r);
+    pipe_submit(&W->P, G);
+    pipe_drain(&W->P, G);
+    group_park_device(&W->P, G);
+    return G;
+}
+
+static void* walker_thread(void* arg)
+{
+    walker_t* W = arg;
+    walkpool_t* o = W->pool;
+    driver* d = o->d;
+    /* buffers as soon as the GPU context exists -- beside the insert-length pass and the FASTA read of the main thread */
+    pthread_mutex_lock(&d->gpu_mu);
+    while (!d->ctx_ready) pthread_cond_wait(&d->gpu_cv, &d->gpu_mu);
+    pthread_mutex_unlock(&d->gpu_mu);
+    if (d->ctx_rc != IM_OK) return NULL;            /* the main thread reports it (gpu_wait) */
+    walker_setup(W, d);
+    pthread_mutex_lock(&o->mu);
+    while (!o->go) pthread_cond_wait(&o->cv, &o->mu);
+    pthread_mutex_unlock(&o->mu);
+    walker_adopt_driver(W, d);
+    for (;;) {
+        pthread_mutex_lock(&o->mu);
+        /* walked groups wait for the main thread with their logs and parked arrays: stay a bounded number of claims ahead of it */
+        while (!g_onepass && !g_mg && o->next_claim < o->n_claims && o->next_claim >= o->staged + 2 * o->nw + 4) pthread_cond_wait(&o->cv, &o->mu);
+        while (g_mg && o->next_claim < o->n_claims && g_mg->claim_walker[o->next_claim] != g_mg->rank) o->next_claim++;      /* another rank walks it */
+        const int ci = o->next_claim < o->n_claims ? o->next_claim++ : -1;
+        pthread_mutex_unlock(&o->mu);
+        if (ci < 0) break;
+        claim_t* c = &o->claims[ci];
+        const int ship = g_mg && g_mg->claim_owner[ci] != g_mg->rank;
+        if (g_handoff_pool) {
+            /* a record the reference dies on ends this walker: the claim is published as it is, marked */
+            W->cur_claim = c;
+            if (setjmp(W->abort_jmp)) {
+                const int cj = (int)(W->cur_claim - o->claims);
+                if (g_mg && g_mg->claim_owner[cj] != g_mg->rank) package_write(g_mg, cj, &W->P, NULL, 1);      /* its owner hands the run over */
+                pthread_mutex_lock(&o->mu);
+                W->cur_claim->G = NULL; W->cur_claim->aborted = 1; W->cur_claim->walked = 1;
+                pthread_cond_broadcast(&o->cv);
+                pthread_mutex_unlock(&o->mu);
+                return NULL;
+            }
+            t_abort_jmp = &W->abort_jmp;
+        }
+        pgroup* G = walk_claim(W, o, c);
+        t_abort_jmp = NULL;
+        if (g_mg) { int64_t nr = 0; group_flush_points(G, &nr); G->from_package = 1; }      /* the counter in front of every piece is known (mg_exchange) */
+        if (ship) {
+            package_write(g_mg, ci, &W->P, G, 0);
+            im_dev_free(W->P.d->gpu, G->sv[0]);
+            group_free(G); free(G);
+            G = NULL;
+        }
+        pthread_mutex_lock(&o->mu);
+        c->G = G; c->walked = 1;
+        pthread_cond_broadcast(&o->cv);
+        pthread_mutex_unlock(&o->mu);
+    }
+    return NULL;
+}
+
+typedef struct { struct walkpool_s* o; int first, step; driver rd; pthread_t th; } apply_job;
+static void* apply_thread(void* arg)
+{
+    apply_job* j = arg;
+    for (int ci = j->first; ci < j->o->n_claims; ci += j->step) {
+        pgroup* G = j->o->claims[ci].G;
+        G->sv_range = group_ranges(&j->rd, G);
+    }
+    return NULL;
+}
+
+/* groups of a contig are freed together: pending evidence points back at the groups it came from */
+static void groups_free_chain(pgroup* G)
+{
+    while (G) { pgroup* n = G->next_of_contig; group_free(G); free(G); G = n; }
+}
+
+static void* replay_thread(void* arg)
+{
+    replayer_t* R = arg;
+    walkpool_t* o = R->pool;
+    for (;;) {
+        pthread_mutex_lock(&o->mu);
+        while (o->next_job >= o->n_jobs && !o->jobs_closed) pthread_cond_wait(&o->cv, &o->mu);
+        const int j = o->next_job < o->n_jobs ? o->next_job++ : -1;
+        pthread_mutex_unlock(&o->mu);
+        if (j < 0) break;
+        rjob_t* J = &o->jobs[j];
+        {   /* test hook: every other replay takes this much longer, so that replays finish out of order on any machine */
+            const char* dl = getenv("INDELMINER_DEBUG_REPLAY_DELAY_MS");
+            if (dl && (j & 1) == 0) { struct timespec ts = { atoi(dl) / 1000, (long)(atoi(dl) % 1000) * 1000000L }; nanosleep(&ts, NULL); }
+        }
+        t_out = open_memstream(&J->buf, &J->len);
+        if (!t_out) fatalf("cannot buffer the output of a group");
+        group_replay(&R->rd, J->G);
+        fclose(t_out);
+        t_out = NULL;
+        pthread_mutex_lock(&o->mu);
+        J->done = 1;
+        pthread_cond_broadcast(&o->cv);
+        pthread_mutex_unlock(&o->mu);
+    }
+    return NULL;
+}
+
+/* Called as soon as the BAM header and index are known: cuts this process's share of the file into pieces, plans the claims and
+ * starts the walkers, which set their buffers up in the background and then wait for run_pipeline's go. */
+static walkpool_t* walkpool_start(driver* d)
+{
+    walkpool_t* o = xcalloc(1, sizeof *o);
+    o->d = d;
+    pthread_mutex_init(&o->mu, NULL); pthread_cond_init(&o->cv, NULL);
+    const int32_t nt = d->hdr->n_targets;
+    /* annotate mode shares the known-variant list with the replay and skips contigs without variants: one walker, one whole
+     * contig per claim, walked by the main thread only after the previous one has been replayed */
+    o->serial = g_vcfname != NULL;
+    const char* e = getenv("INDELMINER_WALKERS");
+    long ncpu = sysconf(_SC_NPROCESSORS_ONLN);
+    {   /* the cores this process may use, not the machine's (a container's CPU quota) */
+        FILE* fp = fopen("/sys/fs/cgroup/cpu.max", "r");
+        long quota = 0, period = 0;
+        if (fp) { if (fscanf(fp, "%ld %ld", &quota, &period) == 2 && quota > 0 && period > 0 && quota / period < ncpu) ncpu = quota / period; fclose(fp); }
+        if (ncpu < 1) ncpu = 1;
+    }
+    /* one walker per core when there are pieces enough to go round (each then inflates its own blocks: no hand-over between
+     * threads); with few pieces, few walkers and the other cores as inflate workers of their readers (set below) */
+    int nw = e ? atoi(e) : (int)(ncpu > 16 ? 16 : ncpu);
+    if (o->serial || nw < 1) nw = 1;
+    if (nw > 32) nw = 32;
+    int64_t total_bytes = 0, total_len = 0;
+    for (int32_t i = 0; i < nt; i++) {
+        if (g_mg && g_mg->skip && g_mg->skip[i]) continue;
+        if (g_region_tid >= 0 && i != g_region_tid) continue;
+        total_bytes += bai_contig_bytes(d->idx, i); total_len += d->hdr->target_len[i];
+    }
+    if (g_mg) { total_bytes /= g_mg->world; total_len /= g_mg->world; }      /* a rank's share: the plan below is the whole run's, the same on every rank */
+    /* pieces: a contig is cut where its compressed bytes cross multiples of the piece size -- about 1/(8 walkers) of the file, at
+     * least 8 MB of it (a stage and a replay have fixed costs per group), so that large contigs spread over all walkers */
+    int64_t piece_bytes = total_bytes / (8 * (int64_t)nw);
+    if (piece_bytes < (8 << 20)) piece_bytes = 8 << 20;
+    if (getenv("INDELMINER_PIECE_BYTES")) piece_bytes = atoll(getenv("INDELMINER_PIECE_BYTES"));
+    if (o->serial) piece_bytes = 0;
+    int cap = 0;
+    for (int32_t i = 0; i < nt; i++) {
+        if (g_mg && g_mg->skip && g_mg->skip[i]) continue;          /* annotate mode: no known variant on it, nobody walks it */
+        if (g_region_tid >= 0 && i != g_region_tid) continue;
+        int32_t cuts[4096];
+        int nc = piece_bytes > 0 ? bai_split_points(d->idx, i, d->hdr->target_len[i], piece_bytes, cuts, 4096) : 0;
+        int32_t lo = 0, hi = d->hdr->target_len[i];
+        if (g_region_tid >= 0) {
+            /* -c: the stretch [beg, end) only; cuts outside it go */
+            lo = g_region_beg < 0 ? 0 : g_region_beg; hi = g_region_end;
+            int m = 0;
+            for (int k = 0; k < nc; k++) if (cuts[k] > lo && cuts[k] < hi) cuts[m++] = cuts[k];
+            nc = m;
+        }
+        if (o->n_pieces + nc + 1 > cap) { cap = (cap + nc + 1) * 2; o->pieces = xrealloc(o->pieces, sizeof(piece_t) * (size_t)cap); }
+        const int64_t w = bai_contig_bytes(d->idx, i);
+        for (int k = 0; k <= nc; k++) {
+            piece_t* pc = &o->pieces[o->n_pieces++];
+            pc->tid = i; pc->beg = k ? cuts[k - 1] : lo; pc->end = k < nc ? cuts[k] : hi;
+            pc->first = k == 0; pc->last = k == nc; pc->weight = w / (nc + 1);
+            pc->overlap = g_region_tid >= 0 && k == 0;
+            pc->index = o->n_pieces - 1;
+        }
+    }
+    /* claims: a piece of a cut contig on its own; whole small contigs together up to about a piece's worth (the stage and the
+     * replay have fixed costs per group) */
+    int64_t claim_len = total_len / (4 * (int64_t)nw);
+    if (claim_len < 2000000) claim_len = 2000000;
+    if (getenv("INDELMINER_CLAIM_BASES")) claim_len = atoll(getenv("INDELMINER_CLAIM_BASES"));
+    o->claims = xcalloc((size_t)(o->n_pieces ? o->n_pieces : 1), sizeof(claim_t));
+    for (int k = 0; k < o->n_pieces;) {
+        claim_t* c = &o->claims[o->n_claims++];
+        c->first = k;
+        const piece_t* p0 = &o->pieces[k];
+        int64_t len = 0;
+        if (!(p0->first && p0->last)) { k++; c->count = 1; continue; }
+        do { len += d->hdr->target_len[o->pieces[k].tid]; k++; }
+        while (!o->serial && k < o->n_pieces && o->pieces[k].first && o->pieces[k].last && len + d->hdr->target_len[o->pieces[k].tid] <= claim_len &&
+               (!g_mg || g_mg->owner[o->pieces[k].tid] == g_mg->owner[p0->tid]));
+        c->count = k - c->first;
+    }
+    if (g_mg) {
+        /* Who walks what.  A contig's stage and replay are its owner's (mg_plan: contigs to ranks by size); its pieces are WALKED --
+         * read, inflated, triaged -- by whichever rank has done the least so far, so that one large contig, or fewer contigs than
+         * GPUs, still keeps every rank's cores and GPU busy.  The walked group then travels to the owner (package_write). */
+        mgpu* m = g_mg;
+        m->claim_owner = xmalloc(sizeof(int32_t) * (size_t)(o->n_claims ? o->n_claims : 1));
+        m->claim_walker = xmalloc(sizeof(int32_t) * (size_t)(o->n_claims ? o->n_claims : 1));
+        m->piece_walker = xmalloc(sizeof(int32_t) * (size_t)(o->n_pieces ? o->n_pieces : 1));
+        int64_t* load = xcalloc((size_t)m->world, sizeof(int64_t));
+        const char* how = getenv("INDELMINER_MG_WALK");
+        for (int ci = 0; ci < o->n_claims; ci++) {
+            const claim_t* c = &o->claims[ci];
+            int64_t w = 1;
+            for (int k = 0; k < c->count; k++) w += o->pieces[c->first + k].weight;
+            const int own = m->owner[o->pieces[c->first].tid];
+            int best = own;
+            for (int r = 0; r < m->world; r++) if (load[r] + w / 8 < load[best]) best = r;      /* the owner unless somebody is clearly idler */
+            if (o->serial || (how && strcmp(how, "owner") == 0)) best = own;
+            m->claim_owner[ci] = own; m->claim_walker[ci] = best;
+            load[best] += w;
+            for (int k = 0; k < c->count; k++) m->piece_walker[c->first + k] = best;
+            if (best != own) m->split = 1;
+        }
+        free(load);
+    }
+    if (nw > o->n_claims) nw = o->n_claims ? o->n_claims : 1;
+    o->nw = nw;
+    o->inflate_workers = getenv("INDELMINER_THREADS") ? -1 : (o->n_claims >= 2 * nw && nw >= ncpu - 1 ? 0 : (int)((ncpu - nw + nw - 1) / nw));
+    if (o->inflate_workers > 4) o->inflate_workers = 4;
+    if (!getenv("INDELMINER_THREADS") && o->inflate_workers < 1 && nw < ncpu - 1) o->inflate_workers = 1;
+    o->w = xcalloc((size_t)nw, sizeof(walker_t));
+    for (int i = 0; i < nw; i++) o->w[i].pool = o;
+    if (!o->serial)
+        for (int i = 0; i < nw; i++)
+            if (pthread_create(&o->w[i].th, NULL, walker_thread, &o->w[i]) != 0) fatalf("cannot start a walking thread");
+    return o;
+}
+
+static void run_pipeline(driver* d, walkpool_t* o)
+{
+    d->pipe_mode = 1;
+    g_verify_triage = getenv("INDELMINER_VERIFY_TRIAGE") != NULL;
+    if (!g_mg && !getenv("INDELMINER_NO_HANDOFF")) {
+        /* from here on this thread prints through the counting stream (see handoff_to_host_child) */
+        t_out = out_cookie_open();
+        if (t_out) g_handoff_pool = o;
+    } else if (g_mg && !getenv("INDELMINER_NO_HANDOFF")) {
+        /* multi-GPU: the parts in front of the contig are complete, rank 0 prints them and starts the child (mg_finish) */
+        g_handoff_pool = o;
+        g_mg_driver = d;
+    }
+    gpu_wait(d);                    /* the reference is on the device */
+    pipe_global_init(d);
+    if (o->serial) { walker_setup(&o->w[0], d); walker_adopt_driver(&o->w[0], d); }
+    pthread_mutex_lock(&o->mu); o->go = 1; pthread_cond_broadcast(&o->cv); pthread_mutex_unlock(&o->mu);
+    /* the main thread's own pipeline: the stage of every group */
+    driver sd = *d;
+    ppipe S;
+    pipe_init(&S, &sd, 0);
+    if (g_onepass) {
+        /* ONE pass over the BAM: the walk above runs without insert lengths (which records are candidates does not depend on
+         * them; the triage leaves range_max open), collecting the extrema per read group as estimate_insertlengths would
+         * (src/bamoperations.c:15-86).  When every piece is in, the table is made -- read groups in the order one process
+         * meets them -- and the stage of every group follows. */
+        pthread_mutex_lock(&o->mu);
+        for (int ci = 0; ci < o->n_claims; ci++) while (!o->claims[ci].walked) pthread_cond_wait(&o->cv, &o->mu);
+        pthread_mutex_unlock(&o->mu);
+        for (int i = 0; i < o->nw; i++) pthread_join(o->w[i].th, NULL);
+        phase_time("the walk of all pieces (inflate + count + insert-length extrema; triage on the device)");
+        int aborted = 0;
+        for (int ci = 0; ci < o->n_claims; ci++) aborted |= o->claims[ci].aborted;
+        if (aborted && g_handoff_pool) pipeline_handoff();      /* nothing is out yet: the record-at-a-time run prints it all */
+        if (!aborted) {
+            mg_rg* all = xcalloc((size_t)(o->n_claims ? o->n_claims : 1) * MG_MAX_RG, sizeof(mg_rg));
+            int n_all = 0;
+            for (int ci = 0; ci < o->n_claims; ci++) {
+                const pgroup* G = o->claims[ci].G;
+                for (int k = 0; k < G->n_rgs; k++) {
+                    mg_rg* m = &all[n_all++];
+                    snprintf(m->name, sizeof m->name, "%s", G->rgs[k].name);
+                    m->min = G->rgs[k].min; m->max = G->rgs[k].max; m->first_tid = G->rgs[k].first_tid; m->first_rec = G->rgs[k].first_rec; m->seen = 1;
+                }
+            }
+            mg_rg* merged = xcalloc((size_t)(n_all ? n_all : 1), sizeof(mg_rg));
+            const int n = merge_rgs(all, n_all, merged);
+            fprintf(stderr, "\nRead-group\tMin-value\tMax-value (estimated during the walk)\n");
+            for (int j = 0; j < n; j++) rg_table_enter(d, &merged[j]);
+            for (int j = 0; j < g_rg_n; j++) fprintf(stderr, "%s\t%d\t%d\n", g_rg_name[j], g_rg_range[j][0], g_rg_range[j][1]);
+            free(all); free(merged);
+            {
+                covlist** ls = xmalloc(sizeof(covlist*) * (size_t)(o->n_claims ? o->n_claims : 1));
+                int nl = 0;
+                for (int ci = 0; ci < o->n_claims; ci++) if (o->claims[ci].G->cov.sum) ls[nl++] = &o->claims[ci].G->cov;
+                cov_means_of_lists(d->hdr->n_targets, ls, nl);
+                free(ls);
+                cov_print_table(d->hdr);
+            }
+            pipe_global_init(d);
+            /* every group's candidates get their range[1], the groups spread over threads */
+            int nt = o->nw > 1 ? o->nw : 1;
+            if (nt > o->n_claims) nt = o->n_claims ? o->n_claims : 1;
+            apply_job* aj = xcalloc((size_t)nt, sizeof(apply_job));
+            for (int i = 0; i < nt; i++) {
+                aj[i].o = o; aj[i].first = i; aj[i].step = nt; aj[i].rd = *d;
+                aj[i].rd.rg_last_val = NULL; aj[i].rd.rg_last_name[0] = 0; aj[i].rd.gpu_pending = 0;
+                if (pthread_create(&aj[i].th, NULL, apply_thread, &aj[i]) != 0) fatalf("cannot start a thread");
+            }
+            for (int i = 0; i < nt; i++) pthread_join(aj[i].th, NULL);
+            free(aj);
+            phase_time("insert lengths applied: candidates' ranges");
+        }
+    }
+    /* Replay workers: the replay of a group (evidence objects, paired-read components, merge, print) is the longest serial
+     * piece of a run once the walks overlap; groups are independent of each other, so several are replayed at once, each
+     * into a buffer that is written out when every group before it has been.  The numbered blocks of -o detailed, annotate
+     * mode (one known-variant list) and the per-contig part files of a multi-GPU run keep the replay on this thread. */
+    const char* re = getenv("INDELMINER_REPLAYERS");
+    int nrep = re ? atoi(re) : (g_onepass ? 8 : 3);      /* one-pass: every replay comes after the walk, nothing else wants the cores */
+    if (o->serial || g_mg || strcmp(O.outputformat, "vcf") != 0 || nrep < 2) nrep = 0;
+    if (nrep > 8) nrep = 8;
+    replayer_t* rp = nrep ? xcalloc((size_t)nrep, sizeof(replayer_t)) : NULL;
+    o->jobs = xcalloc((size_t)(o->n_claims ? o->n_claims : 1), sizeof(rjob_t));
+    for (int i = 0; i < nrep; i++) {
+        rp[i].pool = o; rp[i].rd = *d; rp[i].rd.gpu_pending = 0;
+        if (pthread_create(&rp[i].th, NULL, replay_thread, &rp[i]) != 0) fatalf("cannot start a replay thread");
+    }
+    o->printed = 0;
+    int64_t numread = d->numread;
+    int floor_ = d->marker_floor;
+    carry_t C;
+    memset(&C, 0, sizeof C);
+    C.frozen_min = ~0ull; C.tid = -1;
+    /* groups of the contig being worked on: their replays start when the contig's depth array is complete (its last piece is in) */
+    pgroup** held = xcalloc((size_t)(o->n_claims ? o->n_claims : 1), sizeof(pgroup*));
+    int n_held = 0;
+    pgroup* chain = NULL;                   /* the same groups, for freeing them together */
+    int n_freeable = 0;
+    struct { pgroup* chain; int last_job; } *dead = xcalloc((size_t)(o->n_claims ? o->n_claims : 1), sizeof *dead);
+    /* multi-GPU with pieces of a contig walked by several ranks: no rank's depth array is complete before all ranks have walked
+     * all their pieces -- the contigs' replays wait for the sum (im_depth_allreduce) */
+    struct { pgroup** held; int n_held; pgroup* chain; } *late = (g_mg && g_mg->split) ? xcalloc((size_t)(o->n_claims ? o->n_claims : 1), sizeof *late) : NULL;
+    int n_late = 0;
+    for (int ci = 0; ci < o->n_claims; ci++) {
+        claim_t* c = &o->claims[ci];
+        if (g_mg && g_mg->claim_owner[ci] != g_mg->rank) continue;        /* another rank's contig */
+        g_mg_cur_tid = o->pieces[c->first].tid;
+        if (g_mg && g_mg->claim_walker[ci] != g_mg->rank) {
+            c->G = package_read(g_mg, ci, &S);
+            c->walked = 1; c->aborted = c->G == NULL;
+            if (c->aborted) pipeline_handoff();
+        } else if (o->serial) {
+            /* walked here, after the replay of the previous contig let go of the known-variant list */
+            const int32_t tid = o->pieces[c->first].tid;
+            known_free(&g_known);
+            read_variants(g_vcfname, tid, d->hdr->target_name[tid], &g_known);
+            if (g_known.n == 0) { pthread_mutex_lock(&o->mu); o->staged = ci + 1; pthread_mutex_unlock(&o->mu); continue; }   /* src/indelminer.c:788 */
+            g_main_in_walk = g_handoff_pool != NULL;
+            c->G = walk_claim(&o->w[0], o, c);
+            g_main_in_walk = 0;
+            c->walked = 1;
+        } else {
+            pthread_mutex_lock(&o->mu);
+            while (!c->walked) pthread_cond_wait(&o->cv, &o->mu);
+            pthread_mutex_unlock(&o->mu);
+            if (c->aborted) pipeline_handoff();
+        }
+        phase_time("waited for the walk (inflate + count; triage on the device)");
+        pgroup* G = c->G;
+        G->seq = ci;
+        const int first_of_contig = G->ctg[0].first, last_of_contig = G->ctg[G->n_ctg - 1].last;
+        const int floor_of_contig = (g_mg && first_of_contig) ? g_mg->floor[G->ctg[0].tid] : floor_;
+        static int contig_floor;            /* the floor all pieces of the contig in hand are measured against */
+        if (first_of_contig) contig_floor = floor_of_contig;
+        stage_take_front(G, &C);
+        g_main_in_walk = g_handoff_pool != NULL;        /* a record the reference dies on inside the pair table: hand the run over */
+        group_pair_table(d, G);
+        g_main_in_walk = 0;
+        if (!g_mg && group_meets_earlier_contigs(G)) {
+            if (g_handoff_pool) pipeline_handoff();
+            fatalf("read names are shared between contigs (the reference pairs them across contigs in its one pair table): run with INDELMINER_PIPELINE=host");
+        }
+        if (!G->from_package) group_flush_points(G, &numread);
+        group_resolve_flushes(G, &floor_);
+        stage_run_group(&S, G);
+        stage_leftovers(G, &C, contig_floor);
+        pthread_mutex_lock(&o->mu); o->staged = ci + 1; pthread_cond_broadcast(&o->cv); pthread_mutex_unlock(&o->mu);
+        G->next_of_contig = chain; chain = G;
+        held[n_held++] = G;
+        if (!last_of_contig) continue;
+        if (late) {
+            late[n_late].held = xmalloc(sizeof(pgroup*) * (size_t)n_held);
+            memcpy(late[n_late].held, held, sizeof(pgroup*) * (size_t)n_held);
+            late[n_late].n_held = n_held; late[n_late].chain = chain; n_late++;
+            n_held = 0; chain = NULL;
+            continue;
+        }
+        /* the contig (or the run of small contigs) is complete: its depth array, then its groups' replays */
+        for (int k = 0; k < n_held; k++)
+            for (int cj = 0; cj < held[k]->n_ctg; cj++)
+                if (held[k]->ctg[cj].last && g_region_tid < 0) GPU2(d, im_depth_scan(d->gpu, held[k]->ctg[cj].tid, S.stream));
+        GPU2(d, im_stream_sync(d->gpu, S.stream));
+        if (nrep) {
+            pthread_mutex_lock(&o->mu);
+            for (int k = 0; k < n_held; k++) {
+                rjob_t* J = &o->jobs[o->n_jobs];
+                J->G = held[k]; J->buf = NULL; J->len = 0; J->done = 0; J->last_of_contig = k == n_held - 1;
+                o->n_jobs++;
+            }
+            dead[n_freeable].chain = chain; dead[n_freeable].last_job = o->n_jobs - 1; n_freeable++;
+            pthread_cond_broadcast(&o->cv);
+            /* whatever is complete at the head of the queue goes out now */
+            while (o->printed < o->n_jobs && o->jobs[o->printed].done) {
+                rjob_t* P = &o->jobs[o->printed++];
+                pthread_mutex_unlock(&o->mu);
+                if (P->len && fwrite(P->buf, 1, P->len, OUT) != P->len) fatalf("write to stdout failed");
+                free(P->buf);
+                pthread_mutex_lock(&o->mu);
+            }
+            /* contigs whose every replay is done: their groups go */
+            for (int k = 0; k < n_freeable; k++) {
+                if (!dead[k].chain) continue;
+                int all = 1;
+                for (int j = k ? dead[k - 1].last_job + 1 : 0; j <= dead[k].last_job; j++) all &= o->jobs[j].done;
+                if (all) { pgroup* ch = dead[k].chain; dead[k].chain = NULL; pthread_mutex_unlock(&o->mu); groups_free_chain(ch); pthread_mutex_lock(&o->mu); }
+            }
+            pthread_mutex_unlock(&o->mu);
+        } else {
+            for (int k = 0; k < n_held; k++) group_replay(d, held[k]);
+            phase_time("replay (variants, merge, print)");
+            groups_free_chain(chain);
+        }
+        n_held = 0; chain = NULL;
+    }
+    if (late) {
+        /* every rank has walked what it walks (its walkers are done: the packages are out) and staged what it owns */
+        for (int i = 0; i < o->nw && !o->serial; i++) pthread_join(o->w[i].th, NULL);
+        mg_arm("the sum of the depth arrays");
+        GPU2(d, im_depth_allreduce(d->gpu, g_mg->comm));
+        mg_disarm();
+        phase_time("depth arrays summed over the ranks");
+        for (int k = 0; k < n_late; k++) {
+            for (int j = 0; j < late[k].n_held; j++)
+                for (int cj = 0; cj < late[k].held[j]->n_ctg; cj++)
+                    if (late[k].held[j]->ctg[cj].last) GPU2(d, im_depth_scan(d->gpu, late[k].held[j]->ctg[cj].tid, S.stream));
+            GPU2(d, im_stream_sync(d->gpu, S.stream));
+            for (int j = 0; j < late[k].n_held; j++) group_replay(d, late[k].held[j]);
+            groups_free_chain(late[k].chain);
+            free(late[k].held);
+        }
+        free(late);
+        phase_time("replay (variants, merge, print)");
+    }
+    if (nrep) {
+        pthread_mutex_lock(&o->mu);
+        o->jobs_closed = 1;
+        pthread_cond_broadcast(&o->cv);
+        while (o->printed < o->n_jobs) {
+            while (!o->jobs[o->printed].done) pthread_cond_wait(&o->cv, &o->mu);
+            rjob_t* P = &o->jobs[o->printed++];
+            pthread_mutex_unlock(&o->mu);
+            if (P->len && fwrite(P->buf, 1, P->len, OUT) != P->len) fatalf("write to stdout failed");
+            free(P->buf);
+            pthread_mutex_lock(&o->mu);
+        }
+        pthread_mutex_unlock(&o->mu);
+        for (int i = 0; i < nrep; i++) pthread_join(rp[i].th, NULL);
+        fflush(OUT);
+        fflush(stdout);
+        phase_time("replay workers drained");
+        if (getenv("INDELMINER_TIDY_EXIT")) for (int k = 0; k < n_freeable; k++) if (dead[k].chain) groups_free_chain(dead[k].chain);
+        free(rp);
+    }
+    free(o->jobs); o->jobs = NULL; free(held); free(dead);
+    d->numread = numread;
+    if (g_handoff_pool) { g_handoff_pool = NULL; if (t_out) { fflush(t_out); fclose(t_out); t_out = NULL; } }
+    for (int i = 0; i < o->nw && !o->serial && !g_onepass && !(g_mg && g_mg->split); i++) pthread_join(o->w[i].th, NULL);
+    /* the walkers' pinned rings and device arrays go with the process unless a tidy exit is asked for (leak checkers):
+     * un-pinning and freeing them costs more than the whole device stage of a run */
+    if (getenv("INDELMINER_TIDY_EXIT")) {
+        for (int i = 0; i < o->nw; i++) {
+            walker_t* W = &o->w[i];
+            pipe_destroy(&W->P);
+            bam_header_free(W->hdr);
+            bgzf_close(W->r);
+        }
+        pipe_destroy(&S);
+        pair_table_clear(d);
+        free(C.live.v); free(C.frozen.v);
+        free(o->w); free(o->claims); free(o->pieces);
+        free(o);
+    }
+}
+
+/* main thread, at the first group the reference does not survive: the groups in front go out, then the child takes over */
+static void pipeline_handoff(void)
+{
+    walkpool_t* o = g_handoff_pool;
+    if (g_mg) {
+        /* this rank's parts in front of the claim it is working on are complete; the flag names the claim's first contig and
+         * rank 0, once every rank has reported, prints what lies in front of the smallest such contig and hands over */
+        g_mg->abort_tid = g_mg_cur_tid;
+        mg_finish(g_mg, g_mg_driver);           /* rank 0 does not come back from this */
+        fflush(stderr);
+        _exit(EXIT_SUCCESS);
+    }
+    if (o->jobs) {
+        pthread_mutex_lock(&o->mu);
+        while (o->printed < o->n_jobs) {
+            while (!o->jobs[o->printed].done) pthread_cond_wait(&o->cv, &o->mu);
+            rjob_t* P = &o->jobs[o->printed++];
+            pthread_mutex_unlock(&o->mu);
+            if (P->len && fwrite(P->buf, 1, P->len, OUT) != P->len) fatalf("write to stdout failed");
+            pthread_mutex_lock(&o->mu);
+        }
+        pthread_mutex_unlock(&o->mu);
+    }
+    handoff_to_host_child();
+}

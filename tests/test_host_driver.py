@@ -38,7 +38,9 @@ def _build_shim():
             os.path.join(ROOT, "indelminer_amd", "host", "iminflate.c"),
             os.path.join(ROOT, "tests", "shim", "im_shim.c"), os.path.join(ROOT, "oracle", "im_oracle.c"),
             os.path.join(ROOT, "oracle", "im_oracle_triage.c")]
-    if os.path.exists(SHIM) and all(os.path.getmtime(s) <= os.path.getmtime(SHIM) for s in srcs):
+    from indelminer_amd import build
+    parts = [os.path.join(ROOT, "indelminer_amd", "host", q) for q in build.HOST_PARTS]      # included by imhost.c
+    if os.path.exists(SHIM) and all(os.path.getmtime(s) <= os.path.getmtime(SHIM) for s in srcs + parts):
         return SHIM
     subprocess.check_call(["gcc", "-O2", "-std=c11", "-pthread", "-I" + os.path.join(ROOT, "include"),
                            "-I" + os.path.join(ROOT, "indelminer_amd", "host"), "-o", SHIM] + srcs + ["-lz", "-lm"])
