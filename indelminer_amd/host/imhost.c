@@ -127,13 +127,23 @@ static void handoff_to_host_child(void)
 {
     if (t_out) fflush(t_out);
     fflush(stdout);
-    char skip[32];
-    snprintf(skip, sizeof skip, "%lld", (long long)g_out_bytes);
-    setenv("INDELMINER_PIPELINE", "host", 1);
-    setenv("INDELMINER_SKIP_STDOUT", skip, 1);
+    /* the child's environment is a private copy: other threads (walkers, replay workers) may be inside getenv, and setenv
+     * moves the block they read */
+    char skip[64];
+    snprintf(skip, sizeof skip, "INDELMINER_SKIP_STDOUT=%lld", (long long)g_out_bytes);
+    size_t n_env = 0;
+    while (environ[n_env]) n_env++;
+    char** envp = malloc(sizeof(char*) * (n_env + 3));
+    if (!envp) _exit(EXIT_FAILURE);
+    size_t k = 0;
+    for (size_t i = 0; i < n_env; i++)
+        if (strncmp(environ[i], "INDELMINER_PIPELINE=", 20) != 0 && strncmp(environ[i], "INDELMINER_SKIP_STDOUT=", 23) != 0) envp[k++] = environ[i];
+    envp[k++] = (char*)"INDELMINER_PIPELINE=host";
+    envp[k++] = skip;
+    envp[k] = NULL;
     pid_t pid;
     if (getenv("INDELMINER_DEBUG_HANDOFF")) fprintf(stderr, "[handoff] %lld bytes printed, starting the child\n", (long long)g_out_bytes);
-    if (posix_spawn(&pid, "/proc/self/exe", NULL, NULL, g_argv, environ) != 0) { fprintf(stderr, "indelminer: cannot start the record-at-a-time run\n"); _exit(EXIT_FAILURE); }
+    if (posix_spawn(&pid, "/proc/self/exe", NULL, NULL, g_argv, envp) != 0) { fprintf(stderr, "indelminer: cannot start the record-at-a-time run\n"); _exit(EXIT_FAILURE); }
     int status = 0;
     while (waitpid(pid, &status, 0) < 0 && errno == EINTR) { }
     if (getenv("INDELMINER_DEBUG_HANDOFF")) fprintf(stderr, "[handoff] child status 0x%x\n", status);
