@@ -343,6 +343,44 @@ def test_product_abort_in_a_later_group_prints_what_the_reference_has_printed(tm
     _abort_in_a_later_group(_product(), tmp_path)
 
 
+def _many_indels_in_one_read(binary, tmp_path, envs, expect_handoff=False):
+    """a proper-pair read whose CIGAR carries FIVE insertions / deletions that pass check_variants' end-distance rule
+    (src/indelminer.c:285-337, no bound there): the kernels hold IM_MAX_EV = 4 per read (IM_REC_ERR_LIMIT), the run goes to the
+    record-at-a-time child, which has no such bound -- the reference's output comes out whole"""
+    import numpy as np
+    from indelminer_amd import bamwrite, synth
+    refs, rd = synth.simulate(seed=14, ref_len=60_000, coverage=12, n_contigs=3, big_every=5)
+    width = 11
+    op = np.zeros((rd.n, width), dtype=rd.cig_op.dtype); ln = np.zeros((rd.n, width), dtype=rd.cig_len.dtype)
+    op[:, :rd.cig_op.shape[1]] = rd.cig_op; ln[:, :rd.cig_len.shape[1]] = rd.cig_len
+    idx = [i for i in range(rd.n) if rd.tid[i] == 1 and (rd.flag[i] & 0x3) == 0x3 and rd.ncig[i] == 1 and 20_000 < rd.pos[i] < 30_000][7]
+    # 100 read bases: 16M 1I 16M 2D 16M 1I 16M 2D 16M 1I 17M
+    ops = [(0, 16), (1, 1), (0, 16), (2, 2), (0, 16), (1, 1), (0, 16), (2, 2), (0, 16), (1, 1), (0, 17)]
+    assert sum(l for o, l in ops if o != 2) == rd.seq.shape[1]
+    for j, (o, l) in enumerate(ops):
+        op[idx, j] = o; ln[idx, j] = l
+    rd.cig_op, rd.cig_len = op, ln
+    rd.ncig = rd.ncig.copy(); rd.ncig[idx] = len(ops)
+    contigs = [("ctg%d" % i, len(r)) for i, r in enumerate(refs)]
+    bamwrite.write_fasta(str(tmp_path / "ref.fa"), contigs, refs)
+    bamwrite.write_bam(str(tmp_path / "aln.bam"), contigs, rd)
+    (tmp_path / "cfg.txt").write_text("IL generic 300 700\n")
+    d = str(tmp_path)
+    want = _run(_build_shim(), ["-i", "cfg.txt"], d, ref="ref.fa", bam="aln.bam", env={"INDELMINER_PIPELINE": "host"})
+    ref_bin = os.path.join(ROOT, "oracle", "_ref", "indelminer")
+    if os.path.exists(ref_bin):
+        assert _run(ref_bin, ["-i", "cfg.txt"], d, ref="ref.fa", bam="aln.bam") == want
+    assert want.count(b"\nctg1\t") > 5 and want.count(b"\nctg2\t") > 5
+    for env in envs:
+        assert _run(binary, ["-i", "cfg.txt"], d, ref="ref.fa", bam="aln.bam", env=env) == want, env
+    if expect_handoff:
+        assert b"[handoff]" in _stderr_of(binary, ["-i", "cfg.txt"], d, env={"INDELMINER_DEBUG_HANDOFF": "1"})
+
+
+def test_host_read_with_more_indels_than_the_kernels_hold(tmp_path):
+    _many_indels_in_one_read(_build_shim(), tmp_path, ({}, {"INDELMINER_CLAIM_BASES": "1", "INDELMINER_WALKERS": "3"}))
+
+
 def test_host_contigs_without_reads(tmp_path):
     """contigs that deliver no record at all -- the first, one in the middle, the last -- between contigs that do: claims,
     groups and flush placement must not mind (the read counter and the marker floor simply pass through them)"""
@@ -789,6 +827,11 @@ def test_product_contigs_walked_in_pieces_and_region_runs(synth_small, synth_1mb
 @pytest.mark.gpu
 def test_product_rejects_long_read_library_at_startup(tmp_path):
     _rejects_long_reads(_product(), tmp_path)
+
+
+@pytest.mark.gpu
+def test_product_read_with_more_indels_than_the_kernels_hold(tmp_path):
+    _many_indels_in_one_read(_product(), tmp_path, ({}, {"INDELMINER_CLAIM_BASES": "1", "INDELMINER_WALKERS": "3"}, {"INDELMINER_ONEPASS": "0"}), expect_handoff=True)
 
 
 @pytest.mark.gpu
