@@ -419,8 +419,9 @@ def end_to_end(refs, rd):
 
 def end_to_end_multi(rank, world, local_rank, dist, ref_len=2_000_000):
     """The PRODUCT on all the job's GPUs: every rank starts `indelminer` as a child with its own
-    RANK / LOCAL_RANK / WORLD_SIZE on one BAM of max(world, 2) contigs -- contigs tid % world per rank, one RCCL all-gather
-    of shard summaries, rank 0 prints the VCF -- and rank 0 compares that VCF byte for byte with the single-process run.
+    RANK / LOCAL_RANK / WORLD_SIZE on one BAM of two contigs cut into about 3 x world pieces -- contigs owned longest-first,
+    pieces walked by the least-loaded rank and shipped to the owner, one RCCL all-gather of the ranks' pre-walk logs, one sum of
+    the depth arrays, rank 0 prints the VCF -- and rank 0 compares that VCF byte for byte with the single-process run.
     Reported beside the kernel-level numbers, never `value`; a failure here never touches the line's other fields."""
     import shutil
     import subprocess
@@ -546,11 +547,11 @@ def shard3_measure(device, steps=24, warmup=4):
                 "steps": steps, "ms_per_step": elapsed / steps * 1e3, "reads_per_s": rd.n * steps / elapsed,
                 "candidates_per_s": len(cand["index"]) * steps / elapsed,
                 "band_alignments_per_s": n_band * steps / elapsed, "gcups": 2.0 * L * n_band * steps / elapsed / 1e9,
-                "realign": {"avg_launch_ms": q_realign, "avg_launch_ms_inside_the_overlapped_steps": float(realign_ms.mean()),
+                "realign": {"avg_launch_ms": q_realign, "avg_launch_ms_inside_the_overlapped_steps": float(realign_ms.mean()) if len(realign_ms) else None,
                             "algorithmic_bytes_per_launch": alg, "achieved_gbs": ach,
                             "frac_of_hbm_peak": ach / HBM_PEAK_GBS,
                             "occupancy_rounds": len(cand["index"]) / (256.0 * 24)},
-                "triage": {"avg_ms_3_launches": q_triage, "avg_ms_inside_the_overlapped_steps": float(triage_ms.mean()),
+                "triage": {"avg_ms_3_launches": q_triage, "avg_ms_inside_the_overlapped_steps": float(triage_ms.mean()) if len(triage_ms) else None,
                            "algorithmic_bytes_per_launch": int(tri_bytes), "achieved_gbs": tri_bytes / (q_triage * 1e-3) / 1e9}}
     finally:
         ctx.close()
@@ -748,8 +749,8 @@ def main():
                          "avg_launch_ms_note": "HIP events around the realign launch on its stream with nothing else on the device (the kernel's own "
                                                "duration, what rocprofv3 --kernel-trace reports for it); inside the timed region's overlapped steps the same "
                                                "bracket also holds the wait for a dispatch slot behind the other streams' launches",
-                         "avg_launch_ms_inside_the_overlapped_steps": float(realign_ms.mean()), "launches_timed_inside": int(len(realign_ms)),
-                         "min_launch_ms_inside": float(realign_ms.min()),
+                         "avg_launch_ms_inside_the_overlapped_steps": float(realign_ms.mean()) if len(realign_ms) else None, "launches_timed_inside": int(len(realign_ms)),
+                         "min_launch_ms_inside": float(realign_ms.min()) if len(realign_ms) else None,
                          "peak_measured_copy_gbs": peak_measured,
                          "frac_of_measured_copy": (achieved / peak_measured) if peak_measured else None,
                          "triage": {"algorithmic_bytes_per_launch": int(tri_bytes), "avg_ms_3_launches": q_triage,

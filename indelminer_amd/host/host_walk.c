@@ -365,6 +365,9 @@ static walkpool_t* walkpool_start(driver* d)
             for (int k = 0; k < c->count; k++) m->piece_walker[c->first + k] = best;
             if (best != own) m->split = 1;
         }
+        /* INDELMINER_MG_FORCE_SPLIT=1 (tests): treat the run as one whose contigs were walked by several ranks -- the replays wait
+         * for the sum of the depth arrays (im_depth_allreduce) -- also with one rank, where the sum changes nothing */
+        if (getenv("INDELMINER_MG_FORCE_SPLIT")) m->split = 1;
         free(load);
     }
     if (nw > o->n_claims) nw = o->n_claims ? o->n_claims : 1;

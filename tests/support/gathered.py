@@ -1,22 +1,7 @@
-"""Host-side sharding rules of the multi-GPU design.
-
-The path shards by contig: the reference itself shows that per-contig (-c) runs
-concatenate to the single-run output (src/indelminer.c:536-542,711-713,796-802).
-Rank r owns the contigs with tid % world == r; nothing is exchanged until every
-rank holds its cluster list; one all-gather of fixed-capacity record buffers
-(16-byte records, see im_dev_cluster_records) makes the lists global, and every
-rank (rank 0 prints) orders them by (tid, b1, b2) -- the order in which the
-single-process run meets them (contig loop, then sort_variants).
-"""
+"""Host-side twin of im_dev_cluster_records and of the merge of all-gathered record buffers (test helper for
+tests/test_gpu_cluster.py::test_cluster_records_and_rccl_allgather_world1; the product's multi-rank path is
+indelminer_amd/host/host_multirank.c, covered by tests/test_multi_rank_driver.py)."""
 import numpy as np
-
-
-def contigs_of_rank(n_contigs, rank, world):
-    return [t for t in range(n_contigs) if t % world == rank]
-
-
-def owner_of_contig(tid, world):
-    return tid % world
 
 
 def pack_records(tid, keys_b1, keys_b2, cls, support, n_live, cap):

@@ -126,7 +126,8 @@ def test_cluster_slots_matches_oracle(gpu_ctx, path):
 def test_cluster_records_and_rccl_allgather_world1(gpu_ctx):
     """The gathered unit (16 B cluster records) and the RCCL all-gather entry point with one rank."""
     import ctypes as C
-    from indelminer_amd import capi, shard
+    from indelminer_amd import capi
+    from tests.support import gathered as shard
     L = capi.lib()
     n = 3000
     cls, b1, b2 = _random_evidence(77, n, 40000)
