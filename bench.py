@@ -446,7 +446,8 @@ def end_to_end_multi(rank, world, local_rank, dist, ref_len=2_000_000):
     cmd = [build.HOST_BIN, "-i", "cfg.txt", "ref.fa", "s=aln.bam"]
     # pieces small enough that every rank gets several (the default piece size is for files of gigabytes)
     env = dict(os.environ, RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(local_rank), INDELMINER_RENDEZVOUS=td + "/rdv", INDELMINER_RUN_TOKEN=td,
-               INDELMINER_PIECE_BYTES=str(max(bam_bytes // (3 * max(world, 1)), 200000)))
+               INDELMINER_PIECE_BYTES=str(max(bam_bytes // (3 * max(world, 1)), 200000)),
+               INDELMINER_MG_TIMEOUT="90")            # a rank that waits longer than that for the others gives up (default 600 s)
     if world == 1:
         env["INDELMINER_FORCE_MGPU"] = "1"
     if os.environ.get("IM_BENCH_ONE_DEVICE") == "1":
@@ -455,7 +456,7 @@ def end_to_end_multi(rank, world, local_rank, dist, ref_len=2_000_000):
            "walked groups shipped to the contig's owner, one all-gather of the ranks' logs + one sum of the depth arrays" % n_ctg}
     t = time.perf_counter()
     try:
-        p = subprocess.run(cmd, cwd=td, stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env, timeout=300)
+        p = subprocess.run(cmd, cwd=td, stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env, timeout=200)
         rc, vcf, err = p.returncode, p.stdout, p.stderr[-400:].decode(errors="replace")
     except Exception as ex:
         rc, vcf, err = -1, b"", str(ex)

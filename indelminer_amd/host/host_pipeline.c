@@ -121,6 +121,7 @@ typedef struct {
     int32_t cap_cand; int64_t cap_bases; int32_t cap_pe, cap_fl;
     void *bases, *boff, *len, *tid, *anchor, *range, *res, *cls, *b1, *b2, *consumed, *cand_rec, *counters, *cut;
     void *rstat, *rslot, *rcompact, *rcount; int32_t cap_rc;    /* im_dev_compact_results of the stage pipeline */
+    void* h_stage; size_t h_stage_cap;                          /* pinned block the stage's results arrive in */
     void *order, *clkey, *clfirst, *clcount, *counts, *gscratch, *fdesc, *fgscratch; size_t gscratch_bytes, fgscratch_bytes;
     /* confirmed by harvested chunks / still in flight */
     int32_t conf_cand, conf_err; int64_t conf_bytes, fly_recs, fly_seq;
@@ -227,6 +228,7 @@ static void pipe_destroy(ppipe* P)
     pipe_free_cands(P);
     if (P->rstat) { im_dev_free(P->d->gpu, P->rstat); im_dev_free(P->d->gpu, P->rslot); im_dev_free(P->d->gpu, P->rcompact); }
     if (P->rcount) im_dev_free(P->d->gpu, P->rcount);
+    if (P->h_stage) im_host_free(P->d->gpu, P->h_stage);
     im_dev_free(P->d->gpu, P->counters); im_dev_free(P->d->gpu, P->counts); im_dev_free(P->d->gpu, P->cut); im_dev_free(P->d->gpu, P->fdesc);
     if (P->own_stream) im_stream_destroy(P->d->gpu, P->stream);
     P->ready = 0;
@@ -675,32 +677,45 @@ static void stage_run_group(ppipe* P, pgroup* G)
         for (int k = 0; k < 10; k++) if (dst[k] && bytes[k] && G->sv[k]) GPU(im_dev_copy_async(g, dst[k], G->sv[k], bytes[k], P->stream));
         if (G->sv_range && n_own) GPU(im_dev_upload_async(g, (char*)P->range + 4 * nK, G->sv_range, 4 * nO, P->stream));    /* one-pass: known only now */
     }
-    /* record numbers: the front's, then the own ones counted on from n_virt; the front's slots */
+    /* What the host adds -- record numbers (the front's, then the own ones counted on from n_virt), the front's slots, the
+     * counters, the paired-read entries, the flush list -- is put together in the pinned block and goes up on the stage's stream
+     * (the block is not touched again before the stage's wait at the end). */
+    const size_t up_rec = 0, up_cls = up_rec + ((4 * ((size_t)nc + 1) + 255) & ~(size_t)255), up_b1 = up_cls + 16 * nK, up_b2 = up_b1 + 16 * nK,
+                 up_cnt = (up_b2 + 16 * nK + 255) & ~(size_t)255, up_pe = up_cnt + 256, up_fd = (up_pe + 12 * (size_t)G->n_pe + 255) & ~(size_t)255,
+                 up_end = up_fd + sizeof(im_flush_desc) * (size_t)(G->n_fl ? G->n_fl : 1);
     {
-        int32_t* t = xmalloc(4 * ((size_t)nc + 1) + 12 * nK * IM_MAX_EV + 64);
+        if (!P->h_stage) { P->h_stage_cap = 1 << 20; GPU(im_host_alloc(g, P->h_stage_cap, &P->h_stage)); }
+        if (up_end > P->h_stage_cap) {
+            GPU(im_stream_sync(g, P->stream));
+            im_host_free(g, P->h_stage);
+            while (P->h_stage_cap < up_end) P->h_stage_cap *= 2;
+            GPU(im_host_alloc(g, P->h_stage_cap, &P->h_stage));
+        }
+        char* hb = P->h_stage;
+        int32_t* t = (int32_t*)(hb + up_rec);
         for (int32_t q = 0; q < K; q++) t[q] = G->front_virt[q];
         for (int32_t i = 0; i < n_own; i++) t[K + i] = G->cand_rec[i] + G->n_virt;
-        if (nc) GPU(im_dev_upload(g, P->cand_rec, t, 4 * (size_t)nc));
+        if (nc) GPU(im_dev_upload_async(g, P->cand_rec, t, 4 * (size_t)nc, P->stream));
         if (K) {
-            int32_t *c = t + nc + 1, *x1 = c + nK * IM_MAX_EV, *x2 = x1 + nK * IM_MAX_EV;
+            int32_t *c = (int32_t*)(hb + up_cls), *x1 = (int32_t*)(hb + up_b1), *x2 = (int32_t*)(hb + up_b2);
             for (int32_t q = 0; q < K; q++)
                 for (int k = 0; k < IM_MAX_EV; k++) { c[q * IM_MAX_EV + k] = G->front[q].cls[k]; x1[q * IM_MAX_EV + k] = G->front[q].b1[k]; x2[q * IM_MAX_EV + k] = G->front[q].b2[k]; }
-            GPU(im_dev_upload(g, P->cls, c, 16 * nK)); GPU(im_dev_upload(g, P->b1, x1, 16 * nK)); GPU(im_dev_upload(g, P->b2, x2, 16 * nK));
+            GPU(im_dev_upload_async(g, P->cls, c, 16 * nK, P->stream)); GPU(im_dev_upload_async(g, P->b1, x1, 16 * nK, P->stream));
+            GPU(im_dev_upload_async(g, P->b2, x2, 16 * nK, P->stream));
         }
-        free(t);
-        int32_t cnt[16] = { 0 };
+        int32_t* cnt = (int32_t*)(hb + up_cnt);
+        memset(cnt, 0, 64);
         cnt[0] = nc;
-        GPU(im_dev_upload(g, P->counters, cnt, 64));
-    }
-    if (G->n_pe > 0) {
-        /* paired-read entries (class 2) behind the split-read slots: pending ones of earlier pieces first; an entry without an
-         * evidence object stands for the entries that wait for the contig's end (stage_leftovers) and carries their smallest key */
-        int32_t* t = xmalloc(sizeof(int32_t) * 3 * (size_t)G->n_pe);
-        for (int32_t i = 0; i < G->n_pe; i++) { t[i] = 2; t[G->n_pe + i] = G->pe[i]->b1; t[2 * (size_t)G->n_pe + i] = G->pe[i]->b2; }
-        GPU(im_dev_upload(g, (char*)P->cls + 4 * pe_base, t, 4 * (size_t)G->n_pe));
-        GPU(im_dev_upload(g, (char*)P->b1 + 4 * pe_base, t + G->n_pe, 4 * (size_t)G->n_pe));
-        GPU(im_dev_upload(g, (char*)P->b2 + 4 * pe_base, t + 2 * (size_t)G->n_pe, 4 * (size_t)G->n_pe));
-        free(t);
+        GPU(im_dev_upload_async(g, P->counters, cnt, 64, P->stream));
+        if (G->n_pe > 0) {
+            /* paired-read entries (class 2) behind the split-read slots: pending ones of earlier pieces first; an entry without an
+             * evidence object stands for the entries that wait for the contig's end (stage_leftovers) and carries their smallest key */
+            int32_t* e = (int32_t*)(hb + up_pe);
+            for (int32_t i = 0; i < G->n_pe; i++) { e[i] = 2; e[G->n_pe + i] = G->pe[i]->b1; e[2 * (size_t)G->n_pe + i] = G->pe[i]->b2; }
+            GPU(im_dev_upload_async(g, (char*)P->cls + 4 * pe_base, e, 4 * (size_t)G->n_pe, P->stream));
+            GPU(im_dev_upload_async(g, (char*)P->b1 + 4 * pe_base, e + G->n_pe, 4 * (size_t)G->n_pe, P->stream));
+            GPU(im_dev_upload_async(g, (char*)P->b2 + 4 * pe_base, e + 2 * (size_t)G->n_pe, 4 * (size_t)G->n_pe, P->stream));
+        }
     }
     /* The flush list of the group, in file order, and the split-read group-by.  Within a contig the markers never decrease
      * (find_marker is a minimum over pair-table entries that leave the table or enter it at the current position of a
@@ -708,7 +723,8 @@ static void stage_run_group(ppipe* P, pgroup* G)
      * list and the group-by (im_dev_flush_groupby).  A BAM whose positions run backwards inside a contig can break that;
      * such a group takes the sequential forms: one workgroup walking the list, or one launch pair per flush when no
      * mid-contig flush consumes anything and the pending ranges grow long. */
-    im_flush_desc* fd = xcalloc((size_t)(G->n_fl ? G->n_fl : 1), sizeof(im_flush_desc));
+    im_flush_desc* fd = (im_flush_desc*)((char*)P->h_stage + up_fd);
+    memset(fd, 0, sizeof(im_flush_desc) * (size_t)(G->n_fl ? G->n_fl : 1));
     int64_t longest = 0;
     int monotone = 1;
     for (int ci = 0; ci < G->n_ctg; ci++) {
@@ -739,7 +755,7 @@ static void stage_run_group(ppipe* P, pgroup* G)
         bt.ev_cls = (int32_t*)P->cls + nK * IM_MAX_EV; bt.ev_b1 = (int32_t*)P->b1 + nK * IM_MAX_EV; bt.ev_b2 = (int32_t*)P->b2 + nK * IM_MAX_EV;
         GPU(im_dev_realign_keep(g, &prm, &bt, P->stream));
     }
-    if (!per_flush && G->n_fl) GPU(im_dev_upload(g, P->fdesc, fd, sizeof(im_flush_desc) * (size_t)G->n_fl));    /* synchronous: complete before the launches below */
+    if (!per_flush && G->n_fl) GPU(im_dev_upload_async(g, P->fdesc, fd, sizeof(im_flush_desc) * (size_t)G->n_fl, P->stream));
     if (wide) {
         GPU(im_dev_flush_groupby(g, (const im_flush_desc*)P->fdesc, G->n_fl, P->cls, P->b1, P->b2, P->consumed, P->cand_rec, P->counters, nc,
                                  (int32_t)pe_base, G->n_pe, O.tie_desc, P->order, P->clkey, P->clfirst, P->clcount, P->counts,
@@ -757,7 +773,6 @@ static void stage_run_group(ppipe* P, pgroup* G)
         GPU(im_dev_cluster_groupby(g, nc * IM_MAX_EV, P->cls, P->b1, P->b2, P->consumed, O.tie_desc,
                                    P->order, P->clkey, P->clfirst, P->clcount, P->counts, P->gscratch, P->gscratch_bytes, P->stream));
     }
-    free(fd);
     if (n_own > 0) {
         /* only the realigned records that hold evidence travel whole (im_dev_compact_results) */
         if (n_own > P->cap_rc) {
@@ -774,39 +789,59 @@ static void stage_run_group(ppipe* P, pgroup* G)
     phase_time("device: realign + flush cuts + group-by");
 
     const size_t nn = (size_t)(nc ? nc : 1);
+    /* Results to the host: the counts first, then every array with ONE asynchronous copy into a pinned block and one wait -- a
+     * plain hipMemcpy into freshly allocated pageable memory pins and un-pins the destination per call (a few hundred
+     * microseconds each; a dozen arrays per group, hundreds of groups). */
     int32_t n_evd = 0;
+    int32_t counts[2] = { 0, 0 };
+    {
+        if (!P->h_stage) { P->h_stage_cap = 1 << 20; GPU(im_host_alloc(g, P->h_stage_cap, &P->h_stage)); }
+        int32_t* hc = P->h_stage;
+        hc[0] = 0;
+        if (n_own > 0) GPU(im_dev_download_async(g, hc, P->rcount, 4, P->stream));
+        GPU(im_dev_download_async(g, hc + 2, P->counts, 8, P->stream));
+        GPU(im_stream_sync(g, P->stream));
+        n_evd = hc[0]; counts[0] = hc[2]; counts[1] = hc[3];
+    }
+    G->n_cl = counts[0]; G->n_nodes = counts[1];
     int32_t* rstat = xmalloc(4 * (size_t)(n_own ? n_own : 1));
-    if (n_own > 0) GPU(im_dev_download(g, &n_evd, P->rcount, 4));
     G->res = xrealloc(G->res, sizeof(im_read_result) * (size_t)(n_evd ? n_evd : 1));
     G->res_slot = xrealloc(G->res_slot, 4 * (size_t)(n_own ? n_own : 1));
     G->s_cls = xrealloc(G->s_cls, 4 * nn * IM_MAX_EV); G->s_b1 = xrealloc(G->s_b1, 4 * nn * IM_MAX_EV); G->s_b2 = xrealloc(G->s_b2, 4 * nn * IM_MAX_EV);
     G->cons_sr = xrealloc(G->cons_sr, 4 * nn * IM_MAX_EV);
     G->cons_pe = xrealloc(G->cons_pe, 4 * (size_t)(G->n_pe ? G->n_pe : 1));
-    int32_t counts[2] = { 0, 0 };
-    if (n_own > 0) {
-        GPU(im_dev_download(g, rstat, P->rstat, 4 * nO));
-        GPU(im_dev_download(g, G->res_slot, P->rslot, 4 * nO));
-        if (n_evd > 0) GPU(im_dev_download(g, G->res, P->rcompact, sizeof(im_read_result) * (size_t)n_evd));
-    }
-    if (nc > 0) {
-        GPU(im_dev_download(g, G->s_cls, P->cls, 4 * (size_t)nc * IM_MAX_EV));
-        GPU(im_dev_download(g, G->s_b1, P->b1, 4 * (size_t)nc * IM_MAX_EV));
-        GPU(im_dev_download(g, G->s_b2, P->b2, 4 * (size_t)nc * IM_MAX_EV));
-        GPU(im_dev_download(g, G->cons_sr, P->consumed, 4 * (size_t)nc * IM_MAX_EV));
-    }
-    if (G->n_pe > 0) GPU(im_dev_download(g, G->cons_pe, (char*)P->consumed + 4 * pe_base, 4 * (size_t)G->n_pe));
-    GPU(im_dev_download(g, counts, P->counts, 8));
-    G->n_cl = counts[0]; G->n_nodes = counts[1];
     G->cl_key = xrealloc(G->cl_key, 16 * (size_t)(G->n_cl ? G->n_cl : 1));
     G->cl_first = xrealloc(G->cl_first, 4 * (size_t)(G->n_cl ? G->n_cl : 1));
     G->cl_count = xrealloc(G->cl_count, 4 * (size_t)(G->n_cl ? G->n_cl : 1));
     G->cl_sorted = xrealloc(G->cl_sorted, 4 * (size_t)(G->n_cl ? G->n_cl : 1));
     G->order = xrealloc(G->order, 4 * (size_t)(G->n_nodes ? G->n_nodes : 1));
-    if (G->n_cl > 0) {
-        GPU(im_dev_download(g, G->cl_key, P->clkey, 16 * (size_t)G->n_cl));
-        GPU(im_dev_download(g, G->cl_first, P->clfirst, 4 * (size_t)G->n_cl));
-        GPU(im_dev_download(g, G->cl_count, P->clcount, 4 * (size_t)G->n_cl));
-        GPU(im_dev_download(g, G->order, P->order, 4 * (size_t)G->n_nodes));
+    {
+        const size_t nslb = 4 * (size_t)nc * IM_MAX_EV, ncl = (size_t)G->n_cl;
+        struct { void* dst; const void* src; size_t bytes; } job[13] = {
+            { rstat, P->rstat, n_own > 0 ? 4 * nO : 0 }, { G->res_slot, P->rslot, n_own > 0 ? 4 * nO : 0 },
+            { G->res, P->rcompact, sizeof(im_read_result) * (size_t)n_evd },
+            { G->s_cls, P->cls, nslb }, { G->s_b1, P->b1, nslb }, { G->s_b2, P->b2, nslb }, { G->cons_sr, P->consumed, nslb },
+            { G->cons_pe, (char*)P->consumed + 4 * pe_base, 4 * (size_t)G->n_pe },
+            { G->cl_key, P->clkey, 16 * ncl }, { G->cl_first, P->clfirst, 4 * ncl }, { G->cl_count, P->clcount, 4 * ncl },
+            { G->order, P->order, ncl ? 4 * (size_t)G->n_nodes : 0 }, { NULL, NULL, 0 } };
+        size_t total = 0;
+        for (int k = 0; job[k].dst; k++) total += (job[k].bytes + 255) & ~(size_t)255;
+        if (total > P->h_stage_cap) {
+            im_host_free(g, P->h_stage);
+            while (P->h_stage_cap < total) P->h_stage_cap *= 2;
+            GPU(im_host_alloc(g, P->h_stage_cap, &P->h_stage));
+        }
+        size_t at = 0;
+        for (int k = 0; job[k].dst; k++) {
+            if (job[k].bytes) GPU(im_dev_download_async(g, (char*)P->h_stage + at, job[k].src, job[k].bytes, P->stream));
+            at += (job[k].bytes + 255) & ~(size_t)255;
+        }
+        GPU(im_stream_sync(g, P->stream));
+        at = 0;
+        for (int k = 0; job[k].dst; k++) {
+            if (job[k].bytes) memcpy(job[k].dst, (char*)P->h_stage + at, job[k].bytes);
+            at += (job[k].bytes + 255) & ~(size_t)255;
+        }
     }
     /* the device groups; the host puts the few clusters in (flush, b1, b2, class) order */
     for (int32_t i = 0; i < G->n_cl; i++) G->cl_sorted[i] = i;
