@@ -109,6 +109,9 @@ int main(int argc, char** argv)
         /* the record-at-a-time child of a pipeline run the reference aborts: its first bytes are on stdout already, and so is
          * everything it has to say on stderr until something goes wrong */
         const char* sk = getenv("INDELMINER_SKIP_STDOUT");
+        const char* from = getenv("INDELMINER_HANDOFF_PARENT");       /* only the process that started this one may ask for it: a value
+                                                                        * that leaked into somebody's environment drops nothing */
+        if (sk && !(from && (long)getppid() == atol(from))) sk = NULL;
         if (sk) {
             g_out_skip = atoll(sk);
             unsetenv("INDELMINER_SKIP_STDOUT");

@@ -129,17 +129,20 @@ static void handoff_to_host_child(void)
     fflush(stdout);
     /* the child's environment is a private copy: other threads (walkers, replay workers) may be inside getenv, and setenv
      * moves the block they read */
-    char skip[64];
+    char skip[64], from[64];
     snprintf(skip, sizeof skip, "INDELMINER_SKIP_STDOUT=%lld", (long long)g_out_bytes);
+    snprintf(from, sizeof from, "INDELMINER_HANDOFF_PARENT=%ld", (long)getpid());
     size_t n_env = 0;
     while (environ[n_env]) n_env++;
-    char** envp = malloc(sizeof(char*) * (n_env + 3));
+    char** envp = malloc(sizeof(char*) * (n_env + 4));
     if (!envp) _exit(EXIT_FAILURE);
     size_t k = 0;
     for (size_t i = 0; i < n_env; i++)
-        if (strncmp(environ[i], "INDELMINER_PIPELINE=", 20) != 0 && strncmp(environ[i], "INDELMINER_SKIP_STDOUT=", 23) != 0) envp[k++] = environ[i];
+        if (strncmp(environ[i], "INDELMINER_PIPELINE=", 20) != 0 && strncmp(environ[i], "INDELMINER_SKIP_STDOUT=", 23) != 0 &&
+            strncmp(environ[i], "INDELMINER_HANDOFF_PARENT=", 26) != 0) envp[k++] = environ[i];
     envp[k++] = (char*)"INDELMINER_PIPELINE=host";
     envp[k++] = skip;
+    envp[k++] = from;
     envp[k] = NULL;
     pid_t pid;
     if (getenv("INDELMINER_DEBUG_HANDOFF")) fprintf(stderr, "[handoff] %lld bytes printed, starting the child\n", (long long)g_out_bytes);

@@ -381,6 +381,15 @@ def test_host_read_with_more_indels_than_the_kernels_hold(tmp_path):
     _many_indels_in_one_read(_build_shim(), tmp_path, ({}, {"INDELMINER_CLAIM_BASES": "1", "INDELMINER_WALKERS": "3"}))
 
 
+def test_host_leaked_handoff_variable_drops_nothing(synth_small):
+    """INDELMINER_SKIP_STDOUT is how a hand-over child learns how many bytes its parent has printed; found in the environment of a
+    run that nobody handed anything to (no INDELMINER_HANDOFF_PARENT naming the parent process), it must not eat output"""
+    shim = _build_shim()
+    want = _golden("synth_2ctg_composite")
+    for env in ({"INDELMINER_SKIP_STDOUT": "5000"}, {"INDELMINER_SKIP_STDOUT": "5000", "INDELMINER_HANDOFF_PARENT": "1"}):
+        assert _run(shim, ["-i", "cfg.txt"], synth_small, ref="ref.fa", bam="aln.bam", env=env) == want
+
+
 def test_host_contigs_without_reads(tmp_path):
     """contigs that deliver no record at all -- the first, one in the middle, the last -- between contigs that do: claims,
     groups and flush placement must not mind (the read counter and the marker floor simply pass through them)"""
