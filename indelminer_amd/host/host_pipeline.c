@@ -22,9 +22,14 @@
  *            merge_variants, print_variants -- the reference's own order of output.
  */
 
-#define PIPE_CHUNK_BYTES   (32u << 20)
-#define PIPE_CHUNK_RECS    (PIPE_CHUNK_BYTES / 64u)
+/* A walker's ring: up to PIPE_NCHUNK pinned chunks (and their device twins) of PIPE_CHUNK_BYTES.  Pinning memory is slow
+ * (and serialised in the driver): an input of a few hundred megabytes gets two chunks of 16 MB per walker instead of four of
+ * 32 MB, set once before the walkers start (walkpool_start). */
 #define PIPE_NCHUNK        4
+static uint32_t g_chunk_bytes = 32u << 20;
+static int g_nchunk = PIPE_NCHUNK;
+#define PIPE_CHUNK_BYTES   g_chunk_bytes
+#define PIPE_CHUNK_RECS    (g_chunk_bytes / 64u)
 
 typedef struct {
     uint8_t*  h_raw; uint32_t* h_off; int32_t* h_cnt;        /* pinned */
@@ -188,7 +193,7 @@ static void pipe_init(ppipe* P, driver* d, int with_chunks)
     P->own_stream = !(getenv("INDELMINER_STREAMS") && strcmp(getenv("INDELMINER_STREAMS"), "shared") == 0);
     if (P->own_stream) GPU(im_stream_create(d->gpu, &P->stream));
     else P->stream = im_ctx_stream(d->gpu);
-    for (int i = 0; i < PIPE_NCHUNK && with_chunks; i++) {
+    for (int i = 0; i < g_nchunk && with_chunks; i++) {
         pchunk* c = &P->ck[i];
         GPU(im_host_alloc(d->gpu, PIPE_CHUNK_BYTES, (void**)&c->h_raw));
         GPU(im_host_alloc(d->gpu, 4 * ((size_t)PIPE_CHUNK_RECS + 1), (void**)&c->h_off));
@@ -321,7 +326,7 @@ static void pipe_harvest(ppipe* P, pgroup* G, pchunk* c)
     P->fly_recs -= c->n; P->fly_seq -= c->seq_bytes;
     c->busy = 0; c->n = 0; c->bytes = 0; c->seq_bytes = 0;
     P->n_busy--;
-    P->oldest = (P->oldest + 1) % PIPE_NCHUNK;
+    P->oldest = (P->oldest + 1) % g_nchunk;
 }
 
 static void pipe_drain(ppipe* P, pgroup* G) { while (P->n_busy > 0) pipe_harvest(P, G, &P->ck[P->oldest]); }
@@ -375,7 +380,7 @@ static void pipe_submit(ppipe* P, pgroup* G)
     GPU(im_event_record(c->done, P->stream));
     c->busy = 1; P->n_busy++;
     P->fly_recs += c->n; P->fly_seq += c->seq_bytes;
-    P->cur = (P->cur + 1) % PIPE_NCHUNK;
+    P->cur = (P->cur + 1) % g_nchunk;
     if (P->ck[P->cur].busy) pipe_harvest(P, G, &P->ck[P->cur]);     /* the ring is full: its oldest chunk comes back first */
     P->ck[P->cur].rec_base = G->n_rec;
 }

@@ -295,6 +295,14 @@ static walkpool_t* walkpool_start(driver* d)
         total_bytes += bai_contig_bytes(d->idx, i); total_len += d->hdr->target_len[i];
     }
     if (g_mg) { total_bytes /= g_mg->world; total_len /= g_mg->world; }      /* a rank's share: the plan below is the whole run's, the same on every rank */
+    /* A walker costs its set-up (a pinned ring, device arrays, a stream: tens of milliseconds, serialised in the driver) before it
+     * delivers anything: one walker per ~48 MB of BAM, and a small ring, for inputs that a handful of walkers finish in a few
+     * hundred milliseconds anyway (measured on the 430 MB BAM of BASELINE configs[2]: 4 / 8 / 16 walkers 1.43 / 1.28 / 1.68 s) */
+    if (!e && !o->serial) {
+        const int by_size = (int)(total_bytes / (48 << 20));
+        if (by_size < nw) nw = by_size < 2 ? 2 : by_size;
+    }
+    if (total_bytes < ((int64_t)2 << 30)) { g_chunk_bytes = 16u << 20; g_nchunk = 2; }
     /* pieces: a contig is cut where its compressed bytes cross multiples of the piece size -- about 1/(8 walkers) of the file, at
      * least 8 MB of it (a stage and a replay have fixed costs per group), so that large contigs spread over all walkers */
     int64_t piece_bytes = total_bytes / (8 * (int64_t)nw);
