@@ -332,7 +332,8 @@ int im_set_insert_ranges(im_ctx* ctx, int32_t n, const char* const* names, const
  * of every record's bytes over PCIe and out of HBM.  The deliverer may only leave them out when the CIGAR's read bases do not
  * exceed l_seq (the reference reads on behind the packed bases otherwise, src/readaln.c:186-240).  rec_off has n + 1 entries; record i spans rec_off[i]..rec_off[i+1], which may
  * include up to three bytes of alignment padding behind the aux area: the tag walk treats a tail shorter than the
- * smallest possible field (tag, type, one value byte = 4 bytes) as the end of the record. */
+ * smallest possible field (tag, type, one value byte = 4 bytes) as the end of the record.  The buffer behind `raw` must stay
+ * readable for 64 bytes past the last record (the kernels read whole 16-byte pieces and a short look-ahead). */
 typedef struct im_dev_records {
     int32_t         n;
     const uint8_t*  raw;
