@@ -46,7 +46,7 @@ __device__ unsigned long long im_stamp_acc[32];
 #define IM_STAMP(id) do { if ((id) == IM_STOP_AFTER) { finish(out, IM_ST_NONE, 0, lane); return; } } while (0)
 #define IM_STAMP_ARG , int stamp_base_
 #define IM_STAMP_PASS(base) , base
-#define IM_STAMP_B(id) do { if (stamp_base_ + (id) == IM_STOP_AFTER) { if constexpr (KT == 6) table_undo6(s, p0, nq, lane, read_pk8); \
+#define IM_STAMP_B(id) do { if (stamp_base_ + (id) == IM_STOP_AFTER) { if constexpr (KT == 6 || KT == -1) table_undo(s, p0, nq, lane, read_pk8, kmask); \
                             b.st = IM_ST_ABORT; return b; } } while (0)   /* the k = 6 table must be left clean */
 #else
 #define IM_STAMP_DECL
@@ -97,8 +97,9 @@ struct Band {
 template <int KT, bool DIRECT>
 __device__ __forceinline__ void table_build(WaveLds& s, uint32_t p0, uint32_t nq, uint32_t k, int lane, uint32_t read_pk8)
 {
-    if constexpr (KT == 6) {
-        // k = 6 (the reference default): the read's 2-bit codes travel as one packed byte per lane
+    if constexpr (KT == 6 || KT == -1) {
+        // direct table kept clean (k = 6, the reference default, with its mask a constant; KT = -1: any k <= 6): the read's
+        // 2-bit codes travel as one packed byte per lane
         // (bases 4l..4l+3); the two following lanes' bytes come over DPP, and the lane's four
         // 6-mers are bit fields of that 24-bit window.  The table is kept clean by un-doing the
         // entries after the vote (table_undo), so no 4 KiB clear per band search.
@@ -111,7 +112,7 @@ __device__ __forceinline__ void table_build(WaveLds& s, uint32_t p0, uint32_t nq
         for (int j = 0; j < 4; j++) {
             const uint32_t x = 4u * lane + j;
             have[j] = x >= p0 && x < p0 + nq;
-            code[j] = (w24 >> (2 * j)) & 0xFFFu;
+            code[j] = (w24 >> (2 * j)) & (KT == 6 ? 0xFFFu : ((1u << (2 * k)) - 1u));
         }
 #pragma unroll
         for (int j = 0; j < 4; j++) if (have[j]) t8[code[j]] = (uint8_t)(4u * lane + j - p0 + 1u);
@@ -176,8 +177,8 @@ __device__ __forceinline__ void table_build(WaveLds& s, uint32_t p0, uint32_t nq
     wave_lds_sync();
 }
 
-// un-does table_build<6>: every lane zeroes the entries of its own k-mers
-__device__ __forceinline__ void table_undo6(WaveLds& s, uint32_t p0, uint32_t nq, int lane, uint32_t read_pk8)
+// un-does the clean-table build: every lane zeroes the entries of its own k-mers
+__device__ __forceinline__ void table_undo(WaveLds& s, uint32_t p0, uint32_t nq, int lane, uint32_t read_pk8, uint32_t mask)
 {
     uint8_t* t8 = reinterpret_cast<uint8_t*>(s.tbl);
     const uint32_t n1 = (uint32_t)dpp_mov<kDppWaveShl1>(0, (int)read_pk8);
@@ -186,7 +187,7 @@ __device__ __forceinline__ void table_undo6(WaveLds& s, uint32_t p0, uint32_t nq
 #pragma unroll
     for (int j = 0; j < 4; j++) {
         const uint32_t x = 4u * lane + j;
-        if (x >= p0 && x < p0 + nq) t8[(w24 >> (2 * j)) & 0xFFFu] = 0;
+        if (x >= p0 && x < p0 + nq) t8[(w24 >> (2 * j)) & mask] = 0;
     }
 }
 
@@ -346,8 +347,14 @@ __device__ __forceinline__ Band band_search(WaveLds& s, const uint8_t* __restric
                     const uint32_t v = table_lookup<DIRECT>(s, (uint32_t)(dd >> bsh) & kmask);
                     if (v == 0u || v == 0xFFu) continue;
                     const uint32_t off = obase + i - v;
-                    if (off < (uint32_t)kDiagChunk)
-                        atomicAdd(&s.diag[off >> 2], 1u << ((off & 3u) * 8u));
+                    if (off < (uint32_t)kDiagChunk) {
+                        // the same key as the direct path: the vote that lifts a diagonal to its final count names it
+                        const uint32_t bsel = (off & 3u) * 8u;
+                        const uint32_t old = atomicAdd(&s.diag[off >> 2], 1u << bsel);
+                        const uint32_t cnt = ((old >> bsel) & 255u) + 1u;
+                        const uint32_t near = (uint32_t)(kd - abs(arel - (int)off));
+                        mx = max(mx, (cnt << 22) | (near << 11) | (2047u - off));
+                    }
                 }
             }
         }
@@ -360,8 +367,7 @@ __device__ __forceinline__ Band band_search(WaveLds& s, const uint8_t* __restric
         if (g == 0) {
             // One diagonal per band: select_band's winner of the chunk (most votes, nearest the anchor, smallest index),
             // merged into the running winner over the chunks.
-            const uint32_t nb = iend - c0;
-            if (DIRECT) {
+            {
                 // the votes reported (count, nearness, index) as they landed: one reduction names the chunk's band
                 const uint32_t K = (uint32_t)wave_max((int)mx);          // keys stay below 2^30
                 const int M = (int)(K >> 22);
@@ -369,34 +375,6 @@ __device__ __forceinline__ Band band_search(WaveLds& s, const uint8_t* __restric
                     const int d = dmin + 2047 - (int)((K >> 11) & 2047u);
                     const int i = (int)c0 + 2047 - (int)(K & 2047u);
                     if (M > bc || d < bd || (d == bd && i < bi)) { bc = M; bd = d; bi = i; }
-                }
-            } else {
-                // hash path (k > 6): the chunk's largest count from a pass of packed 16-bit maxima; then only the words that
-                // hold a byte equal to it are visited and the (distance, index)-least of those diagonals kept.  bc is
-                // wave-uniform; bd / bi are per lane here and reduced once at the end.
-                uint32_t me = 0, mo = 0;
-                for (uint32_t dw = lane; 4u * dw < nb; dw += 64) {
-                    const uint32_t v = s.diag[dw];
-                    me = pk_max_u16(me, v & 0x00FF00FFu);
-                    mo = pk_max_u16(mo, (v >> 8) & 0x00FF00FFu);
-                }
-                const uint32_t m2 = pk_max_u16(me, mo);
-                const int M = wave_max((int)max(m2 & 0xFFFFu, m2 >> 16));
-                if (M > 0 && M >= bc) {
-                    if (M > bc) { bc = M; bd = INT_MAX; bi = 0; }
-                    const uint32_t rep = (uint32_t)M * 0x01010101u;
-                    for (uint32_t dw = lane; 4u * dw < nb; dw += 64) {
-                        const uint32_t v = s.diag[dw];
-                        const uint32_t x = v ^ rep;
-                        if (((x - 0x01010101u) & ~x & 0x80808080u) == 0u) continue;      // no byte equals M
-#pragma unroll
-                        for (int bb = 0; bb < 4; bb++) {
-                            if (((v >> (8 * bb)) & 255u) != (uint32_t)M) continue;
-                            const int i = (int)(c0 + 4u * dw) + bb;
-                            const int d = abs(anchor_rel - i);
-                            if (d < bd || (d == bd && i < bi)) { bd = d; bi = i; }
-                        }
-                    }
                 }
             }
         } else {
@@ -418,15 +396,12 @@ __device__ __forceinline__ Band band_search(WaveLds& s, const uint8_t* __restric
         wave_lds_sync();
         IM_STAMP_B(3);
     }
-    if constexpr (KT == 6) table_undo6(s, p0, nq, lane, read_pk8);
+    if constexpr (KT == 6 || KT == -1) table_undo(s, p0, nq, lane, read_pk8, KT == 6 ? 0xFFFu : kmask);
     // select_band's order: most votes, then nearest the anchor, then smallest index
     if (g == 0) {
         if (bc == 0) {
             // no vote anywhere: every diagonal ties at 0 and the nearest to the anchor wins
             bi = min(max(anchor_rel, 0), (int)numdiag - 1);
-        } else if (!DIRECT) {
-            const int D = wave_min(bd);
-            bi = wave_min(bd == D ? bi : INT_MAX);
         }
     } else {
 #pragma unroll
@@ -579,7 +554,7 @@ __device__ __forceinline__ void realign_one(WaveLds& s, const RealignArgs& A, in
     const int tid = sload(A.batch.tid + c);
     const int anchor = sload(A.batch.anchor + c);
     const int R = sload(A.batch.range_max + c);
-    const uint32_t k = KT ? (uint32_t)KT : A.P.klength, g = KT ? 0u : A.P.numgaps, eth = A.P.ethreshold;
+    const uint32_t k = KT > 0 ? (uint32_t)KT : A.P.klength, g = KT ? 0u : A.P.numgaps, eth = A.P.ethreshold;
 
     if (lane < 16) reinterpret_cast<uint32_t*>(&out->band[0])[lane] = 0u;
     if (lane < 7) out->reserved[lane] = 0;
@@ -812,7 +787,7 @@ __global__ __launch_bounds__(64, IM_WAVES_PER_SIMD) void realign_kernel(RealignA
     // blocks with equal blockIdx % 8 share an XCD (observed round-robin placement,
     // speed only): give each XCD a contiguous run of `per` reads per sweep.
     const int mine = (blockIdx.x & 7) * per + (blockIdx.x >> 3);
-    if constexpr (KT == 6) {        // table_build<6> / table_undo6 keep the table clean from here on
+    if constexpr (KT == 6 || KT == -1) {        // table_build / table_undo keep the table clean from here on
         uint4* t4 = reinterpret_cast<uint4*>(s.tbl);
 #pragma unroll
         for (int i = 0; i < kTblBytes / 16 / 64; i++) t4[lane + 64 * i] = make_uint4(0u, 0u, 0u, 0u);
@@ -1791,7 +1766,7 @@ hipError_t launch_realign(const RealignArgs& a, int n_cu, hipStream_t stream)
     } else if (a.P.klength == 6 && a.P.numgaps == 0)
         hipLaunchKernelGGL((realign_kernel<6, true>), dim3(grid), dim3(64), 0, stream, a);     // reference defaults
     else if (a.P.klength <= (uint32_t)kDirectMaxK)
-        hipLaunchKernelGGL((realign_kernel<0, true>), dim3(grid), dim3(64), 0, stream, a);
+        hipLaunchKernelGGL((realign_kernel<-1, true>), dim3(grid), dim3(64), 0, stream, a);     // any other k <= 6: the same clean-table protocol, mask at run time
     else
         hipLaunchKernelGGL((realign_kernel<0, false>), dim3(grid), dim3(64), 0, stream, a);
     return hipGetLastError();

@@ -15,6 +15,8 @@ ctx = capi.Context(0)
 for seed in range(first, first + n):
     T.test_hip_matches_oracle_fuzzed_parameters(ctx, seed)
     print("g=0 fuzz seed %d ok" % seed, flush=True)
+    T.test_hip_long_reads_fuzzed(ctx, seed)
+    print("long-read fuzz seed %d ok" % seed, flush=True)
 for seed in range(first, first + n):
     rng = random.Random(seed)
     for trial in range(10):

@@ -132,10 +132,10 @@ def test_hip_long_reads_match_oracle(gpu_ctx, k, L, Rm, maxdel):
     assert int((out["status"][is_long] == 1).sum()) > 50 and int((out["status"][~is_long] == 1).sum()) > 50
 
 
-def test_hip_long_reads_fuzzed(gpu_ctx):
+def test_hip_long_reads_fuzzed(gpu_ctx, seed=31):
     """lengths around the two kernels' border and the upper bound, short contigs (windows clipped at both ends), every k"""
     from indelminer_amd import capi
-    rng = random.Random(31)
+    rng = random.Random(seed)
     for trial in range(30):
         k = rng.choice([2, 3, 4, 5, 6, 6, 7, 8, 10, 12, 15])
         kw = dict(klength=k, numgaps=0, maxdelsize=rng.choice([50, 300, 1000, 2500]), ethreshold=rng.choice([1, 5, 10, 25]))
