@@ -98,6 +98,9 @@ static void mg_write_flag(const mgpu* m, const char* text)
     rename(tmp, path);
 }
 
+static struct { mgpu* m; driver* d; char path[512]; char token[96]; pthread_t th; int pending; } g_rdv;
+static void* mg_comm_bringup(void* arg);
+
 static void mg_rendezvous(mgpu* m, driver* d)
 {
     /* The RCCL unique id travels through a file in a directory every rank can see (one node).  The directory is this run's
@@ -108,9 +111,8 @@ static void mg_rendezvous(mgpu* m, driver* d)
     else snprintf(m->dir, sizeof m->dir, "/tmp/indelminer_mgpu_%s_%ld", getenv("MASTER_PORT") ? getenv("MASTER_PORT") : "0", (long)getppid());
     pthread_t wd;
     if (pthread_create(&wd, NULL, mg_watchdog, NULL) == 0) pthread_detach(wd);
-    char path[512], tmp[520];
+    char path[512];
     snprintf(path, sizeof path, "%s/rccl_id", m->dir);
-    uint8_t id[IM_COMM_ID_BYTES];
     /* what the ranks of ONE run share and no other run has: the launcher's run id, port and process (or what the caller says) */
     char token[96];
     memset(token, 0, sizeof token);
@@ -134,6 +136,25 @@ static void mg_rendezvous(mgpu* m, driver* d)
             }
         }
         snprintf(g_mg_header_path, sizeof g_mg_header_path, "%s/part.header", m->dir);
+    }
+    /* The id's trip and the communicator bring-up (about two seconds inside librccl) run beside the pre-walk, which needs neither:
+     * the first collective joins this thread (mg_allgather). */
+    g_rdv.m = m; g_rdv.d = d;
+    snprintf(g_rdv.path, sizeof g_rdv.path, "%s", path);
+    memcpy(g_rdv.token, token, sizeof token);
+    if (pthread_create(&g_rdv.th, NULL, mg_comm_bringup, NULL) != 0) fatalf("cannot start the communicator thread");
+    g_rdv.pending = 1;
+}
+
+static void* mg_comm_bringup(void* arg)
+{
+    (void)arg;
+    mgpu* m = g_rdv.m; driver* d = g_rdv.d;
+    const char* path = g_rdv.path;
+    char token[96], tmp[520];
+    memcpy(token, g_rdv.token, sizeof token);
+    uint8_t id[IM_COMM_ID_BYTES];
+    if (m->rank == 0) {
         gpu_wait(d);                                    /* the HIP runtime is up before librccl is asked for anything */
         if (im_comm_unique_id(id) != IM_OK) fatalf("im_comm_unique_id: %s", im_comm_last_error());
         snprintf(tmp, sizeof tmp, "%s.tmp", path);
@@ -161,11 +182,14 @@ static void mg_rendezvous(mgpu* m, driver* d)
     mg_arm("communicator bring-up");
     if (im_comm_init(d->gpu, id, m->rank, m->world, &m->comm) != IM_OK) fatalf("im_comm_init: %s", im_comm_last_error());
     mg_disarm();
+    return NULL;
 }
+static void mg_comm_join(void) { if (g_rdv.pending) { g_rdv.pending = 0; pthread_join(g_rdv.th, NULL); } }
 
 /* every rank contributes `bytes` bytes (a multiple of 4); all[] receives world * bytes */
 static void mg_allgather(mgpu* m, driver* d, const void* mine, void* all, size_t bytes)
 {
+    mg_comm_join();                                 /* the communicator: brought up beside the pre-walk */
     void *ds = NULL, *dr = NULL;
     if (im_dev_alloc(d->gpu, bytes, &ds) != IM_OK || im_dev_alloc(d->gpu, bytes * (size_t)m->world, &dr) != IM_OK) fatalf("im_dev_alloc: %s", im_last_error(d->gpu));
     if (im_dev_upload(d->gpu, ds, mine, bytes) != IM_OK) fatalf("im_dev_upload: %s", im_last_error(d->gpu));
