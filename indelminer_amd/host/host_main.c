@@ -264,6 +264,7 @@ int main(int argc, char** argv)
             pool = walkpool_start(&d);
         }
     }
+    if (g_mg) mg_rendezvous(&mg, &d);          /* the communicator comes up on a thread of its own, beside the FASTA read and the pre-walk */
 
     if (O.configfile) read_configuration(O.configfile, d.insertlengths, d.hdr);
     else if (g_onepass) { }
@@ -293,7 +294,6 @@ int main(int argc, char** argv)
     const char* pl = getenv("INDELMINER_PIPELINE");
     const int use_pipeline = !(pl && strcmp(pl, "host") == 0);
     if (g_mg) {
-        mg_rendezvous(&mg, &d);
         mg_exchange(&mg, &d, O.configfile == NULL, pool->pieces, pool->n_pieces, mg.piece_walker);
         if (mg.cross) {
             /* A first mate left waiting in one contig meets a record of the same name in a later one: the reference's one

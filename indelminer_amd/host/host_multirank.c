@@ -154,8 +154,12 @@ static void* mg_comm_bringup(void* arg)
     char token[96], tmp[520];
     memcpy(token, g_rdv.token, sizeof token);
     uint8_t id[IM_COMM_ID_BYTES];
+    /* the HIP runtime is up before librccl is asked for anything: the context exists (its reference may still be on its way) */
+    pthread_mutex_lock(&d->gpu_mu);
+    while (!d->ctx_ready) pthread_cond_wait(&d->gpu_cv, &d->gpu_mu);
+    pthread_mutex_unlock(&d->gpu_mu);
+    if (d->ctx_rc != IM_OK) return NULL;                /* the main thread reports it (gpu_wait) */
     if (m->rank == 0) {
-        gpu_wait(d);                                    /* the HIP runtime is up before librccl is asked for anything */
         if (im_comm_unique_id(id) != IM_OK) fatalf("im_comm_unique_id: %s", im_comm_last_error());
         snprintf(tmp, sizeof tmp, "%s.tmp", path);
         FILE* fp = fopen(tmp, "wb");
@@ -178,7 +182,6 @@ static void* mg_comm_bringup(void* arg)
             nanosleep(&ts, NULL);
         }
     }
-    gpu_wait(d);
     mg_arm("communicator bring-up");
     if (im_comm_init(d->gpu, id, m->rank, m->world, &m->comm) != IM_OK) fatalf("im_comm_init: %s", im_comm_last_error());
     mg_disarm();
