@@ -829,6 +829,10 @@ static void stage_run_group(ppipe* P, pgroup* G)
             { G->cons_pe, (char*)P->consumed + 4 * pe_base, 4 * (size_t)G->n_pe },
             { G->cl_key, P->clkey, 16 * ncl }, { G->cl_first, P->clfirst, 4 * ncl }, { G->cl_count, P->clcount, 4 * ncl },
             { G->order, P->order, ncl ? 4 * (size_t)G->n_nodes : 0 }, { NULL, NULL, 0 } };
+        /* a large array goes straight to its destination (one pin + un-pin of the destination is cheaper than a second pass
+         * over megabytes of freshly allocated memory); the many small ones share the pinned block */
+        for (int k = 0; job[k].dst; k++)
+            if (job[k].bytes > ((size_t)256 << 10)) { GPU(im_dev_download(g, job[k].dst, job[k].src, job[k].bytes)); job[k].bytes = 0; }
         size_t total = 0;
         for (int k = 0; job[k].dst; k++) total += (job[k].bytes + 255) & ~(size_t)255;
         if (total > P->h_stage_cap) {
