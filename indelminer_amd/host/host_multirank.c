@@ -235,7 +235,16 @@ static void prewalk_piece(const driver* d, bgzf_reader* r, int32_t t, int32_t be
     int64_t counted = 0;
     int32_t rec = 0, n_ev = 0;
     const size_t ev_at = out ? out->n : 0;
-    while (bam_region_next(&it, &b) == 1) {
+    /* the walkers' record loop: records taken from the inflated block in place, base qualities left behind (nothing here reads them) */
+    it.drop_qual = 1;
+    const int64_t cap = 1 << 20;
+    uint8_t* one = xmalloc((size_t)cap + 64);
+    for (;;) {
+        int32_t len = 0;
+        const int rc = bam_region_next_raw(&it, one, cap, &len, &b);
+        if (rc == -2) fatalf("a BAM record larger than %ld bytes", (long)cap);
+        if (rc < 0) fatalf("error while reading %s", d->bam_name);
+        if (rc == 0) break;
         const int flag = b.flag;
         const int32_t this_rec = rec++;
         if (cov) cov_record(cov, &b);
@@ -267,7 +276,7 @@ static void prewalk_piece(const driver* d, bgzf_reader* r, int32_t t, int32_t be
             n_ev++;
         }
     }
-    free(b.data);
+    free(one);
     if (!out) return;
     int32_t* hd = (int32_t*)(out->p + head_at);
     hd[1] = (int32_t)(counted & 0xffffffff); hd[2] = (int32_t)(counted >> 32); hd[3] = n_ev; hd[4] = (int32_t)(out->n - ev_at);
