@@ -67,6 +67,7 @@ bgzf_reader* bgzf_open(const char* path)
     if (!fp) return NULL;
     bgzf_reader* r = calloc(1, sizeof *r);
     r->fp = fp;
+    setvbuf(fp, NULL, _IOFBF, 256 << 10);           /* blocks are read one after the other: a few system calls per megabyte, not per block */
     const char* e = getenv("INDELMINER_THREADS");
     r->nworkers = e ? atoi(e) : 4;
     if (r->nworkers < 0) r->nworkers = 0;

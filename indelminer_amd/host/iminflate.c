@@ -185,53 +185,78 @@ int64_t im_inflate(const uint8_t* in, size_t in_len, uint8_t* out, size_t out_ca
          * run out, nothing is checked per symbol; the careful loop below finishes the block */
         uint8_t* const out_fast = out_cap > 320 ? out_end - 320 : out;
         int done = 0;
-        while (op < out_fast && ip < in_end) {
+        /* The look-up of the NEXT symbol is issued before the current one's bytes are written (its index only needs the bit
+         * buffer): the table load's latency hides behind the copy instead of heading the next iteration's chain. */
+        if (op < out_fast && ip < in_end) {
             REFILL();
             uint32_t e = T.ll[bb & ((1u << LL_BITS) - 1u)];
-            if (e & E_LIT) {
-                /* literals come in runs: up to three from one refill (11 bits each at most straight from the main table) */
-                *op++ = (uint8_t)(e >> 16); TAKE(e & 255u);
-                e = T.ll[bb & ((1u << LL_BITS) - 1u)];
+            for (;;) {
+                /* here: bc >= 56 - 33 when coming from literals, >= 56 otherwise; e is the entry of the bits at hand */
                 if (e & E_LIT) {
+                    /* literals come in runs: up to three from one refill (11 bits each at most straight from the main table) */
                     *op++ = (uint8_t)(e >> 16); TAKE(e & 255u);
                     e = T.ll[bb & ((1u << LL_BITS) - 1u)];
-                    if (e & E_LIT) { *op++ = (uint8_t)(e >> 16); TAKE(e & 255u); continue; }
+                    if (e & E_LIT) {
+                        *op++ = (uint8_t)(e >> 16); TAKE(e & 255u);
+                        e = T.ll[bb & ((1u << LL_BITS) - 1u)];
+                        if (e & E_LIT) { *op++ = (uint8_t)(e >> 16); TAKE(e & 255u); e = T.ll[bb & ((1u << LL_BITS) - 1u)]; }
+                    }
+                    /* <= 33 bits are gone, >= 23 are left: the look-up above saw its 11 bits; what follows may need 48 */
+                    if (!(op < out_fast && ip < in_end)) break;
+                    REFILL();
+                    continue;
                 }
-                /* a length, a sub-table or the end follows: 23 bits at most are gone, 33 are left -- enough for a sub-table look-up
-                 * (15) but not for a whole match (48): start over with a full buffer */
-                continue;
-            }
-            if (e & E_SUB) {
-                TAKE(LL_BITS);
-                e = T.ll[((e >> 16) & 0x1fffu) + (uint32_t)(bb & ((1u << ((e >> 8) & 255u)) - 1u))];
-                if (e & E_LIT) { *op++ = (uint8_t)(e >> 16); TAKE(e & 255u); continue; }
-            }
-            if (e & E_EOB) { if ((e >> 16) & 1u) return -1; TAKE(e & 255u); done = 1; break; }
-            if ((e & 255u) == 0) return -1;
-            TAKE(e & 255u);
-            const unsigned xl = (e >> 8) & 255u;
-            const unsigned length = ((e >> 16) & 0x1fffu) + (unsigned)(bb & ((1u << xl) - 1u));
-            TAKE(xl);
-            uint32_t d = T.of[bb & ((1u << OF_BITS) - 1u)];
-            if (d & D_SUB) { TAKE(OF_BITS); d = T.of[((d >> 16) & 0x7fffu) + (uint32_t)(bb & ((1u << ((d >> 8) & 255u)) - 1u))]; }
-            if ((d & 255u) == 0) return -1;
-            TAKE(d & 255u);
-            const unsigned xd = (d >> 8) & 255u;
-            const unsigned dbase = (d >> 16) & 0x7fffu;
-            if (dbase == 0x7fffu) return -1;
-            const unsigned dist = dbase + (unsigned)(bb & ((1u << xd) - 1u));
-            TAKE(xd);
-            if (dist > (size_t)(op - out)) return -1;
-            const uint8_t* src = op - dist;
-            uint8_t* dst = op;
-            op += length;
-            if (dist >= 8) {
-                memcpy(dst, src, 8); memcpy(dst + 8, src + 8, 8);
-                if (length > 16) { dst += 16; src += 16; do { memcpy(dst, src, 8); dst += 8; src += 8; } while (dst < op); }
-            } else if (dist == 1) {
-                memset(dst, *src, length);
-            } else {
-                do { *dst++ = *src++; } while (dst < op);
+                if (e & E_SUB) {
+                    TAKE(LL_BITS);
+                    e = T.ll[((e >> 16) & 0x1fffu) + (uint32_t)(bb & ((1u << ((e >> 8) & 255u)) - 1u))];
+                    if (e & E_LIT) {
+                        *op++ = (uint8_t)(e >> 16); TAKE(e & 255u);
+                        if (!(op < out_fast && ip < in_end)) break;
+                        REFILL();
+                        e = T.ll[bb & ((1u << LL_BITS) - 1u)];
+                        continue;
+                    }
+                }
+                if (e & E_EOB) { if ((e >> 16) & 1u) return -1; TAKE(e & 255u); done = 1; break; }
+                if ((e & 255u) == 0) return -1;
+                TAKE(e & 255u);
+                const unsigned xl = (e >> 8) & 255u;
+                const unsigned length = ((e >> 16) & 0x1fffu) + (unsigned)(bb & ((1u << xl) - 1u));
+                TAKE(xl);
+                uint32_t d = T.of[bb & ((1u << OF_BITS) - 1u)];
+                if (d & D_SUB) { TAKE(OF_BITS); d = T.of[((d >> 16) & 0x7fffu) + (uint32_t)(bb & ((1u << ((d >> 8) & 255u)) - 1u))]; }
+                if ((d & 255u) == 0) return -1;
+                TAKE(d & 255u);
+                const unsigned xd = (d >> 8) & 255u;
+                const unsigned dbase = (d >> 16) & 0x7fffu;
+                if (dbase == 0x7fffu) return -1;
+                const unsigned dist = dbase + (unsigned)(bb & ((1u << xd) - 1u));
+                TAKE(xd);
+                if (dist > (size_t)(op - out)) return -1;
+                const uint8_t* src = op - dist;
+                uint8_t* dst = op;
+                op += length;
+                /* the next symbol's entry: on its way while the match is copied */
+                const int more = op < out_fast && ip < in_end;
+                if (more) {
+                    /* with 11 bits still at hand the look-up does not wait for the refill's load (the usual case: a match takes ~20) */
+                    if (bc >= LL_BITS) { e = T.ll[bb & ((1u << LL_BITS) - 1u)]; REFILL(); }
+                    else { REFILL(); e = T.ll[bb & ((1u << LL_BITS) - 1u)]; }
+                }
+                if (dist >= 16) {
+                    /* 32 bytes whatever the length (most matches are shorter: no branch on it); the second piece may read what the
+                     * first has just written */
+                    memcpy(dst, src, 16); memcpy(dst + 16, src + 16, 16);
+                    if (length > 32) { dst += 32; src += 32; do { memcpy(dst, src, 16); dst += 16; src += 16; } while (dst < op); }
+                } else if (dist >= 8) {
+                    memcpy(dst, src, 8); memcpy(dst + 8, src + 8, 8);
+                    if (length > 16) { dst += 16; src += 16; do { memcpy(dst, src, 8); dst += 8; src += 8; } while (dst < op); }
+                } else if (dist == 1) {
+                    memset(dst, *src, length);
+                } else {
+                    do { *dst++ = *src++; } while (dst < op);
+                }
+                if (!more) break;
             }
         }
         while (!done) {
