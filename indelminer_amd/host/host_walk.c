@@ -470,7 +470,7 @@ static void run_pipeline(driver* d, walkpool_t* o)
      * into a buffer that is written out when every group before it has been.  The numbered blocks of -o detailed, annotate
      * mode (one known-variant list) and the per-contig part files of a multi-GPU run keep the replay on this thread. */
     const char* re = getenv("INDELMINER_REPLAYERS");
-    int nrep = re ? atoi(re) : (g_onepass ? 8 : 3);      /* one-pass: every replay comes after the walk, nothing else wants the cores */
+    int nrep = re ? atoi(re) : 8;       /* idle while there is nothing to replay; at the end of the walk the cores are theirs (three left the last contigs a backlog of 1.3 s at WGS scale) */
     if (o->serial || g_mg || strcmp(O.outputformat, "vcf") != 0 || nrep < 2) nrep = 0;
     if (nrep > 8) nrep = 8;
     replayer_t* rp = nrep ? xcalloc((size_t)nrep, sizeof(replayer_t)) : NULL;
