@@ -116,7 +116,7 @@ int main(int argc, char** argv)
             g_out_skip = atoll(sk);
             unsetenv("INDELMINER_SKIP_STDOUT");
             t_out = out_cookie_open();
-            if (!getenv("INDELMINER_DEBUG_HANDOFF")) {
+            if (getenv("INDELMINER_HANDOFF_QUIET") && !getenv("INDELMINER_DEBUG_HANDOFF")) {
                 g_real_stderr = dup(STDERR_FILENO);
                 if (!freopen("/dev/null", "w", stderr)) { }
             }

@@ -181,7 +181,7 @@ static void* walker_thread(void* arg)
     for (;;) {
         pthread_mutex_lock(&o->mu);
         /* walked groups wait for the main thread with their logs and parked arrays: stay a bounded number of claims ahead of it */
-        while (!g_onepass && !g_mg && o->next_claim < o->n_claims && o->next_claim >= o->staged + 2 * o->nw + 4) pthread_cond_wait(&o->cv, &o->mu);
+        while ((!g_onepass || g_spec_active) && !g_mg && o->next_claim < o->n_claims && o->next_claim >= o->staged + 2 * o->nw + 4) pthread_cond_wait(&o->cv, &o->mu);
         while (g_mg && o->next_claim < o->n_claims && g_mg->claim_walker[o->next_claim] != g_mg->rank) o->next_claim++;      /* another rank walks it */
         const int ci = o->next_claim < o->n_claims ? o->next_claim++ : -1;
         pthread_mutex_unlock(&o->mu);
@@ -204,6 +204,7 @@ static void* walker_thread(void* arg)
         }
         pgroup* G = walk_claim(W, o, c);
         t_abort_jmp = NULL;
+        if (g_onepass && g_spec_active && !G->sv_range) G->sv_range = group_ranges(&W->wd, G);    /* the provisional table is there: this candidate's range[1] now */
         if (g_mg) { int64_t nr = 0; group_flush_points(G, &nr); G->from_package = 1; }      /* the counter in front of every piece is known (mg_exchange) */
         if (ship) {
             package_write(g_mg, ci, &W->P, G, 0);
@@ -391,6 +392,73 @@ static walkpool_t* walkpool_start(driver* d)
     return o;
 }
 
+/* What the one-pass walk has learnt so far: per read group the insert-size extrema with the first sighting, the spans for the
+ * coverage table (copied out of the groups, which go when their contig has been replayed), and what it has printed so far. */
+typedef struct { mg_rg* rg; int n_rg, cap_rg; covlist cov; mg_rg* prov; int n_prov; char* out; size_t out_len, out_cap; } spec_t;
+static void spec_collect(spec_t* S, driver* d, pgroup* G)
+{
+    if (!G) return;
+    if (S->n_rg + G->n_rgs > S->cap_rg) { S->cap_rg = (S->cap_rg + G->n_rgs) * 2 + 16; S->rg = xrealloc(S->rg, sizeof(mg_rg) * (size_t)S->cap_rg); }
+    for (int k = 0; k < G->n_rgs; k++) {
+        mg_rg* m = &S->rg[S->n_rg++];
+        memset(m, 0, sizeof *m);
+        snprintf(m->name, sizeof m->name, "%s", G->rgs[k].name);
+        m->min = G->rgs[k].min; m->max = G->rgs[k].max; m->first_tid = G->rgs[k].first_tid; m->first_rec = G->rgs[k].first_rec; m->seen = 1;
+    }
+    if (!S->cov.sum) cov_init(&S->cov, d->hdr->n_targets);
+    if (G->cov.sum) {
+        cov_close(&G->cov);
+        for (int32_t t = 0; t < S->cov.nt; t++) S->cov.sum[t] += G->cov.sum[t];
+        for (int64_t k = 0; k < G->cov.n; k++) cov_push(&S->cov, G->cov.seg[k]);
+    }
+}
+/* the collected extrema, read groups in the order one sequential pass meets them, into the insert-length table (table = 1) or
+ * only into a list (the check at the end); returns the list's length, *out = the list */
+static int spec_merge(const spec_t* S, mg_rg** out)
+{
+    mg_rg* all = xmalloc(sizeof(mg_rg) * (size_t)(S->n_rg ? S->n_rg : 1));
+    memcpy(all, S->rg, sizeof(mg_rg) * (size_t)S->n_rg);
+    mg_rg* merged = xcalloc((size_t)(S->n_rg ? S->n_rg : 1), sizeof(mg_rg));
+    const int n = merge_rgs(all, S->n_rg, merged);
+    free(all);
+    *out = merged;
+    return n;
+}
+static void onepass_print_tables(driver* d, spec_t* S)
+{
+    fprintf(stderr, "\nRead-group\tMin-value\tMax-value (estimated during the walk)\n");
+    for (int j = 0; j < g_rg_n; j++) fprintf(stderr, "%s\t%d\t%d\n", g_rg_name[j], g_rg_range[j][0], g_rg_range[j][1]);
+    covlist* one = &S->cov;
+    if (!S->cov.sum) cov_init(&S->cov, d->hdr->n_targets);
+    cov_means_of_lists(d->hdr->n_targets, &one, 1);
+    cov_print_table(d->hdr);
+}
+static int onepass_table(driver* d, spec_t* S, int print)
+{
+    mg_rg* merged;
+    const int n = spec_merge(S, &merged);
+    for (int j = 0; j < n; j++) rg_table_enter(d, &merged[j]);
+    S->prov = merged;
+    if (print) onepass_print_tables(d, S);
+    return n;
+}
+/* the whole file's list against the provisional one: same groups in the same order with the same extrema? */
+static int spec_holds(const spec_t* S)
+{
+    mg_rg* fin;
+    const int n = spec_merge(S, &fin);
+    int ok = n == S->n_prov;
+    for (int j = 0; ok && j < n; j++) ok = strcmp(fin[j].name, S->prov[j].name) == 0 && fin[j].min == S->prov[j].min && fin[j].max == S->prov[j].max;
+    free(fin);
+    return ok;
+}
+static void spec_keep_output(spec_t* S, const char* buf, size_t len)
+{
+    if (S->out_len + len > S->out_cap) { S->out_cap = (S->out_cap + len) * 2 + (1 << 20); S->out = xrealloc(S->out, S->out_cap); }
+    memcpy(S->out + S->out_len, buf, len);
+    S->out_len += len;
+}
+
 static void run_pipeline(driver* d, walkpool_t* o)
 {
     d->pipe_mode = 1;
@@ -412,67 +480,64 @@ static void run_pipeline(driver* d, walkpool_t* o)
     driver sd = *d;
     ppipe S;
     pipe_init(&S, &sd, 0);
+    /* ONE pass over the BAM (no config file): the walk runs without insert lengths (which records are candidates does not depend on
+     * them; the triage leaves range_max open), collecting the extrema per read group as estimate_insertlengths would
+     * (src/bamoperations.c:15-86).  The table made from the FIRST claims' extrema -- proper pairs are flagged against the aligner's
+     * own insert-size bounds, so the extrema of a library show within its first few hundred thousand pairs -- serves as the table
+     * while the rest of the file is still being walked: groups are staged and replayed behind the walk as in a run with a config
+     * file, their output kept back.  When every piece is in, the table of the whole file is made; if it is the provisional one,
+     * the output goes out; if not (or if anything went wrong on the way), only the header is out and the program takes the run
+     * again with the pre-pass (spec_fallback).  INDELMINER_SPECULATE=0, -o detailed: the table is made when the walk is over. */
+    const char* re = getenv("INDELMINER_REPLAYERS");
+    int nrep = re ? atoi(re) : 8;       /* idle while there is nothing to replay; at the end of the walk the cores are theirs (three left the last contigs a backlog of 1.3 s at WGS scale) */
+    if (o->serial || g_mg || strcmp(O.outputformat, "vcf") != 0 || nrep < 2) nrep = 0;
+    if (nrep > 8) nrep = 8;
+    spec_t spec;
+    memset(&spec, 0, sizeof spec);
+    int speculate = 0, spec_first = 0;
     if (g_onepass) {
-        /* ONE pass over the BAM: the walk above runs without insert lengths (which records are candidates does not depend on
-         * them; the triage leaves range_max open), collecting the extrema per read group as estimate_insertlengths would
-         * (src/bamoperations.c:15-86).  When every piece is in, the table is made -- read groups in the order one process
-         * meets them -- and the stage of every group follows. */
+        const char* sp = getenv("INDELMINER_SPECULATE");
+        speculate = t_out != NULL && nrep > 0 && !(sp && strcmp(sp, "0") == 0) && !getenv("INDELMINER_NO_HANDOFF");
+        const int first_k = speculate ? (o->n_claims < o->nw ? o->n_claims : o->nw) : o->n_claims;
         pthread_mutex_lock(&o->mu);
-        for (int ci = 0; ci < o->n_claims; ci++) while (!o->claims[ci].walked) pthread_cond_wait(&o->cv, &o->mu);
+        for (int ci = 0; ci < first_k; ci++) while (!o->claims[ci].walked) pthread_cond_wait(&o->cv, &o->mu);
         pthread_mutex_unlock(&o->mu);
-        for (int i = 0; i < o->nw; i++) pthread_join(o->w[i].th, NULL);
-        phase_time("the walk of all pieces (inflate + count + insert-length extrema; triage on the device)");
+        if (!speculate || first_k == o->n_claims) {
+            speculate = 0;
+            for (int i = 0; i < o->nw; i++) pthread_join(o->w[i].th, NULL);
+            phase_time("the walk of all pieces (inflate + count + insert-length extrema; triage on the device)");
+        }
         int aborted = 0;
-        for (int ci = 0; ci < o->n_claims; ci++) aborted |= o->claims[ci].aborted;
+        for (int ci = 0; ci < first_k; ci++) aborted |= o->claims[ci].aborted;
         if (aborted && g_handoff_pool) pipeline_handoff();      /* nothing is out yet: the record-at-a-time run prints it all */
         if (!aborted) {
-            mg_rg* all = xcalloc((size_t)(o->n_claims ? o->n_claims : 1) * MG_MAX_RG, sizeof(mg_rg));
-            int n_all = 0;
-            for (int ci = 0; ci < o->n_claims; ci++) {
-                const pgroup* G = o->claims[ci].G;
-                for (int k = 0; k < G->n_rgs; k++) {
-                    mg_rg* m = &all[n_all++];
-                    snprintf(m->name, sizeof m->name, "%s", G->rgs[k].name);
-                    m->min = G->rgs[k].min; m->max = G->rgs[k].max; m->first_tid = G->rgs[k].first_tid; m->first_rec = G->rgs[k].first_rec; m->seen = 1;
-                }
-            }
-            mg_rg* merged = xcalloc((size_t)(n_all ? n_all : 1), sizeof(mg_rg));
-            const int n = merge_rgs(all, n_all, merged);
-            fprintf(stderr, "\nRead-group\tMin-value\tMax-value (estimated during the walk)\n");
-            for (int j = 0; j < n; j++) rg_table_enter(d, &merged[j]);
-            for (int j = 0; j < g_rg_n; j++) fprintf(stderr, "%s\t%d\t%d\n", g_rg_name[j], g_rg_range[j][0], g_rg_range[j][1]);
-            free(all); free(merged);
-            {
-                covlist** ls = xmalloc(sizeof(covlist*) * (size_t)(o->n_claims ? o->n_claims : 1));
-                int nl = 0;
-                for (int ci = 0; ci < o->n_claims; ci++) if (o->claims[ci].G->cov.sum) ls[nl++] = &o->claims[ci].G->cov;
-                cov_means_of_lists(d->hdr->n_targets, ls, nl);
-                free(ls);
-                cov_print_table(d->hdr);
-            }
+            for (int ci = 0; ci < first_k; ci++) spec_collect(&spec, d, o->claims[ci].G);
+            spec.n_prov = onepass_table(d, &spec, speculate ? 0 : 1);
             pipe_global_init(d);
-            /* every group's candidates get their range[1], the groups spread over threads */
-            int nt = o->nw > 1 ? o->nw : 1;
-            if (nt > o->n_claims) nt = o->n_claims ? o->n_claims : 1;
-            apply_job* aj = xcalloc((size_t)nt, sizeof(apply_job));
-            for (int i = 0; i < nt; i++) {
-                aj[i].o = o; aj[i].first = i; aj[i].step = nt; aj[i].rd = *d;
-                aj[i].rd.rg_last_val = NULL; aj[i].rd.rg_last_name[0] = 0; aj[i].rd.gpu_pending = 0;
-                if (pthread_create(&aj[i].th, NULL, apply_thread, &aj[i]) != 0) fatalf("cannot start a thread");
+            if (speculate) {
+                spec_first = first_k;
+                pthread_mutex_lock(&o->mu); g_spec_active = 1; pthread_cond_broadcast(&o->cv); pthread_mutex_unlock(&o->mu);
+                phase_time("provisional insert lengths from the first claims");
+            } else {
+                /* every group's candidates get their range[1], the groups spread over threads */
+                int nt = o->nw > 1 ? o->nw : 1;
+                if (nt > o->n_claims) nt = o->n_claims ? o->n_claims : 1;
+                apply_job* aj = xcalloc((size_t)nt, sizeof(apply_job));
+                for (int i = 0; i < nt; i++) {
+                    aj[i].o = o; aj[i].first = i; aj[i].step = nt; aj[i].rd = *d;
+                    aj[i].rd.rg_last_val = NULL; aj[i].rd.rg_last_name[0] = 0; aj[i].rd.gpu_pending = 0;
+                    if (pthread_create(&aj[i].th, NULL, apply_thread, &aj[i]) != 0) fatalf("cannot start a thread");
+                }
+                for (int i = 0; i < nt; i++) pthread_join(aj[i].th, NULL);
+                free(aj);
+                phase_time("insert lengths applied: candidates' ranges");
             }
-            for (int i = 0; i < nt; i++) pthread_join(aj[i].th, NULL);
-            free(aj);
-            phase_time("insert lengths applied: candidates' ranges");
         }
     }
     /* Replay workers: the replay of a group (evidence objects, paired-read components, merge, print) is the longest serial
      * piece of a run once the walks overlap; groups are independent of each other, so several are replayed at once, each
      * into a buffer that is written out when every group before it has been.  The numbered blocks of -o detailed, annotate
      * mode (one known-variant list) and the per-contig part files of a multi-GPU run keep the replay on this thread. */
-    const char* re = getenv("INDELMINER_REPLAYERS");
-    int nrep = re ? atoi(re) : 8;       /* idle while there is nothing to replay; at the end of the walk the cores are theirs (three left the last contigs a backlog of 1.3 s at WGS scale) */
-    if (o->serial || g_mg || strcmp(O.outputformat, "vcf") != 0 || nrep < 2) nrep = 0;
-    if (nrep > 8) nrep = 8;
     replayer_t* rp = nrep ? xcalloc((size_t)nrep, sizeof(replayer_t)) : NULL;
     o->jobs = xcalloc((size_t)(o->n_claims ? o->n_claims : 1), sizeof(rjob_t));
     for (int i = 0; i < nrep; i++) {
@@ -522,6 +587,10 @@ static void run_pipeline(driver* d, walkpool_t* o)
         phase_time("waited for the walk (inflate + count; triage on the device)");
         pgroup* G = c->G;
         G->seq = ci;
+        if (speculate) {
+            if (ci >= spec_first) spec_collect(&spec, d, G);                 /* the first claims' went into the provisional table */
+            if (!G->sv_range) G->sv_range = group_ranges(d, G);               /* walked before that table was there */
+        }
         const int first_of_contig = G->ctg[0].first, last_of_contig = G->ctg[G->n_ctg - 1].last;
         const int floor_of_contig = (g_mg && first_of_contig) ? g_mg->floor[G->ctg[0].tid] : floor_;
         static int contig_floor;            /* the floor all pieces of the contig in hand are measured against */
@@ -567,7 +636,8 @@ static void run_pipeline(driver* d, walkpool_t* o)
             while (o->printed < o->n_jobs && o->jobs[o->printed].done) {
                 rjob_t* P = &o->jobs[o->printed++];
                 pthread_mutex_unlock(&o->mu);
-                if (P->len && fwrite(P->buf, 1, P->len, OUT) != P->len) fatalf("write to stdout failed");
+                if (P->len && speculate) spec_keep_output(&spec, P->buf, P->len);
+                else if (P->len && fwrite(P->buf, 1, P->len, OUT) != P->len) fatalf("write to stdout failed");
                 free(P->buf);
                 pthread_mutex_lock(&o->mu);
             }
@@ -613,12 +683,22 @@ static void run_pipeline(driver* d, walkpool_t* o)
             while (!o->jobs[o->printed].done) pthread_cond_wait(&o->cv, &o->mu);
             rjob_t* P = &o->jobs[o->printed++];
             pthread_mutex_unlock(&o->mu);
-            if (P->len && fwrite(P->buf, 1, P->len, OUT) != P->len) fatalf("write to stdout failed");
+            if (P->len && speculate) spec_keep_output(&spec, P->buf, P->len);
+            else if (P->len && fwrite(P->buf, 1, P->len, OUT) != P->len) fatalf("write to stdout failed");
             free(P->buf);
             pthread_mutex_lock(&o->mu);
         }
         pthread_mutex_unlock(&o->mu);
         for (int i = 0; i < nrep; i++) pthread_join(rp[i].th, NULL);
+        if (speculate) {
+            /* every piece is in and replayed: does the table of the whole file say what the provisional one said? */
+            for (int i = 0; i < o->nw; i++) pthread_join(o->w[i].th, NULL);
+            if (!spec_holds(&spec)) spec_fallback("the extrema of the whole file differ");
+            g_spec_active = 0;
+            onepass_print_tables(d, &spec);
+            if (spec.out_len && fwrite(spec.out, 1, spec.out_len, OUT) != spec.out_len) fatalf("write to stdout failed");
+            free(spec.out); spec.out = NULL;
+        }
         fflush(OUT);
         fflush(stdout);
         phase_time("replay workers drained");
@@ -628,7 +708,7 @@ static void run_pipeline(driver* d, walkpool_t* o)
     free(o->jobs); o->jobs = NULL; free(held); free(dead);
     d->numread = numread;
     if (g_handoff_pool) { g_handoff_pool = NULL; if (t_out) { fflush(t_out); fclose(t_out); t_out = NULL; } }
-    for (int i = 0; i < o->nw && !o->serial && !g_onepass && !(g_mg && g_mg->split); i++) pthread_join(o->w[i].th, NULL);
+    for (int i = 0; i < o->nw && !o->serial && !g_onepass && !(g_mg && g_mg->split); i++) pthread_join(o->w[i].th, NULL);      /* one pass: joined above */
     /* the walkers' pinned rings and device arrays go with the process unless a tidy exit is asked for (leak checkers):
      * un-pinning and freeing them costs more than the whole device stage of a run */
     if (getenv("INDELMINER_TIDY_EXIT")) {
@@ -658,6 +738,7 @@ static void pipeline_handoff(void)
         fflush(stderr);
         _exit(EXIT_SUCCESS);
     }
+    if (g_spec_active) { g_spec_active = 0; handoff_to_host_child(); }      /* a speculative one-pass run has printed nothing but the header */
     if (o->jobs) {
         pthread_mutex_lock(&o->mu);
         while (o->printed < o->n_jobs) {

@@ -57,10 +57,13 @@ static time_t t0;
 static void out_flush_on_exit(void);
 static void walker_bails_out(void);
 static void mg_rank_failed(void);
+static volatile int g_spec_active;      /* the walk is being staged on a provisional insert-length table (run_pipeline) */
+static void spec_fallback(const char* why);
 static void fatalf(const char* fmt, ...)
 {
     /* src/errors.c:15-27: message on stderr, exit(1) */
     va_list ap;
+    if (g_spec_active) spec_fallback(fmt);      /* nothing is out yet: the run without the speculation finds out what is wrong, if anything is */
     walker_bails_out();         /* a walker thread of the pipeline does not come back from this (see handoff_to_host_child) */
     mg_rank_failed();           /* multi-GPU: rank 0 stops waiting for this rank's output */
     va_start(ap, fmt);
@@ -123,8 +126,21 @@ static void out_flush_on_exit(void)
     if (g_real_stderr >= 0) { fflush(stderr); dup2(g_real_stderr, STDERR_FILENO); g_real_stderr = -1; }
 }
 extern char** environ;
-static void handoff_to_host_child(void)
+static void spawn_self_and_exit(const char* mode);
+static void handoff_to_host_child(void) { spawn_self_and_exit("INDELMINER_PIPELINE=host"); }
+/* The one-pass run staged its groups on an insert-length table made from the first pieces, and the whole file says otherwise (or
+ * something else went wrong on the way): only the header is out; the same program takes the run again with the pre-pass. */
+static void spec_fallback(const char* why)
 {
+    static pthread_mutex_t once = PTHREAD_MUTEX_INITIALIZER;
+    pthread_mutex_lock(&once);                  /* the first caller takes the process with it; a second one waits for that */
+    g_spec_active = 0;
+    if (getenv("INDELMINER_TIMING") || getenv("INDELMINER_DEBUG_HANDOFF")) fprintf(stderr, "[one pass] provisional insert lengths did not hold (%s): the run is taken again with the pre-pass\n", why);
+    spawn_self_and_exit("INDELMINER_ONEPASS=0");
+}
+static void spawn_self_and_exit(const char* mode)
+{
+    const int host_mode = strncmp(mode, "INDELMINER_PIPELINE=", 20) == 0;
     if (t_out) fflush(t_out);
     fflush(stdout);
     /* the child's environment is a private copy: other threads (walkers, replay workers) may be inside getenv, and setenv
@@ -134,15 +150,16 @@ static void handoff_to_host_child(void)
     snprintf(from, sizeof from, "INDELMINER_HANDOFF_PARENT=%ld", (long)getpid());
     size_t n_env = 0;
     while (environ[n_env]) n_env++;
-    char** envp = malloc(sizeof(char*) * (n_env + 4));
+    char** envp = malloc(sizeof(char*) * (n_env + 5));
     if (!envp) _exit(EXIT_FAILURE);
     size_t k = 0;
     for (size_t i = 0; i < n_env; i++)
-        if (strncmp(environ[i], "INDELMINER_PIPELINE=", 20) != 0 && strncmp(environ[i], "INDELMINER_SKIP_STDOUT=", 23) != 0 &&
-            strncmp(environ[i], "INDELMINER_HANDOFF_PARENT=", 26) != 0) envp[k++] = environ[i];
-    envp[k++] = (char*)"INDELMINER_PIPELINE=host";
+        if (strncmp(environ[i], host_mode ? "INDELMINER_PIPELINE=" : "INDELMINER_ONEPASS=", host_mode ? 20 : 19) != 0 && strncmp(environ[i], "INDELMINER_SKIP_STDOUT=", 23) != 0 &&
+            strncmp(environ[i], "INDELMINER_HANDOFF_PARENT=", 26) != 0 && strncmp(environ[i], "INDELMINER_HANDOFF_QUIET=", 25) != 0) envp[k++] = environ[i];
+    envp[k++] = (char*)mode;
     envp[k++] = skip;
     envp[k++] = from;
+    if (host_mode) envp[k++] = (char*)"INDELMINER_HANDOFF_QUIET=1";       /* what that child has to say on stderr has been said (until it dies of something) */
     envp[k] = NULL;
     pid_t pid;
     if (getenv("INDELMINER_DEBUG_HANDOFF")) fprintf(stderr, "[handoff] %lld bytes printed, starting the child\n", (long long)g_out_bytes);

@@ -390,6 +390,46 @@ def test_host_leaked_handoff_variable_drops_nothing(synth_small):
         assert _run(shim, ["-i", "cfg.txt"], synth_small, ref="ref.fa", bam="aln.bam", env=env) == want
 
 
+def _speculation_fails_dir(tmp_path):
+    """a proper pair in the last third of the contig with an insert size beyond every one in the first pieces: the insert-length table
+    made from the first claims does not hold for the whole file"""
+    import numpy as np
+    from indelminer_amd import bamwrite, rawrec, synth
+    refs, rd = synth.simulate(seed=33, ref_len=300_000, coverage=20, n_contigs=2, big_every=4)
+    proper = ((rd.flag & 0x3) == 0x3) & (rd.tid == 1) & (rd.pos > 200_000) & (rd.isize > 0)
+    i = int(np.nonzero(proper)[0][5])
+    mate = int(np.nonzero((rd.pair_id == rd.pair_id[i]) & (np.arange(rd.n) != i))[0][0])
+    rd.isize = rd.isize.copy()
+    rd.isize[i] = int(rd.isize.max()) + 40
+    rd.isize[mate] = -int(rd.isize[i])
+    contigs = [("ctg%d" % k, len(r)) for k, r in enumerate(refs)]
+    bamwrite.write_fasta(str(tmp_path / "ref.fa"), contigs, refs)
+    rawrec.write_bam_fast(str(tmp_path / "aln.bam"), contigs, rd)
+    return str(tmp_path)
+
+
+def _one_pass_speculation(binary, tmp_path):
+    """One pass without a config file stages its groups behind the walk on the table made from the first claims and holds its output
+    back; the table of the whole file decides at the end.  When it differs the run is taken again with the pre-pass: the bytes of the
+    pre-pass run either way, and of the reference."""
+    d = _speculation_fails_dir(tmp_path)
+    want = _run(_build_shim(), [], d, ref="ref.fa", bam="aln.bam", env={"INDELMINER_PIPELINE": "host"})
+    ref_bin = os.path.join(ROOT, "oracle", "_ref", "indelminer")
+    if os.path.exists(ref_bin):
+        assert _run(ref_bin, [], d, ref="ref.fa", bam="aln.bam") == want
+    small = {"INDELMINER_PIECE_BYTES": "60000", "INDELMINER_CLAIM_BASES": "1", "INDELMINER_WALKERS": "2", "INDELMINER_TIMING": "1"}
+    e = dict(os.environ, **small)
+    r = subprocess.run([binary, "ref.fa", "s=aln.bam"], cwd=d, stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=e)
+    assert r.returncode == 0 and r.stdout == want, r.stderr.decode()[-1500:]
+    assert b"provisional insert lengths did not hold" in r.stderr
+    for env in ({"INDELMINER_SPECULATE": "0"}, {"INDELMINER_ONEPASS": "0"}, dict(small, INDELMINER_SPECULATE="0")):
+        assert _run(binary, [], d, ref="ref.fa", bam="aln.bam", env=env) == want, env
+
+
+def test_host_one_pass_speculation_that_fails(tmp_path):
+    _one_pass_speculation(_build_shim(), tmp_path)
+
+
 def test_host_contigs_without_reads(tmp_path):
     """contigs that deliver no record at all -- the first, one in the middle, the last -- between contigs that do: claims,
     groups and flush placement must not mind (the read counter and the marker floor simply pass through them)"""
@@ -841,6 +881,11 @@ def test_product_rejects_long_read_library_at_startup(tmp_path):
 @pytest.mark.gpu
 def test_product_read_with_more_indels_than_the_kernels_hold(tmp_path):
     _many_indels_in_one_read(_product(), tmp_path, ({}, {"INDELMINER_CLAIM_BASES": "1", "INDELMINER_WALKERS": "3"}, {"INDELMINER_ONEPASS": "0"}), expect_handoff=True)
+
+
+@pytest.mark.gpu
+def test_product_one_pass_speculation_that_fails(tmp_path):
+    _one_pass_speculation(_product(), tmp_path)
 
 
 @pytest.mark.gpu
