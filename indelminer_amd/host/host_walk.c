@@ -442,13 +442,16 @@ static int onepass_table(driver* d, spec_t* S, int print)
     if (print) onepass_print_tables(d, S);
     return n;
 }
-/* the whole file's list against the provisional one: same groups in the same order with the same extrema? */
-static int spec_holds(const spec_t* S)
+/* The whole file's list against the provisional one: the same groups in the same order with the same range[1]?  range[1] is what
+ * the path reads (src/indelminer.c:520, 583-584, src/alignment.c:775-780); range[0] is only ever printed (and asserted to be
+ * <= range[1]), so a smaller minimum found later just goes into the table before it is printed. */
+static int spec_holds(driver* d, const spec_t* S)
 {
     mg_rg* fin;
     const int n = spec_merge(S, &fin);
     int ok = n == S->n_prov;
-    for (int j = 0; ok && j < n; j++) ok = strcmp(fin[j].name, S->prov[j].name) == 0 && fin[j].min == S->prov[j].min && fin[j].max == S->prov[j].max;
+    for (int j = 0; ok && j < n; j++) ok = strcmp(fin[j].name, S->prov[j].name) == 0 && fin[j].max == S->prov[j].max;
+    if (ok) for (int j = 0; j < n; j++) rg_table_enter(d, &fin[j]);       /* the minima of the whole file */
     free(fin);
     return ok;
 }
@@ -693,7 +696,7 @@ static void run_pipeline(driver* d, walkpool_t* o)
         if (speculate) {
             /* every piece is in and replayed: does the table of the whole file say what the provisional one said? */
             for (int i = 0; i < o->nw; i++) pthread_join(o->w[i].th, NULL);
-            if (!spec_holds(&spec)) spec_fallback("the extrema of the whole file differ");
+            if (!spec_holds(d, &spec)) spec_fallback("the whole file has other read groups or larger insert sizes");
             g_spec_active = 0;
             onepass_print_tables(d, &spec);
             if (spec.out_len && fwrite(spec.out, 1, spec.out_len, OUT) != spec.out_len) fatalf("write to stdout failed");
