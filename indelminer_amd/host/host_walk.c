@@ -490,7 +490,7 @@ static void run_pipeline(driver* d, walkpool_t* o)
      * while the rest of the file is still being walked: groups are staged and replayed behind the walk as in a run with a config
      * file, their output kept back.  When every piece is in, the table of the whole file is made; if it is the provisional one,
      * the output goes out; if not (or if anything went wrong on the way), only the header is out and the program takes the run
-     * again with the pre-pass (spec_fallback).  INDELMINER_SPECULATE=0, -o detailed: the table is made when the walk is over. */
+     * again with the pre-pass (spec_fallback).  Small inputs, -o detailed: the table is made when the walk is over. */
     const char* re = getenv("INDELMINER_REPLAYERS");
     int nrep = re ? atoi(re) : 8;       /* idle while there is nothing to replay; at the end of the walk the cores are theirs (three left the last contigs a backlog of 1.3 s at WGS scale) */
     if (o->serial || g_mg || strcmp(O.outputformat, "vcf") != 0 || nrep < 2) nrep = 0;
@@ -500,7 +500,13 @@ static void run_pipeline(driver* d, walkpool_t* o)
     int speculate = 0, spec_first = 0;
     if (g_onepass) {
         const char* sp = getenv("INDELMINER_SPECULATE");
-        speculate = t_out != NULL && nrep > 0 && !(sp && strcmp(sp, "0") == 0) && !getenv("INDELMINER_NO_HANDOFF");
+        /* Worth it, and likely to hold, on large inputs only: the largest proper-pair insert size is the aligner's cut-off, which a
+         * library of hundreds of millions of pairs meets within its first per cent, a small one perhaps never in its first
+         * claims -- and a run taken twice costs more than the tail it was to hide.  INDELMINER_SPECULATE=1 / =0 override. */
+        int64_t bam_bytes = 0;
+        for (int32_t t = 0; t < d->hdr->n_targets; t++) bam_bytes += bai_contig_bytes(d->idx, t);
+        const int wanted = sp ? strcmp(sp, "0") != 0 : bam_bytes >= ((int64_t)4 << 30);
+        speculate = t_out != NULL && nrep > 0 && wanted && !getenv("INDELMINER_NO_HANDOFF");
         const int first_k = speculate ? (o->n_claims < o->nw ? o->n_claims : o->nw) : o->n_claims;
         pthread_mutex_lock(&o->mu);
         for (int ci = 0; ci < first_k; ci++) while (!o->claims[ci].walked) pthread_cond_wait(&o->cv, &o->mu);

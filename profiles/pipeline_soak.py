@@ -76,6 +76,8 @@ for seed in range(first, first + n):
                 env["INDELMINER_FLUSH_MODE"] = rng.choice(["seq", "per-flush", "wide"])
             if rng.random() < 0.15:
                 env["INDELMINER_KEEP_QUAL"] = "1"
+            if rng.random() < 0.5:
+                env["INDELMINER_SPECULATE"] = "1"                           # one pass staged behind the walk on the first claims' table (may fall back)
             rc, got, err = run(td, flags, env)
             if rc != 0 or got != want:
                 print("MISMATCH seed %d flags %r env %r rc %d: %s" % (seed, flags, env, rc, err.decode(errors="replace")), flush=True)

@@ -121,6 +121,7 @@ def main():
         "config": (["-i", "w.cfg"], {}),
         "estimate": ([], {"INDELMINER_ONEPASS": "0"}),
         "onepass": ([], {}),
+        "onepass_plain": ([], {"INDELMINER_SPECULATE": "0"}),
         "walkers8": (["-i", "w.cfg"], {"INDELMINER_WALKERS": "8"}),
         "walkers1": (["-i", "w.cfg"], {"INDELMINER_WALKERS": "1"}),
         "threads2": (["-i", "w.cfg"], {"INDELMINER_WALKERS": "8", "INDELMINER_THREADS": "2"}),

@@ -417,17 +417,26 @@ def _one_pass_speculation(binary, tmp_path):
     ref_bin = os.path.join(ROOT, "oracle", "_ref", "indelminer")
     if os.path.exists(ref_bin):
         assert _run(ref_bin, [], d, ref="ref.fa", bam="aln.bam") == want
-    small = {"INDELMINER_PIECE_BYTES": "60000", "INDELMINER_CLAIM_BASES": "1", "INDELMINER_WALKERS": "2", "INDELMINER_TIMING": "1"}
+    small = {"INDELMINER_PIECE_BYTES": "60000", "INDELMINER_CLAIM_BASES": "1", "INDELMINER_WALKERS": "2", "INDELMINER_TIMING": "1",
+             "INDELMINER_SPECULATE": "1"}         # by itself only on inputs of gigabytes
     e = dict(os.environ, **small)
     r = subprocess.run([binary, "ref.fa", "s=aln.bam"], cwd=d, stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=e)
     assert r.returncode == 0 and r.stdout == want, r.stderr.decode()[-1500:]
     assert b"provisional insert lengths did not hold" in r.stderr
-    for env in ({"INDELMINER_SPECULATE": "0"}, {"INDELMINER_ONEPASS": "0"}, dict(small, INDELMINER_SPECULATE="0")):
+    for env in ({}, {"INDELMINER_ONEPASS": "0"}, dict(small, INDELMINER_SPECULATE="0")):
         assert _run(binary, [], d, ref="ref.fa", bam="aln.bam", env=env) == want, env
+    # and a speculation that holds: the same input without the late large insert (synth_small's goldens), pieces for two walkers
+    return small
 
 
-def test_host_one_pass_speculation_that_fails(tmp_path):
-    _one_pass_speculation(_build_shim(), tmp_path)
+def test_host_one_pass_speculation(tmp_path, synth_small, synth_1mb):
+    shim = _build_shim()
+    small = _one_pass_speculation(shim, tmp_path)
+    for d, golden in ((synth_small, "synth_2ctg_composite_noconfig"), (synth_1mb, "synth_1mb_30x_noconfig")):
+        r = subprocess.run([shim, "ref.fa", "s=aln.bam"], cwd=d, stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=dict(os.environ, **small))
+        assert r.returncode == 0 and r.stdout == _golden(golden)
+        if b"did not hold" not in r.stderr:
+            assert b"provisional insert lengths from the first claims" in r.stderr       # staged behind the walk, and it held
 
 
 def test_host_contigs_without_reads(tmp_path):
@@ -884,8 +893,12 @@ def test_product_read_with_more_indels_than_the_kernels_hold(tmp_path):
 
 
 @pytest.mark.gpu
-def test_product_one_pass_speculation_that_fails(tmp_path):
-    _one_pass_speculation(_product(), tmp_path)
+def test_product_one_pass_speculation(tmp_path, synth_small, synth_1mb):
+    prod = _product()
+    small = _one_pass_speculation(prod, tmp_path)
+    for d, golden in ((synth_small, "synth_2ctg_composite_noconfig"), (synth_1mb, "synth_1mb_30x_noconfig")):
+        r = subprocess.run([prod, "ref.fa", "s=aln.bam"], cwd=d, stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=dict(os.environ, **small))
+        assert r.returncode == 0 and r.stdout == _golden(golden)
 
 
 @pytest.mark.gpu
