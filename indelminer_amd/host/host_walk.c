@@ -187,7 +187,7 @@ static void* walker_thread(void* arg)
         pthread_mutex_unlock(&o->mu);
         if (ci < 0) break;
         claim_t* c = &o->claims[ci];
-        const int ship = g_mg && g_mg->claim_owner[ci] != g_mg->rank;
+        volatile int ship = g_mg && g_mg->claim_owner[ci] != g_mg->rank;       /* read behind a setjmp */
         if (g_handoff_pool) {
             /* a record the reference dies on ends this walker: the claim is published as it is, marked */
             W->cur_claim = c;
