@@ -252,7 +252,8 @@ int main(int argc, char** argv)
         if (!(pl0 && strcmp(pl0, "host") == 0)) {
             if (chromid != -1) {
                 g_region_tid = chromid; g_region_beg = chromstart; g_region_end = chromstop;
-                if (g_region_end > d.hdr->target_len[chromid]) g_region_end = d.hdr->target_len[chromid];
+                /* not clipped to the contig's length: bam_fetch(tid, beg, end) with "ctg" alone means end = 2^29 and delivers records
+                 * whose position lies behind the contig's end too (a whole-genome run, which fetches [0, length), never sees them) */
                 if (g_region_end < g_region_beg) g_region_end = g_region_beg;
             }
             /* no config file: the insert lengths are estimated by the walk itself (run_pipeline) instead of by a pass of their own;

@@ -97,6 +97,7 @@ typedef struct pgroup_s {
      * own until the main thread stages them */
     rgstat_t rgs[MG_MAX_RG]; int n_rgs;
     covlist cov;                        /* one-pass mode: the group's share of the observed coverage */
+    char crg[MG_MAX_RG][48]; int n_crg, crg_last;   /* the read groups met on COUNTED reads (the reference looks each one's up) */
     uint8_t* npp_raw; int64_t npp_len, npp_cap; int64_t* npp_off; int32_t* npp_rec; int32_t n_npp, cap_npp;
     void* sv[10]; int32_t sv_n; int64_t sv_bytes; int32_t* sv_range;
     /* candidates as the device found them: record index + a host copy of the raw record */
@@ -469,6 +470,30 @@ static void note_long_read(driver* d, int l_seq)
     while (l_seq > cur && !__atomic_compare_exchange_n(&g_longest_read, &cur, l_seq, 1, __ATOMIC_RELAXED, __ATOMIC_RELAXED)) {}
 }
 
+/* fetch_func looks the read group of every read it counts up in the insert-length table and dies where one is missing
+ * (src/indelminer.c:369-376).  With the table in hand (configuration file, several ranks) a walker does the same at the first read
+ * of each group it meets -- its exit hands the run over (walker_bails_out); in one pass the names wait in the group for the table
+ * (run_pipeline). */
+static void note_counted_rg(driver* d, pgroup* G, const bam_record* b)
+{
+    const uint8_t* rg = bam_aux_find(b, "RG");
+    const char* rgname = "generic";
+    if (rg) {
+        if (rg[0] != 'Z') fatalf("a read group tag of %s is not a string", BAMR_QNAME(b));     /* bam_aux2Z gives NULL, strlen(NULL) follows */
+        rgname = bam_aux_str(rg);
+    }
+    if (G->n_crg && strcmp(G->crg[G->crg_last], rgname) == 0) return;
+    int k = 0;
+    while (k < G->n_crg && strcmp(G->crg[k], rgname) != 0) k++;
+    if (k == G->n_crg) {
+        if (!g_onepass && !qhash_lookup(d->insertlengths, rgname, (int)strlen(rgname))) fatalf("did not find %s in the hash", rgname);
+        if (G->n_crg == MG_MAX_RG || strlen(rgname) >= sizeof G->crg[0])
+            fatalf("at most %d read groups with names under %zu bytes are supported here", MG_MAX_RG, sizeof G->crg[0]);
+        snprintf(G->crg[G->n_crg++], sizeof G->crg[0], "%s", rgname);
+    }
+    G->crg_last = k;
+}
+
 static void pipe_host_record(driver* d, pgroup* G, const bam_record* b)
 {
     const int flag = b->flag;
@@ -482,6 +507,7 @@ static void pipe_host_record(driver* d, pgroup* G, const bam_record* b)
     if (b->l_seq > g_longest_read) note_long_read(d, b->l_seq);
     const int is_aligned = (flag & 0x4) == 0, is_mate_aligned = (flag & 0x8) == 0;
     if (is_aligned && is_mate_aligned && b->tid != b->mtid) return;
+    note_counted_rg(d, G, b);
     if (is_aligned && is_mate_aligned && (flag & 0x2) == 0) {
         /* the pair table (src/indelminer.c:516-615) carries entries from one piece of a contig into the next, and pieces are
          * walked at the same time: the record waits, with its place in the group, for the main thread (group_pair_table) */

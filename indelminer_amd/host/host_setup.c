@@ -28,6 +28,20 @@ static void* gpu_open_thread(void* arg)
     return NULL;
 }
 
+/* the output header (src/indelminer.c:745-754) */
+static void print_output_header(void)
+{
+    if (strncmp(O.outputformat, "vcf", 3) == 0) print_vcf_preamble();
+    if (g_vcfname != NULL)
+        printf("##INFO=<ID=%s,Number=0,Type=Flag,Description=\"The variant is also present in this sample\">\n", g_sample_name);
+    if (strncmp(O.outputformat, "vcf", 3) == 0) printf("#CHROM\tPOS\tID\tREF\tALT\tQUAL\tFILTER\tINFO\n");
+    fflush(OUT);
+}
+/* One pass without a config file: the reference prints its header after its estimation pass and the FASTA read -- a run it ends
+ * inside that pass (an RG tag that is not a string) has printed nothing.  Here that pass IS the walk: the header waits until the
+ * insert-length table has been made (run_pipeline). */
+static int g_header_held;
+
 /* every GPU call site passes through here first */
 static void gpu_wait(driver* d)
 {
@@ -39,11 +53,9 @@ static void gpu_wait(driver* d)
     /* the output header (src/indelminer.c:745-754) goes out only once the GPU is known to be there:
      * nothing is printed by a run that cannot compute */
     if (g_mg_rank > 0) return;                          /* multi-GPU: rank 0 prints the header */
+    if (g_header_held) return;
     if (g_mg_header_path[0] && !freopen(g_mg_header_path, "w", stdout)) fatalf("cannot write %s", g_mg_header_path);   /* ... as the first part */
-    if (strncmp(O.outputformat, "vcf", 3) == 0) print_vcf_preamble();
-    if (g_vcfname != NULL)
-        printf("##INFO=<ID=%s,Number=0,Type=Flag,Description=\"The variant is also present in this sample\">\n", g_sample_name);
-    if (strncmp(O.outputformat, "vcf", 3) == 0) printf("#CHROM\tPOS\tID\tREF\tALT\tQUAL\tFILTER\tINFO\n");
+    print_output_header();
     fflush(stdout);
     /* the header part is complete; whatever a library prints on stdout from here on (librccl's banner) is not VCF */
     if (g_mg_header_path[0] && !freopen("/dev/stderr", "w", stdout)) { }

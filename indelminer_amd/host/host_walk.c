@@ -394,7 +394,7 @@ static walkpool_t* walkpool_start(driver* d)
 
 /* What the one-pass walk has learnt so far: per read group the insert-size extrema with the first sighting, the spans for the
  * coverage table (copied out of the groups, which go when their contig has been replayed), and what it has printed so far. */
-typedef struct { mg_rg* rg; int n_rg, cap_rg; covlist cov; mg_rg* prov; int n_prov; char* out; size_t out_len, out_cap; } spec_t;
+typedef struct { mg_rg* rg; int n_rg, cap_rg; covlist cov; mg_rg* prov; int n_prov; char* out; size_t out_len, out_cap; int unknown_counted_rg; } spec_t;
 static void spec_collect(spec_t* S, driver* d, pgroup* G)
 {
     if (!G) return;
@@ -462,6 +462,21 @@ static void spec_keep_output(spec_t* S, const char* buf, size_t len)
     S->out_len += len;
 }
 
+/* fetch_func looks the read group of every counted read up (src/indelminer.c:369-376, must_find_hashtable): a group that occurs on
+ * counted reads but on no proper pair is not in the estimated table, and the reference dies at that read -- header and earlier
+ * flushes out.  The record-at-a-time run reproduces that. */
+static void onepass_counted_groups_known(driver* d, walkpool_t* o, int n_claims)
+{
+    for (int ci = 0; ci < n_claims; ci++) {
+        const pgroup* G = o->claims[ci].G;
+        for (int k = 0; G && k < G->n_crg; k++)
+            if (!qhash_lookup(d->insertlengths, G->crg[k], (int)strlen(G->crg[k]))) {
+                if (g_handoff_pool) pipeline_handoff();
+                fatalf("did not find %s in the hash", G->crg[k]);
+            }
+    }
+}
+
 static void run_pipeline(driver* d, walkpool_t* o)
 {
     d->pipe_mode = 1;
@@ -475,6 +490,7 @@ static void run_pipeline(driver* d, walkpool_t* o)
         g_handoff_pool = o;
         g_mg_driver = d;
     }
+    g_header_held = g_onepass;      /* one pass: the header follows the insert-length table (gpu_wait) */
     gpu_wait(d);                    /* the reference is on the device */
     pipe_global_init(d);
     if (o->serial) { walker_setup(&o->w[0], d); walker_adopt_driver(&o->w[0], d); }
@@ -528,6 +544,9 @@ static void run_pipeline(driver* d, walkpool_t* o)
                 pthread_mutex_lock(&o->mu); g_spec_active = 1; pthread_cond_broadcast(&o->cv); pthread_mutex_unlock(&o->mu);
                 phase_time("provisional insert lengths from the first claims");
             } else {
+                onepass_counted_groups_known(d, o, o->n_claims);      /* a counted read of a group the table does not know: the reference dies at it */
+                g_header_held = 0;
+                print_output_header();
                 /* every group's candidates get their range[1], the groups spread over threads */
                 int nt = o->nw > 1 ? o->nw : 1;
                 if (nt > o->n_claims) nt = o->n_claims ? o->n_claims : 1;
@@ -598,6 +617,7 @@ static void run_pipeline(driver* d, walkpool_t* o)
         G->seq = ci;
         if (speculate) {
             if (ci >= spec_first) spec_collect(&spec, d, G);                 /* the first claims' went into the provisional table */
+            for (int k = 0; k < G->n_crg; k++) if (!qhash_lookup(d->insertlengths, G->crg[k], (int)strlen(G->crg[k]))) spec.unknown_counted_rg = 1;
             if (!G->sv_range) G->sv_range = group_ranges(d, G);               /* walked before that table was there */
         }
         const int first_of_contig = G->ctg[0].first, last_of_contig = G->ctg[G->n_ctg - 1].last;
@@ -702,9 +722,11 @@ static void run_pipeline(driver* d, walkpool_t* o)
         if (speculate) {
             /* every piece is in and replayed: does the table of the whole file say what the provisional one said? */
             for (int i = 0; i < o->nw; i++) pthread_join(o->w[i].th, NULL);
-            if (!spec_holds(d, &spec)) spec_fallback("the whole file has other read groups or larger insert sizes");
+            if (!spec_holds(d, &spec) || spec.unknown_counted_rg) spec_fallback("the whole file has other read groups or larger insert sizes");
             g_spec_active = 0;
             onepass_print_tables(d, &spec);
+            g_header_held = 0;
+            print_output_header();
             if (spec.out_len && fwrite(spec.out, 1, spec.out_len, OUT) != spec.out_len) fatalf("write to stdout failed");
             free(spec.out); spec.out = NULL;
         }

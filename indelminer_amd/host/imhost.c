@@ -129,7 +129,7 @@ extern char** environ;
 static void spawn_self_and_exit(const char* mode);
 static void handoff_to_host_child(void) { spawn_self_and_exit("INDELMINER_PIPELINE=host"); }
 /* The one-pass run staged its groups on an insert-length table made from the first pieces, and the whole file says otherwise (or
- * something else went wrong on the way): only the header is out; the same program takes the run again with the pre-pass. */
+ * something else went wrong on the way): nothing is out, the header waits for the table (g_header_held); the same program takes the run again with the pre-pass. */
 static void spec_fallback(const char* why)
 {
     static pthread_mutex_t once = PTHREAD_MUTEX_INITIALIZER;

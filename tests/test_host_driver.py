@@ -994,7 +994,7 @@ def _odd_inputs(binary, tmp_path, envs, seeds=None):
 
 def test_host_odd_inputs_match_the_reference(tmp_path):
     """host logic on the CPU shim; a third of the list here, the whole list on the GPU below"""
-    assert _odd_inputs(_build_shim(), tmp_path, [{}, {"INDELMINER_PIPELINE": "host"}], seeds=set(range(20000, 20070, 3))) > 20
+    assert _odd_inputs(_build_shim(), tmp_path, [{}, {"INDELMINER_PIPELINE": "host"}], seeds=set(range(20000, 20070, 3)) | {60037, 60058, 60233}) > 20
 
 
 @pytest.mark.gpu
