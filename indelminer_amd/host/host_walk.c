@@ -181,11 +181,16 @@ static void* walker_thread(void* arg)
     for (;;) {
         pthread_mutex_lock(&o->mu);
         /* walked groups wait for the main thread with their logs and parked arrays: stay a bounded number of claims ahead of it */
+        if (g_timing && (!g_onepass || g_spec_active) && !g_mg && o->next_claim < o->n_claims && o->next_claim >= o->staged + 2 * o->nw + 4) {
+            const int64_t t0w = wall_ns();
+            while (o->next_claim < o->n_claims && o->next_claim >= o->staged + 2 * o->nw + 4) pthread_cond_wait(&o->cv, &o->mu);
+            __atomic_fetch_add(&g_wall_walk_throttled_ns, wall_ns() - t0w, __ATOMIC_RELAXED);
+        }
         while ((!g_onepass || g_spec_active) && !g_mg && o->next_claim < o->n_claims && o->next_claim >= o->staged + 2 * o->nw + 4) pthread_cond_wait(&o->cv, &o->mu);
         while (g_mg && o->next_claim < o->n_claims && g_mg->claim_walker[o->next_claim] != g_mg->rank) o->next_claim++;      /* another rank walks it */
         const int ci = o->next_claim < o->n_claims ? o->next_claim++ : -1;
         pthread_mutex_unlock(&o->mu);
-        if (ci < 0) break;
+        if (ci < 0) { __atomic_fetch_add(&g_cpu_walk_ns, thread_cpu_ns(), __ATOMIC_RELAXED); break; }
         claim_t* c = &o->claims[ci];
         volatile int ship = g_mg && g_mg->claim_owner[ci] != g_mg->rank;       /* read behind a setjmp */
         if (g_handoff_pool) {
@@ -246,7 +251,7 @@ static void* replay_thread(void* arg)
         while (o->next_job >= o->n_jobs && !o->jobs_closed) pthread_cond_wait(&o->cv, &o->mu);
         const int j = o->next_job < o->n_jobs ? o->next_job++ : -1;
         pthread_mutex_unlock(&o->mu);
-        if (j < 0) break;
+        if (j < 0) { __atomic_fetch_add(&g_cpu_replay_ns, thread_cpu_ns(), __ATOMIC_RELAXED); break; }
         rjob_t* J = &o->jobs[j];
         {   /* test hook: every other replay takes this much longer, so that replays finish out of order on any machine */
             const char* dl = getenv("INDELMINER_DEBUG_REPLAY_DELAY_MS");
@@ -733,6 +738,7 @@ static void run_pipeline(driver* d, walkpool_t* o)
         fflush(OUT);
         fflush(stdout);
         phase_time("replay workers drained");
+        cpu_report();
         if (getenv("INDELMINER_TIDY_EXIT")) for (int k = 0; k < n_freeable; k++) if (dead[k].chain) groups_free_chain(dead[k].chain);
         free(rp);
     }

@@ -188,6 +188,19 @@ static void phase_time(const char* what)
     g_t_last = t;
 }
 
+/* INDELMINER_TIMING: processor seconds by kind of thread (on a box with as many threads as cores the run is as long as their sum) */
+static int64_t g_cpu_walk_ns, g_cpu_replay_ns, g_wall_walk_throttled_ns;
+static int64_t thread_cpu_ns(void) { struct timespec ts; clock_gettime(CLOCK_THREAD_CPUTIME_ID, &ts); return (int64_t)ts.tv_sec * 1000000000LL + ts.tv_nsec; }
+static int64_t wall_ns(void) { struct timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return (int64_t)ts.tv_sec * 1000000000LL + ts.tv_nsec; }
+static void cpu_report(void)
+{
+    if (!g_timing) return;
+    struct timespec ts; clock_gettime(CLOCK_PROCESS_CPUTIME_ID, &ts);
+    fprintf(stderr, "[timing] processor seconds: walkers %.2f (+ %.2f s held back behind the main thread), replay workers %.2f, main thread %.2f, whole process %.2f\n",
+            __atomic_load_n(&g_cpu_walk_ns, __ATOMIC_RELAXED) / 1e9, __atomic_load_n(&g_wall_walk_throttled_ns, __ATOMIC_RELAXED) / 1e9,
+            __atomic_load_n(&g_cpu_replay_ns, __ATOMIC_RELAXED) / 1e9, thread_cpu_ns() / 1e9, ts.tv_sec + ts.tv_nsec / 1e9);
+}
+
 static void timestamp(const char* fmt, ...)
 {
     va_list ap;

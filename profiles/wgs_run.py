@@ -93,6 +93,11 @@ def phases(err):
     return {k: round(v, 1) for k, v in agg.items()}
 
 
+def cpu_line(err):
+    m = re.search(r"\[timing\] processor seconds: (.*)", err)
+    return m.group(1) if m else None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--total", type=int, default=3_000_000_000)
@@ -130,6 +135,8 @@ def main():
         "w12t1": (["-i", "w.cfg"], {"INDELMINER_WALKERS": "12", "INDELMINER_THREADS": "1"}),
         "w16t1": (["-i", "w.cfg"], {"INDELMINER_WALKERS": "16", "INDELMINER_THREADS": "1"}),
         "onepass16": ([], {"INDELMINER_WALKERS": "16", "INDELMINER_THREADS": "0"}),
+        "rep4": (["-i", "w.cfg"], {"INDELMINER_REPLAYERS": "4"}),
+        "rep12": (["-i", "w.cfg"], {"INDELMINER_REPLAYERS": "12"}),
     }
     runs = {}
     for name in [v for v in args.variants.split(",") if v]:
@@ -139,7 +146,7 @@ def main():
         rc, wall, err, ru = run_timed([prod] + flags + ["w.fa", "s=w.bam"], args.dir, env, vcf)
         md5, nrec = md5_of(vcf) if rc == 0 else (None, 0)
         runs[name] = {"rc": rc, "wall_s": round(wall, 2), "reads_per_s": n_reads / wall if rc == 0 else None, "vcf_md5": md5, "vcf_records": nrec,
-                      "max_rss_gb_of_any_child_so_far": round(ru.ru_maxrss / 1e6, 2), "phases_ms": phases(err), "stderr_tail": err[-600:] if rc else ""}
+                      "max_rss_gb_of_any_child_so_far": round(ru.ru_maxrss / 1e6, 2), "phases_ms": phases(err), "processor_seconds": cpu_line(err), "stderr_tail": err[-600:] if rc else ""}
         print(name, runs[name], file=sys.stderr, flush=True)
     out["product"] = runs
     md5s = {r["vcf_md5"] for r in runs.values() if r["rc"] == 0}
