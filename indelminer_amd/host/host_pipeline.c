@@ -635,7 +635,7 @@ static void pipe_walk_piece(ppipe* P, pgroup* G, const piece_t* pc, bgzf_reader*
             ? bam_region_next_raw(&it, c->h_raw + c->bytes, (int64_t)PIPE_CHUNK_BYTES - c->bytes, &len, &b) : -2;
         if (rc == -2) {
             if (c->n == 0) fatalf("a BAM record larger than %u bytes", PIPE_CHUNK_BYTES);
-            pipe_submit(P, G);
+            DEV_TIMED(pipe_submit(P, G));
             continue;
         }
         if (rc < 0) fatalf("error while reading %s", d->bam_name);
@@ -651,7 +651,7 @@ static void pipe_walk_piece(ppipe* P, pgroup* G, const piece_t* pc, bgzf_reader*
     cg = &G->ctg[G->n_ctg - 1];
     cg->rec1 = G->n_rec; cg->pe1 = G->n_pe; cg->cn1 = G->n_cn;
     /* the piece's last records go out now */
-    pipe_submit(P, G);
+    DEV_TIMED(pipe_submit(P, G));
 }
 
 static int g_tie_for_sort;

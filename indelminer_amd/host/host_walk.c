@@ -157,9 +157,9 @@ static pgroup* walk_claim(walker_t* W, walkpool_t* o, const claim_t* c)
 {
     pgroup* G = xcalloc(1, sizeof(pgroup));
     for (int k = 0; k < c->count; k++) pipe_walk_piece(&W->P, G, &o->pieces[c->first + k], W->r);
-    pipe_submit(&W->P, G);
-    pipe_drain(&W->P, G);
-    group_park_device(&W->P, G);
+    DEV_TIMED(pipe_submit(&W->P, G));
+    DEV_TIMED(pipe_drain(&W->P, G));
+    DEV_TIMED(group_park_device(&W->P, G));
     return G;
 }
 
@@ -190,7 +190,7 @@ static void* walker_thread(void* arg)
         while (g_mg && o->next_claim < o->n_claims && g_mg->claim_walker[o->next_claim] != g_mg->rank) o->next_claim++;      /* another rank walks it */
         const int ci = o->next_claim < o->n_claims ? o->next_claim++ : -1;
         pthread_mutex_unlock(&o->mu);
-        if (ci < 0) { __atomic_fetch_add(&g_cpu_walk_ns, thread_cpu_ns(), __ATOMIC_RELAXED); break; }
+        if (ci < 0) { __atomic_fetch_add(&g_cpu_walk_ns, thread_cpu_ns(), __ATOMIC_RELAXED); __atomic_fetch_add(&g_cpu_walk_dev_ns, t_cpu_dev_ns, __ATOMIC_RELAXED); break; }
         claim_t* c = &o->claims[ci];
         volatile int ship = g_mg && g_mg->claim_owner[ci] != g_mg->rank;       /* read behind a setjmp */
         if (g_handoff_pool) {

@@ -13,6 +13,7 @@
  */
 #include "iminflate.h"
 
+#include <stdlib.h>
 #include <string.h>
 
 #define LL_BITS 11
@@ -21,9 +22,17 @@
 #define OF_SIZE 1024
 
 /* table entries
- *   litlen:  bits 0-7 code bits to take | 8-15 extra bits (length) or sub-table bits | 16-28 literal / length base / sub-table start
- *            | 31 literal | 30 sub-table | 29 end of block
- *   dist:    bits 0-7 | 8-15 extra bits or sub-table bits | 16-30 distance base / sub-table start | 31 sub-table */
+ *   litlen:  bits 0-7 ALL the bits the symbol takes, codeword + extra bits | 8-11 the codeword's share of them | 12-15 extra bits
+ *            | 16-28 literal / length base | 31 literal | 29 end of block
+ *            sub-table pointer (30): bits 0-7 the main table's bits | 8-15 sub-table bits | 16-28 sub-table start
+ *   dist:    the same fields | 16-30 distance base / sub-table start | 31 sub-table
+ *            an error entry (codes 30, 31; the unused half of a one-code table) has bit 31 and the start 0x7fff
+ * One shift per symbol: the extra bits are read out of a copy of the bit buffer -- (saved & low `all` bits) >> codeword bits, a
+ * BZHI and a SHRX where the processor has them (im_inflate picks that instance at run time) -- off the chain of dependent
+ * operations that runs from one symbol's table entry through the bit buffer to the next look-up.  The loop is bound by the number
+ * of instructions per match, not by that chain: entries are laid out so that a match needs no masking of flags (they are zero
+ * in a length / distance entry) and no validity checks (every slot of an accepted code's tables is filled; what is invalid
+ * carries a flag of the rare path). */
 #define E_LIT  0x80000000u
 #define E_SUB  0x40000000u
 #define E_EOB  0x20000000u
@@ -48,12 +57,12 @@ static inline uint32_t ll_entry(int sym)
     if (sym < 256) return E_LIT | ((uint32_t)sym << 16);
     if (sym == 256) return E_EOB;
     if (sym > 285) return E_EOB | (1u << 16);          /* 286, 287: not valid in a stream; decoding one is an error */
-    return ((uint32_t)kLenBase[sym - 257] << 16) | ((uint32_t)kLenExtra[sym - 257] << 8);
+    return ((uint32_t)kLenBase[sym - 257] << 16) | ((uint32_t)kLenExtra[sym - 257] << 12) | kLenExtra[sym - 257];
 }
 static inline uint32_t of_entry(int sym)
 {
-    if (sym > 29) return (0x7fffu << 16);               /* 30, 31: an error when met */
-    return ((uint32_t)kDistBase[sym] << 16) | ((uint32_t)kDistExtra[sym] << 8);
+    if (sym > 29) return D_SUB | (0x7fffu << 16);       /* 30, 31: an error when met (found on the sub-table path) */
+    return ((uint32_t)kDistBase[sym] << 16) | ((uint32_t)kDistExtra[sym] << 12) | kDistExtra[sym];
 }
 
 /* canonical Huffman code -> look-up table with sub-tables; kind: 0 precode, 1 litlen, 2 distance.  Returns 0 / -1. */
@@ -66,7 +75,7 @@ static int build(uint32_t* table, int table_size, int table_bits, const uint8_t*
     const int nused = nsyms - count[0];
     if (nused == 0) {
         /* no codes at all: legal for the distance code of a block of literals only */
-        for (int i = 0; i < (1 << table_bits); i++) table[i] = kind == 2 ? (0x7fffu << 16) | 1u : (E_EOB | (1u << 16) | 1u);
+        for (int i = 0; i < (1 << table_bits); i++) table[i] = kind == 2 ? (D_SUB | (0x7fffu << 16) | 1u) : (E_EOB | (1u << 16) | 1u);
         return 0;
     }
     if (left > 0 && (kind == 0 || !(nused == 1 && count[1] == 1))) return -1;     /* incomplete: only a litlen / distance code of ONE 1-bit codeword is allowed */
@@ -74,7 +83,7 @@ static int build(uint32_t* table, int table_size, int table_bits, const uint8_t*
     for (int l = 1; l < 15; l++) offs[l + 1] = offs[l] + count[l];
     for (int s = 0; s < nsyms; s++) if (lens[s]) sorted[offs[lens[s]]++] = (uint16_t)s;
     /* the unused half of a one-code table decodes to an error entry */
-    if (left > 0) for (int i = 0; i < (1 << table_bits); i++) table[i] = kind == 2 ? (0x7fffu << 16) | 1u : (E_EOB | (1u << 16) | 1u);
+    if (left > 0) for (int i = 0; i < (1 << table_bits); i++) table[i] = kind == 2 ? (D_SUB | (0x7fffu << 16) | 1u) : (E_EOB | (1u << 16) | 1u);
     uint32_t code = 0;              /* bit-reversed codeword */
     int at = 0, sub_next = 1 << table_bits, sub_prefix = -1, sub_start = 0, sub_bits = 0;
     for (int len = 1; len <= maxlen; len++) {
@@ -82,7 +91,7 @@ static int build(uint32_t* table, int table_size, int table_bits, const uint8_t*
             const int sym = sorted[at];
             const uint32_t e = kind == 0 ? ((uint32_t)sym << 16) : kind == 1 ? ll_entry(sym) : of_entry(sym);
             if (len <= table_bits) {
-                for (uint32_t i = code; i < (1u << table_bits); i += 1u << len) table[i] = e | (uint32_t)len;
+                for (uint32_t i = code; i < (1u << table_bits); i += 1u << len) table[i] = e + (uint32_t)len * 257u;
             } else {
                 const int prefix = (int)(code & ((1u << table_bits) - 1u));
                 if (prefix != sub_prefix) {
@@ -95,7 +104,7 @@ static int build(uint32_t* table, int table_size, int table_bits, const uint8_t*
                     table[prefix] = (kind == 2 ? D_SUB : E_SUB) | ((uint32_t)sub_start << 16) | ((uint32_t)sub_bits << 8) | (uint32_t)table_bits;
                 }
                 const int rest = len - table_bits;
-                for (uint32_t i = code >> table_bits; i < (1u << sub_bits); i += 1u << rest) table[sub_start + (int)i] = e | (uint32_t)rest;
+                for (uint32_t i = code >> table_bits; i < (1u << sub_bits); i += 1u << rest) table[sub_start + (int)i] = e + (uint32_t)rest * 257u;
             }
             /* next codeword, in reversed bits */
             uint32_t bit = 1u << (len - 1);
@@ -109,7 +118,10 @@ static int build(uint32_t* table, int table_size, int table_bits, const uint8_t*
 
 static inline uint64_t load64(const uint8_t* p) { uint64_t v; memcpy(&v, p, 8); return v; }
 
-int64_t im_inflate(const uint8_t* in, size_t in_len, uint8_t* out, size_t out_cap)
+/* the extra bits of the symbol whose entry is ent, out of the bit buffer as it stood in front of the symbol */
+#define EXTRA_BITS(saved, ent) (((saved) & ((1ull << ((ent) & 63u)) - 1ull)) >> (((ent) >> 8) & 15u))
+
+static inline __attribute__((always_inline)) int64_t inflate_stream(const uint8_t* in, size_t in_len, uint8_t* out, size_t out_cap)
 {
     tables_t T;
     const uint8_t* ip = in;
@@ -206,7 +218,8 @@ int64_t im_inflate(const uint8_t* in, size_t in_len, uint8_t* out, size_t out_ca
                     REFILL();
                     continue;
                 }
-                if (e & E_SUB) {
+                if (e & (E_SUB | E_EOB)) {
+                    if (e & E_EOB) { if ((e >> 16) & 1u) return -1; TAKE(e & 255u); done = 1; break; }
                     TAKE(LL_BITS);
                     e = T.ll[((e >> 16) & 0x1fffu) + (uint32_t)(bb & ((1u << ((e >> 8) & 255u)) - 1u))];
                     if (e & E_LIT) {
@@ -216,22 +229,22 @@ int64_t im_inflate(const uint8_t* in, size_t in_len, uint8_t* out, size_t out_ca
                         e = T.ll[bb & ((1u << LL_BITS) - 1u)];
                         continue;
                     }
+                    if (e & E_EOB) { if ((e >> 16) & 1u) return -1; TAKE(e & 255u); done = 1; break; }
                 }
-                if (e & E_EOB) { if ((e >> 16) & 1u) return -1; TAKE(e & 255u); done = 1; break; }
-                if ((e & 255u) == 0) return -1;
+                /* a length: no flags in e */
+                const uint64_t bl = bb;
                 TAKE(e & 255u);
-                const unsigned xl = (e >> 8) & 255u;
-                const unsigned length = ((e >> 16) & 0x1fffu) + (unsigned)(bb & ((1u << xl) - 1u));
-                TAKE(xl);
+                const unsigned length = (e >> 16) + (unsigned)EXTRA_BITS(bl, e);
                 uint32_t d = T.of[bb & ((1u << OF_BITS) - 1u)];
-                if (d & D_SUB) { TAKE(OF_BITS); d = T.of[((d >> 16) & 0x7fffu) + (uint32_t)(bb & ((1u << ((d >> 8) & 255u)) - 1u))]; }
-                if ((d & 255u) == 0) return -1;
+                if (d & D_SUB) {
+                    if (((d >> 16) & 0x7fffu) == 0x7fffu) return -1;
+                    TAKE(OF_BITS);
+                    d = T.of[((d >> 16) & 0x7fffu) + (uint32_t)(bb & ((1u << ((d >> 8) & 255u)) - 1u))];
+                    if (d & D_SUB) return -1;
+                }
+                const uint64_t bd = bb;
                 TAKE(d & 255u);
-                const unsigned xd = (d >> 8) & 255u;
-                const unsigned dbase = (d >> 16) & 0x7fffu;
-                if (dbase == 0x7fffu) return -1;
-                const unsigned dist = dbase + (unsigned)(bb & ((1u << xd) - 1u));
-                TAKE(xd);
+                const unsigned dist = (d >> 16) + (unsigned)EXTRA_BITS(bd, d);
                 if (dist > (size_t)(op - out)) return -1;
                 const uint8_t* src = op - dist;
                 uint8_t* dst = op;
@@ -271,21 +284,20 @@ int64_t im_inflate(const uint8_t* in, size_t in_len, uint8_t* out, size_t out_ca
                 continue;
             }
             if (e & E_EOB) { if ((e >> 16) & 1u) return -1; TAKE(e & 255u); break; }
-            if ((e & 255u) == 0) return -1;
+            const uint64_t bl = bb;
             TAKE(e & 255u);
-            const unsigned xl = (e >> 8) & 255u;
-            const unsigned length = ((e >> 16) & 0x1fffu) + (unsigned)(bb & ((1u << xl) - 1u));
-            TAKE(xl);
+            const unsigned length = (e >> 16) + (unsigned)EXTRA_BITS(bl, e);
             /* <= 15 + 5 bits gone of >= 56: the distance code and its extra bits (15 + 13) fit what is left */
             uint32_t d = T.of[bb & ((1u << OF_BITS) - 1u)];
-            if (d & D_SUB) { TAKE(OF_BITS); d = T.of[((d >> 16) & 0x7fffu) + (uint32_t)(bb & ((1u << ((d >> 8) & 255u)) - 1u))]; }
-            if ((d & 255u) == 0) return -1;
+            if (d & D_SUB) {
+                if (((d >> 16) & 0x7fffu) == 0x7fffu) return -1;
+                TAKE(OF_BITS);
+                d = T.of[((d >> 16) & 0x7fffu) + (uint32_t)(bb & ((1u << ((d >> 8) & 255u)) - 1u))];
+                if (d & D_SUB) return -1;
+            }
+            const uint64_t bd = bb;
             TAKE(d & 255u);
-            const unsigned xd = (d >> 8) & 255u;
-            const unsigned dbase = (d >> 16) & 0x7fffu;
-            if (dbase == 0x7fffu) return -1;
-            const unsigned dist = dbase + (unsigned)(bb & ((1u << xd) - 1u));
-            TAKE(xd);
+            const unsigned dist = (d >> 16) + (unsigned)EXTRA_BITS(bd, d);
             if (dist > (size_t)(op - out) || (size_t)(out_end - op) < length) return -1;
             const uint8_t* src = op - dist;
             uint8_t* dst = op;
@@ -305,4 +317,20 @@ int64_t im_inflate(const uint8_t* in, size_t in_len, uint8_t* out, size_t out_ca
     return (int64_t)(op - out);
 #undef REFILL
 #undef TAKE
+}
+
+static int64_t inflate_plain(const uint8_t* in, size_t in_len, uint8_t* out, size_t out_cap) { return inflate_stream(in, in_len, out, out_cap); }
+__attribute__((target("bmi,bmi2"))) static int64_t inflate_bmi2(const uint8_t* in, size_t in_len, uint8_t* out, size_t out_cap) { return inflate_stream(in, in_len, out, out_cap); }
+
+int64_t im_inflate(const uint8_t* in, size_t in_len, uint8_t* out, size_t out_cap)
+{
+    static int64_t (*fn)(const uint8_t*, size_t, uint8_t*, size_t);
+    int64_t (*f)(const uint8_t*, size_t, uint8_t*, size_t) = __atomic_load_n(&fn, __ATOMIC_RELAXED);
+    if (!f) {
+        __builtin_cpu_init();
+        const char* plain = getenv("INDELMINER_INFLATE_PLAIN");       /* the instance for processors without BMI2, for the tests */
+        f = __builtin_cpu_supports("bmi2") && __builtin_cpu_supports("bmi") && !(plain && plain[0] == '1') ? inflate_bmi2 : inflate_plain;
+        __atomic_store_n(&fn, f, __ATOMIC_RELAXED);
+    }
+    return f(in, in_len, out, out_cap);
 }

@@ -136,14 +136,18 @@ def main():
         "w16t1": (["-i", "w.cfg"], {"INDELMINER_WALKERS": "16", "INDELMINER_THREADS": "1"}),
         "onepass16": ([], {"INDELMINER_WALKERS": "16", "INDELMINER_THREADS": "0"}),
         "rep4": (["-i", "w.cfg"], {"INDELMINER_REPLAYERS": "4"}),
+        "config_v3": (["-i", "w.cfg"], {}),
         "rep12": (["-i", "w.cfg"], {"INDELMINER_REPLAYERS": "12"}),
     }
     runs = {}
     for name in [v for v in args.variants.split(",") if v]:
         flags, env = variants[name]
+        binary = prod
+        if name.endswith("_v3"):        # the host built with -march=x86-64-v3 (exp_libs/indelminer_v3, built by hand)
+            binary = os.path.join(ROOT, "exp_libs", "indelminer_v3")
         vcf = os.path.join(args.dir, "out_%s.vcf" % name)
         env = dict(env, INDELMINER_TIMING="1")
-        rc, wall, err, ru = run_timed([prod] + flags + ["w.fa", "s=w.bam"], args.dir, env, vcf)
+        rc, wall, err, ru = run_timed([binary] + flags + ["w.fa", "s=w.bam"], args.dir, env, vcf)
         md5, nrec = md5_of(vcf) if rc == 0 else (None, 0)
         runs[name] = {"rc": rc, "wall_s": round(wall, 2), "reads_per_s": n_reads / wall if rc == 0 else None, "vcf_md5": md5, "vcf_records": nrec,
                       "max_rss_gb_of_any_child_so_far": round(ru.ru_maxrss / 1e6, 2), "phases_ms": phases(err), "processor_seconds": cpu_line(err), "stderr_tail": err[-600:] if rc else ""}

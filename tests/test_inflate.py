@@ -20,8 +20,10 @@ def _harness(tmp_path, sanitize=True):
 
 def test_inflate_matches_zlib_and_survives_bad_streams(tmp_path):
     exe = _harness(tmp_path)
-    for seed in (1, 2):
-        r = subprocess.run([exe, "350", str(seed)], stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=dict(os.environ, ASAN_OPTIONS="detect_leaks=0"))
+    # the decoder has two instances of its loop (with and without BMI2's bit-field instructions, picked at run time): both
+    for seed, plain in ((1, "0"), (2, "0"), (1, "1"), (3, "1")):
+        r = subprocess.run([exe, "350", str(seed)], stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                           env=dict(os.environ, ASAN_OPTIONS="detect_leaks=0", INDELMINER_INFLATE_PLAIN=plain))
         assert r.returncode == 0, r.stderr.decode()[-3000:]
         got = json.loads(r.stdout.decode())
         assert got["valid"] == 350 and got["truncated"] > 1500 and got["corrupted"] > 3000
