@@ -166,6 +166,20 @@ static seglist seglist_copy(const seglist* a)
     return s;
 }
 
+/* What the VCF output reads of a split-read evidence object is its numbers; the read's name is printed by `-o detailed` only, and
+ * its bases are read by `-o detailed` and by voted_consensus (an INSERTED segment's bases, src/variant.c:52-113).  The device
+ * pipeline builds tens of millions of these objects per run: there they carry neither where nothing reads them. */
+static int g_lean_evidence;
+static seglist seglist_copy_for_evidence(const seglist* a, int seg)
+{
+    if (!g_lean_evidence || CIG_OP(a->ops[seg]) != OP_D) return seglist_copy(a);
+    seglist s = *a;
+    s.ops = xmalloc(sizeof(uint32_t) * (size_t)(a->n ? a->n : 1));
+    memcpy(s.ops, a->ops, sizeof(uint32_t) * (size_t)a->n);
+    s.bases = NULL;
+    return s;
+}
+
 static void seglist_free(seglist* s) { free(s->ops); free(s->bases); s->ops = NULL; s->bases = NULL; s->n = 0; }
 
 static int seglist_first_start(const seglist* s) { return s->ref_start; }
@@ -217,8 +231,8 @@ static evidence_t* evidence_new_sr(const seglist* whole, int seg, int cls, char 
      * indel segment, aln3 = the rest; b1/b2 = the segment's start/end */
     evidence_t* e = xcalloc(1, sizeof *e);
     e->type = EV_SPLIT_READ; e->cls = cls; e->strand = strand; e->qual = qual;
-    e->qname = xstrdup(qname);
-    e->aln = seglist_copy(whole);
+    e->qname = g_lean_evidence ? NULL : xstrdup(qname);
+    e->aln = seglist_copy_for_evidence(whole, seg);
     e->seg = seg;
     int refpos = whole->ref_start;
     for (int i = 0; i < seg; i++) {

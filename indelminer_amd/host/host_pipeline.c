@@ -174,6 +174,7 @@ static void pipe_free_cands(ppipe* P)
 /* once per run, when the reference is on the device and the insert lengths are known */
 static void pipe_global_init(driver* d)
 {
+    g_lean_evidence = g_vcfname == NULL && strncmp(O.outputformat, "vcf", 3) == 0;     /* host_logic.c: what nothing reads is not built */
     /* the insert-length table in the order its entries were added, range[1] of each */
     int32_t* rmax = xmalloc(sizeof(int32_t) * (size_t)(g_rg_n ? g_rg_n : 1));
     for (int i = 0; i < g_rg_n; i++) rmax[i] = g_rg_range[i][1];
@@ -909,15 +910,18 @@ static void candidate_evidence(driver* d, const pgroup* S, int32_t cand, int64_t
     const char* qname = BAMR_QNAME(&b);
     const im_read_result* r = S->res_slot[cand] >= 0 ? &S->res[S->res_slot[cand]] : NULL;
     if (r) {                                        /* status == IM_ST_EVIDENCE, n_ev > 0 */
-        char* bases = decode_bases(&b);
+        /* the read as it was realigned (src/indelminer.c:388-455: the mate's strand decides) -- when something will read it */
+        int want_bases = !g_lean_evidence;
+        for (int k = 0; k < r->n_ev && k < IM_MAX_EV && !want_bases; k++) want_bases = CIG_OP(((const uint32_t*)r->ops)[r->ev[k].seg]) != OP_D;
+        char* bases = want_bases ? decode_bases(&b) : NULL;
         char strand = is_rc ? '-' : '+';
         uint8_t qual;
         if (!is_aligned) {
             qual = (uint8_t)mate_mapq(&b, 1);
-            if (!is_mate_rc) { revcomp_inplace(bases); strand = (strand == '+') ? '-' : '+'; }
+            if (!is_mate_rc) { if (bases) revcomp_inplace(bases); strand = (strand == '+') ? '-' : '+'; }
         } else {
             qual = b.mapq;
-            if (is_rc == is_mate_rc) { revcomp_inplace(bases); strand = (strand == '+') ? '-' : '+'; }
+            if (is_rc == is_mate_rc) { if (bases) revcomp_inplace(bases); strand = (strand == '+') ? '-' : '+'; }
         }
         seglist whole;
         whole.ref_start = r->ref_start; whole.n = r->n_ops; whole.ops = (uint32_t*)r->ops; whole.bases = bases;
@@ -925,8 +929,8 @@ static void candidate_evidence(driver* d, const pgroup* S, int32_t cand, int64_t
             const im_evidence* ge = &r->ev[k];
             evidence_t* e = xcalloc(1, sizeof *e);
             e->type = EV_SPLIT_READ; e->cls = ge->cls; e->strand = strand; e->qual = qual;
-            e->qname = xstrdup(qname);
-            e->aln = seglist_copy(&whole);
+            e->qname = g_lean_evidence ? NULL : xstrdup(qname);
+            e->aln = seglist_copy_for_evidence(&whole, ge->seg);
             e->seg = ge->seg; e->b1 = ge->b1; e->b2 = ge->b2;
             e->lflank = ge->lflank; e->rflank = ge->rflank; e->nd_print = ge->nd_print; e->nd_filter = ge->nd_filter;
             e->arrival = arrival0 + k;

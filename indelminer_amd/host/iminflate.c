@@ -119,7 +119,7 @@ static int build(uint32_t* table, int table_size, int table_bits, const uint8_t*
 static inline uint64_t load64(const uint8_t* p) { uint64_t v; memcpy(&v, p, 8); return v; }
 
 /* the extra bits of the symbol whose entry is ent, out of the bit buffer as it stood in front of the symbol */
-#define EXTRA_BITS(saved, ent) (((saved) & ((1ull << ((ent) & 63u)) - 1ull)) >> (((ent) >> 8) & 15u))
+#define EXTRA_BITS(saved, ent) (((uint32_t)(saved) & ((1u << ((ent) & 31u)) - 1u)) >> (((ent) >> 8) & 15u))     /* a symbol takes at most 15 + 13 bits */
 
 static inline __attribute__((always_inline)) int64_t inflate_stream(const uint8_t* in, size_t in_len, uint8_t* out, size_t out_cap)
 {
