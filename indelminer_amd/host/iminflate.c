@@ -59,6 +59,8 @@ static inline uint32_t ll_entry(int sym)
     if (sym > 285) return E_EOB | (1u << 16);          /* 286, 287: not valid in a stream; decoding one is an error */
     return ((uint32_t)kLenBase[sym - 257] << 16) | ((uint32_t)kLenExtra[sym - 257] << 12) | kLenExtra[sym - 257];
 }
+static uint32_t kLitlenEntry[288];
+static void litlen_entries_init(void) { for (int s = 0; s < 288; s++) kLitlenEntry[s] = ll_entry(s); }
 static inline uint32_t of_entry(int sym)
 {
     if (sym > 29) return D_SUB | (0x7fffu << 16);       /* 30, 31: an error when met (found on the sub-table path) */
@@ -86,12 +88,23 @@ static int build(uint32_t* table, int table_size, int table_bits, const uint8_t*
     if (left > 0) for (int i = 0; i < (1 << table_bits); i++) table[i] = kind == 2 ? (D_SUB | (0x7fffu << 16) | 1u) : (E_EOB | (1u << 16) | 1u);
     uint32_t code = 0;              /* bit-reversed codeword */
     int at = 0, sub_next = 1 << table_bits, sub_prefix = -1, sub_start = 0, sub_bits = 0;
+    /* The main table grows by doubling: while the codes of length len are entered it is 2^len entries long (a codeword IS its
+     * index there), and before the next length it is copied behind itself -- every entry reaches its 2^(bits - len) places
+     * by block copies instead of by strided stores. */
+    int tb = 0;                     /* the main table is 2^tb entries long so far; 0 = nothing entered yet */
     for (int len = 1; len <= maxlen; len++) {
+        if (count[len] && len <= table_bits) {
+            if (tb == 0) tb = len;
+            for (; tb < len; tb++) memcpy(table + (1u << tb), table, sizeof(uint32_t) << tb);
+        } else if (count[len] && tb < table_bits) {
+            if (tb == 0) tb = table_bits;       /* every code is longer than the main table: its entries are all sub-table pointers */
+            for (; tb < table_bits; tb++) memcpy(table + (1u << tb), table, sizeof(uint32_t) << tb);
+        }
         for (int c = 0; c < count[len]; c++, at++) {
             const int sym = sorted[at];
-            const uint32_t e = kind == 0 ? ((uint32_t)sym << 16) : kind == 1 ? ll_entry(sym) : of_entry(sym);
+            const uint32_t e = kind == 0 ? ((uint32_t)sym << 16) : kind == 1 ? kLitlenEntry[sym] : of_entry(sym);
             if (len <= table_bits) {
-                for (uint32_t i = code; i < (1u << table_bits); i += 1u << len) table[i] = e + (uint32_t)len * 257u;
+                table[code] = e + (uint32_t)len * 257u;
             } else {
                 const int prefix = (int)(code & ((1u << table_bits) - 1u));
                 if (prefix != sub_prefix) {
@@ -113,6 +126,8 @@ static int build(uint32_t* table, int table_size, int table_bits, const uint8_t*
         }
         /* the codes get one bit longer: in reversed form the new bit is the most significant one, and it is 0 already */
     }
+    if (tb == 0) tb = table_bits;
+    for (; tb < table_bits; tb++) memcpy(table + (1u << tb), table, sizeof(uint32_t) << tb);
     return 0;
 }
 
@@ -325,12 +340,13 @@ __attribute__((target("bmi,bmi2"))) static int64_t inflate_bmi2(const uint8_t* i
 int64_t im_inflate(const uint8_t* in, size_t in_len, uint8_t* out, size_t out_cap)
 {
     static int64_t (*fn)(const uint8_t*, size_t, uint8_t*, size_t);
-    int64_t (*f)(const uint8_t*, size_t, uint8_t*, size_t) = __atomic_load_n(&fn, __ATOMIC_RELAXED);
+    int64_t (*f)(const uint8_t*, size_t, uint8_t*, size_t) = __atomic_load_n(&fn, __ATOMIC_ACQUIRE);
     if (!f) {
+        litlen_entries_init();          /* the same values from whichever thread comes first */
         __builtin_cpu_init();
         const char* plain = getenv("INDELMINER_INFLATE_PLAIN");       /* the instance for processors without BMI2, for the tests */
         f = __builtin_cpu_supports("bmi2") && __builtin_cpu_supports("bmi") && !(plain && plain[0] == '1') ? inflate_bmi2 : inflate_plain;
-        __atomic_store_n(&fn, f, __ATOMIC_RELAXED);
+        __atomic_store_n(&fn, f, __ATOMIC_RELEASE);
     }
     return f(in, in_len, out, out_cap);
 }
