@@ -335,6 +335,7 @@ int main(int argc, char** argv)
         /* everything is printed: the GPU context, the pinned rings and the device arrays go with the process -- tearing the
          * HIP runtime down in order costs about as long as the whole device work of a small run (leak checkers: INDELMINER_TIDY_EXIT=1) */
         fflush(stdout);
+        phase_time("output flushed; the process ends (what follows is the kernel taking it apart)");
         fflush(stderr);
         _exit(EXIT_SUCCESS);
     }

@@ -84,7 +84,12 @@ typedef struct pgroup_s {
      * place the READCHUNK flush points itself (src/indelminer.c:617-670).  It logs what placing them needs -- for every
      * counted read its record bound and position -- and group_resolve_flushes places them once the pieces before this one
      * have been counted; the pair table's smallest waiting start is logged whenever it moves (group_pair_table). */
-    int32_t *cn_rec, *cn_pos; int64_t n_cn, cap_cn;
+    /* the log of counted reads (record number, position): two bytes per read -- the steps from the read in front of it -- under
+     * checkpoints of absolute values every CN_STRIDE reads, at the start of a piece and wherever a step does not fit a byte
+     * (a whole-genome run counts ~1e9 reads: whole values were 7 GB of the run's memory; cn_at() looks a read up) */
+    uint8_t* cn_step; int64_t n_cn, cap_cn;
+    struct cn_ck { int64_t k; int32_t rec, pos; }* cn_ck; int64_t n_cnck, cap_cnck;
+    int32_t cn_last_rec, cn_last_pos;
     int32_t *lm_rec; int *lm_val; int32_t n_lm, cap_lm;
     /* The reference keeps ONE pair table for the run (readpairs is never reset): a first mate left waiting in one contig is found
      * by a record of the same name in a later contig.  Contigs are worked on independently here, each with a table of its own, so the
@@ -245,7 +250,7 @@ static void group_free(pgroup* G)
 {
     if (G->phantom && G->pe && G->n_pe_front > 0 && G->pe[G->n_pe_front - 1] && G->pe[G->n_pe_front - 1]->type == EV_PHANTOM) evidence_free(G->pe[G->n_pe_front - 1]);
     free(G->ctg); free(G->fl); free(G->fp); free(G->pe); free(G->pe_rec); free(G->cand_rec); free(G->craw_off); free(G->craw);
-    free(G->cn_rec); free(G->cn_pos); free(G->lm_rec); free(G->lm_val);
+    free(G->cn_step); free(G->cn_ck); free(G->lm_rec); free(G->lm_val);
     free(G->npp_raw); free(G->npp_off); free(G->npp_rec); free(G->dn); free(G->sn);
     free(G->res); free(G->res_slot); free(G->s_cls); free(G->s_b1); free(G->s_b2); free(G->cons_sr); free(G->cons_pe); free(G->front); free(G->front_virt);
     free(G->cl_key); free(G->cl_first); free(G->cl_count); free(G->order); free(G->cl_sorted); free(G->ev_cache);
@@ -471,6 +476,31 @@ static void note_long_read(driver* d, int l_seq)
     while (l_seq > cur && !__atomic_compare_exchange_n(&g_longest_read, &cur, l_seq, 1, __ATOMIC_RELAXED, __ATOMIC_RELAXED)) {}
 }
 
+#define CN_STRIDE 256
+static void cn_log(pgroup* G, int32_t rec, int32_t pos)
+{
+    const int64_t k = G->n_cn;
+    if (k == G->cap_cn) { G->cap_cn = G->cap_cn ? G->cap_cn * 2 : (1 << 20); G->cn_step = xrealloc(G->cn_step, 2 * (size_t)G->cap_cn); }
+    const int64_t dr = (int64_t)rec - G->cn_last_rec, dp = (int64_t)pos - G->cn_last_pos;
+    const int64_t since = G->n_cnck ? k - G->cn_ck[G->n_cnck - 1].k : CN_STRIDE;
+    if (since >= CN_STRIDE || k == G->ctg[G->cur_ctg].cn0 || dr < 0 || dr > 255 || dp < 0 || dp > 255) {
+        if (G->n_cnck == G->cap_cnck) { G->cap_cnck = G->cap_cnck ? G->cap_cnck * 2 : 4096; G->cn_ck = xrealloc(G->cn_ck, sizeof *G->cn_ck * (size_t)G->cap_cnck); }
+        G->cn_ck[G->n_cnck].k = k; G->cn_ck[G->n_cnck].rec = rec; G->cn_ck[G->n_cnck].pos = pos; G->n_cnck++;
+        G->cn_step[2 * k] = 0; G->cn_step[2 * k + 1] = 0;
+    } else { G->cn_step[2 * k] = (uint8_t)dr; G->cn_step[2 * k + 1] = (uint8_t)dp; }
+    G->cn_last_rec = rec; G->cn_last_pos = pos;
+    G->n_cn = k + 1;
+}
+/* counted read k of the group (0 <= k < n_cn): its record number and position */
+static void cn_at(const pgroup* G, int64_t k, int32_t* rec, int32_t* pos)
+{
+    int64_t lo = 0, hi = G->n_cnck - 1;                 /* the last checkpoint at or in front of k */
+    while (lo < hi) { const int64_t mid = (lo + hi + 1) >> 1; if (G->cn_ck[mid].k <= k) lo = mid; else hi = mid - 1; }
+    int32_t r = G->cn_ck[lo].rec, p = G->cn_ck[lo].pos;
+    for (int64_t j = G->cn_ck[lo].k + 1; j <= k; j++) { r += G->cn_step[2 * j]; p += G->cn_step[2 * j + 1]; }
+    *rec = r; *pos = p;
+}
+
 /* fetch_func looks the read group of every read it counts up in the insert-length table and dies where one is missing
  * (src/indelminer.c:369-376).  With the table in hand (configuration file, several ranks) a walker does the same at the first read
  * of each group it meets -- its exit hands the run over (walker_bails_out); in one pass the names wait in the group for the table
@@ -526,12 +556,7 @@ static void pipe_host_record(driver* d, pgroup* G, const bam_record* b)
         G->npp_off[G->n_npp] = G->npp_len;
     }
     /* a counted read (src/indelminer.c:617): every READCHUNK-th of the whole run is a flush point */
-    if (G->n_cn == G->cap_cn) {
-        G->cap_cn = G->cap_cn ? G->cap_cn * 2 : (1 << 20);
-        G->cn_rec = xrealloc(G->cn_rec, sizeof(int32_t) * (size_t)G->cap_cn);
-        G->cn_pos = xrealloc(G->cn_pos, sizeof(int32_t) * (size_t)G->cap_cn);
-    }
-    G->cn_rec[G->n_cn] = (int32_t)G->n_rec; G->cn_pos[G->n_cn] = b->pos; G->n_cn++;
+    cn_log(G, (int32_t)G->n_rec, b->pos);
 }
 
 static void group_push_flush(pgroup* G, int64_t rec, int32_t pe, int marker, int32_t tid)
@@ -557,7 +582,9 @@ static void group_flush_points(pgroup* G, int64_t* numread)
         /* the k-th counted read of the piece (k from 0) is read number *numread + k + 1 of the run */
         for (int64_t k = (READCHUNK - 1 - (*numread % READCHUNK)) % READCHUNK; k < ncount; k += READCHUNK) {
             if (G->n_fp == G->cap_fp) { G->cap_fp = G->cap_fp ? G->cap_fp * 2 : 64; G->fp = xrealloc(G->fp, sizeof(gfpoint) * (size_t)G->cap_fp); }
-            G->fp[G->n_fp].rec = G->cn_rec[cg->cn0 + k]; G->fp[G->n_fp].pos = G->cn_pos[cg->cn0 + k]; G->n_fp++;
+            int32_t rec_k, pos_k;
+            cn_at(G, cg->cn0 + k, &rec_k, &pos_k);
+            G->fp[G->n_fp].rec = rec_k; G->fp[G->n_fp].pos = pos_k; G->n_fp++;
             timestamp("Read %ld reads", (long)(*numread + k + 1));
         }
         cg->fp1 = G->n_fp;

@@ -178,6 +178,7 @@ static void* walker_thread(void* arg)
     while (!o->go) pthread_cond_wait(&o->cv, &o->mu);
     pthread_mutex_unlock(&o->mu);
     walker_adopt_driver(W, d);
+    const int64_t w_start = wall_ns(), c_start = thread_cpu_ns();
     for (;;) {
         pthread_mutex_lock(&o->mu);
         /* walked groups wait for the main thread with their logs and parked arrays: stay a bounded number of claims ahead of it */
@@ -190,7 +191,11 @@ static void* walker_thread(void* arg)
         while (g_mg && o->next_claim < o->n_claims && g_mg->claim_walker[o->next_claim] != g_mg->rank) o->next_claim++;      /* another rank walks it */
         const int ci = o->next_claim < o->n_claims ? o->next_claim++ : -1;
         pthread_mutex_unlock(&o->mu);
-        if (ci < 0) { __atomic_fetch_add(&g_cpu_walk_ns, thread_cpu_ns(), __ATOMIC_RELAXED); __atomic_fetch_add(&g_cpu_walk_dev_ns, t_cpu_dev_ns, __ATOMIC_RELAXED); break; }
+        if (ci < 0) {
+            __atomic_fetch_add(&g_cpu_walk_ns, thread_cpu_ns() - c_start, __ATOMIC_RELAXED); __atomic_fetch_add(&g_cpu_walk_dev_ns, t_cpu_dev_ns, __ATOMIC_RELAXED);
+            __atomic_fetch_add(&g_wall_walk_ns, wall_ns() - w_start, __ATOMIC_RELAXED); __atomic_fetch_add(&g_wall_walk_dev_ns, t_wall_dev_ns, __ATOMIC_RELAXED);
+            break;
+        }
         claim_t* c = &o->claims[ci];
         volatile int ship = g_mg && g_mg->claim_owner[ci] != g_mg->rank;       /* read behind a setjmp */
         if (g_handoff_pool) {

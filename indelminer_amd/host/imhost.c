@@ -189,15 +189,17 @@ static void phase_time(const char* what)
 }
 
 /* INDELMINER_TIMING: processor seconds by kind of thread (on a box with as many threads as cores the run is as long as their sum) */
-static int64_t g_cpu_walk_ns, g_cpu_walk_dev_ns, g_cpu_replay_ns, g_wall_walk_throttled_ns;
-static __thread int64_t t_cpu_dev_ns;      /* a walker's processor time inside device calls (uploads, launches, waits) */
-#define DEV_TIMED(call) do { if (g_timing) { const int64_t t0_ = thread_cpu_ns(); call; t_cpu_dev_ns += thread_cpu_ns() - t0_; } else { call; } } while (0)
+static int64_t g_cpu_walk_ns, g_cpu_walk_dev_ns, g_cpu_replay_ns, g_wall_walk_throttled_ns, g_wall_walk_ns, g_wall_walk_dev_ns;
+static __thread int64_t t_cpu_dev_ns, t_wall_dev_ns;      /* a walker's processor time inside device calls (uploads, launches, waits) */
+#define DEV_TIMED(call) do { if (g_timing) { const int64_t t0_ = thread_cpu_ns(), w0_ = wall_ns(); call; t_cpu_dev_ns += thread_cpu_ns() - t0_; t_wall_dev_ns += wall_ns() - w0_; } else { call; } } while (0)
 static int64_t thread_cpu_ns(void) { struct timespec ts; clock_gettime(CLOCK_THREAD_CPUTIME_ID, &ts); return (int64_t)ts.tv_sec * 1000000000LL + ts.tv_nsec; }
 static int64_t wall_ns(void) { struct timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return (int64_t)ts.tv_sec * 1000000000LL + ts.tv_nsec; }
 static void cpu_report(void)
 {
     if (!g_timing) return;
     struct timespec ts; clock_gettime(CLOCK_PROCESS_CPUTIME_ID, &ts);
+    fprintf(stderr, "[timing] walkers: %.2f s of wall time between their start and their last piece, %.2f of them inside device calls\n",
+            __atomic_load_n(&g_wall_walk_ns, __ATOMIC_RELAXED) / 1e9, __atomic_load_n(&g_wall_walk_dev_ns, __ATOMIC_RELAXED) / 1e9);
     fprintf(stderr, "[timing] processor seconds: walkers %.2f (%.2f of them in device calls; + %.2f s held back behind the main thread), replay workers %.2f, main thread %.2f, whole process %.2f\n",
             __atomic_load_n(&g_cpu_walk_ns, __ATOMIC_RELAXED) / 1e9, __atomic_load_n(&g_cpu_walk_dev_ns, __ATOMIC_RELAXED) / 1e9, __atomic_load_n(&g_wall_walk_throttled_ns, __ATOMIC_RELAXED) / 1e9,
             __atomic_load_n(&g_cpu_replay_ns, __ATOMIC_RELAXED) / 1e9, thread_cpu_ns() / 1e9, ts.tv_sec + ts.tv_nsec / 1e9);
