@@ -442,12 +442,11 @@ static void host_discordant(driver* d, pgroup* G, const bam_record* b, int64_t r
 
 /* estimate_insertlengths' share of a record (src/bamoperations.c:15-86): extrema of the insert size per read group, and where
  * the group was first seen (the table lists the groups in file order: its prefix-match look-up depends on that) */
-static void host_rg_stat(pgroup* G, const bam_record* b, int64_t rec_in_contig)
+static void host_rg_stat(pgroup* G, const bam_record* b, const uint8_t* rg, int64_t rec_in_contig)
 {
     const int flag = b->flag;
     if (!((flag & 0x1) && !(flag & 0x4) && (flag & 0x2) && !(flag & (0x100 | 0x200 | 0x400)) &&
           b->isize >= 0 && b->mpos - b->pos >= 0 && b->isize >= b->mpos - b->pos)) return;
-    const uint8_t* rg = bam_aux_find(b, "RG");
     const char* rgname = "generic";
     if (rg) { forceassert(rg[0] == 'Z'); rgname = bam_aux_str(rg); }
     int k = G->n_rgs - 1;                           /* the last group seen first: records of one library come in runs */
@@ -505,9 +504,8 @@ static void cn_at(const pgroup* G, int64_t k, int32_t* rec, int32_t* pos)
  * (src/indelminer.c:369-376).  With the table in hand (configuration file, several ranks) a walker does the same at the first read
  * of each group it meets -- its exit hands the run over (walker_bails_out); in one pass the names wait in the group for the table
  * (run_pipeline). */
-static void note_counted_rg(driver* d, pgroup* G, const bam_record* b)
+static void note_counted_rg(driver* d, pgroup* G, const bam_record* b, const uint8_t* rg)
 {
-    const uint8_t* rg = bam_aux_find(b, "RG");
     const char* rgname = "generic";
     if (rg) {
         if (rg[0] != 'Z') fatalf("a read group tag of %s is not a string", BAMR_QNAME(b));     /* bam_aux2Z gives NULL, strlen(NULL) follows */
@@ -528,8 +526,10 @@ static void note_counted_rg(driver* d, pgroup* G, const bam_record* b)
 static void pipe_host_record(driver* d, pgroup* G, const bam_record* b)
 {
     const int flag = b->flag;
+    const uint8_t* rg = NULL;               /* the record's RG tag, looked for once */
     if (g_onepass) {
-        host_rg_stat(G, b, ((int64_t)(b->pos < 0 ? 0 : b->pos) << 32) | (G->n_rec - 1 - G->ctg[G->cur_ctg].rec0));
+        rg = bam_aux_find(b, "RG");
+        host_rg_stat(G, b, rg, ((int64_t)(b->pos < 0 ? 0 : b->pos) << 32) | (G->n_rec - 1 - G->ctg[G->cur_ctg].rec0));
         if (!G->cov.sum) cov_init(&G->cov, d->hdr->n_targets);
         cov_record(&G->cov, b);
     }
@@ -538,7 +538,7 @@ static void pipe_host_record(driver* d, pgroup* G, const bam_record* b)
     if (b->l_seq > g_longest_read) note_long_read(d, b->l_seq);
     const int is_aligned = (flag & 0x4) == 0, is_mate_aligned = (flag & 0x8) == 0;
     if (is_aligned && is_mate_aligned && b->tid != b->mtid) return;
-    note_counted_rg(d, G, b);
+    note_counted_rg(d, G, b, g_onepass ? rg : bam_aux_find(b, "RG"));
     if (is_aligned && is_mate_aligned && (flag & 0x2) == 0) {
         /* the pair table (src/indelminer.c:516-615) carries entries from one piece of a contig into the next, and pieces are
          * walked at the same time: the record waits, with its place in the group, for the main thread (group_pair_table) */
