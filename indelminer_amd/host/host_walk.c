@@ -314,9 +314,12 @@ static walkpool_t* walkpool_start(driver* d)
         if (by_size < nw) nw = by_size < 2 ? 2 : by_size;
     }
     if (total_bytes < ((int64_t)2 << 30)) { g_chunk_bytes = 16u << 20; g_nchunk = 2; }
+    if (getenv("INDELMINER_CHUNK_MB") && atoi(getenv("INDELMINER_CHUNK_MB")) >= 1 && atoi(getenv("INDELMINER_CHUNK_MB")) <= 256) g_chunk_bytes = (uint32_t)atoi(getenv("INDELMINER_CHUNK_MB")) << 20;
+    if (getenv("INDELMINER_CHUNKS") && atoi(getenv("INDELMINER_CHUNKS")) >= 2 && atoi(getenv("INDELMINER_CHUNKS")) <= PIPE_NCHUNK) g_nchunk = atoi(getenv("INDELMINER_CHUNKS"));
     /* pieces: a contig is cut where its compressed bytes cross multiples of the piece size -- about 1/(8 walkers) of the file, at
      * least 8 MB of it (a stage and a replay have fixed costs per group), so that large contigs spread over all walkers */
     int64_t piece_bytes = total_bytes / (8 * (int64_t)nw);
+    if (piece_bytes > (64 << 20)) piece_bytes = 64 << 20;       /* a piece is what the walkers' ends can differ by: 64 MB is a third of a second */
     if (piece_bytes < (8 << 20)) piece_bytes = 8 << 20;
     if (getenv("INDELMINER_PIECE_BYTES")) piece_bytes = atoll(getenv("INDELMINER_PIECE_BYTES"));
     if (o->serial) piece_bytes = 0;

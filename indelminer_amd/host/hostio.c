@@ -3,6 +3,7 @@
  * Own code over zlib.  Formats: SAM/BAM specification sections 4.1-4.2, 5.
  * Behaviour the reference observes through libbam is cited as SURVEY.md A.12 items.
  */
+#define _DEFAULT_SOURCE         /* madvise(MADV_HUGEPAGE) */
 #define _POSIX_C_SOURCE 200809L
 #include "hostio.h"
 
@@ -923,6 +924,11 @@ int fasta_load(const char* path, int32_t n_expected, char*** seqs_out, int64_t**
                 size_t tot = 0;
                 for (size_t i = first_of[r]; i < first_of[r + 1]; i++) tot += sl[i].kept;
                 char* buf = malloc(tot + 2);
+                if (buf && tot >= ((size_t)4 << 20) && !(getenv("INDELMINER_THP") && getenv("INDELMINER_THP")[0] == '0')) {
+                    /* a genome is gigabytes of first touches: 2 MB pages where the kernel hands them out on request */
+                    const uintptr_t a = (uintptr_t)buf & ~(uintptr_t)4095, z = ((uintptr_t)buf + tot) & ~(uintptr_t)4095;
+                    if (z > a) (void)madvise((void*)a, (size_t)(z - a), MADV_HUGEPAGE);
+                }
                 size_t off = 0;
                 for (size_t i = first_of[r]; i < first_of[r + 1]; i++) { sl[i].dst = buf + off; off += sl[i].kept; sl[i].write = 1; }
                 buf[tot] = 0;

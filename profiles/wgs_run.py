@@ -96,7 +96,8 @@ def phases(err):
 def cpu_line(err):
     m = re.search(r"\[timing\] processor seconds: (.*)", err)
     w = re.search(r"\[timing\] walkers: (.*)", err)
-    return ((w.group(1) + "; ") if w else "") + m.group(1) if m else None
+    r = re.search(r"\[timing\] resident memory at the end: (.*)", err)
+    return ((r.group(1) + "; ") if r else "") + ((w.group(1) + "; ") if w else "") + m.group(1) if m else None
 
 
 def main():
@@ -138,6 +139,18 @@ def main():
         "onepass16": ([], {"INDELMINER_WALKERS": "16", "INDELMINER_THREADS": "0"}),
         "rep4": (["-i", "w.cfg"], {"INDELMINER_REPLAYERS": "4"}),
         "config_v3": (["-i", "w.cfg"], {}),
+        "maps": (["-i", "w.cfg"], {"INDELMINER_TIMING_MAPS": "1"}),
+        "q4": (["-i", "w.cfg"], {"GPU_MAX_HW_QUEUES": "4", "INDELMINER_TIMING_MAPS": "1"}),
+        "q8": (["-i", "w.cfg"], {"GPU_MAX_HW_QUEUES": "8", "INDELMINER_TIMING_MAPS": "1"}),
+        "q2": (["-i", "w.cfg"], {"GPU_MAX_HW_QUEUES": "2", "INDELMINER_TIMING_MAPS": "1"}),
+        "nothp": (["-i", "w.cfg"], {"INDELMINER_THP": "0"}),
+        "nothp2": (["-i", "w.cfg"], {"INDELMINER_THP": "0"}),
+        "config2": (["-i", "w.cfg"], {}),
+        "p96": (["-i", "w.cfg"], {"INDELMINER_PIECE_BYTES": str(96 << 20)}),
+        "p64": (["-i", "w.cfg"], {"INDELMINER_PIECE_BYTES": str(64 << 20)}),
+        "p32": (["-i", "w.cfg"], {"INDELMINER_PIECE_BYTES": str(32 << 20)}),
+        "ring2": (["-i", "w.cfg"], {"INDELMINER_CHUNKS": "2"}),
+        "ring2x16": (["-i", "w.cfg"], {"INDELMINER_CHUNKS": "2", "INDELMINER_CHUNK_MB": "16"}),
         "w20": (["-i", "w.cfg"], {"INDELMINER_WALKERS": "20"}),
         "w24": (["-i", "w.cfg"], {"INDELMINER_WALKERS": "24"}),
         "rep12": (["-i", "w.cfg"], {"INDELMINER_REPLAYERS": "12"}),
@@ -153,7 +166,7 @@ def main():
         rc, wall, err, ru = run_timed([binary] + flags + ["w.fa", "s=w.bam"], args.dir, env, vcf)
         md5, nrec = md5_of(vcf) if rc == 0 else (None, 0)
         runs[name] = {"rc": rc, "wall_s": round(wall, 2), "reads_per_s": n_reads / wall if rc == 0 else None, "vcf_md5": md5, "vcf_records": nrec,
-                      "max_rss_gb_of_any_child_so_far": round(ru.ru_maxrss / 1e6, 2), "phases_ms": phases(err), "wall_s_behind_the_last_phase": round(wall - sum(phases(err).values()) / 1e3, 2), "processor_seconds": cpu_line(err), "stderr_tail": err[-600:] if rc else ""}
+                      "max_rss_gb_of_any_child_so_far": round(ru.ru_maxrss / 1e6, 2), "phases_ms": phases(err), "wall_s_behind_the_last_phase": round(wall - sum(phases(err).values()) / 1e3, 2), "processor_seconds": cpu_line(err), "maps": re.findall(r"\[maps\] (.*)", err), "stderr_tail": err[-600:] if rc else ""}
         print(name, runs[name], file=sys.stderr, flush=True)
     out["product"] = runs
     md5s = {r["vcf_md5"] for r in runs.values() if r["rc"] == 0}
