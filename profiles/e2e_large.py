@@ -27,9 +27,12 @@ with tempfile.TemporaryDirectory() as td:
     print("BAM written in %.1f s, %d bytes" % (time.perf_counter() - t, os.path.getsize(td + "/aln.bam")), flush=True)
     cmd = ["ref.fa", "s=aln.bam"]
     tp = None
+    # E2E_ENVS="A=1 B=2|C=3": every set of settings in turn (alternating, so that a drifting box does not favour one)
+    envsets = [dict(kv.split("=", 1) for kv in es.split()) for es in os.environ.get("E2E_ENVS", "").split("|")]
     for thr in os.environ.get("E2E_THREADS", "").split(","):     # inflate workers per reader (INDELMINER_THREADS), "" = default
-        for _ in range(int(os.environ.get("E2E_REPEAT", "1"))):      # the first run also pages the binary and the inputs in
-            env = dict(os.environ, INDELMINER_TIMING="1")
+        for rep in range(int(os.environ.get("E2E_REPEAT", "1")) * len(envsets)):      # the first run also pages the binary and the inputs in
+            env = dict(os.environ, INDELMINER_TIMING="1", **envsets[rep % len(envsets)])
+            if envsets[rep % len(envsets)]: print("settings:", envsets[rep % len(envsets)], flush=True)
             if thr:                                   # "4" = inflate workers; "4:3" = inflate workers : walkers
                 env["INDELMINER_THREADS"] = thr.split(":")[0]
                 if ":" in thr:
