@@ -140,6 +140,8 @@ def main():
         "rep4": (["-i", "w.cfg"], {"INDELMINER_REPLAYERS": "4"}),
         "config_v3": (["-i", "w.cfg"], {}),
         "maps": (["-i", "w.cfg"], {"INDELMINER_TIMING_MAPS": "1"}),
+        "shared": (["-i", "w.cfg"], {"INDELMINER_STREAMS": "shared", "INDELMINER_TIMING_MAPS": "1"}),
+        "shared2": (["-i", "w.cfg"], {"INDELMINER_STREAMS": "shared", "INDELMINER_TIMING_MAPS": "1"}),
         "q4": (["-i", "w.cfg"], {"GPU_MAX_HW_QUEUES": "4", "INDELMINER_TIMING_MAPS": "1"}),
         "q8": (["-i", "w.cfg"], {"GPU_MAX_HW_QUEUES": "8", "INDELMINER_TIMING_MAPS": "1"}),
         "q2": (["-i", "w.cfg"], {"GPU_MAX_HW_QUEUES": "2", "INDELMINER_TIMING_MAPS": "1"}),
