@@ -236,7 +236,7 @@ static void cpu_report(void)
     }
     fprintf(stderr, "[timing] walkers: %.2f s of wall time between their start and their last piece, %.2f of them inside device calls\n",
             __atomic_load_n(&g_wall_walk_ns, __ATOMIC_RELAXED) / 1e9, __atomic_load_n(&g_wall_walk_dev_ns, __ATOMIC_RELAXED) / 1e9);
-    fprintf(stderr, "[timing] processor seconds: walkers %.2f (%.2f of them in device calls; + %.2f s held back behind the main thread), replay workers %.2f, main thread %.2f, whole process %.2f\n",
+    fprintf(stderr, "[timing] processor seconds: walkers %.2f (%.2f of them in device calls; + %.2f s held back behind the main thread), replay workers %.3f, main thread %.2f, whole process %.2f\n",
             __atomic_load_n(&g_cpu_walk_ns, __ATOMIC_RELAXED) / 1e9, __atomic_load_n(&g_cpu_walk_dev_ns, __ATOMIC_RELAXED) / 1e9, __atomic_load_n(&g_wall_walk_throttled_ns, __ATOMIC_RELAXED) / 1e9,
             __atomic_load_n(&g_cpu_replay_ns, __ATOMIC_RELAXED) / 1e9, thread_cpu_ns() / 1e9, ts.tv_sec + ts.tv_nsec / 1e9);
 }
