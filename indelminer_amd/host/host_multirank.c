@@ -751,7 +751,9 @@ struct claim_s { int first, count; pgroup* G; int walked, aborted; };
 
 /* a group whose stage is done, on its way through a replay worker: what it prints waits in buf until every group
  * before it has been printed */
-typedef struct { pgroup* G; char* buf; size_t len; int done; int last_of_contig; } rjob_t;
+/* a replay job's output; in a multi-GPU run it is cut into the stretches of its contigs (each goes to that contig's part file) */
+typedef struct { int32_t tid; int first; size_t off; } rpart_t;
+typedef struct { pgroup* G; char* buf; size_t len; int done; int last_of_contig; rpart_t* part; int n_part, cap_part; } rjob_t;
 typedef struct { struct walkpool_s* pool; driver rd; pthread_t th; } replayer_t;
 
 typedef struct walkpool_s {

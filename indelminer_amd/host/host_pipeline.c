@@ -1119,6 +1119,8 @@ static void group_process_flush(driver* d, pgroup* G, const gcontig* cg, int f, 
 #undef USED_PUSH
 }
 
+static __thread void (*t_part_log)(void* arg, int32_t tid, int first, size_t off);
+static __thread void* t_part_arg;
 static void group_replay(driver* d, pgroup* G)
 {
     int32_t cursor = 0;
@@ -1126,7 +1128,10 @@ static void group_replay(driver* d, pgroup* G)
         const gcontig* cg = &G->ctg[ci];
         const int32_t tid = cg->tid;
         d->depth_tid = g_region_tid < 0 ? tid : -1;     /* -c: the depth of a variant is taken from the file (it reaches outside the stretch) */
-        if (g_mg) {                                     /* one VCF part per contig, concatenated by rank 0 in contig order */
+        if (g_mg && t_part_log) {                       /* a replay worker: the job's buffer, cut per contig (replay_thread) */
+            fflush(t_out);
+            t_part_log(t_part_arg, tid, cg->first, (size_t)ftell(t_out));
+        } else if (g_mg) {                              /* one VCF part per contig, concatenated by rank 0 in contig order */
             char path[512];
             mg_path(g_mg, path, sizeof path, "part", tid);
             fflush(stdout);

@@ -247,6 +247,26 @@ static void groups_free_chain(pgroup* G)
     while (G) { pgroup* n = G->next_of_contig; group_free(G); free(G); G = n; }
 }
 
+static void job_part_log(void* arg, int32_t tid, int first, size_t off)
+{
+    rjob_t* J = arg;
+    if (J->n_part == J->cap_part) { J->cap_part = J->cap_part ? J->cap_part * 2 : 4; J->part = xrealloc(J->part, sizeof(rpart_t) * (size_t)J->cap_part); }
+    J->part[J->n_part].tid = tid; J->part[J->n_part].first = first; J->part[J->n_part].off = off; J->n_part++;
+}
+/* a finished job's output, in file order: to the output stream, or (multi-GPU) stretch by stretch to its contigs' part files */
+static void job_emit(rjob_t* P)
+{
+    if (!g_mg) { if (P->len && fwrite(P->buf, 1, P->len, OUT) != P->len) fatalf("write to stdout failed"); return; }
+    for (int i = 0; i < P->n_part; i++) {
+        const size_t a = P->part[i].off, z = i + 1 < P->n_part ? P->part[i + 1].off : P->len;
+        char path[512];
+        mg_path(g_mg, path, sizeof path, "part", P->part[i].tid);
+        FILE* fp = fopen(path, P->part[i].first ? "w" : "a");
+        if (!fp || (z > a && fwrite(P->buf + a, 1, z - a, fp) != z - a) || fclose(fp) != 0) fatalf("cannot write %s", path);
+    }
+    free(P->part); P->part = NULL; P->n_part = P->cap_part = 0;
+}
+
 static void* replay_thread(void* arg)
 {
     replayer_t* R = arg;
@@ -264,7 +284,9 @@ static void* replay_thread(void* arg)
         }
         t_out = open_memstream(&J->buf, &J->len);
         if (!t_out) fatalf("cannot buffer the output of a group");
+        t_part_log = g_mg ? job_part_log : NULL; t_part_arg = J;
         group_replay(&R->rd, J->G);
+        t_part_log = NULL;
         fclose(t_out);
         t_out = NULL;
         pthread_mutex_lock(&o->mu);
@@ -522,7 +544,7 @@ static void run_pipeline(driver* d, walkpool_t* o)
      * again with the pre-pass (spec_fallback).  Small inputs, -o detailed: the table is made when the walk is over. */
     const char* re = getenv("INDELMINER_REPLAYERS");
     int nrep = re ? atoi(re) : 8;       /* idle while there is nothing to replay; at the end of the walk the cores are theirs (three left the last contigs a backlog of 1.3 s at WGS scale) */
-    if (o->serial || g_mg || strcmp(O.outputformat, "vcf") != 0 || nrep < 2) nrep = 0;
+    if (o->serial || strcmp(O.outputformat, "vcf") != 0 || nrep < 2) nrep = 0;
     if (nrep > 8) nrep = 8;
     spec_t spec;
     memset(&spec, 0, sizeof spec);
@@ -578,7 +600,7 @@ static void run_pipeline(driver* d, walkpool_t* o)
     /* Replay workers: the replay of a group (evidence objects, paired-read components, merge, print) is the longest serial
      * piece of a run once the walks overlap; groups are independent of each other, so several are replayed at once, each
      * into a buffer that is written out when every group before it has been.  The numbered blocks of -o detailed, annotate
-     * mode (one known-variant list) and the per-contig part files of a multi-GPU run keep the replay on this thread. */
+     * mode (one known-variant list) keep the replay on this thread; a multi-GPU run's jobs go to their contigs' part files (job_emit). */
     replayer_t* rp = nrep ? xcalloc((size_t)nrep, sizeof(replayer_t)) : NULL;
     o->jobs = xcalloc((size_t)(o->n_claims ? o->n_claims : 1), sizeof(rjob_t));
     for (int i = 0; i < nrep; i++) {
@@ -679,7 +701,7 @@ static void run_pipeline(driver* d, walkpool_t* o)
                 rjob_t* P = &o->jobs[o->printed++];
                 pthread_mutex_unlock(&o->mu);
                 if (P->len && speculate) spec_keep_output(&spec, P->buf, P->len);
-                else if (P->len && fwrite(P->buf, 1, P->len, OUT) != P->len) fatalf("write to stdout failed");
+                else job_emit(P);
                 free(P->buf);
                 pthread_mutex_lock(&o->mu);
             }
@@ -710,8 +732,20 @@ static void run_pipeline(driver* d, walkpool_t* o)
                 for (int cj = 0; cj < late[k].held[j]->n_ctg; cj++)
                     if (late[k].held[j]->ctg[cj].last) GPU2(d, im_depth_scan(d->gpu, late[k].held[j]->ctg[cj].tid, S.stream));
             GPU2(d, im_stream_sync(d->gpu, S.stream));
-            for (int j = 0; j < late[k].n_held; j++) group_replay(d, late[k].held[j]);
-            groups_free_chain(late[k].chain);
+            if (nrep) {
+                pthread_mutex_lock(&o->mu);
+                for (int j = 0; j < late[k].n_held; j++) {
+                    rjob_t* J = &o->jobs[o->n_jobs];
+                    J->G = late[k].held[j]; J->buf = NULL; J->len = 0; J->done = 0; J->last_of_contig = j == late[k].n_held - 1;
+                    o->n_jobs++;
+                }
+                dead[n_freeable].chain = late[k].chain; dead[n_freeable].last_job = o->n_jobs - 1; n_freeable++;
+                pthread_cond_broadcast(&o->cv);
+                pthread_mutex_unlock(&o->mu);
+            } else {
+                for (int j = 0; j < late[k].n_held; j++) group_replay(d, late[k].held[j]);
+                groups_free_chain(late[k].chain);
+            }
             free(late[k].held);
         }
         free(late);
@@ -726,7 +760,7 @@ static void run_pipeline(driver* d, walkpool_t* o)
             rjob_t* P = &o->jobs[o->printed++];
             pthread_mutex_unlock(&o->mu);
             if (P->len && speculate) spec_keep_output(&spec, P->buf, P->len);
-            else if (P->len && fwrite(P->buf, 1, P->len, OUT) != P->len) fatalf("write to stdout failed");
+            else job_emit(P);
             free(P->buf);
             pthread_mutex_lock(&o->mu);
         }
@@ -776,8 +810,20 @@ static void pipeline_handoff(void)
 {
     walkpool_t* o = g_handoff_pool;
     if (g_mg) {
-        /* this rank's parts in front of the claim it is working on are complete; the flag names the claim's first contig and
-         * rank 0, once every rank has reported, prints what lies in front of the smallest such contig and hands over */
+        /* this rank's parts in front of the claim it is working on are complete (the replay workers' jobs first); the flag names
+         * the claim's first contig and rank 0, once every rank has reported, prints what lies in front of the smallest such
+         * contig and hands over */
+        if (o && o->jobs) {
+            pthread_mutex_lock(&o->mu);
+            while (o->printed < o->n_jobs) {
+                while (!o->jobs[o->printed].done) pthread_cond_wait(&o->cv, &o->mu);
+                rjob_t* P = &o->jobs[o->printed++];
+                pthread_mutex_unlock(&o->mu);
+                job_emit(P);
+                pthread_mutex_lock(&o->mu);
+            }
+            pthread_mutex_unlock(&o->mu);
+        }
         g_mg->abort_tid = g_mg_cur_tid;
         mg_finish(g_mg, g_mg_driver);           /* rank 0 does not come back from this */
         fflush(stderr);

@@ -140,6 +140,10 @@ def main():
         "rep4": (["-i", "w.cfg"], {"INDELMINER_REPLAYERS": "4"}),
         "config_v3": (["-i", "w.cfg"], {}),
         "maps": (["-i", "w.cfg"], {"INDELMINER_TIMING_MAPS": "1"}),
+        # the multi-GPU path of the CLI with one rank: pre-walk, the real RCCL all-gather over one rank, the plan, the parts put together
+        "mg1": (["-i", "w.cfg"], {"INDELMINER_FORCE_MGPU": "1", "RANK": "0", "WORLD_SIZE": "1", "LOCAL_RANK": "0", "INDELMINER_RENDEZVOUS": "/tmp/wgs_rdv1"}),
+        "mg1_noconfig": ([], {"INDELMINER_FORCE_MGPU": "1", "RANK": "0", "WORLD_SIZE": "1", "LOCAL_RANK": "0", "INDELMINER_RENDEZVOUS": "/tmp/wgs_rdv2"}),
+        "mg1_split": (["-i", "w.cfg"], {"INDELMINER_FORCE_MGPU": "1", "RANK": "0", "WORLD_SIZE": "1", "LOCAL_RANK": "0", "INDELMINER_MG_FORCE_SPLIT": "1", "INDELMINER_RENDEZVOUS": "/tmp/wgs_rdv3"}),
         "shared": (["-i", "w.cfg"], {"INDELMINER_STREAMS": "shared", "INDELMINER_TIMING_MAPS": "1"}),
         "shared2": (["-i", "w.cfg"], {"INDELMINER_STREAMS": "shared", "INDELMINER_TIMING_MAPS": "1"}),
         "q4": (["-i", "w.cfg"], {"GPU_MAX_HW_QUEUES": "4", "INDELMINER_TIMING_MAPS": "1"}),
