@@ -51,6 +51,8 @@ struct bgzf_reader {
     int64_t  block_coff;        /* file offset of the block in ubuf */
     int64_t  next_coff;         /* file offset of the next block */
     int      eof;
+    const uint8_t* map; int64_t map_size;   /* the file, mapped (shared by the readers of one path): blocks are inflated where they lie */
+    int64_t  map_lo;            /* this reader has mapped pages in from here to next_coff since its last seek */
     /* read-ahead */
     int      nworkers, started, stop, run;
     pthread_t workers[16];
@@ -61,6 +63,26 @@ struct bgzf_reader {
     int64_t  fill_coff;         /* file offset of the next block to fetch */
     int      fill_eof;
 };
+
+/* One mapping per file for all its readers (a run opens the BAM once per walker): with it a block's payload goes from the page
+ * cache straight through the decoder -- no copy into the stdio buffer and from there into the reader's.  INDELMINER_BAM_MMAP=0
+ * keeps the reads. */
+static struct { pthread_mutex_t mu; char path[1024]; const uint8_t* map; int64_t size; } g_bam_map = { PTHREAD_MUTEX_INITIALIZER, "", NULL, 0 };
+static void bgzf_map_file(bgzf_reader* r, const char* path)
+{
+    const char* e = getenv("INDELMINER_BAM_MMAP");
+    if ((e && e[0] == '0') || strlen(path) >= sizeof g_bam_map.path) return;
+    pthread_mutex_lock(&g_bam_map.mu);
+    if (!g_bam_map.map || strcmp(g_bam_map.path, path) != 0) {
+        struct stat sb;
+        if (!g_bam_map.map && fstat(fileno(r->fp), &sb) == 0 && S_ISREG(sb.st_mode) && sb.st_size > 0) {
+            void* m = mmap(NULL, (size_t)sb.st_size, PROT_READ, MAP_SHARED, fileno(r->fp), 0);
+            if (m != MAP_FAILED) { g_bam_map.map = m; g_bam_map.size = sb.st_size; snprintf(g_bam_map.path, sizeof g_bam_map.path, "%s", path); }
+        }
+    }
+    if (g_bam_map.map && strcmp(g_bam_map.path, path) == 0) { r->map = g_bam_map.map; r->map_size = g_bam_map.size; }
+    pthread_mutex_unlock(&g_bam_map.mu);
+}
 
 bgzf_reader* bgzf_open(const char* path)
 {
@@ -73,6 +95,7 @@ bgzf_reader* bgzf_open(const char* path)
     r->nworkers = e ? atoi(e) : 4;
     if (r->nworkers < 0) r->nworkers = 0;
     if (r->nworkers > 16) r->nworkers = 16;
+    bgzf_map_file(r, path);
     return r;
 }
 
@@ -253,6 +276,29 @@ static int bgzf_load_block(bgzf_reader* r)
         if (!r->started) bgzf_pool_start(r);
         if (r->started) return bgzf_load_ahead(r);
     }
+    if (r->map && r->next_coff + 18 <= r->map_size) {
+        /* the usual block (one BC subfield), whole inside the mapping with the decoder's slack behind it: inflated where it lies */
+        const uint8_t* h = r->map + r->next_coff;
+        if (h[0] == 31 && h[1] == 139 && h[2] == 8 && (h[3] & 4) && h[10] == 6 && h[11] == 0 && h[12] == 'B' && h[13] == 'C') {
+            const int total = (h[16] | (h[17] << 8)) + 1;
+            if (total >= 18 + 8 && total <= BGZF_MAX_BLOCK + 64 && r->next_coff + total + IM_INFLATE_SLACK <= r->map_size) {
+                const int ulen = bgzf_inflate(h, total, 18, r->ubuf);
+                if (ulen < 0) return -1;
+                r->block_coff = r->next_coff;
+                r->next_coff += total;
+                r->ulen = ulen; r->upos = 0;
+                /* what lies behind is not read again: its page-table entries go now, 8 MB at a time (the pages stay in the
+                 * page cache), so that the mapping never counts for more than the readers' working sets */
+                if (r->map_lo > r->block_coff) r->map_lo = r->block_coff;
+                if (r->block_coff - r->map_lo >= ((int64_t)8 << 20)) {
+                    const int64_t a = (r->map_lo + 4095) & ~(int64_t)4095, z = r->block_coff & ~(int64_t)4095;
+                    if (z > a) (void)madvise((void*)(r->map + a), (size_t)(z - a), MADV_DONTNEED);
+                    r->map_lo = z;
+                }
+                return 1;
+            }
+        }
+    }
     int hdr = 0;
     const int total = bgzf_fetch(r->fp, r->next_coff, r->cbuf, &hdr);
     if (total == 0) { r->eof = 1; r->ulen = r->upos = 0; return 0; }
@@ -297,6 +343,11 @@ int bgzf_seek(bgzf_reader* r, int64_t voffset)
     bgzf_pool_reset(r);
     r->run = 0;
     r->eof = 0;
+    if (r->map && r->next_coff > r->map_lo) {          /* the rest of what this reader mapped in before the seek */
+        const int64_t a = (r->map_lo + 4095) & ~(int64_t)4095, z = (r->next_coff < r->map_size ? r->next_coff : r->map_size) & ~(int64_t)4095;
+        if (z > a) (void)madvise((void*)(r->map + a), (size_t)(z - a), MADV_DONTNEED);
+    }
+    r->map_lo = voffset >> 16;
     r->next_coff = voffset >> 16;
     r->ulen = r->upos = 0;
     const int within = (int)(voffset & 0xffff);

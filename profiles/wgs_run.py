@@ -144,6 +144,8 @@ def main():
         "mg1": (["-i", "w.cfg"], {"INDELMINER_FORCE_MGPU": "1", "RANK": "0", "WORLD_SIZE": "1", "LOCAL_RANK": "0", "INDELMINER_RENDEZVOUS": "/tmp/wgs_rdv1"}),
         "mg1_noconfig": ([], {"INDELMINER_FORCE_MGPU": "1", "RANK": "0", "WORLD_SIZE": "1", "LOCAL_RANK": "0", "INDELMINER_RENDEZVOUS": "/tmp/wgs_rdv2"}),
         "mg1_split": (["-i", "w.cfg"], {"INDELMINER_FORCE_MGPU": "1", "RANK": "0", "WORLD_SIZE": "1", "LOCAL_RANK": "0", "INDELMINER_MG_FORCE_SPLIT": "1", "INDELMINER_RENDEZVOUS": "/tmp/wgs_rdv3"}),
+        "read": (["-i", "w.cfg"], {"INDELMINER_BAM_MMAP": "0"}),
+        "read2": (["-i", "w.cfg"], {"INDELMINER_BAM_MMAP": "0"}),
         "shared": (["-i", "w.cfg"], {"INDELMINER_STREAMS": "shared", "INDELMINER_TIMING_MAPS": "1"}),
         "shared2": (["-i", "w.cfg"], {"INDELMINER_STREAMS": "shared", "INDELMINER_TIMING_MAPS": "1"}),
         "q4": (["-i", "w.cfg"], {"GPU_MAX_HW_QUEUES": "4", "INDELMINER_TIMING_MAPS": "1"}),
