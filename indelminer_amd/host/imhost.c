@@ -60,6 +60,12 @@ static void out_flush_on_exit(void);
 static void walker_bails_out(void);
 static void mg_rank_failed(void);
 static volatile int g_spec_active;      /* the walk is being staged on a provisional insert-length table (run_pipeline) */
+/* ONE thread ends the process -- with a message, or by handing the run to a child and waiting for it; a second thread that gets
+ * there (two walkers meeting the same unknown read group while the first one's fall-back child is already running) waits
+ * for ever, i.e. until the first one's exit.  Found by pipeline_soak.py 94036: a walker's message and exit(1) under a running child. */
+static pthread_mutex_t g_end_mu = PTHREAD_MUTEX_INITIALIZER;
+static __thread int t_holds_end;
+static void end_lock(void) { if (!t_holds_end) { pthread_mutex_lock(&g_end_mu); t_holds_end = 1; } }
 static void spec_fallback(const char* why);
 static void fatalf(const char* fmt, ...)
 {
@@ -68,6 +74,7 @@ static void fatalf(const char* fmt, ...)
     if (g_spec_active) spec_fallback(fmt);      /* nothing is out yet: the run without the speculation finds out what is wrong, if anything is */
     walker_bails_out();         /* a walker thread of the pipeline does not come back from this (see handoff_to_host_child) */
     mg_rank_failed();           /* multi-GPU: rank 0 stops waiting for this rank's output */
+    end_lock();
     va_start(ap, fmt);
     out_flush_on_exit();
     fflush(stdout);
@@ -143,6 +150,7 @@ static void spec_fallback(const char* why)
 static void spawn_self_and_exit(const char* mode)
 {
     const int host_mode = strncmp(mode, "INDELMINER_PIPELINE=", 20) == 0;
+    end_lock();
     if (t_out) fflush(t_out);
     fflush(stdout);
     /* the child's environment is a private copy: other threads (walkers, replay workers) may be inside getenv, and setenv
@@ -172,7 +180,7 @@ static void spawn_self_and_exit(const char* mode)
     _exit(WIFEXITED(status) ? WEXITSTATUS(status) : EXIT_FAILURE);
 }
 
-#define forceassert(e) do { if (!(e)) { walker_bails_out(); out_flush_on_exit(); fprintf(stderr, "Assertion failed: %s file %s line %d\n", #e, __FILE__, __LINE__); exit(EXIT_FAILURE); } } while (0)
+#define forceassert(e) do { if (!(e)) { walker_bails_out(); end_lock(); out_flush_on_exit(); fprintf(stderr, "Assertion failed: %s file %s line %d\n", #e, __FILE__, __LINE__); exit(EXIT_FAILURE); } } while (0)
 
 static double now_ms(void)
 {
