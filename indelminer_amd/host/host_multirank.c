@@ -248,14 +248,16 @@ static void prewalk_piece(const driver* d, bgzf_reader* r, int32_t t, int32_t be
         const int flag = b.flag;
         const int32_t this_rec = rec++;
         if (cov) cov_record(cov, &b);
-        if (estimate && (flag & 0x1) && !(flag & 0x4) && (flag & 0x2) && !(flag & (0x100 | 0x200 | 0x400)) &&
-            b.isize >= 0 && b.mpos - b.pos >= 0 && b.isize >= b.mpos - b.pos) {
+        if (estimate && (flag & 0x1) && !(flag & 0x4) && (flag & 0x2) && !(flag & (0x100 | 0x200 | 0x400)) && b.isize >= 0) {
+            /* the tag's type is asserted in front of the two mate-position tests (src/bamoperations.c:37-46) */
             const uint8_t* rg = bam_aux_find(&b, "RG");
             const char* rgname = "generic";
             if (rg) { forceassert(rg[0] == 'Z'); rgname = bam_aux_str(rg); }
-            mg_rg* g = &rgs[mg_rg_index(rgs, pn_rg, rgname)];
-            if (!g->seen) { g->seen = 1; g->min = g->max = b.isize; g->first_tid = t; g->first_rec = ((int64_t)(b.pos < 0 ? 0 : b.pos) << 32) | (uint32_t)this_rec; }
-            else { if (g->min > b.isize) g->min = b.isize; if (g->max < b.isize) g->max = b.isize; }
+            if (b.mpos - b.pos >= 0 && b.isize >= b.mpos - b.pos) {
+                mg_rg* g = &rgs[mg_rg_index(rgs, pn_rg, rgname)];
+                if (!g->seen) { g->seen = 1; g->min = g->max = b.isize; g->first_tid = t; g->first_rec = ((int64_t)(b.pos < 0 ? 0 : b.pos) << 32) | (uint32_t)this_rec; }
+                else { if (g->min > b.isize) g->min = b.isize; if (g->max < b.isize) g->max = b.isize; }
+            }
         }
         if (!out) continue;
         if (flag & (0x100 | 0x200 | 0x400 | 0x800)) continue;

@@ -445,10 +445,10 @@ static void host_discordant(driver* d, pgroup* G, const bam_record* b, int64_t r
 static void host_rg_stat(pgroup* G, const bam_record* b, const uint8_t* rg, int64_t rec_in_contig)
 {
     const int flag = b->flag;
-    if (!((flag & 0x1) && !(flag & 0x4) && (flag & 0x2) && !(flag & (0x100 | 0x200 | 0x400)) &&
-          b->isize >= 0 && b->mpos - b->pos >= 0 && b->isize >= b->mpos - b->pos)) return;
+    if (!((flag & 0x1) && !(flag & 0x4) && (flag & 0x2) && !(flag & (0x100 | 0x200 | 0x400)) && b->isize >= 0)) return;
     const char* rgname = "generic";
-    if (rg) { forceassert(rg[0] == 'Z'); rgname = bam_aux_str(rg); }
+    if (rg) { forceassert(rg[0] == 'Z'); rgname = bam_aux_str(rg); }       /* asserted in front of the two mate-position tests (src/bamoperations.c:37-46) */
+    if (!(b->mpos - b->pos >= 0 && b->isize >= b->mpos - b->pos)) return;
     int k = G->n_rgs - 1;                           /* the last group seen first: records of one library come in runs */
     while (k >= 0 && strcmp(G->rgs[k].name, rgname) != 0) k--;
     if (k < 0) {
