@@ -40,8 +40,10 @@ from indelminer_amd import capi, rawrec, synth  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0           # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 PIPELINE_DEPTH = int(os.environ.get("IM_BENCH_DEPTH", "4"))   # sets of realign output buffers in flight
-KERNEL_EVENT_STRIDE = 40        # one launch bracketed by HIP events on timed steps 20, 60, 100, ... (those steps are issued call by call, not
-                                # as a graph); a run of fewer than 21 steps brackets nothing inside the timed region
+MIN_TIMED_S = 0.12              # the --steps long region is repeated until at least this much time has been measured (and at least
+MIN_REGIONS, MAX_REGIONS = 5, 400   # MIN_REGIONS times): ms_per_step is the MEDIAN region's, the spread is reported beside it
+BRACKET_STEPS = 96              # after the timed regions: this many overlapped steps of which every fourth has ONE launch bracketed by HIP
+                                # events on its stream (realign / triage alternating); those steps are issued call by call, not as a graph
 FLUSH_WIDE = os.environ.get("IM_BENCH_FLUSH", "wide") == "wide"   # im_dev_flush_groupby (3 chip-wide launches) or the sequential flush list + 4 group-by launches
 
 
@@ -56,6 +58,19 @@ def measured_traffic():
             return int(json.load(fh)["hbm_bytes_per_launch"]), os.path.relpath(files[-1], ROOT)
     except Exception:
         return None, None
+
+
+def measured_issue():
+    """What binds the realign kernel is instruction issue, not HBM: per-read instruction counts, the share of the SIMDs' issue
+    cycles its VALU instructions take and the LDS bank-conflict share, from the SQ counter passes of the same committed set
+    (profiles/traffic_json.py writes them into the traffic file next to the HBM bytes)."""
+    import glob
+    files = sorted(f for f in glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_*_traffic.json")) if "shard3" not in f)
+    try:
+        with open(files[-1]) as fh:
+            return json.load(fh).get("issue")
+    except Exception:
+        return None
 
 
 def algorithmic_bytes(res):
@@ -417,6 +432,60 @@ def end_to_end(refs, rd):
         return out
 
 
+def end_to_end_config3():
+    """BASELINE configs[2] AT FULL SIZE (8 contigs x 6.25 Mb, 30x: 15 M reads, a 430 MB BAM) through the product CLI on this one GPU,
+    no config file; the VCF's md5 must be the one the compiled reference printed for this input (tests/golden/large_config3.json,
+    508 s of reference time in the build container).  A whole-program number at a size where start-up is not the run.  Beside it the
+    CPU side on this box's cores: tests/shim/indelminer_shim -- this host driver over the CPU oracle, record at a time, i.e. the
+    reference's path without its per-candidate strlen of the contig -- as one process and as eight -c processes at once (the
+    reference's only parallel mode, src/indelminer.c:536-542)."""
+    import hashlib
+    import importlib.util
+    import subprocess
+    import tempfile
+    from indelminer_amd import build
+    spec = importlib.util.spec_from_file_location("make_golden_large", os.path.join(ROOT, "tests", "golden", "make_golden_large.py"))
+    mg = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mg)
+    want = json.load(open(os.path.join(ROOT, "tests", "golden", "large_config3.json")))
+    prod = build.HOST_BIN
+    with tempfile.TemporaryDirectory() as td:
+        t = time.perf_counter()
+        n, flags = mg.materialise("config3", td)
+        out = {"workload": "BASELINE configs[2] at full size: 8 contigs x 6.25 Mb, 100 bp PE at 30x, every seventh planted event a 150-900 bp deletion; "
+                           "no config file (insert lengths estimated by the run)", "reads": int(n), "bam_bytes": os.path.getsize(td + "/aln.bam"),
+               "generation_s": time.perf_counter() - t, "reference_wall_s_build_container": want.get("reference_wall_s")}
+        cmd = flags + ["ref.fa", "s=aln.bam"]
+        walls = []
+        for _ in range(3):
+            t = time.perf_counter()
+            p = subprocess.run([prod] + cmd, cwd=td, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+            walls.append(time.perf_counter() - t)
+        d = mg.digest(p.stdout)
+        out.update(product_rc=p.returncode, product_wall_s_runs=walls, product_wall_s=float(np.median(walls)), product_reads_per_s=n / float(np.median(walls)),
+                   vcf_records=d["records"], product_md5=d["md5"], product_md5_is_the_references=bool(p.returncode == 0 and d["md5"] == want["md5"]))
+        try:
+            from tests.support.shimbuild import build_shim
+            shim = build_shim()
+            env = dict(os.environ, INDELMINER_PIPELINE="host")
+            t = time.perf_counter()
+            q = subprocess.run([shim] + cmd, cwd=td, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, env=env)
+            w1 = time.perf_counter() - t
+            out["cpu_1_process"] = {"kind": "port", "wall_s": w1, "reads_per_s": n / w1, "cores": 1, "md5_is_the_references": hashlib.md5(q.stdout).hexdigest() == want["md5"]}
+            t = time.perf_counter()
+            procs = [subprocess.Popen([shim, "-c", "ctg%d" % i] + cmd, cwd=td, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, env=env) for i in range(8)]
+            outs = [pr.communicate()[0] for pr in procs]
+            w8 = time.perf_counter() - t
+            body = lambda b: [l for l in b.splitlines() if not l.startswith(b"#")]
+            out["cpu_8_processes"] = {"kind": "port", "wall_s": w8, "reads_per_s": n / w8, "cores": 8,
+                                      "same_records_as_the_whole_run": sum((body(o) for o in outs), []) == body(q.stdout)}
+            out["product_over_cpu_1_process"] = w1 / out["product_wall_s"]
+            out["product_over_cpu_8_processes"] = w8 / out["product_wall_s"]
+        except Exception as ex:
+            out["cpu_error"] = str(ex)
+        return out
+
+
 def end_to_end_multi(rank, world, local_rank, dist, ref_len=2_000_000):
     """The PRODUCT on all the job's GPUs: every rank starts `indelminer` as a child with its own
     RANK / LOCAL_RANK / WORLD_SIZE on one BAM of two contigs cut into about 3 x world pieces -- contigs owned longest-first,
@@ -568,6 +637,7 @@ def main():
     ap.add_argument("--big-every", type=int, default=0, help="every k-th planted event a 150-900 bp deletion (config-3 style shards)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-shard3", action="store_true", help="skip the config-3 per-GPU shard measurement (N=1 only)")
+    ap.add_argument("--no-config3", action="store_true", help="skip the whole-program leg on BASELINE configs[2] at full size (N=1 only, about a minute)")
     args = ap.parse_args()
 
     # stdout carries ONE JSON line and nothing else: gloo ("[Gloo] Rank 0 is connected ...") and librccl (its
@@ -577,6 +647,7 @@ def main():
     real_stdout = os.dup(1)
     os.dup2(2, 1)
 
+    failed = False
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -619,41 +690,58 @@ def main():
         ps.step()
     barrier()
 
-    # HIP events around ONE launch of every KERNEL_EVENT_STRIDE-th timed step, on the stream that step runs on: the
-    # realign launch (call 4) on steps 0, 8, 16 ... and the triage launches (call 3) on steps 4, 12, ...
-    timers = []
-    for i in range(args.steps):
-        if i % KERNEL_EVENT_STRIDE == KERNEL_EVENT_STRIDE // 2:
-            p0 = ps.sets[0]["pipe"]
-            timers.append((capi.Timer(ctx), p0.realign_call_index if (i // KERNEL_EVENT_STRIDE) % 2 == 0 else p0.triage_call_index))
-        else:
-            timers.append((None, None))
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        ps.step(timers[i][0], timers[i][1])
-    ps.sync()
-    t1 = time.perf_counter()
+    # ---- the timed region: EXACTLY --steps steps between barrier + device sync on both sides, max over ranks.  A region of 20 steps
+    # is 1.3 ms, so the region is repeated (same bracket every time) until MIN_TIMED_S have been measured; the line carries the
+    # MEDIAN region and the spread.  Nothing but graph launches is issued inside a region.
+    def region():
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            ps.step()
+        ps.sync()
+        t1 = time.perf_counter()
+        if dist is not None:
+            dist.barrier()
+        e = t1 - t0
+        if dist is not None:
+            t = torch.tensor([e], dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            e = float(t[0])
+        return e
+
+    regions = [region()]
+    n_regions = int(min(MAX_REGIONS, max(MIN_REGIONS, np.ceil(MIN_TIMED_S / max(regions[0], 1e-6)))))
     if dist is not None:
-        dist.barrier()
-    elapsed = t1 - t0
-    if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64)
+        t = torch.tensor([n_regions], dtype=torch.int64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t[0])
+        n_regions = int(t[0])
+    for _ in range(n_regions - 1):
+        regions.append(region())
+    regions = np.array(regions)
+    elapsed = float(np.median(regions))
+    if dist is not None:
         tot = torch.tensor([n_reads, n_cand], dtype=torch.int64)
         dist.all_reduce(tot, op=dist.ReduceOp.SUM)
         total_reads, total_cand = int(tot[0]), int(tot[1])
     else:
         total_reads, total_cand = n_reads, n_cand
 
+    # ---- outside the timing: overlapped steps with ONE launch of every fourth step bracketed by HIP events on its stream
+    timers = []
+    p0 = ps.sets[0]["pipe"]
+    for i in range(BRACKET_STEPS):
+        timers.append((capi.Timer(ctx), p0.realign_call_index if (i // 4) % 2 == 0 else p0.triage_call_index) if i % 4 == 2 else (None, None))
+    for i in range(BRACKET_STEPS):
+        ps.step(timers[i][0], timers[i][1])
+    ps.sync()
+
     # every buffer set must hold exactly what the pass leaves when it runs alone: the timed passes overlap on PIPELINE_DEPTH streams
-    digests = [ps.digest(st_) for st_ in ps.sets[:min(len(ps.sets), args.steps + args.warmup)]]
+    digests = [ps.digest(st_) for st_ in ps.sets]
     overlap_ok = all(dg == digest0 for dg in digests)
     try:
-        depth_ok = bool(ps.depth_check(rd, len(refs[0]))) if args.steps + args.warmup >= len(ps.sets) else None
+        depth_ok = bool(ps.depth_check(rd, len(refs[0])))
     except Exception as ex:
         depth_ok = "not checked: %s" % ex
-    p0 = ps.sets[0]["pipe"]
     realign_ms = np.array([tm.elapsed_ms() for tm, at in timers if tm is not None and at == p0.realign_call_index])
     triage_ms = np.array([tm.elapsed_ms() for tm, at in timers if tm is not None and at == p0.triage_call_index])
     cnt, res, counts = ps.results()
@@ -715,7 +803,12 @@ def main():
         line = {
             "metric": "reads/sec through split-read realign+cluster; VCF diff-clean vs reference",
             "value": value, "unit": "reads/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "ms_per_step": ms_per_step, "ms_per_step_is": "the median of %d timed regions of --steps steps each" % len(regions),
+            "timed_regions": {"n": int(len(regions)), "timed_s_in_total": float(regions.sum()),
+                              "ms_per_step_min": float(regions.min() / args.steps * 1e3), "ms_per_step_max": float(regions.max() / args.steps * 1e3),
+                              "spread_iqr_over_median": float((np.percentile(regions, 75) - np.percentile(regions, 25)) / elapsed),
+                              "spread_range_over_median": float((regions.max() - regions.min()) / elapsed)},
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "u8/int32", "data": "synthetic",
             "config": {"workload": "BASELINE configs[1]: synthetic %.1f Mb contig per GPU, 100 bp PE reads at %gx, seeded "
                                    "1-50 bp indels every ~2 kb, BWA-like S/I/D emission; -k 6 -g 0 -s 1000 -n 10 -q 10"
@@ -746,6 +839,10 @@ def main():
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": measured_traffic()[0],
                          "longest_stage_of_the_step": "realign_kernel" if q_realign >= q_triage else "triage (classify + emit + decode, three launches)",
                          "traffic_source": "%s: PMC passes of an EARLIER run of this command (FETCH_SIZE x 2 + WRITE_SIZE per launch), not measured in this run" % measured_traffic()[1],
+                         "issue": measured_issue(),
+                         "issue_note": "what binds this kernel: its reference windows come out of L2 (traffic is a fraction of the algorithmic bytes), the time goes "
+                                       "into instruction issue and LDS round trips -- valu/salu/lds instructions per candidate read, VALU issue cycles over "
+                                       "the SIMDs' cycles, LDS bank-conflict cycles over LDS-active cycles, from the same committed counter passes as `traffic`",
                          "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": q_realign,
                          "avg_launch_ms_note": "HIP events around the realign launch on its stream with nothing else on the device (the kernel's own "
                                                "duration, what rocprofv3 --kernel-trace reports for it); inside the timed region's overlapped steps the same "
@@ -767,11 +864,43 @@ def main():
                 line["shard_config3"] = shard3_measure(0 if os.environ.get("IM_BENCH_ONE_DEVICE") == "1" else local_rank)
             except Exception as ex:
                 line["shard_config3"] = {"error": str(ex)}
+        if world == 1 and not args.no_cpu_baseline and not args.no_config3:
+            try:
+                line["end_to_end_config3"] = end_to_end_config3()
+            except Exception as ex:
+                line["end_to_end_config3"] = {"error": str(ex)}
+        # every self-check of the line in one place; the process exits non-zero when one of them is not true
+        checks = {"candidates_counted_on_the_device_equal_the_simulator": True,      # asserted above
+                  "overlapped_passes_equal_the_pass_alone": overlap_ok is True,
+                  "depth_range_sums_equal_the_pileup_rule": depth_ok is True}
+        if parity is not None:
+            checks["realign_identical_to_the_reference_on_the_sample"] = parity.startswith("identical")
+        if isinstance(e2e, dict):
+            checks["end_to_end_ran"] = "error" not in e2e and e2e.get("product_rc") == 0
+            if "vcf_identical_to_reference" in e2e:
+                checks["end_to_end_vcf_identical_to_reference"] = e2e["vcf_identical_to_reference"] is True
+        if isinstance(e2e_mg, dict):
+            checks["multi_gpu_all_ranks_ok"] = e2e_mg.get("all_ranks_ok") is True
+            checks["multi_gpu_vcf_identical_to_single_process"] = e2e_mg.get("vcf_identical_to_single_process") is True
+            for k_, v_ in (e2e_mg.get("strong") or {}).items():
+                if isinstance(v_, dict) and "vcf_identical_to_single_process" in v_:
+                    checks["multi_gpu_strong_%s_vcf_identical" % k_] = v_["vcf_identical_to_single_process"] is True
+        if isinstance(line.get("shard_config3"), dict):
+            checks["shard_config3_ran"] = "error" not in line["shard_config3"]
+        if isinstance(line.get("end_to_end_config3"), dict):
+            c3 = line["end_to_end_config3"]
+            checks["end_to_end_config3_md5_is_the_references"] = c3.get("product_md5_is_the_references") is True
+        line["self_checks"] = checks
+        line["self_checks_all_true"] = all(checks.values())
         sys.stdout.flush()
         os.write(real_stdout, (json.dumps(line) + "\n").encode())
+        failed = not line["self_checks_all_true"]
     if dist is not None:
         dist.destroy_process_group()
     ctx.close()
+    if rank == 0 and failed:
+        sys.stderr.write("bench.py: a self-check of the line is not true: %s\n" % [k for k, v in line["self_checks"].items() if not v])
+        sys.exit(1)
 
 
 if __name__ == "__main__":

@@ -35,7 +35,10 @@ static int parse(const uint8_t* p, uint32_t len, rec_t* r)
     if (r->l_seq < 0) return 0;
     uint64_t o = 32u + (uint64_t)r->l_qname;
     r->cigar = p + o; o += 4u * (uint64_t)r->n_cigar;
-    r->seq = p + o; o += ((uint64_t)r->l_seq + 1) / 2 + (uint64_t)r->l_seq;
+    /* the delivered-record form of include/indelminer_amd.h (im_dev_records): bin = 0xFFFF marks a record that travels
+     * WITHOUT its l_seq quality bytes -- the aux area follows the packed bases directly */
+    const int no_qual = p[10] == 0xFF && p[11] == 0xFF;
+    r->seq = p + o; o += ((uint64_t)r->l_seq + 1) / 2 + (no_qual ? 0u : (uint64_t)r->l_seq);
     if (o > len) return 0;
     r->aux = p + o; r->end = p + len;
     return 1;

@@ -32,5 +32,29 @@ doc = {"kernel": "realign_kernel<6, true>",
 if "FETCH_SIZE" in tri:
     doc["triage_classify_kernel"] = {"FETCH_SIZE_KB_per_launch": tri["FETCH_SIZE"], "WRITE_SIZE_KB_per_launch": tri.get("WRITE_SIZE"),
                                      "hbm_bytes_per_launch": int(tri["FETCH_SIZE"] * 1024 * 2 + tri.get("WRITE_SIZE", 0) * 1024)}
+# what binds the kernels: instruction issue (SQ counter passes of the same summary).  GRBM_GUI_ACTIVE counts per XCD (8 of them);
+# 1024 SIMDs; a wave-wide VALU instruction holds its SIMD's issue port for 4 cycles.
+def issue(v, units):
+    if "SQ_INSTS_VALU" not in v or not units:
+        return None
+    cyc = v.get("GRBM_GUI_ACTIVE", 0) / 8.0
+    d = {"valu_per_read": v["SQ_INSTS_VALU"] / units, "salu_per_read": v["SQ_INSTS_SALU"] / units, "lds_per_read": v["SQ_INSTS_LDS"] / units,
+         "valu_busy_frac": (v["SQ_ACTIVE_INST_VALU"] * 4.0 / (1024 * cyc)) if cyc else None,
+         "valu_active_over_wave_cycles": v["SQ_ACTIVE_INST_VALU"] * 4.0 / v["SQ_WAVE_CYCLES"],
+         "wait_frac_of_wave_cycles": v["SQ_WAIT_ANY"] / v["SQ_WAVE_CYCLES"],
+         "lds_conflict_frac": (v["SQ_LDS_BANK_CONFLICT"] / v["SQ_LDS_IDX_ACTIVE"]) if v.get("SQ_LDS_IDX_ACTIVE") else None,
+         "kernel_cycles": cyc, "units_per_launch": units}
+    return d
+cfg = b.get("config", b)
+n_cand = cfg.get("candidates_per_step")
+n_rec = cfg.get("reads_per_step")
+doc["issue"] = issue(vals, n_cand)
+if doc["issue"]:
+    doc["issue"]["unit"] = "candidate read"
+    doc["issue"]["source"] = "rocprofv3 --kernel-trace --pmc <SQ counters> (two passes) -- " + cmd
+ti = issue(tri, n_rec)
+if ti and "triage_classify_kernel" in doc:
+    ti["unit"] = "delivered record"
+    doc["triage_classify_kernel"]["issue"] = ti
 json.dump(doc, open(out, "w"), indent=2)
 print(open(out).read())

@@ -34,17 +34,8 @@ FLAG_MATRIX = {
 
 
 def _build_shim():
-    srcs = [os.path.join(ROOT, "indelminer_amd", "host", "imhost.c"), os.path.join(ROOT, "indelminer_amd", "host", "hostio.c"),
-            os.path.join(ROOT, "indelminer_amd", "host", "iminflate.c"),
-            os.path.join(ROOT, "tests", "shim", "im_shim.c"), os.path.join(ROOT, "oracle", "im_oracle.c"),
-            os.path.join(ROOT, "oracle", "im_oracle_triage.c")]
-    from indelminer_amd import build
-    parts = [os.path.join(ROOT, "indelminer_amd", "host", q) for q in build.HOST_PARTS]      # included by imhost.c
-    if os.path.exists(SHIM) and all(os.path.getmtime(s) <= os.path.getmtime(SHIM) for s in srcs + parts):
-        return SHIM
-    subprocess.check_call(["gcc", "-O2", "-std=c11", "-pthread", "-I" + os.path.join(ROOT, "include"),
-                           "-I" + os.path.join(ROOT, "indelminer_amd", "host"), "-o", SHIM] + srcs + ["-lz", "-lm"])
-    return SHIM
+    from tests.support.shimbuild import build_shim
+    return build_shim()
 
 
 def _product():

@@ -85,3 +85,24 @@ def test_flush_nohistory_refuses_decreasing_markers():
     marker = np.array([500, 300, 2**31 - 1], np.int32)
     z = np.zeros(1, np.int32)
     assert ob.flush_nohistory(marker, [1, 2, 3], [2, 2, 2], z, z, z, z) is None
+
+
+def test_oracle_reads_both_record_forms():
+    """the delivered-record contract (include/indelminer_amd.h, im_dev_records): a record with bin = 0xFFFF travels without its
+    base qualities.  The oracle's record rules and its pileup depth rule must give the same answers on both forms -- bench.py's
+    DP= self-check fed the quality-less form to an oracle that could not parse it and compared against an all-zero depth."""
+    from indelminer_amd import rawrec, synth
+    refs, rd = synth.simulate(seed=3, ref_len=30_000, coverage=12, big_every=5)
+    raw, off = rawrec.records(rd)
+    raw2, off2 = rawrec.records(rd, qual=False)
+    assert len(raw2) < len(raw) and len(off) == len(off2)
+    clen = len(refs[0])
+    d1 = ob.depth_of(raw, off, 0, clen)
+    d2 = ob.depth_of(raw2, off2, 0, clen)
+    assert d1.sum() > 0 and np.array_equal(d1, d2)
+    t1 = ob.triage_records(raw, off, ["generic"], [rd.range_max])
+    t2 = ob.triage_records(raw2, off2, ["generic"], [rd.range_max])
+    assert sum(1 for t, _ in t1 if t.cls in (2, 3)) > 0
+    for (a, ba), (b, bb) in zip(t1, t2):
+        assert (a.cls, a.tid, a.anchor, a.range_max, a.n_ev, a.l_seq) == (b.cls, b.tid, b.anchor, b.range_max, b.n_ev, b.l_seq)
+        assert ba == bb
