@@ -252,6 +252,7 @@ static int dev_realign(im_ctx* ctx, const im_params* params, const im_dev_batch*
     a.P = *params;
     a.keep_slots = keep;
     a.n_dev = n_dev;
+    a.first = 0;
     HIP_TRY(ctx, im::launch_realign(a, ctx->n_cu, (hipStream_t)stream));
     if (ctx->expect_len.load(std::memory_order_relaxed) > im::kShortRead && params->numgaps == 0)
         HIP_TRY(ctx, im::launch_realign_long(a, ctx->n_cu, (hipStream_t)stream));

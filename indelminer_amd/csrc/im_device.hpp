@@ -37,6 +37,7 @@ struct RealignArgs {
     im_params   P;
     int32_t     keep_slots;     // 1: evidence slots of reads without realigned evidence are left as they are
     const int32_t* n_dev;       // device-resident batch size (null: batch.n), batch.n is then the upper bound
+    int32_t     first;          // realign_kernel: the first read of this launch's slice (launch_realign cuts a batch beyond its largest grid)
 };
 
 // The read-group -> range[1] table of the insert-length hashtable, flattened into one blob:

@@ -80,6 +80,9 @@ struct WaveLds {
     alignas(16) uint32_t diag[kDiagWords];
     alignas(16) uint32_t tbl[kTblBytes / 4];
     uint32_t rd[(256 + 16) / 4];            // read bases, read coordinates
+#ifdef IM_LDS_PAD                           // diagnostic builds only (occupancy experiments)
+    uint32_t pad[IM_LDS_PAD / 4];
+#endif
 };
 
 // ---- K1: band search ---------------------------------------------------------
@@ -205,23 +208,42 @@ __device__ __forceinline__ uint32_t table_lookup(const WaveLds& s, uint32_t code
     return 0u;
 }
 
+// One vote of the direct path: count the diagonal, and hand back select_band's order for it as ONE key, largest wins --
+// this diagonal's count after the vote, then nearest the anchor, then smallest index.  The vote that lifts a diagonal to
+// its final count records that diagonal's key, so the largest key any lane saw names the chunk's band: no pass over the
+// histogram afterwards.  With the anchor clamped into the chunk (ac, band_search) nearness is 2047 - |ac - off|, and
+//   key = (count << 22) | (near << 11) | (2047 - off) = (count << 22) + Q0 - ((|ac - off| << 11) + off),   Q0 = 2047 * 2049:
+// one v_sad_u32, two shift-adds and a subtraction (Q0 also carries the + 1 of the count).
+__device__ __forceinline__ uint32_t vote_direct(WaveLds& s, uint32_t off, uint32_t ac, uint32_t Q0, uint32_t mx)
+{
+    const uint32_t bsel = (off & 3u) * 8u;
+    const uint32_t old = atomicAdd(&s.diag[off >> 2], 1u << bsel);
+    const uint32_t cnt = __builtin_amdgcn_ubfe(old, bsel, 8u);
+    uint32_t dist;                                                  // |off - ac|, one instruction
+    asm("v_sad_u32 %0, %1, %2, 0" : "=v"(dist) : "v"(off), "s"(ac));
+    const uint32_t t = (dist << 11) + off;
+    return max(mx, ((cnt << 22) + Q0) - t);
+}
+
 // One unit of the vote (k <= 6, direct table): the 512 window starts whose packed dwords are in cur[],
 // eight per lane.  Loads the next unit's dwords into nxt[] first (cur and nxt swap roles unit by
-// unit, so nothing is copied).  Returns the largest count any of this lane's votes produced.
+// unit, so nothing is copied).  `check`: the unit holds starts past the window's last k-mer, or the window
+// has several chunks -- every vote is then tested.  Returns the largest key any of this lane's votes produced.
 template <int KT>
 __device__ __forceinline__ uint32_t vote_unit_direct(WaveLds& s, const uint32_t (&cur)[8], uint32_t (&nxt)[8],
                                                      const uint8_t* __restrict__ src_next, bool more,
                                                      uint32_t bsh, uint32_t kmask, uint32_t i0, uint32_t span,
-                                                     uint32_t obase, uint32_t off_limit, int arel, int kd, uint32_t mx)
+                                                     uint32_t obase, bool check, uint32_t off_limit, uint32_t ac, uint32_t Q0, uint32_t mx)
 {
     // all eight table reads first, then the (rare) hits
     uint32_t v[8];
 #pragma unroll
     for (int j = 0; j < 8; j++) v[j] = (cur[j] >> bsh) & (KT == 6 ? 0xFFFu : kmask);
-    if (more) {
+#ifndef IM_VOTE_UNCOND_LOAD
+    if (more)
+#endif
 #pragma unroll
-        for (int j = 0; j < 8; j++) nxt[j] = load_u32_unaligned(src_next + 16 * j);
-    }
+    for (int j = 0; j < 8; j++) nxt[j] = load_u32_unaligned(src_next + 16 * j);
 #pragma unroll
     for (int j = 0; j < 8; j++) v[j] = lds_byte(s.tbl, v[j]);
     // pack the table bytes four to a word (v_perm), flag the non-zero bytes (bit 7 of each), merge the
@@ -231,25 +253,32 @@ __device__ __forceinline__ uint32_t vote_unit_direct(WaveLds& s, const uint32_t 
     const uint32_t ma = (((xa & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | xa) & 0x80808080u;
     const uint32_t mb = (((xb & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | xb) & 0x80808080u;
     uint32_t m = (ma >> 7) | (mb >> 6);
-    while (m) {
-        const uint32_t bit = (uint32_t)__builtin_ctz(m);
-        m &= m - 1u;
-        const uint32_t h = bit & 1u, sh = bit & 24u;
-        const uint32_t x = h ? xb : xa;
-        const uint32_t i = i0 + (h << 8) + (sh << 3);                    // + 64 * (4h + sh / 8)
-        const uint32_t off = obase + i - ((x >> sh) & 255u);             // diagonal index - c0
-        // one predicate, one exec-mask change: a start past the window's last k-mer, or (several chunks
-        // only, off_limit is all ones otherwise) a diagonal that belongs to another chunk, does not vote
-        if (i <= span && off < off_limit) {
-            const uint32_t bsel = (off & 3u) * 8u;
-            const uint32_t old = atomicAdd(&s.diag[off >> 2], 1u << bsel);
-            // select_band's order as ONE key, largest wins: this diagonal's count after the vote, then nearest the anchor,
-            // then smallest index (kd - |anchor - off| and 2047 - off both fit 11 bits inside a chunk).  The vote that
-            // lifts a diagonal to its final count records that diagonal's key, so the largest key any lane saw names the
-            // chunk's band -- no pass over the histogram afterwards.
-            const uint32_t cnt = ((old >> bsel) & 255u) + 1u;
-            const uint32_t near = (uint32_t)(kd - abs(arel - (int)off));
-            mx = max(mx, (cnt << 22) | (near << 11) | (2047u - off));
+    // start index of mask bit b = 8 jj + h: 64 (4 h + jj) = 8 b + 248 h
+    const uint32_t ob = obase + i0;
+#ifdef IM_ALWAYS_CHECK
+    if (false) {
+#else
+    if (!check) {
+#endif
+        while (m) {
+            const uint32_t bit = (uint32_t)__builtin_ctz(m);
+            m &= m - 1u;
+            const bool hb = (bit & 1u) != 0u;
+            const uint32_t x = hb ? xb : xa;
+            const uint32_t off = ob + 8u * bit + (hb ? 248u : 0u) - __builtin_amdgcn_ubfe(x, bit & 24u, 8u);   // diagonal index - c0
+            mx = vote_direct(s, off, ac, Q0, mx);
+        }
+    } else {
+        while (m) {
+            const uint32_t bit = (uint32_t)__builtin_ctz(m);
+            m &= m - 1u;
+            const bool hb = (bit & 1u) != 0u;
+            const uint32_t x = hb ? xb : xa;
+            const uint32_t di = 8u * bit + (hb ? 248u : 0u);
+            const uint32_t off = ob + di - __builtin_amdgcn_ubfe(x, bit & 24u, 8u);
+            // one predicate, one exec-mask change: a start past the window's last k-mer, or (several chunks
+            // only, off_limit is all ones otherwise) a diagonal that belongs to another chunk, does not vote
+            if (i0 + di <= span && off < off_limit) mx = vote_direct(s, off, ac, Q0, mx);
         }
     }
     return mx;
@@ -300,7 +329,9 @@ __device__ __forceinline__ Band band_search(WaveLds& s, const uint8_t* __restric
         const uint8_t* src = pk + (P0 >> 2);
         const uint32_t bsh = 2u * (P0 & 3u);                       // the same for all of a lane's starts: 64 starts = 16 bytes
         uint32_t wd[8], we[8];
-        if (DIRECT && any) {
+#pragma unroll
+        for (int j = 0; j < 8; j++) asm volatile("" : "=v"(we[j]));  // no value needed before the first load (saves the compiler's zero fill)
+        if (DIRECT) {                                              // unconditional: P0 is a valid place whatever `any` says
 #pragma unroll
             for (int j = 0; j < 8; j++) wd[j] = load_u32_unaligned(src + 16 * j);
         }
@@ -328,12 +359,18 @@ __device__ __forceinline__ Band band_search(WaveLds& s, const uint8_t* __restric
         const int dmin = arel < 0 ? -arel : (arel >= nbc ? arel - (nbc - 1) : 0);
         const int kd = 2047 + dmin;
         if (DIRECT) {
+            // the anchor clamped into the chunk: every diagonal's nearness 2047 + dmin - |arel - off| is what it was (outside the
+            // chunk the distance is monotone in the index, and dmin moves with the anchor), and the key needs no sign
+            const uint32_t ac = (uint32_t)min(max(arel, 0), nbc - 1);
+            const uint32_t Q0 = 2047u * 2049u + (1u << 22);
+            // units whose every start lies inside the window vote unchecked (one chunk only)
+            const uint32_t nfull = off_limit == 0xFFFFFFFFu ? (span + 1u) / 512u : 0u;
             for (uint32_t u = 0; u < nunit; u += 2) {
                 mx = vote_unit_direct<KT>(s, wd, we, src + 128u * (u + 1u), u + 1 < nunit, bsh, kmask,
-                                          512u * u + (uint32_t)lane, span, obase, off_limit, arel, kd, mx);
+                                          512u * u + (uint32_t)lane, span, obase, u >= nfull, off_limit, ac, Q0, mx);
                 if (u + 1 < nunit)
                     mx = vote_unit_direct<KT>(s, we, wd, src + 128u * (u + 2u), u + 2 < nunit, bsh, kmask,
-                                              512u * (u + 1u) + (uint32_t)lane, span, obase, off_limit, arel, kd, mx);
+                                              512u * (u + 1u) + (uint32_t)lane, span, obase, u + 1 >= nfull, off_limit, ac, Q0, mx);
             }
         } else {
             for (uint32_t u = 0; u < nunit; u++) {
@@ -470,12 +507,15 @@ __device__ __forceinline__ Aln diag_scan(WaveLds& s, const uint8_t* __restrict__
     int c[4];
 #pragma unroll
     for (int j = 0; j < 4; j++) c[j] = S[j] - min(pm, m[j]);
-    const int best = wave_max(max(max(c[0], c[1]), max(c[2], c[3])));
-    if (best <= 0) return a;                                       // score <= 0 (src/alignment.c:365-372)
-    int e_loc = INT_MAX;
+    // the best score and the FIRST cell that holds it in one reduction: scores are 0..255 (c_t >= 0, at most one per base
+    // of a read of up to 255), cells 0..255 -- (score << 8) | (255 - t), largest wins
+    int bk = (c[0] << 8) | (255 - t0);
 #pragma unroll
-    for (int j = 3; j >= 0; j--) if (c[j] == best) e_loc = t0 + j;
-    const int end = wave_min(e_loc);
+    for (int j = 1; j < 4; j++) bk = max(bk, (c[j] << 8) | (255 - t0 - j));
+    bk = wave_max(bk);
+    const int best = bk >> 8;
+    if (best <= 0) return a;                                       // score <= 0 (src/alignment.c:365-372)
+    const int end = 255 - (bk & 255);
     const int el = end >> 2, ej = end & 3;
     int s_sel = (ej == 0) ? S[0] : (ej == 1) ? S[1] : (ej == 2) ? S[2] : S[3];
     const int Send = __builtin_amdgcn_readlane(s_sel, el);
@@ -577,7 +617,7 @@ __device__ __forceinline__ void realign_one(WaveLds& s, const RealignArgs& A, in
         if (rem < 4) v &= (rem <= 0) ? 0u : ((1u << (8 * rem)) - 1u);
         s.rd[lane] = v;
         if (lane < 4) s.rd[64 + lane] = 0u;
-        read_pk8 = code2(v & 255u) | (code2((v >> 8) & 255u) << 2) | (code2((v >> 16) & 255u) << 4) | (code2(v >> 24) << 6);
+        read_pk8 = code2x4(v);
     }
     wave_lds_sync();
 
@@ -664,8 +704,10 @@ __device__ __forceinline__ void realign_one(WaveLds& s, const RealignArgs& A, in
         fb[j] = (x >= qb1 && x < L) ? (int)((wb >> j) & 1u) : 0;
     }
     const int ta = fa[0] + fa[1] + fa[2] + fa[3], tb = fb[0] + fb[1] + fb[2] + fb[3];
-    const int ia = wave_scan_add(ta, lane), ib = wave_scan_add(tb, lane);
-    const int totA = __builtin_amdgcn_readlane(ia, 63), totB = __builtin_amdgcn_readlane(ib, 63);
+    const int iab = wave_scan_add(ta | (tb << 16), lane);          // both counts in one scan: each stays below 2^15
+    const int tot = __builtin_amdgcn_readlane(iab, 63);
+    const int ia = iab & 0xFFFF, ib = iab >> 16;
+    const int totA = tot & 0xFFFF, totB = tot >> 16;
     int pa[4], pb[4];                   // exclusive prefix counts at x
     pa[0] = ia - ta; pb[0] = ib - tb;
 #pragma unroll
@@ -675,20 +717,18 @@ __device__ __forceinline__ void realign_one(WaveLds& s, const RealignArgs& A, in
     if (split) {
         // count_matches(i) = '=' of A in read[0,i) + '=' of B in read[i,L); X counts are
         // L - that, so "max matches, then min mismatches, first wins" is the first maximum.
-        int bs = -1, bx = INT_MAX;
+        // one reduction for both: (matches << 8) | (255 - x), largest wins -- matches and x stay below 256
+        int bk = -1;
 #pragma unroll
         for (int j = 0; j < 4; j++) {
             const int x = x0 + j;
-            if (x >= qb1 && x <= qa2) {
-                const int sc = pa[j] + (totB - pb[j]);
-                if (sc > bs) { bs = sc; bx = x; }
-            }
+            if (x >= qb1 && x <= qa2) bk = max(bk, ((pa[j] + (totB - pb[j])) << 8) | (255 - x));
         }
-        const int best = wave_max(bs);
-        index = wave_min(bs == best ? bx : INT_MAX);
-        if (best < 0 || index == INT_MAX) { finish(out, IM_ST_ABORT, 2, lane); return; }   // forceassert(index != -1)
+        bk = wave_max(bk);
+        if (bk < 0) { finish(out, IM_ST_ABORT, 2, lane); return; }                         // forceassert(index != -1)
+        index = 255 - (bk & 255);
         nextindex = index;
-        matches = best;
+        matches = bk >> 8;
     } else {
         index = qa2; nextindex = qb1;
         matches = totA + totB;
@@ -746,7 +786,7 @@ __device__ __forceinline__ void realign_one(WaveLds& s, const RealignArgs& A, in
             slot++;
         }
     }
-    seg_indel = wave_max(seg_indel);     // only one lane set it (others 0); slot >= 1 there
+    seg_indel = __builtin_amdgcn_readlane(seg_indel, index >> 2);     // the lane that owns read position `index` set it
     if (lane == 0) {
         if (hasD) out->ops[seg_indel] = ((uint32_t)(rindex - refindx) << 4) | IM_OP_D;
         im_evidence* e = &out->ev[0];
@@ -778,26 +818,25 @@ __global__ __launch_bounds__(64, IM_WAVES_PER_SIMD) void realign_kernel(RealignA
 {
     __shared__ WaveLds s;
     const int lane = threadIdx.x;
-    // the batch size may live on the device (the triage kernel's running count): the launch is sized for an upper
-    // bound and the workgroups beyond the count leave at once
+    // ONE read per wave and no loop around it: nothing of the launch's arguments has to stay in registers for a next
+    // read (launch_realign cuts a batch beyond the largest grid into slices).  The batch size may live on the device
+    // (the triage kernel's running count): the launch is sized for an upper bound and the workgroups beyond the count
+    // leave at once.
     const int n = A.n_dev ? min(sload(A.n_dev), A.batch.n) : A.batch.n;
-    const int G = min((int)gridDim.x, (n + 7) / 8 * 8);     // multiple of 8
+    const int left = n - A.first;                           // reads of this slice and behind it
+    const int G = min((int)gridDim.x, (left + 7) / 8 * 8);  // multiple of 8
     if ((int)blockIdx.x >= G) return;
-    const int per = G >> 3;
     // blocks with equal blockIdx % 8 share an XCD (observed round-robin placement,
-    // speed only): give each XCD a contiguous run of `per` reads per sweep.
-    const int mine = (blockIdx.x & 7) * per + (blockIdx.x >> 3);
+    // speed only): give each XCD a contiguous run of reads.
+    const int c = A.first + (blockIdx.x & 7) * (G >> 3) + (blockIdx.x >> 3);
+    if (c >= n) return;
     if constexpr (KT == 6 || KT == -1) {        // table_build / table_undo keep the table clean from here on
         uint4* t4 = reinterpret_cast<uint4*>(s.tbl);
 #pragma unroll
         for (int i = 0; i < kTblBytes / 16 / 64; i++) t4[lane + 64 * i] = make_uint4(0u, 0u, 0u, 0u);
         wave_lds_sync();
     }
-    for (int base = 0; base < n; base += G) {
-        const int c = base + mine;
-        if (c < n) realign_one<KT, DIRECT>(s, A, c, lane);
-        wave_lds_sync();
-    }
+    realign_one<KT, DIRECT>(s, A, c, lane);
 }
 
 // ---- numgaps > 0: banded affine-gap path ------------------------------------------
@@ -1539,9 +1578,10 @@ __global__ __launch_bounds__(64, 4) void realign_band_kernel(RealignArgs A)
     // The band alignment's state lives where the vote's histogram and k-mer table are (both dead between two band
     // searches; band_search<0, ..> rebuilds them from scratch): 6.4 KB of LDS per wave instead of 12, twice the waves per CU.
     __shared__ WaveLds s;
-    static_assert(sizeof(BandLds) <= sizeof(s.diag) + sizeof(s.tbl), "BandLds must fit over the vote's histogram + table");
     static_assert(offsetof(WaveLds, tbl) == sizeof(s.diag), "diag and tbl are contiguous");
-    BandLds& G = *reinterpret_cast<BandLds*>(s.diag);
+    constexpr bool kOverlay = sizeof(BandLds) <= sizeof(s.diag) + sizeof(s.tbl);     // a smaller histogram (IM_DIAG_CHUNK) leaves no room: own block then
+    __shared__ uint32_t band_own[kOverlay ? 1 : (sizeof(BandLds) + 3) / 4];
+    BandLds& G = *reinterpret_cast<BandLds*>(kOverlay ? s.diag : band_own);
     __shared__ uint32_t c1_keep[IM_MAX_OPS + 4];            // the first piece's CIGAR outlives the second band search
     const int lane = threadIdx.x;
     const uint32_t k = A.P.klength, g = A.P.numgaps, eth = A.P.ethreshold;
@@ -1752,8 +1792,6 @@ hipError_t launch_realign(const RealignArgs& a, int n_cu, hipStream_t stream)
     // 6352 B of LDS per one-wave workgroup (6400 allocated) -> 25 fit a CU; <= 80 VGPRs -> 6 waves per SIMD.
     int64_t want = (int64_t)n_cu * IM_BLOCKS_PER_CU;
     int64_t need = ((int64_t)a.batch.n + 7) / 8 * 8;
-    int grid = (int)(need < want ? need : want);
-    grid = (grid + 7) / 8 * 8;
     if (a.P.numgaps > 0) {
         // one wave per read; the band kernel holds more LDS per wave than the single-diagonal one
         // up to 128 one-wave workgroups per CU: reads differ widely in cost (one or two band alignments, with or without the
@@ -1763,12 +1801,23 @@ hipError_t launch_realign(const RealignArgs& a, int n_cu, hipStream_t stream)
             hipLaunchKernelGGL((realign_band_kernel<true>), dim3(gg), dim3(64), 0, stream, a);
         else
             hipLaunchKernelGGL((realign_band_kernel<false>), dim3(gg), dim3(64), 0, stream, a);
-    } else if (a.P.klength == 6 && a.P.numgaps == 0)
-        hipLaunchKernelGGL((realign_kernel<6, true>), dim3(grid), dim3(64), 0, stream, a);     // reference defaults
-    else if (a.P.klength <= (uint32_t)kDirectMaxK)
-        hipLaunchKernelGGL((realign_kernel<-1, true>), dim3(grid), dim3(64), 0, stream, a);     // any other k <= 6: the same clean-table protocol, mask at run time
-    else
-        hipLaunchKernelGGL((realign_kernel<0, false>), dim3(grid), dim3(64), 0, stream, a);
+    }
+    else {
+        // one read per wave: a batch beyond the largest grid goes out in slices
+        const int64_t cap = want / 8 * 8;
+        for (int64_t first = 0; first < (int64_t)a.batch.n; first += cap) {
+            RealignArgs b = a;
+            b.first = (int32_t)first;
+            const int64_t rest = ((int64_t)a.batch.n - first + 7) / 8 * 8;
+            const int g = (int)(rest < cap ? rest : cap);
+            if (a.P.klength == 6)
+                hipLaunchKernelGGL((realign_kernel<6, true>), dim3(g), dim3(64), 0, stream, b);     // reference defaults
+            else if (a.P.klength <= (uint32_t)kDirectMaxK)
+                hipLaunchKernelGGL((realign_kernel<-1, true>), dim3(g), dim3(64), 0, stream, b);    // any other k <= 6: the same clean-table protocol, mask at run time
+            else
+                hipLaunchKernelGGL((realign_kernel<0, false>), dim3(g), dim3(64), 0, stream, b);
+        }
+    }
     return hipGetLastError();
 }
 

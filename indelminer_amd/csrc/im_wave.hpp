@@ -106,6 +106,20 @@ __device__ __forceinline__ uint32_t code2(uint32_t c)
     return valid ? x : 0u;
 }
 
+// base2bits of four ASCII bytes at once: byte j's code in bits 2j, 2j+1 of the result.  Per byte the code is
+// (c >> 1) & 3 with its two upper values swapped; a byte counts only when its lower-case form IS the letter
+// that code stands for (one v_perm looks the four letters up), anything else codes 0 like the reference's default.
+__device__ __forceinline__ uint32_t code2x4(uint32_t v)
+{
+    uint32_t x = (v >> 1) & 0x03030303u;
+    x ^= (x >> 1) & 0x01010101u;
+    const uint32_t want = __builtin_amdgcn_perm(0u, 0x74676361u, x);           // 'a' 'c' 'g' 't' by code
+    const uint32_t d = (v | 0x20202020u) ^ want;                                // zero byte: a valid letter
+    const uint32_t nz = (((d & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | d) & 0x80808080u;  // 0x80 in every non-zero byte
+    x &= ~((nz >> 7) * 3u);
+    return (x | (x >> 6) | (x >> 12) | (x >> 18)) & 0xFFu;
+}
+
 typedef unsigned short im_u16x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ uint32_t pk_max_u16(uint32_t a, uint32_t b)     // v_pk_max_u16
 {
@@ -139,11 +153,11 @@ __device__ __forceinline__ void finish(im_read_result* out, int status, int n_ba
 __device__ __forceinline__ void write_slots(const RealignArgs& A, int c, int n_ev, int cls0, int b1, int b2, int lane)
 {
     if (A.batch.ev_cls && lane < IM_MAX_EV) {
-        const int64_t sl = (int64_t)c * IM_MAX_EV + lane;
+        const int64_t base = (int64_t)c * IM_MAX_EV;            // wave-uniform: the stores take it as their scalar base
         const bool live = lane < n_ev;
-        A.batch.ev_cls[sl] = live ? cls0 : -1;
-        A.batch.ev_b1[sl] = live ? b1 : 0;
-        A.batch.ev_b2[sl] = live ? b2 : 0;
+        (A.batch.ev_cls + base)[lane] = live ? cls0 : -1;
+        (A.batch.ev_b1 + base)[lane] = live ? b1 : 0;
+        (A.batch.ev_b2 + base)[lane] = live ? b2 : 0;
     }
 }
 
