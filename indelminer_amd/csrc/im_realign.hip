@@ -46,8 +46,7 @@ __device__ unsigned long long im_stamp_acc[32];
 #define IM_STAMP(id) do { if ((id) == IM_STOP_AFTER) { finish(out, IM_ST_NONE, 0, lane); return; } } while (0)
 #define IM_STAMP_ARG , int stamp_base_
 #define IM_STAMP_PASS(base) , base
-#define IM_STAMP_B(id) do { if (stamp_base_ + (id) == IM_STOP_AFTER) { if constexpr (KT == 6 || KT == -1) table_undo(s, p0, nq, lane, read_pk8, kmask); \
-                            b.st = IM_ST_ABORT; return b; } } while (0)   /* the k = 6 table must be left clean */
+#define IM_STAMP_B(id) do { if (stamp_base_ + (id) == IM_STOP_AFTER) { b.st = IM_ST_ABORT; return b; } } while (0)
 #else
 #define IM_STAMP_DECL
 #define IM_STAMP(id)
@@ -101,11 +100,17 @@ template <int KT, bool DIRECT>
 __device__ __forceinline__ void table_build(WaveLds& s, uint32_t p0, uint32_t nq, uint32_t k, int lane, uint32_t read_pk8)
 {
     if constexpr (KT == 6 || KT == -1) {
-        // direct table kept clean (k = 6, the reference default, with its mask a constant; KT = -1: any k <= 6): the read's
-        // 2-bit codes travel as one packed byte per lane
+        // direct table (k = 6, the reference default, with its mask a constant; KT = -1: any k <= 6): cleared with four
+        // 16-byte stores per lane -- cheaper in vector instructions than un-doing the entries after the vote, and vector
+        // issue is what binds the kernel.  The read's 2-bit codes travel as one packed byte per lane
         // (bases 4l..4l+3); the two following lanes' bytes come over DPP, and the lane's four
-        // 6-mers are bit fields of that 24-bit window.  The table is kept clean by un-doing the
-        // entries after the vote (table_undo), so no 4 KiB clear per band search.
+        // 6-mers are bit fields of that 24-bit window.
+        {
+            uint4* t4 = reinterpret_cast<uint4*>(s.tbl);
+#pragma unroll
+            for (int i = 0; i < kTblBytes / 16 / 64; i++) t4[lane + 64 * i] = make_uint4(0u, 0u, 0u, 0u);
+            wave_lds_sync();
+        }
         uint8_t* t8 = reinterpret_cast<uint8_t*>(s.tbl);
         const uint32_t n1 = (uint32_t)dpp_mov<kDppWaveShl1>(0, (int)read_pk8);
         const uint32_t n2 = (uint32_t)dpp_mov<kDppWaveShl1>(0, (int)n1);
@@ -180,20 +185,6 @@ __device__ __forceinline__ void table_build(WaveLds& s, uint32_t p0, uint32_t nq
     wave_lds_sync();
 }
 
-// un-does the clean-table build: every lane zeroes the entries of its own k-mers
-__device__ __forceinline__ void table_undo(WaveLds& s, uint32_t p0, uint32_t nq, int lane, uint32_t read_pk8, uint32_t mask)
-{
-    uint8_t* t8 = reinterpret_cast<uint8_t*>(s.tbl);
-    const uint32_t n1 = (uint32_t)dpp_mov<kDppWaveShl1>(0, (int)read_pk8);
-    const uint32_t n2 = (uint32_t)dpp_mov<kDppWaveShl1>(0, (int)n1);
-    const uint32_t w24 = read_pk8 | (n1 << 8) | (n2 << 16);
-#pragma unroll
-    for (int j = 0; j < 4; j++) {
-        const uint32_t x = 4u * lane + j;
-        if (x >= p0 && x < p0 + nq) t8[(w24 >> (2 * j)) & mask] = 0;
-    }
-}
-
 template <bool DIRECT>
 __device__ __forceinline__ uint32_t table_lookup(const WaveLds& s, uint32_t code)
 {
@@ -237,8 +228,13 @@ __device__ __forceinline__ uint32_t vote_unit_direct(WaveLds& s, const uint32_t 
 {
     // all eight table reads first, then the (rare) hits
     uint32_t v[8];
+    __builtin_amdgcn_s_waitcnt(0x0F70);         // vmcnt(0): the current dwords, loaded a unit ago -- one wait instead of eight counted ones
 #pragma unroll
     for (int j = 0; j < 8; j++) v[j] = (cur[j] >> bsh) & (KT == 6 ? 0xFFFu : kmask);
+    // The next unit's loads go out BEHIND the uses of the current dwords (the empty asm pins that): the
+    // counted waits in front of those uses are merged over both values of `more`, and with the new loads already issued
+    // the merged count makes every use wait for them too -- a memory round trip per unit instead of an overlap.
+    asm volatile("" : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5]), "+v"(v[6]), "+v"(v[7]) :: "memory");
 #ifndef IM_VOTE_UNCOND_LOAD
     if (more)
 #endif
@@ -433,7 +429,6 @@ __device__ __forceinline__ Band band_search(WaveLds& s, const uint8_t* __restric
         wave_lds_sync();
         IM_STAMP_B(3);
     }
-    if constexpr (KT == 6 || KT == -1) table_undo(s, p0, nq, lane, read_pk8, KT == 6 ? 0xFFFu : kmask);
     // select_band's order: most votes, then nearest the anchor, then smallest index
     if (g == 0) {
         if (bc == 0) {
@@ -608,17 +603,16 @@ __device__ __forceinline__ void realign_one(WaveLds& s, const RealignArgs& A, in
     const uint8_t* pk = A.ref.pk + sload(A.ref.pk_off + tid);
     const int clen = sload(A.ref.len + tid);
 
-    // stage the read
-    uint32_t read_pk8 = 0;      // 2-bit codes of this lane's four bases, first base in the low bits
+    // stage the read; lane l also keeps the 2-bit codes of its four bases (read_pk8, for the k-mer table)
+    uint32_t rdw = 0;
+    if (4 * lane < L) rdw = *reinterpret_cast<const uint32_t*>(A.batch.bases + off + 4 * lane);
     {
-        uint32_t v = 0;
-        if (4 * lane < L) v = *reinterpret_cast<const uint32_t*>(A.batch.bases + off + 4 * lane);
         const int rem = L - 4 * lane;                              // zero the bytes past the read
-        if (rem < 4) v &= (rem <= 0) ? 0u : ((1u << (8 * rem)) - 1u);
-        s.rd[lane] = v;
-        if (lane < 4) s.rd[64 + lane] = 0u;
-        read_pk8 = code2x4(v);
+        if (rem < 4) rdw &= (rem <= 0) ? 0u : ((1u << (8 * rem)) - 1u);
     }
+    const uint32_t read_pk8 = code2x4(rdw);      // 2-bit codes of this lane's four bases, first base in the low bits
+    s.rd[lane] = rdw;
+    if (lane < 4) s.rd[64 + lane] = 0u;
     wave_lds_sync();
 
     // window geometry (src/alignment.c:774-783)
@@ -830,12 +824,6 @@ __global__ __launch_bounds__(64, IM_WAVES_PER_SIMD) void realign_kernel(RealignA
     // speed only): give each XCD a contiguous run of reads.
     const int c = A.first + (blockIdx.x & 7) * (G >> 3) + (blockIdx.x >> 3);
     if (c >= n) return;
-    if constexpr (KT == 6 || KT == -1) {        // table_build / table_undo keep the table clean from here on
-        uint4* t4 = reinterpret_cast<uint4*>(s.tbl);
-#pragma unroll
-        for (int i = 0; i < kTblBytes / 16 / 64; i++) t4[lane + 64 * i] = make_uint4(0u, 0u, 0u, 0u);
-        wave_lds_sync();
-    }
     realign_one<KT, DIRECT>(s, A, c, lane);
 }
 
