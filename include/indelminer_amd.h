@@ -499,6 +499,13 @@ int  im_comm_init(im_ctx* ctx, const void* id_bytes, int rank, int world, im_com
 int  im_comm_allgather(im_comm* comm, const void* send_dev, void* recv_dev, size_t bytes_per_rank, void* stream);
 /* in place: buf[i] = sum over ranks of buf[i].  Asynchronous. */
 int  im_comm_allreduce_sum_i32(im_comm* comm, int32_t* buf_dev, size_t count, void* stream);
+/* Point-to-point traffic of one exchange step, device memory to device memory over RCCL (xGMI): n operations issued as ONE group.
+ * Operation k SENDS bytes[k] bytes at dev[k] to rank peer[k] (dir[k] = 0) or RECEIVES them from it (dir[k] = 1).  Every rank passes
+ * the operations it takes part in, all ranks in the same global order (the host driver: walked groups in claim order, a group's host
+ * part in front of its device arrays), so that sends and receives pair up whatever the ranks' timing.  Asynchronous.
+ * Replaces nothing in the reference (it has no communication: src/indelminer.c:536-542); it is how a group walked by one rank
+ * reaches the rank that owns its contig. */
+int  im_comm_exchange(im_comm* comm, int32_t n, const int32_t* dir, const int32_t* peer, void* const* dev, const size_t* bytes, void* stream);
 void im_comm_destroy(im_comm* comm);
 const char* im_comm_last_error(void);
 

@@ -30,6 +30,10 @@ struct RcclApi {
     ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
     ncclResult_t (*AllGather)(const void*, void*, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
     ncclResult_t (*AllReduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*Send)(const void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*Recv)(void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*GroupStart)() = nullptr;
+    ncclResult_t (*GroupEnd)() = nullptr;
     ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
     const char* (*GetErrorString)(ncclResult_t) = nullptr;
     char err[256] = {0};
@@ -68,6 +72,10 @@ bool load_rccl()
     LOAD(CommInitRank, "ncclCommInitRank")
     LOAD(AllGather, "ncclAllGather")
     LOAD(AllReduce, "ncclAllReduce")
+    LOAD(Send, "ncclSend")
+    LOAD(Recv, "ncclRecv")
+    LOAD(GroupStart, "ncclGroupStart")
+    LOAD(GroupEnd, "ncclGroupEnd")
     LOAD(CommDestroy, "ncclCommDestroy")
     LOAD(GetErrorString, "ncclGetErrorString")
 #undef LOAD
@@ -130,6 +138,28 @@ int im_comm_allreduce_sum_i32(im_comm* c, int32_t* buf_dev, size_t count, void* 
     ncclResult_t r = g_rccl.AllReduce(buf_dev, buf_dev, count, ncclInt32, ncclSum, c->comm, (hipStream_t)stream);
     if (r != ncclSuccess) {
         snprintf(g_rccl.err, sizeof g_rccl.err, "ncclAllReduce: %s", g_rccl.GetErrorString(r));
+        return IM_E_HIP;
+    }
+    return IM_OK;
+}
+
+int im_comm_exchange(im_comm* c, int32_t n, const int32_t* dir, const int32_t* peer, void* const* dev, const size_t* bytes, void* stream)
+{
+    if (!c || n < 0 || (n > 0 && (!dir || !peer || !dev || !bytes))) return IM_E_ARG;
+    for (int32_t k = 0; k < n; k++)
+        if (peer[k] < 0 || peer[k] >= c->world || (bytes[k] && !dev[k])) return IM_E_ARG;
+    if (n == 0) return IM_OK;
+    // one group: the operations are matched rank to rank in the order they are listed, and none of them can block another
+    ncclResult_t r = g_rccl.GroupStart();
+    for (int32_t k = 0; r == ncclSuccess && k < n; k++) {
+        if (!bytes[k]) continue;
+        r = dir[k] == 0 ? g_rccl.Send(dev[k], bytes[k], ncclInt8, peer[k], c->comm, (hipStream_t)stream)
+                        : g_rccl.Recv(dev[k], bytes[k], ncclInt8, peer[k], c->comm, (hipStream_t)stream);
+    }
+    const ncclResult_t e = g_rccl.GroupEnd();
+    if (r == ncclSuccess) r = e;
+    if (r != ncclSuccess) {
+        snprintf(g_rccl.err, sizeof g_rccl.err, "ncclSend / ncclRecv group: %s", g_rccl.GetErrorString(r));
         return IM_E_HIP;
     }
     return IM_OK;

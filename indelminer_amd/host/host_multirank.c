@@ -32,6 +32,7 @@ static void* mgbuf_take(mgbuf* b, size_t bytes)
 }
 
 /* a run that hangs in a collective (a rank died, a stale rendezvous) ends here, not never */
+static void mg_rank_failed(void);
 static volatile double g_mg_deadline = 0;
 static const char* volatile g_mg_waiting_for = "";
 static void* mg_watchdog(void* arg)
@@ -43,6 +44,7 @@ static void* mg_watchdog(void* arg)
         const double dl = g_mg_deadline;
         if (dl > 0 && now_ms() > dl) {
             fprintf(stderr, "indelminer: rank %d gave up waiting for the other ranks (%s)\n", g_mg_rank, g_mg_waiting_for);
+            mg_rank_failed();                      /* the others stop with this rank's message instead of waiting out their own limit */
             _exit(3);
         }
     }
@@ -796,93 +798,159 @@ static void group_park_device(ppipe* P, pgroup* G)
 /* ---- multi-GPU: a group walked by one rank, staged and replayed by another ---- */
 /* What the owner of the contig needs of a walked group: the pieces' bounds and counted reads, the flush points (placed by the
  * walking rank, which knows the read counter in front of its pieces from the exchange), the kept records of not-proper pairs,
- * the candidates' record numbers and BAM records, and the parked device arrays.  One file per claim in the rendezvous directory,
- * written under another name and renamed when complete; `aborted` = the walk met a record the reference dies on. */
-#define PKG_MAGIC 0x504b4733
-typedef struct { int32_t magic, aborted, n_ctg, n_fp, n_npp, n_cand, sv_n; int64_t n_rec, npp_len, craw_len, sv_bytes; } pkg_head;
+ * the candidates' record numbers and BAM records -- the group's HOST part, one block of bytes -- and the parked device arrays, one
+ * device allocation.  Both travel device to device in ONE RCCL send / receive group when every rank has walked what it walks
+ * (mg_ship_groups); `aborted` = the walk met a record the reference dies on. */
+#define PKG_MAGIC 0x504b4734
+typedef struct { int32_t magic, aborted, n_ctg, n_fp, n_npp, n_cand, sv_n, longest_read; int64_t n_rec, npp_len, craw_len, sv_bytes; } pkg_head;
+typedef struct { char* blob; size_t blob_len; void* slab; size_t slab_bytes; int aborted, walked; } mg_parcel;     /* a walked group on its way */
+static mg_parcel* g_parcel = NULL;            /* [claims] filled by this rank's walkers for the claims other ranks own */
 
-static void pkg_put(FILE* fp, const void* p, size_t bytes, const char* path) { if (bytes && fwrite(p, 1, bytes, fp) != bytes) fatalf("cannot write %s", path); }
-static void pkg_get(FILE* fp, void* p, size_t bytes, const char* path) { if (bytes && fread(p, 1, bytes, fp) != bytes) fatalf("%s is cut short", path); }
+static void pkg_put(FILE* fp, const void* p, size_t bytes) { if (bytes && fwrite(p, 1, bytes, fp) != bytes) fatalf("cannot serialise a walked group"); }
+static void pkg_get(FILE* fp, void* p, size_t bytes) { if (bytes && fread(p, 1, bytes, fp) != bytes) fatalf("a walked group arrived cut short"); }
 
-static void package_write(const mgpu* m, int ci, ppipe* P, pgroup* G, int aborted)
+static size_t group_slab_bytes(int32_t sv_n, int64_t sv_bytes)
 {
-    char path[512], tmp[520];
-    mg_path(m, path, sizeof path, "pkg", ci);
-    snprintf(tmp, sizeof tmp, "%s.tmp", path);
-    FILE* fp = fopen(tmp, "wb");
-    if (!fp) fatalf("cannot write %s", tmp);
+    const size_t n = (size_t)sv_n, ns = n * IM_MAX_EV;
+    const size_t bytes[10] = { (size_t)sv_bytes, 8 * n, 4 * n, 4 * n, 4 * n, 4 * n, 4 * ns, 4 * ns, 4 * ns, 4 * n };
+    size_t total = 0;
+    for (int k = 0; k < 10; k++) total += (bytes[k] + 255) & ~(size_t)255;
+    return total;
+}
+
+/* the walker's side: the group's host part as one block (the group itself is freed by the caller), its device slab stays parked */
+static void package_pack(int ci, pgroup* G, int aborted)
+{
+    mg_parcel* pc = &g_parcel[ci];
+    FILE* fp = open_memstream(&pc->blob, &pc->blob_len);
+    if (!fp) fatalf("cannot serialise a walked group");
     pkg_head h;
     memset(&h, 0, sizeof h);
     h.magic = PKG_MAGIC; h.aborted = aborted;
     if (!aborted) {
-        h.n_ctg = G->n_ctg; h.n_fp = G->n_fp; h.n_npp = G->n_npp; h.n_cand = G->n_cand; h.sv_n = G->sv_n;
+        h.n_ctg = G->n_ctg; h.n_fp = G->n_fp; h.n_npp = G->n_npp; h.n_cand = G->n_cand; h.sv_n = G->sv_n; h.longest_read = g_longest_read;
         h.n_rec = G->n_rec; h.npp_len = G->npp_len; h.craw_len = G->craw_len; h.sv_bytes = G->sv_bytes;
     }
-    pkg_put(fp, &h, sizeof h, tmp);
+    pkg_put(fp, &h, sizeof h);
     if (!aborted) {
-        pkg_put(fp, G->ctg, sizeof(gcontig) * (size_t)G->n_ctg, tmp);
-        pkg_put(fp, G->fp, sizeof(gfpoint) * (size_t)G->n_fp, tmp);
-        pkg_put(fp, G->npp_off, sizeof(int64_t) * ((size_t)G->n_npp + (G->n_npp ? 1 : 0)), tmp);
-        pkg_put(fp, G->npp_rec, sizeof(int32_t) * (size_t)G->n_npp, tmp);
-        pkg_put(fp, G->npp_raw, (size_t)G->npp_len, tmp);
-        pkg_put(fp, G->cand_rec, sizeof(int32_t) * (size_t)G->n_cand, tmp);
-        pkg_put(fp, G->craw_off, sizeof(int64_t) * ((size_t)G->n_cand + (G->n_cand ? 1 : 0)), tmp);
-        pkg_put(fp, G->craw, (size_t)G->craw_len, tmp);
-        const size_t n = (size_t)G->sv_n, ns = n * IM_MAX_EV;
-        const size_t bytes[10] = { (size_t)G->sv_bytes, 8 * n, 4 * n, 4 * n, 4 * n, 4 * n, 4 * ns, 4 * ns, 4 * ns, 4 * n };
-        size_t most = 0;
-        for (int k = 0; k < 10; k++) if (bytes[k] > most) most = bytes[k];
-        uint8_t* t = xmalloc(most + 8);
-        for (int k = 0; k < 10; k++) {
-            if (!bytes[k]) continue;
-            GPU(im_dev_download(P->d->gpu, t, G->sv[k], bytes[k]));
-            pkg_put(fp, t, bytes[k], tmp);
-        }
-        free(t);
+        pkg_put(fp, G->ctg, sizeof(gcontig) * (size_t)G->n_ctg);
+        pkg_put(fp, G->fp, sizeof(gfpoint) * (size_t)G->n_fp);
+        pkg_put(fp, G->npp_off, sizeof(int64_t) * ((size_t)G->n_npp + (G->n_npp ? 1 : 0)));
+        pkg_put(fp, G->npp_rec, sizeof(int32_t) * (size_t)G->n_npp);
+        pkg_put(fp, G->npp_raw, (size_t)G->npp_len);
+        pkg_put(fp, G->cand_rec, sizeof(int32_t) * (size_t)G->n_cand);
+        pkg_put(fp, G->craw_off, sizeof(int64_t) * ((size_t)G->n_cand + (G->n_cand ? 1 : 0)));
+        pkg_put(fp, G->craw, (size_t)G->craw_len);
+        pc->slab = G->sv[0]; pc->slab_bytes = group_slab_bytes(G->sv_n, G->sv_bytes);
     }
-    if (fclose(fp) != 0 || rename(tmp, path) != 0) fatalf("cannot publish %s", path);
+    if (fclose(fp) != 0) fatalf("cannot serialise a walked group");
+    pc->aborted = aborted; pc->walked = 1;
 }
 
-/* the owner's side: waits for the file, rebuilds the group, parks its arrays on this rank's device; NULL = the walk was aborted */
-static pgroup* package_read(const mgpu* m, int ci, ppipe* P)
+/* the owner's side: the group rebuilt from its host part; slab = its device arrays as they arrived.  NULL = the walk was aborted */
+static pgroup* package_unpack(driver* d, const char* blob, size_t len, void* slab)
 {
-    char path[512];
-    mg_path(m, path, sizeof path, "pkg", ci);
-    FILE* fp = NULL;
-    mg_arm("a piece another rank walks");
-    while (!(fp = fopen(path, "rb"))) { struct timespec ts = { 0, 2 * 1000 * 1000 }; nanosleep(&ts, NULL); }
-    mg_disarm();
+    FILE* fp = fmemopen((void*)blob, len, "rb");
+    if (!fp) fatalf("cannot read a walked group");
     pkg_head h;
-    pkg_get(fp, &h, sizeof h, path);
-    if (h.magic != PKG_MAGIC) fatalf("%s is not a group of this run", path);
-    if (h.aborted) { fclose(fp); unlink(path); return NULL; }
+    pkg_get(fp, &h, sizeof h);
+    if (h.magic != PKG_MAGIC) fatalf("what arrived is not a walked group of this run");
+    if (h.aborted) { fclose(fp); return NULL; }
+    if (h.longest_read > g_longest_read) note_long_read(d, h.longest_read);      /* this rank's realign launches must know of reads beyond 255 bases too */
     pgroup* G = xcalloc(1, sizeof(pgroup));
     G->from_package = 1;
     G->n_ctg = G->cap_ctg = h.n_ctg; G->n_fp = G->cap_fp = h.n_fp; G->n_npp = G->cap_npp = h.n_npp; G->n_cand = G->cap_cand = h.n_cand; G->sv_n = h.sv_n;
     G->n_rec = h.n_rec; G->npp_len = G->npp_cap = h.npp_len; G->craw_len = G->craw_cap = h.craw_len; G->sv_bytes = h.sv_bytes;
-    G->ctg = xmalloc(sizeof(gcontig) * (size_t)(h.n_ctg ? h.n_ctg : 1)); pkg_get(fp, G->ctg, sizeof(gcontig) * (size_t)h.n_ctg, path);
-    G->fp = xmalloc(sizeof(gfpoint) * (size_t)(h.n_fp ? h.n_fp : 1)); pkg_get(fp, G->fp, sizeof(gfpoint) * (size_t)h.n_fp, path);
-    G->npp_off = xmalloc(sizeof(int64_t) * ((size_t)h.n_npp + 1)); pkg_get(fp, G->npp_off, sizeof(int64_t) * ((size_t)h.n_npp + (h.n_npp ? 1 : 0)), path);
-    G->npp_rec = xmalloc(sizeof(int32_t) * (size_t)(h.n_npp ? h.n_npp : 1)); pkg_get(fp, G->npp_rec, sizeof(int32_t) * (size_t)h.n_npp, path);
-    G->npp_raw = xmalloc((size_t)h.npp_len + 1); pkg_get(fp, G->npp_raw, (size_t)h.npp_len, path);
-    G->cand_rec = xmalloc(sizeof(int32_t) * (size_t)(h.n_cand ? h.n_cand : 1)); pkg_get(fp, G->cand_rec, sizeof(int32_t) * (size_t)h.n_cand, path);
-    G->craw_off = xmalloc(sizeof(int64_t) * ((size_t)h.n_cand + 1)); pkg_get(fp, G->craw_off, sizeof(int64_t) * ((size_t)h.n_cand + (h.n_cand ? 1 : 0)), path);
-    G->craw = xmalloc((size_t)h.craw_len + 1); pkg_get(fp, G->craw, (size_t)h.craw_len, path);
+    G->ctg = xmalloc(sizeof(gcontig) * (size_t)(h.n_ctg ? h.n_ctg : 1)); pkg_get(fp, G->ctg, sizeof(gcontig) * (size_t)h.n_ctg);
+    G->fp = xmalloc(sizeof(gfpoint) * (size_t)(h.n_fp ? h.n_fp : 1)); pkg_get(fp, G->fp, sizeof(gfpoint) * (size_t)h.n_fp);
+    G->npp_off = xmalloc(sizeof(int64_t) * ((size_t)h.n_npp + 1)); pkg_get(fp, G->npp_off, sizeof(int64_t) * ((size_t)h.n_npp + (h.n_npp ? 1 : 0)));
+    G->npp_rec = xmalloc(sizeof(int32_t) * (size_t)(h.n_npp ? h.n_npp : 1)); pkg_get(fp, G->npp_rec, sizeof(int32_t) * (size_t)h.n_npp);
+    G->npp_raw = xmalloc((size_t)h.npp_len + 1); pkg_get(fp, G->npp_raw, (size_t)h.npp_len);
+    G->cand_rec = xmalloc(sizeof(int32_t) * (size_t)(h.n_cand ? h.n_cand : 1)); pkg_get(fp, G->cand_rec, sizeof(int32_t) * (size_t)h.n_cand);
+    G->craw_off = xmalloc(sizeof(int64_t) * ((size_t)h.n_cand + 1)); pkg_get(fp, G->craw_off, sizeof(int64_t) * ((size_t)h.n_cand + (h.n_cand ? 1 : 0)));
+    G->craw = xmalloc((size_t)h.craw_len + 1); pkg_get(fp, G->craw, (size_t)h.craw_len);
+    fclose(fp);
     const size_t n = (size_t)G->sv_n, ns = n * IM_MAX_EV;
     const size_t bytes[10] = { (size_t)G->sv_bytes, 8 * n, 4 * n, 4 * n, 4 * n, 4 * n, 4 * ns, 4 * ns, 4 * ns, 4 * n };
-    size_t total = 0, most = 0;
-    for (int k = 0; k < 10; k++) { total += (bytes[k] + 255) & ~(size_t)255; if (bytes[k] > most) most = bytes[k]; }
-    char* slab = pdev_alloc(P, total);
-    uint8_t* t = xmalloc(most + 8);
-    for (int k = 0; k < 10; k++) {
-        G->sv[k] = slab;
-        if (bytes[k]) { pkg_get(fp, t, bytes[k], path); GPU(im_dev_upload(P->d->gpu, G->sv[k], t, bytes[k])); }
-        slab += (bytes[k] + 255) & ~(size_t)255;
-    }
-    free(t);
-    fclose(fp);
-    unlink(path);
+    char* at = slab;
+    for (int k = 0; k < 10; k++) { G->sv[k] = at; at += (bytes[k] + 255) & ~(size_t)255; }
     return G;
+}
+
+/* Every rank has walked what it walks.  ONE all-gather tells all ranks what every claim's walk left (sizes, aborted or not), then
+ * the groups walked for other ranks' contigs go to their owners in ONE group of RCCL sends / receives, device memory to device
+ * memory -- claim by claim in file order on every rank, a group's host part (uploaded into a device block for the trip) in front
+ * of its device arrays.  out_G[ci] = the arrived group for the claims this rank owns and another walked (NULL: aborted).
+ * Returns the first claim whose walk was aborted anywhere (n_claims: none): every rank knows it, before any later collective. */
+static int mg_ship_groups(mgpu* m, driver* d, int n_claims, const uint8_t* walk_aborted, pgroup** out_G)
+{
+    typedef struct { int64_t blob_len, slab_bytes, flags; } row;      /* flags: 1 walked by the sender, 2 aborted */
+    const size_t nrow = (size_t)(n_claims ? n_claims : 1), tab = sizeof(row) * nrow;
+    row* mine = xcalloc(1, tab);
+    row* all = xmalloc(tab * (size_t)m->world);
+    for (int ci = 0; ci < n_claims; ci++) {
+        if (m->claim_walker[ci] != m->rank) continue;
+        mine[ci].flags = 1 | (walk_aborted[ci] ? 2 : 0);
+        if (!g_parcel[ci].walked) continue;                             /* stays here: this rank owns it */
+        mine[ci].blob_len = (int64_t)g_parcel[ci].blob_len; mine[ci].slab_bytes = (int64_t)g_parcel[ci].slab_bytes;
+        if (g_parcel[ci].aborted) mine[ci].flags |= 2;
+    }
+    mg_allgather(m, d, mine, all, tab);
+    int first_abort = n_claims;
+    int32_t n_op = 0;
+    const size_t cap_op = 4 * ((size_t)n_claims + 1);
+    int32_t* dir = xmalloc(sizeof(int32_t) * cap_op); int32_t* peer = xmalloc(sizeof(int32_t) * cap_op);
+    void** dev = xmalloc(sizeof(void*) * cap_op); size_t* bytes = xmalloc(sizeof(size_t) * cap_op);
+    void** out_blob = xcalloc((size_t)n_claims + 1, sizeof(void*));    /* device blocks the host parts travel in: outgoing, */
+    void** in_blob = xcalloc((size_t)n_claims + 1, sizeof(void*));     /* incoming, */
+    void** in_slab = xcalloc((size_t)n_claims + 1, sizeof(void*));     /* and the device arrays as they arrive */
+    for (int ci = 0; ci < n_claims; ci++) {
+        const int w = m->claim_walker[ci], o = m->claim_owner[ci];
+        const row* r = &all[(size_t)w * nrow + (size_t)ci];
+        forceassert(r->flags & 1);
+        if ((r->flags & 2) && ci < first_abort) first_abort = ci;
+        if (r->blob_len == 0) continue;                                  /* stays where it was walked */
+        const size_t bl = ((size_t)r->blob_len + 255) & ~(size_t)255;
+        if (w == m->rank) {
+            if (im_dev_alloc(d->gpu, bl, &out_blob[ci]) != IM_OK) fatalf("im_dev_alloc: %s", im_last_error(d->gpu));
+            if (im_dev_upload(d->gpu, out_blob[ci], g_parcel[ci].blob, g_parcel[ci].blob_len) != IM_OK) fatalf("im_dev_upload: %s", im_last_error(d->gpu));
+            dir[n_op] = 0; peer[n_op] = o; dev[n_op] = out_blob[ci]; bytes[n_op] = bl; n_op++;
+            if (r->slab_bytes) { dir[n_op] = 0; peer[n_op] = o; dev[n_op] = g_parcel[ci].slab; bytes[n_op] = (size_t)r->slab_bytes; n_op++; }
+        }
+        if (o == m->rank) {
+            if (im_dev_alloc(d->gpu, bl, &in_blob[ci]) != IM_OK) fatalf("im_dev_alloc: %s", im_last_error(d->gpu));
+            dir[n_op] = 1; peer[n_op] = w; dev[n_op] = in_blob[ci]; bytes[n_op] = bl; n_op++;
+            if (r->slab_bytes) {
+                if (im_dev_alloc(d->gpu, (size_t)r->slab_bytes, &in_slab[ci]) != IM_OK) fatalf("im_dev_alloc: %s", im_last_error(d->gpu));
+                dir[n_op] = 1; peer[n_op] = w; dev[n_op] = in_slab[ci]; bytes[n_op] = (size_t)r->slab_bytes; n_op++;
+            }
+        }
+    }
+    void* st = im_ctx_stream(d->gpu);
+    mg_arm("the walked groups of other ranks");
+    if (im_comm_exchange(m->comm, n_op, dir, peer, dev, bytes, st) != IM_OK) fatalf("im_comm_exchange: %s", im_comm_last_error());
+    if (im_stream_sync(d->gpu, st) != IM_OK) fatalf("im_stream_sync: %s", im_last_error(d->gpu));
+    mg_disarm();
+    for (int ci = 0; ci < n_claims; ci++) {
+        const int w = m->claim_walker[ci], o = m->claim_owner[ci];
+        const row* r = &all[(size_t)w * nrow + (size_t)ci];
+        if (r->blob_len == 0) continue;
+        if (o == m->rank) {
+            char* host = xmalloc((size_t)r->blob_len + 8);
+            if (im_dev_download(d->gpu, host, in_blob[ci], (size_t)r->blob_len) != IM_OK) fatalf("im_dev_download: %s", im_last_error(d->gpu));
+            out_G[ci] = package_unpack(d, host, (size_t)r->blob_len, in_slab[ci]);
+            free(host);
+            im_dev_free(d->gpu, in_blob[ci]);
+        }
+        if (w == m->rank) {
+            im_dev_free(d->gpu, out_blob[ci]);
+            if (g_parcel[ci].slab) im_dev_free(d->gpu, g_parcel[ci].slab);
+            free(g_parcel[ci].blob);
+            memset(&g_parcel[ci], 0, sizeof g_parcel[ci]);
+        }
+    }
+    free(mine); free(all); free(dir); free(peer); free(dev); free(bytes); free(out_blob); free(in_blob); free(in_slab);
+    return first_abort;
 }
 
 /* ONE-PASS mode, once the insert lengths are known: every candidate's range[1] from its own record */

@@ -385,6 +385,7 @@ typedef struct {
 } mgpu;
 
 static mgpu* g_mg = NULL;
+static int g_mg_self_ship = 0;          /* tests: claims this rank owns AND walks go through the exchange too */
 static driver* g_mg_driver = NULL;
 static void mg_finish(mgpu* m, driver* d);
 static int g_mg_cur_tid = -1;          /* the first contig of the claim the main thread is working on */

@@ -197,13 +197,13 @@ static void* walker_thread(void* arg)
             break;
         }
         claim_t* c = &o->claims[ci];
-        volatile int ship = g_mg && g_mg->claim_owner[ci] != g_mg->rank;       /* read behind a setjmp */
+        volatile int ship = g_mg && (g_mg->claim_owner[ci] != g_mg->rank || g_mg_self_ship);       /* read behind a setjmp */
         if (g_handoff_pool) {
             /* a record the reference dies on ends this walker: the claim is published as it is, marked */
             W->cur_claim = c;
             if (setjmp(W->abort_jmp)) {
                 const int cj = (int)(W->cur_claim - o->claims);
-                if (g_mg && g_mg->claim_owner[cj] != g_mg->rank) package_write(g_mg, cj, &W->P, NULL, 1);      /* its owner hands the run over */
+                if (g_mg && (g_mg->claim_owner[cj] != g_mg->rank || g_mg_self_ship)) package_pack(cj, NULL, 1);      /* its owner hands the run over */
                 pthread_mutex_lock(&o->mu);
                 W->cur_claim->G = NULL; W->cur_claim->aborted = 1; W->cur_claim->walked = 1;
                 pthread_cond_broadcast(&o->cv);
@@ -217,8 +217,7 @@ static void* walker_thread(void* arg)
         if (g_onepass && g_spec_active && !G->sv_range) G->sv_range = group_ranges(&W->wd, G);    /* the provisional table is there: this candidate's range[1] now */
         if (g_mg) { int64_t nr = 0; group_flush_points(G, &nr); G->from_package = 1; }      /* the counter in front of every piece is known (mg_exchange) */
         if (ship) {
-            package_write(g_mg, ci, &W->P, G, 0);
-            im_dev_free(W->P.d->gpu, G->sv[0]);
+            package_pack(ci, G, 0);         /* the host part as one block; the device arrays stay parked until the ranks exchange (mg_ship_groups) */
             group_free(G); free(G);
             G = NULL;
         }
@@ -412,6 +411,11 @@ static walkpool_t* walkpool_start(driver* d)
         /* INDELMINER_MG_FORCE_SPLIT=1 (tests): treat the run as one whose contigs were walked by several ranks -- the replays wait
          * for the sum of the depth arrays (im_depth_allreduce) -- also with one rank, where the sum changes nothing */
         if (getenv("INDELMINER_MG_FORCE_SPLIT")) m->split = 1;
+        /* INDELMINER_MG_SELF_SHIP=1 (tests, one rank): every claim takes the road of a claim walked for another rank -- parcelled,
+         * through the send / receive group (to this rank itself), unpacked */
+        g_mg_self_ship = getenv("INDELMINER_MG_SELF_SHIP") != NULL && !o->serial;
+        if (g_mg_self_ship) m->split = 1;
+        g_parcel = xcalloc((size_t)(o->n_claims ? o->n_claims : 1), sizeof(mg_parcel));
         free(load);
     }
     if (nw > o->n_claims) nw = o->n_claims ? o->n_claims : 1;
@@ -511,6 +515,9 @@ static void onepass_counted_groups_known(driver* d, walkpool_t* o, int n_claims)
             }
     }
 }
+
+static jmp_buf g_mg_split_abort;
+static int g_mg_split_armed = 0;
 
 static void run_pipeline(driver* d, walkpool_t* o)
 {
@@ -622,13 +629,33 @@ static void run_pipeline(driver* d, walkpool_t* o)
     /* multi-GPU with pieces of a contig walked by several ranks: no rank's depth array is complete before all ranks have walked
      * all their pieces -- the contigs' replays wait for the sum (im_depth_allreduce) */
     struct { pgroup** held; int n_held; pgroup* chain; } *late = (g_mg && g_mg->split) ? xcalloc((size_t)(o->n_claims ? o->n_claims : 1), sizeof *late) : NULL;
-    int n_late = 0;
+    volatile int n_late = 0;                /* read behind a longjmp (g_mg_split_abort) */
+    pgroup** arrived = NULL;                /* multi-GPU, pieces over several ranks: the groups other ranks walked for this rank's contigs */
+    int32_t mg_abort_tid = INT_MAX;         /* ... and the first contig some rank's WALK met a record the reference dies on: all ranks know */
+    if (late) {
+        /* Every rank walks what it walks, then ONE exchange: what each claim's walk left (all-gather), and the walked groups to
+         * their contigs' owners device to device (one RCCL send / receive group).  Staging follows, in file order. */
+        for (int i = 0; i < o->nw && !o->serial; i++) pthread_join(o->w[i].th, NULL);
+        phase_time("the walk of this rank's pieces (inflate + count; triage on the device)");
+        uint8_t* wab = xcalloc((size_t)(o->n_claims ? o->n_claims : 1), 1);
+        for (int ci = 0; ci < o->n_claims; ci++) wab[ci] = (uint8_t)(o->claims[ci].aborted != 0);
+        arrived = xcalloc((size_t)(o->n_claims ? o->n_claims : 1), sizeof(pgroup*));
+        const int fa = mg_ship_groups(g_mg, d, o->n_claims, wab, arrived);
+        free(wab);
+        if (fa < o->n_claims) mg_abort_tid = o->pieces[o->claims[fa].first].tid;
+        phase_time("walked groups exchanged between the ranks (RCCL send / receive)");
+        /* a record the reference dies on, met while this rank stages: the rank stops staging there but still joins the sum of
+         * the depth arrays below -- the other ranks are on their way into it (pipeline_handoff jumps here) */
+        g_mg_split_armed = 1;
+        if (setjmp(g_mg_split_abort)) goto claims_done;
+    }
     for (int ci = 0; ci < o->n_claims; ci++) {
         claim_t* c = &o->claims[ci];
         if (g_mg && g_mg->claim_owner[ci] != g_mg->rank) continue;        /* another rank's contig */
         g_mg_cur_tid = o->pieces[c->first].tid;
-        if (g_mg && g_mg->claim_walker[ci] != g_mg->rank) {
-            c->G = package_read(g_mg, ci, &S);
+        if (late && g_mg_cur_tid >= mg_abort_tid) { g_mg->abort_tid = mg_abort_tid; break; }      /* every rank stops in front of that contig */
+        if (g_mg && (g_mg->claim_walker[ci] != g_mg->rank || (g_mg_self_ship && !o->serial))) {
+            c->G = arrived[ci];
             c->walked = 1; c->aborted = c->G == NULL;
             if (c->aborted) pipeline_handoff();
         } else if (o->serial) {
@@ -720,9 +747,11 @@ static void run_pipeline(driver* d, walkpool_t* o)
         }
         n_held = 0; chain = NULL;
     }
+claims_done:
+    g_mg_split_armed = 0;
     if (late) {
-        /* every rank has walked what it walks (its walkers are done: the packages are out) and staged what it owns */
-        for (int i = 0; i < o->nw && !o->serial; i++) pthread_join(o->w[i].th, NULL);
+        /* every rank has walked what it walks and staged what it owns */
+        free(arrived);
         mg_arm("the sum of the depth arrays");
         GPU2(d, im_depth_allreduce(d->gpu, g_mg->comm));
         mg_disarm();
@@ -809,6 +838,12 @@ static void run_pipeline(driver* d, walkpool_t* o)
 static void pipeline_handoff(void)
 {
     walkpool_t* o = g_handoff_pool;
+    if (g_mg && g_mg_split_armed) {
+        /* pieces of contigs over several ranks: the other ranks are heading for the sum of the depth arrays -- this rank stops
+         * staging here, joins that sum, replays the contigs it has complete and reports the contig when it is done (mg_finish) */
+        g_mg->abort_tid = g_mg_cur_tid;
+        longjmp(g_mg_split_abort, 1);
+    }
     if (g_mg) {
         /* this rank's parts in front of the claim it is working on are complete (the replay workers' jobs first); the flag names
          * the claim's first contig and rank 0, once every rank has reported, prints what lies in front of the smallest such

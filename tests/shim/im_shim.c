@@ -485,6 +485,42 @@ int im_comm_allgather(im_comm* m, const void* send, void* recv, size_t bytes, vo
     m->seq++;
     return IM_OK;
 }
+/* the point-to-point step over files: every send leaves x.<step>.<from>.<to>.<k-th operation between the two>, every receive waits for its file */
+int im_comm_exchange(im_comm* m, int32_t n, const int32_t* dir, const int32_t* peer, void* const* dev, const size_t* bytes, void* stream)
+{
+    (void)stream;
+    int* nth = calloc((size_t)m->world * 2, sizeof(int));
+    char path[320], tmp[330];
+    for (int pass = 0; pass < 2; pass++)                /* all sends first: nothing here can wait on itself */
+        for (int32_t k = 0; k < n; k++) {
+            if (dir[k] != pass) continue;
+            const int ord = nth[peer[k] * 2 + pass]++;
+            if (pass == 0) {
+                snprintf(path, sizeof path, "%s/x.%d.%d.%d.%d", m->dir, m->seq, m->rank, peer[k], ord);
+                snprintf(tmp, sizeof tmp, "%s.tmp", path);
+                FILE* fp = fopen(tmp, "wb");
+                if (!fp || (bytes[k] && fwrite(dev[k], 1, bytes[k], fp) != bytes[k])) { snprintf(g_comm_err, sizeof g_comm_err, "cannot write %s", tmp); free(nth); return IM_E_HIP; }
+                fclose(fp);
+                rename(tmp, path);
+            } else {
+                snprintf(path, sizeof path, "%s/x.%d.%d.%d.%d", m->dir, m->seq, peer[k], m->rank, ord);
+                for (int tries = 0;; tries++) {
+                    FILE* fp = fopen(path, "rb");
+                    if (fp) {
+                        const size_t got = bytes[k] ? fread(dev[k], 1, bytes[k], fp) : 0;
+                        fclose(fp);
+                        if (got == bytes[k]) { unlink(path); break; }
+                    }
+                    if (tries > 6000) { snprintf(g_comm_err, sizeof g_comm_err, "rank %d never wrote %s", peer[k], path); free(nth); return IM_E_HIP; }
+                    struct timespec ts = { 0, 10 * 1000 * 1000 };
+                    nanosleep(&ts, NULL);
+                }
+            }
+        }
+    free(nth);
+    m->seq++;
+    return IM_OK;
+}
 int im_comm_allreduce_sum_i32(im_comm* m, int32_t* buf, size_t count, void* stream)
 {
     int32_t* all = malloc(4 * count * (size_t)m->world);

@@ -956,6 +956,12 @@ def test_product_multi_gpu_path_one_rank(synth_small, tmp_path):
                    env={"INDELMINER_FORCE_MGPU": "1", "RANK": "0", "WORLD_SIZE": "1", "LOCAL_RANK": "0", "INDELMINER_MG_FORCE_SPLIT": "1",
                         "INDELMINER_PIECE_BYTES": "150000", "INDELMINER_RENDEZVOUS": str(tmp_path / "rdv2")})
         assert out == _golden(gold)
+        # the road of a group walked for another rank's contig: host part serialised and uploaded, host part + device arrays through
+        # ONE ncclSend / ncclRecv group (here from the rank to itself), unpacked and staged from the arrived arrays
+        out = _run(_product(), flags, synth_small, "ref.fa", "aln.bam",
+                   env={"INDELMINER_FORCE_MGPU": "1", "RANK": "0", "WORLD_SIZE": "1", "LOCAL_RANK": "0", "INDELMINER_MG_SELF_SHIP": "1",
+                        "INDELMINER_PIECE_BYTES": "150000", "INDELMINER_RENDEZVOUS": str(tmp_path / "rdv3")})
+        assert out == _golden(gold)
 
 
 def _odd_inputs(binary, tmp_path, envs, seeds=None):

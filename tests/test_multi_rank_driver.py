@@ -178,6 +178,51 @@ def test_ranks_hand_a_run_the_reference_aborts_to_one_process(tmp_path):
         del os.environ["IM_TEST_RC0"]
 
 
+def test_ranks_hand_over_an_aborted_run_whose_contigs_lie_in_pieces_over_the_ranks(tmp_path):
+    """the same record with the contigs cut into pieces that every rank walks (walked groups travel to the contig's owner, the
+    depth arrays are summed over the ranks): the rank that meets the record must not leave the others waiting in a collective --
+    every rank learns of the aborted walk in the exchange, stops in front of that contig, joins the sum and reports; rank 0
+    prints what lies in front and starts the record-at-a-time child.  The single run's bytes and status, within seconds."""
+    import time
+    import numpy as np
+    from indelminer_amd import bamwrite, rawrec, synth
+    refs, rd = synth.simulate(seed=54, ref_len=220_000, coverage=30, n_contigs=4, big_every=3)
+    proper = ((rd.flag & 0x2) != 0) & (rd.tid == 2) & (rd.pos > 150_000) & (rd.ncig == 1)
+    i = int(np.nonzero(proper)[0][5])
+    rd.cig_op[i, 0] = 3
+    contigs = [("ctg%d" % k, len(r)) for k, r in enumerate(refs)]
+    bamwrite.write_fasta(str(tmp_path / "ref.fa"), contigs, refs)
+    rawrec.write_bam_fast(str(tmp_path / "aln.bam"), contigs, rd)
+    one = subprocess.run([th._build_shim(), "ref.fa", "s=aln.bam"], cwd=str(tmp_path), stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                         env=dict(os.environ, INDELMINER_PIPELINE="host"))
+    assert one.returncode == 1 and b"new_readseg_bam" in one.stderr and one.stdout.count(b"\n") > 60
+    env = {"IM_TEST_RC0": "1", "INDELMINER_MG_FORCE_SPLIT": "1", "INDELMINER_PIECE_BYTES": "150000", "INDELMINER_MG_TIMEOUT": "60"}
+    old = {k: os.environ.get(k) for k in env}
+    os.environ.update(env)
+    try:
+        for world in (2, 3):
+            t = time.time()
+            assert _run_world(world, [], str(tmp_path), "ref.fa", "aln.bam") == one.stdout, world
+            assert time.time() - t < 50, "a rank sat out its watchdog"
+    finally:
+        for k, v in old.items():
+            if v is None:
+                del os.environ[k]
+            else:
+                os.environ[k] = v
+
+
+def test_one_rank_ships_every_group_to_itself(tmp_path_factory):
+    """INDELMINER_MG_SELF_SHIP=1: every claim takes the road of a claim walked for another rank's contig -- the group's host
+    part serialised, host part and device arrays through the send / receive group (here to the rank itself), unpacked, staged
+    from the arrived arrays: the single run's bytes (the same test runs on the GPU box with the real RCCL group)"""
+    d = th._synth_dir(tmp_path_factory, "synth_2ctg_composite")
+    env = {"INDELMINER_FORCE_MGPU": "1", "INDELMINER_MG_SELF_SHIP": "1", "INDELMINER_PIECE_BYTES": "60000",
+           "INDELMINER_RENDEZVOUS": os.path.join(d, "rdv_self"), "INDELMINER_RUN_TOKEN": "self"}
+    got = th._run(th._build_shim(), ["-i", "cfg.txt"], d, ref="ref.fa", bam="aln.bam", env=env)
+    assert got == th._golden("synth_2ctg_composite")
+
+
 def _with_env(env, fn):
     old = {k: os.environ.get(k) for k in env}
     os.environ.update(env)
