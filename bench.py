@@ -486,23 +486,86 @@ def end_to_end_config3():
         return out
 
 
-def end_to_end_multi(rank, world, local_rank, dist, ref_len=2_000_000):
-    """The PRODUCT on all the job's GPUs: every rank starts `indelminer` as a child with its own
-    RANK / LOCAL_RANK / WORLD_SIZE on one BAM of two contigs cut into about 3 x world pieces -- contigs owned longest-first,
-    pieces walked by the least-loaded rank and shipped to the owner, one RCCL all-gather of the ranks' pre-walk logs, one sum of
-    the depth arrays, rank 0 prints the VCF -- and rank 0 compares that VCF byte for byte with the single-process run.
-    Reported beside the kernel-level numbers, never `value`; a failure here never touches the line's other fields."""
-    import shutil
+def _mg_product_run(rank, world, local_rank, dist, td, flags, n_reads, piece_bytes, single_wall=None, single_vcf=None):
+    """the product CLI on every rank of the job over the input in td (ref.fa, aln.bam); rank 0 also runs it as ONE process and compares
+    the bytes.  Returns (on rank 0) wall time = max over ranks, reads/s, per-rank phase times and what RCCL said about the communicator."""
+    import re
     import subprocess
+    from indelminer_amd import build
+    cmd = [build.HOST_BIN] + flags + ["ref.fa", "s=aln.bam"]
+    env = dict(os.environ, RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(local_rank), INDELMINER_RENDEZVOUS=td + "/rdv", INDELMINER_RUN_TOKEN=td,
+               INDELMINER_TIMING="1", INDELMINER_MG_TIMEOUT="120")          # a rank that waits longer than that for the others gives up (default 600 s)
+    if piece_bytes:
+        env["INDELMINER_PIECE_BYTES"] = str(piece_bytes)
+    if world == 1:
+        env["INDELMINER_FORCE_MGPU"] = "1"
+    if os.environ.get("IM_BENCH_ONE_DEVICE") == "1":
+        env["INDELMINER_DEVICE"] = "0"
+    t = time.perf_counter()
+    try:
+        p = subprocess.run(cmd, cwd=td, stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env, timeout=400)
+        rc, vcf, err = p.returncode, p.stdout, p.stderr.decode(errors="replace")
+    except Exception as ex:
+        rc, vcf, err = -1, b"", str(ex)
+    wall = time.perf_counter() - t
+    phases = {}
+    for m_ in re.finditer(r"\[timing\] (.+?)\s+([0-9.]+) ms", err):
+        phases[m_.group(1).strip()] = phases.get(m_.group(1).strip(), 0.0) + float(m_.group(2))
+    keep = ("the walk of this rank's pieces", "the ranks' walk logs exchanged", "walked groups exchanged between the ranks", "depth arrays summed over the ranks",
+            "GPU context + reference upload", "read FASTA", "device: realign + flush cuts + group-by", "results to the host", "replay workers drained")
+    mine = {"rank": rank, "wall_s": wall, "rc": rc, "rccl": re.findall(r"RCCL communicator of (\d+) ranks", err)[:1],
+            "phases_ms": {k: round(sum(v for n_, v in phases.items() if n_.startswith(k)), 1) for k in keep}}
+    per_rank = [mine]
+    ok = rc == 0
+    if dist is not None:
+        import torch
+        w = torch.tensor([wall], dtype=torch.float64); dist.all_reduce(w, op=dist.ReduceOp.MAX); wall = float(w[0])
+        k = torch.tensor([1 if ok else 0]); dist.all_reduce(k, op=dist.ReduceOp.MIN); ok = bool(int(k[0]))
+        got = [None] * world if rank == 0 else None
+        dist.gather_object(mine, got, dst=0)
+        if rank == 0:
+            per_rank = got
+    if rank != 0:
+        return None
+    out = {"n_gpus": world, "reads": n_reads, "all_ranks_ok": ok, "wall_s": wall, "reads_per_s": n_reads / wall if ok else None,
+           "rccl_ranks_seen": sorted({int(x) for r_ in per_rank for x in r_["rccl"]}), "per_rank": per_rank}
+    if not ok:
+        out["rank0_stderr_tail"] = err[-400:]
+    if single_vcf is None:
+        env1 = {k_: v for k_, v in os.environ.items() if k_ not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "LOCAL_WORLD_SIZE", "GROUP_RANK")}
+        if os.environ.get("IM_BENCH_ONE_DEVICE") == "1":
+            env1["INDELMINER_DEVICE"] = "0"
+        t = time.perf_counter()
+        q = subprocess.run(cmd, cwd=td, stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env1, timeout=400)
+        single_wall, single_vcf = time.perf_counter() - t, (q.stdout if q.returncode == 0 else None)
+    out["single_process_wall_s"] = single_wall
+    out["vcf_records"] = sum(1 for l in (single_vcf or b"").splitlines() if not l.startswith(b"#"))
+    out["vcf_identical_to_single_process"] = bool(ok and single_vcf is not None and single_vcf == vcf)
+    out["speedup_over_single_process"] = (single_wall / wall) if ok else None
+    return out
+
+
+def end_to_end_multi(rank, world, local_rank, dist):
+    """STRONG scaling of the PRODUCT on the job's GPUs: every rank starts `indelminer` as a child with its own
+    RANK / LOCAL_RANK / WORLD_SIZE on the SAME input -- contigs owned longest-first, pieces walked by the least-loaded rank, ONE RCCL
+    all-gather of the ranks' walk logs, walked groups to their owners in ONE RCCL send / receive group, one sum of the depth arrays,
+    rank 0 prints the VCF -- and rank 0 compares that VCF byte for byte with the single-process run.  Two inputs:
+      config3     BASELINE configs[2] at full size (8 contigs x 6.25 Mb, 15 M reads, no config file): contigs over the ranks
+      one_contig  BASELINE configs[1] (ONE 1 Mb contig) cut into about 3 x world pieces: every rank walks pieces of the one contig
+    Reported beside the kernel-level numbers, never `value`."""
+    import importlib.util
+    import shutil
     import tempfile
     from indelminer_amd import bamwrite, build
     if not os.path.exists(build.HOST_BIN):
         return None
-    n_ctg = 2                     # fewer contigs than GPUs from 3 ranks on: their pieces are walked by every rank
+    out = {"what": "the product CLI, one process per GPU, the same input for every N (strong scaling); per rank the [timing] phases it printed"}
+    strong = {}
+    # ---- one contig in pieces
     box = [None, 0, 0]
     if rank == 0:
         box[0] = tempfile.mkdtemp(prefix="im_mgpu_")
-        refs, rd = synth.simulate(seed=11, ref_len=ref_len, coverage=30, read_len=100, n_contigs=n_ctg, big_every=7)
+        refs, rd = synth.simulate(seed=1, ref_len=1_000_000, coverage=30, read_len=100)
         contigs = [("ctg%d" % i, len(r)) for i, r in enumerate(refs)]
         bamwrite.write_fasta(box[0] + "/ref.fa", contigs, refs)
         rawrec.write_bam_fast(box[0] + "/aln.bam", contigs, rd, level=6)
@@ -512,51 +575,47 @@ def end_to_end_multi(rank, world, local_rank, dist, ref_len=2_000_000):
     if dist is not None:
         dist.broadcast_object_list(box, src=0)
     td, n_reads, bam_bytes = box
-    cmd = [build.HOST_BIN, "-i", "cfg.txt", "ref.fa", "s=aln.bam"]
-    # pieces small enough that every rank gets several (the default piece size is for files of gigabytes)
-    env = dict(os.environ, RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(local_rank), INDELMINER_RENDEZVOUS=td + "/rdv", INDELMINER_RUN_TOKEN=td,
-               INDELMINER_PIECE_BYTES=str(max(bam_bytes // (3 * max(world, 1)), 200000)),
-               INDELMINER_MG_TIMEOUT="90")            # a rank that waits longer than that for the others gives up (default 600 s)
-    if world == 1:
-        env["INDELMINER_FORCE_MGPU"] = "1"
-    if os.environ.get("IM_BENCH_ONE_DEVICE") == "1":
-        env["INDELMINER_DEVICE"] = "0"
-    out = {"n_gpus": world, "contigs": n_ctg, "reads": n_reads, "what": "the product CLI, one process per GPU: %d contigs cut into pieces that all ranks walk, "
-           "walked groups shipped to the contig's owner, one all-gather of the ranks' logs + one sum of the depth arrays" % n_ctg}
-    t = time.perf_counter()
     try:
-        p = subprocess.run(cmd, cwd=td, stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env, timeout=200)
-        rc, vcf, err = p.returncode, p.stdout, p.stderr[-400:].decode(errors="replace")
+        strong["one_contig"] = _mg_product_run(rank, world, local_rank, dist, td, ["-i", "cfg.txt"], n_reads, max(bam_bytes // (3 * max(world, 1)), 200000))
     except Exception as ex:
-        rc, vcf, err = -1, b"", str(ex)
-    wall = time.perf_counter() - t
-    ok = rc == 0
-    if dist is not None:
-        import torch
-        w = torch.tensor([wall], dtype=torch.float64); dist.all_reduce(w, op=dist.ReduceOp.MAX); wall = float(w[0])
-        k = torch.tensor([1 if ok else 0]); dist.all_reduce(k, op=dist.ReduceOp.MIN); ok = bool(int(k[0]))
-    if rank == 0:
-        out.update(all_ranks_ok=ok, wall_s=wall, reads_per_s=n_reads / wall if ok else None,
-                   note="whole program per rank incl. process start, GPU context, the pre-walk of the rank's contigs and the RCCL "
-                        "communicator bring-up (about 2 s of the wall time on its own, measured with one rank)")
-        if not ok:
-            out["rank0_stderr_tail"] = err
-        env1 = {k_: v for k_, v in os.environ.items() if k_ not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "LOCAL_WORLD_SIZE", "GROUP_RANK")}
-        if os.environ.get("IM_BENCH_ONE_DEVICE") == "1":
-            env1["INDELMINER_DEVICE"] = "0"
-        t = time.perf_counter()
-        try:
-            q = subprocess.run(cmd, cwd=td, stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env1, timeout=300)
-            out["single_process_wall_s"] = time.perf_counter() - t
-            out["vcf_records"] = sum(1 for l in q.stdout.splitlines() if not l.startswith(b"#"))
-            out["vcf_identical_to_single_process"] = bool(ok and q.returncode == 0 and q.stdout == vcf)
-        except Exception as ex:
-            out["single_process_error"] = str(ex)
+        strong["one_contig"] = {"error": str(ex)}
     if dist is not None:
         dist.barrier()
     if rank == 0:
         shutil.rmtree(td, ignore_errors=True)
-    return out if rank == 0 else None
+    # ---- configs[2] at full size
+    if os.environ.get("IM_BENCH_MG_CONFIG3", "1") == "1":
+        box = [None, 0]
+        if rank == 0:
+            spec = importlib.util.spec_from_file_location("make_golden_large", os.path.join(ROOT, "tests", "golden", "make_golden_large.py"))
+            mg = importlib.util.module_from_spec(spec)
+            spec.loader.exec_module(mg)
+            box[0] = tempfile.mkdtemp(prefix="im_mgpu3_")
+            box[1], _ = mg.materialise("config3", box[0])
+        if dist is not None:
+            dist.broadcast_object_list(box, src=0)
+        td, n_reads = box
+        try:
+            r3 = _mg_product_run(rank, world, local_rank, dist, td, [], int(n_reads), 0)
+            if rank == 0:
+                import hashlib
+                want = json.load(open(os.path.join(ROOT, "tests", "golden", "large_config3.json")))
+                r3["workload"] = "BASELINE configs[2] at full size, no config file"
+                r3["vcf_records_of_the_reference"] = want["records"]
+            strong["config3"] = r3
+        except Exception as ex:
+            strong["config3"] = {"error": str(ex)}
+        if dist is not None:
+            dist.barrier()
+        if rank == 0:
+            shutil.rmtree(td, ignore_errors=True)
+    if rank != 0:
+        return None
+    out["strong"] = strong
+    good = [v for v in strong.values() if isinstance(v, dict) and "error" not in v]
+    out["all_ranks_ok"] = bool(good) and len(good) == len(strong) and all(v["all_ranks_ok"] for v in good)
+    out["vcf_identical_to_single_process"] = bool(good) and len(good) == len(strong) and all(v["vcf_identical_to_single_process"] for v in good)
+    return out
 
 
 def cpu_port_baseline(ref, cand, read_len, n_reads_total, m):

@@ -260,7 +260,8 @@ int main(int argc, char** argv)
              * multi-GPU runs and annotate mode keep the pre-pass (the shard summaries / the serial walk need the table up front) */
             {
                 const char* op = getenv("INDELMINER_ONEPASS");          /* INDELMINER_ONEPASS=0: the pre-pass of the reference's layout */
-                g_onepass = O.configfile == NULL && !g_mg && g_vcfname == NULL && chromid == -1 && !(op && strcmp(op, "0") == 0);
+                /* several ranks: always the one walk (run_pipeline: the ranks exchange what their walks logged) */
+                g_onepass = O.configfile == NULL && g_vcfname == NULL && chromid == -1 && (g_mg || !(op && strcmp(op, "0") == 0));
             }
             pool = walkpool_start(&d);
         }
@@ -294,24 +295,10 @@ int main(int argc, char** argv)
 
     const char* pl = getenv("INDELMINER_PIPELINE");
     const int use_pipeline = !(pl && strcmp(pl, "host") == 0);
-    if (g_mg) {
+    if (g_mg && pool->serial) {
+        /* annotate mode: contigs are walked one by one behind each other's replays -- the logs come from a pass of their own */
         mg_exchange(&mg, &d, O.configfile == NULL, pool->pieces, pool->n_pieces, mg.piece_walker);
-        if (mg.cross) {
-            /* A first mate left waiting in one contig meets a record of the same name in a later one: the reference's one
-             * pair table pairs them across contigs (readpairs is never reset, src/indelminer.c), so the contigs of this
-             * input are not independent.  Every rank sees that in the exchanged logs; the run goes to ONE process that
-             * serves one table record by record, the other ranks have nothing to add. */
-            if (mg.rank != 0) { im_comm_destroy(mg.comm); fflush(stderr); _exit(EXIT_SUCCESS); }
-            fprintf(stderr, "indelminer: read names are shared between contigs (pairs across contigs in the one pair table): one process takes the run\n");
-            mg_discard_dir(&mg);
-            mg_restore_stdout(&mg);
-            handoff_to_host_child();
-        }
-        if (O.configfile == NULL && mg.rank == 0) {
-            fprintf(stderr, "\nRead-group\tMin-value\tMax-value (estimated over all ranks' contigs)\n");
-            for (int j = 0; j < g_rg_n; j++) fprintf(stderr, "%s\t%d\t%d\n", g_rg_name[j], g_rg_range[j][0], g_rg_range[j][1]);
-            cov_print_table(d.hdr);
-        }
+        mg_after_logs(&mg, &d);
     }
     if (use_pipeline) run_pipeline(&d, pool);
     if (g_mg) mg_finish(&mg, &d);

@@ -187,6 +187,7 @@ static void* mg_comm_bringup(void* arg)
     mg_arm("communicator bring-up");
     if (im_comm_init(d->gpu, id, m->rank, m->world, &m->comm) != IM_OK) fatalf("im_comm_init: %s", im_comm_last_error());
     mg_disarm();
+    if (g_timing) fprintf(stderr, "    [timing] rank %d: RCCL communicator of %d ranks is up\n", m->rank, m->world);
     return NULL;
 }
 static void mg_comm_join(void) { if (g_rdv.pending) { g_rdv.pending = 0; pthread_join(g_rdv.th, NULL); } }
@@ -498,13 +499,21 @@ static void estimate_insertlengths_threads(driver* d, const piece_t* pieces, int
 /* the pair table of the replay: name -> the waiting first mate's start and contig; the entries that wait, for the floor */
 typedef struct { int32_t start, tid, slot; } mg_wait;
 
-/* exchange + merge: the insert-length table (when estimated), the counter prefix and the marker floor of every contig */
+static void mg_exchange_logs(mgpu* m, driver* d, int estimate, mgbuf mine, const piece_t* pieces, int n_pieces, const int32_t* piece_walker);
+/* annotate mode (contigs walked one by one, by the main thread): the logs come from a pass of their own over this rank's pieces */
 static void mg_exchange(mgpu* m, driver* d, int estimate, const piece_t* pieces, int n_pieces, const int32_t* piece_walker)
 {
-    const int32_t nt = d->hdr->n_targets;
     mgbuf mine = { NULL, 0, 0 };
     mg_prewalk(m, d, estimate, &mine, pieces, n_pieces, piece_walker);
     phase_time("pre-walk of this rank's contigs (count, pair-table events, insert lengths)");
+    mg_exchange_logs(m, d, estimate, mine, pieces, n_pieces, piece_walker);
+}
+
+/* exchange + merge: the insert-length table (when estimated), the counter prefix and the marker floor of every contig, and the first
+ * piece some rank's walk did not survive (m->abort_piece) */
+static void mg_exchange_logs(mgpu* m, driver* d, int estimate, mgbuf mine, const piece_t* pieces, int n_pieces, const int32_t* piece_walker)
+{
+    const int32_t nt = d->hdr->n_targets;
     /* ONE all-gather of fixed-size buffers.  Every rank derives the same size from the same file: pair-table events are a few
      * per thousand records, so a 64th of the file holds them many times over; a rank whose log does not fit says so in its
      * header and the exchange is repeated once with the size that does (all ranks see all headers: all agree). */
@@ -603,9 +612,11 @@ static void mg_exchange(mgpu* m, driver* d, int estimate, const piece_t* pieces,
     qhash* table = qhash_new(16);
     mg_wait** live = NULL; int32_t n_live = 0, cap_live = 0;
     int64_t run = 0;
+    m->abort_piece = n_pieces;
     for (int pi = 0; pi < n_pieces; pi++) {
         const int32_t t = pieces[pi].tid;
         m->piece_prefix[pi] = run;
+        if (block[pi] && block[pi][1] == -1 && block[pi][2] == -1) { m->abort_piece = pi; break; }      /* that piece's walk met a record the reference dies on: nothing behind it is printed by this run */
         if (pieces[pi].first) {
             int fl = INT_MAX;
             for (int32_t i = 0; i < n_live; i++) if (live[i]->start < fl) fl = live[i]->start;
@@ -802,7 +813,7 @@ static void group_park_device(ppipe* P, pgroup* G)
  * device allocation.  Both travel device to device in ONE RCCL send / receive group when every rank has walked what it walks
  * (mg_ship_groups); `aborted` = the walk met a record the reference dies on. */
 #define PKG_MAGIC 0x504b4734
-typedef struct { int32_t magic, aborted, n_ctg, n_fp, n_npp, n_cand, sv_n, longest_read; int64_t n_rec, npp_len, craw_len, sv_bytes; } pkg_head;
+typedef struct { int32_t magic, aborted, n_ctg, n_fp, n_npp, n_cand, sv_n, longest_read, has_range, pad; int64_t n_rec, npp_len, craw_len, sv_bytes; } pkg_head;
 typedef struct { char* blob; size_t blob_len; void* slab; size_t slab_bytes; int aborted, walked; } mg_parcel;     /* a walked group on its way */
 static mg_parcel* g_parcel = NULL;            /* [claims] filled by this rank's walkers for the claims other ranks own */
 
@@ -828,7 +839,7 @@ static void package_pack(int ci, pgroup* G, int aborted)
     memset(&h, 0, sizeof h);
     h.magic = PKG_MAGIC; h.aborted = aborted;
     if (!aborted) {
-        h.n_ctg = G->n_ctg; h.n_fp = G->n_fp; h.n_npp = G->n_npp; h.n_cand = G->n_cand; h.sv_n = G->sv_n; h.longest_read = g_longest_read;
+        h.n_ctg = G->n_ctg; h.n_fp = G->n_fp; h.n_npp = G->n_npp; h.n_cand = G->n_cand; h.sv_n = G->sv_n; h.longest_read = g_longest_read; h.has_range = G->sv_range != NULL;
         h.n_rec = G->n_rec; h.npp_len = G->npp_len; h.craw_len = G->craw_len; h.sv_bytes = G->sv_bytes;
     }
     pkg_put(fp, &h, sizeof h);
@@ -841,6 +852,7 @@ static void package_pack(int ci, pgroup* G, int aborted)
         pkg_put(fp, G->cand_rec, sizeof(int32_t) * (size_t)G->n_cand);
         pkg_put(fp, G->craw_off, sizeof(int64_t) * ((size_t)G->n_cand + (G->n_cand ? 1 : 0)));
         pkg_put(fp, G->craw, (size_t)G->craw_len);
+        if (G->sv_range) pkg_put(fp, G->sv_range, sizeof(int32_t) * (size_t)G->n_cand);
         pc->slab = G->sv[0]; pc->slab_bytes = group_slab_bytes(G->sv_n, G->sv_bytes);
     }
     if (fclose(fp) != 0) fatalf("cannot serialise a walked group");
@@ -869,6 +881,7 @@ static pgroup* package_unpack(driver* d, const char* blob, size_t len, void* sla
     G->cand_rec = xmalloc(sizeof(int32_t) * (size_t)(h.n_cand ? h.n_cand : 1)); pkg_get(fp, G->cand_rec, sizeof(int32_t) * (size_t)h.n_cand);
     G->craw_off = xmalloc(sizeof(int64_t) * ((size_t)h.n_cand + 1)); pkg_get(fp, G->craw_off, sizeof(int64_t) * ((size_t)h.n_cand + (h.n_cand ? 1 : 0)));
     G->craw = xmalloc((size_t)h.craw_len + 1); pkg_get(fp, G->craw, (size_t)h.craw_len);
+    if (h.has_range) { G->sv_range = xmalloc(sizeof(int32_t) * (size_t)(h.n_cand ? h.n_cand : 1)); pkg_get(fp, G->sv_range, sizeof(int32_t) * (size_t)h.n_cand); }
     fclose(fp);
     const size_t n = (size_t)G->sv_n, ns = n * IM_MAX_EV;
     const size_t bytes[10] = { (size_t)G->sv_bytes, 8 * n, 4 * n, 4 * n, 4 * n, 4 * n, 4 * ns, 4 * ns, 4 * ns, 4 * n };
@@ -963,6 +976,114 @@ static int32_t* group_ranges(driver* d, pgroup* G)
         range[j] = record_range(d, &b)[1];
     }
     return range;
+}
+
+/* ONE walk per rank: the log the ranks exchange (mg_exchange_logs) is made of what the walk itself left in the groups -- the counted
+ * reads of every piece, the records of not-proper pairs (kept whole for the pair table: the events are read off them), and, without
+ * a configuration file, the insert-size extrema per read group and the coverage spans the walkers collected on the way.  Same
+ * layout as the pre-walk's log (mg_prewalk); a claim whose walk met a record the reference dies on leaves blocks that say so. */
+static void mg_log_from_groups(mgpu* m, driver* d, walkpool_t* o, int estimate, mgbuf* out)
+{
+    mg_rg* rgs = xcalloc(MG_MAX_RG, sizeof(mg_rg));
+    int n_rg = 0, n_mine = 0;
+    covlist cov;
+    cov_init(&cov, d->hdr->n_targets);
+    mgbuf_take(out, 4 * (MG_HEAD_WORDS + (size_t)MG_MAX_RG * MG_RG_WORDS));
+    for (int ci = 0; ci < o->n_claims; ci++) {
+        if (m->claim_walker[ci] != m->rank) continue;
+        const claim_t* c = &o->claims[ci];
+        pgroup* G = c->G;
+        if (!G) {
+            /* not survived (or never reached behind such a claim): its pieces say so */
+            for (int k = 0; k < c->count; k++) {
+                int32_t* hd = mgbuf_take(out, 20);
+                hd[0] = o->pieces[c->first + k].index; hd[1] = -1; hd[2] = -1;
+                n_mine++;
+            }
+            continue;
+        }
+        if (estimate) {
+            for (int k = 0; k < G->n_rgs; k++) {
+                mg_rg* t = &rgs[mg_rg_index(rgs, &n_rg, G->rgs[k].name)];
+                const rgstat_t* g = &G->rgs[k];
+                if (!t->seen) { t->seen = 1; t->min = g->min; t->max = g->max; t->first_tid = g->first_tid; t->first_rec = g->first_rec; }
+                else {
+                    if (g->min < t->min) t->min = g->min;
+                    if (g->max > t->max) t->max = g->max;
+                    if (g->first_tid < t->first_tid || (g->first_tid == t->first_tid && g->first_rec < t->first_rec)) { t->first_tid = g->first_tid; t->first_rec = g->first_rec; }
+                }
+            }
+            if (G->cov.sum) {
+                cov_close(&G->cov);
+                for (int32_t t = 0; t < cov.nt; t++) cov.sum[t] += G->cov.sum[t];
+                for (int64_t k = 0; k < G->cov.n; k++) cov_push(&cov, G->cov.seg[k]);
+            }
+        }
+        int32_t k = 0;
+        for (int pi = 0; pi < G->n_ctg; pi++) {
+            const gcontig* cg = &G->ctg[pi];
+            const size_t head_at = out->n;
+            { int32_t* hd = mgbuf_take(out, 20); hd[0] = cg->piece; }
+            const size_t ev_at = out->n;
+            int32_t n_ev = 0;
+            for (; k < G->n_npp && G->npp_rec[k] <= cg->rec1; k++) {
+                bam_record b;
+                bam_record_view(G->npp_raw + G->npp_off[k], (int32_t)(G->npp_off[k + 1] - G->npp_off[k]), &b);
+                /* what src/indelminer.c:516-522 asks of a record apart from |isize| > range[1], which waits for the final table */
+                if (!(((b.flag & 0x10) != 0) != ((b.flag & 0x20) != 0) && (uint32_t)abs(b.isize) < O.maxpedelsize)) continue;
+                const uint8_t* rg = bam_aux_find(&b, "RG");
+                const int gi = mg_rg_index(rgs, &n_rg, rg ? bam_aux_str(rg) : "generic");
+                const size_t nl = (size_t)b.l_qname;
+                int32_t* ev = mgbuf_take(out, 16 + ((nl + 3) & ~(size_t)3));
+                ev[0] = b.pos; ev[1] = abs(b.isize); ev[2] = (int32_t)(G->npp_rec[k] - cg->rec0);
+                ev[3] = (b.pos < b.mpos ? 1 : 0) | (gi << 8) | ((int32_t)nl << 16);
+                memcpy(ev + 4, BAMR_QNAME(&b), nl);
+                n_ev++;
+            }
+            int32_t* hd = (int32_t*)(out->p + head_at);
+            const int64_t counted = cg->cn1 - cg->cn0;
+            hd[1] = (int32_t)(counted & 0xffffffff); hd[2] = (int32_t)(counted >> 32); hd[3] = n_ev; hd[4] = (int32_t)(out->n - ev_at);
+            n_mine++;
+        }
+    }
+    {
+        const int32_t ntg = d->hdr->n_targets;
+        int32_t* cw = mgbuf_take(out, 4 * (1 + 2 * (size_t)ntg + 3 * (size_t)cov.n));
+        cw[0] = (int32_t)cov.n;
+        for (int32_t t = 0; t < ntg; t++) { cw[1 + 2 * t] = (int32_t)(uint32_t)cov.sum[t]; cw[2 + 2 * t] = (int32_t)(uint32_t)(cov.sum[t] >> 32); }
+        int32_t* sg = cw + 1 + 2 * (size_t)ntg;
+        for (int64_t k = 0; k < cov.n; k++) { *sg++ = cov.seg[k].tid; *sg++ = cov.seg[k].beg; *sg++ = cov.seg[k].end; }
+        cov_free(&cov);
+    }
+    int32_t* w = (int32_t*)out->p;
+    w[0] = MG_MAGIC; w[1] = n_rg; w[2] = n_mine; w[3] = (int32_t)(out->n & 0xffffffff); w[4] = (int32_t)((uint64_t)out->n >> 32);
+    for (int k = 0; k < n_rg; k++) {
+        int32_t* g = w + MG_HEAD_WORDS + (size_t)k * MG_RG_WORDS;
+        memcpy(g, rgs[k].name, 48);
+        g[12] = rgs[k].min; g[13] = rgs[k].max; g[14] = rgs[k].first_tid; g[15] = (int32_t)(rgs[k].first_rec >> 32); g[16] = rgs[k].seen; g[17] = (int32_t)(uint32_t)rgs[k].first_rec;
+    }
+    free(rgs);
+}
+
+/* what every rank does with the exchanged logs before it stages anything */
+static void mg_after_logs(mgpu* m, driver* d)
+{
+    if (m->cross) {
+        /* A first mate left waiting in one contig meets a record of the same name in a later one: the reference's one
+         * pair table pairs them across contigs (readpairs is never reset, src/indelminer.c), so the contigs of this
+         * input are not independent.  Every rank sees that in the exchanged logs; the run goes to ONE process that
+         * serves one table record by record, the other ranks have nothing to add. */
+        if (m->rank != 0) { im_comm_destroy(m->comm); fflush(stderr); _exit(EXIT_SUCCESS); }
+        fprintf(stderr, "indelminer: read names are shared between contigs (pairs across contigs in the one pair table): one process takes the run\n");
+        mg_discard_dir(m);
+        mg_restore_stdout(m);
+        handoff_to_host_child();
+    }
+    if (O.configfile == NULL && m->rank == 0) {
+        fprintf(stderr, "\nRead-group\tMin-value\tMax-value (estimated over all ranks' contigs)\n");
+        for (int j = 0; j < g_rg_n; j++) fprintf(stderr, "%s\t%d\t%d\n", g_rg_name[j], g_rg_range[j][0], g_rg_range[j][1]);
+        cov_print_table(d->hdr);
+    }
 }
 
 /* the driver's pair table, emptied (a contig begins: what earlier contigs left waiting reaches it as the marker floor, not as entries) */

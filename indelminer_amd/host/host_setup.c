@@ -42,6 +42,17 @@ static void print_output_header(void)
  * insert-length table has been made (run_pipeline). */
 static int g_header_held;
 
+/* the output header (src/indelminer.c:745-754); multi-GPU: rank 0 prints it, as the first part */
+static void header_out(void)
+{
+    if (g_mg_rank > 0) return;
+    if (g_mg_header_path[0] && !freopen(g_mg_header_path, "w", stdout)) fatalf("cannot write %s", g_mg_header_path);
+    print_output_header();
+    fflush(stdout);
+    /* the header part is complete; whatever a library prints on stdout from here on (librccl's banner) is not VCF */
+    if (g_mg_header_path[0] && !freopen("/dev/stderr", "w", stdout)) { }
+}
+
 /* every GPU call site passes through here first */
 static void gpu_wait(driver* d)
 {
@@ -52,13 +63,8 @@ static void gpu_wait(driver* d)
     phase_time("GPU context + reference upload (helper thread, joined)");
     /* the output header (src/indelminer.c:745-754) goes out only once the GPU is known to be there:
      * nothing is printed by a run that cannot compute */
-    if (g_mg_rank > 0) return;                          /* multi-GPU: rank 0 prints the header */
     if (g_header_held) return;
-    if (g_mg_header_path[0] && !freopen(g_mg_header_path, "w", stdout)) fatalf("cannot write %s", g_mg_header_path);   /* ... as the first part */
-    print_output_header();
-    fflush(stdout);
-    /* the header part is complete; whatever a library prints on stdout from here on (librccl's banner) is not VCF */
-    if (g_mg_header_path[0] && !freopen("/dev/stderr", "w", stdout)) { }
+    header_out();
 }
 
 /* ------------------------------------------------------ config / estimates -- */
@@ -382,6 +388,7 @@ typedef struct {
     uint8_t* skip;              /* [n_targets] annotate mode: contigs without known variants are not walked at all */
     int      abort_tid;         /* -1, or the first contig of this rank that holds a record the reference dies on */
     int      cross;             /* the exchanged pair-table logs show entries of one contig meeting records of another */
+    int      abort_piece;       /* the first piece (plan index) whose walk some rank did not survive; the number of pieces: none */
 } mgpu;
 
 static mgpu* g_mg = NULL;

@@ -203,7 +203,6 @@ static void* walker_thread(void* arg)
             W->cur_claim = c;
             if (setjmp(W->abort_jmp)) {
                 const int cj = (int)(W->cur_claim - o->claims);
-                if (g_mg && (g_mg->claim_owner[cj] != g_mg->rank || g_mg_self_ship)) package_pack(cj, NULL, 1);      /* its owner hands the run over */
                 pthread_mutex_lock(&o->mu);
                 W->cur_claim->G = NULL; W->cur_claim->aborted = 1; W->cur_claim->walked = 1;
                 pthread_cond_broadcast(&o->cv);
@@ -215,12 +214,8 @@ static void* walker_thread(void* arg)
         pgroup* G = walk_claim(W, o, c);
         t_abort_jmp = NULL;
         if (g_onepass && g_spec_active && !G->sv_range) G->sv_range = group_ranges(&W->wd, G);    /* the provisional table is there: this candidate's range[1] now */
-        if (g_mg) { int64_t nr = 0; group_flush_points(G, &nr); G->from_package = 1; }      /* the counter in front of every piece is known (mg_exchange) */
-        if (ship) {
-            package_pack(ci, G, 0);         /* the host part as one block; the device arrays stay parked until the ranks exchange (mg_ship_groups) */
-            group_free(G); free(G);
-            G = NULL;
-        }
+        if (g_mg && o->serial) { int64_t nr = 0; group_flush_points(G, &nr); G->from_package = 1; }      /* annotate mode: the counter in front of every piece is known (mg_exchange) */
+        (void)ship;
         pthread_mutex_lock(&o->mu);
         c->G = G; c->walked = 1;
         pthread_cond_broadcast(&o->cv);
@@ -235,6 +230,7 @@ static void* apply_thread(void* arg)
     apply_job* j = arg;
     for (int ci = j->first; ci < j->o->n_claims; ci += j->step) {
         pgroup* G = j->o->claims[ci].G;
+        if (!G) continue;                   /* several ranks: another rank's walk, or a walk that was not survived */
         G->sv_range = group_ranges(&j->rd, G);
     }
     return NULL;
@@ -556,7 +552,72 @@ static void run_pipeline(driver* d, walkpool_t* o)
     spec_t spec;
     memset(&spec, 0, sizeof spec);
     int speculate = 0, spec_first = 0;
-    if (g_onepass) {
+    int32_t mg_abort_tid = INT_MAX;         /* several ranks: the first contig some rank's WALK met a record the reference dies on -- all ranks know */
+    if (g_mg && !o->serial) {
+        /* ONE walk per rank.  Every rank walks the pieces the plan gives it -- without insert lengths when there is no config file
+         * (which records are candidates does not depend on them), collecting what the estimate needs as it goes -- and the ranks
+         * then exchange what their walks logged, in ONE all-gather: from it every rank makes the same insert-length table, read-counter
+         * prefixes and marker floors a single process would have (mg_exchange_logs).  The BAM is inflated once. */
+        for (int i = 0; i < o->nw; i++) pthread_join(o->w[i].th, NULL);
+        phase_time("the walk of this rank's pieces (inflate + count; triage on the device)");
+        const int estimate = O.configfile == NULL;
+        mgbuf mine = { NULL, 0, 0 };
+        mg_log_from_groups(g_mg, d, o, estimate, &mine);
+        mg_exchange_logs(g_mg, d, estimate, mine, o->pieces, o->n_pieces, g_mg->piece_walker);
+        phase_time("the ranks' walk logs exchanged (one all-gather) and merged");
+        if (estimate && g_mg->abort_piece < o->n_pieces && !getenv("INDELMINER_NO_HANDOFF")) {
+            /* a walk was not survived and the insert lengths were to come from the walks: the table would miss that piece's pairs.
+             * Nothing is out yet, not even the header -- one record-at-a-time process takes the whole run, as in a single-process
+             * one-pass run (the reference would have finished its estimation pass and died in its walk) */
+            if (g_mg->rank != 0) { im_comm_destroy(g_mg->comm); fflush(stderr); _exit(EXIT_SUCCESS); }
+            mg_discard_dir(g_mg);
+            mg_restore_stdout(g_mg);
+            handoff_to_host_child();
+        }
+        mg_after_logs(g_mg, d);
+        if (g_mg->abort_piece < o->n_pieces) mg_abort_tid = o->pieces[g_mg->abort_piece].tid;
+        if (g_header_held) { g_header_held = 0; header_out(); }
+        if (estimate) {
+            /* fetch_func looks the read group of every counted read up: a group the table does not know ends the reference at that
+             * read -- the claim counts as one whose walk was not survived (the record-at-a-time child finds the read) */
+            for (int ci = 0; ci < o->n_claims; ci++) {
+                pgroup* G = o->claims[ci].G;
+                for (int k = 0; G && k < G->n_crg; k++)
+                    if (!qhash_lookup(d->insertlengths, G->crg[k], (int)strlen(G->crg[k]))) { o->claims[ci].aborted = 1; o->claims[ci].G = NULL; break; }
+            }
+            pipe_global_init(d);
+            /* every walked group's candidates get their range[1], the groups spread over threads */
+            int nt = o->nw > 1 ? o->nw : 1;
+            if (nt > o->n_claims) nt = o->n_claims ? o->n_claims : 1;
+            apply_job* aj = xcalloc((size_t)nt, sizeof(apply_job));
+            for (int i = 0; i < nt; i++) {
+                aj[i].o = o; aj[i].first = i; aj[i].step = nt; aj[i].rd = *d;
+                aj[i].rd.rg_last_val = NULL; aj[i].rd.rg_last_name[0] = 0; aj[i].rd.gpu_pending = 0;
+                if (pthread_create(&aj[i].th, NULL, apply_thread, &aj[i]) != 0) fatalf("cannot start a thread");
+            }
+            for (int i = 0; i < nt; i++) pthread_join(aj[i].th, NULL);
+            free(aj);
+            phase_time("insert lengths applied: candidates' ranges");
+        }
+        /* the flush points of every walked group (the read counter in front of each piece is known now), and the groups walked
+         * for other ranks' contigs made ready for the trip */
+        for (int ci = 0; ci < o->n_claims; ci++) {
+            if (g_mg->claim_walker[ci] != g_mg->rank) continue;
+            claim_t* c = &o->claims[ci];
+            const int ship = g_mg->claim_owner[ci] != g_mg->rank || g_mg_self_ship;
+            if (!c->G) { if (ship) package_pack(ci, NULL, 1); continue; }
+            if (o->pieces[c->first].tid >= mg_abort_tid) continue;      /* nobody stages it */
+            int64_t nr = 0;
+            group_flush_points(c->G, &nr);
+            c->G->from_package = 1;
+            if (ship) {
+                package_pack(ci, c->G, 0);      /* the host part as one block; the device arrays stay parked until mg_ship_groups */
+                group_free(c->G); free(c->G);
+                c->G = NULL;
+            }
+        }
+    }
+    if (g_onepass && !g_mg) {
         const char* sp = getenv("INDELMINER_SPECULATE");
         /* Worth it, and likely to hold, on large inputs only: the largest proper-pair insert size is the aligner's cut-off, which a
          * library of hundreds of millions of pairs meets within its first per cent, a small one perhaps never in its first
@@ -631,18 +692,15 @@ static void run_pipeline(driver* d, walkpool_t* o)
     struct { pgroup** held; int n_held; pgroup* chain; } *late = (g_mg && g_mg->split) ? xcalloc((size_t)(o->n_claims ? o->n_claims : 1), sizeof *late) : NULL;
     volatile int n_late = 0;                /* read behind a longjmp (g_mg_split_abort) */
     pgroup** arrived = NULL;                /* multi-GPU, pieces over several ranks: the groups other ranks walked for this rank's contigs */
-    int32_t mg_abort_tid = INT_MAX;         /* ... and the first contig some rank's WALK met a record the reference dies on: all ranks know */
     if (late) {
-        /* Every rank walks what it walks, then ONE exchange: what each claim's walk left (all-gather), and the walked groups to
-         * their contigs' owners device to device (one RCCL send / receive group).  Staging follows, in file order. */
-        for (int i = 0; i < o->nw && !o->serial; i++) pthread_join(o->w[i].th, NULL);
-        phase_time("the walk of this rank's pieces (inflate + count; triage on the device)");
+        /* ONE exchange: what each claim's walk left (all-gather), and the walked groups to their contigs' owners device to device
+         * (one RCCL send / receive group).  Staging follows, in file order. */
         uint8_t* wab = xcalloc((size_t)(o->n_claims ? o->n_claims : 1), 1);
         for (int ci = 0; ci < o->n_claims; ci++) wab[ci] = (uint8_t)(o->claims[ci].aborted != 0);
         arrived = xcalloc((size_t)(o->n_claims ? o->n_claims : 1), sizeof(pgroup*));
         const int fa = mg_ship_groups(g_mg, d, o->n_claims, wab, arrived);
         free(wab);
-        if (fa < o->n_claims) mg_abort_tid = o->pieces[o->claims[fa].first].tid;
+        if (fa < o->n_claims && o->pieces[o->claims[fa].first].tid < mg_abort_tid) mg_abort_tid = o->pieces[o->claims[fa].first].tid;
         phase_time("walked groups exchanged between the ranks (RCCL send / receive)");
         /* a record the reference dies on, met while this rank stages: the rank stops staging there but still joins the sum of
          * the depth arrays below -- the other ranks are on their way into it (pipeline_handoff jumps here) */
@@ -653,7 +711,10 @@ static void run_pipeline(driver* d, walkpool_t* o)
         claim_t* c = &o->claims[ci];
         if (g_mg && g_mg->claim_owner[ci] != g_mg->rank) continue;        /* another rank's contig */
         g_mg_cur_tid = o->pieces[c->first].tid;
-        if (late && g_mg_cur_tid >= mg_abort_tid) { g_mg->abort_tid = mg_abort_tid; break; }      /* every rank stops in front of that contig */
+        if (g_mg && g_mg_cur_tid >= mg_abort_tid) {      /* every rank stops in front of that contig */
+            if (late) { g_mg->abort_tid = mg_abort_tid; break; }
+            pipeline_handoff();                          /* contigs walked by their owners: the rank reports and is done (no collective follows) */
+        }
         if (g_mg && (g_mg->claim_walker[ci] != g_mg->rank || (g_mg_self_ship && !o->serial))) {
             c->G = arrived[ci];
             c->walked = 1; c->aborted = c->G == NULL;
@@ -816,7 +877,7 @@ claims_done:
     free(o->jobs); o->jobs = NULL; free(held); free(dead);
     d->numread = numread;
     if (g_handoff_pool) { g_handoff_pool = NULL; if (t_out) { fflush(t_out); fclose(t_out); t_out = NULL; } }
-    for (int i = 0; i < o->nw && !o->serial && !g_onepass && !(g_mg && g_mg->split); i++) pthread_join(o->w[i].th, NULL);      /* one pass: joined above */
+    for (int i = 0; i < o->nw && !o->serial && !g_onepass && !g_mg; i++) pthread_join(o->w[i].th, NULL);      /* one pass, several ranks: joined above */
     /* the walkers' pinned rings and device arrays go with the process unless a tidy exit is asked for (leak checkers):
      * un-pinning and freeing them costs more than the whole device stage of a run */
     if (getenv("INDELMINER_TIDY_EXIT")) {
