@@ -123,6 +123,13 @@ static void mg_rendezvous(mgpu* m, driver* d)
     if (m->rank == 0) {
         /* no fork() here: the GPU helper thread is inside the HIP runtime's start-up */
         if (mkdir(m->dir, 0700) != 0 && errno != EEXIST) fatalf("cannot create the rendezvous directory %s", m->dir);
+        {
+            /* a directory that was already there must be this user's own and nobody else's to write (a predictable name under
+             * /tmp: somebody else may have made it, or a link of that name) -- the ranks trust what they find in it */
+            struct stat sb;
+            if (lstat(m->dir, &sb) != 0 || !S_ISDIR(sb.st_mode) || sb.st_uid != getuid() || (sb.st_mode & (S_IWGRP | S_IWOTH)))
+                fatalf("the rendezvous directory %s is not a directory of this user's alone", m->dir);
+        }
         unlink(path);
         {   /* whatever an earlier run left behind: parts, flags, logs */
             DIR* dp = opendir(m->dir);
@@ -172,6 +179,11 @@ static void* mg_comm_bringup(void* arg)
         const double t_end = now_ms() + 120e3;
         for (;;) {
             /* an id file that does not carry this run's token is somebody else's (an earlier run in a re-used directory) */
+            {
+                struct stat sb;
+                if (lstat(m->dir, &sb) == 0 && (!S_ISDIR(sb.st_mode) || sb.st_uid != getuid() || (sb.st_mode & (S_IWGRP | S_IWOTH))))
+                    fatalf("the rendezvous directory %s is not a directory of this user's alone", m->dir);
+            }
             char seen[sizeof token];
             FILE* fp = fopen(path, "rb");
             if (fp) {

@@ -181,7 +181,7 @@ static inline __attribute__((always_inline)) int64_t inflate_stream(const uint8_
             TAKE(14);
             if (hlit > 286u || hdist > 30u) return -1;
             uint8_t pl[19] = { 0 };
-            for (unsigned i = 0; i < hclen; i++) { if (bc < 3) REFILL(); pl[kPreOrder[i]] = (uint8_t)(bb & 7u); TAKE(3); }
+            for (unsigned i = 0; i < hclen; i++) { if (bc < 3) { if (ip > in_end + 8) return -1; REFILL(); } pl[kPreOrder[i]] = (uint8_t)(bb & 7u); TAKE(3); }
             if (build(T.pre, 128, 7, pl, 19, 0, T.sorted)) return -1;
             unsigned n = 0;
             while (n < hlit + hdist) {
