@@ -480,6 +480,11 @@ int im_depth_scan(im_ctx* ctx, int32_t tid, void* stream);
 /* contig tid's run back to zeros (asynchronous): a contig that is to go through triage + im_depth_scan AGAIN */
 int im_depth_reset(im_ctx* ctx, int32_t tid, void* stream);
 int im_depth_query_tid(im_ctx* ctx, int32_t tid, int32_t n, const int32_t* beg, const int32_t* end, uint32_t* sum_out);
+/* the same, and per query the DEEPEST position of [beg - 1, end] (max_out, may be NULL).  The depth array counts every record; samtools'
+ * pileup, which the reference's DP= comes from (src/shared.c:178-212), stops buffering records that start at the position it stands on
+ * once 8000 are buffered (src/samtools-0.1.19/bam_pileup.c:172,244): the host driver asks the file, with that rule, about the queries
+ * whose maximum says the rule may have applied. */
+int im_depth_query_max_tid(im_ctx* ctx, int32_t tid, int32_t n, const int32_t* beg, const int32_t* end, uint32_t* sum_out, uint32_t* max_out);
 /* Multi-GPU, pieces of one contig walked by several ranks: every rank's difference array holds the +-1 of the records IT
  * delivered; their sum (one RCCL all-reduce over the whole array, before any im_depth_scan) is the single run's array.  The
  * reference has no counterpart (calculate_cov_params re-reads the file per variant, src/shared.c:178-212).  Synchronous. */

@@ -522,23 +522,30 @@ int im_depth_allreduce(im_ctx* ctx, im_comm* comm)
     return IM_OK;
 }
 
-int im_depth_query_tid(im_ctx* ctx, int32_t tid, int32_t n, const int32_t* beg, const int32_t* end, uint32_t* sum_out)
+int im_depth_query_max_tid(im_ctx* ctx, int32_t tid, int32_t n, const int32_t* beg, const int32_t* end, uint32_t* sum_out, uint32_t* max_out)
 {
     if (!ctx || n < 0 || !ctx->gdepth || tid < 0 || tid >= ctx->n_contigs) return IM_E_ARG;
     if (n == 0) return IM_OK;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     const size_t sb = up256(sizeof(int32_t) * (size_t)n);
-    int rc = ensure_ws(ctx, 3 * sb);
+    int rc = ensure_ws(ctx, 4 * sb);
     if (rc) return rc;
     int32_t* d_beg = (int32_t*)ctx->ws;
     int32_t* d_end = (int32_t*)((char*)ctx->ws + sb);
     uint32_t* d_out = (uint32_t*)((char*)ctx->ws + 2 * sb);
+    uint32_t* d_max = max_out ? (uint32_t*)((char*)ctx->ws + 3 * sb) : nullptr;
     HIP_TRY(ctx, hipMemcpyAsync(d_beg, beg, sizeof(int32_t) * (size_t)n, hipMemcpyHostToDevice, ctx->stream));
     HIP_TRY(ctx, hipMemcpyAsync(d_end, end, sizeof(int32_t) * (size_t)n, hipMemcpyHostToDevice, ctx->stream));
-    HIP_TRY(ctx, im::launch_depth_query_tiled(n, d_beg, d_end, ctx->gdepth + ctx->h_asc_off[tid], ctx->gdepth_sums + ctx->h_sums_off[tid], ctx->h_len[tid], d_out, ctx->stream));
+    HIP_TRY(ctx, im::launch_depth_query_tiled(n, d_beg, d_end, ctx->gdepth + ctx->h_asc_off[tid], ctx->gdepth_sums + ctx->h_sums_off[tid], ctx->h_len[tid], d_out, d_max, ctx->stream));
     HIP_TRY(ctx, hipMemcpyAsync(sum_out, d_out, sizeof(uint32_t) * (size_t)n, hipMemcpyDeviceToHost, ctx->stream));
+    if (max_out) HIP_TRY(ctx, hipMemcpyAsync(max_out, d_max, sizeof(uint32_t) * (size_t)n, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     return IM_OK;
+}
+
+int im_depth_query_tid(im_ctx* ctx, int32_t tid, int32_t n, const int32_t* beg, const int32_t* end, uint32_t* sum_out)
+{
+    return im_depth_query_max_tid(ctx, tid, n, beg, end, sum_out, nullptr);
 }
 
 // Host-buffer entry point.  The batch is cut into chunks that travel through a two-slot pipeline: chunk c is

@@ -122,7 +122,7 @@ __global__ __launch_bounds__(kScanBlock) void depth_scan_tiled_kernel(int32_t* _
 
 __global__ __launch_bounds__(256) void depth_query_tiled_kernel(int32_t nq, const int32_t* __restrict__ beg, const int32_t* __restrict__ end,
                                                                const int32_t* __restrict__ depth, const int32_t* __restrict__ sums,
-                                                               int64_t clen, uint32_t* __restrict__ out)
+                                                               int64_t clen, uint32_t* __restrict__ out, uint32_t* __restrict__ out_max)
 {
     const int lane = threadIdx.x & 63;
     const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
@@ -131,11 +131,17 @@ __global__ __launch_bounds__(256) void depth_query_tiled_kernel(int32_t nq, cons
         int64_t a = beg[q], b = end[q];
         if (a < 0) a = 0;
         if (b > clen) b = clen;
-        uint32_t s = 0;
-        for (int64_t p = a + lane; p < b; p += 64) s += (uint32_t)(depth[p] + sums[p / kScanTile]);
+        // out_max: the deepest position of [beg - 1, end] (the host asks the file about loci deep enough for samtools' pileup cap)
+        const int64_t a1 = out_max && a > 0 ? a - 1 : a, b1 = out_max && b < clen ? b + 1 : b;
+        uint32_t s = 0, mx = 0;
+        for (int64_t p = a1 + lane; p < b1; p += 64) {
+            const uint32_t v = (uint32_t)(depth[p] + sums[p / kScanTile]);
+            if (p >= a && p < b) s += v;
+            mx = max(mx, v);
+        }
 #pragma unroll
-        for (int o = 32; o > 0; o >>= 1) s += (uint32_t)__shfl_xor((int)s, o);
-        if (lane == 0) out[q] = s;
+        for (int o = 32; o > 0; o >>= 1) { s += (uint32_t)__shfl_xor((int)s, o); mx = max(mx, (uint32_t)__shfl_xor((int)mx, o)); }
+        if (lane == 0) { out[q] = s; if (out_max) out_max[q] = mx; }
     }
 }
 
@@ -232,12 +238,12 @@ hipError_t launch_depth_scan_tiled(int32_t* depth, int64_t n, int32_t* sums, hip
 }
 
 hipError_t launch_depth_query_tiled(int32_t nq, const int32_t* beg, const int32_t* end, const int32_t* depth, const int32_t* sums,
-                                    int64_t clen, uint32_t* out, hipStream_t stream)
+                                    int64_t clen, uint32_t* out, uint32_t* out_max, hipStream_t stream)
 {
     if (nq <= 0) return hipSuccess;
     int b = (nq + 3) / 4;
     if (b > 2048) b = 2048;
-    hipLaunchKernelGGL(depth_query_tiled_kernel, dim3(b), dim3(256), 0, stream, nq, beg, end, depth, sums, clen, out);
+    hipLaunchKernelGGL(depth_query_tiled_kernel, dim3(b), dim3(256), 0, stream, nq, beg, end, depth, sums, clen, out, out_max);
     return hipGetLastError();
 }
 

@@ -76,7 +76,7 @@ hipError_t launch_flush_groupby(int32_t n_slots_layout, int32_t n_fl_layout, con
 hipError_t launch_depth_scan(int32_t* depth, int64_t n, int32_t* sums, hipStream_t stream);
 hipError_t launch_depth_scan_tiled(int32_t* depth, int64_t n, int32_t* sums, hipStream_t stream);
 hipError_t launch_depth_query_tiled(int32_t nq, const int32_t* beg, const int32_t* end, const int32_t* depth, const int32_t* sums,
-                                    int64_t clen, uint32_t* out, hipStream_t stream);
+                                    int64_t clen, uint32_t* out, uint32_t* out_max, hipStream_t stream);
 
 // launchers (im_realign.hip / im_cluster.hip)
 hipError_t launch_pack_reference(const uint8_t* ascii, uint64_t* pk, int64_t n_bases_padded,

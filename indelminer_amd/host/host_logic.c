@@ -805,6 +805,12 @@ static void merge_variants(variant_list* pvs, const char* reference, int64_t ref
 }
 
 /* ---- region depth, calculate_cov_params (src/shared.c:178-212) ---- */
+/* Loci at which samtools' pileup, the reference's source of DP= (src/shared.c:178-212), may have stopped taking records: a record
+ * is left out when it starts at the position the iterator stands on and more than 8000 nodes are allocated
+ * (src/samtools-0.1.19/bam_pileup.c:172,244).  The device's depth array counts every record, so a query whose deepest position
+ * reaches this bound is answered from the file with that rule (region_depth_from_bam). */
+#define DP_DEEP_LOCUS 4000
+
 static uint32_t region_depth_from_bam(driver* d, int32_t tid, int32_t start, int32_t stop);
 
 static uint32_t region_depth(driver* d, int32_t tid, int32_t start, int32_t stop)
@@ -815,10 +821,12 @@ static uint32_t region_depth(driver* d, int32_t tid, int32_t start, int32_t stop
         uint32_t sum = 0;
         gpu_wait(d);
         pthread_mutex_lock(&g_query_mu);
-        const int qrc = d->pipe_mode ? im_depth_query_tid(d->gpu, tid, 1, &start, &stop, &sum) : im_depth_query(d->gpu, 1, &start, &stop, &sum);
+        uint32_t deepest = 0;
+        const int qrc = d->pipe_mode ? im_depth_query_max_tid(d->gpu, tid, 1, &start, &stop, &sum, &deepest) : im_depth_query(d->gpu, 1, &start, &stop, &sum);
         pthread_mutex_unlock(&g_query_mu);
         if (qrc != IM_OK)
             fatalf("im_depth_query: %s", im_last_error(d->gpu));
+        if (deepest >= DP_DEEP_LOCUS) return region_depth_from_bam(d, tid, start, stop);      /* the pileup's cap may have applied */
         return (uint32_t)floor(sum * 1.0 / (uint32_t)(stop - start));
     }
     /* region runs (-c): the reference pileups the whole BAM around the variant, which can reach
@@ -829,7 +837,11 @@ static uint32_t region_depth(driver* d, int32_t tid, int32_t start, int32_t stop
 static uint32_t region_depth_from_bam(driver* d, int32_t tid, int32_t start, int32_t stop)
 {
     /* pileup semantics (bam_pileup.c:67-143,238-265): records with flag & (0x4|0x100|0x200|0x400)
-     * or tid < 0 are skipped; a position counts a read iff its covering op is M/=/X */
+     * or tid < 0 are skipped; a position counts a read iff its covering op is M/=/X.
+     * The iterator's buffer, restated: after a record starting at p has been taken, every position in front of p has been
+     * served and the records that ended there are gone -- the buffer holds the taken records with end >= p.  The next record
+     * is refused iff it starts at that same p and the pool counts more than 8000 nodes (the buffered records + the list's open
+     * tail node + the dummy node, bam_pileup.c:164-166,201): its bases are not counted anywhere. */
     if (stop <= start) return 0;
     uint32_t* cov = xcalloc((size_t)(stop - start), sizeof(uint32_t));
     bgzf_reader* r = bgzf_open(d->bam_name);
@@ -837,9 +849,13 @@ static uint32_t region_depth_from_bam(driver* d, int32_t tid, int32_t start, int
     bam_header* h = bam_header_load(r);
     bam_region_iter it;
     bam_record b; memset(&b, 0, sizeof b);
+    int32_t* heap = NULL; int64_t nh = 0, caph = 0;          /* ends of the buffered records, smallest on top */
+    int32_t it_tid = 0, it_pos = 0;                          /* where the iterator stands (calloc'ed: contig 0, position 0) */
     if (h && bam_region_begin(&it, r, d->idx, tid, start, stop) == 0) {
         while (bam_region_next(&it, &b) == 1) {
             if (b.tid < 0 || (b.flag & (0x4 | 0x100 | 0x200 | 0x400))) continue;
+            if (it_tid == b.tid && it_pos == b.pos && nh + 2 > 8000) continue;          /* bam_plp_push: not taken */
+            const int32_t rend = bam_record_end(&b);
             const uint8_t* cig = BAMR_CIGAR(&b);
             int32_t x = b.pos;
             for (int k = 0; k < b.n_cigar; k++) {
@@ -850,8 +866,30 @@ static uint32_t region_depth_from_bam(driver* d, int32_t tid, int32_t start, int
                     x += len;
                 } else if (op == OP_D || op == OP_N) x += len;
             }
+            /* the node stays in the list when the record reaches beyond the iterator's position (bam_pileup.c:260-263) */
+            if (rend > it_pos || b.tid > it_tid) {
+                if (nh == caph) { caph = caph ? caph * 2 : 1024; heap = xrealloc(heap, sizeof(int32_t) * (size_t)caph); }
+                int64_t i = nh++;
+                while (i > 0 && heap[(i - 1) / 2] > rend) { heap[i] = heap[(i - 1) / 2]; i = (i - 1) / 2; }
+                heap[i] = rend;
+            }
+            /* bam_plbuf_push drains: every position in front of this record's start is served, what ended there leaves */
+            if (b.tid > it_tid || b.pos > it_pos) { it_tid = b.tid; it_pos = b.pos; }
+            while (nh > 0 && heap[0] < it_pos) {
+                const int32_t last = heap[--nh];
+                int64_t i = 0;
+                for (;;) {
+                    int64_t c = 2 * i + 1;
+                    if (c >= nh) break;
+                    if (c + 1 < nh && heap[c + 1] < heap[c]) c++;
+                    if (heap[c] >= last) break;
+                    heap[i] = heap[c]; i = c;
+                }
+                if (nh > 0) heap[i] = last;
+            }
         }
     }
+    free(heap);
     free(b.data);
     bam_header_free(h);
     bgzf_close(r);
@@ -1131,6 +1169,7 @@ static void print_variants(driver* d, variant_list* vs)
         int32_t* beg = xmalloc(sizeof(int32_t) * (size_t)out.n);
         int32_t* end = xmalloc(sizeof(int32_t) * (size_t)out.n);
         uint32_t* sum = xmalloc(sizeof(uint32_t) * (size_t)out.n);
+        uint32_t* deepest = xmalloc(sizeof(uint32_t) * (size_t)out.n);
         int* who = xmalloc(sizeof(int) * (size_t)out.n);
         int m = 0;
         for (int i = 0; i < out.n; i++) {
@@ -1144,17 +1183,19 @@ static void print_variants(driver* d, variant_list* vs)
         if (m > 0) {
             gpu_wait(d);
             pthread_mutex_lock(&g_query_mu);
-            const int qrc = d->pipe_mode ? im_depth_query_tid(d->gpu, d->depth_tid, m, beg, end, sum) : im_depth_query(d->gpu, m, beg, end, sum);
+            for (int q = 0; q < m; q++) deepest[q] = 0;
+            const int qrc = d->pipe_mode ? im_depth_query_max_tid(d->gpu, d->depth_tid, m, beg, end, sum, deepest) : im_depth_query(d->gpu, m, beg, end, sum);
             pthread_mutex_unlock(&g_query_mu);
             if (qrc != IM_OK)
                 fatalf("im_depth_query: %s", im_last_error(d->gpu));
             for (int q = 0; q < m; q++) {
                 variant_t* v = out.v[who[q]];
-                v->dp_cached = (int32_t)(uint32_t)floor(sum[q] * 1.0 / (uint32_t)(end[q] - beg[q]));
+                v->dp_cached = deepest[q] >= DP_DEEP_LOCUS ? (int32_t)region_depth_from_bam(d, d->depth_tid, beg[q], end[q])      /* the pileup's cap may have applied */
+                                                           : (int32_t)(uint32_t)floor(sum[q] * 1.0 / (uint32_t)(end[q] - beg[q]));
                 v->dp_valid = 1;
             }
         }
-        free(beg); free(end); free(sum); free(who);
+        free(beg); free(end); free(sum); free(deepest); free(who);
     }
     /* ... and out they go */
     for (int i = 0; i < out.n; i++) emit_variant(d, out.v[i]);

@@ -5,6 +5,7 @@
 
   python tests/golden/make_golden_large.py config3        # 8 x 6.25 Mb, 30x, 15 M reads (~5 min of reference time)
   python tests/golden/make_golden_large.py config4like    # 24 contigs, human-like length spread, > 2^31 reference bytes, low coverage
+  python tests/golden/make_golden_large.py config5        # tumour + normal, 8 x 6.25 Mb each, discovery then annotate mode (~25 min of reference time)
 """
 import hashlib
 import json
@@ -32,6 +33,60 @@ LARGE = {
 }
 
 
+# BASELINE configs[4]: tumour / normal at the size of configs[2] -- the normal is the donor genome with its germline indels, the tumour
+# the same genome (same seed: same germline events) read with another read stream and with somatic indels on top, one per ~50 kb
+TN = {
+    "normal": dict(seed=4, ref_len=6_250_000, coverage=30, n_contigs=8),
+    "tumor": dict(seed=4, ref_len=6_250_000, coverage=30, n_contigs=8, read_seed=55, somatic_spacing=50_000),
+}
+
+
+def materialise_tn(td):
+    """ref.fa, tumor_aln.bam, normal_aln.bam (+ indexes) and cfg.txt into td; returns (tumour reads, normal reads)"""
+    n = {}
+    for who in ("tumor", "normal"):
+        refs, rd = synth.simulate(**TN[who])
+        contigs = [("ctg%d" % i, len(r)) for i, r in enumerate(refs)]
+        if who == "tumor":
+            bamwrite.write_fasta(os.path.join(td, "ref.fa"), contigs, refs)
+        rawrec.write_bam_fast(os.path.join(td, "%s_aln.bam" % who), contigs, rd)
+        n[who] = int(rd.n)
+        rmax = int(rd.range_max)
+        del refs, rd
+    open(os.path.join(td, "cfg.txt"), "w").write("IL generic 300 %d\n" % rmax)
+    return n["tumor"], n["normal"]
+
+
+TN_DISCOVER = ["-i", "cfg.txt", "ref.fa", "t=tumor_aln.bam"]
+TN_ANNOTATE = ["-i", "cfg.txt", "-q", "0", "-a", "-e", "1", "ref.fa", "tumor.vcf", "normal=normal_aln.bam"]
+
+
+def make_tn():
+    """discovery on the tumour, then annotate mode on the normal (README.md:116), by the compiled reference"""
+    with tempfile.TemporaryDirectory() as td:
+        t = time.perf_counter()
+        nt_, nn_ = materialise_tn(td)
+        print("config5: %d + %d reads written in %.1f s" % (nt_, nn_, time.perf_counter() - t), flush=True)
+        t = time.perf_counter()
+        q = subprocess.run([REF_BIN] + TN_DISCOVER, cwd=td, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+        t_disc = time.perf_counter() - t
+        assert q.returncode == 0, q.stderr.decode()[-2000:]
+        open(os.path.join(td, "tumor.vcf"), "wb").write(q.stdout)
+        print("config5: discovery %.1f s, %d bytes" % (t_disc, len(q.stdout)), flush=True)
+        t = time.perf_counter()
+        a = subprocess.run([REF_BIN] + TN_ANNOTATE, cwd=td, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+        t_ann = time.perf_counter() - t
+        assert a.returncode == 0, a.stderr.decode()[-2000:]
+        body = [l for l in a.stdout.splitlines() if not l.startswith(b"#")]
+        out = dict(tumor=digest(q.stdout), annotate=digest(a.stdout), tagged_normal=sum(1 for l in body if l.endswith(b";normal")),
+                   tumor_reads=nt_, normal_reads=nn_, reference_discovery_wall_s=round(t_disc, 1), reference_annotate_wall_s=round(t_ann, 1),
+                   sim=TN, made_by="oracle/_ref/indelminer (the reference's own sources, oracle/Makefile), 1 thread, build container")
+        print(json.dumps(out))
+        with open(os.path.join(ROOT, "tests", "golden", "large_config5.json"), "w") as fh:
+            json.dump(out, fh, indent=1)
+            fh.write("\n")
+
+
 def materialise(name, td):
     """writes ref.fa / aln.bam (+ .bai) for the named configuration into td; returns (n_reads, flags)"""
     cfg = LARGE[name]
@@ -51,6 +106,8 @@ def digest(vcf_bytes):
 
 def main():
     name = sys.argv[1]
+    if name == "config5":
+        return make_tn()
     with tempfile.TemporaryDirectory() as td:
         t = time.perf_counter()
         n, flags = materialise(name, td)

@@ -165,6 +165,23 @@ int im_depth_reset(im_ctx* c, int32_t tid, void* stream)
     memset(g_gdepth[tid], 0, sizeof(int32_t) * ((size_t)c->lens[tid] + 1));
     return IM_OK;
 }
+int im_depth_query_max_tid(im_ctx* c, int32_t tid, int32_t n, const int32_t* beg, const int32_t* end, uint32_t* sum_out, uint32_t* max_out)
+{
+    for (int32_t q = 0; q < n; q++) {
+        int64_t a = beg[q], b = end[q];
+        if (a < 0) a = 0;
+        if (b > c->lens[tid]) b = c->lens[tid];
+        uint32_t s = 0, mx = 0;
+        for (int64_t p = a > 0 ? a - 1 : a; p < (b < c->lens[tid] ? b + 1 : b); p++) {
+            const uint32_t v = (uint32_t)g_gdepth[tid][p];
+            if (p >= a && p < b) s += v;
+            if (v > mx) mx = v;
+        }
+        sum_out[q] = s;
+        if (max_out) max_out[q] = mx;
+    }
+    return IM_OK;
+}
 int im_depth_query_tid(im_ctx* c, int32_t tid, int32_t n, const int32_t* beg, const int32_t* end, uint32_t* sum_out)
 {
     for (int32_t q = 0; q < n; q++) {

@@ -964,6 +964,27 @@ def test_product_multi_gpu_path_one_rank(synth_small, tmp_path):
         assert out == _golden(gold)
 
 
+def _deep_locus(binary, tmp_path):
+    """DP= at a locus deeper than samtools' pileup buffers (bam_pileup.c:172,244): 9000 plain pairs stacked on the base in front
+    of a called deletion -- the reference's pileup stops taking the stack's records at 8000 nodes and prints DP=365 where a plain
+    depth count gives 409; 7900 stacked pairs stay below the cap.  Goldens: the compiled reference (make_golden_deep.py)."""
+    from tests.support import deeplocus
+    for name, depth in (("deep_locus_9000", 9000), ("deep_locus_7900", 7900)):
+        d = tmp_path / name
+        d.mkdir()
+        deeplocus.write(str(d), depth=depth)
+        assert _run(binary, ["-i", "cfg.txt"], str(d), "ref.fa", "aln.bam") == _golden(name), name
+
+
+def test_host_logic_dp_at_a_locus_deeper_than_the_pileup_buffers(tmp_path):
+    _deep_locus(_build_shim(), tmp_path)
+
+
+@pytest.mark.gpu
+def test_product_dp_at_a_locus_deeper_than_the_pileup_buffers(tmp_path):
+    _deep_locus(_product(), tmp_path)
+
+
 def _odd_inputs(binary, tmp_path, envs, seeds=None):
     """the inputs of tests/golden/odd_inputs.py regenerated from their seeds; what the compiled reference did with each is in
     tests/golden/odd_inputs.json (make_golden_odd.py): same exit status; same stdout where the reference completes"""
