@@ -486,6 +486,52 @@ def end_to_end_config3():
         return out
 
 
+def end_to_end_config5():
+    """BASELINE configs[4] at the size of configs[2]: tumour + normal, 8 contigs x 6.25 Mb at 30x each (15 M reads per sample; the tumour
+    is the normal's genome with somatic indels on top).  The product CLI runs discovery on the tumour, then annotate mode
+    (-q 0 -a -e 1, README.md:116) on the normal with the tumour's VCF; both outputs must carry the md5 the compiled reference
+    printed for these inputs (tests/golden/large_config5.json: 451 s + 403 s of reference time in the build container).
+    Throughput of the annotate step = the normal's reads / its wall time."""
+    import importlib.util
+    import re
+    import subprocess
+    import tempfile
+    from indelminer_amd import build
+    spec = importlib.util.spec_from_file_location("make_golden_large", os.path.join(ROOT, "tests", "golden", "make_golden_large.py"))
+    mg = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mg)
+    want = json.load(open(os.path.join(ROOT, "tests", "golden", "large_config5.json")))
+    prod = build.HOST_BIN
+    with tempfile.TemporaryDirectory() as td:
+        t = time.perf_counter()
+        n_t, n_n = mg.materialise_tn(td)
+        out = {"workload": "BASELINE configs[4]: tumour + normal, 8 contigs x 6.25 Mb, 100 bp PE at 30x each; discovery on the tumour, then -q 0 -a -e 1 on the normal",
+               "tumor_reads": n_t, "normal_reads": n_n, "generation_s": time.perf_counter() - t,
+               "reference_wall_s_build_container": {"discovery": want["reference_discovery_wall_s"], "annotate": want["reference_annotate_wall_s"]}}
+        env = dict(os.environ, INDELMINER_TIMING="1")
+        t = time.perf_counter()
+        p = subprocess.run([prod] + mg.TN_DISCOVER, cwd=td, stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env)
+        w_disc = time.perf_counter() - t
+        open(td + "/tumor.vcf", "wb").write(p.stdout)
+        t = time.perf_counter()
+        a = subprocess.run([prod] + mg.TN_ANNOTATE, cwd=td, stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env)
+        w_ann = time.perf_counter() - t
+        d1, d2 = mg.digest(p.stdout), mg.digest(a.stdout)
+        body = [l for l in a.stdout.splitlines() if not l.startswith(b"#")]
+        sw = re.search(r"annotate mode: (\d+) im_support_batch calls, (\d+) tasks, (\d+) cells, ([0-9.]+) s", a.stderr.decode(errors="replace"))
+        out.update(discovery={"rc": p.returncode, "wall_s": w_disc, "reads_per_s": n_t / w_disc, "vcf_records": d1["records"], "md5": d1["md5"],
+                              "md5_is_the_references": bool(p.returncode == 0 and d1["md5"] == want["tumor"]["md5"])},
+                   annotate={"rc": a.returncode, "wall_s": w_ann, "reads_per_s": n_n / w_ann, "vcf_records": d2["records"], "md5": d2["md5"],
+                             "tagged_normal": sum(1 for l in body if l.endswith(b";normal")),
+                             "md5_is_the_references": bool(a.returncode == 0 and d2["md5"] == want["annotate"]["md5"]),
+                             "support_kernel": ({"calls": int(sw.group(1)), "tasks": int(sw.group(2)), "cells": int(sw.group(3)), "s_in_calls": float(sw.group(4)),
+                                                 "note": "affine Smith-Waterman of annotate mode (src/variant.c:1246-1424); only variants the normal's own discovery "
+                                                         "does not already carry reach it"} if sw else None)})
+        out["product_md5s_are_the_references"] = bool(out["discovery"]["md5_is_the_references"] and out["annotate"]["md5_is_the_references"])
+        out["speedup_over_reference_build_container"] = {"discovery": want["reference_discovery_wall_s"] / w_disc, "annotate": want["reference_annotate_wall_s"] / w_ann}
+        return out
+
+
 def _mg_product_run(rank, world, local_rank, dist, td, flags, n_reads, piece_bytes, single_wall=None, single_vcf=None):
     """the product CLI on every rank of the job over the input in td (ref.fa, aln.bam); rank 0 also runs it as ONE process and compares
     the bytes.  Returns (on rank 0) wall time = max over ranks, reads/s, per-rank phase times and what RCCL said about the communicator."""
@@ -697,6 +743,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-shard3", action="store_true", help="skip the config-3 per-GPU shard measurement (N=1 only)")
     ap.add_argument("--no-config3", action="store_true", help="skip the whole-program leg on BASELINE configs[2] at full size (N=1 only, about a minute)")
+    ap.add_argument("--no-config5", action="store_true", help="skip the tumour / normal leg (BASELINE configs[4]: discovery + annotate mode, N=1 only, about a minute and a half)")
     args = ap.parse_args()
 
     # stdout carries ONE JSON line and nothing else: gloo ("[Gloo] Rank 0 is connected ...") and librccl (its
@@ -928,6 +975,11 @@ def main():
                 line["end_to_end_config3"] = end_to_end_config3()
             except Exception as ex:
                 line["end_to_end_config3"] = {"error": str(ex)}
+        if world == 1 and not args.no_cpu_baseline and not args.no_config5:
+            try:
+                line["end_to_end_config5"] = end_to_end_config5()
+            except Exception as ex:
+                line["end_to_end_config5"] = {"error": str(ex)}
         # every self-check of the line in one place; the process exits non-zero when one of them is not true
         checks = {"candidates_counted_on_the_device_equal_the_simulator": True,      # asserted above
                   "overlapped_passes_equal_the_pass_alone": overlap_ok is True,
@@ -949,6 +1001,8 @@ def main():
         if isinstance(line.get("end_to_end_config3"), dict):
             c3 = line["end_to_end_config3"]
             checks["end_to_end_config3_md5_is_the_references"] = c3.get("product_md5_is_the_references") is True
+        if isinstance(line.get("end_to_end_config5"), dict):
+            checks["end_to_end_config5_md5s_are_the_references"] = line["end_to_end_config5"].get("product_md5s_are_the_references") is True
         line["self_checks"] = checks
         line["self_checks_all_true"] = all(checks.values())
         sys.stdout.flush()

@@ -1537,7 +1537,12 @@ static int is_indel_supported(driver* d, knownvariant_t* k)
     if (!k->diffsample_support && nt > 0) {
         int32_t* res = xmalloc(sizeof(int32_t) * 4 * (size_t)nt);
         gpu_wait(d);
+        const int64_t t0sw = wall_ns();
         if (im_support_batch(d->gpu, nt, tg, to, qs, qo, res) != IM_OK) fatalf("im_support_batch: %s", im_last_error(d->gpu));
+        if (g_timing) {         /* annotate mode's Smith-Waterman work (src/variant.c:1288-1424: (query + 1) x (target + 1) cells per task) */
+            g_sw_ns += wall_ns() - t0sw; g_sw_calls++; g_sw_tasks += nt;
+            for (int i = 0; i < nt; i++) g_sw_cells += (to[i + 1] - to[i] + 1) * (qo[i + 1] - qo[i] + 1);
+        }
         for (int i = 0; i < nt; i++)
             if (res[4 * i] <= own[3 * i] && res[4 * i + 1] <= own[3 * i + 1] && res[4 * i + 2] >= own[3 * i + 2]) { k->diffsample_support = 1; break; }
         free(res);

@@ -318,6 +318,7 @@ int main(int argc, char** argv)
 
     gpu_wait(&d);
     if (t_out) fflush(t_out);
+    if (g_vcfname != NULL) cpu_report();            /* annotate mode has no replay workers: its report comes here */
     if (!getenv("INDELMINER_TIDY_EXIT")) {
         /* everything is printed: the GPU context, the pinned rings and the device arrays go with the process -- tearing the
          * HIP runtime down in order costs about as long as the whole device work of a small run (leak checkers: INDELMINER_TIDY_EXIT=1) */

@@ -204,9 +204,12 @@ static __thread int64_t t_cpu_dev_ns, t_wall_dev_ns;      /* a walker's processo
 #define DEV_TIMED(call) do { if (g_timing) { const int64_t t0_ = thread_cpu_ns(), w0_ = wall_ns(); call; t_cpu_dev_ns += thread_cpu_ns() - t0_; t_wall_dev_ns += wall_ns() - w0_; } else { call; } } while (0)
 static int64_t thread_cpu_ns(void) { struct timespec ts; clock_gettime(CLOCK_THREAD_CPUTIME_ID, &ts); return (int64_t)ts.tv_sec * 1000000000LL + ts.tv_nsec; }
 static int64_t wall_ns(void) { struct timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return (int64_t)ts.tv_sec * 1000000000LL + ts.tv_nsec; }
+static int64_t g_sw_ns, g_sw_calls, g_sw_tasks, g_sw_cells;      /* annotate mode: im_support_batch calls, their tasks and DP cells */
 static void cpu_report(void)
 {
     if (!g_timing) return;
+    if (g_sw_calls) fprintf(stderr, "[timing] annotate mode: %ld im_support_batch calls, %ld tasks, %ld cells, %.3f s in the calls (launch + copies + kernel)\n",
+                            (long)g_sw_calls, (long)g_sw_tasks, (long)g_sw_cells, g_sw_ns / 1e9);
     struct timespec ts; clock_gettime(CLOCK_PROCESS_CPUTIME_ID, &ts);
     {   /* what the kernel will have to take apart when the process ends */
         FILE* fp = fopen("/proc/self/status", "r");

@@ -43,6 +43,30 @@ def test_large_config_matches_reference_digest(tmp_path, name):
         assert got[k] == want[k], (k, got[k], want[k])
 
 
+def test_large_config5_tumor_normal_matches_reference_digests(tmp_path):
+    """BASELINE configs[4] at the size of configs[2]: discovery on the tumour, annotate mode (-q 0 -a -e 1) on the normal with the
+    tumour's VCF -- both outputs against the digests of what the compiled reference printed (make_golden_large.py config5)"""
+    from indelminer_amd import build
+    mg = _mg()
+    want = json.load(open(os.path.join(GOLD, "large_config5.json")))
+    n_t, n_n = mg.materialise_tn(str(tmp_path))
+    assert (n_t, n_n) == (want["tumor_reads"], want["normal_reads"])
+    build.build()
+    prod = build.build_host()
+    p = subprocess.run([prod] + mg.TN_DISCOVER, cwd=str(tmp_path), stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    assert p.returncode == 0, p.stderr.decode()[-2000:]
+    got = mg.digest(p.stdout)
+    for k in ("records", "composite", "insertions", "bytes", "md5"):
+        assert got[k] == want["tumor"][k], (k, got[k], want["tumor"][k])
+    open(str(tmp_path / "tumor.vcf"), "wb").write(p.stdout)
+    a = subprocess.run([prod] + mg.TN_ANNOTATE, cwd=str(tmp_path), stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    assert a.returncode == 0, a.stderr.decode()[-2000:]
+    got = mg.digest(a.stdout)
+    for k in ("records", "bytes", "md5"):
+        assert got[k] == want["annotate"][k], (k, got[k], want["annotate"][k])
+    assert sum(1 for l in a.stdout.splitlines() if l.endswith(b";normal")) == want["tagged_normal"]
+
+
 def test_wgs_scale_reference_at_1x(tmp_path):
     """BASELINE configs[3]'s reference -- 3.0e9 bases in 24 contigs with the human length spread -- at 1x (3.0e7 reads), generated on
     the box by tests/support/simgen.c, through the product: the VCF's digest is the CPU shim's (the record-at-a-time path over the
