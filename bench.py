@@ -681,6 +681,59 @@ def cpu_port_baseline(ref, cand, read_len, n_reads_total, m):
             "candidates_per_s": m / dt}
 
 
+def long_reads_measure(device, reps=12):
+    """A 2 x 300 library (1 Mb contig at 30x, insert ~ N(900, 50)): the candidates of its delivered reads through the realign launches --
+    realign_kernel turns reads beyond 255 bases away, realign_long_kernel (sixteen read positions per lane) takes them -- timed with
+    HIP events on a resident batch, every result checked against the CPU oracle on a sample.  Algorithmic bytes as for the short
+    kernel, from the window / piece sizes the kernel records."""
+    from tests.support import gpucmp, oraclebind as ob
+    L = 300
+    refs, rd = synth.simulate(seed=8, ref_len=1_000_000, coverage=30, read_len=L, isize_mean=900, isize_sd=50, isize_min=700, isize_max=1100)
+    cand = synth.candidates(rd)
+    n = len(cand["index"])
+    ctx = capi.Context(device)
+    try:
+        ctx.set_reference([refs[0].tobytes()])
+        ctx.expect_read_length(L)
+        stride = (L + 3) // 4 * 4
+        bases = np.zeros((n, stride), dtype=np.uint8)
+        bases[:, :L] = cand["bases"]
+        flat = np.concatenate([bases.reshape(-1), np.zeros(16, np.uint8)])
+        d_bases = capi.DevBuf(ctx, flat.nbytes).upload(flat)
+        d_off = capi.DevBuf(ctx, 8 * n).upload(np.arange(n, dtype=np.int64) * stride)
+        d_len = capi.DevBuf(ctx, 4 * n).upload(np.full(n, L, np.int32))
+        d_tid = capi.DevBuf(ctx, 4 * n).upload(np.zeros(n, np.int32))
+        d_anchor = capi.DevBuf(ctx, 4 * n).upload(cand["anchor"].astype(np.int32))
+        d_range = capi.DevBuf(ctx, 4 * n).upload(cand["range_max"].astype(np.int32))
+        d_res = capi.DevBuf(ctx, 512 * n)
+        batch = capi.DevBatch(n, d_bases.ptr, d_off.ptr, d_len.ptr, d_tid.ptr, d_anchor.ptr, d_range.ptr, d_res.ptr, None, None, None)
+        P = capi.params()
+        L_ = capi.lib()
+        tm = capi.Timer(ctx)
+        ts = []
+        for _ in range(reps + 2):
+            tm.start(ctx.stream)
+            ctx._check(L_.im_dev_realign(ctx.h, C.byref(P), C.byref(batch), ctx.stream))
+            tm.stop(ctx.stream)
+            ts.append(tm.elapsed_ms())
+        ms = float(np.median(ts[2:]))
+        res = d_res.download(capi.RESULT_DTYPE, n)
+        alg = algorithmic_bytes(res)
+        contig = refs[0].tobytes()
+        Po = ob.params()
+        bad = 0
+        m = min(n, 1500)
+        for j in range(m):
+            st, r_ = ob.realign(Po, contig, len(contig), int(cand["anchor"][j]), int(cand["range_max"][j]), bytes(cand["bases"][j]))
+            bad += gpucmp.hip_vs_oracle(res[j], st, r_) is not None
+        return {"workload": "2 x 300 library: 1 Mb contig, 30x, insert ~ N(900, 50); the candidate reads of its %d delivered reads" % rd.n,
+                "candidates": n, "evidence_found": int((res["status"] == 1).sum()), "ms_both_launches": ms, "candidates_per_s": n / (ms * 1e-3),
+                "delivered_reads_per_s_equivalent": rd.n / (ms * 1e-3), "algorithmic_bytes": alg, "achieved_gbs": alg / (ms * 1e-3) / 1e9,
+                "frac_of_hbm_peak": alg / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "identical_to_the_oracle_on_the_sample": bool(bad == 0), "sample": m}
+    finally:
+        ctx.close()
+
+
 def shard3_measure(device, steps=24, warmup=4):
     """The same device pass on ONE GPU's share of BASELINE configs[2] (a 6.25 Mb contig at 30x, every seventh planted event a
     150-900 bp deletion: 1.9 M delivered reads, ~76 k candidates, ~19 READCHUNK flushes per step): the launch sizes a real
@@ -970,6 +1023,11 @@ def main():
                 line["shard_config3"] = shard3_measure(0 if os.environ.get("IM_BENCH_ONE_DEVICE") == "1" else local_rank)
             except Exception as ex:
                 line["shard_config3"] = {"error": str(ex)}
+        if world == 1 and not args.no_shard3:
+            try:
+                line["long_reads_2x300"] = long_reads_measure(0 if os.environ.get("IM_BENCH_ONE_DEVICE") == "1" else local_rank)
+            except Exception as ex:
+                line["long_reads_2x300"] = {"error": str(ex)}
         if world == 1 and not args.no_cpu_baseline and not args.no_config3:
             try:
                 line["end_to_end_config3"] = end_to_end_config3()
@@ -1001,6 +1059,8 @@ def main():
         if isinstance(line.get("end_to_end_config3"), dict):
             c3 = line["end_to_end_config3"]
             checks["end_to_end_config3_md5_is_the_references"] = c3.get("product_md5_is_the_references") is True
+        if isinstance(line.get("long_reads_2x300"), dict):
+            checks["long_reads_identical_to_the_oracle"] = line["long_reads_2x300"].get("identical_to_the_oracle_on_the_sample") is True
         if isinstance(line.get("end_to_end_config5"), dict):
             checks["end_to_end_config5_md5s_are_the_references"] = line["end_to_end_config5"].get("product_md5s_are_the_references") is True
         line["self_checks"] = checks

@@ -97,7 +97,7 @@ struct Band {
 // (bin_diagonals only lets read-unique k-mers vote, 97-98).  In the direct (k <= 6) table every
 // other entry is 0, so "votes" is simply "non-zero"; the hash table (k > 6) marks repeats 0xFF.
 template <int KT, bool DIRECT>
-__device__ __forceinline__ void table_build(WaveLds& s, uint32_t p0, uint32_t nq, uint32_t k, int lane, uint32_t read_pk8)
+__device__ __forceinline__ void table_build(WaveLds& s, uint32_t p0, uint32_t nq, uint32_t k, int lane, uint32_t read_pk8, uint32_t* codes)
 {
     if constexpr (KT == 6 || KT == -1) {
         // direct table (k = 6, the reference default, with its mask a constant; KT = -1: any k <= 6): cleared with four
@@ -132,6 +132,62 @@ __device__ __forceinline__ void table_build(WaveLds& s, uint32_t p0, uint32_t nq
 #pragma unroll
         for (int j = 0; j < 4; j++) if (lost[j]) t8[code[j]] = 0u;      // repeated: nobody votes with it
         wave_lds_sync();
+        return;
+    }
+    if constexpr (KT == 7) {
+        // k = 7..13 ("prefix table"): the 4 KiB byte table goes by the k-mer's FIRST SIX bases and names the read position (+ 1);
+        // the whole k-mer of every read position waits in codes[] for the vote to check.  Entries that meet an occupied slot take
+        // the next one; a k-mer that meets ITSELF there occurs twice in the read: the entry is flagged, neither copy votes.
+        uint8_t* t8 = reinterpret_cast<uint8_t*>(s.tbl);
+        {
+            uint4* t4 = reinterpret_cast<uint4*>(s.tbl);
+#pragma unroll
+            for (int i = 0; i < kTblBytes / 16 / 64; i++) t4[lane + 64 * i] = make_uint4(0u, 0u, 0u, 0u);
+        }
+        // bases 4l .. 4l+18 of the read as 2-bit codes: this lane's byte and the four lanes' behind it
+        const uint32_t n1 = (uint32_t)dpp_mov<kDppWaveShl1>(0, (int)read_pk8);
+        const uint32_t n2 = (uint32_t)dpp_mov<kDppWaveShl1>(0, (int)n1);
+        const uint32_t n3 = (uint32_t)dpp_mov<kDppWaveShl1>(0, (int)n2);
+        const uint32_t n4 = (uint32_t)dpp_mov<kDppWaveShl1>(0, (int)n3);
+        const uint32_t lo = read_pk8 | (n1 << 8) | (n2 << 16) | (n3 << 24);
+        const uint32_t kmask = (1u << (2 * k)) - 1u;
+        uint32_t code[4], slot[4]; bool pend[4];
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const uint32_t x = 4u * lane + j;
+            pend[j] = x >= p0 && x < p0 + nq;
+            code[j] = __builtin_amdgcn_alignbit(n4, lo, 2u * j) & kmask;          // k <= 13: 26 bits
+            slot[j] = code[j] & 0xFFFu;
+            if (pend[j]) codes[x - p0] = code[j];
+        }
+        wave_lds_sync();
+        for (;;) {
+            uint32_t e[4];
+#pragma unroll
+            for (int j = 0; j < 4; j++) { e[j] = pend[j] ? lds_byte(s.tbl, slot[j]) : 1u; }
+            wave_lds_sync();
+#pragma unroll
+            for (int j = 0; j < 4; j++) if (pend[j] && e[j] == 0u) t8[slot[j]] = (uint8_t)(4u * lane + j - p0 + 1u);
+            wave_lds_sync();
+            bool any = false;
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                if (!pend[j]) continue;
+                const uint32_t me = 4u * lane + j - p0 + 1u;
+                const uint32_t now = lds_byte(s.tbl, slot[j]);
+                if (now == me) { pend[j] = false; continue; }                       // in
+                const uint32_t other = codes[now - 1u];
+                if ((other & 0x7FFFFFFFu) == code[j]) {                             // the same k-mer twice in the read: nobody votes with it
+                    atomicOr(&codes[now - 1u], 0x80000000u);
+                    pend[j] = false;
+                    continue;
+                }
+                slot[j] = (slot[j] + 1u) & 0xFFFu;                                   // a neighbour's: the next slot
+                any = true;
+            }
+            wave_lds_sync();
+            if (!__builtin_amdgcn_ballot_w64(any)) break;
+        }
         return;
     }
     uint8_t* t8 = reinterpret_cast<uint8_t*>(s.tbl);
@@ -224,13 +280,14 @@ template <int KT>
 __device__ __forceinline__ uint32_t vote_unit_direct(WaveLds& s, const uint32_t (&cur)[8], uint32_t (&nxt)[8],
                                                      const uint8_t* __restrict__ src_next, bool more,
                                                      uint32_t bsh, uint32_t kmask, uint32_t i0, uint32_t span,
-                                                     uint32_t obase, bool check, uint32_t off_limit, uint32_t ac, uint32_t Q0, uint32_t mx)
+                                                     uint32_t obase, bool check, uint32_t off_limit, uint32_t ac, uint32_t Q0, uint32_t mx,
+                                                     const uint32_t* codes)
 {
     // all eight table reads first, then the (rare) hits
     uint32_t v[8];
     __builtin_amdgcn_s_waitcnt(0x0F70);         // vmcnt(0): the current dwords, loaded a unit ago -- one wait instead of eight counted ones
 #pragma unroll
-    for (int j = 0; j < 8; j++) v[j] = (cur[j] >> bsh) & (KT == 6 ? 0xFFFu : kmask);
+    for (int j = 0; j < 8; j++) v[j] = (cur[j] >> bsh) & (KT == 6 || KT == 7 ? 0xFFFu : kmask);
     // The next unit's loads go out BEHIND the uses of the current dwords (the empty asm pins that): the
     // counted waits in front of those uses are merged over both values of `more`, and with the new loads already issued
     // the merged count makes every use wait for them too -- a memory round trip per unit instead of an overlap.
@@ -251,31 +308,39 @@ __device__ __forceinline__ uint32_t vote_unit_direct(WaveLds& s, const uint32_t 
     uint32_t m = (ma >> 7) | (mb >> 6);
     // start index of mask bit b = 8 jj + h: 64 (4 h + jj) = 8 b + 248 h
     const uint32_t ob = obase + i0;
-#ifdef IM_ALWAYS_CHECK
-    if (false) {
-#else
-    if (!check) {
-#endif
-        while (m) {
-            const uint32_t bit = (uint32_t)__builtin_ctz(m);
-            m &= m - 1u;
-            const bool hb = (bit & 1u) != 0u;
-            const uint32_t x = hb ? xb : xa;
-            const uint32_t off = ob + 8u * bit + (hb ? 248u : 0u) - __builtin_amdgcn_ubfe(x, bit & 24u, 8u);   // diagonal index - c0
-            mx = vote_direct(s, off, ac, Q0, mx);
+    (void)check;
+    while (m) {
+        const uint32_t bit = (uint32_t)__builtin_ctz(m);
+        m &= m - 1u;
+        const bool hb = (bit & 1u) != 0u;
+        const uint32_t x = hb ? xb : xa;
+        const uint32_t di = 8u * bit + (hb ? 248u : 0u);
+        uint32_t val = __builtin_amdgcn_ubfe(x, bit & 24u, 8u);
+        bool votes = i0 + di <= span;                       // a start past the window's last k-mer does not vote
+        if constexpr (KT == 7) {
+            // k = 7..13: the table went by the k-mer's first six bases; the entry names a read position whose WHOLE k-mer is in
+            // codes[] -- the same k-mer votes, a flagged one (it occurs twice in the read) does not, another one means the slot was
+            // taken by a neighbour: the next slot then (rare: a hundred entries in 4096 slots)
+            const uint32_t j8 = (bit >> 3) + (hb ? 4u : 0u);
+            // cur[j8] by a tree of selects on j8's bits: registers, not an indexed array (which the compiler would keep in scratch)
+            const bool s0 = (j8 & 1u) != 0u, s1 = (j8 & 2u) != 0u, s2 = (j8 & 4u) != 0u;
+            const uint32_t a0 = s0 ? cur[1] : cur[0], a1 = s0 ? cur[3] : cur[2], a2 = s0 ? cur[5] : cur[4], a3 = s0 ? cur[7] : cur[6];
+            const uint32_t b0 = s1 ? a1 : a0, b1 = s1 ? a3 : a2;
+            const uint32_t w = s2 ? b1 : b0;
+            const uint32_t wcode = (w >> bsh) & kmask;
+            uint32_t slot = wcode & 0xFFFu;
+            for (;;) {
+                const uint32_t rc = codes[val - 1u];
+                if (rc == wcode) break;
+                if ((rc & 0x7FFFFFFFu) == wcode) { votes = false; break; }
+                slot = (slot + 1u) & 0xFFFu;
+                val = lds_byte(s.tbl, slot);
+                if (val == 0u) { votes = false; break; }
+            }
         }
-    } else {
-        while (m) {
-            const uint32_t bit = (uint32_t)__builtin_ctz(m);
-            m &= m - 1u;
-            const bool hb = (bit & 1u) != 0u;
-            const uint32_t x = hb ? xb : xa;
-            const uint32_t di = 8u * bit + (hb ? 248u : 0u);
-            const uint32_t off = ob + di - __builtin_amdgcn_ubfe(x, bit & 24u, 8u);
-            // one predicate, one exec-mask change: a start past the window's last k-mer, or (several chunks
-            // only, off_limit is all ones otherwise) a diagonal that belongs to another chunk, does not vote
-            if (i0 + di <= span && off < off_limit) mx = vote_direct(s, off, ac, Q0, mx);
-        }
+        const uint32_t off = ob + di - val;                 // diagonal index - c0
+        // (several chunks only, off_limit is all ones otherwise) a diagonal that belongs to another chunk does not vote either
+        if (votes && off < off_limit) mx = vote_direct(s, off, ac, Q0, mx);
     }
     return mx;
 }
@@ -286,7 +351,7 @@ __device__ __forceinline__ uint32_t vote_unit_direct(WaveLds& s, const uint32_t 
 template <int KT, bool DIRECT>
 __device__ __forceinline__ Band band_search(WaveLds& s, const uint8_t* __restrict__ pk, const uint8_t* __restrict__ contig,
                             uint32_t w0, uint32_t w1, uint32_t anchor,
-                            uint32_t p0, uint32_t p1, uint32_t k, uint32_t g, int lane, uint32_t read_pk8 IM_STAMP_ARG)
+                            uint32_t p0, uint32_t p1, uint32_t k, uint32_t g, int lane, uint32_t read_pk8, uint32_t* codes IM_STAMP_ARG)
 {
     Band b;
     const uint32_t W = w1 - w0, Lp = p1 - p0;
@@ -332,7 +397,7 @@ __device__ __forceinline__ Band band_search(WaveLds& s, const uint8_t* __restric
             for (int j = 0; j < 8; j++) wd[j] = load_u32_unaligned(src + 16 * j);
         }
         if (c0 == 0) {
-            table_build<KT, DIRECT>(s, p0, nq, k, lane, read_pk8);
+            table_build<KT, DIRECT>(s, p0, nq, k, lane, read_pk8, codes);
             IM_STAMP_B(0);
         }
         // clear the histogram: 16 bytes per lane and store, whole array (two stores for 1984 bytes)
@@ -363,10 +428,10 @@ __device__ __forceinline__ Band band_search(WaveLds& s, const uint8_t* __restric
             const uint32_t nfull = off_limit == 0xFFFFFFFFu ? (span + 1u) / 512u : 0u;
             for (uint32_t u = 0; u < nunit; u += 2) {
                 mx = vote_unit_direct<KT>(s, wd, we, src + 128u * (u + 1u), u + 1 < nunit, bsh, kmask,
-                                          512u * u + (uint32_t)lane, span, obase, u >= nfull, off_limit, ac, Q0, mx);
+                                          512u * u + (uint32_t)lane, span, obase, u >= nfull, off_limit, ac, Q0, mx, codes);
                 if (u + 1 < nunit)
                     mx = vote_unit_direct<KT>(s, we, wd, src + 128u * (u + 2u), u + 2 < nunit, bsh, kmask,
-                                              512u * (u + 1u) + (uint32_t)lane, span, obase, u + 1 >= nfull, off_limit, ac, Q0, mx);
+                                              512u * (u + 1u) + (uint32_t)lane, span, obase, u + 1 >= nfull, off_limit, ac, Q0, mx, codes);
             }
         } else {
             for (uint32_t u = 0; u < nunit; u++) {
@@ -577,7 +642,7 @@ __device__ __forceinline__ void store_band(im_read_result* out, int which, const
 
 // attempt_pe_alignment -> attempt_diagonal_alignments (src/alignment.c:539-799)
 template <int KT, bool DIRECT>
-__device__ __forceinline__ void realign_one(WaveLds& s, const RealignArgs& A, int c, int lane)
+__device__ __forceinline__ void realign_one(WaveLds& s, const RealignArgs& A, int c, int lane, uint32_t* codes)
 {
     IM_STAMP_DECL
     im_read_result* out = &A.batch.out[c];
@@ -589,7 +654,7 @@ __device__ __forceinline__ void realign_one(WaveLds& s, const RealignArgs& A, in
     const int tid = sload(A.batch.tid + c);
     const int anchor = sload(A.batch.anchor + c);
     const int R = sload(A.batch.range_max + c);
-    const uint32_t k = KT > 0 ? (uint32_t)KT : A.P.klength, g = KT ? 0u : A.P.numgaps, eth = A.P.ethreshold;
+    const uint32_t k = KT == 6 ? 6u : A.P.klength, g = KT ? 0u : A.P.numgaps, eth = A.P.ethreshold;
 
     if (lane < 16) reinterpret_cast<uint32_t*>(&out->band[0])[lane] = 0u;
     if (lane < 7) out->reserved[lane] = 0;
@@ -627,7 +692,7 @@ __device__ __forceinline__ void realign_one(WaveLds& s, const RealignArgs& A, in
 
     // piece 1: the whole read in [left1,right1) (557-566)
     IM_STAMP(0);
-    const Band b1 = band_search<KT, DIRECT>(s, pk, contig, (uint32_t)left1, (uint32_t)right1, (uint32_t)anchor, 0u, (uint32_t)L, k, g, lane, read_pk8 IM_STAMP_PASS(1));
+    const Band b1 = band_search<KT, DIRECT>(s, pk, contig, (uint32_t)left1, (uint32_t)right1, (uint32_t)anchor, 0u, (uint32_t)L, k, g, lane, read_pk8, codes IM_STAMP_PASS(1));
     if (b1.st) { finish(out, b1.st, 1, lane); return; }
     const Aln a1 = diag_scan<true>(s, contig, (uint32_t)left1, (uint32_t)right1, 0u, (uint32_t)L, b1.low, lane);
     store_band(out, 0, b1, a1, lane);
@@ -665,7 +730,7 @@ __device__ __forceinline__ void realign_one(WaveLds& s, const RealignArgs& A, in
     if ((int32_t)(w1 - w0) <= 0) { finish(out, IM_ST_ABORT, 1, lane); return; }
 
     IM_STAMP(7);
-    const Band b2 = band_search<KT, DIRECT>(s, pk, contig, w0, w1, anc, p0, p1, k, g, lane, read_pk8 IM_STAMP_PASS(8));
+    const Band b2 = band_search<KT, DIRECT>(s, pk, contig, w0, w1, anc, p0, p1, k, g, lane, read_pk8, codes IM_STAMP_PASS(8));
     if (b2.st) { finish(out, b2.st, 2, lane); return; }
     const Aln a2 = diag_scan<false>(s, contig, w0, w1, p0, p1, b2.low, lane);
     store_band(out, 1, b2, a2, lane);
@@ -824,7 +889,12 @@ __global__ __launch_bounds__(64, IM_WAVES_PER_SIMD) void realign_kernel(RealignA
     // speed only): give each XCD a contiguous run of reads.
     const int c = A.first + (blockIdx.x & 7) * (G >> 3) + (blockIdx.x >> 3);
     if (c >= n) return;
-    realign_one<KT, DIRECT>(s, A, c, lane);
+    uint32_t* codes = nullptr;
+    if constexpr (KT == 7) {
+        __shared__ uint32_t codes_lds[256];          // the read's whole k-mers, by read position (prefix-table mode)
+        codes = codes_lds;
+    }
+    realign_one<KT, DIRECT>(s, A, c, lane, codes);
 }
 
 // ---- numgaps > 0: banded affine-gap path ------------------------------------------
@@ -1613,7 +1683,7 @@ __global__ __launch_bounds__(64, 4) void realign_band_kernel(RealignArgs A)
             finish(out, IM_ST_ABORT, 0, lane); continue;
         }
         // piece 1: the whole read in [left1, right1)
-        const Band b1 = band_search<0, DIRECT>(s, pk, contig, (uint32_t)left1, (uint32_t)right1, (uint32_t)anchor, 0u, (uint32_t)L, k, g, lane, 0u IM_STAMP_PASS(16));
+        const Band b1 = band_search<0, DIRECT>(s, pk, contig, (uint32_t)left1, (uint32_t)right1, (uint32_t)anchor, 0u, (uint32_t)L, k, g, lane, 0u, nullptr IM_STAMP_PASS(16));
         if (b1.st) { finish(out, b1.st, 1, lane); continue; }
         const int up1 = ((uint32_t)L < k) ? b1.low : b1.low + (int)g;      // read shorter than k: low == up (408-412)
         const BandAln a1 = band_alignment(G, contig, rd, 0, L, left1, right1 - left1, b1.low, up1, 0, lane);
@@ -1672,7 +1742,7 @@ __global__ __launch_bounds__(64, 4) void realign_band_kernel(RealignArgs A)
         if (none) { finish(out, IM_ST_NONE, 1, lane); continue; }
         if ((int32_t)(w1 - w0) <= 0) { finish(out, IM_ST_ABORT, 1, lane); continue; }
         // piece 2
-        const Band b2 = band_search<0, DIRECT>(s, pk, contig, w0, w1, anc, p0, p1, k, g, lane, 0u IM_STAMP_PASS(21));
+        const Band b2 = band_search<0, DIRECT>(s, pk, contig, w0, w1, anc, p0, p1, k, g, lane, 0u, nullptr IM_STAMP_PASS(21));
         if (b2.st) { finish(out, b2.st, 2, lane); continue; }
         const int up2 = ((p1 - p0) < k) ? b2.low : b2.low + (int)g;
         const BandAln a2 = band_alignment(G, contig, rd, (int)p0, (int)(p1 - p0), (int)w0, (int)(w1 - w0), b2.low, up2, 1, lane);
@@ -1802,8 +1872,10 @@ hipError_t launch_realign(const RealignArgs& a, int n_cu, hipStream_t stream)
                 hipLaunchKernelGGL((realign_kernel<6, true>), dim3(g), dim3(64), 0, stream, b);     // reference defaults
             else if (a.P.klength <= (uint32_t)kDirectMaxK)
                 hipLaunchKernelGGL((realign_kernel<-1, true>), dim3(g), dim3(64), 0, stream, b);    // any other k <= 6: the same clean-table protocol, mask at run time
+            else if (a.P.klength <= 13u)
+                hipLaunchKernelGGL((realign_kernel<7, true>), dim3(g), dim3(64), 0, stream, b);     // k = 7..13: table by the first six bases, whole k-mers checked at the vote
             else
-                hipLaunchKernelGGL((realign_kernel<0, false>), dim3(g), dim3(64), 0, stream, b);
+                hipLaunchKernelGGL((realign_kernel<0, false>), dim3(g), dim3(64), 0, stream, b);     // k = 14, 15: the hash table
         }
     }
     return hipGetLastError();

@@ -302,7 +302,11 @@ static void run_contig(driver* d, int32_t tid, int32_t beg, int32_t end, bgzf_re
     if (bam_region_begin(&it, r, d->idx, tid, beg, end) != 0) fatalf("cannot seek in %s", d->bam_name);
     d->n_seg = 0;
     const int whole = (beg <= 0 && end >= d->hdr->target_len[tid]);
-    while (bam_region_next(&it, &b) == 1) {
+    volatile int died = 0;              /* a record the reference dies on ended the pass: the flushes in front of it are still to print */
+    t_is_main_thread_of_passA = 1;
+    if (setjmp(g_passA_jmp)) died = 1;
+    else g_passA_armed = 1;
+    while (!died && bam_region_next(&it, &b) == 1) {
         if (whole && b.tid >= 0 && !(b.flag & (0x4 | 0x100 | 0x200 | 0x400))) {
             /* what samtools' pileup would count for DP= (bam_pileup.c:171-172,238-265) */
             const uint8_t* cig = BAMR_CIGAR(&b);
@@ -322,6 +326,7 @@ static void run_contig(driver* d, int32_t tid, int32_t beg, int32_t end, bgzf_re
         }
         dispatch_record(d, &b);
     }
+    g_passA_armed = 0;
     free(b.data);
     phase_time("pass A (BAM decode + dispatch)");
     d->depth_tid = -1;
@@ -355,6 +360,14 @@ static void run_contig(driver* d, int32_t tid, int32_t beg, int32_t end, bgzf_re
         else pending_push(d, itm->pe);
     }
     free(res);
+    if (died) {
+        /* what the reference had printed when it met the record is out; its message and status follow */
+        out_flush_on_exit();
+        fflush(stdout);
+        if (g_passA_msg[0] == 1) fprintf(stderr, "%s\n", g_passA_msg + 1);     /* an assertion's own form */
+        else fprintf(stderr, "indelminer: %s\n", g_passA_msg);
+        exit(EXIT_FAILURE);
+    }
     flush_variants(d, tid, INT_MAX);        /* end of contig (src/indelminer.c:806-823) */
     phase_time("pass B (cluster, merge, print)");
     if (g_vcfname != NULL) {

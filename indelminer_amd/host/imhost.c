@@ -67,10 +67,25 @@ static pthread_mutex_t g_end_mu = PTHREAD_MUTEX_INITIALIZER;
 static __thread int t_holds_end;
 static void end_lock(void) { if (!t_holds_end) { pthread_mutex_lock(&g_end_mu); t_holds_end = 1; } }
 static void spec_fallback(const char* why);
+/* The record-at-a-time path reads a contig's records first (pass A: dispatch, candidates, flush points) and clusters / prints
+ * behind that (pass B).  The reference prints every READCHUNK flush as it goes, so a record it dies on has the flushes in front of
+ * it on stdout: a death in pass A waits -- the message is kept, the pass ends at that record, pass B prints the flushes that lie
+ * in front of it, then the run ends with the message and the status (run_contig). */
+static jmp_buf g_passA_jmp;
+static int g_passA_armed = 0;
+static char g_passA_msg[1024];
+static __thread int t_is_main_thread_of_passA = 0;
+static void passA_defer(const char* fmt, va_list ap)
+{
+    vsnprintf(g_passA_msg, sizeof g_passA_msg, fmt, ap);
+    g_passA_armed = 0;
+    longjmp(g_passA_jmp, 1);
+}
 static void fatalf(const char* fmt, ...)
 {
     /* src/errors.c:15-27: message on stderr, exit(1) */
     va_list ap;
+    if (g_passA_armed && t_is_main_thread_of_passA) { va_start(ap, fmt); passA_defer(fmt, ap); }
     if (g_spec_active) spec_fallback(fmt);      /* nothing is out yet: the run without the speculation finds out what is wrong, if anything is */
     walker_bails_out();         /* a walker thread of the pipeline does not come back from this (see handoff_to_host_child) */
     mg_rank_failed();           /* multi-GPU: rank 0 stops waiting for this rank's output */
@@ -180,7 +195,9 @@ static void spawn_self_and_exit(const char* mode)
     _exit(WIFEXITED(status) ? WEXITSTATUS(status) : EXIT_FAILURE);
 }
 
-#define forceassert(e) do { if (!(e)) { walker_bails_out(); end_lock(); out_flush_on_exit(); fprintf(stderr, "Assertion failed: %s file %s line %d\n", #e, __FILE__, __LINE__); exit(EXIT_FAILURE); } } while (0)
+static void passA_assert(const char* fmt, ...) { va_list ap; va_start(ap, fmt); passA_defer(fmt, ap); }
+#define forceassert(e) do { if (!(e)) { if (g_passA_armed && t_is_main_thread_of_passA) passA_assert("\x01" "Assertion failed: %s file %s line %d", #e, __FILE__, __LINE__); \
+                                        walker_bails_out(); end_lock(); out_flush_on_exit(); fprintf(stderr, "Assertion failed: %s file %s line %d\n", #e, __FILE__, __LINE__); exit(EXIT_FAILURE); } } while (0)
 
 static double now_ms(void)
 {

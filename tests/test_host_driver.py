@@ -430,6 +430,36 @@ def test_host_one_pass_speculation(tmp_path, synth_small, synth_1mb):
             assert b"provisional insert lengths from the first claims" in r.stderr       # staged behind the walk, and it held
 
 
+def test_host_two_walkers_meet_the_same_unknown_read_group(tmp_path):
+    """No config file; a read group that occurs on counted reads but on no proper pair is missing from the estimated table and
+    the reference dies AT the first such read (must_find_hashtable, src/indelminer.c:369-376) -- header and earlier flushes out.
+    Here such reads lie in every piece behind the first ones, several walkers meet them at once under the speculation
+    (INDELMINER_SPECULATE=1) and each wants to end the run: ONE of them hands the run over, the others wait (end_lock;
+    profiles/pipeline_soak.py seed 94036 had one thread exit under the other's hand-over child).  Status and bytes of the
+    record-at-a-time run -- and of the compiled reference -- every time."""
+    import numpy as np
+    from indelminer_amd import bamwrite, synth
+    refs, rd = synth.simulate(seed=94, ref_len=800_000, coverage=30, big_every=5)
+    rd.rg_names = ["libA", "libB"]
+    rd.rg_idx = np.where(((rd.flag & 0x2) == 0) & (rd.pos > 500_000), 1, 0).astype(np.int64)      # behind the first READCHUNK flush
+    contigs = [("ctg0", len(refs[0]))]
+    bamwrite.write_fasta(str(tmp_path / "ref.fa"), contigs, refs)
+    bamwrite.write_bam(str(tmp_path / "aln.bam"), contigs, rd)
+    shim = _build_shim()
+    one = subprocess.run([shim, "ref.fa", "s=aln.bam"], cwd=str(tmp_path), stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                         env=dict(os.environ, INDELMINER_PIPELINE="host"))
+    assert one.returncode == 1 and one.stderr.decode().strip().splitlines()[-1] == "indelminer: did not find libB in the hash"
+    assert one.stdout.startswith(b"##fileformat")     # the header (and what the flushes in front of the read printed) is out
+    ref_bin = os.path.join(ROOT, "oracle", "_ref", "indelminer")
+    if os.path.exists(ref_bin):
+        r = subprocess.run([ref_bin, "ref.fa", "s=aln.bam"], cwd=str(tmp_path), stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+        assert (r.returncode, r.stdout) == (one.returncode, one.stdout)
+    env = dict(os.environ, INDELMINER_SPECULATE="1", INDELMINER_WALKERS="4", INDELMINER_PIECE_BYTES="60000", INDELMINER_CLAIM_BASES="1")
+    for attempt in range(6):
+        r = subprocess.run([shim, "ref.fa", "s=aln.bam"], cwd=str(tmp_path), stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env)
+        assert (r.returncode, r.stdout) == (one.returncode, one.stdout), (attempt, r.returncode, r.stderr.decode()[-800:])
+
+
 def test_host_contigs_without_reads(tmp_path):
     """contigs that deliver no record at all -- the first, one in the middle, the last -- between contigs that do: claims,
     groups and flush placement must not mind (the read counter and the marker floor simply pass through them)"""
