@@ -483,23 +483,23 @@ __global__ __launch_bounds__(64) void realign_long_kernel(RealignArgs A)
 {
     __shared__ LongLds s;
     const int lane = threadIdx.x;
+    // ONE read per wave, as in realign_kernel: a 2 x 300 library is all long reads, and a wave per 64 consecutive reads (the first
+    // form of this kernel: long reads were the exception then) left the chip a wave per CU.  The launch covers every read of the
+    // slice; the waves of reads the four-positions-per-lane kernel has served leave at once.
     const int n = A.n_dev ? min(sload(A.n_dev), A.batch.n) : A.batch.n;
+    const int left = n - A.first;
+    const int G = min((int)gridDim.x, (left + 7) / 8 * 8);
+    if ((int)blockIdx.x >= G) return;
+    const int c = A.first + (blockIdx.x & 7) * (G >> 3) + (blockIdx.x >> 3);      // blocks of one XCD take neighbouring reads
+    if (c >= n) return;
+    const int L = sload(A.batch.read_len + c);
+    if (!(L > kShortRead && L <= IM_MAX_READ)) return;
     if (DIRECT) {
-        for (int i = lane; i < 2 * kLHash; i += 64) s.tbl[i] = 0u;
+        uint4* t4 = reinterpret_cast<uint4*>(s.tbl);
+        for (int i = lane; i < 2 * kLHash / 4; i += 64) t4[i] = make_uint4(0u, 0u, 0u, 0u);
         wave_lds_sync();
     }
-    // every workgroup looks at every 64th-of-the-grid read's length; only the long ones are work
-    for (int base = blockIdx.x * 64; base < n; base += gridDim.x * 64) {
-        const int c = base + lane;
-        const int len = c < n ? (int)A.batch.read_len[c] : 0;
-        uint64_t todo = __ballot(len > kShortRead && len <= IM_MAX_READ);
-        while (todo) {
-            const int j = uni(__builtin_ctzll(todo));
-            todo &= todo - 1;
-            const int L = __builtin_amdgcn_readlane(len, j);
-            realign_long_one<DIRECT>(s, A, base + j, L, lane);
-        }
-    }
+    realign_long_one<DIRECT>(s, A, c, L, lane);
 }
 
 }  // namespace
@@ -507,13 +507,17 @@ __global__ __launch_bounds__(64) void realign_long_kernel(RealignArgs A)
 hipError_t launch_realign_long(const RealignArgs& a, int n_cu, hipStream_t stream)
 {
     if (a.batch.n <= 0 || a.P.numgaps != 0) return hipSuccess;
-    int64_t groups = ((int64_t)a.batch.n + 63) / 64;
-    int64_t want = (int64_t)n_cu * 8;
-    const int grid = (int)(groups < want ? groups : want);
-    if (a.P.klength <= 6)
-        hipLaunchKernelGGL((realign_long_kernel<true>), dim3(grid), dim3(64), 0, stream, a);
-    else
-        hipLaunchKernelGGL((realign_long_kernel<false>), dim3(grid), dim3(64), 0, stream, a);
+    const int64_t cap = (int64_t)n_cu * 4096 / 8 * 8;       // one read per wave: a batch beyond the largest grid goes out in slices
+    for (int64_t first = 0; first < (int64_t)a.batch.n; first += cap) {
+        RealignArgs b = a;
+        b.first = (int32_t)first;
+        const int64_t rest = ((int64_t)a.batch.n - first + 7) / 8 * 8;
+        const int g = (int)(rest < cap ? rest : cap);
+        if (a.P.klength <= 6)
+            hipLaunchKernelGGL((realign_long_kernel<true>), dim3(g), dim3(64), 0, stream, b);
+        else
+            hipLaunchKernelGGL((realign_long_kernel<false>), dim3(g), dim3(64), 0, stream, b);
+    }
     return hipGetLastError();
 }
 
