@@ -50,6 +50,9 @@ def run_timed(cmd, cwd, env=None, stdout_path=None):
     return p.returncode, time.perf_counter() - t, err.decode(errors="replace"), ru
 
 
+PINNED_30X = {"md5": "cb94cde98fb247cb87241cae585b1989", "records": 1404007}      # simgen --human 3000000000 --coverage 30 --seed 3, every run since round 3
+
+
 def md5_of(path):
     h = hashlib.md5()
     n = 0
@@ -213,6 +216,18 @@ def main():
         if first:
             out["ratio_product_over_cpu_1_process"] = runs[first]["reads_per_s"] / out["cpu_baseline_shim"]["reads_per_s"]
             out["ratio_product_over_cpu_8_processes"] = runs[first]["reads_per_s"] / out["cpu_baseline_shim_8_processes"]["reads_per_s"]
+    # the headline run fails loudly instead of printing: the VCF of BASELINE configs[3] (3.0e9 bases, 30x, seed 3) is pinned -- every
+    # mode and every round must print these bytes -- and the contig the CPU shim ran must be the product's records of that contig
+    failures = []
+    if not out["same_vcf_in_every_mode"]:
+        failures.append("the runs did not all end with status 0 and the same VCF")
+    if args.total == 3_000_000_000 and float(args.coverage) == 30.0:
+        for name, r in runs.items():
+            if r["vcf_md5"] != PINNED_30X["md5"] or r["vcf_records"] != PINNED_30X["records"]:
+                failures.append("%s: md5 %s / %s records, pinned %s / %d" % (name, r["vcf_md5"], r["vcf_records"], PINNED_30X["md5"], PINNED_30X["records"]))
+    if args.cpu_contig >= 0 and first and not out["contig_%d_product_vs_cpu_shim" % args.cpu_contig]["same_set_of_records"]:
+        failures.append("contig %d: the product's records are not the CPU shim's" % args.cpu_contig)
+    out["assertions"] = {"failed": failures, "pinned": PINNED_30X}
     os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
     with open(os.path.join(ROOT, "gpurun_out", args.tag + ".json"), "w") as fh:
         json.dump(out, fh, indent=1)
@@ -220,6 +235,9 @@ def main():
     if not args.keep:
         for f in os.listdir(args.dir):
             os.unlink(os.path.join(args.dir, f))
+    if failures:
+        sys.stderr.write("wgs_run: %s\n" % "; ".join(failures))
+        sys.exit(1)
 
 
 if __name__ == "__main__":

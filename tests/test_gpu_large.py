@@ -67,14 +67,14 @@ def test_large_config5_tumor_normal_matches_reference_digests(tmp_path):
     assert sum(1 for l in a.stdout.splitlines() if l.endswith(b";normal")) == want["tagged_normal"]
 
 
-def test_wgs_scale_reference_at_1x(tmp_path):
-    """BASELINE configs[3]'s reference -- 3.0e9 bases in 24 contigs with the human length spread -- at 1x (3.0e7 reads), generated on
+def test_wgs_scale_reference_at_3x(tmp_path):
+    """BASELINE configs[3]'s reference -- 3.0e9 bases in 24 contigs with the human length spread -- at 3x (9.0e7 reads, a 3.6 GB BAM), generated on
     the box by tests/support/simgen.c, through the product: the VCF's digest is the CPU shim's (the record-at-a-time path over the
-    oracle, tests/golden/large_wgs1x.json); the same bytes with the insert lengths estimated in the same pass and with the contigs
+    oracle, tests/golden/large_wgs3x.json, made by tests/golden/make_golden_wgs.py); the same bytes with the insert lengths estimated in the same pass and with the contigs
     cut into many more pieces.  (At 30x this input is profiles/wgs_run.py: minutes of GPU-box time, not a test.)"""
     import hashlib
     from indelminer_amd import build
-    want = json.load(open(os.path.join(GOLD, "large_wgs1x.json")))
+    want = json.load(open(os.path.join(GOLD, "large_wgs3x.json")))
     gen = os.path.join(ROOT, "tests", "support", "simgen")
     subprocess.check_call(["gcc", "-O2", "-std=gnu11", "-pthread", "-o", gen, gen + ".c", "-lz", "-lm"])
     out = subprocess.run([gen, "--prefix", str(tmp_path / "w"), "--threads", "16"] + want["simgen"], stdout=subprocess.PIPE, check=True)
