@@ -7,7 +7,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libindelminer_amd.so")
-SOURCES = ["im_realign.hip", "im_realign_long.hip", "im_results.hip", "im_cluster.hip", "im_depth.hip", "im_support.hip", "im_triage.hip", "im_flush.hip", "im_flushwide.hip", "im_capi.hip", "im_comm.hip"]
+SOURCES = ["im_realign.hip", "im_realign_long.hip", "im_realign_any.hip", "im_results.hip", "im_cluster.hip", "im_depth.hip", "im_support.hip", "im_triage.hip", "im_flush.hip", "im_flushwide.hip", "im_capi.hip", "im_comm.hip"]
 HEADERS = [os.path.join(ROOT, "include", "indelminer_amd.h"), os.path.join(CSRC, "im_device.hpp")]
 
 

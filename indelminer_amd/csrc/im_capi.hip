@@ -52,6 +52,11 @@ struct im_ctx {
     // read-group -> range[1] table (im_set_insert_ranges), flattened hashtable chains
     void* rg_blob = nullptr;
     im::RgTable rg = {nullptr, 0, 0};
+    // the general realign pass (im_realign_any.hip): list of the reads it takes, counters, arena; one call at a time
+    std::mutex any_mu;
+    int32_t* any_list = nullptr; int32_t any_list_cap = 0;
+    int32_t* any_counters = nullptr;
+    int32_t* any_arena = nullptr; size_t any_arena_bytes = 0;
 };
 
 namespace {
@@ -82,10 +87,7 @@ int check_params(im_ctx* ctx, const im_params* p)
     // forceassert((klength > 1) && (klength < 16)), src/indelminer.c:1028
     if (p->klength < 2 || p->klength > 15) { set_err(ctx, "klength %u outside 2..15", p->klength); return IM_E_ARG; }
     if (p->maxdelsize == 0) { set_err(ctx, "maxdelsize must be > 0"); return IM_E_ARG; }
-    if (p->numgaps > 60) {
-        set_err(ctx, "numgaps=%u: the banded kernel holds bands of at most 61 diagonals", p->numgaps);
-        return IM_E_UNSUPPORTED;
-    }
+    if (p->numgaps > (1u << 20)) { set_err(ctx, "numgaps=%u", p->numgaps); return IM_E_ARG; }
     return IM_OK;
 }
 
@@ -171,6 +173,9 @@ void im_ctx_destroy(im_ctx* ctx)
     if (ctx->depth) (void)hipFree(ctx->depth);
     if (ctx->depth_sums) (void)hipFree(ctx->depth_sums);
     if (ctx->rg_blob) (void)hipFree(ctx->rg_blob);
+    if (ctx->any_list) (void)hipFree(ctx->any_list);
+    if (ctx->any_counters) (void)hipFree(ctx->any_counters);
+    if (ctx->any_arena) (void)hipFree(ctx->any_arena);
     if (ctx->pin) (void)hipHostFree(ctx->pin);
     for (int i = 0; i < 2; i++) {
         if (ctx->ev_in[i]) (void)hipEventDestroy(ctx->ev_in[i]);
@@ -223,6 +228,44 @@ int im_set_reference(im_ctx* ctx, int32_t n_contigs, const char* const* seqs, co
 
 static int dev_realign(im_ctx* ctx, const im_params* params, const im_dev_batch* batch, int keep, const int32_t* n_dev, void* stream);
 
+// The general pass: list what is left, size the arena from the longest read and the widest window on the list, work the list off.
+// The list's size comes back to the host in between (a stream synchronisation: this pass is for inputs outside what sequencers
+// deliver, and cannot be captured into a launch graph); one call at a time per context.
+static int realign_any(im_ctx* ctx, const im::RealignArgs& a, int all, hipStream_t stream)
+{
+    if (a.batch.n <= 0) return IM_OK;
+    std::lock_guard<std::mutex> lk(ctx->any_mu);
+    if (!ctx->any_counters) HIP_TRY(ctx, hipMalloc((void**)&ctx->any_counters, 4 * sizeof(int32_t)));
+    if (a.batch.n > ctx->any_list_cap) {
+        if (ctx->any_list) { HIP_TRY(ctx, hipFree(ctx->any_list)); ctx->any_list = nullptr; ctx->any_list_cap = 0; }
+        const int32_t cap = a.batch.n < (1 << 16) ? (1 << 16) : a.batch.n;
+        HIP_TRY(ctx, hipMalloc((void**)&ctx->any_list, sizeof(int32_t) * (size_t)cap));
+        ctx->any_list_cap = cap;
+    }
+    HIP_TRY(ctx, im::launch_realign_any_pick(a, all, ctx->any_list, ctx->any_counters, stream));
+    int32_t h[4] = {0, 0, 0, 0};
+    HIP_TRY(ctx, hipMemcpyAsync(h, ctx->any_counters, sizeof h, hipMemcpyDeviceToHost, stream));
+    HIP_TRY(ctx, hipStreamSynchronize(stream));
+    if (h[0] <= 0) return IM_OK;
+    const int32_t max_read = h[1], max_window = h[2];
+    const size_t per_wave = im::realign_any_arena_bytes(max_read, max_window, a.P.numgaps, 1);
+    int64_t waves = ((int64_t)h[0] + 63) / 64;
+    const int64_t most = (int64_t)ctx->n_cu * 8;                                  // eight waves per CU hide each other's memory latency
+    if (waves > most) waves = most;
+    const size_t budget = (size_t)6 << 30;
+    if (per_wave * (size_t)waves > budget) waves = (int64_t)(budget / per_wave);
+    if (waves < 1) waves = 1;
+    const size_t need = per_wave * (size_t)waves;
+    if (need > ctx->any_arena_bytes) {
+        if (ctx->any_arena) { HIP_TRY(ctx, hipFree(ctx->any_arena)); ctx->any_arena = nullptr; ctx->any_arena_bytes = 0; }
+        HIP_TRY(ctx, hipMalloc((void**)&ctx->any_arena, need));
+        ctx->any_arena_bytes = need;
+    }
+    HIP_TRY(ctx, im::launch_realign_any(a, ctx->any_list, ctx->any_counters, ctx->any_arena, max_read, max_window, (int32_t)waves, stream));
+    HIP_TRY(ctx, hipStreamSynchronize(stream));                                   // the list and the arena are free for the next call
+    return IM_OK;
+}
+
 int im_dev_realign(im_ctx* ctx, const im_params* params, const im_dev_batch* batch, void* stream)
 {
     return dev_realign(ctx, params, batch, 0, nullptr, stream);
@@ -253,9 +296,15 @@ static int dev_realign(im_ctx* ctx, const im_params* params, const im_dev_batch*
     a.keep_slots = keep;
     a.n_dev = n_dev;
     a.first = 0;
-    HIP_TRY(ctx, im::launch_realign(a, ctx->n_cu, (hipStream_t)stream));
-    if (ctx->expect_len.load(std::memory_order_relaxed) > im::kShortRead && params->numgaps == 0)
+    // Reads of up to 255 bases (1020 at numgaps == 0) and bands of up to 61 diagonals run in the kernels laid out for them; what
+    // those leave IM_ST_UNSUPPORTED -- and every read when the band is wider than a wave -- takes the general pass behind them.
+    const int expect = ctx->expect_len.load(std::memory_order_relaxed);
+    const bool wide = params->numgaps > (uint32_t)im::kMaxWaveGaps;
+    if (!wide) HIP_TRY(ctx, im::launch_realign(a, ctx->n_cu, (hipStream_t)stream));
+    if (expect > im::kShortRead && params->numgaps == 0)
         HIP_TRY(ctx, im::launch_realign_long(a, ctx->n_cu, (hipStream_t)stream));
+    if (wide || expect > IM_MAX_READ || (params->numgaps > 0 && expect > im::kShortRead))
+        return realign_any(ctx, a, wide ? 1 : 0, (hipStream_t)stream);
     return IM_OK;
 }
 
@@ -271,7 +320,6 @@ int im_dev_compact_results(im_ctx* ctx, const im_read_result* res, int32_t n, co
 int im_expect_read_length(im_ctx* ctx, int32_t max_len)
 {
     if (!ctx) return IM_E_ARG;
-    if (max_len > IM_MAX_READ) { set_err(ctx, "reads of %d bases: this build realigns reads of up to IM_MAX_READ=%d bases", max_len, IM_MAX_READ); return IM_E_UNSUPPORTED; }
     int cur = ctx->expect_len.load(std::memory_order_relaxed);
     while (max_len > cur && !ctx->expect_len.compare_exchange_weak(cur, max_len)) {}
     return IM_OK;
@@ -631,7 +679,7 @@ int im_realign_batch(im_ctx* ctx, const im_params* params, const im_read_batch* 
         memcpy(h_tid, batch->tid + c0, sizeof(int32_t) * (size_t)m);
         memcpy(h_anchor, batch->anchor + c0, sizeof(int32_t) * (size_t)m);
         memcpy(h_range, batch->range_max + c0, sizeof(int32_t) * (size_t)m);
-        if (longest > im::kShortRead && longest <= IM_MAX_READ) im_expect_read_length(ctx, (int32_t)longest);
+        if (longest > im::kShortRead) im_expect_read_length(ctx, (int32_t)longest);
         HIP_TRY(ctx, hipMemcpyAsync(dp, hp, in_bytes, hipMemcpyHostToDevice, ctx->copy_stream));
         HIP_TRY(ctx, hipEventRecord(ctx->ev_in[sl], ctx->copy_stream));
         HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_in[sl], 0));
@@ -716,21 +764,28 @@ int im_support_batch(im_ctx* ctx, int32_t n, const uint8_t* targets, const int64
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     const size_t tb = up256((size_t)t_off[n] + 16), qb = up256((size_t)q_off[n] + 16);
     const size_t ob = up256(sizeof(int64_t) * ((size_t)n + 1)), rb = up256(sizeof(int32_t) * 4 * (size_t)n);
-    int rc = ensure_ws(ctx, tb + qb + 2 * ob + rb);
+    int64_t max_t = 0, max_q = 0;                                // max_t sizes the kernel's LDS; beyond the LDS form's bounds: the second launch
+    for (int32_t i = 0; i < n; i++) {
+        const int64_t l = t_off[i + 1] - t_off[i], q = q_off[i + 1] - q_off[i];
+        if (l > max_t) max_t = l;
+        if (q > max_q) max_q = q;
+    }
+    int32_t big_grid = 0;
+    const size_t bigb = up256(im::support_big_scratch_bytes(max_t, max_q, n, &big_grid));
+    int rc = ensure_ws(ctx, tb + qb + 2 * ob + rb + bigb);
     if (rc) return rc;
     char* w = static_cast<char*>(ctx->ws);
     uint8_t* d_t = (uint8_t*)w; w += tb;
     uint8_t* d_q = (uint8_t*)w; w += qb;
     int64_t* d_to = (int64_t*)w; w += ob;
     int64_t* d_qo = (int64_t*)w; w += ob;
-    int32_t* d_out = (int32_t*)w;
+    int32_t* d_out = (int32_t*)w; w += rb;
+    void* d_big = (void*)w;
     HIP_TRY(ctx, hipMemcpyAsync(d_t, targets, (size_t)t_off[n], hipMemcpyHostToDevice, ctx->stream));
     HIP_TRY(ctx, hipMemcpyAsync(d_q, queries, (size_t)q_off[n], hipMemcpyHostToDevice, ctx->stream));
     HIP_TRY(ctx, hipMemcpyAsync(d_to, t_off, sizeof(int64_t) * ((size_t)n + 1), hipMemcpyHostToDevice, ctx->stream));
     HIP_TRY(ctx, hipMemcpyAsync(d_qo, q_off, sizeof(int64_t) * ((size_t)n + 1), hipMemcpyHostToDevice, ctx->stream));
-    int64_t max_t = 0;                                           // sizes the kernel's LDS
-    for (int32_t i = 0; i < n; i++) { const int64_t l = t_off[i + 1] - t_off[i]; if (l > max_t) max_t = l; }
-    HIP_TRY(ctx, im::launch_support(n, d_t, d_to, d_q, d_qo, d_out, (int32_t)(max_t > 0x7fffffff ? 0x7fffffff : max_t), ctx->n_cu, ctx->stream));
+    HIP_TRY(ctx, im::launch_support(n, d_t, d_to, d_q, d_qo, d_out, max_t, max_q, d_big, big_grid, ctx->n_cu, ctx->stream));
     HIP_TRY(ctx, hipMemcpyAsync(out, d_out, sizeof(int32_t) * 4 * (size_t)n, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     for (int32_t i = 0; i < n; i++)

@@ -30,6 +30,7 @@ struct RefDev {
 };
 
 constexpr int kShortRead = 255;      // longest read of the four-positions-per-lane kernels (im_realign.hip)
+constexpr int kMaxWaveGaps = 60;     // widest numgaps of the lane-per-diagonal band kernel (a band of 61 diagonals and its two borders in one wave)
 
 struct RealignArgs {
     RefDev      ref;
@@ -85,6 +86,14 @@ hipError_t launch_realign(const RealignArgs& a, int n_cu, hipStream_t stream);
 // im_realign_long.hip: the reads of kShortRead + 1 .. IM_MAX_READ bases of the same batch (numgaps == 0)
 hipError_t launch_realign_long(const RealignArgs& a, int n_cu, hipStream_t stream);
 
+// im_realign_any.hip: the reads the laid-out kernels leave IM_ST_UNSUPPORTED (any length, any band width), one lane per read.
+// pick lists them (all != 0: every read of the batch, which no other kernel has seen) into list[] with counters[0] = how many,
+// [1] = the longest read, [2] = the widest window among them; the caller sizes the arena from those (n_waves waves of 64 lanes).
+hipError_t launch_realign_any_pick(const RealignArgs& a, int all, int32_t* list, int32_t* counters, hipStream_t stream);
+size_t realign_any_arena_bytes(int32_t max_read, int32_t max_window, uint32_t numgaps, int32_t n_waves);
+hipError_t launch_realign_any(const RealignArgs& a, const int32_t* list, int32_t* counters, int32_t* arena,
+                              int32_t max_read, int32_t max_window, int32_t n_waves, hipStream_t stream);
+
 // im_results.hip
 hipError_t launch_compact_results(const im_read_result* res, int32_t n_cap, const int32_t* n_dev, int32_t* status, int32_t* slot,
                                   im_read_result* compact, int32_t* count, int n_cu, hipStream_t stream);
@@ -126,7 +135,11 @@ int64_t depth_tiles(int64_t clen);
 hipError_t launch_depth_query(int32_t nq, const int32_t* beg, const int32_t* end, const int32_t* depth, int64_t clen,
                               uint32_t* out, hipStream_t stream);
 
+// tasks within IM_MAX_SW_TARGET / IM_MAX_READ run in the LDS form; when the batch holds longer ones (big_grid > 0) a second launch
+// with its boundary rows in big_scratch (support_big_scratch_bytes) takes those
+size_t support_big_scratch_bytes(int64_t max_target, int64_t max_query, int32_t n_tasks, int32_t* grid_out);
 hipError_t launch_support(int32_t n_tasks, const uint8_t* targets, const int64_t* t_off,
-                          const uint8_t* queries, const int64_t* q_off, int32_t* out, int32_t max_target, int n_cu, hipStream_t stream);
+                          const uint8_t* queries, const int64_t* q_off, int32_t* out, int64_t max_target, int64_t max_query,
+                          void* big_scratch, int32_t big_grid, int n_cu, hipStream_t stream);
 
 }  // namespace im

@@ -46,60 +46,6 @@ static void print_help(FILE* file)
 
 static void free_range(void* p) { free(p); }
 
-/* The realignment kernels take reads of up to IM_MAX_READ bases, 255 with -g > 0 (include/indelminer_amd.h; the reference has
- * no such bound, src/readaln.c:242-267).  A library of longer reads is turned away here, before any work, rather than at its
- * first long candidate somewhere inside a contig; a stray long read later on still stops the run with its name. */
-static void check_read_lengths(const char* bam_name)
-{
-    bgzf_reader* r = bgzf_open(bam_name);
-    if (!r) return;
-    bam_header* h = bam_header_load(r);
-    if (h) {
-        bam_record b; memset(&b, 0, sizeof b);
-        for (int i = 0; i < 20000 && bam_read_record(r, &b) == 1; i++)
-            if (b.l_seq > (O.numgaps ? 255 : IM_MAX_READ) && (b.flag & (0x100 | 0x800)) == 0)
-                fatalf("%s holds reads of %d bases (%s): this build realigns reads of up to %d bases (IM_MAX_READ, "
-                       "include/indelminer_amd.h)%s", bam_name, (int)b.l_seq, BAMR_QNAME(&b), O.numgaps ? 255 : IM_MAX_READ,
-                       O.numgaps ? " when -g is not 0" : "");
-        free(b.data);
-        bam_header_free(h);
-    }
-    bgzf_close(r);
-}
-
-/* annotate mode: im_support_batch aligns a read against its reference span widened by the indel's size on both sides with
- * the variant applied (check_for_indel, src/variant.c:1427-1556), at most IM_MAX_SW_TARGET bytes.  A variant file with a
- * larger split-read indel is turned away before any work. */
-static void check_known_variants(const char* vcfname)
-{
-    FILE* fp = fopen(vcfname, "r");
-    if (!fp) return;            /* the reference finds that out when it reads the first contig's variants, its header already printed: so here */
-    size_t cap = 2;
-    char* line = xmalloc(cap);
-    while (im_getline(&line, &cap, fp) != -1) {
-        if (line[0] == '#') continue;
-        const char* f = line;
-        size_t flen[5] = {0, 0, 0, 0, 0};
-        for (int c = 0; c < 5 && *f; c++) {                 /* CHROM POS ID REF ALT */
-            while (*f == ' ' || *f == '\t') f++;
-            const char* e = f;
-            while (*e && *e != ' ' && *e != '\t' && *e != '\n') e++;
-            flen[c] = (size_t)(e - f);
-            f = e;
-        }
-        if (strstr(line, "SPLIT_READ") == NULL) continue;      /* only split-read variants are realigned (src/variant.c:1655) */
-        const size_t rl = flen[3], al = flen[4];
-        const size_t indel = rl > al ? rl - al : al - rl;
-        if ((size_t)IM_MAX_READ + 2 * indel + al + 8 > (size_t)IM_MAX_SW_TARGET) {
-            line[flen[0] + flen[1] + 2 < 80 ? flen[0] + flen[1] + 2 : 80] = 0;
-            fatalf("%s: the indel of %zu bases at %s is beyond what annotate mode realigns against (windows of up to %d bytes, "
-                   "IM_MAX_SW_TARGET in include/indelminer_amd.h)", vcfname, indel, line, IM_MAX_SW_TARGET);
-        }
-    }
-    free(line);
-    fclose(fp);
-}
-
 int main(int argc, char** argv)
 {
     t_is_main = 1;
@@ -196,8 +142,6 @@ int main(int argc, char** argv)
     if (!d.hdr) fatalf("%s is not a BAM file", bam_name);
     d.idx = bai_load(bam_name);
     if (!d.idx) fatalf("BAM indexing file is not available.");
-    check_read_lengths(bam_name);
-    if (g_vcfname != NULL) check_known_variants(g_vcfname);
     d.insertlengths = qhash_new(4);
     d.readpairs = qhash_new(20);
 

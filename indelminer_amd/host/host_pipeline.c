@@ -464,12 +464,11 @@ static void host_rg_stat(pgroup* G, const bam_record* b, const uint8_t* rg, int6
 }
 
 /* the host's share of fetch_func for one record: count it, serve the pair table, log what the flush points need */
-/* Reads beyond 255 bases take the realign kernels' second launch (im_expect_read_length, include/indelminer_amd.h): the context
+/* Reads beyond 255 bases take the realign kernels' later launches (im_expect_read_length, include/indelminer_amd.h): the context
  * hears of the longest read so far the moment a walker meets it, i.e. before the group that holds it is launched. */
 static volatile int g_longest_read = 255;
 static void note_long_read(driver* d, int l_seq)
 {
-    if (l_seq > IM_MAX_READ || O.numgaps != 0) return;                 /* the kernel reports such a candidate, the run stops with its name */
     if (im_expect_read_length(d->gpu, l_seq) != IM_OK) fatalf("im_expect_read_length: %s", im_last_error(d->gpu));
     int cur = __atomic_load_n(&g_longest_read, __ATOMIC_RELAXED);
     while (l_seq > cur && !__atomic_compare_exchange_n(&g_longest_read, &cur, l_seq, 1, __ATOMIC_RELAXED, __ATOMIC_RELAXED)) {}
@@ -918,7 +917,7 @@ static void stage_run_group(ppipe* P, pgroup* G)
         if ((st == IM_ST_ABORT || st == IM_ST_OVERFLOW || st == IM_ST_UNSUPPORTED) && g_handoff_pool) pipeline_handoff();
         if (st == IM_ST_ABORT) fatalf("im_dev_realign: read %d: the reference would abort on this input", i);
         if (st == IM_ST_OVERFLOW) fatalf("im_dev_realign: read %d: segment list longer than IM_MAX_OPS", i);
-        if (st == IM_ST_UNSUPPORTED) fatalf("im_dev_realign: read %d: longer than IM_MAX_READ=%d", i, O.numgaps ? 255 : IM_MAX_READ);
+        if (st == IM_ST_UNSUPPORTED) fatalf("im_dev_realign: read %d: left unrealigned (the context was not told of its length)", i);
     }
     free(rstat);
     if (G->sv[0]) { if (getenv("INDELMINER_TIDY_EXIT") || g_free_slabs) im_dev_free(g, G->sv[0]); G->sv[0] = NULL; }

@@ -202,7 +202,6 @@ static void* walker_thread(void* arg)
             /* a record the reference dies on ends this walker: the claim is published as it is, marked */
             W->cur_claim = c;
             if (setjmp(W->abort_jmp)) {
-                const int cj = (int)(W->cur_claim - o->claims);
                 pthread_mutex_lock(&o->mu);
                 W->cur_claim->G = NULL; W->cur_claim->aborted = 1; W->cur_claim->walked = 1;
                 pthread_cond_broadcast(&o->cv);

@@ -567,7 +567,8 @@ int bam_region_begin(bam_region_iter* it, bgzf_reader* r, const bai_index* idx, 
 {
     memset(it, 0, sizeof *it);
     it->r = r; it->tid = tid; it->beg = beg < 0 ? 0 : beg; it->end = end;
-    if (!idx || tid < 0 || tid >= idx->n_ref || end < it->beg) { it->done = 1; return 0; }
+    /* an empty interval meets no bin (reg2bins returns 0 for beg >= end, bam_index.c:559): bam_fetch(beg == end) delivers nothing */
+    if (!idx || tid < 0 || tid >= idx->n_ref || end <= it->beg) { it->done = 1; return 0; }
     const bai_ref* br = &idx->ref[tid];
     if (br->first_chunk == 0) { it->done = 1; return 0; }        /* no record on this contig */
     /* smallest offset of any record overlapping the 16 kb window of beg (bam_index.c:605-615);

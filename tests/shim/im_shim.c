@@ -46,7 +46,7 @@ int im_dev_compact_results(im_ctx* c, const im_read_result* res, int32_t n, cons
     return IM_OK;
 }
 
-int im_expect_read_length(im_ctx* c, int32_t max_len) { (void)c; return max_len > IM_MAX_READ ? IM_E_UNSUPPORTED : IM_OK; }   /* the oracle has one path for every length */
+int im_expect_read_length(im_ctx* c, int32_t max_len) { (void)c; (void)max_len; return IM_OK; }   /* the oracle has one path for every length */
 
 int im_realign_batch(im_ctx* c, const im_params* p, const im_read_batch* b, im_read_result* out)
 {

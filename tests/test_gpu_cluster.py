@@ -217,6 +217,42 @@ def test_support_sw_matches_oracle(gpu_ctx):
         assert tuple(got[k][:3]) == (s.value, i.value, a.value), (k, len(t), len(q), tuple(got[k]), (s.value, i.value, a.value))
 
 
+def test_support_sw_long_windows_and_queries(gpu_ctx):
+    """Windows beyond IM_MAX_SW_TARGET and queries beyond IM_MAX_READ (the reference takes any, src/variant.c:1246-1424): the
+    support kernel's second form -- boundary row in device memory, 64-bit packed statistics -- in one batch with tasks of the LDS form"""
+    import ctypes as C
+    from indelminer_amd import capi
+    from tests.support import oraclebind as ob
+    L = ob.lib()
+    rng = np.random.default_rng(77)
+    targets, queries = [], []
+    shapes = [(4096, 100), (5100, 100), (13000, 150), (9000, 300), (3000, 1021), (6000, 1500), (2000, 2600), (200, 100), (1500, 255), (4095, 1020), (20000, 64)]
+    for it in range(40):
+        len1, len2 = shapes[it % len(shapes)]
+        t = rng.choice(list(b"ACGT"), size=len1).astype(np.uint8)
+        p = int(rng.integers(0, max(1, len1 - len2)))
+        q = t[p:p + len2].copy()
+        if len(q) < len2:
+            q = np.concatenate([q, rng.choice(list(b"ACGT"), size=len2 - len(q)).astype(np.uint8)])
+        if it % 3 == 0:
+            cut = int(rng.integers(5, len2 - 5)); d = int(rng.integers(1, 30))
+            q = np.concatenate([q[:cut], q[cut + d:], rng.choice(list(b"ACGT"), size=d).astype(np.uint8)])
+        elif it % 3 == 1:
+            cut = int(rng.integers(5, len2 - 5)); d = int(rng.integers(1, 30))
+            q = np.concatenate([q[:cut], rng.choice(list(b"ACGT"), size=d).astype(np.uint8), q[cut:]])[:len2]
+        sub = rng.random(len(q)) < rng.choice([0, 0.02, 0.1])
+        q[sub] = rng.choice(list(b"ACGT"), size=int(sub.sum())).astype(np.uint8)
+        targets.append(t.tobytes()); queries.append(q.tobytes())
+    got = gpu_ctx.support_batch(targets, queries)
+    n_big = 0
+    for k, (t, q) in enumerate(zip(targets, queries)):
+        s, i, a = C.c_int32(), C.c_int32(), C.c_int32()
+        L.imo_sw_indel(t, len(t), q, len(q), C.byref(s), C.byref(i), C.byref(a))
+        assert tuple(got[k][:3]) == (s.value, i.value, a.value) and got[k][3] == capi.ST_EVIDENCE, (k, len(t), len(q), tuple(got[k]), (s.value, i.value, a.value))
+        n_big += len(t) > 4095 or len(q) > capi.MAX_READ
+    assert n_big >= 20
+
+
 def test_cluster_kernels_match_reference_process_evidence(gpu_ctx):
     """the device cluster path against vectors the reference's own process_evidence produced (tests/golden/units_cluster.json)"""
     import json

@@ -759,20 +759,25 @@ def test_host_takes_a_2x300_library(tmp_path):
     _long_read_library(_build_shim(), tmp_path, envs=({}, {"INDELMINER_PIECE_BYTES": "150000", "INDELMINER_WALKERS": "3"}))
 
 
-def _rejects_long_reads(binary, tmp_path):
-    """reads beyond IM_MAX_READ (1020; 255 with -g > 0): the reference has no bound (src/readaln.c:242-267), the kernels do --
-    the driver says so before any work instead of dying at the first long candidate inside a contig"""
-    (tmp_path / "a").mkdir(); (tmp_path / "b").mkdir()
-    d = _long_read_dir(tmp_path / "a", read_len=1100)
-    r = subprocess.run([binary, "-i", "cfg.txt", "ref.fa", "s=aln.bam"], cwd=d, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
-    assert r.returncode != 0 and b"IM_MAX_READ" in r.stderr and b"1100 bases" in r.stderr and r.stdout == b""
-    d = _long_read_dir(tmp_path / "b", read_len=300)
-    r = subprocess.run([binary, "-i", "cfg.txt", "-g", "2", "ref.fa", "s=aln.bam"], cwd=d, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
-    assert r.returncode != 0 and b"IM_MAX_READ" in r.stderr and b"300 bases" in r.stderr and b"-g is not 0" in r.stderr and r.stdout == b""
+def _beyond_the_laid_out_kernels(binary, tmp_path, envs=({},)):
+    """reads beyond 1020 bases, reads beyond 255 bases with -g > 0, bands wider than a wave (-g > 60): the reference has no bound
+    (src/readaln.c:242-267, src/indelminer.c:934,948) and until round 4 the driver turned such runs away at start-up; they take
+    the realign kernels' general pass now (im_realign_any.hip) and the run must print what the reference prints"""
+    shim = _build_shim()
+    ref_bin = os.path.join(ROOT, "oracle", "_ref", "indelminer")
+    for sub, read_len, flags in (("a", 1100, []), ("b", 300, ["-g", "2"]), ("c", 150, ["-g", "80"]), ("d", 1400, ["-g", "3", "-k", "8"])):
+        (tmp_path / sub).mkdir()
+        d = _long_read_dir(tmp_path / sub, read_len=read_len, ref_len=60_000, coverage=12 if read_len < 1000 else 20, seed=40 + read_len)
+        want = _run(shim, ["-i", "cfg.txt"] + flags, d, ref="ref.fa", bam="aln.bam", env={"INDELMINER_PIPELINE": "host"})
+        assert want.count(b"SPLIT_READ") > 5, (sub, want.count(b"SPLIT_READ"))
+        if os.path.exists(ref_bin):
+            assert _run(ref_bin, ["-i", "cfg.txt"] + flags, d, ref="ref.fa", bam="aln.bam") == want, sub
+        for env in envs:
+            assert _run(binary, ["-i", "cfg.txt"] + flags, d, ref="ref.fa", bam="aln.bam", env=env) == want, (sub, env)
 
 
-def test_host_rejects_long_read_library_at_startup(tmp_path):
-    _rejects_long_reads(_build_shim(), tmp_path)
+def test_host_runs_beyond_the_laid_out_kernels(tmp_path):
+    _beyond_the_laid_out_kernels(_build_shim(), tmp_path, envs=({}, {"INDELMINER_PIECE_BYTES": "150000", "INDELMINER_WALKERS": "3"}))
 
 
 def _coverage_dir(tmp_path):
@@ -827,16 +832,41 @@ def test_host_coverage_table(tmp_path):
                                               {"INDELMINER_PIECE_BYTES": "60000", "INDELMINER_WALKERS": "3", "INDELMINER_ONEPASS": "1"}))
 
 
-def test_host_rejects_oversized_known_indel_at_startup(tmp_path):
-    """annotate mode realigns reads against windows of up to IM_MAX_SW_TARGET bytes: a split-read deletion of 2500 bases in
-    the variant file is named at startup (the reference's own line buffers are sized by -s, src/variant.c:853-856)"""
+def _large_known_indels(binary, tmp_path, envs=({},)):
+    """annotate mode with split-read indels far beyond what discovery reports with the default -s: the reference realigns every
+    overlapping read against its span widened by the indel on both sides (src/variant.c:1246-1312: any size up to -p), i.e. windows
+    of 5 to 13 kb here -- beyond the LDS form of the support kernel (IM_MAX_SW_TARGET), which until round 4 made the driver turn
+    the variant file away.  Known deletions of 2500 / 6000 bases and an insertion of 1800 in the reference's own test data."""
+    from tests.support import bamlite
+    _, seqs = bamlite.read_fasta(os.path.join(TD, "reference.fa"))
+    seq = seqs[0]
+    ins = "".join("ACGT"[(i * 7 + i // 3) % 4] for i in range(1800))
     vcf = tmp_path / "known.vcf"
-    vcf.write_text("##fileformat=VCFv4.1\n#CHROM\tPOS\tID\tREF\tALT\tQUAL\tFILTER\tINFO\n"
-                   "reference\t1000\t.\t%s\tA\t.\t.\tDELETION;SPLIT_READ;NS=3;END=3500;BP_END=3500;UTAILS=3\n" % ("A" * 2501))
-    r = subprocess.run([_build_shim(), "-i", "indelminer.config", "-s", "3000", "reference.fa", str(vcf), "s=alignments.bam"], cwd=TD,
-                       stdout=subprocess.PIPE, stderr=subprocess.PIPE)
-    assert r.returncode != 0 and b"IM_MAX_SW_TARGET" in r.stderr and b"2500 bases" in r.stderr
-    assert r.stdout == b""
+    lines = ["##fileformat=VCFv4.1", "#CHROM\tPOS\tID\tREF\tALT\tQUAL\tFILTER\tINFO"]
+    for pos, dl in ((1000, 2500), (6000, 6000)):
+        lines.append("reference\t%d\t.\t%s\t%s\t.\t.\tDELETION;SPLIT_READ;NS=3;END=%d;BP_END=%d;UTAILS=3"
+                     % (pos, seq[pos - 1:pos + dl], seq[pos - 1], pos + dl, pos + dl))
+    lines.append("reference\t14000\t.\t%s\t%s\t.\t.\tINSERTION;SPLIT_READ;NS=4;END=14001;BP_END=14001;UTAILS=4" % (seq[13999], seq[13999] + ins))
+    # END == POS: bam_fetch over an empty interval delivers no read (reg2bins, bam_index.c:559), the variant stays unsupported
+    lines.append("reference\t15000\t.\t%s\t%s\t.\t.\tINSERTION;SPLIT_READ;NS=4;END=15000;BP_END=15000;UTAILS=4" % (seq[14999], seq[14999] + ins[:30]))
+    vcf.write_text("\n".join(lines) + "\n")
+    flags = ["-i", "indelminer.config", "-q", "0", "-a", "-e", "1", "reference.fa", str(vcf), "normal=alignments.bam"]
+    def run(b, env=None):
+        r = subprocess.run([b] + flags, cwd=TD, stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=dict(os.environ, **(env or {})))
+        assert r.returncode == 0, r.stderr[-600:]
+        return r.stdout
+    want = run(_build_shim(), {"INDELMINER_PIPELINE": "host"})
+    assert len([ln for ln in want.split(b"\n") if ln and not ln.startswith(b"#")]) == 4
+    ref_bin = os.path.join(ROOT, "oracle", "_ref", "indelminer")
+    if os.path.exists(ref_bin):
+        assert run(ref_bin) == want
+    for env in envs:
+        assert run(binary, env) == want, env
+
+
+def test_host_takes_large_known_indels(tmp_path):
+    _large_known_indels(_build_shim(), tmp_path)
+
 
 
 # ---------------------------------------------------------------- product binary on the GPU
@@ -904,8 +934,8 @@ def test_product_contigs_walked_in_pieces_and_region_runs(synth_small, synth_1mb
 
 
 @pytest.mark.gpu
-def test_product_rejects_long_read_library_at_startup(tmp_path):
-    _rejects_long_reads(_product(), tmp_path)
+def test_product_runs_beyond_the_laid_out_kernels(tmp_path):
+    _beyond_the_laid_out_kernels(_product(), tmp_path, envs=({}, {"INDELMINER_PIECE_BYTES": "150000", "INDELMINER_WALKERS": "3"}, {"INDELMINER_PIPELINE": "host"}))
 
 
 @pytest.mark.gpu
@@ -952,10 +982,17 @@ def test_product_synthetic(synth_small, synth_1mb):
 
 
 @pytest.mark.gpu
-def test_product_refuses_out_of_range_band_loudly():
-    r = subprocess.run([_product(), "-i", "indelminer.config", "-g", "200", "reference.fa", "s=alignments.bam"], cwd=TD,
-                       stdout=subprocess.PIPE, stderr=subprocess.PIPE)
-    assert r.returncode != 0 and b"numgaps" in r.stderr
+def test_product_takes_a_band_wider_than_a_wave():
+    """-g 200 on the reference's own test data: every candidate through the general pass, output = the CPU shim's"""
+    want = _run(_build_shim(), ["-i", "indelminer.config", "-g", "200"], TD, env={"INDELMINER_PIPELINE": "host"})
+    assert want.count(b"\n") > 30
+    assert _run(_product(), ["-i", "indelminer.config", "-g", "200"], TD) == want
+
+
+
+@pytest.mark.gpu
+def test_product_takes_large_known_indels(tmp_path):
+    _large_known_indels(_product(), tmp_path, envs=({}, {"INDELMINER_PIPELINE": "host"}))
 
 
 @pytest.mark.gpu
