@@ -42,7 +42,7 @@ extern "C" {
 #define IM_ST_EVIDENCE    1     /* segment list + n_ev >= 1 evidence records valid   */
 #define IM_ST_ABORT      -1     /* the reference would have exited on this read      */
 #define IM_ST_OVERFLOW   -2
-#define IM_ST_UNSUPPORTED -3    /* e.g. read longer than IM_MAX_READ, or than 255 bases without im_expect_read_length */
+#define IM_ST_UNSUPPORTED -3    /* a read beyond 255 bases when im_expect_read_length was not told of it; base_off not a multiple of 4 */
 
 /* CIGAR op codes in packed words (len<<4|op): samtools bam.h + src/readaln.h:10-11 */
 #define IM_OP_M  0
@@ -52,9 +52,11 @@ extern "C" {
 #define IM_OP_EQ 7
 #define IM_OP_X  8
 
-#define IM_MAX_READ  1020       /* longest read the realign kernels take (numgaps == 0; 255 with numgaps > 0);
-                                   reads beyond 255 bases run in a second kernel, see im_expect_read_length */
-#define IM_MAX_SW_TARGET 4095   /* longest annotate-mode window (reference span + variant) im_support_batch takes */
+#define IM_MAX_READ  1020       /* longest read of the LAID-OUT realign kernels (numgaps == 0; 255 with numgaps > 0); longer
+                                   reads -- the reference takes any, src/readaln.c:242-267 -- run in a general pass behind them,
+                                   see im_expect_read_length */
+#define IM_MAX_SW_TARGET 4095   /* longest annotate-mode window (reference span + variant) of im_support_batch's LDS form; longer
+                                   windows and queries beyond IM_MAX_READ run in its second form */
 #define IM_MAX_OPS   64         /* packed segment words per realigned read           */
 #define IM_MAX_EV    4          /* indel segments (= evidence) per realigned read    */
 
@@ -188,8 +190,8 @@ int im_depth_query(im_ctx* ctx, int32_t n, const int32_t* beg, const int32_t* en
  * the caller exactly as 1260-1272 do) and returns the three counts check_for_indel compares with
  * the read's existing alignment (1549-1553): substitutions, inserted+deleted bases, aligned bases.
  * targets/queries: concatenated bytes with n+1 offsets.  out: n x 4 int32 {subs, indels, aligned,
- * status (IM_ST_EVIDENCE = valid, IM_ST_UNSUPPORTED = target longer than IM_MAX_SW_TARGET or query longer
- * than IM_MAX_READ)}. */
+ * status (IM_ST_EVIDENCE = valid; IM_ST_UNSUPPORTED only for a query beyond 2^20 bases)}.  Targets and queries of any
+ * length: within IM_MAX_SW_TARGET / IM_MAX_READ the task runs with its boundary row in LDS, beyond in device memory. */
 int im_support_batch(im_ctx* ctx, int32_t n,
                      const uint8_t* targets, const int64_t* t_off,
                      const uint8_t* queries, const int64_t* q_off, int32_t* out);
@@ -222,13 +224,15 @@ typedef struct im_dev_batch {
 int im_dev_realign(im_ctx* ctx, const im_params* params,
                    const im_dev_batch* batch, void* stream);
 
-/* The reference realigns reads of any length (src/readaln.c:242-267).  Here reads of up to 255 bases run in the
- * kernel laid out for them (four read positions per lane); reads of 256 .. IM_MAX_READ bases (2 x 300 chemistry)
- * take a second launch with sixteen positions per lane, which every im_dev_realign* call issues behind the first
- * once the context has been told that such reads occur: max_len = the longest read seen so far (the value only
- * ever grows; callable from any thread).  im_realign (host buffers) calls it by itself.  Without the call such a
- * read comes back IM_ST_UNSUPPORTED, as does any read beyond 255 bases when numgaps > 0.
- * Returns IM_E_UNSUPPORTED for max_len > IM_MAX_READ. */
+/* The reference realigns reads of any length with a band of any width (src/readaln.c:242-267, src/indelminer.c:934,948).
+ * Here reads of up to 255 bases run in the kernels laid out for them (four read positions per lane; numgaps <= 60: a lane
+ * per band diagonal); reads of 256 .. IM_MAX_READ bases at numgaps == 0 (2 x 300 chemistry) take a second launch with
+ * sixteen positions per lane; reads beyond IM_MAX_READ, reads beyond 255 bases with numgaps > 0, and every read when
+ * numgaps > 60 take a general pass (one lane per read, its state in device memory; it synchronises the stream once and
+ * cannot be captured into a launch graph).  Every im_dev_realign* call issues the later launches behind the first once the
+ * context has been told that such reads occur: max_len = the longest read seen so far (the value only ever grows; callable
+ * from any thread).  im_realign_batch (host buffers) calls it by itself.  Without the call a read beyond 255 bases comes
+ * back IM_ST_UNSUPPORTED. */
 int im_expect_read_length(im_ctx* ctx, int32_t max_len);
 
 /* The results' trip to the host.  attempt_pe_alignment returns NULL for most candidates (src/alignment.c:764-799), and the

@@ -529,7 +529,7 @@ int im_depth_enable(im_ctx* ctx)
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     int64_t tiles = 0;
     ctx->h_sums_off.clear();
-    for (int32_t l : ctx->h_len) { ctx->h_sums_off.push_back(tiles); tiles += im::depth_tiles(l) + 1; }
+    for (int32_t l : ctx->h_len) { ctx->h_sums_off.push_back(tiles); tiles += im::depth_sums_ints(l); }
     HIP_TRY(ctx, hipMalloc((void**)&ctx->gdepth, (size_t)ctx->ref_total * sizeof(int32_t)));
     HIP_TRY(ctx, hipMalloc((void**)&ctx->gdepth_sums, (size_t)(tiles + 1) * sizeof(int32_t)));
     HIP_TRY(ctx, hipMemsetAsync(ctx->gdepth, 0, (size_t)ctx->ref_total * sizeof(int32_t), ctx->stream));

@@ -132,6 +132,7 @@ hipError_t launch_gather_evidence(const im_read_result* res, int32_t n,
 hipError_t launch_depth_build(int64_t clen, int32_t n_seg, const int32_t* seg_start, const int32_t* seg_len,
                               int32_t* depth, int32_t* sums, hipStream_t stream);
 int64_t depth_tiles(int64_t clen);
+int64_t depth_sums_ints(int64_t clen);
 hipError_t launch_depth_query(int32_t nq, const int32_t* beg, const int32_t* end, const int32_t* depth, int64_t clen,
                               uint32_t* out, hipStream_t stream);
 

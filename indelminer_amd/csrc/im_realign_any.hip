@@ -39,6 +39,7 @@ enum : int { kKindEq = 0, kKindX = 1, kKindI = 2, kKindNone = 3 };
 // arena layout in words per lane (the same function sizes the arena on the host)
 struct AnyLayout {
     int32_t maxM, maxW, maxB, hslots;
+    int32_t rows_in_lds;        // 1: o_cc .. o_dp index the wave's LDS block (from 0), not the arena
     int32_t o_hkey, o_hpos, o_hcnt, o_diag, o_cc, o_dd, o_cp, o_dp, o_mp0, o_mp1, o_mp2, o_fp, o_pos0, o_pos1, o_ops0, o_ops1, o_fin, o_stk;
     int32_t words;
 };
@@ -53,7 +54,10 @@ __host__ __device__ inline AnyLayout make_layout(int32_t maxM, int32_t maxW, int
     auto take = [&](int32_t n) { const int32_t o = at; at += n; return o; };
     y.o_hkey = take(h); y.o_hpos = take(h); y.o_hcnt = take(h);
     y.o_diag = take(maxW + maxM + 8);
-    y.o_cc = take(maxB + 4); y.o_dd = take(maxB + 4); y.o_cp = take(maxB + 4); y.o_dp = take(maxB + 4);
+    // the four rows: 4 * (maxB + 4) words per lane, 256 bytes per word over the wave; in LDS up to 64 KiB of it
+    y.rows_in_lds = (size_t)4 * (size_t)(maxB + 4) * 256u <= ((size_t)64 << 10) ? 1 : 0;
+    if (y.rows_in_lds) { y.o_cc = 0; y.o_dd = maxB + 4; y.o_cp = 2 * (maxB + 4); y.o_dp = 3 * (maxB + 4); }
+    else { y.o_cc = take(maxB + 4); y.o_dd = take(maxB + 4); y.o_cp = take(maxB + 4); y.o_dp = take(maxB + 4); }
     y.o_mp0 = take(maxM + 2); y.o_mp1 = take(maxM + 2); y.o_mp2 = take(maxM + 2); y.o_fp = take(maxM + 2);
     y.o_pos0 = take(maxM + 2); y.o_pos1 = take(maxM + 2);       // per read position: kind | reference bases skipped in front << 2
     y.o_ops0 = take(IM_MAX_OPS + 4); y.o_ops1 = take(IM_MAX_OPS + 4); y.o_fin = take(IM_MAX_OPS + 4);
@@ -62,11 +66,15 @@ __host__ __device__ inline AnyLayout make_layout(int32_t maxM, int32_t maxW, int
     return y;
 }
 
-// one lane's view of its arena
+// one lane's view of its arena.  The four rows of the banded passes (CC / DD / CP / DP: the arrays every cell of the dynamic
+// programs reads and writes) live in LDS when the band is narrow enough for 64 lanes' rows to fit -- the launch decides --
+// and in the arena otherwise: q is that home, lane-interleaved like the arena (offsets o_cc .. then count from 0).
 struct Ar {
     int32_t* p;
+    int32_t* q;
     __device__ __forceinline__ int32_t& at(int32_t off, int32_t i) const { return p[(int64_t)(off + i) << 6]; }
     __device__ __forceinline__ uint32_t& atu(int32_t off, int32_t i) const { return reinterpret_cast<uint32_t*>(p)[(int64_t)(off + i) << 6]; }
+    __device__ __forceinline__ int32_t& row(int32_t off, int32_t i) const { return q[(int64_t)(off + i) << 6]; }
 };
 
 __device__ __forceinline__ int wsub(uint32_t a, uint32_t b) { return a == b ? kScoreMatch : kScoreMismatch; }   // W[i][j], src/localalign.c:61-67
@@ -177,10 +185,10 @@ __device__ Fwd any_global_forward(const Ar& a, const AnyLayout& Y, const uint8_t
     Fwd o; o.rmid = low + midd - 1;
     int leftd = 1 - low, rightd = up - low + 1;
     int c = 0, d = 0, e = 0, IP = 0;
-#define CC(i) a.at(Y.o_cc, (i))
-#define DD(i) a.at(Y.o_dd, (i))
-#define CP(i) a.at(Y.o_cp, (i))
-#define DP(i) a.at(Y.o_dp, (i))
+#define CC(i) a.row(Y.o_cc, (i))
+#define DD(i) a.row(Y.o_dd, (i))
+#define CP(i) a.row(Y.o_cp, (i))
+#define DP(i) a.row(Y.o_dp, (i))
 #define MP0(i) a.at(Y.o_mp0, (i))
 #define MP1(i) a.at(Y.o_mp1, (i))
 #define MP2(i) a.at(Y.o_mp2, (i))
@@ -428,8 +436,19 @@ __device__ AnyAln any_band_alignment(const Ar& a, const AnyLayout& Y, const uint
     if (up2 - lo2 + 1 <= 1) {                                                         // 358-365
         for (int i = 1; i <= Ma; i++) { score += wsub(A0[i], B0[i]); s_rep(a, S, A0, B0); }
     } else {
-        const int st = any_global_align(a, Y, S, A0, B0, Ma, Na, lo2, up2, &score);
-        if (st) { r.st = st; return r; }
+        // Equal lengths and at most three mismatches on the main diagonal: that alignment is the ONLY optimal one -- any other
+        // path between the same corners holds at least one inserted and one deleted base (two gaps, 40 or more) and at most
+        // Ma - 1 matches, so it scores below Ma - 41 < Ma - 11 * 3 -- and ALIGN, which returns an optimal alignment inside the
+        // band (diagonal 0 always lies in it: lo2 <= 0 <= up2), can only come back with it: the divide and conquer is skipped.
+        int mm = 4;
+        if (Ma == Na) { mm = 0; for (int i = 1; i <= Ma && mm <= 3; i++) mm += A0[i] != B0[i] ? 1 : 0; }
+        if (mm <= 3) {
+            for (int i = 1; i <= Ma; i++) s_rep(a, S, A0, B0);
+            score = Ma * kScoreMatch + mm * (kScoreMismatch - kScoreMatch);
+        } else {
+            const int st = any_global_align(a, Y, S, A0, B0, Ma, Na, lo2, up2, &score);
+            if (st) { r.st = st; return r; }
+        }
     }
     if (score <= 0) return r;                                                         // src/alignment.c:365-372
     // fetch_cigar (507-604): [AP S] runs [tail S]; deletion lengths count into the consumed total as there (541-595)
@@ -724,8 +743,10 @@ __global__ __launch_bounds__(256) void any_pick_kernel(RealignArgs A, int all, i
 
 __global__ __launch_bounds__(64) void realign_any_kernel(RealignArgs A, const int32_t* list, int32_t* counters, int32_t* arena, AnyLayout Y)
 {
+    extern __shared__ int32_t s_rows[];
     const int lane = threadIdx.x;
     Ar a; a.p = arena + (int64_t)blockIdx.x * Y.words * 64 + lane;
+    a.q = Y.rows_in_lds ? s_rows + lane : a.p;
     const int n = counters[0];
     // a lane claims the next read of the list when it is done with one: reads differ in cost by orders of magnitude
     for (;;) {
@@ -758,7 +779,14 @@ hipError_t launch_realign_any(const RealignArgs& a, const int32_t* list, int32_t
                               int32_t max_read, int32_t max_window, int32_t n_waves, hipStream_t stream)
 {
     const AnyLayout y = make_layout(max_read, max_window, (int32_t)a.P.numgaps + 1);
-    hipLaunchKernelGGL(realign_any_kernel, dim3(n_waves), dim3(64), 0, stream, a, list, counters, arena, y);
+    const size_t lds = y.rows_in_lds ? (size_t)4 * (size_t)(y.maxB + 4) * 256u : 0;
+    static size_t attr_bytes = 0;
+    if (lds > attr_bytes) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(realign_any_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 64 << 10);
+        if (e != hipSuccess) return e;
+        attr_bytes = (size_t)64 << 10;
+    }
+    hipLaunchKernelGGL(realign_any_kernel, dim3(n_waves), dim3(64), lds, stream, a, list, counters, arena, y);
     return hipGetLastError();
 }
 

@@ -29,6 +29,8 @@ namespace im {
 namespace {
 
 constexpr int kTriBlock = 256;
+constexpr int kTriGroup = 32;           // workgroups that count their publication into one word (see the classify kernel's tail)
+constexpr int kTriGroupsMax = 2048;
 
 __device__ __forceinline__ uint32_t ld_u32(const uint8_t* p) { uint32_t v; __builtin_memcpy(&v, p, 4); return v; }
 __device__ __forceinline__ uint32_t ld_u16(const uint8_t* p) { uint16_t v; __builtin_memcpy(&v, p, 2); return v; }
@@ -379,8 +381,12 @@ struct TriageArgs {
     int32_t* depth_diff;    // genome-wide difference array (index = ascii offset of the position) or null
     uint32_t* info;         // [n] class | revcomp << 8
     int32_t* rmax;          // [n]
-    uint2* blk;             // [blocks] candidates, padded read bytes -> exclusive bases after the scan
-    uint32_t* blocks_done;  // [1] zero between launches: the workgroup that finishes last scans blk[]
+    uint2* blk;             // [blocks] one packed word per workgroup: padded read bytes << 32 | candidates | counted << 9 | errors << 18
+    uint32_t* blocks_done;  // [1] zero between launches: groups of workgroups that are complete; the group that comes last scans grp[]
+    uint32_t* grp_done;     // [kTriGroupsMax] zero between launches: workgroups of a group that have published their totals
+    unsigned long long* grp;// [2 * groups] a group's totals: bytes << 32 | candidates, counted << 32 | errors
+    uint2* grp_base;        // [groups] candidates / bytes in front of a group (running counters included), written by the last group
+    int32_t group_size;     // workgroups per group
     uint32_t* seq_at;       // [cap_cand] byte offset of a candidate's packed bases in recs.raw, | 1 << 31 = reverse complement
     int32_t* chunk_base;    // [1] candidates before this chunk (written by the scan)
 };
@@ -505,24 +511,51 @@ __global__ __launch_bounds__(kTriBlock) void triage_classify_kernel(TriageArgs A
             if (v != 0 && idx < room) atomicAdd(&dst[idx], v);
         }
     }
-    __shared__ uint32_t s_last;
+    // Publication.  A workgroup's totals go out with a RETURNING agent-scope atomic and are counted only once the return is
+    // in: the count cannot overtake the totals, and no fence is needed (an agent-scope fence is a whole-L2 write-back per
+    // workgroup on this chip, profiles/README.md).  The counting is in two levels: a thousand workgroups adding to ONE word
+    // took 12 of the kernel's 36 us (same-address atomics are served one after the other, ~9 ns each; measured by leaving the
+    // tail out, profiles/r04_d_*), so a workgroup counts into its GROUP's word, the workgroup that completes a group adds the
+    // group's totals up and counts the group, and the workgroup that completes the last group scans the groups.
+    __shared__ uint32_t s_role;
+    const int32_t n_blocks = (int32_t)gridDim.x;
+    const int32_t gsz = A.group_size, g = (int32_t)blockIdx.x / gsz, g_first = g * gsz;
+    const int32_t g_n = min(gsz, n_blocks - g_first), n_groups = (n_blocks + gsz - 1) / gsz;
     if (t == 0) {
         uint32_t c = 0, b = 0, k = 0, e = 0;
         for (int wv = 0; wv < kTriBlock / 64; wv++) { c += s_cnt[wv]; b += s_bytes[wv]; k += s_counted[wv]; e += s_err[wv]; }
-        // Published with a RETURNING agent-scope atomic and counted only once the return is in: the count below cannot
-        // overtake the totals, and no fence is needed (an agent-scope fence is a whole-L2 write-back per workgroup on
-        // this chip, profiles/README.md).
         // one word per workgroup: padded read bytes | candidates, counted records and error records (each <= 256: 9 bits)
         unsigned long long seen = atomicExch(reinterpret_cast<unsigned long long*>(&A.blk[blockIdx.x]),
                                              ((unsigned long long)b << 32) | c | (k << 9) | (e << 18));
         asm volatile("" :: "v"(seen));
-        s_last = atomicAdd(A.blocks_done, 1u) == gridDim.x - 1u ? 1u : 0u;
+        s_role = atomicAdd(&A.grp_done[g], 1u) == (uint32_t)g_n - 1u ? 1u : 0u;
     }
     __syncthreads();
-    if (!s_last) return;
-    // Last workgroup to finish: exclusive scan of the workgroup totals on top of the running counters (candidates are
-    // appended in record order).  One launch less than a scan kernel of its own; a few thousand totals at most, read
-    // back through the same atomic path they were published on.
+    if (!s_role) return;
+    // last workgroup of its group: the group's totals (the members' words come back through the atomic path they went out on)
+    if (t < 64) {
+        unsigned long long cb = 0, ke = 0;
+        for (int32_t j = t; j < g_n; j += 64) {
+            const unsigned long long pv = atomicAdd(reinterpret_cast<unsigned long long*>(&A.blk[g_first + j]), 0ull);
+            cb += (pv & 0xFFFFFFFF00000000ull) | ((uint32_t)pv & 511u);
+            ke += ((unsigned long long)(((uint32_t)pv >> 9) & 511u) << 32) | (((uint32_t)pv >> 18) & 511u);
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            cb += ((unsigned long long)(uint32_t)__shfl_xor((int)(uint32_t)(cb >> 32), o) << 32) | (uint32_t)__shfl_xor((int)(uint32_t)cb, o);
+            ke += ((unsigned long long)(uint32_t)__shfl_xor((int)(uint32_t)(ke >> 32), o) << 32) | (uint32_t)__shfl_xor((int)(uint32_t)ke, o);
+        }
+        if (t == 0) {
+            unsigned long long s0 = atomicExch(&A.grp[2 * g], cb), s1 = atomicExch(&A.grp[2 * g + 1], ke);
+            asm volatile("" :: "v"(s0), "v"(s1));
+            atomicExch(&A.grp_done[g], 0u);                                     // ready for the next launch
+            s_role = atomicAdd(A.blocks_done, 1u) == (uint32_t)n_groups - 1u ? 2u : 0u;
+        }
+    }
+    __syncthreads();
+    if (s_role != 2u) return;
+    // Last group to complete: exclusive scan of the groups' totals on top of the running counters (candidates are appended in
+    // record order).  A few hundred totals at most; the emit kernel adds the workgroups in front of it inside its group.
     __shared__ uint32_t wc[kTriBlock / 64], wbb[kTriBlock / 64];
     __shared__ uint32_t carry_c, carry_b, s_ke[2];
     // restart: this launch opens a new batch -- the running counters count as zero whatever they hold (no memset in front)
@@ -534,15 +567,13 @@ __global__ __launch_bounds__(kTriBlock) void triage_classify_kernel(TriageArgs A
     }
     uint32_t sum_k = 0, sum_e = 0;
     __syncthreads();
-    const int32_t n_blocks = (int32_t)gridDim.x;
-    uint2* blk = A.blk;
-    for (int32_t base = 0; base < n_blocks; base += kTriBlock) {
+    for (int32_t base = 0; base < n_groups; base += kTriBlock) {
         const int32_t j = base + t;
         uint2 v = make_uint2(0u, 0u);
-        if (j < n_blocks) {
-            const unsigned long long pv = atomicAdd(reinterpret_cast<unsigned long long*>(&blk[j]), 0ull);
-            v.x = (uint32_t)pv & 511u; v.y = (uint32_t)(pv >> 32);
-            sum_k += ((uint32_t)pv >> 9) & 511u; sum_e += ((uint32_t)pv >> 18) & 511u;
+        if (j < n_groups) {
+            const unsigned long long cb = atomicAdd(&A.grp[2 * j], 0ull), ke = atomicAdd(&A.grp[2 * j + 1], 0ull);
+            v.x = (uint32_t)cb; v.y = (uint32_t)(cb >> 32);
+            sum_k += (uint32_t)(ke >> 32); sum_e += (uint32_t)ke;
         }
         uint32_t c = v.x, b = v.y;
 #pragma unroll
@@ -554,10 +585,10 @@ __global__ __launch_bounds__(kTriBlock) void triage_classify_kernel(TriageArgs A
         __syncthreads();
         uint32_t oc = 0, ob = 0;
         for (int wv = 0; wv < wave; wv++) { oc += wc[wv]; ob += wbb[wv]; }
-        const uint32_t cc = carry_c, cb = carry_b;
-        if (j < n_blocks) blk[j] = make_uint2(cc + oc + c - v.x, cb + ob + b - v.y);
+        const uint32_t cc = carry_c, cb0 = carry_b;
+        if (j < n_groups) A.grp_base[j] = make_uint2(cc + oc + c - v.x, cb0 + ob + b - v.y);
         __syncthreads();
-        if (t == kTriBlock - 1) { carry_c = cc + oc + c; carry_b = cb + ob + b; }
+        if (t == kTriBlock - 1) { carry_c = cc + oc + c; carry_b = cb0 + ob + b; }
         __syncthreads();
     }
 #pragma unroll
@@ -607,11 +638,21 @@ __global__ __launch_bounds__(kTriBlock) void triage_emit_kernel(TriageArgs A)
 #pragma unroll
     for (int o = 1; o < 64; o <<= 1) { const uint32_t tb = (uint32_t)__shfl_up((int)ib, o); if (lane >= o) ib += tb; }
     if (lane == 63) { s_cnt[wave] = (uint32_t)__popcll(mc); s_bytes[wave] = ib; }
+    // candidates / bytes in front of this workgroup: its group's base (the classify kernel's scan) + the workgroups of the group in front
+    __shared__ uint2 s_base;
+    if (t < 64) {
+        const int32_t gsz = A.group_size, g = (int32_t)blockIdx.x / gsz, g_first = g * gsz, mine = (int32_t)blockIdx.x - g_first;
+        uint32_t fc = 0, fb = 0;
+        for (int32_t j = t; j < mine; j += 64) { const uint2 pv = A.blk[g_first + j]; fc += pv.x & 511u; fb += pv.y; }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) { fc += (uint32_t)__shfl_xor((int)fc, o); fb += (uint32_t)__shfl_xor((int)fb, o); }
+        if (t == 0) { const uint2 gb = A.grp_base[g]; s_base = make_uint2(gb.x + fc, gb.y + fb); }
+    }
     __syncthreads();
     if (!cand) return;
     uint32_t oc = 0, ob = 0;
     for (int w = 0; w < wave; w++) { oc += s_cnt[w]; ob += s_bytes[w]; }
-    const uint2 base = A.blk[blockIdx.x];
+    const uint2 base = s_base;
     const uint32_t ci = base.x + oc + below;
     const uint32_t bo = base.y + ob + ib - bytes;
     if (!(ci < (uint32_t)A.out.cap_cand && (uint64_t)bo + bytes + 16u <= (uint64_t)A.out.cap_bases)) { atomicAdd(&A.out.counters[4], 1); return; }
@@ -720,19 +761,23 @@ __global__ __launch_bounds__(256) void triage_decode_kernel(TriageArgs A)
 
 }  // namespace
 
+// fixed words at the head of the scratch: chunk_base (256 B), blocks_done (256 B), grp_done (zero between launches), grp, grp_base
+constexpr size_t kTriFixedZero = 512 + 4 * (size_t)kTriGroupsMax;
+constexpr size_t kTriFixed = kTriFixedZero + 16 * (size_t)kTriGroupsMax + 8 * (size_t)kTriGroupsMax;
+
 size_t triage_scratch_bytes(int32_t n_records)
 {
     const size_t n = (size_t)(n_records > 0 ? n_records : 1);
     const size_t blocks = (n + kTriBlock - 1) / kTriBlock;
     auto up = [](size_t x) { return (x + 255) / 256 * 256; };
-    return up(n * 4) + up(n * 4) + up(blocks * 8) + up(n * 4) + 512;
+    return up(n * 4) + up(n * 4) + up(blocks * 8) + up(n * 4) + kTriFixed;
 }
 
 // offset of the words that must be zero before the first launch on a scratch buffer
 size_t triage_scratch_zero_offset(int32_t n_records, size_t* bytes)
 {
     (void)n_records;
-    *bytes = 512;
+    *bytes = kTriFixedZero;
     return 0;
 }
 
@@ -750,6 +795,11 @@ hipError_t launch_triage(const RefDev& ref, const RgTable& rg, int32_t* depth_di
     char* s = static_cast<char*>(scratch);
     A.chunk_base = reinterpret_cast<int32_t*>(s); s += 256;
     A.blocks_done = reinterpret_cast<uint32_t*>(s); s += 256;      // zeroed by im_dev_triage_scratch_init, left zero by every launch
+    A.grp_done = reinterpret_cast<uint32_t*>(s); s += 4 * (size_t)kTriGroupsMax;       // likewise
+    A.grp = reinterpret_cast<unsigned long long*>(s); s += 16 * (size_t)kTriGroupsMax;
+    A.grp_base = reinterpret_cast<uint2*>(s); s += 8 * (size_t)kTriGroupsMax;
+    A.group_size = kTriGroup;
+    while ((blocks + A.group_size - 1) / A.group_size > kTriGroupsMax) A.group_size *= 2;
     A.info = reinterpret_cast<uint32_t*>(s); s += up(n * 4);
     A.rmax = reinterpret_cast<int32_t*>(s); s += up(n * 4);
     A.blk = reinterpret_cast<uint2*>(s); s += up((size_t)blocks * 8);

@@ -11,15 +11,18 @@ import numpy as np  # noqa: E402
 from indelminer_amd import capi, rawrec, synth  # noqa: E402
 
 L = capi.lib()
+ONLY = sys.argv[1] if len(sys.argv) > 1 else None          # "configs[1]" / "shard3": that input alone, records without qualities, with depth
 for name, kw in (("configs[1]", dict(seed=1, ref_len=1_000_000)), ("shard3", dict(seed=2, ref_len=6_250_000, big_every=7))):
+    if ONLY and name != ONLY:
+        continue
     refs, rd = synth.simulate(coverage=30, read_len=100, **kw)
     ctx = capi.Context(0)
     ctx.set_reference([refs[0].tobytes()])
     ctx.set_insert_ranges(["generic"], [rd.range_max])
     ctx.depth_enable()
-    for qual in (False, True):
+    for qual in ((False,) if ONLY else (False, True)):
         raw, off = rawrec.records(rd, qual=qual)
-        for want_depth in (True, False):
+        for want_depth in ((True,) if ONLY else (True, False)):
             pipe = capi.Pipeline(ctx, rd.n, len(raw), cap_cand=max(4096, rd.n // 8), read_len_max=100, want_depth=want_depth)
             pipe.upload(raw, off)
             tp = capi.TriageParams(pipe.tp.qthreshold, pipe.tp.ethreshold_vcfcheck, pipe.tp.maxpedelsize, 1 if want_depth else 0, 0, 1)
