@@ -726,7 +726,7 @@ def long_reads_measure(device, reps=12):
         for j in range(m):
             st, r_ = ob.realign(Po, contig, len(contig), int(cand["anchor"][j]), int(cand["range_max"][j]), bytes(cand["bases"][j]))
             bad += gpucmp.hip_vs_oracle(res[j], st, r_) is not None
-        # the same batch with -g 2: reads beyond 255 bases with a band take the general pass (im_realign_any.hip, one lane per read)
+        # the same batch with -g 2: reads beyond 255 bases with a band take the general pass (im_realign_any.hip)
         Pg = capi.params(numgaps=2)
         tg = []
         for _ in range(4):
@@ -742,7 +742,7 @@ def long_reads_measure(device, reps=12):
         for j in range(mg):
             st, r_ = ob.realign(Pog, contig, len(contig), int(cand["anchor"][j]), int(cand["range_max"][j]), bytes(cand["bases"][j]))
             badg += gpucmp.hip_vs_oracle(resg[j], st, r_) is not None
-        gapped = {"numgaps": 2, "kernel": "realign_any_kernel (general pass: one lane per read, arena in device memory)", "ms": msg_,
+        gapped = {"numgaps": 2, "kernel": "realign_any_kernel (general pass: band searches by the whole wave read by read, dynamic programs one lane per read)", "ms": msg_,
                   "candidates_per_s": n / (msg_ * 1e-3), "evidence_found": int((resg["status"] == 1).sum()),
                   "identical_to_the_oracle_on_the_sample": bool(badg == 0), "sample": mg}
         return {"workload": "2 x 300 library: 1 Mb contig, 30x, insert ~ N(900, 50); the candidate reads of its %d delivered reads" % rd.n,

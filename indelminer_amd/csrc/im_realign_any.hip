@@ -3,9 +3,10 @@
 // The reference realigns reads of any length with a band of any width (src/readaln.c:242-267, src/indelminer.c:934,948:
 // numgaps is an unbounded unsigned).  The kernels of im_realign.hip / im_realign_long.hip are laid out for what sequencers
 // deliver -- reads of up to 255 / 1020 bases at numgaps == 0, up to 255 bases and bands of up to 61 diagonals otherwise (one
-// lane per diagonal) -- and leave every other read IM_ST_UNSUPPORTED.  This file takes those: ONE LANE PER READ, all state
-// in a per-lane arena of device memory whose words are interleaved over the 64 lanes of a wave (word i of lane l lives at
-// arena[64 i + l], so lanes that walk their arrays in step touch four cache lines per access, not sixty-four).  It follows
+// lane per diagonal) -- and leave every other read IM_ST_UNSUPPORTED.  This file takes those: ONE LANE PER READ for the
+// dynamic programs and the merge, their state in a per-lane arena of device memory whose words are interleaved over the 64
+// lanes of a wave (word i of lane l lives at arena[64 i + l], so lanes that walk their arrays in step touch four cache lines
+// per access, not sixty-four); the k-mer band searches in between by the WHOLE WAVE on one read after the other.  It follows
 // the reference statement by statement where order matters (the strict comparisons of the three dynamic programs decide
 // between co-optimal alignments) and restates what is order-free (the k-mer tables as one open-addressing
 // table per read piece, the band sums as a running sum):
@@ -20,9 +21,8 @@
 //   a11 new_evidence             src/evidence.c:4-34 (+ the reductions of src/variant.c:217-290,704-775)
 //
 // Two launches: any_pick_kernel lists the reads the other kernels left (or, for numgaps > 60, every read) with the largest
-// read and window among them; the host sizes the arena from those and realign_any_kernel works the list off, a lane taking
-// the next unclaimed read when it is done with one.  The result record's own bounds (IM_MAX_OPS segments, IM_MAX_EV indels
-// per read) stay.
+// read and window among them; the host sizes the arena from those and realign_any_kernel works the list off, every lane
+// of a wave claiming a read per round.  The result record's own bounds (IM_MAX_OPS segments, IM_MAX_EV indels per read) stay.
 
 #include "im_device.hpp"
 #include "im_wave.hpp"
@@ -40,6 +40,10 @@ enum : int { kKindEq = 0, kKindX = 1, kKindI = 2, kKindNone = 3 };
 struct AnyLayout {
     int32_t maxM, maxW, maxB, hslots;
     int32_t rows_in_lds;        // 1: o_cc .. o_dp index the wave's LDS block (from 0), not the arena
+    int32_t l_rows_words;       // LDS words of the four rows (0 when they live in the arena)
+    int32_t l_tab_slots;        // slots of the wave's k-mer table in LDS (key, offset, count: 3 words each); 0: every lane searches alone
+    int32_t l_diag_words;       // LDS words of the wave's diagonal histogram (longer ones go to the arena)
+    int32_t lds_bytes;
     int32_t o_hkey, o_hpos, o_hcnt, o_diag, o_cc, o_dd, o_cp, o_dp, o_mp0, o_mp1, o_mp2, o_fp, o_pos0, o_pos1, o_ops0, o_ops1, o_fin, o_stk;
     int32_t words;
 };
@@ -63,6 +67,15 @@ __host__ __device__ inline AnyLayout make_layout(int32_t maxM, int32_t maxW, int
     y.o_ops0 = take(IM_MAX_OPS + 4); y.o_ops1 = take(IM_MAX_OPS + 4); y.o_fin = take(IM_MAX_OPS + 4);
     y.o_stk = take(kFrames * kFrameWords);
     y.words = at;
+    // the wave's LDS: the rows (64 lanes' worth), then the shared table and histogram of the cooperative band search, 144 KiB at
+    // most (a workgroup may take all of a CU's 160 KiB): tables of reads of up to 4096 bases
+    const int32_t budget = (144 << 10) / 4;
+    y.l_rows_words = y.rows_in_lds ? 4 * (maxB + 4) * 64 : 0;
+    y.l_tab_slots = (y.l_rows_words + 3 * h + 1024 <= budget) ? h : 0;
+    int32_t left = budget - y.l_rows_words - 3 * y.l_tab_slots;
+    if (left > maxW + maxM + 8) left = maxW + maxM + 8;
+    y.l_diag_words = y.l_tab_slots ? left : 0;
+    y.lds_bytes = 4 * (y.l_rows_words + 3 * y.l_tab_slots + y.l_diag_words);
     return y;
 }
 
@@ -610,34 +623,157 @@ __device__ __forceinline__ void any_store_band(im_read_result* out, int which, c
     o->r1 = x.r1; o->r2 = x.r2; o->q1 = x.q1; o->q2 = x.q2; o->low = b.low; o->votes = b.votes; o->win_bytes = win; o->piece_bytes = piece;
 }
 
-// attempt_pe_alignment (764-799) + attempt_diagonal_alignments (539-759) for read c
-__device__ void any_realign_one(const Ar& a, const AnyLayout& Y, const RealignArgs& R, int c)
+// ---- the band search with the whole wave on ONE read ----------------------------------------------------------------
+//
+// One lane per read leaves the k-mer vote -- a probe of the read's table per window position, thousands per read -- a chain of
+// dependent round trips to device memory with nothing to hide them (a batch of long reads is a few hundred waves: 7 of the
+// 14 ms of a 2 x 300 library at -g 2, profiles/r04_f_any_probe.txt).  So the wave takes its lanes' searches one after the
+// other, all 64 lanes on one read: the table (open addressing: key, offset, count per slot) and the diagonal histogram in
+// LDS, lanes on contiguous stretches of the read's k-mers / the window / the diagonals.  Reads whose table does not fit the
+// LDS share keep the search of their own lane (any_find_band).
+
+struct CoopLds { uint32_t* key; int32_t* pos; int32_t* cnt; int32_t* diag; int32_t tab_slots, diag_words; };
+
+__device__ __forceinline__ bool band_better(int c1, int d1, int i1, int c2, int d2, int i2)     // select_band's order (142-181)
+{
+    return c1 > c2 || (c1 == c2 && (d1 < d2 || (d1 == d2 && i1 < i2)));
+}
+
+// every argument wave-uniform; gdiag: the wave's own contiguous stretch of device memory for histograms beyond the LDS share
+__device__ AnyBand coop_find_band(const CoopLds& T, int32_t* gdiag, const uint8_t* ref, uint32_t z1, uint32_t e1, uint32_t anchor,
+                                  const uint8_t* read, uint32_t z2, uint32_t e2, uint32_t k, uint32_t g, int lane)
+{
+    AnyBand b; b.st = 0; b.low = b.up = 0; b.votes = 0;
+    const uint32_t W = e1 - z1, L = e2 - z2;
+    const uint32_t numdiag = (W - (k - 1)) + (L - (k - 1));                 // unsigned, as written (403-404)
+    if (!(numdiag > g) || e2 < z2) { b.st = IM_ST_ABORT; return b; }       // forceasserts 405, 407
+    if (L < k) { b.low = b.up = (int)(numdiag - 1); return b; }            // 408-412
+    if ((int32_t)numdiag <= 0 || numdiag > (1u << 28)) { b.st = IM_ST_ABORT; return b; }
+    const uint32_t mask = (1u << (2 * k)) - 1u, nread = L - k + 1;
+    uint32_t H = 16; while (H < 2u * nread) H <<= 1;
+    const uint32_t hm = H - 1u;
+    const bool dlds = numdiag <= (uint32_t)T.diag_words;
+    int32_t* diag = dlds ? T.diag : gdiag;
+    for (uint32_t i = (uint32_t)lane; i < H; i += 64u) { T.key[i] = kEmpty; T.cnt[i] = 0; }
+    for (uint32_t i = (uint32_t)lane; i < numdiag; i += 64u) diag[i] = 0;
+    if (!dlds) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");          // the zeros are in before any lane's vote
+    wave_lds_sync();
+    // the read piece's k-mers, a contiguous stretch per lane with a rolling code
+    {
+        const uint32_t per = (nread + 63u) / 64u, s0 = (uint32_t)lane * per, s1 = min(nread, s0 + per);
+        uint32_t code = 0;
+        if (s0 < s1) for (uint32_t u = 0; u + 1 < k; u++) code = (code << 2) | code2(read[z2 + s0 + u]);
+        for (uint32_t q = s0; q < s1; q++) {
+            code = ((code << 2) | code2(read[z2 + q + k - 1])) & mask;
+            uint32_t h = (code * 2654435761u) >> 7 & hm;
+            for (;;) {
+                const uint32_t old = atomicCAS(&T.key[h], kEmpty, code);
+                if (old == kEmpty) { T.pos[h] = (int32_t)q; atomicAdd(&T.cnt[h], 1); break; }
+                if (old == code) { atomicAdd(&T.cnt[h], 1); break; }
+                h = (h + 1) & hm;
+            }
+        }
+    }
+    wave_lds_sync();
+    // every window position whose k-mer occurs exactly once in the piece votes for its diagonal (97-112)
+    if (W >= k) {
+        const uint32_t npos = W - k + 1, per = (npos + 63u) / 64u, s0 = (uint32_t)lane * per, s1 = min(npos, s0 + per);
+        uint32_t code = 0;
+        if (s0 < s1) for (uint32_t u = 0; u + 1 < k; u++) code = (code << 2) | code2(ref[z1 + s0 + u]);
+        for (uint32_t p = s0; p < s1; p++) {
+            code = ((code << 2) | code2(ref[z1 + p + k - 1])) & mask;
+            uint32_t h = (code * 2654435761u) >> 7 & hm;
+            for (;;) {
+                const uint32_t key = T.key[h];
+                if (key == kEmpty) break;
+                if (key == code) {
+                    if (T.cnt[h] == 1) {
+                        const uint32_t indx = p - (uint32_t)T.pos[h] + L - k + 1;                              // 102-105
+                        if (indx < numdiag) atomicAdd(&diag[indx], 1);
+                    }
+                    break;
+                }
+                h = (h + 1) & hm;
+            }
+        }
+    }
+    if (!dlds) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    wave_lds_sync();
+    // bin_bands + select_band: a contiguous stretch of bands per lane with a running sum, then the wave's best
+    const int anchor_rel = (int)(anchor - z1);
+    int bc = -1, bd = INT_MAX, bi = INT_MAX;
+    {
+        auto dg = [&](uint32_t i) -> int { return dlds ? diag[i] : __hip_atomic_load(&diag[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
+        const uint32_t per = (numdiag + 63u) / 64u, i0 = (uint32_t)lane * per, i1 = min(numdiag, i0 + per);
+        int run = 0;
+        if (i0 < i1 && i0 < numdiag - g) for (uint32_t j = i0; j <= i0 + g; j++) run += dg(j);
+        for (uint32_t i = i0; i < i1; i++) {
+            const int bsum = i < numdiag - g ? run : 0;
+            int d = (int)((uint32_t)anchor_rel - i); if (d < 0) d = -d;
+            if (band_better(bsum, d, (int)i, bc, bd, bi)) { bc = bsum; bd = d; bi = (int)i; }
+            if (i + g + 1 < numdiag) run += dg(i + g + 1) - dg(i);
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const int oc = __shfl_xor(bc, o), od = __shfl_xor(bd, o), oi = __shfl_xor(bi, o);
+        if (band_better(oc, od, oi, bc, bd, bi)) { bc = oc; bd = od; bi = oi; }
+    }
+    wave_lds_sync();
+    b.votes = bc;
+    b.low = (int)((uint32_t)bi - (L - k + 1));                              // 438-439
+    b.up = (int)((uint32_t)bi + g - (L - k + 1));
+    return b;
+}
+
+// ---- attempt_pe_alignment (764-799) + attempt_diagonal_alignments (539-759) for one read, in three steps with the two band
+// searches between them (the wave does those together where it can)
+
+struct AnyRead {
+    int c, L, tid, anchor;
+    int left1, right1, left2, right2;
+    int stage;                      // 0: done; 1: wants band search 1; 2: wants band search 2
+    AnyBand b1, b2;
+    int r1, r2, q1, q2, n1;
+    uint32_t f, l, w0, w1, anc, p0, p1;
+    bool want_tail;
+};
+
+__device__ void any_step_begin(const RealignArgs& R, int c, AnyRead& X)
 {
     im_read_result* out = &R.batch.out[c];
-    const int64_t off = R.batch.base_off[c];
-    const int L = R.batch.read_len[c];
-    const int tid = R.batch.tid[c], anchor = R.batch.anchor[c], range = R.batch.range_max[c];
-    const uint32_t k = R.P.klength, g = R.P.numgaps, eth = R.P.ethreshold;
-    const uint8_t* contig = R.ref.ascii + R.ref.asc_off[tid];
-    const int clen = R.ref.len[tid];
-    const uint8_t* read = R.batch.bases + off;
+    X.c = c; X.L = R.batch.read_len[c]; X.tid = R.batch.tid[c]; X.anchor = R.batch.anchor[c];
+    const int range = R.batch.range_max[c], clen = R.ref.len[X.tid], anchor = X.anchor;
     int distance = range;                                                             // 774-783
-    const int left1  = anchor >= distance ? anchor - distance : 0;
-    const int right1 = clen < (anchor + distance) ? clen : anchor + distance;
+    X.left1  = anchor >= distance ? anchor - distance : 0;
+    X.right1 = clen < (anchor + distance) ? clen : anchor + distance;
     distance = range + (int)R.P.maxdelsize;
-    const int left2  = anchor >= distance ? anchor - distance : 0;
-    const int right2 = clen < (anchor + distance) ? clen : anchor + distance;
-    if (!(anchor >= left1 && anchor >= left2 && anchor <= right1 && anchor <= right2 && left2 >= 0 && right2 > 0)) { any_finish(out, IM_ST_ABORT, 0); return; }   // 548-553
-    // piece 1: the whole read in [left1, right1)
-    const AnyBand b1 = any_find_band(a, Y, contig, (uint32_t)left1, (uint32_t)right1, (uint32_t)anchor, read, 0u, (uint32_t)L, k, g);
-    if (b1.st) { any_finish(out, b1.st, 0); return; }
-    const AnyAln a1 = any_band_alignment(a, Y, contig, read, 0, L, left1, right1 - left1, b1.low, b1.up, Y.o_pos0, Y.o_ops0);
-    any_store_band(out, 0, b1, a1, right1 - left1, L);
+    X.left2  = anchor >= distance ? anchor - distance : 0;
+    X.right2 = clen < (anchor + distance) ? clen : anchor + distance;
+    X.stage = 1;
+    if (!(anchor >= X.left1 && anchor >= X.left2 && anchor <= X.right1 && anchor <= X.right2 && X.left2 >= 0 && X.right2 > 0)) {
+        any_finish(out, IM_ST_ABORT, 0); X.stage = 0;                                 // 548-553
+    }
+}
+
+// behind band search 1: the first alignment, the geometric case, the second search's window and piece
+__device__ void any_step_middle(const Ar& a, const AnyLayout& Y, const RealignArgs& R, AnyRead& X)
+{
+    im_read_result* out = &R.batch.out[X.c];
+    const int L = X.L, anchor = X.anchor;
+    const uint32_t eth = R.P.ethreshold;
+    const uint8_t* contig = R.ref.ascii + R.ref.asc_off[X.tid];
+    const uint8_t* read = R.batch.bases + R.batch.base_off[X.c];
+    X.stage = 0;
+    if (X.b1.st) { any_finish(out, X.b1.st, 0); return; }
+    const AnyAln a1 = any_band_alignment(a, Y, contig, read, 0, L, X.left1, X.right1 - X.left1, X.b1.low, X.b1.up, Y.o_pos0, Y.o_ops0);
+    any_store_band(out, 0, X.b1, a1, X.right1 - X.left1, L);
     if (a1.st) { any_finish(out, a1.st, 1); return; }
     const int r1 = a1.r1, r2 = a1.r2, q1 = a1.q1, q2 = a1.q2, n1 = a1.n_ops;
+    X.r1 = r1; X.r2 = r2; X.q1 = q1; X.q2 = q2; X.n1 = n1;
     if (q1 == q2) { any_finish(out, IM_ST_NONE, 1); return; }                         // 568-572
     if (q1 == 0 && q2 == L) {                                                         // 575-582
-        any_finish(out, any_build_result(a, Y, out, R, c, r1, Y.o_ops0, n1, L, 0, -1, Y.o_ops1, 0), 1);
+        any_finish(out, any_build_result(a, Y, out, R, X.c, r1, Y.o_ops0, n1, L, 0, -1, Y.o_ops1, 0), 1);
         return;
     }
     // leading / trailing '=' runs of the first CIGAR (585-599)
@@ -650,8 +786,10 @@ __device__ void any_realign_one(const Ar& a, const AnyLayout& Y, const RealignAr
         for (int i = n1 - 1; i >= 0; i--) { const uint32_t w = a.atu(Y.o_ops0, i); if (i == n1 - 1 && OPS_OP(w) == IM_OP_S) continue; if (OPS_OP(w) != IM_OP_EQ) break; j += OPS_LEN(w); }
         l = (uint32_t)j;
     }
+    X.f = f; X.l = l;
     // piece 2 by the four geometric cases; the guards in unsigned arithmetic as written (605-717)
     const uint32_t uL = (uint32_t)L;
+    const int right2 = X.right2, left2 = X.left2;
     uint32_t w0, w1, anc, p0, p1; bool want_tail;
     if (r1 > anchor) {
         if (q1 == 0) {
@@ -676,10 +814,24 @@ __device__ void any_realign_one(const Ar& a, const AnyLayout& Y, const RealignAr
         } else { any_finish(out, IM_ST_NONE, 1); return; }
     } else { any_finish(out, IM_ST_NONE, 1); return; }                                // r1 == anchor (712-717)
     if ((int32_t)(w1 - w0) <= 0) { any_finish(out, IM_ST_ABORT, 1); return; }
-    const AnyBand b2 = any_find_band(a, Y, contig, w0, w1, anc, read, p0, p1, k, g);
-    if (b2.st) { any_finish(out, b2.st, 1); return; }
-    const AnyAln a2 = any_band_alignment(a, Y, contig, read, (int)p0, (int)(p1 - p0), (int)w0, (int)(w1 - w0), b2.low, b2.up, Y.o_pos1, Y.o_ops1);
-    any_store_band(out, 1, b2, a2, (int)(w1 - w0), (int)(p1 - p0));
+    X.w0 = w0; X.w1 = w1; X.anc = anc; X.p0 = p0; X.p1 = p1; X.want_tail = want_tail;
+    X.stage = 2;
+}
+
+// behind band search 2: the second alignment and the merge of the two pieces
+__device__ void any_step_end(const Ar& a, const AnyLayout& Y, const RealignArgs& R, AnyRead& X)
+{
+    im_read_result* out = &R.batch.out[X.c];
+    const int L = X.L, c = X.c;
+    const uint8_t* contig = R.ref.ascii + R.ref.asc_off[X.tid];
+    const uint8_t* read = R.batch.bases + R.batch.base_off[c];
+    const int r1 = X.r1, r2 = X.r2, q1 = X.q1, q2 = X.q2, n1 = X.n1;
+    const uint32_t f = X.f, l = X.l, w0 = X.w0, w1 = X.w1, p0 = X.p0, p1 = X.p1;
+    const bool want_tail = X.want_tail;
+    X.stage = 0;
+    if (X.b2.st) { any_finish(out, X.b2.st, 1); return; }
+    const AnyAln a2 = any_band_alignment(a, Y, contig, read, (int)p0, (int)(p1 - p0), (int)w0, (int)(w1 - w0), X.b2.low, X.b2.up, Y.o_pos1, Y.o_ops1);
+    any_store_band(out, 1, X.b2, a2, (int)(w1 - w0), (int)(p1 - p0));
     if (a2.st) { any_finish(out, a2.st, 2); return; }
     const int r3 = a2.r1, r4 = a2.r2, q3 = a2.q1, q4 = a2.q2; int n2 = a2.n_ops;
     if (want_tail) { if (q4 != L || q3 == q4) { any_finish(out, IM_ST_NONE, 2); return; } }
@@ -709,6 +861,37 @@ __device__ void any_realign_one(const Ar& a, const AnyLayout& Y, const RealignAr
     else if (q3 > q2 && r2 == r3) st = any_build_result(a, Y, out, R, c, r1, Y.o_ops0, n1, q2, q3, r3, Y.o_ops1, n2);         // 745-749
     else st = IM_ST_NONE;
     any_finish(out, st, 2);
+}
+
+// One band search for every lane whose read is at `stage`: the wave together, lane by lane, where the read's table fits the
+// LDS share; the lane alone otherwise.
+__device__ void any_search_round(const Ar& a, const AnyLayout& Y, const RealignArgs& R, const CoopLds& T, int32_t* gdiag, AnyRead& X, int stage, int lane)
+{
+    const uint32_t k = R.P.klength, g = R.P.numgaps;
+    const bool mine = X.stage == stage;
+    // the piece and the window of this lane's search
+    const uint32_t z1 = stage == 1 ? (uint32_t)X.left1 : X.w0, e1 = stage == 1 ? (uint32_t)X.right1 : X.w1;
+    const uint32_t anc = stage == 1 ? (uint32_t)X.anchor : X.anc;
+    const uint32_t z2 = stage == 1 ? 0u : X.p0, e2 = stage == 1 ? (uint32_t)X.L : X.p1;
+    const uint32_t piece = e2 - z2;
+    const bool coop = mine && T.tab_slots > 0 && e2 >= z2 && piece >= k && 2ull * (piece - k + 1) <= (unsigned long long)T.tab_slots;
+    uint64_t m = __ballot(coop);
+    while (m) {
+        const int r = (int)__builtin_ctzll(m);
+        m &= m - 1ull;
+        const int tid = __shfl(X.tid, r), c = __shfl(X.c, r);
+        const uint8_t* contig = R.ref.ascii + R.ref.asc_off[tid];
+        const uint8_t* read = R.batch.bases + R.batch.base_off[c];
+        const AnyBand b = coop_find_band(T, gdiag, contig, (uint32_t)__shfl((int)z1, r), (uint32_t)__shfl((int)e1, r), (uint32_t)__shfl((int)anc, r),
+                                         read, (uint32_t)__shfl((int)z2, r), (uint32_t)__shfl((int)e2, r), k, g, lane);
+        if (lane == r) { if (stage == 1) X.b1 = b; else X.b2 = b; }
+    }
+    if (mine && !coop) {
+        const uint8_t* contig = R.ref.ascii + R.ref.asc_off[X.tid];
+        const uint8_t* read = R.batch.bases + R.batch.base_off[X.c];
+        const AnyBand b = any_find_band(a, Y, contig, z1, e1, anc, read, z2, e2, k, g);
+        if (stage == 1) X.b1 = b; else X.b2 = b;
+    }
 }
 
 // counters: [0] reads listed, [1] longest read among them, [2] widest window, [3] next list entry to claim
@@ -743,16 +926,33 @@ __global__ __launch_bounds__(256) void any_pick_kernel(RealignArgs A, int all, i
 
 __global__ __launch_bounds__(64) void realign_any_kernel(RealignArgs A, const int32_t* list, int32_t* counters, int32_t* arena, AnyLayout Y)
 {
-    extern __shared__ int32_t s_rows[];
+    extern __shared__ int32_t s_dyn[];
     const int lane = threadIdx.x;
-    Ar a; a.p = arena + (int64_t)blockIdx.x * Y.words * 64 + lane;
-    a.q = Y.rows_in_lds ? s_rows + lane : a.p;
+    int32_t* wave_arena = arena + (int64_t)blockIdx.x * Y.words * 64;
+    Ar a; a.p = wave_arena + lane;
+    a.q = Y.rows_in_lds ? s_dyn + lane : a.p;
+    CoopLds T;
+    T.tab_slots = Y.l_tab_slots; T.diag_words = Y.l_diag_words;
+    T.key = reinterpret_cast<uint32_t*>(s_dyn + Y.l_rows_words);
+    T.pos = s_dyn + Y.l_rows_words + Y.l_tab_slots;
+    T.cnt = T.pos + Y.l_tab_slots;
+    T.diag = T.cnt + Y.l_tab_slots;
+    // the 64 lanes' histogram words of the arena are one contiguous stretch: the wave's own when it votes together
+    int32_t* gdiag = wave_arena + (int64_t)Y.o_diag * 64;
     const int n = counters[0];
-    // a lane claims the next read of the list when it is done with one: reads differ in cost by orders of magnitude
+    // a lane claims the next read of the list when it is done with one; the wave moves through the three steps together so
+    // that the band searches in between can be done by all lanes on one read
     for (;;) {
         const int at = atomicAdd(&counters[3], 1);
-        if (at >= n) break;
-        any_realign_one(a, Y, A, list[at]);
+        const bool have = at < n;
+        if (__ballot(have) == 0ull) break;
+        AnyRead X; X.stage = 0; X.c = 0; X.tid = 0; X.L = 0; X.anchor = 0; X.left1 = X.right1 = 0;
+        X.w0 = X.w1 = X.anc = X.p0 = X.p1 = 0;
+        if (have) any_step_begin(A, list[at], X);
+        any_search_round(a, Y, A, T, gdiag, X, 1, lane);
+        if (X.stage == 1) any_step_middle(a, Y, A, X);
+        any_search_round(a, Y, A, T, gdiag, X, 2, lane);
+        if (X.stage == 2) any_step_end(a, Y, A, X);
     }
 }
 
@@ -779,12 +979,12 @@ hipError_t launch_realign_any(const RealignArgs& a, const int32_t* list, int32_t
                               int32_t max_read, int32_t max_window, int32_t n_waves, hipStream_t stream)
 {
     const AnyLayout y = make_layout(max_read, max_window, (int32_t)a.P.numgaps + 1);
-    const size_t lds = y.rows_in_lds ? (size_t)4 * (size_t)(y.maxB + 4) * 256u : 0;
+    const size_t lds = (size_t)y.lds_bytes;
     static size_t attr_bytes = 0;
     if (lds > attr_bytes) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(realign_any_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 64 << 10);
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(realign_any_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 144 << 10);
         if (e != hipSuccess) return e;
-        attr_bytes = (size_t)64 << 10;
+        attr_bytes = (size_t)144 << 10;
     }
     hipLaunchKernelGGL(realign_any_kernel, dim3(n_waves), dim3(64), lds, stream, a, list, counters, arena, y);
     return hipGetLastError();
