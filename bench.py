@@ -754,6 +754,61 @@ def long_reads_measure(device, reps=12):
         ctx.close()
 
 
+def other_parameters_measure(device, reps=10):
+    """The flags users run besides the defaults, on the configs[1] candidates (12 232 reads of 100 bases): -g 1 / 2 / 5 / 12
+    (realign_band_kernel: a lane per band diagonal), -k 8 / 13 (the table by the k-mer's first six bases), -k 14 (the hash).  Each
+    setting: the realign launch alone on the device (HIP events), a sample of its results against the CPU oracle."""
+    from tests.support import gpucmp, oraclebind as ob
+    L = 100
+    refs, rd = synth.simulate(seed=1, ref_len=1_000_000, coverage=30, read_len=L)
+    cand = synth.candidates(rd)
+    n = len(cand["index"])
+    ctx = capi.Context(device)
+    try:
+        ctx.set_reference([refs[0].tobytes()])
+        stride = (L + 3) // 4 * 4
+        bases = np.zeros((n, stride), dtype=np.uint8)
+        bases[:, :L] = cand["bases"]
+        flat = np.concatenate([bases.reshape(-1), np.zeros(16, np.uint8)])
+        d_bases = capi.DevBuf(ctx, flat.nbytes).upload(flat)
+        d_off = capi.DevBuf(ctx, 8 * n).upload(np.arange(n, dtype=np.int64) * stride)
+        d_len = capi.DevBuf(ctx, 4 * n).upload(np.full(n, L, np.int32))
+        d_tid = capi.DevBuf(ctx, 4 * n).upload(np.zeros(n, np.int32))
+        d_anchor = capi.DevBuf(ctx, 4 * n).upload(cand["anchor"].astype(np.int32))
+        d_range = capi.DevBuf(ctx, 4 * n).upload(cand["range_max"].astype(np.int32))
+        d_res = capi.DevBuf(ctx, 512 * n)
+        batch = capi.DevBatch(n, d_bases.ptr, d_off.ptr, d_len.ptr, d_tid.ptr, d_anchor.ptr, d_range.ptr, d_res.ptr, None, None, None)
+        L_ = capi.lib()
+        tm = capi.Timer(ctx)
+        contig = refs[0].tobytes()
+        out = {"workload": "the %d candidate reads of the configs[1] step (100 bases), one realign launch per setting" % n, "settings": []}
+        ok = True
+        for kw in (dict(numgaps=1), dict(numgaps=2), dict(numgaps=5), dict(numgaps=12), dict(klength=8), dict(klength=13), dict(klength=14)):
+            P = capi.params(**kw)
+            ts = []
+            for _ in range(reps + 2):
+                tm.start(ctx.stream)
+                ctx._check(L_.im_dev_realign(ctx.h, C.byref(P), C.byref(batch), ctx.stream))
+                tm.stop(ctx.stream)
+                ts.append(tm.elapsed_ms())
+            ms = float(np.median(ts[2:]))
+            res = d_res.download(capi.RESULT_DTYPE, n)
+            Po = ob.params(**kw)
+            m = min(n, 250)
+            bad = 0
+            for j in range(m):
+                st, r_ = ob.realign(Po, contig, len(contig), int(cand["anchor"][j]), int(cand["range_max"][j]), bytes(cand["bases"][j]))
+                bad += gpucmp.hip_vs_oracle(res[j], st, r_) is not None
+            ok = ok and bad == 0
+            out["settings"].append({"flags": " ".join("-%s %d" % ("g" if k_ == "numgaps" else "k", v_) for k_, v_ in kw.items()),
+                                    "ms": ms, "candidates_per_s": n / (ms * 1e-3), "evidence_found": int((res["status"] == 1).sum()),
+                                    "identical_to_the_oracle_on_the_sample": bool(bad == 0), "sample": m})
+        out["identical_to_the_oracle_on_the_samples"] = bool(ok)
+        return out
+    finally:
+        ctx.close()
+
+
 def shard3_measure(device, steps=24, warmup=4):
     """The same device pass on ONE GPU's share of BASELINE configs[2] (a 6.25 Mb contig at 30x, every seventh planted event a
     150-900 bp deletion: 1.9 M delivered reads, ~76 k candidates, ~19 READCHUNK flushes per step): the launch sizes a real
@@ -1048,6 +1103,11 @@ def main():
                 line["long_reads_2x300"] = long_reads_measure(0 if os.environ.get("IM_BENCH_ONE_DEVICE") == "1" else local_rank)
             except Exception as ex:
                 line["long_reads_2x300"] = {"error": str(ex)}
+        if world == 1 and not args.no_shard3:
+            try:
+                line["other_parameters"] = other_parameters_measure(0 if os.environ.get("IM_BENCH_ONE_DEVICE") == "1" else local_rank)
+            except Exception as ex:
+                line["other_parameters"] = {"error": str(ex)}
         if world == 1 and not args.no_cpu_baseline and not args.no_config3:
             try:
                 line["end_to_end_config3"] = end_to_end_config3()
@@ -1081,6 +1141,8 @@ def main():
             checks["end_to_end_config3_md5_is_the_references"] = c3.get("product_md5_is_the_references") is True
         if isinstance(line.get("long_reads_2x300"), dict):
             checks["long_reads_identical_to_the_oracle"] = line["long_reads_2x300"].get("identical_to_the_oracle_on_the_sample") is True
+            if isinstance(line.get("other_parameters"), dict):
+                checks["other_parameters_identical_to_the_oracle"] = line["other_parameters"].get("identical_to_the_oracle_on_the_samples") is True
             if isinstance(line["long_reads_2x300"].get("with_gaps"), dict):
                 checks["long_reads_with_gaps_identical_to_the_oracle"] = line["long_reads_2x300"]["with_gaps"].get("identical_to_the_oracle_on_the_sample") is True
         if isinstance(line.get("end_to_end_config5"), dict):

@@ -716,7 +716,9 @@ __global__ __launch_bounds__(kTriBlock) void triage_emit_kernel(TriageArgs A)
 
 // new_unaligned_readaln's decode (src/readaln.c:242-267) + reverse_complement_string (src/sequences.c:204-220) for the
 // chunk's candidates, 32 lanes per read, four bases per lane and pass: candidates cluster around the indel sites, so
-// the work is spread over the candidate list and not over the records
+// the work is spread over the candidate list and not over the records (decoding inside the emit kernel, each wave its own
+// candidates one after the other, was tried in round 4: a wave at an indel site holds thirty candidates, its neighbours none --
+// 57 us against 6.2 + 5.6 at 300 000 records, 103 against 15 + 20 at 1.875 M)
 __global__ __launch_bounds__(256) void triage_decode_kernel(TriageArgs A)
 {
     const int sub = threadIdx.x >> 5, l32 = threadIdx.x & 31;
@@ -730,13 +732,18 @@ __global__ __launch_bounds__(256) void triage_decode_kernel(TriageArgs A)
         uint8_t* dst = const_cast<uint8_t*>(A.out.batch.bases) + A.out.batch.base_off[ci];
         bool bad = false;
         for (int32_t p0 = 4 * l32; p0 < (int32_t)padded4(L); p0 += 128) {
+            // the lane's (up to) four bases in ONE load: forwards they are two bytes (p0 is even), backwards they lie in the
+            // three bytes from that of the last base on -- four bytes from there stay inside the record or the chunk's slack
+            const int32_t n_here = min(4, L - p0);
+            const int32_t qlo = rc ? L - p0 - n_here : p0;
+            const uint32_t packed = rc ? ld_u32(seq + (qlo >> 1)) : ld_u16(seq + (p0 >> 1));
+            const int32_t b0 = qlo >> 1;
             uint32_t word = 0;
 #pragma unroll
             for (int j = 0; j < 4; j++) {
-                const int32_t p = p0 + j;
-                if (p >= L) break;
-                const int32_t q = rc ? L - 1 - p : p;
-                const uint32_t byte = seq[q >> 1];
+                if (j >= n_here) break;
+                const int32_t q = rc ? L - 1 - p0 - j : p0 + j;
+                const uint32_t byte = (packed >> (8 * ((q >> 1) - b0))) & 255u;
                 uint32_t code = (q & 1) ? (byte & 15u) : (byte >> 4);
                 if (rc) code = comp_code(code);
                 const uint32_t ch = base_ascii(code);
@@ -807,7 +814,7 @@ hipError_t launch_triage(const RefDev& ref, const RgTable& rg, int32_t* depth_di
     hipLaunchKernelGGL(triage_classify_kernel, dim3(blocks), dim3(kTriBlock), 0, stream, A);
     hipLaunchKernelGGL(triage_emit_kernel, dim3(blocks), dim3(kTriBlock), 0, stream, A);
     int dgrid = (int)((n + 63) / 64);           // one 32-lane group per candidate, 8 per workgroup; ~1/8 of the records at most pays off
-    if (dgrid > 2048) dgrid = 2048;
+    if (dgrid > 16384) dgrid = 16384;           // a candidate per 32-lane group while that stays a sane grid: a group's candidates are a chain of dependent loads each
     hipLaunchKernelGGL(triage_decode_kernel, dim3(dgrid), dim3(256), 0, stream, A);
     return hipGetLastError();
 }

@@ -776,6 +776,42 @@ def _beyond_the_laid_out_kernels(binary, tmp_path, envs=({},)):
             assert _run(binary, ["-i", "cfg.txt"] + flags, d, ref="ref.fa", bam="aln.bam", env=env) == want, (sub, env)
 
 
+def _long_read_tumour_normal(binary, tmp_path, envs=({},)):
+    """tumour / normal pair of a 2 x 1100 library: discovery realigns through the general pass, annotate mode (-q 0 -a -e 1) aligns
+    queries beyond 1020 bases (the support kernel's second form).  Both VCFs = the CPU shim's = the compiled reference's."""
+    from indelminer_amd import bamwrite, synth
+    d = str(tmp_path)
+    L, isz = 1100, 3300
+    base = dict(seed=77, ref_len=80_000, coverage=16, read_len=L, isize_mean=isz, isize_min=isz - 200, isize_max=isz + 200, indel_spacing=4000)
+    for prefix, kw in (("tumor_", dict(base, read_seed=91, somatic_spacing=12_000)), ("normal_", base)):
+        refs, rd = synth.simulate(**kw)
+        contigs = [("ctg0", len(refs[0]))]
+        bamwrite.write_fasta(d + "/ref.fa", contigs, refs)
+        bamwrite.write_bam(d + "/%saln.bam" % prefix, contigs, rd)
+    open(d + "/cfg.txt", "w").write("IL generic %d %d\n" % (isz - 200, isz + 200))
+    def run_pair(b, env):
+        e = dict(os.environ, **env)
+        r = subprocess.run([b, "-i", "cfg.txt", "ref.fa", "t=tumor_aln.bam"], cwd=d, stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=e)
+        assert r.returncode == 0, r.stderr.decode()[-1500:]
+        open(os.path.join(d, "tumor.vcf"), "wb").write(r.stdout)
+        a = subprocess.run([b, "-i", "cfg.txt", "-q", "0", "-a", "-e", "1", "ref.fa", "tumor.vcf", "normal=normal_aln.bam"], cwd=d,
+                           stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=e)
+        assert a.returncode == 0, a.stderr.decode()[-1500:]
+        return r.stdout, a.stdout
+    want_t, want_a = run_pair(_build_shim(), {"INDELMINER_PIPELINE": "host"})
+    body = [ln for ln in want_a.split(b"\n") if ln and not ln.startswith(b"#")]
+    assert len(body) > 10 and 0 < sum(1 for ln in body if ln.endswith(b";normal")) < len(body)
+    ref_bin = os.path.join(ROOT, "oracle", "_ref", "indelminer")
+    if os.path.exists(ref_bin):
+        assert run_pair(ref_bin, {}) == (want_t, want_a)
+    for env in envs:
+        assert run_pair(binary, env) == (want_t, want_a), env
+
+
+def test_host_long_read_tumour_normal(tmp_path):
+    _long_read_tumour_normal(_build_shim(), tmp_path)
+
+
 def test_host_runs_beyond_the_laid_out_kernels(tmp_path):
     _beyond_the_laid_out_kernels(_build_shim(), tmp_path, envs=({}, {"INDELMINER_PIECE_BYTES": "150000", "INDELMINER_WALKERS": "3"}))
 
@@ -988,6 +1024,11 @@ def test_product_takes_a_band_wider_than_a_wave():
     assert want.count(b"\n") > 30
     assert _run(_product(), ["-i", "indelminer.config", "-g", "200"], TD) == want
 
+
+
+@pytest.mark.gpu
+def test_product_long_read_tumour_normal(tmp_path):
+    _long_read_tumour_normal(_product(), tmp_path, envs=({}, {"INDELMINER_PIPELINE": "host"}))
 
 
 @pytest.mark.gpu
