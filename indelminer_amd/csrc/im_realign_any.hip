@@ -33,6 +33,7 @@ namespace {
 constexpr int kNegInf = -9999999;            // MININT, src/localalign.c:3
 constexpr int kOpen = 10, kExt = 10;         // src/localalign.c:10-13
 constexpr int kFrameWords = 16, kFrames = 48;
+constexpr int kCoopMaxBand = 32;             // bands up to this wide: the wave searches together and steps together (realign_any_kernel)
 constexpr uint32_t kEmpty = 0xFFFFFFFFu;
 enum : int { kKindEq = 0, kKindX = 1, kKindI = 2, kKindNone = 3 };
 
@@ -414,12 +415,17 @@ __device__ AnyAln any_band_alignment(const Ar& a, const AnyLayout& Y, const uint
     CC(leftd - 1) = DD(leftd - 1) = kNegInf;
     DD(rightd) = -g;
     bool found = false;
+    // The reverse pass has no `ib > 0` guard in the reference: a band that hangs off the window's left edge makes it compare read
+    // bases with the bytes IN FRONT of the window -- the contig's own bytes when the window starts inside it (read as they are),
+    // whatever lies in front of the contig otherwise (undefined there; here the zero padding every contig has in front, and zero
+    // for anything further out: a read of 2600 bases against a window at the contig's start walks 2500 bytes out).
+    auto before = [&](int j) -> uint32_t { const int64_t at = (int64_t)w0 + j - 1; return at >= -64 ? contig[at] : 0u; };
     for (int i = endi; i >= 1 && !found; i--) {                                       // 144-176
         if (i + low <= 0) leftd++;
         if (rightd < band) rightd++;
         const uint32_t ai = A[i];
         if ((c = CC(rightd - 1) - m) > (d = DD(rightd - 1) - h)) d = c;
-        if ((ib = rightd + low - 1 + i) <= N) c = CC(rightd) + wsub(ai, B[ib]);
+        if ((ib = rightd + low - 1 + i) <= N) c = CC(rightd) + wsub(ai, before(ib));
         if (d > c) c = d;
         e = c - g;
         DD(rightd) = d; CC(rightd) = c;
@@ -427,7 +433,7 @@ __device__ AnyAln any_band_alignment(const Ar& a, const AnyLayout& Y, const uint
         for (int curd = rightd - 1; curd >= leftd; curd--) {
             if ((c = c - m) > (e = e - h)) e = c;
             if ((c = CC(curd - 1) - m) > (d = DD(curd - 1) - h)) d = c;
-            c = CC(curd) + wsub(ai, B[curd + low - 1 + i]);                           // no `ib > 0` guard here in the reference either
+            c = CC(curd) + wsub(ai, before(curd + low - 1 + i));                      // no `ib > 0` guard here in the reference either
             if (e > c) c = e;
             if (d > c) c = d;
             CC(curd) = c; DD(curd) = d;
@@ -940,8 +946,28 @@ __global__ __launch_bounds__(64) void realign_any_kernel(RealignArgs A, const in
     // the 64 lanes' histogram words of the arena are one contiguous stretch: the wave's own when it votes together
     int32_t* gdiag = wave_arena + (int64_t)Y.o_diag * 64;
     const int n = counters[0];
-    // a lane claims the next read of the list when it is done with one; the wave moves through the three steps together so
-    // that the band searches in between can be done by all lanes on one read
+    if (Y.maxB > kCoopMaxBand) {
+        // wide bands: the row-by-row dynamic programs are the pass and differ widely from read to read -- every lane on its own,
+        // claiming its next read when it is done with one (waiting for each other at the steps cost 64 -> 76 ms at -g 61)
+        const uint32_t k = A.P.klength, g = A.P.numgaps;
+        for (;;) {
+            const int at = atomicAdd(&counters[3], 1);
+            if (at >= n) break;
+            AnyRead X;
+            any_step_begin(A, list[at], X);
+            if (X.stage != 1) continue;
+            const uint8_t* contig = A.ref.ascii + A.ref.asc_off[X.tid];
+            const uint8_t* read = A.batch.bases + A.batch.base_off[X.c];
+            X.b1 = any_find_band(a, Y, contig, (uint32_t)X.left1, (uint32_t)X.right1, (uint32_t)X.anchor, read, 0u, (uint32_t)X.L, k, g);
+            any_step_middle(a, Y, A, X);
+            if (X.stage != 2) continue;
+            X.b2 = any_find_band(a, Y, contig, X.w0, X.w1, X.anc, read, X.p0, X.p1, k, g);
+            any_step_end(a, Y, A, X);
+        }
+        return;
+    }
+    // narrow bands: the band searches are the pass.  A lane claims a read per round; the wave moves through the three steps
+    // together so that the searches in between can be done by all lanes on one read
     for (;;) {
         const int at = atomicAdd(&counters[3], 1);
         const bool have = at < n;

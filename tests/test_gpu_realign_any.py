@@ -131,6 +131,27 @@ def test_general_pass_left_edge_bands(gpu_ctx, k, g, seed):
     _compare(gpu_ctx, capi, dict(klength=k, numgaps=g), contig.encode(), cases, "left edge")
 
 
+@pytest.mark.parametrize("k,g", [(3, 0), (6, 0), (6, 2), (3, 70)])
+def test_long_reads_hanging_off_the_contig_start(gpu_ctx, k, g):
+    """A long read against a narrow window at the contig's start: the chosen band hangs thousands of bases off the window's left
+    edge, the forward pass finds no positive cell, and local_align's reverse pass -- which has no `ib > 0` guard
+    (src/localalign.c:144-176) -- walks all the way out in front of the contig.  The reference reads whatever lies there (and returns
+    no alignment whatever it reads); the general pass must not fault (profiles/any_fuzz.py seed 2 did, in round 4)."""
+    from indelminer_amd import capi
+    rng = random.Random(500 + k + g)
+    clen = 3000
+    contig = "".join(rng.choice("ACGT") for _ in range(clen))
+    cases = []
+    for _ in range(48):
+        L = rng.choice([1100, 2047, 2600]) if g == 0 else rng.choice([300, 1100, 2600])
+        read = "".join(rng.choice("ACGT") for _ in range(L))
+        if rng.random() < 0.3:
+            read = read[:L - 20] + contig[:20]
+        cases.append(dict(anchor=rng.choice([0, 0, 1, 7, 59]), range_max=rng.choice([60, 200]), read=read))
+    gpu_ctx.set_reference([contig.encode()])
+    _compare(gpu_ctx, capi, dict(klength=k, numgaps=g, maxdelsize=50), contig.encode(), cases, "off the contig's start")
+
+
 def test_general_pass_on_the_device_entry(gpu_ctx):
     """im_dev_realign_keep with evidence slots: a read the general pass realigns replaces its CIGAR-derived slots, one it finds
     nothing for keeps them (src/indelminer.c:494-512)"""
