@@ -110,7 +110,36 @@ for seed in range(first, first + rounds):
             print("MISMATCH seed %d record %d: hip %d oracle %d | len %d flag 0x%x mapq %d l_seq %d mtid %d isize %d cigar %r aux %r" %
                   (seed, i, h_cls[i], o_cls[i], len(r), flag, mapq, ls, mtid, isz, cig, aux), flush=True)
         sys.exit(1)
-    tri, cand = T._compare_triage(pipe, raw, off, NAMES, RANGES, tri=tri)
+    try:
+        tri, cand = T._compare_triage(pipe, raw, off, NAMES, RANGES, tri=tri)
+    except AssertionError as ex:
+        # The one known way the two record forms differ: an aux area that ends in 1-3 bytes which are not a whole field (a truncated
+        # record, a junk tail).  Records travel at 4-byte aligned offsets with up to three zero bytes behind them, and the tag walk
+        # takes a tail of fewer than 4 bytes for that padding: whether tail + padding reaches 4 depends on the record's length, which
+        # leaving the qualities out changes.  Anything else is a failure.
+        def short_tail(r):
+            tid, pos, lq, mapq, b, nc, flag, ls, mtid, mpos, isz = struct.unpack("<iiBBHHHiiii", r[:32])
+            s_ = 32 + lq + 4 * nc + (ls + 1) // 2 + ls
+            if ls < 0 or s_ > len(r):
+                return False
+            sizes = {"A": 1, "c": 1, "C": 1, "s": 2, "S": 2, "i": 4, "I": 4, "f": 4, "d": 8}
+            while s_ + 4 <= len(r):
+                typ = chr(r[s_ + 2]); s_ += 3
+                if typ in "ZH":
+                    while s_ < len(r) and r[s_]: s_ += 1
+                    s_ += 1
+                elif typ == "B":
+                    if s_ + 5 > len(r): return False
+                    es = sizes.get(chr(r[s_]), 0); s_ += 5 + es * struct.unpack("<I", r[s_ + 1:s_ + 5])[0]
+                elif typ in sizes: s_ += sizes[typ]
+                else: return False
+            return 0 < len(r) - s_ < 4
+        lst = ex.args[0] if ex.args and isinstance(ex.args[0], list) else None
+        if lst and all(short_tail(recs[i]) for i, _, _ in lst):
+            print("seed %d: %d record(s) with an aux tail of 1-3 bytes classed differently with and without qualities (known ambiguity): %r" % (seed, len(lst), lst[:3]), flush=True)
+            continue
+        print("seed %d: %r" % (seed, ex.args), flush=True)
+        raise
     cl = {}
     for t, _ in tri:
         cl[t.cls] = cl.get(t.cls, 0) + 1
