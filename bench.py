@@ -754,6 +754,39 @@ def long_reads_measure(device, reps=12):
         ctx.close()
 
 
+def triage_with_aligner_tags(device, rd, contig, reps=8):
+    """The triage launches alone on the step's records WITH what an aligner writes into the aux area (NM:C MD:Z AS:C XS:C MC:Z in front
+    of MQ:C and an RG:Z tag, 46 bytes; the synthetic records of the timed step carry MQ:C alone): the tag walk of fetch_func's RG / MQ
+    look-up is then most of classify.  Candidate count and classes must be what they are without the tags."""
+    ctx = capi.Context(device)
+    try:
+        ctx.set_reference([contig])
+        ctx.set_insert_ranges(["generic"], [rd.range_max])
+        out = {}
+        cls = {}
+        L_ = capi.lib()
+        for name, kw in (("plain", {}), ("tagged", dict(rg="generic", aux_prefix=b"NMC\x00" + b"MDZ100\x00" + b"ASC\x64" + b"XSC\x00" + b"MCZ100M\x00"))):
+            raw, off = rawrec.records(rd, qual=False, **kw)
+            pipe = capi.Pipeline(ctx, rd.n, len(raw), cap_cand=max(4096, rd.n // 8), read_len_max=rd.read_len)
+            pipe.upload(raw, off)
+            tp = capi.TriageParams(pipe.tp.qthreshold, pipe.tp.ethreshold_vcfcheck, pipe.tp.maxpedelsize, 0, 0, 1)
+            tm = capi.Timer(ctx)
+            ts = []
+            for _ in range(reps):
+                ctx._check(L_.im_stream_sync(ctx.h, ctx.stream))
+                tm.start(ctx.stream)
+                ctx._check(L_.im_dev_triage(ctx.h, C.byref(tp), C.byref(pipe.recs), C.byref(pipe.cands), pipe.d_ts.ptr, pipe.ts_bytes, ctx.stream))
+                tm.stop(ctx.stream)
+                ts.append(tm.elapsed_ms())
+            out[name] = {"record_bytes": int(len(raw)), "ms_3_launches": float(np.median(ts[2:]))}
+            cls[name] = (pipe.d_class.download(np.uint8, rd.n).tobytes(), int(pipe.fetch_counts()[0]))
+            del pipe
+        out["same_classes_and_candidates"] = bool(cls["plain"] == cls["tagged"])
+        return out
+    finally:
+        ctx.close()
+
+
 def other_parameters_measure(device, reps=10):
     """The flags users run besides the defaults, on the configs[1] candidates (12 232 reads of 100 bases): -g 1 / 2 / 5 / 12
     (realign_band_kernel: a lane per band diagonal), -k 8 / 13 (the table by the k-mer's first six bases), -k 14 (the hash).  Each
@@ -1108,6 +1141,10 @@ def main():
                 line["other_parameters"] = other_parameters_measure(0 if os.environ.get("IM_BENCH_ONE_DEVICE") == "1" else local_rank)
             except Exception as ex:
                 line["other_parameters"] = {"error": str(ex)}
+            try:
+                line["triage_with_aligner_tags"] = triage_with_aligner_tags(0 if os.environ.get("IM_BENCH_ONE_DEVICE") == "1" else local_rank, rd, refs[0].tobytes())
+            except Exception as ex:
+                line["triage_with_aligner_tags"] = {"error": str(ex)}
         if world == 1 and not args.no_cpu_baseline and not args.no_config3:
             try:
                 line["end_to_end_config3"] = end_to_end_config3()
@@ -1141,6 +1178,8 @@ def main():
             checks["end_to_end_config3_md5_is_the_references"] = c3.get("product_md5_is_the_references") is True
         if isinstance(line.get("long_reads_2x300"), dict):
             checks["long_reads_identical_to_the_oracle"] = line["long_reads_2x300"].get("identical_to_the_oracle_on_the_sample") is True
+            if isinstance(line.get("triage_with_aligner_tags"), dict):
+                checks["aligner_tags_leave_the_classes_as_they_are"] = line["triage_with_aligner_tags"].get("same_classes_and_candidates") is True
             if isinstance(line.get("other_parameters"), dict):
                 checks["other_parameters_identical_to_the_oracle"] = line["other_parameters"].get("identical_to_the_oracle_on_the_samples") is True
             if isinstance(line["long_reads_2x300"].get("with_gaps"), dict):

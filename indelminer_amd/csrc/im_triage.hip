@@ -45,7 +45,8 @@ struct RecView {
     bool ok;
 };
 
-constexpr int kAuxWin = 24;     // bytes of the aux area staged per record (MQ + a short RG fit; longer walks go to memory)
+constexpr int kAuxWin = 24;     // bytes of the aux area a lane holds in LDS at a time: the tag walk slides the window along (aux_slide); more LDS
+                                // would cost the kernel its sixth workgroup per CU
 
 __device__ __forceinline__ RecView view_record(const uint8_t* raw, uint32_t off, uint32_t end)
 {
@@ -90,28 +91,50 @@ __device__ __forceinline__ int aux_size(uint32_t t)
     }
 }
 
-// a byte of the record at offset o: the staged aux window (LDS) when it covers o, memory otherwise
-struct AuxWin { const uint8_t* lds; uint32_t o0; };
+// a byte of the record at offset o: the lane's aux window (LDS) when it covers o, memory otherwise
+struct AuxWin { uint32_t* lds; uint32_t o0; };
 __device__ __forceinline__ uint32_t rec_byte(const RecView& r, const AuxWin& w, uint32_t o)
 {
     const uint32_t d = o - w.o0;
-    return d < (uint32_t)kAuxWin ? w.lds[d] : r.p[o];
+    return d < (uint32_t)kAuxWin ? reinterpret_cast<const uint8_t*>(w.lds)[d] : r.p[o];
+}
+// The window moved to offset o: six dword loads by the lane that needs them.  What an aligner writes in front of RG and MQ
+// (NM MD AS XS MC ...: 30-100 bytes) used to be walked through memory byte by byte behind the first 24 -- every byte a 64-line
+// gather: records with such fields took classify from 25 to 77 us per 300 000 (profiles/r04_m_*).  Reads past the record stay
+// inside the chunk buffer (>= 64 spare bytes behind the last record).
+__device__ __forceinline__ void aux_slide(const RecView& r, AuxWin& w, uint32_t o)
+{
+    w.o0 = o;
+#pragma unroll
+    for (int k = 0; k < kAuxWin / 4; k++) w.lds[k] = ld_u32(r.p + o + 4u * k);
+}
+// the byte at o for a walk that only moves forward: the window follows
+__device__ __forceinline__ uint32_t walk_byte(const RecView& r, AuxWin& w, uint32_t o)
+{
+    if (o - w.o0 >= (uint32_t)kAuxWin) aux_slide(r, w, o);
+    return reinterpret_cast<const uint8_t*>(w.lds)[o - w.o0];
+}
+// [o, o + need) inside the window (need <= kAuxWin)
+__device__ __forceinline__ void aux_cover(const RecView& r, AuxWin& w, uint32_t o, uint32_t need)
+{
+    if (!(o >= w.o0 && o + need <= w.o0 + (uint32_t)kAuxWin)) aux_slide(r, w, o);
 }
 
 // bam_aux_get for RG and MQ in one walk (bam_aux.c:27-54): offsets of the TYPE byte of the first
 // occurrence, 0 = absent.  The walk stops where samtools' would (unknown type, truncated B array).
-__device__ __forceinline__ void find_rg_mq(const RecView& r, const AuxWin& w, uint32_t& o_rg, uint32_t& o_mq)
+__device__ __forceinline__ void find_rg_mq(const RecView& r, AuxWin& w, uint32_t& o_rg, uint32_t& o_mq)
 {
     o_rg = 0; o_mq = 0;
     uint32_t s = r.o_aux;
     const uint32_t end = r.len;
     while (s + 4u <= end) {      // a tail of < 4 bytes is alignment padding (include/indelminer_amd.h, im_dev_records)
+        aux_cover(r, w, s, 8u);  // tag, type and what a B array's header takes
         const uint32_t t0 = rec_byte(r, w, s), t1 = rec_byte(r, w, s + 1), type = rec_byte(r, w, s + 2);
         if (t0 == 'R' && t1 == 'G' && !o_rg) o_rg = s + 2u;
         if (t0 == 'M' && t1 == 'Q' && !o_mq) o_mq = s + 2u;
         if (o_rg && o_mq) return;
         s += 3u;
-        if (type == 'Z' || type == 'H') { while (s < end && rec_byte(r, w, s)) s++; s++; }
+        if (type == 'Z' || type == 'H') { while (s < end && walk_byte(r, w, s)) s++; s++; }
         else if (type == 'B') {
             if (s + 5u > end) return;
             const int sz = aux_size(rec_byte(r, w, s));
@@ -287,7 +310,7 @@ struct Verdict {
 };
 
 // generic_ok / generic_range: the lookup of "generic" (records without an RG tag, src/indelminer.c:370), done once per workgroup
-__device__ __forceinline__ Verdict classify(const RecView& r, const AuxWin& w, const im_triage_params& tp, const RgView& T,
+__device__ __forceinline__ Verdict classify(const RecView& r, AuxWin w, const im_triage_params& tp, const RgView& T,
                                             bool generic_ok, int32_t generic_range, uint32_t fb)
 {
     Verdict v; v.cls = IM_REC_SKIP; v.revcomp = false; v.range_max = 0;
@@ -313,8 +336,14 @@ __device__ __forceinline__ Verdict classify(const RecView& r, const AuxWin& w, c
         const uint32_t type = rec_byte(r, w, o_rg);
         bool ok = type == 'Z' || type == 'H';                                  // else bam_aux2Z returns NULL: strlen(NULL)
         if (ok) {
+            // the name's length; a name that runs out of the window brings the window to the tag (names of up to 22 bytes then lie in it)
             uint32_t len = 0;
-            while (o_rg + 1u + len < r.len && rec_byte(r, w, o_rg + 1u + len)) len++;
+            while (o_rg + 1u + len < r.len) {
+                const uint32_t o = o_rg + 1u + len;
+                if (o - w.o0 >= (uint32_t)kAuxWin && w.o0 != o_rg) aux_slide(r, w, o_rg);
+                if (!rec_byte(r, w, o)) break;
+                len++;
+            }
             const uint32_t o_name = o_rg + 1u;
             ok = rg_lookup(T, [&](uint32_t k) { return rec_byte(r, w, o_name + k); }, len, v.range_max);
         }
@@ -325,6 +354,7 @@ __device__ __forceinline__ Verdict classify(const RecView& r, const AuxWin& w, c
     if (!aligned && mate_aligned) {                                            // 386-424
         int32_t mmq = (int32_t)r.mapq;
         if (o_mq) {
+            aux_cover(r, w, o_mq, 5u);
             const uint32_t t = rec_byte(r, w, o_mq);
             if (!(t == 'I' || t == 'i' || t == 'C' || t == 'c' || t == 'S' || t == 's')) { v.cls = IM_REC_ERR_MQ; return v; }
             mmq = aux_int(r, w, o_mq);
@@ -359,6 +389,7 @@ __device__ __forceinline__ Verdict classify(const RecView& r, const AuxWin& w, c
         if (fb != 0xFFFFFFFFu) { v.cls = IM_REC_ERR_BASE; return v; }
         if (ndel + nins + nclip == 0u) return v;
         if ((nclip == 0u || (nclip == 1u && three)) && ndel == 0u && nins == 0u) return v;            // 457-460
+        if (o_mq) aux_cover(r, w, o_mq, 5u);
         const int32_t mmq = o_mq ? aux_int(r, w, o_mq) : (int32_t)r.mapq;
         if (mmq >= tp.qthreshold) { v.cls = IM_REC_CAND_PROPER; v.revcomp = is_rc == mate_rc; }
         return v;
@@ -429,8 +460,10 @@ __global__ __launch_bounds__(kTriBlock) void triage_classify_kernel(TriageArgs A
         // reads past the record stay inside the chunk buffer (>= 64 spare bytes behind the last record)
 #pragma unroll
         for (int k = 0; k < 4; k++) r.cig[k] = ld_u32(r.p + r.o_cigar + 4u * k);
+        // the aux window: as many dwords as the record's aux area has (a record with the MQ tag alone: one or two)
+        const uint32_t aux_bytes = r.len - r.o_aux;
 #pragma unroll
-        for (int k = 0; k < kAuxWin / 4; k++) s_aux[t][k] = ld_u32(r.p + r.o_aux + 4u * k);
+        for (int k = 0; k < kAuxWin / 4; k++) if (4u * k < aux_bytes) s_aux[t][k] = ld_u32(r.p + r.o_aux + 4u * k);
     }
     sweep_finish(S, A.recs.raw, sw_so, sw_lim, s_fb + 64 * wave, lane);
     // the depth window starts at the first pileup-eligible record of the workgroup (records are sorted inside a contig)
@@ -462,7 +495,7 @@ __global__ __launch_bounds__(kTriBlock) void triage_classify_kernel(TriageArgs A
     uint32_t cls = IM_REC_SKIP, bytes = 0;
     bool cand = false;
     if (i < A.recs.n) {
-        AuxWin w; w.lds = reinterpret_cast<const uint8_t*>(s_aux[t]); w.o0 = r.o_aux;
+        AuxWin w; w.lds = s_aux[t]; w.o0 = r.o_aux;
         const Verdict v = classify(r, w, A.tp, T, s_generic[0] != 0, s_generic[1], s_fb[t]);
         cls = v.cls;
         cand = cls == IM_REC_CAND_UNMAPPED || cls == IM_REC_CAND_PROPER;

@@ -46,9 +46,10 @@ def _scatter(dst, starts, lens, flat):
     dst[idx] = flat
 
 
-def build(rd, lo=0, hi=None, qname_prefix="r", align=4, block_size_word=False, rg=None):
+def build(rd, lo=0, hi=None, qname_prefix="r", align=4, block_size_word=False, rg=None, aux_prefix=b""):
     """Records lo..hi of rd as one uint8 array.  Returns (raw, off) with off[n + 1] (int64) the record
-    starts (of the block_size word when block_size_word).  rg: optional read-group name (RG:Z tag)."""
+    starts (of the block_size word when block_size_word).  rg: optional read-group name (RG:Z tag); aux_prefix: bytes of whole aux
+    fields put in front of the MQ tag of every record (what an aligner writes first: NM, MD, AS, XS ...)."""
     hi = rd.n if hi is None else hi
     n = hi - lo
     L = rd.read_len
@@ -65,7 +66,7 @@ def build(rd, lo=0, hi=None, qname_prefix="r", align=4, block_size_word=False, r
     qlen = np.char.str_len(names).astype(np.int64) + 1
     tags_fixed = 4
     rg_bytes = b"" if rg is None else b"RGZ" + rg.encode() + b"\0"
-    body = 32 + qlen + 4 * ncig + (L + 1) // 2 + L + tags_fixed + len(rg_bytes)
+    body = 32 + qlen + 4 * ncig + (L + 1) // 2 + L + len(aux_prefix) + tags_fixed + len(rg_bytes)
     pre = 4 if block_size_word else 0
     rec = pre + body
     step = (rec + align - 1) // align * align
@@ -109,6 +110,10 @@ def build(rd, lo=0, hi=None, qname_prefix="r", align=4, block_size_word=False, r
     o_qual = o_seq + hb
     raw[(o_qual[:, None] + np.arange(L)[None, :]).reshape(-1)] = 0x28
     o_tag = o_qual + L
+    if aux_prefix:
+        ab = np.frombuffer(bytes(aux_prefix), dtype=np.uint8)
+        raw[(o_tag[:, None] + np.arange(len(ab))[None, :]).reshape(-1)] = np.tile(ab, n)
+        o_tag = o_tag + len(ab)
     mq = np.where((flag & 0x8) != 0, 0, rd.mapq).astype(np.uint8)
     tag = np.zeros((n, 4), dtype=np.uint8)
     tag[:, 0] = ord("M"); tag[:, 1] = ord("Q"); tag[:, 2] = ord("C"); tag[:, 3] = mq
@@ -119,9 +124,9 @@ def build(rd, lo=0, hi=None, qname_prefix="r", align=4, block_size_word=False, r
     return raw, off, dict(pos=pos, end=end, bin=core["bin"].astype(np.int64), tid=rd.tid[sl].astype(np.int64))
 
 
-def records(rd, lo=0, hi=None, qname_prefix="r", rg=None, qual=True):
+def records(rd, lo=0, hi=None, qname_prefix="r", rg=None, qual=True, aux_prefix=b""):
     """Device layout: (raw uint8, rec_off uint32[n + 1]).  qual=False: without base qualities, as the product delivers records."""
-    raw, off, _ = build(rd, lo, hi, qname_prefix, align=4, block_size_word=False, rg=rg)
+    raw, off, _ = build(rd, lo, hi, qname_prefix, align=4, block_size_word=False, rg=rg, aux_prefix=aux_prefix)
     assert off[-1] < 2**32
     if not qual:
         return strip_quals(raw, off)

@@ -20,8 +20,11 @@ for name, kw in (("configs[1]", dict(seed=1, ref_len=1_000_000)), ("shard3", dic
     ctx.set_reference([refs[0].tobytes()])
     ctx.set_insert_ranges(["generic"], [rd.range_max])
     ctx.depth_enable()
+    # AUX=1: every record carries what an aligner writes in front of MQ / RG (NM:C MD:Z AS:C XS:C MC:Z, 31 bytes) and an RG:Z tag
+    AUX = os.environ.get("AUX") == "1"
     for qual in ((False,) if ONLY else (False, True)):
-        raw, off = rawrec.records(rd, qual=qual)
+        raw, off = rawrec.records(rd, qual=qual, rg="generic" if AUX else None,
+                                  aux_prefix=(b"NMC\x00" + b"MDZ100\x00" + b"ASC\x64" + b"XSC\x00" + b"MCZ100M\x00") if AUX else b"")
         for want_depth in ((True,) if ONLY else (True, False)):
             pipe = capi.Pipeline(ctx, rd.n, len(raw), cap_cand=max(4096, rd.n // 8), read_len_max=100, want_depth=want_depth)
             pipe.upload(raw, off)
