@@ -249,6 +249,19 @@ def test_one_contig_over_several_ranks(tmp_path_factory, world):
         assert got == th._golden(golden), (flags, pb)
 
 
+def test_long_read_library_over_two_ranks(tmp_path):
+    """a 2 x 1100 library and a 2 x 300 library with -g 2, ONE contig in pieces over two ranks: the owner realigns groups another rank
+    walked, so it must hear of their longest read from the package (the realign launches for long reads / the general pass follow
+    im_expect_read_length).  The bytes of the record-at-a-time run."""
+    for sub, read_len, flags in (("a", 1100, ["-i", "cfg.txt"]), ("b", 300, ["-i", "cfg.txt", "-g", "2"])):
+        (tmp_path / sub).mkdir()
+        d = th._long_read_dir(tmp_path / sub, read_len=read_len, ref_len=120_000, coverage=14, seed=70 + read_len)
+        want = th._run(th._build_shim(), flags, d, ref="ref.fa", bam="aln.bam", env={"INDELMINER_PIPELINE": "host"})
+        assert want.count(b"SPLIT_READ") > 10
+        got = _with_env({"INDELMINER_PIECE_BYTES": "150000", "INDELMINER_MG_FORCE_SPLIT": "1"}, lambda: _run_world(2, flags, d, "ref.fa", "aln.bam"))
+        assert got == want, sub
+
+
 def test_contigs_in_pieces_over_ranks_with_markers_pinned_low(tmp_path):
     """four contigs, first mates that wait for ever in two of them (every later marker pinned, also in later contigs), pieces of
     every contig on every rank: counter prefixes per piece, marker floors per contig, frozen evidence waiting for its contig's end"""
