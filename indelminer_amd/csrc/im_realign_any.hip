@@ -976,8 +976,17 @@ __global__ __launch_bounds__(64) void realign_any_kernel(RealignArgs A, const in
         X.w0 = X.w1 = X.anc = X.p0 = X.p1 = 0;
         if (have) any_step_begin(A, list[at], X);
         any_search_round(a, Y, A, T, gdiag, X, 1, lane);
+#if defined(IM_ANY_STOP) && IM_ANY_STOP == 1
+        continue;
+#endif
         if (X.stage == 1) any_step_middle(a, Y, A, X);
+#if defined(IM_ANY_STOP) && IM_ANY_STOP == 2
+        continue;
+#endif
         any_search_round(a, Y, A, T, gdiag, X, 2, lane);
+#if defined(IM_ANY_STOP) && IM_ANY_STOP == 3
+        continue;
+#endif
         if (X.stage == 2) any_step_end(a, Y, A, X);
     }
 }
