@@ -248,11 +248,18 @@ static int realign_any(im_ctx* ctx, const im::RealignArgs& a, int all, hipStream
     HIP_TRY(ctx, hipStreamSynchronize(stream));
     if (h[0] <= 0) return IM_OK;
     const int32_t max_read = h[1], max_window = h[2];
-    const size_t per_wave = im::realign_any_arena_bytes(max_read, max_window, a.P.numgaps, 1);
-    int64_t waves = ((int64_t)h[0] + 63) / 64;
-    const int64_t most = (int64_t)ctx->n_cu * 8;                                  // eight waves per CU hide each other's memory latency
-    if (waves > most) waves = most;
+    // A batch of long reads is small against the chip (13 918 candidates of a 2 x 300 library are 218 waves of 64: less than one per CU
+    // with three of its SIMDs idle): a wave then holds FEWER reads -- R = 8 .. 64 lanes with a read each, the others only help in the band
+    // searches -- until every SIMD has a wave (a wave's instructions cost the same whatever the number of lanes at work: more waves than
+    // SIMDs only add work -- 8 reads per wave took a 2 x 300 batch at -g 61 from 64 to 105 ms).
+    const int64_t most = (int64_t)ctx->n_cu * 8, simds = (int64_t)ctx->n_cu * 4;
+    int32_t lane_shift = 6;
+    // (bands beyond the cooperative form's 32 diagonals: every lane on its own with a read each, as measured best)
+    while (a.P.numgaps < 32u && lane_shift > 3 && ((int64_t)h[0] + (1 << (lane_shift - 1)) - 1) >> (lane_shift - 1) <= simds) lane_shift--;
     const size_t budget = (size_t)6 << 30;
+    size_t per_wave = im::realign_any_arena_bytes(max_read, max_window, a.P.numgaps, lane_shift, 1);
+    int64_t waves = ((int64_t)h[0] + (1 << lane_shift) - 1) >> lane_shift;
+    if (waves > most) waves = most;
     if (per_wave * (size_t)waves > budget) waves = (int64_t)(budget / per_wave);
     if (waves < 1) waves = 1;
     const size_t need = per_wave * (size_t)waves;
@@ -261,7 +268,7 @@ static int realign_any(im_ctx* ctx, const im::RealignArgs& a, int all, hipStream
         HIP_TRY(ctx, hipMalloc((void**)&ctx->any_arena, need));
         ctx->any_arena_bytes = need;
     }
-    HIP_TRY(ctx, im::launch_realign_any(a, ctx->any_list, ctx->any_counters, ctx->any_arena, max_read, max_window, (int32_t)waves, stream));
+    HIP_TRY(ctx, im::launch_realign_any(a, ctx->any_list, ctx->any_counters, ctx->any_arena, max_read, max_window, lane_shift, (int32_t)waves, stream));
     HIP_TRY(ctx, hipStreamSynchronize(stream));                                   // the list and the arena are free for the next call
     return IM_OK;
 }

@@ -90,9 +90,10 @@ hipError_t launch_realign_long(const RealignArgs& a, int n_cu, hipStream_t strea
 // pick lists them (all != 0: every read of the batch, which no other kernel has seen) into list[] with counters[0] = how many,
 // [1] = the longest read, [2] = the widest window among them; the caller sizes the arena from those (n_waves waves of 64 lanes).
 hipError_t launch_realign_any_pick(const RealignArgs& a, int all, int32_t* list, int32_t* counters, hipStream_t stream);
-size_t realign_any_arena_bytes(int32_t max_read, int32_t max_window, uint32_t numgaps, int32_t n_waves);
+// lane_shift: log2 of the reads a wave holds at a time (6 = every lane; fewer reads per wave = more waves for a small batch)
+size_t realign_any_arena_bytes(int32_t max_read, int32_t max_window, uint32_t numgaps, int32_t lane_shift, int32_t n_waves);
 hipError_t launch_realign_any(const RealignArgs& a, const int32_t* list, int32_t* counters, int32_t* arena,
-                              int32_t max_read, int32_t max_window, int32_t n_waves, hipStream_t stream);
+                              int32_t max_read, int32_t max_window, int32_t lane_shift, int32_t n_waves, hipStream_t stream);
 
 // im_results.hip
 hipError_t launch_compact_results(const im_read_result* res, int32_t n_cap, const int32_t* n_dev, int32_t* status, int32_t* slot,

@@ -5,8 +5,8 @@
 // deliver -- reads of up to 255 / 1020 bases at numgaps == 0, up to 255 bases and bands of up to 61 diagonals otherwise (one
 // lane per diagonal) -- and leave every other read IM_ST_UNSUPPORTED.  This file takes those: ONE LANE PER READ for the
 // dynamic programs and the merge, their state in a per-lane arena of device memory whose words are interleaved over the 64
-// lanes of a wave (word i of lane l lives at arena[64 i + l], so lanes that walk their arrays in step touch four cache lines
-// per access, not sixty-four); the k-mer band searches in between by the WHOLE WAVE on one read after the other.  It follows
+// lanes of a wave that hold a read (word i of lane l lives at arena[R i + l], so lanes that walk their arrays in step touch a
+// few cache lines per access, not one each; R = 64 for large batches, fewer when the batch would leave SIMDs without a wave); the k-mer band searches in between by the WHOLE WAVE on one read after the other.  It follows
 // the reference statement by statement where order matters (the strict comparisons of the three dynamic programs decide
 // between co-optimal alignments) and restates what is order-free (the k-mer tables as one open-addressing
 // table per read piece, the band sums as a running sum):
@@ -40,6 +40,8 @@ enum : int { kKindEq = 0, kKindX = 1, kKindI = 2, kKindNone = 3 };
 // arena layout in words per lane (the same function sizes the arena on the host)
 struct AnyLayout {
     int32_t maxM, maxW, maxB, hslots;
+    int32_t lane_shift;         // log2 of the reads a wave takes per round (R = 1 << lane_shift lanes hold a read each; the arena is
+                                // interleaved over R lanes): 64 for large batches, fewer when the batch would leave SIMDs without a wave
     int32_t rows_in_lds;        // 1: o_cc .. o_dp index the wave's LDS block (from 0), not the arena
     int32_t l_rows_words;       // LDS words of the four rows (0 when they live in the arena)
     int32_t l_tab_slots;        // slots of the wave's k-mer table in LDS (key, offset, count: 3 words each); 0: every lane searches alone
@@ -49,10 +51,11 @@ struct AnyLayout {
     int32_t words;
 };
 
-__host__ __device__ inline AnyLayout make_layout(int32_t maxM, int32_t maxW, int32_t maxB)
+__host__ __device__ inline AnyLayout make_layout(int32_t maxM, int32_t maxW, int32_t maxB, int32_t lane_shift)
 {
     AnyLayout y;
-    y.maxM = maxM; y.maxW = maxW; y.maxB = maxB;
+    y.maxM = maxM; y.maxW = maxW; y.maxB = maxB; y.lane_shift = lane_shift;
+    const int32_t R = 1 << lane_shift;
     int32_t h = 16; while (h < 2 * maxM) h <<= 1;
     y.hslots = h;
     int32_t at = 0;
@@ -60,7 +63,7 @@ __host__ __device__ inline AnyLayout make_layout(int32_t maxM, int32_t maxW, int
     y.o_hkey = take(h); y.o_hpos = take(h); y.o_hcnt = take(h);
     y.o_diag = take(maxW + maxM + 8);
     // the four rows: 4 * (maxB + 4) words per lane, 256 bytes per word over the wave; in LDS up to 64 KiB of it
-    y.rows_in_lds = (size_t)4 * (size_t)(maxB + 4) * 256u <= ((size_t)64 << 10) ? 1 : 0;
+    y.rows_in_lds = (size_t)4 * (size_t)(maxB + 4) * 4u * (size_t)R <= ((size_t)64 << 10) ? 1 : 0;
     if (y.rows_in_lds) { y.o_cc = 0; y.o_dd = maxB + 4; y.o_cp = 2 * (maxB + 4); y.o_dp = 3 * (maxB + 4); }
     else { y.o_cc = take(maxB + 4); y.o_dd = take(maxB + 4); y.o_cp = take(maxB + 4); y.o_dp = take(maxB + 4); }
     y.o_mp0 = take(maxM + 2); y.o_mp1 = take(maxM + 2); y.o_mp2 = take(maxM + 2); y.o_fp = take(maxM + 2);
@@ -71,7 +74,7 @@ __host__ __device__ inline AnyLayout make_layout(int32_t maxM, int32_t maxW, int
     // the wave's LDS: the rows (64 lanes' worth), then the shared table and histogram of the cooperative band search, 144 KiB at
     // most (a workgroup may take all of a CU's 160 KiB): tables of reads of up to 4096 bases
     const int32_t budget = (144 << 10) / 4;
-    y.l_rows_words = y.rows_in_lds ? 4 * (maxB + 4) * 64 : 0;
+    y.l_rows_words = y.rows_in_lds ? 4 * (maxB + 4) * R : 0;
     y.l_tab_slots = (y.l_rows_words + 3 * h + 1024 <= budget) ? h : 0;
     int32_t left = budget - y.l_rows_words - 3 * y.l_tab_slots;
     if (left > maxW + maxM + 8) left = maxW + maxM + 8;
@@ -83,12 +86,21 @@ __host__ __device__ inline AnyLayout make_layout(int32_t maxM, int32_t maxW, int
 // one lane's view of its arena.  The four rows of the banded passes (CC / DD / CP / DP: the arrays every cell of the dynamic
 // programs reads and writes) live in LDS when the band is narrow enough for 64 lanes' rows to fit -- the launch decides --
 // and in the arena otherwise: q is that home, lane-interleaved like the arena (offsets o_cc .. then count from 0).
-struct Ar {
-    int32_t* p;
-    int32_t* q;
-    __device__ __forceinline__ int32_t& at(int32_t off, int32_t i) const { return p[(int64_t)(off + i) << 6]; }
-    __device__ __forceinline__ uint32_t& atu(int32_t off, int32_t i) const { return reinterpret_cast<uint32_t*>(p)[(int64_t)(off + i) << 6]; }
-    __device__ __forceinline__ int32_t& row(int32_t off, int32_t i) const { return q[(int64_t)(off + i) << 6]; }
+#define IM_GLOBAL_AS __attribute__((address_space(1)))
+typedef IM_GLOBAL_AS const uint8_t* gbytes;        // the contig's and the read's bytes: device memory, and said to be
+#define IM_LDS_AS __attribute__((address_space(3)))
+template <bool LDSROWS> struct RowPtr { typedef IM_GLOBAL_AS int32_t* T; };
+template <> struct RowPtr<true> { typedef IM_LDS_AS int32_t* T; };
+// The pointers carry their address space (global arena, LDS rows): through the calls below a plain pointer would be a generic one and
+// every access a flat instruction (1 070 of them in the first build) -- slower than a global or LDS access and counted on both wait counters.
+template <bool LDSROWS>
+struct ArT {
+    IM_GLOBAL_AS int32_t* p;
+    typename RowPtr<LDSROWS>::T q;
+    int32_t sh;         // AnyLayout::lane_shift
+    __device__ __forceinline__ auto& at(int32_t off, int32_t i) const { return p[(int64_t)(off + i) << sh]; }
+    __device__ __forceinline__ auto& atu(int32_t off, int32_t i) const { return ((IM_GLOBAL_AS uint32_t*)p)[(int64_t)(off + i) << sh]; }
+    __device__ __forceinline__ auto& row(int32_t off, int32_t i) const { return q[(int64_t)(off + i) << sh]; }
 };
 
 __device__ __forceinline__ int wsub(uint32_t a, uint32_t b) { return a == b ? kScoreMatch : kScoreMismatch; }   // W[i][j], src/localalign.c:61-67
@@ -96,8 +108,9 @@ __device__ __forceinline__ int wsub(uint32_t a, uint32_t b) { return a == b ? kS
 struct AnyBand { int st, low, up, votes; };
 
 // find_best_band.  ref / read are the contig and the read; the window is [z1, e1), the piece [z2, e2).
-__device__ AnyBand any_find_band(const Ar& a, const AnyLayout& Y, const uint8_t* ref, uint32_t z1, uint32_t e1, uint32_t anchor,
-                                 const uint8_t* read, uint32_t z2, uint32_t e2, uint32_t k, uint32_t g)
+template <class AR>
+__device__ AnyBand any_find_band(const AR& a, const AnyLayout& Y, gbytes ref, uint32_t z1, uint32_t e1, uint32_t anchor,
+                                 gbytes read, uint32_t z2, uint32_t e2, uint32_t k, uint32_t g)
 {
     AnyBand b; b.st = 0; b.low = b.up = 0; b.votes = 0;
     const uint32_t W = e1 - z1, L = e2 - z2;
@@ -168,19 +181,22 @@ __device__ AnyBand any_find_band(const Ar& a, const AnyLayout& Y, const uint8_t*
 // bases skipped in front of it -- what DEL / INS / REP (36-59) append, in a form fetch_cigar's run lengths fall out of.
 struct Script { int32_t o_pos; int32_t pos0; int32_t ia, jb; };
 
-__device__ __forceinline__ void s_rep(const Ar& a, Script& S, const uint8_t* A0, const uint8_t* B0)
+template <class AR>
+__device__ __forceinline__ void s_rep(const AR& a, Script& S, gbytes A0, gbytes B0)
 {
     const int32_t p = S.pos0 + S.ia;
     const int32_t w = a.at(S.o_pos, p);
     a.at(S.o_pos, p) = (w & ~3) | (A0[S.ia + 1] == B0[S.jb + 1] ? kKindEq : kKindX);
     S.ia++; S.jb++;
 }
-__device__ __forceinline__ void s_del(const Ar& a, Script& S, int n)       // read bases without a partner
+template <class AR>
+__device__ __forceinline__ void s_del(const AR& a, Script& S, int n)       // read bases without a partner
 {
     for (int t = 0; t < n; t++) { const int32_t p = S.pos0 + S.ia + t; a.at(S.o_pos, p) = (a.at(S.o_pos, p) & ~3) | kKindI; }
     S.ia += n;
 }
-__device__ __forceinline__ void s_ins(const Ar& a, Script& S, int n)       // reference bases skipped
+template <class AR>
+__device__ __forceinline__ void s_ins(const AR& a, Script& S, int n)       // reference bases skipped
 {
     a.at(S.o_pos, S.pos0 + S.ia) += n << 2;
     S.jb += n;
@@ -192,7 +208,8 @@ __device__ __forceinline__ int32_t mpk(int ptr, int type) { return ((ptr + 1) <<
 struct Fwd { int k, l, v, rmid; };
 
 // the forward pass of align() (100-248) on A[1..M], B[1..N] inside [low, up]
-__device__ Fwd any_global_forward(const Ar& a, const AnyLayout& Y, const uint8_t* A, const uint8_t* B, int M, int N, int low, int up, int tb, int te)
+template <class AR>
+__device__ Fwd any_global_forward(const AR& a, const AnyLayout& Y, gbytes A, gbytes B, int M, int N, int low, int up, int tb, int te)
 {
     const int g = kOpen, h = kExt, m = g + h;
     const int band = up - low + 1, midd = band / 2 + 1;
@@ -278,7 +295,8 @@ __device__ Fwd any_global_forward(const Ar& a, const AnyLayout& Y, const uint8_t
 }
 
 // align()'s divide and conquer (66-307) as frames.  A0 / B0: 1-based views of the located sub-strings.  Returns 0 or a status.
-__device__ int any_global_align(const Ar& a, const AnyLayout& Y, Script& S, const uint8_t* A0, const uint8_t* B0, int Ma, int Na, int low, int up, int* score_out)
+template <class AR>
+__device__ int any_global_align(const AR& a, const AnyLayout& Y, Script& S, gbytes A0, gbytes B0, int Ma, int Na, int low, int up, int* score_out)
 {
     enum { F_AO, F_BO, F_M, F_N, F_LOW, F_UP, F_TB, F_TE, F_PHASE, F_K, F_L, F_KT, F_RMID };
     int sp = 0, top = 0, guard = 0; bool first = true;
@@ -297,7 +315,7 @@ __device__ int any_global_align(const Ar& a, const AnyLayout& Y, Script& S, cons
         const int ao = FR(fs, F_AO), bo = FR(fs, F_BO), M = FR(fs, F_M), N = FR(fs, F_N), lo = FR(fs, F_LOW), u = FR(fs, F_UP);
         const int tb = FR(fs, F_TB), te = FR(fs, F_TE), phase = FR(fs, F_PHASE);
         int k = FR(fs, F_K), l = FR(fs, F_L), kt = FR(fs, F_KT), rmid = FR(fs, F_RMID);
-        const uint8_t* A = A0 + ao; const uint8_t* B = B0 + bo;
+        gbytes A = A0 + ao; gbytes B = B0 + bo;
         int nphase = phase; bool pop = false, pushed = false;
         int c_ao = 0, c_bo = 0, c_M = 0, c_N = 0, c_lo = 0, c_u = 0, c_tb = 0, c_te = 0;
         auto child = [&](int xa, int xb, int xM, int xN, int xlo, int xu, int xtb, int xte) {
@@ -360,13 +378,14 @@ struct AnyAln { int st, r1, r2, q1, q2, n_ops; };
 
 // attempt_band_alignment = local_align + ALIGN + fetch_cigar (src/alignment.c:343-391).  Window = contig[w0, w0 + N),
 // piece = read[p0, p0 + M); the CIGAR lands at o_ops.
-__device__ AnyAln any_band_alignment(const Ar& a, const AnyLayout& Y, const uint8_t* contig, const uint8_t* read, int p0, int M, int w0, int N,
+template <class AR>
+__device__ AnyAln any_band_alignment(const AR& a, const AnyLayout& Y, gbytes contig, gbytes read, int p0, int M, int w0, int N,
                                      int low_in, int up_in, int32_t o_pos, int32_t o_ops)
 {
     AnyAln r; r.st = 0; r.r1 = r.r2 = r.q1 = r.q2 = 0; r.n_ops = 0;
     if (low_in > up_in || M <= 0 || N <= 0) { r.st = IM_ST_ABORT; return r; }        // forceassert 359; strlen > 0, src/localalign.c:31-32
-    const uint8_t* A = read + p0 - 1;                                                // 1-based views (42-43)
-    const uint8_t* B = contig + w0 - 1;
+    gbytes A = read + p0 - 1;                                                // 1-based views (42-43)
+    gbytes B = contig + w0 - 1;
     const int g = kOpen, h = kExt, m = g + h;
     const int low = max(-M, low_in), up = min(N, up_in);                              // 70-71
     const int band = up - low + 1;
@@ -447,8 +466,8 @@ __device__ AnyAln any_band_alignment(const Ar& a, const AnyLayout& Y, const uint
     int lo2 = low - (startj - starti), up2 = up - (startj - starti);
     lo2 = min(max(-Ma, lo2), min(Na - Ma, 0));                                        // 347-348
     up2 = max(min(Na, up2), max(Na - Ma, 0));
-    const uint8_t* A0 = A + starti - 1;
-    const uint8_t* B0 = B + startj - 1;
+    gbytes A0 = A + starti - 1;
+    gbytes B0 = B + startj - 1;
     Script S; S.o_pos = o_pos; S.pos0 = starti - 1; S.ia = 0; S.jb = 0;
     for (int p = 0; p <= M; p++) a.at(o_pos, p) = kKindNone;
     int score = 0;
@@ -500,7 +519,8 @@ __device__ AnyAln any_band_alignment(const Ar& a, const AnyLayout& Y, const uint
 #define OPS_LEN(w) ((int)((w) >> 4))
 
 // count_matches (src/alignment.c:219-303) for one candidate split
-__device__ int any_split_score(const Ar& a, int32_t o1, int n1, int q2, int32_t o2, int n2, int q4, int* pmm)
+template <class AR>
+__device__ int any_split_score(const AR& a, int32_t o1, int n1, int q2, int32_t o2, int n2, int q4, int* pmm)
 {
     const int q3 = q2;
     int i, j, matches = 0, mm = 0;
@@ -526,7 +546,8 @@ __device__ int any_split_score(const Ar& a, int32_t o1, int n1, int q2, int32_t 
 }
 
 // find_best_del_candidate (306-339)
-__device__ int any_best_split(const Ar& a, int q1, int q2, int32_t o1, int n1, int q3, int q4, int32_t o2, int n2, int L, int* pindex)
+template <class AR>
+__device__ int any_best_split(const AR& a, int q1, int q2, int32_t o1, int n1, int q3, int q4, int32_t o2, int n2, int L, int* pindex)
 {
     if (q1 != 0 || q3 > q2) return IM_ST_ABORT;
     int bestm = 0, bestmm = INT_MAX, index = -1;
@@ -542,7 +563,8 @@ __device__ int any_best_split(const Ar& a, int q1, int q2, int32_t o1, int n1, i
 }
 
 // update_readsegs (src/readaln.c:348-458) into the arena's final list, then the evidence records and the result record
-__device__ int any_build_result(const Ar& a, const AnyLayout& Y, im_read_result* out, const RealignArgs& R, int cidx,
+template <class AR>
+__device__ int any_build_result(const AR& a, const AnyLayout& Y, im_read_result* out, const RealignArgs& R, int cidx,
                                 int r1, int32_t o1, int n1, int index, int q2, int r2, int32_t o2, int n2)
 {
     int n = 0, refindx = r1; bool over = false;
@@ -638,7 +660,7 @@ __device__ __forceinline__ void any_store_band(im_read_result* out, int which, c
 // LDS, lanes on contiguous stretches of the read's k-mers / the window / the diagonals.  Reads whose table does not fit the
 // LDS share keep the search of their own lane (any_find_band).
 
-struct CoopLds { uint32_t* key; int32_t* pos; int32_t* cnt; int32_t* diag; int32_t tab_slots, diag_words; };
+struct CoopLds { IM_LDS_AS uint32_t* key; IM_LDS_AS int32_t* pos; IM_LDS_AS int32_t* cnt; IM_LDS_AS int32_t* diag; int32_t tab_slots, diag_words; };
 
 __device__ __forceinline__ bool band_better(int c1, int d1, int i1, int c2, int d2, int i2)     // select_band's order (142-181)
 {
@@ -646,8 +668,8 @@ __device__ __forceinline__ bool band_better(int c1, int d1, int i1, int c2, int 
 }
 
 // every argument wave-uniform; gdiag: the wave's own contiguous stretch of device memory for histograms beyond the LDS share
-__device__ AnyBand coop_find_band(const CoopLds& T, int32_t* gdiag, const uint8_t* ref, uint32_t z1, uint32_t e1, uint32_t anchor,
-                                  const uint8_t* read, uint32_t z2, uint32_t e2, uint32_t k, uint32_t g, int lane)
+__device__ AnyBand coop_find_band(const CoopLds& T, IM_GLOBAL_AS int32_t* gdiag, gbytes ref, uint32_t z1, uint32_t e1, uint32_t anchor,
+                                  gbytes read, uint32_t z2, uint32_t e2, uint32_t k, uint32_t g, int lane)
 {
     AnyBand b; b.st = 0; b.low = b.up = 0; b.votes = 0;
     const uint32_t W = e1 - z1, L = e2 - z2;
@@ -659,9 +681,12 @@ __device__ AnyBand coop_find_band(const CoopLds& T, int32_t* gdiag, const uint8_
     uint32_t H = 16; while (H < 2u * nread) H <<= 1;
     const uint32_t hm = H - 1u;
     const bool dlds = numdiag <= (uint32_t)T.diag_words;
-    int32_t* diag = dlds ? T.diag : gdiag;
+    // the histogram's home: LDS, or the wave's stretch of the arena -- each with the accesses of its own address space
+    auto dzero = [&](uint32_t i) { if (dlds) T.diag[i] = 0; else gdiag[i] = 0; };
+    auto dvote = [&](uint32_t i) { if (dlds) __hip_atomic_fetch_add(&T.diag[i], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                                   else __hip_atomic_fetch_add(&gdiag[i], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
     for (uint32_t i = (uint32_t)lane; i < H; i += 64u) { T.key[i] = kEmpty; T.cnt[i] = 0; }
-    for (uint32_t i = (uint32_t)lane; i < numdiag; i += 64u) diag[i] = 0;
+    for (uint32_t i = (uint32_t)lane; i < numdiag; i += 64u) dzero(i);
     if (!dlds) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");          // the zeros are in before any lane's vote
     wave_lds_sync();
     // the read piece's k-mers, a contiguous stretch per lane with a rolling code
@@ -673,9 +698,10 @@ __device__ AnyBand coop_find_band(const CoopLds& T, int32_t* gdiag, const uint8_
             code = ((code << 2) | code2(read[z2 + q + k - 1])) & mask;
             uint32_t h = (code * 2654435761u) >> 7 & hm;
             for (;;) {
-                const uint32_t old = atomicCAS(&T.key[h], kEmpty, code);
-                if (old == kEmpty) { T.pos[h] = (int32_t)q; atomicAdd(&T.cnt[h], 1); break; }
-                if (old == code) { atomicAdd(&T.cnt[h], 1); break; }
+                uint32_t old = kEmpty;
+                __hip_atomic_compare_exchange_strong(&T.key[h], &old, code, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                if (old == kEmpty) { T.pos[h] = (int32_t)q; __hip_atomic_fetch_add(&T.cnt[h], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); break; }
+                if (old == code) { __hip_atomic_fetch_add(&T.cnt[h], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); break; }
                 h = (h + 1) & hm;
             }
         }
@@ -695,7 +721,7 @@ __device__ AnyBand coop_find_band(const CoopLds& T, int32_t* gdiag, const uint8_
                 if (key == code) {
                     if (T.cnt[h] == 1) {
                         const uint32_t indx = p - (uint32_t)T.pos[h] + L - k + 1;                              // 102-105
-                        if (indx < numdiag) atomicAdd(&diag[indx], 1);
+                        if (indx < numdiag) dvote(indx);
                     }
                     break;
                 }
@@ -709,7 +735,7 @@ __device__ AnyBand coop_find_band(const CoopLds& T, int32_t* gdiag, const uint8_
     const int anchor_rel = (int)(anchor - z1);
     int bc = -1, bd = INT_MAX, bi = INT_MAX;
     {
-        auto dg = [&](uint32_t i) -> int { return dlds ? diag[i] : __hip_atomic_load(&diag[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
+        auto dg = [&](uint32_t i) -> int { return dlds ? T.diag[i] : __hip_atomic_load(&gdiag[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
         const uint32_t per = (numdiag + 63u) / 64u, i0 = (uint32_t)lane * per, i1 = min(numdiag, i0 + per);
         int run = 0;
         if (i0 < i1 && i0 < numdiag - g) for (uint32_t j = i0; j <= i0 + g; j++) run += dg(j);
@@ -763,13 +789,14 @@ __device__ void any_step_begin(const RealignArgs& R, int c, AnyRead& X)
 }
 
 // behind band search 1: the first alignment, the geometric case, the second search's window and piece
-__device__ void any_step_middle(const Ar& a, const AnyLayout& Y, const RealignArgs& R, AnyRead& X)
+template <class AR>
+__device__ void any_step_middle(const AR& a, const AnyLayout& Y, const RealignArgs& R, AnyRead& X)
 {
     im_read_result* out = &R.batch.out[X.c];
     const int L = X.L, anchor = X.anchor;
     const uint32_t eth = R.P.ethreshold;
-    const uint8_t* contig = R.ref.ascii + R.ref.asc_off[X.tid];
-    const uint8_t* read = R.batch.bases + R.batch.base_off[X.c];
+    gbytes contig = (gbytes)(R.ref.ascii + R.ref.asc_off[X.tid]);
+    gbytes read = (gbytes)(R.batch.bases + R.batch.base_off[X.c]);
     X.stage = 0;
     if (X.b1.st) { any_finish(out, X.b1.st, 0); return; }
     const AnyAln a1 = any_band_alignment(a, Y, contig, read, 0, L, X.left1, X.right1 - X.left1, X.b1.low, X.b1.up, Y.o_pos0, Y.o_ops0);
@@ -825,12 +852,13 @@ __device__ void any_step_middle(const Ar& a, const AnyLayout& Y, const RealignAr
 }
 
 // behind band search 2: the second alignment and the merge of the two pieces
-__device__ void any_step_end(const Ar& a, const AnyLayout& Y, const RealignArgs& R, AnyRead& X)
+template <class AR>
+__device__ void any_step_end(const AR& a, const AnyLayout& Y, const RealignArgs& R, AnyRead& X)
 {
     im_read_result* out = &R.batch.out[X.c];
     const int L = X.L, c = X.c;
-    const uint8_t* contig = R.ref.ascii + R.ref.asc_off[X.tid];
-    const uint8_t* read = R.batch.bases + R.batch.base_off[c];
+    gbytes contig = (gbytes)(R.ref.ascii + R.ref.asc_off[X.tid]);
+    gbytes read = (gbytes)(R.batch.bases + R.batch.base_off[c]);
     const int r1 = X.r1, r2 = X.r2, q1 = X.q1, q2 = X.q2, n1 = X.n1;
     const uint32_t f = X.f, l = X.l, w0 = X.w0, w1 = X.w1, p0 = X.p0, p1 = X.p1;
     const bool want_tail = X.want_tail;
@@ -871,7 +899,8 @@ __device__ void any_step_end(const Ar& a, const AnyLayout& Y, const RealignArgs&
 
 // One band search for every lane whose read is at `stage`: the wave together, lane by lane, where the read's table fits the
 // LDS share; the lane alone otherwise.
-__device__ void any_search_round(const Ar& a, const AnyLayout& Y, const RealignArgs& R, const CoopLds& T, int32_t* gdiag, AnyRead& X, int stage, int lane)
+template <class AR>
+__device__ void any_search_round(const AR& a, const AnyLayout& Y, const RealignArgs& R, const CoopLds& T, IM_GLOBAL_AS int32_t* gdiag, AnyRead& X, int stage, int lane)
 {
     const uint32_t k = R.P.klength, g = R.P.numgaps;
     const bool mine = X.stage == stage;
@@ -886,15 +915,15 @@ __device__ void any_search_round(const Ar& a, const AnyLayout& Y, const RealignA
         const int r = (int)__builtin_ctzll(m);
         m &= m - 1ull;
         const int tid = __shfl(X.tid, r), c = __shfl(X.c, r);
-        const uint8_t* contig = R.ref.ascii + R.ref.asc_off[tid];
-        const uint8_t* read = R.batch.bases + R.batch.base_off[c];
+        gbytes contig = (gbytes)(R.ref.ascii + R.ref.asc_off[tid]);
+        gbytes read = (gbytes)(R.batch.bases + R.batch.base_off[c]);
         const AnyBand b = coop_find_band(T, gdiag, contig, (uint32_t)__shfl((int)z1, r), (uint32_t)__shfl((int)e1, r), (uint32_t)__shfl((int)anc, r),
                                          read, (uint32_t)__shfl((int)z2, r), (uint32_t)__shfl((int)e2, r), k, g, lane);
         if (lane == r) { if (stage == 1) X.b1 = b; else X.b2 = b; }
     }
     if (mine && !coop) {
-        const uint8_t* contig = R.ref.ascii + R.ref.asc_off[X.tid];
-        const uint8_t* read = R.batch.bases + R.batch.base_off[X.c];
+        gbytes contig = (gbytes)(R.ref.ascii + R.ref.asc_off[X.tid]);
+        gbytes read = (gbytes)(R.batch.bases + R.batch.base_off[X.c]);
         const AnyBand b = any_find_band(a, Y, contig, z1, e1, anc, read, z2, e2, k, g);
         if (stage == 1) X.b1 = b; else X.b2 = b;
     }
@@ -930,34 +959,39 @@ __global__ __launch_bounds__(256) void any_pick_kernel(RealignArgs A, int all, i
     }
 }
 
+// LDSROWS: the four rows of the banded passes live in LDS (the launch decides: make_layout's rows_in_lds)
+template <bool LDSROWS>
 __global__ __launch_bounds__(64) void realign_any_kernel(RealignArgs A, const int32_t* list, int32_t* counters, int32_t* arena, AnyLayout Y)
 {
     extern __shared__ int32_t s_dyn[];
     const int lane = threadIdx.x;
-    int32_t* wave_arena = arena + (int64_t)blockIdx.x * Y.words * 64;
-    Ar a; a.p = wave_arena + lane;
-    a.q = Y.rows_in_lds ? s_dyn + lane : a.p;
+    const int R = 1 << Y.lane_shift;                    // lanes that hold a read; the others only take part in the band searches
+    IM_GLOBAL_AS int32_t* wave_arena = (IM_GLOBAL_AS int32_t*)arena + ((int64_t)blockIdx.x * Y.words << Y.lane_shift);
+    IM_LDS_AS int32_t* lds = (IM_LDS_AS int32_t*)s_dyn;
+    ArT<LDSROWS> a; a.sh = Y.lane_shift; a.p = wave_arena + (lane & (R - 1));
+    if constexpr (LDSROWS) a.q = lds + (lane & (R - 1)); else a.q = a.p;
     CoopLds T;
     T.tab_slots = Y.l_tab_slots; T.diag_words = Y.l_diag_words;
-    T.key = reinterpret_cast<uint32_t*>(s_dyn + Y.l_rows_words);
-    T.pos = s_dyn + Y.l_rows_words + Y.l_tab_slots;
+    T.key = (IM_LDS_AS uint32_t*)(lds + Y.l_rows_words);
+    T.pos = lds + Y.l_rows_words + Y.l_tab_slots;
     T.cnt = T.pos + Y.l_tab_slots;
     T.diag = T.cnt + Y.l_tab_slots;
-    // the 64 lanes' histogram words of the arena are one contiguous stretch: the wave's own when it votes together
-    int32_t* gdiag = wave_arena + (int64_t)Y.o_diag * 64;
+    // the lanes' histogram words of the arena are one contiguous stretch: the wave's own when it votes together
+    IM_GLOBAL_AS int32_t* gdiag = wave_arena + ((int64_t)Y.o_diag << Y.lane_shift);
     const int n = counters[0];
     if (Y.maxB > kCoopMaxBand) {
         // wide bands: the row-by-row dynamic programs are the pass and differ widely from read to read -- every lane on its own,
         // claiming its next read when it is done with one (waiting for each other at the steps cost 64 -> 76 ms at -g 61)
         const uint32_t k = A.P.klength, g = A.P.numgaps;
+        if (lane >= R) return;
         for (;;) {
             const int at = atomicAdd(&counters[3], 1);
             if (at >= n) break;
             AnyRead X;
             any_step_begin(A, list[at], X);
             if (X.stage != 1) continue;
-            const uint8_t* contig = A.ref.ascii + A.ref.asc_off[X.tid];
-            const uint8_t* read = A.batch.bases + A.batch.base_off[X.c];
+            gbytes contig = (gbytes)(A.ref.ascii + A.ref.asc_off[X.tid]);
+            gbytes read = (gbytes)(A.batch.bases + A.batch.base_off[X.c]);
             X.b1 = any_find_band(a, Y, contig, (uint32_t)X.left1, (uint32_t)X.right1, (uint32_t)X.anchor, read, 0u, (uint32_t)X.L, k, g);
             any_step_middle(a, Y, A, X);
             if (X.stage != 2) continue;
@@ -969,7 +1003,7 @@ __global__ __launch_bounds__(64) void realign_any_kernel(RealignArgs A, const in
     // narrow bands: the band searches are the pass.  A lane claims a read per round; the wave moves through the three steps
     // together so that the searches in between can be done by all lanes on one read
     for (;;) {
-        const int at = atomicAdd(&counters[3], 1);
+        const int at = lane < R ? atomicAdd(&counters[3], 1) : n;
         const bool have = at < n;
         if (__ballot(have) == 0ull) break;
         AnyRead X; X.stage = 0; X.c = 0; X.tid = 0; X.L = 0; X.anchor = 0; X.left1 = X.right1 = 0;
@@ -993,10 +1027,10 @@ __global__ __launch_bounds__(64) void realign_any_kernel(RealignArgs A, const in
 
 }  // namespace
 
-size_t realign_any_arena_bytes(int32_t max_read, int32_t max_window, uint32_t numgaps, int32_t n_waves)
+size_t realign_any_arena_bytes(int32_t max_read, int32_t max_window, uint32_t numgaps, int32_t lane_shift, int32_t n_waves)
 {
-    const AnyLayout y = make_layout(max_read, max_window, (int32_t)numgaps + 1);
-    return (size_t)y.words * 64 * sizeof(int32_t) * (size_t)n_waves;
+    const AnyLayout y = make_layout(max_read, max_window, (int32_t)numgaps + 1, lane_shift);
+    return ((size_t)y.words << lane_shift) * sizeof(int32_t) * (size_t)n_waves;
 }
 
 hipError_t launch_realign_any_pick(const RealignArgs& a, int all, int32_t* list, int32_t* counters, hipStream_t stream)
@@ -1011,17 +1045,19 @@ hipError_t launch_realign_any_pick(const RealignArgs& a, int all, int32_t* list,
 }
 
 hipError_t launch_realign_any(const RealignArgs& a, const int32_t* list, int32_t* counters, int32_t* arena,
-                              int32_t max_read, int32_t max_window, int32_t n_waves, hipStream_t stream)
+                              int32_t max_read, int32_t max_window, int32_t lane_shift, int32_t n_waves, hipStream_t stream)
 {
-    const AnyLayout y = make_layout(max_read, max_window, (int32_t)a.P.numgaps + 1);
+    const AnyLayout y = make_layout(max_read, max_window, (int32_t)a.P.numgaps + 1, lane_shift);
     const size_t lds = (size_t)y.lds_bytes;
     static size_t attr_bytes = 0;
     if (lds > attr_bytes) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(realign_any_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 144 << 10);
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(realign_any_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 144 << 10);
+        if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(realign_any_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 144 << 10);
         if (e != hipSuccess) return e;
         attr_bytes = (size_t)144 << 10;
     }
-    hipLaunchKernelGGL(realign_any_kernel, dim3(n_waves), dim3(64), lds, stream, a, list, counters, arena, y);
+    if (y.rows_in_lds) hipLaunchKernelGGL(realign_any_kernel<true>, dim3(n_waves), dim3(64), lds, stream, a, list, counters, arena, y);
+    else hipLaunchKernelGGL(realign_any_kernel<false>, dim3(n_waves), dim3(64), lds, stream, a, list, counters, arena, y);
     return hipGetLastError();
 }
 
