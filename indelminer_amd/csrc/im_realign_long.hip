@@ -28,9 +28,12 @@ constexpr int kLHash = 2048;                    // hash slots, k > 6 (at most IM
 constexpr int kLRead = 64 * kLB;                // 1024
 constexpr uint32_t kRepeat = 0xFFFFu;           // hash table: the k-mer occurs more than once in the read piece
 
-struct LongLds {
+// DIRECT (k <= 6, the default): the table is the 8 KiB of 4^6 16-bit entries -- 15.4 KiB per wave, ten waves on a CU; the hash form
+// (k > 6) holds kLHash keys and kLHash values, 16 KiB.
+template <bool DIRECT>
+struct LongLdsT {
     alignas(16) uint32_t diag[kLDiag / 2 + 8];
-    alignas(16) uint32_t tbl[2 * kLHash];       // k <= 6: 4^6 16-bit entries (first 8 KiB); k > 6: kLHash keys, kLHash values
+    alignas(16) uint32_t tbl[DIRECT ? kLHash : 2 * kLHash];
     alignas(16) uint32_t rd[(kLRead + 16) / 4]; // read bases, read coordinates
     alignas(16) uint8_t  eq[2][kLRead + 16];    // per band alignment: 1 where the read position is an aligned '='
     int32_t bpos[IM_MAX_OPS + 2];
@@ -38,6 +41,7 @@ struct LongLds {
 
 struct LBand { int st, low, votes, win, piece; };
 
+template <class LongLds>
 __device__ __forceinline__ uint32_t read_kmer(const LongLds& s, uint32_t at, uint32_t k)
 {
     uint32_t c = 0;
@@ -49,7 +53,7 @@ __device__ __forceinline__ uint32_t hash_of(uint32_t code) { return (code * 2654
 
 // find_best_band (src/alignment.c:393-447) for numgaps == 0: read_seeds x2 (29-68), bin_diagonals (70-128),
 // bin_bands (130-140: the band is the diagonal), select_band (142-181).
-template <bool DIRECT>
+template <bool DIRECT, class LongLds>
 __device__ LBand band_search_long(LongLds& s, const uint8_t* __restrict__ pk, uint32_t w0, uint32_t w1, uint32_t anchor,
                                   uint32_t p0, uint32_t p1, uint32_t k, int lane)
 {
@@ -169,6 +173,7 @@ struct LAln {
 //   forward : c_t = max(0, c_{t-1} + w_t); end = first t where c_t is the strict maximum
 //   reverse : start = largest s <= end with sum_{s..end} w == best
 // The '=' flags of the aligned positions land in s.eq[which], in read coordinates.
+template <class LongLds>
 __device__ LAln diag_scan_long(LongLds& s, int which, const uint8_t* __restrict__ contig, uint32_t w0, uint32_t w1, uint32_t p0, uint32_t p1,
                                int d, int lane)
 {
@@ -268,7 +273,7 @@ __device__ __forceinline__ void store_band_long(im_read_result* out, int which, 
 }
 
 // attempt_pe_alignment -> attempt_diagonal_alignments (src/alignment.c:539-799)
-template <bool DIRECT>
+template <bool DIRECT, class LongLds>
 __device__ void realign_long_one(LongLds& s, const RealignArgs& A, int c, int L, int lane)
 {
     im_read_result* out = &A.batch.out[c];
@@ -479,9 +484,9 @@ __device__ void realign_long_one(LongLds& s, const RealignArgs& A, int c, int L,
 }
 
 template <bool DIRECT>
-__global__ __launch_bounds__(64) void realign_long_kernel(RealignArgs A)
+__global__ __launch_bounds__(64, 3) void realign_long_kernel(RealignArgs A)
 {
-    __shared__ LongLds s;
+    __shared__ LongLdsT<DIRECT> s;
     const int lane = threadIdx.x;
     // ONE read per wave, as in realign_kernel: a 2 x 300 library is all long reads, and a wave per 64 consecutive reads (the first
     // form of this kernel: long reads were the exception then) left the chip a wave per CU.  The launch covers every read of the
@@ -496,7 +501,7 @@ __global__ __launch_bounds__(64) void realign_long_kernel(RealignArgs A)
     if (!(L > kShortRead && L <= IM_MAX_READ)) return;
     if (DIRECT) {
         uint4* t4 = reinterpret_cast<uint4*>(s.tbl);
-        for (int i = lane; i < 2 * kLHash / 4; i += 64) t4[i] = make_uint4(0u, 0u, 0u, 0u);
+        for (int i = lane; i < (int)(sizeof(s.tbl) / 16); i += 64) t4[i] = make_uint4(0u, 0u, 0u, 0u);
         wave_lds_sync();
     }
     realign_long_one<DIRECT>(s, A, c, L, lane);

@@ -427,7 +427,7 @@ __device__ __forceinline__ uint32_t padded4(int32_t l) { return ((uint32_t)l + 3
 constexpr int kRgLds = 2048;        // an insert-length table up to this size is copied to LDS
 constexpr int kDepthWin = 4096;     // positions of the depth difference array a workgroup gathers in LDS before it touches memory
 
-__global__ __launch_bounds__(kTriBlock) void triage_classify_kernel(TriageArgs A)
+__global__ __launch_bounds__(kTriBlock, 6) void triage_classify_kernel(TriageArgs A)
 {
     __shared__ uint32_t s_cnt[kTriBlock / 64], s_bytes[kTriBlock / 64], s_counted[kTriBlock / 64], s_err[kTriBlock / 64];
     __shared__ uint32_t s_aux[kTriBlock][kAuxWin / 4];
