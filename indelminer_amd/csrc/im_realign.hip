@@ -1631,7 +1631,7 @@ __device__ int band_build_result(im_read_result* out, BandLds& G, int r1, const 
 }
 
 template <bool DIRECT>
-__global__ __launch_bounds__(64, 4) void realign_band_kernel(RealignArgs A)
+__global__ __launch_bounds__(64, 5) void realign_band_kernel(RealignArgs A)
 {
     // The band alignment's state lives where the vote's histogram and k-mer table are (both dead between two band
     // searches; band_search<0, ..> rebuilds them from scratch): 6.4 KB of LDS per wave instead of 12, twice the waves per CU.

@@ -484,7 +484,7 @@ __device__ void realign_long_one(LongLds& s, const RealignArgs& A, int c, int L,
 }
 
 template <bool DIRECT>
-__global__ __launch_bounds__(64, 3) void realign_long_kernel(RealignArgs A)
+__global__ __launch_bounds__(64, (DIRECT ? 3 : 2)) void realign_long_kernel(RealignArgs A)
 {
     __shared__ LongLdsT<DIRECT> s;
     const int lane = threadIdx.x;
