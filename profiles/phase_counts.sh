@@ -10,8 +10,8 @@ PHASES="0 1 2 3 4 5 6 7 8 9 10 11 12 13 14 full"
 if [ "$1" = build ]; then
   mkdir -p exp_libs/obj
   FL="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Iinclude -Iindelminer_amd/csrc"
-  for s in im_realign_long im_results im_cluster im_depth im_support im_triage im_flush im_flushwide im_capi im_comm; do hipcc $FL -c indelminer_amd/csrc/$s.hip -o exp_libs/obj/$s.o & done; wait
-  build_one() { n=$1; d=""; [ $n != full ] && d="-DIM_STOP_AFTER=$n"; hipcc $FL $d -c indelminer_amd/csrc/im_realign.hip -o exp_libs/obj/realign_$n.o && hipcc --offload-arch=gfx950 -shared -fPIC exp_libs/obj/realign_$n.o exp_libs/obj/im_realign_long.o exp_libs/obj/im_results.o exp_libs/obj/im_cluster.o exp_libs/obj/im_depth.o exp_libs/obj/im_support.o exp_libs/obj/im_triage.o exp_libs/obj/im_flush.o exp_libs/obj/im_flushwide.o exp_libs/obj/im_capi.o exp_libs/obj/im_comm.o -ldl -o exp_libs/stop_$n.so; }
+  for s in im_realign_long im_realign_any im_results im_cluster im_depth im_support im_triage im_flush im_flushwide im_capi im_comm; do hipcc $FL -c indelminer_amd/csrc/$s.hip -o exp_libs/obj/$s.o & done; wait
+  build_one() { n=$1; d=""; [ $n != full ] && d="-DIM_STOP_AFTER=$n"; hipcc $FL $d -c indelminer_amd/csrc/im_realign.hip -o exp_libs/obj/realign_$n.o && hipcc --offload-arch=gfx950 -shared -fPIC exp_libs/obj/realign_$n.o exp_libs/obj/im_realign_long.o exp_libs/obj/im_realign_any.o exp_libs/obj/im_results.o exp_libs/obj/im_cluster.o exp_libs/obj/im_depth.o exp_libs/obj/im_support.o exp_libs/obj/im_triage.o exp_libs/obj/im_flush.o exp_libs/obj/im_flushwide.o exp_libs/obj/im_capi.o exp_libs/obj/im_comm.o -ldl -o exp_libs/stop_$n.so; }
   i=0; for n in $PHASES; do build_one $n & i=$((i+1)); [ $((i % 6)) = 0 ] && wait; done; wait
   ls exp_libs/stop_*.so | wc -l
 else
