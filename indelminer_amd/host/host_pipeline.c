@@ -28,6 +28,7 @@
 #define PIPE_NCHUNK        4
 static uint32_t g_chunk_bytes = 32u << 20;
 static int g_nchunk = PIPE_NCHUNK;
+static int g_small_input;           /* walkpool_start: an input of less than 64 MB -- no streams of the pipelines' own */
 #define PIPE_CHUNK_BYTES   g_chunk_bytes
 #define PIPE_CHUNK_RECS    (g_chunk_bytes / 64u)
 
@@ -138,6 +139,7 @@ typedef struct {
     int32_t conf_cand, conf_err; int64_t conf_bytes, fly_recs, fly_seq;
     im_triage_params tp;
     int ready, own_stream;
+    uint8_t* h_ring;                    /* the chunks' pinned memory, one allocation */
 } ppipe;
 
 #define GPU(call) do { if ((call) != IM_OK) fatalf("%s: %s", #call, im_last_error(P->d->gpu)); } while (0)
@@ -194,17 +196,25 @@ static void pipe_init(ppipe* P, driver* d, int with_chunks)
 {
     memset(P, 0, sizeof *P);
     P->d = d;
+    const int64_t t_in = wall_ns();
     /* a stream per walker: its uploads and triage launches, and the device stage of its groups.  INDELMINER_STREAMS=shared
      * puts every walker on the context's stream instead (the GPU then sees the run exactly as with one walker: a
      * debugging aid -- it is how the group-by scratch bug of profiles/README.md r02 was told apart from a device race) */
-    P->own_stream = !(getenv("INDELMINER_STREAMS") && strcmp(getenv("INDELMINER_STREAMS"), "shared") == 0);
+    {
+        const char* sm = getenv("INDELMINER_STREAMS");             /* shared | own; default: own, except on small inputs (walkpool_start) */
+        P->own_stream = sm ? strcmp(sm, "shared") != 0 : !g_small_input;
+    }
     if (P->own_stream) GPU(im_stream_create(d->gpu, &P->stream));
     else P->stream = im_ctx_stream(d->gpu);
+    /* the ring's pinned memory is ONE allocation (a call costs ~2 ms whatever its size): per chunk the records, their offsets, 64 bytes of counts */
+    const size_t pin_off = (((size_t)PIPE_CHUNK_BYTES + 255) & ~(size_t)255) + 256, pin_cnt = pin_off + ((4 * ((size_t)PIPE_CHUNK_RECS + 1) + 255) & ~(size_t)255);
+    const size_t pin_chunk = pin_cnt + 256;
+    if (with_chunks) GPU(im_host_alloc(d->gpu, pin_chunk * (size_t)g_nchunk, (void**)&P->h_ring));
     for (int i = 0; i < g_nchunk && with_chunks; i++) {
         pchunk* c = &P->ck[i];
-        GPU(im_host_alloc(d->gpu, PIPE_CHUNK_BYTES, (void**)&c->h_raw));
-        GPU(im_host_alloc(d->gpu, 4 * ((size_t)PIPE_CHUNK_RECS + 1), (void**)&c->h_off));
-        GPU(im_host_alloc(d->gpu, 64, (void**)&c->h_cnt));
+        c->h_raw = P->h_ring + pin_chunk * (size_t)i;
+        c->h_off = (uint32_t*)(c->h_raw + pin_off);
+        c->h_cnt = (int32_t*)(c->h_raw + pin_cnt);
         c->d_raw = pdev_alloc(P, PIPE_CHUNK_BYTES + 64);
         c->d_off = pdev_alloc(P, 4 * ((size_t)PIPE_CHUNK_RECS + 1));
         c->d_class = pdev_alloc(P, PIPE_CHUNK_RECS);
@@ -213,6 +223,7 @@ static void pipe_init(ppipe* P, driver* d, int with_chunks)
         GPU(im_dev_triage_scratch_init(d->gpu, (int32_t)PIPE_CHUNK_RECS, c->d_scratch, c->scratch_bytes, P->stream));
         GPU(im_event_create(d->gpu, &c->done));
     }
+    const int64_t t_ring = wall_ns();
     P->counters = pdev_alloc(P, 64);
     P->counts = pdev_alloc(P, 64);
     /* device allocations are not zeroed (a recycled block keeps what its previous owner wrote): the triage's running counts start from 0 */
@@ -226,6 +237,7 @@ static void pipe_init(ppipe* P, driver* d, int with_chunks)
     P->tp.want_depth = g_region_tid < 0;        /* -c: DP= comes from the file around each variant, like the reference's (region_depth) */
     P->tp.defer_ranges = g_onepass;
     P->ready = 1;
+    if (g_timing) fprintf(stderr, "    [timing] a pipeline's buffers: %.2f ms (stream + %d ring chunks %.2f, candidate arrays %.2f)\n", (wall_ns() - t_in) / 1e6, with_chunks ? g_nchunk : 0, (t_ring - t_in) / 1e6, (wall_ns() - t_ring) / 1e6);
 }
 
 static void pipe_destroy(ppipe* P)
@@ -233,7 +245,6 @@ static void pipe_destroy(ppipe* P)
     if (!P->ready) return;
     for (int i = 0; i < PIPE_NCHUNK && P->ck[i].h_raw; i++) {
         pchunk* c = &P->ck[i];
-        im_host_free(P->d->gpu, c->h_raw); im_host_free(P->d->gpu, c->h_off); im_host_free(P->d->gpu, c->h_cnt);
         im_dev_free(P->d->gpu, c->d_raw); im_dev_free(P->d->gpu, c->d_off); im_dev_free(P->d->gpu, c->d_class); im_dev_free(P->d->gpu, c->d_scratch);
         im_event_destroy(c->done);
     }
@@ -241,6 +252,7 @@ static void pipe_destroy(ppipe* P)
     if (P->rstat) { im_dev_free(P->d->gpu, P->rstat); im_dev_free(P->d->gpu, P->rslot); im_dev_free(P->d->gpu, P->rcompact); }
     if (P->rcount) im_dev_free(P->d->gpu, P->rcount);
     if (P->h_stage) im_host_free(P->d->gpu, P->h_stage);
+    if (P->h_ring) im_host_free(P->d->gpu, P->h_ring);
     im_dev_free(P->d->gpu, P->counters); im_dev_free(P->d->gpu, P->counts); im_dev_free(P->d->gpu, P->cut); im_dev_free(P->d->gpu, P->fdesc);
     if (P->own_stream) im_stream_destroy(P->d->gpu, P->stream);
     P->ready = 0;

@@ -330,6 +330,10 @@ static walkpool_t* walkpool_start(driver* d)
         if (by_size < nw) nw = by_size < 2 ? 2 : by_size;
     }
     if (total_bytes < ((int64_t)2 << 30)) { g_chunk_bytes = 16u << 20; g_nchunk = 2; }
+    /* A run of a few tenths of a second is mostly set-up: a HIP stream costs ~16 ms to create and pinning ~0.4 ms per MB, one after
+     * the other in the driver (INDELMINER_TIMING: "a pipeline's buffers").  Below 64 MB of BAM the walkers and the stage take the
+     * context's stream (nothing is there to overlap with) and ring chunks of 8 MB. */
+    if (total_bytes < ((int64_t)64 << 20) && !g_mg) { g_chunk_bytes = 8u << 20; g_small_input = 1; }
     if (getenv("INDELMINER_CHUNK_MB") && atoi(getenv("INDELMINER_CHUNK_MB")) >= 1 && atoi(getenv("INDELMINER_CHUNK_MB")) <= 256) g_chunk_bytes = (uint32_t)atoi(getenv("INDELMINER_CHUNK_MB")) << 20;
     if (getenv("INDELMINER_CHUNKS") && atoi(getenv("INDELMINER_CHUNKS")) >= 2 && atoi(getenv("INDELMINER_CHUNKS")) <= PIPE_NCHUNK) g_nchunk = atoi(getenv("INDELMINER_CHUNKS"));
     /* pieces: a contig is cut where its compressed bytes cross multiples of the piece size -- about 1/(8 walkers) of the file, at
