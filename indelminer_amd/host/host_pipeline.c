@@ -237,7 +237,7 @@ static void pipe_init(ppipe* P, driver* d, int with_chunks)
     P->tp.want_depth = g_region_tid < 0;        /* -c: DP= comes from the file around each variant, like the reference's (region_depth) */
     P->tp.defer_ranges = g_onepass;
     P->ready = 1;
-    if (g_timing) fprintf(stderr, "    [timing] a pipeline's buffers: %.2f ms (stream + %d ring chunks %.2f, candidate arrays %.2f)\n", (wall_ns() - t_in) / 1e6, with_chunks ? g_nchunk : 0, (t_ring - t_in) / 1e6, (wall_ns() - t_ring) / 1e6);
+    if (g_timing) fprintf(stderr, "[timing]     a pipeline's buffers: %.2f ms (stream + %d ring chunks %.2f, candidate arrays %.2f)\n", (wall_ns() - t_in) / 1e6, with_chunks ? g_nchunk : 0, (t_ring - t_in) / 1e6, (wall_ns() - t_ring) / 1e6);
 }
 
 static void pipe_destroy(ppipe* P)

@@ -43,6 +43,10 @@ with tempfile.TemporaryDirectory() as td:
             import hashlib
             print("product run (inflate workers %s): %.2f s  rc %d  md5 %s" % (thr or "default", dt, p.returncode, hashlib.md5(p.stdout).hexdigest()), flush=True)
             tp = dt if tp is None else min(tp, dt)
+            if os.environ.get("E2E_SETUP_LINES") == "1":      # the set-up phases of every run, not only of the last one
+                for l in p.stderr.decode().splitlines():
+                    if l.startswith("[timing]") and ("buffers" in l or "GPU context" in l or "walk of all" in l or "read FASTA" in l):
+                        print("       ", l, flush=True)
     body = [l for l in p.stdout.splitlines() if not l.startswith(b"#")]
     print("product   rc %d  %.2f s  %d VCF records (%d COMPOSITE, %d PAIRED_READ only)" %
           (p.returncode, tp, len(body), sum(b"COMPOSITE" in l for l in body), sum(b"PAIRED_READ" in l and b"COMPOSITE" not in l for l in body)), flush=True)
