@@ -932,6 +932,10 @@ def test_product_parallel_walkers_and_replayers(tmp_path):
     for env in ({}, {"INDELMINER_WALKERS": "1"}, {"INDELMINER_WALKERS": "6", "INDELMINER_CLAIM_BASES": "1", "INDELMINER_REPLAYERS": "4"},
                 {"INDELMINER_WALKERS": "3", "INDELMINER_CLAIM_BASES": "1", "INDELMINER_REPLAYERS": "1", "INDELMINER_STREAMS": "shared"},
                 {"INDELMINER_WALKERS": "4", "INDELMINER_CLAIM_BASES": "250000", "INDELMINER_VERIFY_TRIAGE": "1"},
+                # inputs below 64 MB put every pipeline on the context's stream: streams of their own (the large-input layout) by hand,
+                # with a ring of four small chunks
+                {"INDELMINER_STREAMS": "own", "INDELMINER_WALKERS": "6", "INDELMINER_CLAIM_BASES": "1", "INDELMINER_REPLAYERS": "4"},
+                {"INDELMINER_STREAMS": "own", "INDELMINER_CHUNK_MB": "1", "INDELMINER_CHUNKS": "4", "INDELMINER_PIECE_BYTES": "100000"},
                 {"INDELMINER_ONEPASS": "0"}, {"INDELMINER_ONEPASS": "1", "INDELMINER_WALKERS": "6", "INDELMINER_CLAIM_BASES": "1"},
                 {"INDELMINER_PIECE_BYTES": "200000", "INDELMINER_WALKERS": "5"}, {"INDELMINER_PIECE_BYTES": "60000", "INDELMINER_ONEPASS": "1"},
                 {"INDELMINER_PIECE_BYTES": "100000", "INDELMINER_FLUSH_MODE": "seq", "INDELMINER_THREADS": "0"}):
