@@ -139,7 +139,7 @@ typedef struct {
     int32_t conf_cand, conf_err; int64_t conf_bytes, fly_recs, fly_seq;
     im_triage_params tp;
     int ready, own_stream;
-    uint8_t* h_ring;                    /* the chunks' pinned memory, one allocation */
+    uint8_t* h_ring;                    /* the chunks' pinned memory when it is one allocation */
 } ppipe;
 
 #define GPU(call) do { if ((call) != IM_OK) fatalf("%s: %s", #call, im_last_error(P->d->gpu)); } while (0)
@@ -206,15 +206,23 @@ static void pipe_init(ppipe* P, driver* d, int with_chunks)
     }
     if (P->own_stream) GPU(im_stream_create(d->gpu, &P->stream));
     else P->stream = im_ctx_stream(d->gpu);
-    /* the ring's pinned memory is ONE allocation (a call costs ~2 ms whatever its size): per chunk the records, their offsets, 64 bytes of counts */
+    /* The ring's pinned memory is ONE allocation (per chunk the records, their offsets, 64 bytes of counts): sixteen walkers pinning
+     * three blocks per chunk each queue up in the driver (INDELMINER_RING=split is that layout, kept for the A/B). */
     const size_t pin_off = (((size_t)PIPE_CHUNK_BYTES + 255) & ~(size_t)255) + 256, pin_cnt = pin_off + ((4 * ((size_t)PIPE_CHUNK_RECS + 1) + 255) & ~(size_t)255);
     const size_t pin_chunk = pin_cnt + 256;
-    if (with_chunks) GPU(im_host_alloc(d->gpu, pin_chunk * (size_t)g_nchunk, (void**)&P->h_ring));
+    const int ring_one = !(getenv("INDELMINER_RING") && strcmp(getenv("INDELMINER_RING"), "split") == 0);
+    if (with_chunks && ring_one) GPU(im_host_alloc(d->gpu, pin_chunk * (size_t)g_nchunk, (void**)&P->h_ring));
     for (int i = 0; i < g_nchunk && with_chunks; i++) {
         pchunk* c = &P->ck[i];
-        c->h_raw = P->h_ring + pin_chunk * (size_t)i;
-        c->h_off = (uint32_t*)(c->h_raw + pin_off);
-        c->h_cnt = (int32_t*)(c->h_raw + pin_cnt);
+        if (ring_one) {
+            c->h_raw = P->h_ring + pin_chunk * (size_t)i;
+            c->h_off = (uint32_t*)(c->h_raw + pin_off);
+            c->h_cnt = (int32_t*)(c->h_raw + pin_cnt);
+        } else {
+            GPU(im_host_alloc(d->gpu, PIPE_CHUNK_BYTES, (void**)&c->h_raw));
+            GPU(im_host_alloc(d->gpu, 4 * ((size_t)PIPE_CHUNK_RECS + 1), (void**)&c->h_off));
+            GPU(im_host_alloc(d->gpu, 64, (void**)&c->h_cnt));
+        }
         c->d_raw = pdev_alloc(P, PIPE_CHUNK_BYTES + 64);
         c->d_off = pdev_alloc(P, 4 * ((size_t)PIPE_CHUNK_RECS + 1));
         c->d_class = pdev_alloc(P, PIPE_CHUNK_RECS);
@@ -245,6 +253,7 @@ static void pipe_destroy(ppipe* P)
     if (!P->ready) return;
     for (int i = 0; i < PIPE_NCHUNK && P->ck[i].h_raw; i++) {
         pchunk* c = &P->ck[i];
+        if (!P->h_ring) { im_host_free(P->d->gpu, c->h_raw); im_host_free(P->d->gpu, c->h_off); im_host_free(P->d->gpu, c->h_cnt); }
         im_dev_free(P->d->gpu, c->d_raw); im_dev_free(P->d->gpu, c->d_off); im_dev_free(P->d->gpu, c->d_class); im_dev_free(P->d->gpu, c->d_scratch);
         im_event_destroy(c->done);
     }

@@ -130,6 +130,9 @@ def main():
     variants = {
         "config": (["-i", "w.cfg"], {}),
         "estimate": ([], {"INDELMINER_ONEPASS": "0"}),
+        "ringsplit": (["-i", "w.cfg"], {"INDELMINER_RING": "split"}),
+        "config2": (["-i", "w.cfg"], {}),
+        "ringsplit2": (["-i", "w.cfg"], {"INDELMINER_RING": "split"}),
         "onepass": ([], {}),
         "onepass_plain": ([], {"INDELMINER_SPECULATE": "0"}),
         "walkers8": (["-i", "w.cfg"], {"INDELMINER_WALKERS": "8"}),
