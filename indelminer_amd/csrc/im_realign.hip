@@ -265,11 +265,11 @@ __device__ __forceinline__ uint32_t vote_direct(WaveLds& s, uint32_t off, uint32
 {
     const uint32_t bsel = (off & 3u) * 8u;
     const uint32_t old = atomicAdd(&s.diag[off >> 2], 1u << bsel);
-    const uint32_t cnt = __builtin_amdgcn_ubfe(old, bsel, 8u);
+    const uint32_t cnt = __builtin_amdgcn_ubfe(old, off << 3, 8u);  // v_bfe_u32 takes the field offset modulo 32: (off & 3) * 8 without the mask
     uint32_t dist;                                                  // |off - ac|, one instruction
     asm("v_sad_u32 %0, %1, %2, 0" : "=v"(dist) : "v"(off), "s"(ac));
-    const uint32_t t = (dist << 11) + off;
-    return max(mx, ((cnt << 22) + Q0) - t);
+    const uint32_t u = Q0 - ((dist << 11) + off);                   // shift-add, subtract, shift-add: Q0 arrives in a register (band_search)
+    return max(mx, (cnt << 22) + u);
 }
 
 // One unit of the vote (k <= 6, direct table): the 512 window starts whose packed dwords are in cur[],
@@ -305,23 +305,21 @@ __device__ __forceinline__ uint32_t vote_unit_direct(WaveLds& s, const uint32_t 
     const uint32_t xb = __builtin_amdgcn_perm(__builtin_amdgcn_perm(v[7], v[6], 0x0C0C0400u), __builtin_amdgcn_perm(v[5], v[4], 0x0C0C0400u), 0x05040100u);
     const uint32_t ma = (((xa & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | xa) & 0x80808080u;
     const uint32_t mb = (((xb & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | xb) & 0x80808080u;
-    uint32_t m = (ma >> 7) | (mb >> 6);
-    // start index of mask bit b = 8 jj + h: 64 (4 h + jj) = 8 b + 248 h
+    uint32_t m = (ma >> 7) | (mb >> 3);
+    // mask bit b = 8 jj + 4 h stands for byte jj of word h, i.e. for this lane's load j8 = 4 h + jj = (b >> 3) | (b & 4): start i0 + 64 j8
     const uint32_t ob = obase + i0;
+    const int jmax = (int)(span - i0) >> 6;                 // starts up to the window's last k-mer vote: j8 <= jmax (negative: none of this lane's)
     (void)check;
     while (m) {
         const uint32_t bit = (uint32_t)__builtin_ctz(m);
         m &= m - 1u;
-        const bool hb = (bit & 1u) != 0u;
-        const uint32_t x = hb ? xb : xa;
-        const uint32_t di = 8u * bit + (hb ? 248u : 0u);
-        uint32_t val = __builtin_amdgcn_ubfe(x, bit & 24u, 8u);
-        bool votes = i0 + di <= span;                       // a start past the window's last k-mer does not vote
+        const uint32_t j8 = (bit >> 3) | (bit & 4u);
+        uint32_t val = __builtin_amdgcn_perm(xb, xa, j8) & 0xFFu;      // byte j8 of the eight table bytes
+        bool votes = (int)j8 <= jmax;                       // a start past the window's last k-mer does not vote
         if constexpr (KT == 7) {
             // k = 7..13: the table went by the k-mer's first six bases; the entry names a read position whose WHOLE k-mer is in
             // codes[] -- the same k-mer votes, a flagged one (it occurs twice in the read) does not, another one means the slot was
             // taken by a neighbour: the next slot then (rare: a hundred entries in 4096 slots)
-            const uint32_t j8 = (bit >> 3) + (hb ? 4u : 0u);
             // cur[j8] by a tree of selects on j8's bits: registers, not an indexed array (which the compiler would keep in scratch)
             const bool s0 = (j8 & 1u) != 0u, s1 = (j8 & 2u) != 0u, s2 = (j8 & 4u) != 0u;
             const uint32_t a0 = s0 ? cur[1] : cur[0], a1 = s0 ? cur[3] : cur[2], a2 = s0 ? cur[5] : cur[4], a3 = s0 ? cur[7] : cur[6];
@@ -338,7 +336,7 @@ __device__ __forceinline__ uint32_t vote_unit_direct(WaveLds& s, const uint32_t 
                 if (val == 0u) { votes = false; break; }
             }
         }
-        const uint32_t off = ob + di - val;                 // diagonal index - c0
+        const uint32_t off = ob + (j8 << 6) - val;          // diagonal index - c0
         // (several chunks only, off_limit is all ones otherwise) a diagonal that belongs to another chunk does not vote either
         if (votes && off < off_limit) mx = vote_direct(s, off, ac, Q0, mx);
     }
@@ -423,7 +421,8 @@ __device__ __forceinline__ Band band_search(WaveLds& s, const uint8_t* __restric
             // the anchor clamped into the chunk: every diagonal's nearness 2047 + dmin - |arel - off| is what it was (outside the
             // chunk the distance is monotone in the index, and dmin moves with the anchor), and the key needs no sign
             const uint32_t ac = (uint32_t)min(max(arel, 0), nbc - 1);
-            const uint32_t Q0 = 2047u * 2049u + (1u << 22);
+            uint32_t Q0 = 2047u * 2049u + (1u << 22);
+            asm("" : "+s"(Q0));     // not a constant to the compiler: it would move it to the end of the key's sum, a fourth instruction per vote
             // units whose every start lies inside the window vote unchecked (one chunk only)
             const uint32_t nfull = off_limit == 0xFFFFFFFFu ? (span + 1u) / 512u : 0u;
             for (uint32_t u = 0; u < nunit; u += 2) {
