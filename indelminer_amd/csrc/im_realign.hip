@@ -265,6 +265,9 @@ __device__ __forceinline__ uint32_t vote_direct(WaveLds& s, uint32_t off, uint32
 {
     const uint32_t bsel = (off & 3u) * 8u;
     const uint32_t old = atomicAdd(&s.diag[off >> 2], 1u << bsel);
+#ifdef IM_VOTE_DOUBLE_ATOMIC                                        // diagnostic builds only: what one more atomic of the same address pattern costs
+    { uint32_t z = 0u; asm volatile("" : "+v"(z)); const uint32_t o2 = atomicAdd(&s.diag[off >> 2], z); asm volatile("" :: "v"(o2)); }
+#endif
     const uint32_t cnt = __builtin_amdgcn_ubfe(old, off << 3, 8u);  // v_bfe_u32 takes the field offset modulo 32: (off & 3) * 8 without the mask
     uint32_t dist;                                                  // |off - ac|, one instruction
     asm("v_sad_u32 %0, %1, %2, 0" : "=v"(dist) : "v"(off), "s"(ac));
